@@ -1,0 +1,137 @@
+"""Signal features / resynthesis on the GPU: the host-side mirror of the reference's ``audio_util.py``.
+
+Same function names, argument order and shapes as the reference (``Sp_and_phase_Speech``,
+``Sp_and_phase_Noise``, ``SP_to_wav``, ``compute_band_E`` via ``stft_band``, ``NoisePSD``, ``rms``),
+plus batched entry points that take/return device tensors with a leading batch dimension.  All
+arithmetic happens in libnele_hip.so (csrc/features.hip); torch only owns the memory.
+
+Device layouts (frame-major): spec [B,T,257] complex64, band [B,T,64] f32,
+psd [B,T,257] f32.  The single-utterance reference-shaped wrappers return mag/phase as [257,T].
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+NB_BANDS = 64
+N_FFT = 512
+HOP = 256
+N_BINS = 257
+fs = 16000
+# audio_util.py:23
+gmtband = [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 28, 30, 32, 34,
+           36, 38, 41, 43, 46, 49, 52, 55, 58, 62, 66, 70, 74, 79, 83, 88, 93, 99, 105, 111, 117, 124, 131, 139, 147,
+           156, 165, 174, 184, 195, 206, 218, 230, 243, 257]
+
+
+def _dev(x, device=None):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not x.is_cuda:
+        x = x.to(device or 'cuda')
+    return x.contiguous()
+
+
+def n_frames(L):
+    """T = 1 + L // 256 (centred STFT, audio_util.py:53-58)."""
+    return 1 + L // HOP
+
+
+# ------------------------------------------------------------------ batched device API
+def stft_band(wav, power=1.0 / 6, want_spec=True, want_band=True):
+    """wav [B,L] f32 (device) -> (spec [B,T,257] complex64 | None, band [B,T,64] f32 | None).
+    band = compute_band_E(|STFT|) ** power (audio_util.py:426-433)."""
+    wav = _dev(wav).float()
+    if wav.dim() != 2:
+        raise ValueError("stft_band: wav must be [B, L]")
+    B, L = wav.shape
+    T = n_frames(L)
+    spec = torch.empty((B, T, N_BINS), dtype=torch.complex64, device=wav.device) if want_spec else None
+    band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=wav.device) if want_band else None
+    call('nele_stft_band', ptr(wav), B, L, float(power), ptr(spec), ptr(band), stream())
+    return spec, band
+
+
+def imcra_band(spec, power=1.0 / 6, want_psd=False):
+    """spec [B,T,257] complex64 -> (psd [B,T,257] f32 | None, band [B,T,64] f32) with
+    band = compute_band_E(sqrt(NoisePSD(spec))) ** power (audio_util.py:445-451)."""
+    if spec.dtype != torch.complex64 or spec.dim() != 3 or spec.shape[2] != N_BINS:
+        raise ValueError("imcra_band: spec must be [B, T, 257] complex64")
+    spec = spec.contiguous()
+    B, T, _ = spec.shape
+    psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=spec.device) if want_psd else None
+    band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=spec.device)
+    call('nele_imcra_band', ptr(spec), B, T, float(power), ptr(psd), ptr(band), stream())
+    return psd, band
+
+
+def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False):
+    """alpha2 [B,T,64] f32 (energy gains), spec [B,T,257] complex64 -> wav [B, 256*(T-1)] f32.
+    Resyn (audio_util.py:76-90) + optional enh/rms(enh)*target (inference.py:109) + optional
+    PCM_16 write/read round trip (train_nele.py:313, dataloader.py:58)."""
+    alpha2 = _dev(alpha2).float()
+    spec = spec.contiguous()
+    B, T, _ = spec.shape
+    if alpha2.shape != (B, T, NB_BANDS):
+        raise ValueError("gain_istft: alpha2 must be [B, T, 64] matching spec")
+    wav = torch.empty((B, HOP * (T - 1)), dtype=torch.float32, device=spec.device)
+    call('nele_gain_istft', ptr(alpha2), ptr(spec), B, T, ptr(wav), stream())
+    if rms_target > 0 or pcm16:
+        call('nele_wav_post', ptr(wav), B, wav.shape[1], float(rms_target), int(bool(pcm16)), stream())
+    return wav
+
+
+def pcm16_roundtrip(wav):
+    """In-place emulation of sf.write(..., 'PCM_16') followed by librosa.load."""
+    wav = wav.contiguous()
+    B = 1 if wav.dim() == 1 else wav.shape[0]
+    call('nele_wav_post', ptr(wav), B, wav.shape[-1], 0.0, 1, stream())
+    return wav
+
+
+# ------------------------------------------------------------------ reference-shaped wrappers
+def STFT(x, nfft=512, nw=512, nm=256):
+    """audio_util.py:53-58: [L] -> [257, T] complex64 (device tensor)."""
+    spec, _ = stft_band(_dev(x).reshape(1, -1), want_band=False)
+    return spec[0].transpose(0, 1)
+
+
+def NoisePSD(MIXED, nfft=512):
+    """audio_util.py:113-117: MIXED [257, T] complex64 -> estimated noise PSD [257, T] f32."""
+    spec = _dev(MIXED).transpose(0, 1).contiguous().unsqueeze(0)
+    psd, _ = imcra_band(spec, want_psd=True)
+    return psd[0].transpose(0, 1)
+
+
+def Sp_and_phase_Speech(signal, power, Normalization=True):
+    """audio_util.py:422-437 -> (bandE [T,64], mag [257,T], phase [257,T]) device tensors."""
+    spec, band = stft_band(_dev(signal).reshape(1, -1), power if Normalization else 1.0)
+    if not Normalization:
+        print('No normalization for func: Sp_and_phase_Clean')
+    F = spec[0].transpose(0, 1)
+    return band[0], F.abs(), F.angle()
+
+
+def Sp_and_phase_Noise(signal, power, Normalization=True):
+    """audio_util.py:439-456."""
+    spec, _ = stft_band(_dev(signal).reshape(1, -1), want_band=False)
+    _, band = imcra_band(spec, power if Normalization else 1.0)
+    if not Normalization:
+        print('No normalization for func: Sp_and_phase_Noise')
+    F = spec[0].transpose(0, 1)
+    return band[0], F.abs(), F.angle()
+
+
+def SP_to_wav(alpha2, mag, phase, signal_length=None):
+    """audio_util.py:458-461: alpha2 [T,64], mag/phase [257,T] -> wav [256*(T-1)]."""
+    mag = _dev(mag)
+    phase = _dev(phase)
+    spec = torch.polar(mag.float(), phase.float()).transpose(0, 1).contiguous().unsqueeze(0)
+    return gain_istft(_dev(alpha2).unsqueeze(0), spec)[0]
+
+
+def rms(x):
+    """audio_util.py:463-464."""
+    x = _dev(x) if not isinstance(x, torch.Tensor) else x
+    return torch.sqrt(torch.mean(x ** 2))

@@ -1,0 +1,78 @@
+// Shared host/device helpers for libnele_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#define NELE_OK 0
+#define NELE_ERR_INVALID_ARG (-1)
+#define NELE_ERR_UNSUPPORTED (-2)
+#define NELE_ERR_SIGNAL (-3)   // signal below threshold / too short (reference raises)
+#define NELE_ERR_HIP (-4)
+#define NELE_ERR_WORKSPACE (-5)
+
+#define NELE_NFFT 512
+#define NELE_HOP 256
+#define NELE_NBINS 257
+#define NELE_NBANDS 64
+
+int nele_set_error(int code, const char* fmt, ...);
+
+#define NELE_CHECK_ARG(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) return nele_set_error(NELE_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define NELE_CHECK_LAUNCH(name)                                                      \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess)                                                        \
+            return nele_set_error(NELE_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- wave64 reductions (fixed-order butterflies: deterministic) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum of doubles through LDS scratch (>= blockDim/64 doubles); result to all threads.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ double block_max(double v, double* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double t = scratch[0];
+    for (int i = 1; i < nw; ++i) t = fmax(t, scratch[i]);
+    return t;
+}

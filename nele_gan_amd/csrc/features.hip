@@ -1,0 +1,350 @@
+// Signal features / resynthesis kernels.
+//   nele_stft_band  : wav -> complex64 spectrum + 64-band energies ** p      (audio_util.py:53-58, 30-50, 422-437)
+//   nele_imcra_band : spectrum -> IMCRA noise PSD + band energies ** p        (noise_est/imcra.py:363-484, 521-577; audio_util.py:113-117, 439-456)
+//   nele_gain_istft : alpha^2 band gains + spectrum -> waveform               (audio_util.py:76-110, 458-461, 60-65)
+//   nele_wav_post   : optional RMS normalisation + PCM_16 round trip          (inference.py:109, 115; train_nele.py:313)
+//
+// Layouts in HBM (row-major): wav [B][L] f32; spec [B][T][257] float2 (frame-major so a frame's bins
+// are one coalesced 2 KB run); band [B][T][64] f32; psd [B][T][257] f32.
+// This file is compiled with -ffp-contract=off: the float32/float64 op sequence below mirrors numpy's.
+#include "common.h"
+#include "fft512.h"
+
+__constant__ int c_gmt[NELE_NBANDS] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
+                                        24, 25, 26, 28, 30, 32, 34, 36, 38, 41, 43, 46, 49, 52, 55, 58, 62, 66, 70, 74,
+                                        79, 83, 88, 93, 99, 105, 111, 117, 124, 131, 139, 147, 156, 165, 174, 184, 195,
+                                        206, 218, 230, 243, 257};
+
+// Band energy of band i from tmp[257] (= |X|^2, float32), in the accumulation order of
+// compute_band_E (audio_util.py:40-48): first the "frac" shares of band i-1's bins, then the
+// "1-frac" shares of band i's own bins; float32 products, float64 running sum.
+__device__ __forceinline__ float band_energy(const float* tmp, int i) {
+    double acc = 0.0;
+    if (i >= 1) {
+        const int g0 = c_gmt[i - 1], size = c_gmt[i] - g0;
+        for (int j = 0; j < size; ++j) {
+            const float fr = (float)((double)j / (double)size);
+            acc += (double)(fr * tmp[g0 + j]);
+        }
+    }
+    if (i <= NELE_NBANDS - 2) {
+        const int g0 = c_gmt[i], size = c_gmt[i + 1] - g0;
+        for (int j = 0; j < size; ++j) {
+            const float fr = (float)(1.0 - (double)j / (double)size);
+            acc += (double)(fr * tmp[g0 + j]);
+        }
+    }
+    return (float)acc;
+}
+
+__device__ __forceinline__ float pow_f32(float x, float p) { return (float)pow((double)x, (double)p); }
+
+__device__ __forceinline__ double hann512(int n) { return 0.5 - 0.5 * cospi((double)n / 256.0); }
+
+// ------------------------------------------------------------------------------------------ STFT
+// grid (ceil(T/2), B), block 256.  Frames 2p and 2p+1 share one complex FFT.
+__global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict__ wav, int L, int T, float power,
+                                                        float2* __restrict__ spec, float* __restrict__ band) {
+    __shared__ Fft512Lds s;
+    __shared__ float tmp[2][NELE_NBINS + 3];
+    const int b = blockIdx.y, t0 = 2 * blockIdx.x, t1 = t0 + 1;
+    const bool has1 = t1 < T;
+    const float* x = wav + (size_t)b * L;
+    fft512_init_twiddles(s);
+    for (int n = threadIdx.x; n < NELE_NFFT; n += 256) {
+        int o0 = NELE_HOP * t0 + n - NELE_HOP;
+        if (o0 < 0) o0 = -o0;
+        if (o0 >= L) o0 = 2 * (L - 1) - o0;
+        int o1 = o0;
+        if (has1) {
+            o1 = NELE_HOP * t1 + n - NELE_HOP;
+            if (o1 >= L) o1 = 2 * (L - 1) - o1;
+        }
+        const double w = hann512(n);
+        const double zr = w * (double)x[o0];
+        const double zi = has1 ? w * (double)x[o1] : 0.0;
+        s.x[fft512_brev(n)] = make_double2(zr, zi);
+    }
+    __syncthreads();
+    fft512_run<false>(s);
+    for (int k = threadIdx.x; k < NELE_NBINS; k += 256) {
+        const double2 zk = s.x[k], zn = s.x[(NELE_NFFT - k) & (NELE_NFFT - 1)];
+        const float2 A = make_float2((float)(0.5 * (zk.x + zn.x)), (float)(0.5 * (zk.y - zn.y)));
+        const float2 Bv = make_float2((float)(0.5 * (zk.y + zn.y)), (float)(0.5 * (zn.x - zk.x)));
+        if (spec) {
+            spec[((size_t)b * T + t0) * NELE_NBINS + k] = A;
+            if (has1) spec[((size_t)b * T + t1) * NELE_NBINS + k] = Bv;
+        }
+        // np.abs(complex64) -> float32 magnitude, squared in float32 (audio_util.py:428, 44)
+        const float m0 = (float)sqrt((double)A.x * A.x + (double)A.y * A.y);
+        const float m1 = (float)sqrt((double)Bv.x * Bv.x + (double)Bv.y * Bv.y);
+        tmp[0][k] = m0 * m0;
+        tmp[1][k] = m1 * m1;
+    }
+    __syncthreads();
+    if (band && threadIdx.x < 2 * NELE_NBANDS) {
+        const int f = threadIdx.x >> 6, i = threadIdx.x & 63, t = t0 + f;
+        if (t < T) {
+            const float e = band_energy(tmp[f], i);
+            band[((size_t)b * T + t) * NELE_NBANDS + i] = pow_f32(e, power);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ IMCRA
+// One block (320 threads, bins 0..256 active) per utterance; serial over frames (true recurrence),
+// neighbour bins exchanged through LDS.  float32 / float64 staging follows numpy (see oracle/features.py).
+#define IMCRA_THREADS 320
+struct ImcraLds {
+    double a[NELE_NBINS + 2];
+    double b[NELE_NBINS + 2];
+    double st[8][NELE_NBINS];
+    double tst[8][NELE_NBINS];
+    float tmp[NELE_NBINS + 3];
+};
+
+__device__ __forceinline__ double fsmooth3(const double* v, int k, double w0, double w1, double w2) {
+    return (w0 * v[k] + w1 * v[k + 1]) + w2 * v[k + 2];  // v is offset by one: v[k+1] is bin k
+}
+
+__global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2* __restrict__ spec, int T, float power,
+                                                                   float* __restrict__ psd, float* __restrict__ band) {
+    __shared__ ImcraLds s;
+    const int b = blockIdx.x, k = threadIdx.x;
+    const bool act = k < NELE_NBINS;
+    const bool edge_lo = (k == 0), edge_hi = (k == NELE_NBINS - 1);
+    const float2* Y = spec + (size_t)b * T * NELE_NBINS;
+    const double alpha_s = 0.9, alpha_d = 0.85, Bmin = 3.2, Gamma0 = 4.6, Gamma1 = 3.0, zeta0 = 1.67, beta = 1.47;
+    const double alpha_dd = 0.92, xi_min = pow(10.0, -25.0 / 20.0), p_up = 0.9;
+    const double one_m_as = 1.0 - alpha_s, one_m_ad = 1.0 - alpha_d, one_m_add = 1.0 - alpha_dd;
+    double w0 = 0.25, w1 = 0.5, w2 = 0.25;  // imcra.py:270-280 (sym_hanning(3), row-normalised)
+    if (edge_lo) { w0 = 0.0; w1 = 1.0 / 1.5; w2 = 0.5 / 1.5; }
+    if (edge_hi) { w0 = 0.5 / 1.5; w1 = 1.0 / 1.5; w2 = 0.0; }
+
+    double S = 0, tS = 0, Smin = 0, tSmin = 0, Smin_sw = 0, tSmin_sw = 0, ovL = 0, Lam64 = 1e-6, G = 1.0, Gamma = 1.0;
+    float Lam32 = 0.f;
+    int j = 0, u = 0;
+    for (int l = 0; l < T; ++l) {
+        float Y2f = 0.f, outv = 0.f;
+        double xi = 0.0, I = 0.0;
+        if (act) {
+            const float2 y = Y[(size_t)l * NELE_NBINS + k];
+            const float h = (float)sqrt((double)y.x * y.x + (double)y.y * y.y);  // np.abs(complex64)
+            Y2f = h * h;                                                          // **2 on a float32 array
+            s.a[k + 1] = (double)Y2f;
+            if (edge_lo) s.a[0] = (double)Y2f;
+            if (edge_hi) s.a[NELE_NBINS + 1] = (double)Y2f;
+        }
+        __syncthreads();
+        if (act) {
+            const double Y2 = (double)Y2f;
+            const double Sf = fsmooth3(s.a, k, w0, w1, w2);
+            // ---- decision-directed a-priori SNR (imcra.py:543-557)
+            const double xi_G = (l == 0) ? 1.0 : (G * G) * Gamma;
+            double term;
+            if (l == 0 || l >= 16) {
+                Gamma = Y2 / Lam64;
+                double xi_ML = Gamma - 1.0;
+                if (xi_ML < 1e-6) xi_ML = 1e-6;
+                term = one_m_add * xi_ML;
+            } else {  // Lambda_D (hence Gamma, xi_ML) is a float32 array for frames 1..15
+                const float Gf = Y2f / Lam32;
+                float xf = Gf - 1.0f;
+                if (xf < (float)1e-6) xf = (float)1e-6;
+                term = (double)((float)one_m_add * xf);
+                Gamma = (double)Gf;
+            }
+            xi = alpha_dd * xi_G + term;
+            if (xi < xi_min) xi = xi_min;
+            G = xi / (1.0 + xi);
+            // ---- imcra.update (imcra.py:363-484)
+            if (l == 0) {  // init_params (imcra.py:338-361)
+                S = Sf; tS = Sf; Smin = Sf; tSmin = Sf; Smin_sw = Sf; tSmin_sw = Sf;
+                ovL = Y2;
+                Lam32 = Y2f;
+            }
+            S = alpha_s * S + one_m_as * Sf;
+            Smin = fmin(Smin, S);
+            Smin_sw = fmin(Smin_sw, S);
+            if (l < 15) {
+                Lam32 = (float)alpha_d * Lam32 + (float)one_m_ad * Y2f;
+                outv = Lam32;
+            } else {
+                const double Gamma_min = Y2 / (Bmin * Smin);
+                const double zeta = S / (Bmin * Smin);
+                I = (Gamma_min < Gamma0 && zeta < zeta0) ? 1.0 : 0.0;
+            }
+        }
+        if (l >= 15) {  // block-uniform branch
+            __syncthreads();  // everyone is done reading s.a (|Y|^2)
+            if (act) {
+                const double IY = I * (double)Y2f;
+                s.a[k + 1] = IY;
+                s.b[k + 1] = I;
+                if (edge_lo) { s.a[0] = IY; s.b[0] = I; }
+                if (edge_hi) { s.a[NELE_NBINS + 1] = IY; s.b[NELE_NBINS + 1] = I; }
+            }
+            __syncthreads();
+            if (act) {
+                const double Y2 = (double)Y2f;
+                const double norm = fsmooth3(s.b, k, w0, w1, w2);
+                double tSf = fsmooth3(s.a, k, w0, w1, w2);
+                if (norm > 0.0) tSf = tSf / norm;
+                tS = alpha_s * tS + one_m_as * tSf;
+                tSmin = fmin(tSmin, tS);
+                tSmin_sw = fmin(tSmin_sw, tS);
+                const double tG = Y2 / (Bmin * tSmin);
+                const double tz = S / (Bmin * tSmin);
+                double q = 0.0;
+                if (tG <= 1.0 && tz < zeta0) q = 1.0;
+                else if (1.0 < tG && tG < Gamma1 && tz < zeta0) q = (Gamma1 - tG) / (Gamma1 - 1.0);
+                // post_speech_prob (imcra.py:22-36)
+                const double nu = Gamma * xi / (1.0 + xi);
+                double p = 0.0;
+                if (q < 1.0) p = 1.0 / (1.0 + (q / (1.0 - q)) * (1.0 + xi) * exp(-nu));
+                if (p > p_up) p = p_up;
+                const double tad = alpha_d + one_m_ad * p;
+                ovL = tad * ovL + (1.0 - tad) * Y2;
+                Lam64 = beta * ovL;
+                outv = (float)Lam64;
+                // minimum tracking (imcra.py:452-481); np.roll of the U=8 store == ring buffer
+                if (j + 1 == 15) {
+                    const int slot = u & 7;
+                    s.st[slot][k] = Smin_sw;
+                    s.tst[slot][k] = tSmin_sw;
+                    const int n = (u < 8) ? (u + 1) : 8;
+                    double m = s.st[0][k], tm = s.tst[0][k];
+                    for (int i = 1; i < n; ++i) { m = fmin(m, s.st[i][k]); tm = fmin(tm, s.tst[i][k]); }
+                    Smin = m; tSmin = tm;
+                    Smin_sw = S; tSmin_sw = tS;
+                }
+            }
+            if (++j == 15) { j = 0; ++u; }
+        }
+        // ---- band feature of sqrt(PSD) (audio_util.py:446-451)
+        if (act) {
+            if (psd) psd[((size_t)b * T + l) * NELE_NBINS + k] = outv;
+            const float r = sqrtf(outv);
+            s.tmp[k] = r * r;
+        }
+        __syncthreads();
+        if (band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = pow_f32(band_energy(s.tmp, k), power);
+        // next iteration's first barrier orders these reads of s.tmp / s.a against its writes
+    }
+}
+
+// ------------------------------------------------------------------------------------------ iSTFT
+// grid (T-1, B), block 256: output samples [256 j, 256 j + 256) of the trimmed signal = second half
+// of frame j + first half of frame j+1; both real inverse transforms ride one complex FFT.
+__device__ __forceinline__ double band_gain_sqrt(const float* __restrict__ a2, int k) {
+    // interp_band_gain (audio_util.py:93-110) then np.sqrt (audio_util.py:85)
+    if (k <= 1) return sqrt(1e-4);
+    if (k == NELE_NBINS - 1) return sqrt(1e-2);
+    int i = 0;
+    while (c_gmt[i + 1] <= k) ++i;
+    const int size = c_gmt[i + 1] - c_gmt[i], jj = k - c_gmt[i];
+    const double frac = (double)jj / (double)size;
+    const float g = (float)(1.0 - frac) * a2[i] + (float)frac * a2[i + 1];
+    return sqrt((double)g);
+}
+
+__global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
+                                                         int T, float* __restrict__ wav) {
+    __shared__ Fft512Lds s;
+    const int b = blockIdx.y, fa = blockIdx.x, fb = fa + 1;
+    const float* a2a = alpha2 + ((size_t)b * T + fa) * NELE_NBANDS;
+    const float* a2b = a2a + NELE_NBANDS;
+    const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
+    const float2* Xb = Xa + NELE_NBINS;
+    fft512_init_twiddles(s);
+    for (int k = threadIdx.x; k < NELE_NBINS; k += 256) {
+        const double ga = band_gain_sqrt(a2a, k), gb = band_gain_sqrt(a2b, k);
+        const float2 xa = Xa[k], xb = Xb[k];
+        double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
+        double br = gb * (double)xb.x, bi = gb * (double)xb.y;
+        if (k == 0 || k == NELE_NBINS - 1) { ai = 0.0; bi = 0.0; }  // c2r ignores these imaginary parts
+        s.x[fft512_brev(k)] = make_double2(ar - bi, ai + br);
+        if (k >= 1 && k <= 255) s.x[fft512_brev(NELE_NFFT - k)] = make_double2(ar + bi, br - ai);
+    }
+    __syncthreads();
+    fft512_run<true>(s);
+    {
+        const int n = threadIdx.x;
+        const double x1 = s.x[n + 256].x * (1.0 / 512.0);  // frame fa, second half
+        const double x2 = s.x[n].y * (1.0 / 512.0);        // frame fb, first half
+        const double wa = hann512(n + 256), wb = hann512(n);
+        float y = (float)(wa * x1);                        // overlap-add into a float32 buffer
+        y = (float)((double)y + wb * x2);
+        float wss = (float)(wa * wa);                      // window_sumsquare, same float32 staging
+        wss = (float)((double)wss + wb * wb);
+        wav[(size_t)b * (NELE_HOP * (T - 1)) + (size_t)NELE_HOP * fa + n] = y / wss;
+    }
+}
+
+// One block per utterance: optional enh / rms(enh) * target (inference.py:109) and optional PCM_16
+// round trip (libsndfile float->short with 0x7FFF scaling + lrintf, read back / 32768: PARITY UNPINNED).
+__global__ __launch_bounds__(256) void wav_post_kernel(float* __restrict__ wav, int N, float target_rms, int pcm16) {
+    __shared__ double red[8];
+    float* x = wav + (size_t)blockIdx.x * N;
+    float scale = 1.f;
+    if (target_rms > 0.f) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) acc += (double)(x[i] * x[i]);
+        acc = block_sum(acc, red);
+        const float r = sqrtf((float)(acc / (double)N));
+        scale = 1.f / r;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            float v = x[i] / r * target_rms;
+            if (pcm16) {
+                float q = rintf(v * 32767.f);
+                q = fminf(fmaxf(q, -32768.f), 32767.f);
+                v = q / 32768.f;
+            }
+            x[i] = v;
+        }
+    } else if (pcm16) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            float q = rintf(x[i] * 32767.f);
+            q = fminf(fmaxf(q, -32768.f), 32767.f);
+            x[i] = q / 32768.f;
+        }
+    }
+    (void)scale;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int nele_stft_band(const float* wav, int B, int L, float power, void* spec, float* band, void* stream) {
+    NELE_CHECK_ARG(wav && B > 0, "nele_stft_band: null wav or B <= 0");
+    NELE_CHECK_ARG(L > NELE_HOP, "nele_stft_band: L=%d must exceed 256 (reflect padding)", L);
+    NELE_CHECK_ARG(spec || band, "nele_stft_band: no output requested");
+    const int T = 1 + L / NELE_HOP;
+    dim3 grid((T + 1) / 2, B);
+    hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band);
+    NELE_CHECK_LAUNCH("nele_stft_band");
+    return NELE_OK;
+}
+
+extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream) {
+    NELE_CHECK_ARG(spec && B > 0 && T > 0, "nele_imcra_band: bad arguments");
+    NELE_CHECK_ARG(psd || band, "nele_imcra_band: no output requested");
+    hipLaunchKernelGGL(imcra_band_kernel, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power,
+                       psd, band);
+    NELE_CHECK_LAUNCH("nele_imcra_band");
+    return NELE_OK;
+}
+
+extern "C" int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream) {
+    NELE_CHECK_ARG(alpha2 && spec && wav && B > 0, "nele_gain_istft: bad arguments");
+    NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
+    hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav);
+    NELE_CHECK_LAUNCH("nele_gain_istft");
+    return NELE_OK;
+}
+
+extern "C" int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream) {
+    NELE_CHECK_ARG(wav && B > 0 && N > 0, "nele_wav_post: bad arguments");
+    if (target_rms <= 0.f && !pcm16) return NELE_OK;
+    hipLaunchKernelGGL(wav_post_kernel, dim3(B), dim3(256), 0, as_stream(stream), wav, N, target_rms, pcm16);
+    NELE_CHECK_LAUNCH("nele_wav_post");
+    return NELE_OK;
+}
