@@ -37,6 +37,18 @@ __device__ __forceinline__ float band_energy(const float* tmp, int i) {
     return (float)acc;
 }
 
+// np.abs(complex64) as numpy >= 1.25 computes it on FMA-capable x86 hosts (SIMD loop
+// loops_unary_complex: larger * sqrt(fma(r, r, 1)), r = smaller / larger), so that |X|^2 is
+// bit-identical to the oracle's and threshold decisions downstream (IMCRA, VAD) see the same values.
+__device__ __forceinline__ float np_cabsf(float re, float im) {
+    re = fabsf(re);
+    im = fabsf(im);
+    const float larger = fmaxf(re, im), smaller = fminf(im, re);
+    if (larger == 0.f) return 0.f;
+    const float ratio = smaller / larger;
+    return sqrtf(__builtin_fmaf(ratio, ratio, 1.0f)) * larger;
+}
+
 __device__ __forceinline__ float pow_f32(float x, float p) { return (float)pow((double)x, (double)p); }
 
 __device__ __forceinline__ double hann512(int n) { return 0.5 - 0.5 * cospi((double)n / 256.0); }
@@ -76,8 +88,8 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
             if (has1) spec[((size_t)b * T + t1) * NELE_NBINS + k] = Bv;
         }
         // np.abs(complex64) -> float32 magnitude, squared in float32 (audio_util.py:428, 44)
-        const float m0 = (float)sqrt((double)A.x * A.x + (double)A.y * A.y);
-        const float m1 = (float)sqrt((double)Bv.x * Bv.x + (double)Bv.y * Bv.y);
+        const float m0 = np_cabsf(A.x, A.y);
+        const float m1 = np_cabsf(Bv.x, Bv.y);
         tmp[0][k] = m0 * m0;
         tmp[1][k] = m1 * m1;
     }
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
         double xi = 0.0, I = 0.0;
         if (act) {
             const float2 y = Y[(size_t)l * NELE_NBINS + k];
-            const float h = (float)sqrt((double)y.x * y.x + (double)y.y * y.y);  // np.abs(complex64)
+            const float h = np_cabsf(y.x, y.y);                                   // np.abs(complex64)
             Y2f = h * h;                                                          // **2 on a float32 array
             s.a[k + 1] = (double)Y2f;
             if (edge_lo) s.a[0] = (double)Y2f;

@@ -33,7 +33,7 @@ def clean_utterance(i, length):
     env = np.clip((env - 0.2) / 0.8, 0.0, 1.0) ** 2          # ~30 % of each syllable cycle silent
     # slower phrase-level modulation so that frames differ in level
     env *= 0.6 + 0.4 * np.cos(2 * np.pi * 0.7 * t + rng.uniform(0, 2 * np.pi)) ** 2
-    x = x * env
+    x = x * np.maximum(env, 3e-3)                            # gaps are -50 dB, not digital silence
     x = x / np.sqrt(np.mean(x ** 2)) * 0.03
     return x.astype(np.float32)
 
