@@ -45,6 +45,91 @@ int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* 
  * write/read round trip of train_nele.py:313 + dataloader.py:58 (pcm16 != 0).  In place on wav [B][N]. */
 int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream);
 
+/* ---- dense layers: convolution as implicit GEMM on the f32 matrix cores (csrc/dense.hip) ------- */
+
+/* ConvGeom, passed as 15 ints {H, W, C, ih0, iw0, Hout, Wout, seglen=KW*C, segstride=W*C, Ktot=KH*KW*C,
+ * OH, OW, OC, oh0, ow0}: channels-last input buffer [B][H][W][C]; output position (b,ho,wo) reads the
+ * window whose origin is (ho+ih0, wo+iw0) and writes element (ho+oh0, wo+ow0, n) of [B][OH][OW][OC].
+ *
+ * nele_conv_gemm: out = epi(sum_kk A_view[m][kk] * Wg[n][kk]), m = (b,ho,wo), M = B*Hout*Wout.
+ * Replaces torch.nn.Conv1d + Chomp1d (model.py:10-40, 49-77; H = 1 on a left-padded time axis),
+ * torch.nn.Conv2d (model.py:105-109), torch.nn.Linear (model.py:81-82, 95-97) and, run over a
+ * zero-bordered gradient buffer with flipped weights, their data gradients (autograd in the reference).
+ * epi: 0 none, 1 +bias, 2 +bias then LeakyReLU(slope), 3 multiply by LeakyReLU'(aux) (aux = forward
+ * activation, unpadded [M][OC]), 4 +bias then exp(3.2*tanh(.)) (model.py:98). */
+int nele_conv_gemm(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
+                   int epi, float slope, const int* geom_host, void* stream);
+
+/* Weight gradient dW[n][ci][kh][kw] (+)= sum_m dOut[m][n] * A_view[m][(kh,kw,ci)], db[n] (+)= sum_m dOut[m][n]
+ * (autograd of the layers above).  Split over m across workgroups, partials summed in fixed order.
+ * workspace_floats >= nele_conv_wgrad_workspace_floats(M, N, Ktot, &splits). */
+long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, int* splits_out_host);
+int nele_conv_wgrad(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                    const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
+
+/* PyTorch parameter layout [N][Cvalid][KH][KW] (optionally / sigma[0]) -> GEMM layouts:
+ * Wf[n][kh][kw][c] (c zero-padded to C) and, if Wb != NULL, the flipped data-gradient layout
+ * Wb[c][KH-1-kh][KW-1-kw][n]. */
+int nele_weight_prep(const float* Wt, const float* sigma, int N, int Cvalid, int C, int KH, int KW, float* Wf, float* Wb,
+                     void* stream);
+
+/* ---- generator glue (csrc/gen.hip) -------------------------------------------------------------- */
+
+/* model.py:85-86: cat(x,y) [B][T][64]x2 -> left-padded conv input [B][T+pad][128]. */
+int nele_g_pack(const float* x, const float* y, float* out, int B, int T, int pad, void* stream);
+
+/* model.py:168-205 cLN followed by LeakyReLU (model.py:88-91): Y [B][T][C] -> out (rows pad.. of
+ * [B][T+pad][C]); saves the cumulative mean / 1/std per frame for the backward pass. */
+int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, int B, int T,
+                 int C, int pad, float slope, void* stream);
+/* Backward of the above: dAct [B][T][C] -> dY (rows 0..T-1 of the END-padded [B][T+pade][C]),
+ * per-utterance gain/bias gradient partials [B][C] (reduce with nele_colsum). */
+int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
+                 const float* rstd, float* dY, float* dgain_part, float* dbias_part, int B, int T, int C, int pade,
+                 float slope, void* stream);
+int nele_colsum(const float* part, int rows, int cols, float* out, int accumulate, void* stream);
+
+/* Gradient of model.py:98 exp(3.2*tanh(o)) given the mask itself. */
+int nele_exptanh_bwd(const float* dmask, const float* mask, float* dout, long long n, void* stream);
+
+/* train_nele.py:133-146 (per utterance): beta2 = sum(clean^inv_p) / sum(mask*clean^inv_p);
+ * din [B][64][T][4] = (clean*mask^p*beta2^p, noise, clean, 0) channels-last D input (may be NULL);
+ * alpha2 = mask*beta2 (train_nele.py:307, inference.py:104; may be NULL); s2 = sum(mask*clean^inv_p). */
+int nele_energy_norm_fwd(const float* clean, const float* mask, const float* noise, float p, float inv_p, float* beta2,
+                         float* s2, float* din, float* alpha2, int B, int T, void* stream);
+int nele_energy_norm_bwd(const float* clean, const float* mask, const float* beta2, const float* s2, const float* ddin,
+                         float p, float inv_p, float* dmask, int B, int T, void* stream);
+
+/* dataloader.py:76-84: band features (enhanced, noise, clean) [B][T][64] -> D input [B][64][T][4]
+ * (c2 NULL for Discriminator_Quality's (enhanced, clean)). */
+int nele_d_pack(const float* c0, const float* c1, const float* c2, float* din, int B, int T, void* stream);
+/* Reference tensor layout [B][Cin][64][T] (model.py:118) <-> channels-last [B][64][T][4]. */
+int nele_d_layout(const float* src, float* dst, int B, int Cin, int T, int to_nhwc, void* stream);
+
+/* ---- discriminator glue + optimiser (csrc/disc.hip) --------------------------------------------- */
+
+/* torch.nn.utils.spectral_norm as used at model.py:105-116: n_iter (1 in train mode, 0 in eval) power
+ * iterations updating u [N], v [K] in place, then sigma = u . (W v); W = weight_orig as [N][K]. */
+int nele_spectral_norm(const float* W, float* u, float* v, float* sigma, int N, int K, int n_iter, void* stream);
+/* dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma : gradient through W/sigma with u, v constant. */
+int nele_sn_grad(const float* dW, const float* W, const float* u, const float* v, const float* sigma, int N, int K,
+                 float* dst, int accumulate, void* stream);
+
+/* model.py:123-132: AdaptiveAvgPool2d(1) over act [B][P][64] + fc1/fc2/fc3 (spectral-norm Linear) +
+ * LeakyReLU + sigmoid.  mlp_host: HOST array of 9 device pointers {w1,b1,sigma1,w2,b2,sigma2,w3,b3,sigma3}. */
+int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled,
+                     float* h1, float* h2, float* score, void* stream);
+/* Backward of the head: dscore [B][nout] -> dz3, dz2, dz1, dpooled and (gbuf != NULL) the gradient of
+ * the last conv activation written into the zero-bordered buffer [B][OH][OW][64] at (oh0, ow0). */
+int nele_gap_mlp_bwd(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                     const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, int OH, int OW, int oh0,
+                     int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream);
+int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream);
+
+/* torch.optim.Adam (train_nele.py:89-91) on flat buffers; step counts from 1. */
+int nele_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

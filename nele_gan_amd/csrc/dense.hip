@@ -1,0 +1,406 @@
+// Dense kernels of the generator / discriminator: convolution as implicit GEMM on the f32-input
+// matrix cores (v_mfma_f32_16x16x4_f32: exact float32 products and accumulation, so results agree
+// with the reference's float32 torch modules to rounding-order level).
+//
+//   nele_conv_gemm  : out[m][n] = epi( sum_kk A_view[m][kk] * Wg[n][kk] )      forward and data-gradient
+//   nele_conv_wgrad : part[s][n][kk] = sum_{m in split s} dOut[m][n] * A_view[m][kk]   weight gradient
+//
+// A_view is never materialised: activations are channels-last [B][H][W][C], so the im2col row of
+// output position (b,ho,wo) is KH contiguous runs of KW*C floats (run stride W*C).  Conv1d of the
+// generator (model.py:49-77) is the H=1 case on a time-padded buffer (Chomp1d == left padding only),
+// Conv2d of the discriminator (model.py:105-109) the general case, Linear the KH=KW=1 case.
+// Data gradients are the same kernel run over a zero-bordered gradient buffer with flipped weights.
+//
+// Tiling: 256 threads = 4 waves stacked along M; wave tile 64 x (16*TN); block tile 256 x (16*TN);
+// K step 8 (two 16x16x4 MFMAs per tile), LDS double-buffered, one barrier per step.
+#include "common.h"
+#include <cstring>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvGeom {
+    // input buffer [B][H][W][C]; window origin of output (ho,wo) is (ho+ih0, wo+iw0)
+    int H, W, C, ih0, iw0;
+    int Hout, Wout;           // output positions per utterance; M = B*Hout*Wout
+    int seglen, segstride;    // KW*C, W*C
+    int Ktot;                 // KH*KW*C
+    // output buffer [B][OH][OW][OC]; element (ho,wo,n) at (ho+oh0, wo+ow0, n)
+    int OH, OW, OC, oh0, ow0;
+};
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_LRELU = 2, EPI_MASK_LRELU_GRAD = 3, EPI_BIAS_EXPTANH = 4 };
+
+struct GemmArgs {
+    const float* A;
+    const float* Wg;     // [N][Ktot]
+    const float* bias;   // [N] or null
+    const float* aux;    // EPI_MASK_LRELU_GRAD: forward activation, unpadded [B][Hout][Wout][OC]
+    float* out;
+    int M, N;
+    int epi;
+    float slope;
+    ConvGeom g;
+};
+
+__device__ __forceinline__ void decode_m(int m, const ConvGeom& g, int& b, int& ho, int& wo) {
+    const int hw = g.Hout * g.Wout;
+    b = m / hw;
+    const int r = m - b * hw;
+    ho = r / g.Wout;
+    wo = r - ho * g.Wout;
+}
+
+#define GEMM_BM 256
+#define GEMM_BK 8
+#define LDS_STRIDE 8
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
+    constexpr int BN = 16 * TN;
+    __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDS_STRIDE];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN;
+
+    // ---- loader roles: A: 2 float4 per thread (rows tid>>1 and 128+(tid>>1), k-quad tid&1)
+    const int kq = tid & 1;
+    size_t a_off[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (tid >> 1) + 128 * i;
+        a_ok[i] = m < p.M;
+        int b = 0, ho = 0, wo = 0;
+        if (a_ok[i]) decode_m(m, g, b, ho, wo);
+        a_off[i] = (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C;
+    }
+    // B: 64 rows x 2 quads = 128 float4: threads < 2*BN
+    const int bn = tid >> 1;
+    const bool b_ok = (tid < 2 * BN) && (n0 + bn < p.N);
+    const float* wrow = p.Wg + (size_t)(n0 + bn) * g.Ktot;
+
+    // this thread's k position: kk = step*8 + 4*kq -> (segment kh, offset r)
+    int kk = 4 * kq, kh = 0, r = 4 * kq;
+    while (r >= g.seglen) { r -= g.seglen; ++kh; }
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (g.Ktot + GEMM_BK - 1) / GEMM_BK;
+    float4 ra[2], rb;
+    auto gload = [&]() {
+        const bool kin = kk < g.Ktot;
+        const size_t koff = (size_t)kh * g.segstride + r;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            ra[i] = (a_ok[i] && kin) ? *reinterpret_cast<const float4*>(p.A + a_off[i] + koff) : make_float4(0, 0, 0, 0);
+        rb = (b_ok && kin) ? *reinterpret_cast<const float4*>(wrow + kk) : make_float4(0, 0, 0, 0);
+        kk += GEMM_BK;
+        r += GEMM_BK;
+        while (r >= g.seglen) { r -= g.seglen; ++kh; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 1) + 128 * i) * LDS_STRIDE + 4 * kq]) = ra[i];
+        if (tid < 2 * BN) *reinterpret_cast<float4*>(&Bs[buf][bn * LDS_STRIDE + 4 * kq]) = rb;
+    };
+
+    gload();
+    lstore(0);
+    __syncthreads();
+    const int li = lane & 15, lg = lane >> 4;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload();
+        // fragments: lane group lg takes k = 2*lg, 2*lg+1 of this step (same permutation for A and B)
+        float2 af[4], bf[TN];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            af[i] = *reinterpret_cast<const float2*>(&As[buf][(wave * 64 + i * 16 + li) * LDS_STRIDE + 2 * lg]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float2*>(&Bs[buf][(j * 16 + li) * LDS_STRIDE + 2 * lg]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][reg] is (row = 16 i + 4 lg + reg, col = 16 j + li) of the wave tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wave * 64 + i * 16 + 4 * lg + reg;
+            if (m >= p.M) continue;
+            int b, ho, wo;
+            decode_m(m, g, b, ho, wo);
+            const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+            const size_t x_off = (size_t)m * g.OC;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 16 + li;
+                if (n >= p.N) continue;
+                float v = acc[i][j][reg];
+                switch (p.epi) {
+                    case EPI_BIAS: v += p.bias[n]; break;
+                    case EPI_BIAS_LRELU: v += p.bias[n]; v = v > 0.f ? v : p.slope * v; break;
+                    case EPI_MASK_LRELU_GRAD: v = p.aux[x_off + n] > 0.f ? v : p.slope * v; break;
+                    case EPI_BIAS_EXPTANH: v += p.bias[n]; v = expf(3.2f * tanhf(v)); break;
+                    default: break;
+                }
+                p.out[o_off + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+    const float* A;      // forward input activations (geometry g: H,W,C,ih0,iw0,seglen,segstride,Ktot,Hout,Wout)
+    const float* dOut;   // gradient wrt the layer output, buffer [B][OH][OW][OC] at offset (oh0,ow0)
+    float* part;         // [splits][N][Ktot]
+    float* bpart;        // [splits][N] (bias gradient partials) or null
+    int M, N;
+    int rows_per_split;  // multiple of 8
+    ConvGeom g;
+};
+
+#define WG_BKK 128
+#define WG_BN 64
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ds[2][8 * WG_BN];
+    __shared__ __attribute__((aligned(16))) float Av[2][8 * WG_BKK];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk0 = blockIdx.x * WG_BKK, split = blockIdx.y, n0 = blockIdx.z * WG_BN;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    // Av loader: row tid>>5 (0..7), quad tid&31 -> kk fixed for the whole loop
+    const int arow = tid >> 5, akk = kk0 + 4 * (tid & 31);
+    const bool a_kin = akk < g.Ktot;
+    int kh = 0, r = akk;
+    if (a_kin) { kh = akk / g.seglen; r = akk - kh * g.seglen; }
+    const size_t a_koff = (size_t)kh * g.segstride + r;
+    // Ds loader: threads < 128: row tid>>4, quad tid&15
+    const int drow = tid >> 4, dn = n0 + 4 * (tid & 15);
+    const bool d_role = tid < 128;
+    const bool d_nin = dn < p.N;  // N is a multiple of 4 for every layer
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    float4 ra, rd;
+    auto gload = [&](int mbase) {
+        {
+            const int m = mbase + arow;
+            ra = make_float4(0, 0, 0, 0);
+            if (a_kin && m < m_end) {
+                int b, ho, wo;
+                decode_m(m, g, b, ho, wo);
+                const size_t off = (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C;
+                ra = *reinterpret_cast<const float4*>(p.A + off + a_koff);
+            }
+        }
+        if (d_role) {
+            const int m = mbase + drow;
+            rd = make_float4(0, 0, 0, 0);
+            if (d_nin && m < m_end) {
+                int b, ho, wo;
+                decode_m(m, g, b, ho, wo);
+                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+                rd = *reinterpret_cast<const float4*>(p.dOut + off + dn);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<float4*>(&Av[buf][arow * WG_BKK + 4 * (tid & 31)]) = ra;
+        if (d_role) *reinterpret_cast<float4*>(&Ds[buf][drow * WG_BN + 4 * (tid & 15)]) = rd;
+    };
+
+    const int li = lane & 15, lg = lane >> 4;
+    if (m_begin < m_end) {
+        gload(m_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += 8, buf ^= 1) {
+        const bool more = mb + 8 < m_end;
+        if (more) gload(mb + 8);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = Ds[buf][(4 * s + lg) * WG_BN + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Av[buf][(4 * s + lg) * WG_BKK + wave * 32 + j * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (p.bpart && blockIdx.x == 0 && tid < WG_BN) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) bsum += Ds[buf][rr * WG_BN + tid];
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[i][j][reg]: n = n0 + 16 i + 4 lg + reg, kk = kk0 + 32 wave + 16 j + li
+    float* part = p.part + (size_t)split * p.N * g.Ktot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int n = n0 + i * 16 + 4 * lg + reg;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kk = kk0 + wave * 32 + j * 16 + li;
+                if (kk < g.Ktot) part[(size_t)n * g.Ktot + kk] = acc[i][j][reg];
+            }
+        }
+    if (p.bpart && blockIdx.x == 0 && tid < WG_BN && n0 + tid < p.N) p.bpart[(size_t)split * p.N + n0 + tid] = bsum;
+}
+
+// Sum the split partials in fixed order and scatter from GEMM layout [n][kh][kw][ci] to the
+// PyTorch parameter layout [n][ci][kh][kw] (flip != 0: the partials are in the flipped data-gradient
+// layout, never used for weights).  One thread per weight element.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int splits, int N,
+                                    int KH, int KW, int C, int Cvalid, float* __restrict__ dW, float* __restrict__ db,
+                                    int accumulate) {
+    const int Ktot = KH * KW * C;
+    const int total = N * Ktot;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int n = idx / Ktot, kk = idx - n * Ktot;
+        const int ci = kk % C, t = kk / C, kw = t % KW, kh = t / KW;
+        if (ci >= Cvalid) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
+        const size_t o = (((size_t)n * Cvalid + ci) * KH + kh) * KW + kw;
+        dW[o] = accumulate ? dW[o] + s : s;
+    }
+    if (db && bpart) {
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += bpart[(size_t)sp * N + n];
+            db[n] = accumulate ? db[n] + s : s;
+        }
+    }
+}
+
+// PyTorch weight [N][Cvalid][KH][KW] (optionally scaled by 1/sigma[0]) -> forward GEMM layout
+// Wf[n][kh][kw][c] (c padded to C with zeros) and, if Wb != null, data-gradient layout
+// Wb[c][KH-1-kh][KW-1-kw][n] (rows c < Cvalid only; Cb = N is its channel count).
+__global__ void weight_prep_kernel(const float* __restrict__ Wt, const float* __restrict__ sigma, int N, int Cvalid, int C,
+                                   int KH, int KW, float* __restrict__ Wf, float* __restrict__ Wb) {
+    const int total = N * Cvalid * KH * KW;
+    const float inv = sigma ? 1.f / sigma[0] : 1.f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int kw = t % KW; t /= KW;
+        const int kh = t % KH; t /= KH;
+        const int ci = t % Cvalid;
+        const int n = t / Cvalid;
+        const float v = Wt[idx] * inv;
+        Wf[(((size_t)n * KH + kh) * KW + kw) * C + ci] = v;
+        if (Wb) Wb[(((size_t)ci * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * N + n] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static int check_geom(const char* who, const ConvGeom& g, int M, int N) {
+    if (M <= 0 || N <= 0) return nele_set_error(NELE_ERR_INVALID_ARG, "%s: M=%d N=%d", who, M, N);
+    if (g.C % 4 || g.seglen % 4 || g.segstride % 4 || g.Ktot % 4)
+        return nele_set_error(NELE_ERR_UNSUPPORTED, "%s: channel counts must be multiples of 4 (C=%d seglen=%d)", who, g.C, g.seglen);
+    if (g.Ktot % g.seglen) return nele_set_error(NELE_ERR_INVALID_ARG, "%s: Ktot %% seglen != 0", who);
+    return NELE_OK;
+}
+
+// geom: 15 ints in ConvGeom order
+extern "C" int nele_conv_gemm(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
+                              int epi, float slope, const int* geom, void* stream) {
+    NELE_CHECK_ARG(A && Wg && out && geom, "nele_conv_gemm: null pointer");
+    GemmArgs p;
+    p.A = A; p.Wg = Wg; p.bias = bias; p.aux = aux; p.out = out; p.M = M; p.N = N; p.epi = epi; p.slope = slope;
+    memcpy(&p.g, geom, sizeof(ConvGeom));
+    int st = check_geom("nele_conv_gemm", p.g, M, N);
+    if (st) return st;
+    NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_gemm: epilogue needs bias");
+    NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_gemm: epilogue needs aux");
+    const int gx = (M + GEMM_BM - 1) / GEMM_BM;
+    hipStream_t s = as_stream(stream);
+    if (N <= 16) hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3(gx, 1), dim3(256), 0, s, p);
+    else if (N <= 32) hipLaunchKernelGGL(conv_gemm_kernel<2>, dim3(gx, 1), dim3(256), 0, s, p);
+    else if (N <= 48) hipLaunchKernelGGL(conv_gemm_kernel<3>, dim3(gx, 1), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_gemm_kernel<4>, dim3(gx, (N + 63) / 64), dim3(256), 0, s, p);
+    NELE_CHECK_LAUNCH("nele_conv_gemm");
+    return NELE_OK;
+}
+
+extern "C" long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, int* splits_out) {
+    // enough splits to fill the chip (>= ~1024 blocks) while keeping >= 512 rows per split
+    const int kt = (Ktot + WG_BKK - 1) / WG_BKK, nt = (N + WG_BN - 1) / WG_BN;
+    int splits = (1024 + kt * nt - 1) / (kt * nt);
+    const int max_splits = (M + 511) / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    if (splits_out) *splits_out = splits;
+    return (long long)splits * ((long long)N * Ktot + N);
+}
+
+extern "C" int nele_conv_wgrad(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                               const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
+    NELE_CHECK_ARG(A && dOut && workspace && geom && dW, "nele_conv_wgrad: null pointer");
+    WgradArgs p;
+    memcpy(&p.g, geom, sizeof(ConvGeom));
+    int st = check_geom("nele_conv_wgrad", p.g, M, N);
+    if (st) return st;
+    NELE_CHECK_ARG(N % 4 == 0 && p.g.OC % 4 == 0, "nele_conv_wgrad: N and OC must be multiples of 4");
+    NELE_CHECK_ARG(KH * KW * p.g.C == p.g.Ktot, "nele_conv_wgrad: KH*KW*C != Ktot");
+    int splits = 1;
+    const long long need = nele_conv_wgrad_workspace_floats(M, N, p.g.Ktot, &splits);
+    if (workspace_floats < need) return nele_set_error(NELE_ERR_WORKSPACE, "nele_conv_wgrad: workspace %lld < %lld floats", workspace_floats, need);
+    p.A = A; p.dOut = dOut; p.M = M; p.N = N;
+    p.part = workspace;
+    p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
+    int rps = (M + splits - 1) / splits;
+    rps = (rps + 7) / 8 * 8;
+    p.rows_per_split = rps;
+    hipStream_t s = as_stream(stream);
+    dim3 grid((p.g.Ktot + WG_BKK - 1) / WG_BKK, splits, (N + WG_BN - 1) / WG_BN);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    NELE_CHECK_LAUNCH("nele_conv_wgrad");
+    const int total = N * p.g.Ktot;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, s, p.part, p.bpart, splits, N, KH, KW,
+                       p.g.C, Cvalid, dW, db, accumulate);
+    NELE_CHECK_LAUNCH("nele_conv_wgrad(reduce)");
+    return NELE_OK;
+}
+
+extern "C" int nele_weight_prep(const float* Wt, const float* sigma, int N, int Cvalid, int C, int KH, int KW, float* Wf, float* Wb,
+                                void* stream) {
+    NELE_CHECK_ARG(Wt && Wf && N > 0 && Cvalid > 0 && C >= Cvalid, "nele_weight_prep: bad arguments");
+    const int total = N * Cvalid * KH * KW;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, as_stream(stream), Wt, sigma, N, Cvalid, C,
+                       KH, KW, Wf, Wb);
+    NELE_CHECK_LAUNCH("nele_weight_prep");
+    return NELE_OK;
+}

@@ -1,0 +1,283 @@
+// Discriminator-side kernels other than the conv GEMMs (model.py:101-166) and the optimiser:
+//   nele_spectral_norm     : one power iteration (train) or none (eval) + sigma = u^T W v   (torch.nn.utils.spectral_norm, model.py:105-116)
+//   nele_sn_grad           : gradient through W/sigma with u,v held constant
+//   nele_gap_mlp_fwd       : AdaptiveAvgPool2d(1) + 3 spectral-norm Linear + LeakyReLU + sigmoid (model.py:123-132)
+//   nele_gap_mlp_bwd       : MSE-loss gradient back to the last conv activation (into the zero-bordered gradient buffer)
+//   nele_mlp_wgrad         : Linear weight / bias gradients, fixed-order over the batch
+//   nele_adam_step         : torch.optim.Adam update on a flat parameter buffer            (train_nele.py:89-91)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ spectral norm
+// W [N][K] row-major (weight_orig viewed as (out, -1)); u [N], v [K] updated in place when n_iter == 1.
+// v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); normalize(x) = x / max(||x||, 1e-12).
+__global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
+                                                            float* __restrict__ sigma, int N, int K, int n_iter) {
+    __shared__ double red[8];
+    __shared__ float su[64], swv[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < N) su[tid] = u[tid];
+    __syncthreads();
+    if (n_iter > 0) {
+        double nrm = 0.0;
+        for (int k = tid; k < K; k += 256) {
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a += W[(size_t)n * K + k] * su[n];
+            v[k] = a;
+            nrm += (double)a * (double)a;
+        }
+        nrm = block_sum(nrm, red);
+        const float inv = 1.f / fmaxf((float)sqrt(nrm), 1e-12f);
+        for (int k = tid; k < K; k += 256) v[k] *= inv;
+        __syncthreads();
+    }
+    // W v
+    for (int n = wave; n < N; n += 4) {
+        float a = 0.f;
+        for (int k = lane; k < K; k += 64) a += W[(size_t)n * K + k] * v[k];
+        a = wave_sum(a);
+        if (lane == 0) swv[n] = a;
+    }
+    __syncthreads();
+    if (n_iter > 0) {
+        double nrm = 0.0;
+        if (tid < N) nrm = (double)swv[tid] * (double)swv[tid];
+        nrm = block_sum(nrm, red);
+        const float inv = 1.f / fmaxf((float)sqrt(nrm), 1e-12f);
+        if (tid < N) {
+            su[tid] = swv[tid] * inv;
+            u[tid] = su[tid];
+        }
+        __syncthreads();
+    }
+    double s = 0.0;
+    if (tid < N) s = (double)su[tid] * (double)swv[tid];
+    s = block_sum(s, red);
+    if (tid == 0) sigma[0] = (float)s;
+}
+
+// dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma      ([N][K] parameter layout)
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ dW, const float* __restrict__ W, const float* __restrict__ u,
+                                                      const float* __restrict__ v, const float* __restrict__ sigma, int N, int K,
+                                                      float* __restrict__ dst, int accumulate) {
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const float inv = 1.f / sigma[0];
+    double d = 0.0;
+    const int total = N * K;
+    for (int i = tid; i < total; i += 256) d += (double)dW[i] * (double)(W[i] * inv);
+    d = block_sum(d, red);
+    const float dot = (float)d;
+    for (int i = tid; i < total; i += 256) {
+        const int n = i / K, k = i - n * K;
+        const float val = (dW[i] - dot * u[n] * v[k]) * inv;
+        dst[i] = accumulate ? dst[i] + val : val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GAP + MLP
+struct MlpW {
+    const float *w1, *b1, *s1;  // [64][64], [64], sigma
+    const float *w2, *b2, *s2;  // [16][64]
+    const float *w3, *b3, *s3;  // [nout][16]
+};
+
+// One block per utterance. act [B][P][64] (P = Hout*Wout positions, channels-last).
+__global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const float* __restrict__ act, int P, MlpW w, int nout, float slope,
+                                                          float* __restrict__ pooled, float* __restrict__ h1, float* __restrict__ h2,
+                                                          float* __restrict__ score) {
+    __shared__ double part[4][64];
+    __shared__ float sp[64], sh1[64], sh2[16];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+    const float* a = act + (size_t)b * P * 64;
+    double s = 0.0;
+    for (int pos = g; pos < P; pos += 4) s += (double)a[(size_t)pos * 64 + c];
+    part[g][c] = s;
+    __syncthreads();
+    if (tid < 64) {
+        const float m = (float)((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / (double)P);
+        sp[tid] = m;
+        pooled[(size_t)b * 64 + tid] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float inv = 1.f / w.s1[0];
+        float z = 0.f;
+        for (int k = 0; k < 64; ++k) z += w.w1[tid * 64 + k] * inv * sp[k];
+        z += w.b1[tid];
+        z = z > 0.f ? z : slope * z;
+        sh1[tid] = z;
+        h1[(size_t)b * 64 + tid] = z;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const float inv = 1.f / w.s2[0];
+        float z = 0.f;
+        for (int k = 0; k < 64; ++k) z += w.w2[tid * 64 + k] * inv * sh1[k];
+        z += w.b2[tid];
+        z = z > 0.f ? z : slope * z;
+        sh2[tid] = z;
+        h2[(size_t)b * 16 + tid] = z;
+    }
+    __syncthreads();
+    if (tid < nout) {
+        const float inv = 1.f / w.s3[0];
+        float z = 0.f;
+        for (int k = 0; k < 16; ++k) z += w.w3[tid * 16 + k] * inv * sh2[k];
+        z += w.b3[tid];
+        score[(size_t)b * nout + tid] = 1.f / (1.f + expf(-z));
+    }
+}
+
+// dscore [B][nout] (gradient wrt the sigmoid outputs) -> dz3, dz2, dz1 (pre-activation gradients) and
+// dpooled; one block (64 threads) per utterance.
+__global__ __launch_bounds__(64) void mlp_bwd_kernel(const float* __restrict__ dscore, const float* __restrict__ score,
+                                                     const float* __restrict__ h1, const float* __restrict__ h2, MlpW w, int nout,
+                                                     float slope, float* __restrict__ dz3, float* __restrict__ dz2,
+                                                     float* __restrict__ dz1, float* __restrict__ dpooled) {
+    __shared__ float s3[4], s2[16], s1[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < nout) {
+        const float sc = score[(size_t)b * nout + tid];
+        const float d = dscore[(size_t)b * nout + tid] * sc * (1.f - sc);
+        s3[tid] = d;
+        dz3[(size_t)b * nout + tid] = d;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const float inv = 1.f / w.s3[0];
+        float d = 0.f;
+        for (int n = 0; n < nout; ++n) d += w.w3[n * 16 + tid] * inv * s3[n];
+        d *= (h2[(size_t)b * 16 + tid] > 0.f ? 1.f : slope);
+        s2[tid] = d;
+        dz2[(size_t)b * 16 + tid] = d;
+    }
+    __syncthreads();
+    {
+        const float inv = 1.f / w.s2[0];
+        float d = 0.f;
+        for (int n = 0; n < 16; ++n) d += w.w2[n * 64 + tid] * inv * s2[n];
+        d *= (h1[(size_t)b * 64 + tid] > 0.f ? 1.f : slope);
+        s1[tid] = d;
+        dz1[(size_t)b * 64 + tid] = d;
+    }
+    __syncthreads();
+    {
+        const float inv = 1.f / w.s1[0];
+        float d = 0.f;
+        for (int n = 0; n < 64; ++n) d += w.w1[n * 64 + tid] * inv * s1[n];
+        dpooled[(size_t)b * 64 + tid] = d;
+    }
+}
+
+// d act[b][pos][c] = dpooled[b][c] / P * lrelu'(act), written into the zero-bordered gradient buffer
+// [B][OH][OW][64] at offset (oh0, ow0).
+__global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, int Hout, int Wout, int OH, int OW,
+                               int oh0, int ow0, float slope, float* __restrict__ gbuf) {
+    const int b = blockIdx.y, P = Hout * Wout;
+    const float invP = 1.f / (float)P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P * 64; i += gridDim.x * blockDim.x) {
+        const int pos = i >> 6, c = i & 63;
+        const int ho = pos / Wout, wo = pos - ho * Wout;
+        const float a = act[(size_t)b * P * 64 + i];
+        const float d = dpooled[(size_t)b * 64 + c] * invP * (a > 0.f ? 1.f : slope);
+        gbuf[(((size_t)b * OH + ho + oh0) * OW + wo + ow0) * 64 + c] = d;
+    }
+}
+
+// dW[n][k] = sum_b dz[b][n] * x[b][k] (sigma-normalised weight gradient; nele_sn_grad maps it to
+// weight_orig), db[n] = sum_b dz[b][n].  One thread per (n,k); batch summed in order.
+__global__ void mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B, int N, int K, float* __restrict__ dW,
+                                 float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * K) {
+        const int n = i / K, k = i - n * K;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz[(size_t)b * N + n] * x[(size_t)b * K + k];
+        dW[i] = s;
+    }
+    if (i < N) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz[(size_t)b * N + i];
+        db[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam (no amsgrad, no weight decay): one fused pass over the flat buffers.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int nele_spectral_norm(const float* W, float* u, float* v, float* sigma, int N, int K, int n_iter, void* stream) {
+    NELE_CHECK_ARG(W && u && v && sigma && N > 0 && N <= 64 && K > 0, "nele_spectral_norm: bad arguments (N must be <= 64)");
+    hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(256), 0, as_stream(stream), W, u, v, sigma, N, K, n_iter);
+    NELE_CHECK_LAUNCH("nele_spectral_norm");
+    return NELE_OK;
+}
+
+extern "C" int nele_sn_grad(const float* dW, const float* W, const float* u, const float* v, const float* sigma, int N, int K,
+                            float* dst, int accumulate, void* stream) {
+    NELE_CHECK_ARG(dW && W && u && v && sigma && dst && N > 0 && K > 0, "nele_sn_grad: bad arguments");
+    hipLaunchKernelGGL(sn_grad_kernel, dim3(1), dim3(256), 0, as_stream(stream), dW, W, u, v, sigma, N, K, dst, accumulate);
+    NELE_CHECK_LAUNCH("nele_sn_grad");
+    return NELE_OK;
+}
+
+// mlp: 9 device pointers {w1,b1,sigma1,w2,b2,sigma2,w3,b3,sigma3}
+extern "C" int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled, float* h1,
+                                float* h2, float* score, void* stream) {
+    NELE_CHECK_ARG(act && mlp_host && pooled && h1 && h2 && score && B > 0 && P > 0 && nout >= 1 && nout <= 4, "nele_gap_mlp_fwd: bad arguments");
+    const float* const* mlp = mlp_host;
+    MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
+    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), act, P, w, nout, slope, pooled, h1, h2, score);
+    NELE_CHECK_LAUNCH("nele_gap_mlp_fwd");
+    return NELE_OK;
+}
+
+extern "C" int nele_gap_mlp_bwd(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                                const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, int OH, int OW, int oh0,
+                                int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream) {
+    NELE_CHECK_ARG(dscore && score && h1 && h2 && mlp_host && dz3 && dz2 && dz1 && dpooled && B > 0, "nele_gap_mlp_bwd: bad arguments");
+    const float* const* mlp = mlp_host;
+    MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(B), dim3(64), 0, s, dscore, score, h1, h2, w, nout, slope, dz3, dz2, dz1, dpooled);
+    NELE_CHECK_LAUNCH("nele_gap_mlp_bwd(mlp)");
+    if (gbuf) {
+        NELE_CHECK_ARG(act, "nele_gap_mlp_bwd: act required for the pooling gradient");
+        const int P = Hout * Wout;
+        hipLaunchKernelGGL(gap_bwd_kernel, dim3(min(512, (P * 64 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout, OH, OW, oh0,
+                           ow0, slope, gbuf);
+        NELE_CHECK_LAUNCH("nele_gap_mlp_bwd(gap)");
+    }
+    return NELE_OK;
+}
+
+extern "C" int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream) {
+    NELE_CHECK_ARG(dz && x && dW && db && B > 0 && N > 0 && K > 0, "nele_mlp_wgrad: bad arguments");
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((N * K + 255) / 256), dim3(256), 0, as_stream(stream), dz, x, B, N, K, dW, db);
+    NELE_CHECK_LAUNCH("nele_mlp_wgrad");
+    return NELE_OK;
+}
+
+extern "C" int nele_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                              int step, void* stream) {
+    NELE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "nele_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long long)2048, (n + 255) / 256)), dim3(256), 0, as_stream(stream), p, g, m, v,
+                       (size_t)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    NELE_CHECK_LAUNCH("nele_adam_step");
+    return NELE_OK;
+}

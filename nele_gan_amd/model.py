@@ -1,0 +1,544 @@
+"""Generator / discriminators of NELE-GAN on the MI355X: the host-side mirror of the reference ``model.py``.
+
+Same class names, ``forward`` signatures, shapes and ``state_dict`` keys as the reference
+(``Generator_Conv1D_cLN.forward(x[B,T,64], y[B,T,64]) -> [B,T,64]`` model.py:83;
+``Discriminator.forward(x[B,3,64,T]) -> [B,3]`` model.py:118; ``Discriminator_Quality`` model.py:152),
+so reference checkpoints ('enhance-model' / 'intel-model', train_nele.py:274-277) load unchanged.
+
+The torch ``nn.Module`` objects only OWN the parameters (torch's Conv1d / Conv2d / Linear /
+spectral_norm containers are used so that keys, shapes and initialisation match by construction; they
+are never called).  Every forward and backward pass runs in libnele_hip.so: implicit-GEMM convolutions
+on the f32 matrix cores (csrc/dense.hip), cLN scan, spectral-norm power iteration, pooling + MLP head
+(csrc/gen.hip, csrc/disc.hip).  ``torch.autograd.Function`` is the glue that lets the reference's loop
+(``loss.backward()``) drive those kernels; parameter gradients are accumulated straight into a flat
+gradient buffer (one bucket per model: what Adam and the RCCL all-reduce operate on).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from ._lib import c_void_p, call, ptr, stream
+from .ops import EPI_BIAS, EPI_BIAS_EXPTANH, EPI_BIAS_LRELU, EPI_MASK_LRELU_GRAD, EPI_NONE, SLOPE, Geom
+
+
+# ------------------------------------------------------------------ parameter containers (reference names)
+class ConvNorm(nn.Module):
+    """model.py:10-28 (parameter container; the convolution itself runs in nele_conv_gemm)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1, bias=True,
+                 w_init_gain='linear'):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1
+            padding = int(dilation * (kernel_size - 1) / 2)
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+        nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+
+class Chomp1d(nn.Module):
+    """model.py:31-40: dropping the right overhang of a conv padded by k-1 == causal left padding."""
+
+    def __init__(self, chomp_size):
+        super().__init__()
+        self.chomp_size = chomp_size
+
+
+class cLN(nn.Module):
+    """model.py:168-205 (parameter container; the scan runs in nele_cln_fwd / nele_cln_bwd)."""
+
+    def __init__(self, dimension, eps=1e-8, trainable=True):
+        super().__init__()
+        self.eps = eps
+        self.gain0 = nn.Parameter(torch.ones(1, dimension, 1), requires_grad=trainable)
+        self.bias0 = nn.Parameter(torch.zeros(1, dimension, 1), requires_grad=trainable)
+
+
+class FlatParams:
+    """All parameters of a module as views into ONE flat buffer (+ one flat gradient buffer)."""
+
+    def __init__(self, module):
+        self.module = module
+        self.flat = None
+        self.grad = None
+
+    def params(self):
+        return [p for p in self.module.parameters()]
+
+    def valid(self, device):
+        if self.flat is None or self.flat.device != device:
+            return False
+        off = 0
+        for p in self.params():
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def ensure(self, device):
+        if self.valid(device):
+            return
+        ps = self.params()
+        n = sum(p.numel() for p in ps)
+        flat = torch.empty(n, dtype=torch.float32, device=device)
+        grad = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1).to(device))
+            if p.grad is not None:
+                grad[off:off + k].copy_(p.grad.reshape(-1).to(device))
+            p.data = flat[off:off + k].view(p.shape)
+            p.grad = grad[off:off + k].view(p.shape)
+            off += k
+        self.flat, self.grad = flat, grad
+
+
+class _Anchor:
+    """A 1-element leaf that requires grad, so autograd calls our backward even when the data
+    inputs do not require grad (G-step: clean/noise features are constants)."""
+
+    def __init__(self):
+        self.t = None
+
+    def get(self, device):
+        if self.t is None or self.t.device != device:
+            self.t = torch.zeros(1, device=device, requires_grad=True)
+        return self.t
+
+
+def _zeros(shape, dev):
+    return torch.zeros(shape, dtype=torch.float32, device=dev)
+
+
+def _empty(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+# ================================================================== Generator
+_G_LAYERS = [(128, 256, 5), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 64, 5)]
+
+
+class _GBuffers:
+    def __init__(self, B, T, dev):
+        self.B, self.T = B, T
+        self.inp = []      # time-padded inputs of each conv [B][T+K-1][Cin]
+        self.Y = []        # raw conv outputs [B][T][Cout]
+        self.mean, self.rstd = [], []
+        for (cin, cout, k) in _G_LAYERS:
+            self.inp.append(_zeros((B, T + k - 1, cin), dev))
+            self.Y.append(_empty((B, T, cout), dev))
+            self.mean.append(_empty((B, T), dev))
+            self.rstd.append(_empty((B, T), dev))
+        self.a5 = _empty((B, T, 64), dev)
+        self.h1 = _empty((B, T, 64), dev)
+        # forward geometries: H=1 conv over the padded time axis
+        self.gf = [Geom(1, T + k - 1, cin, 1, T, 1, k, 1, T, cout) for (cin, cout, k) in _G_LAYERS]
+        self.gfc = Geom(1, T, 64, 1, T, 1, 1, 1, T, 64)
+        # backward buffers
+        self.dY = [_zeros((B, T + k - 1, cout), dev) for (cin, cout, k) in _G_LAYERS]   # END-padded
+        self.dA = [_empty((B, T, cin), dev) for (cin, cout, k) in _G_LAYERS]              # grad wrt conv input (index l: input of layer l)
+        self.da5 = _empty((B, T, 64), dev)
+        self.do2 = _empty((B, T, 64), dev)
+        self.dpre1 = _empty((B, T, 64), dev)
+        self.gpart = _empty((B, 256), dev)
+        self.bpart = _empty((B, 256), dev)
+        # data-gradient geometries: input = END-padded dY_l [B][T+k-1][cout], output = dA_l [B][T][cin]
+        self.gb = [Geom(1, T + k - 1, cout, 1, T, 1, k, 1, T, cin) for (cin, cout, k) in _G_LAYERS]
+        # weight-gradient geometries: A = padded input of layer l, dOut = dY_l (buffer width T+k-1)
+        self.gw = [Geom(1, T + k - 1, cin, 1, T, 1, k, 1, T + k - 1, cout) for (cin, cout, k) in _G_LAYERS]
+        self.gwfc = Geom(1, T, 64, 1, T, 1, 1, 1, T, 64)
+        nws = max([ops.wgrad_workspace_floats(B, cout, g) for (cin, cout, k), g in zip(_G_LAYERS, self.gw)] +
+                  [ops.wgrad_workspace_floats(B, 64, self.gwfc)])
+        self.ws = _empty((nws,), dev)
+
+
+class _GFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, anchor, module):
+        ctx.module = module
+        ctx.key = module._forward_impl(x, y)
+        ctx.mask = module._last_mask
+        return ctx.mask
+
+    @staticmethod
+    def backward(ctx, dmask):
+        ctx.module._backward_impl(dmask.contiguous(), ctx.key, ctx.mask)
+        return None, None, None, None
+
+
+class Generator_Conv1D_cLN(nn.Module):
+    """model.py:43-98."""
+
+    def __init__(self):
+        super().__init__()
+        self.convolutions = nn.ModuleList()
+        self.convolutions.append(nn.Sequential(
+            ConvNorm(64 * 2, 256, kernel_size=5, stride=1, padding=int(5 - 1), dilation=1, w_init_gain='tanh'),
+            Chomp1d(5 - 1), cLN(256)))
+        for _ in range(1, 6 - 1):
+            self.convolutions.append(nn.Sequential(
+                ConvNorm(256, 256, kernel_size=7, stride=1, padding=int(7 - 1), dilation=1, w_init_gain='tanh'),
+                Chomp1d(7 - 1), cLN(256)))
+        self.convolutions.append(nn.Sequential(
+            ConvNorm(256, 64, kernel_size=5, stride=1, padding=int(5 - 1), dilation=1, w_init_gain='linear'),
+            Chomp1d(5 - 1), cLN(64)))
+        self.LReLU = nn.LeakyReLU(0.3)
+        self.fc1 = nn.Linear(64, 64)
+        self.fc2 = nn.Linear(64, 64)
+        self._flat = FlatParams(self)
+        self._anchor = _Anchor()
+        self._bufs = {}
+        self._wf = None
+        self._last_mask = None
+
+    # ---- plumbing
+    def flat_parameters(self, device=None):
+        device = device or next(self.parameters()).device
+        self._flat.ensure(device)
+        return self._flat
+
+    def _weights(self, dev):
+        if self._wf is None or self._wf[0][0].device != dev:
+            wf, wb = [], []
+            for (cin, cout, k) in _G_LAYERS:
+                wf.append(_zeros((cout, k * cin), dev))
+                wb.append(_zeros((cin, k * cout), dev))
+            wf.append(_zeros((64, 64), dev)); wb.append(_zeros((64, 64), dev))   # fc1
+            wf.append(_zeros((64, 64), dev)); wb.append(_zeros((64, 64), dev))   # fc2
+            self._wf = (wf, wb)
+        return self._wf
+
+    def _prep_weights(self, dev):
+        wf, wb = self._weights(dev)
+        for l, (cin, cout, k) in enumerate(_G_LAYERS):
+            w = self.convolutions[l][0].conv.weight
+            ops.weight_prep(w, None, cout, cin, cin, 1, k, wf[l], wb[l])
+        ops.weight_prep(self.fc1.weight, None, 64, 64, 64, 1, 1, wf[6], wb[6])
+        ops.weight_prep(self.fc2.weight, None, 64, 64, 64, 1, 1, wf[7], wb[7])
+        return wf, wb
+
+    def _get_bufs(self, B, T, dev):
+        key = (B, T, str(dev))
+        if key not in self._bufs:
+            self._bufs[key] = _GBuffers(B, T, dev)
+        return key, self._bufs[key]
+
+    # ---- forward (model.py:83-98)
+    def _forward_impl(self, x, y):
+        if x.dim() != 3 or x.shape[2] != 64 or y.shape != x.shape:
+            raise ValueError("Generator_Conv1D_cLN.forward: x and y must both be [B, T, 64]")
+        if not x.is_cuda:
+            raise RuntimeError("nele_gan_amd: the generator runs on the GPU only (no CPU fallback)")
+        dev = x.device
+        self._flat.ensure(dev)
+        B, T, _ = x.shape
+        key, bf = self._get_bufs(B, T, dev)
+        wf, wb = self._prep_weights(dev)
+        call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
+        for l, (cin, cout, k) in enumerate(_G_LAYERS):
+            seq = self.convolutions[l]
+            ops.conv_gemm(bf.inp[l], wf[l], seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l])
+            if l + 1 < len(_G_LAYERS):
+                nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
+            else:
+                nxt, pad = bf.a5, 0
+            call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]), B, T,
+                 cout, pad, SLOPE, stream())
+        ops.conv_gemm(bf.a5, wf[6], self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
+        mask = _empty((B, T, 64), dev)
+        ops.conv_gemm(bf.h1, wf[7], self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
+        self._last_mask = mask
+        return key
+
+    def forward(self, x, y):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _GFn.apply(x, y, self._anchor.get(x.device), self)
+        self._forward_impl(x, y)
+        return self._last_mask
+
+    # ---- backward: accumulates into the flat gradient buffer
+    def _backward_impl(self, dmask, key, mask):
+        bf = self._bufs[key]
+        B, T = bf.B, bf.T
+        wf, wb = self._wf
+        call('nele_exptanh_bwd', ptr(dmask), ptr(mask), ptr(bf.do2), dmask.numel(), stream())
+        # fc2
+        ops.conv_wgrad(bf.h1, bf.do2, bf.ws, B, 64, bf.gwfc, 64, self.fc2.weight.grad, self.fc2.bias.grad)
+        ops.conv_gemm(bf.do2, wb[7], None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc)
+        # fc1
+        ops.conv_wgrad(bf.a5, bf.dpre1, bf.ws, B, 64, bf.gwfc, 64, self.fc1.weight.grad, self.fc1.bias.grad)
+        ops.conv_gemm(bf.dpre1, wb[6], None, None, bf.da5, B, 64, EPI_NONE, bf.gfc)
+        dact = bf.da5
+        for l in range(len(_G_LAYERS) - 1, -1, -1):
+            cin, cout, k = _G_LAYERS[l]
+            seq = self.convolutions[l]
+            call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
+                 ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), B, T, cout, k - 1, SLOPE, stream())
+            call('nele_colsum', ptr(bf.gpart), B, cout, ptr(seq[2].gain0.grad), 1, stream())
+            call('nele_colsum', ptr(bf.bpart), B, cout, ptr(seq[2].bias0.grad), 1, stream())
+            ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad)
+            if l > 0:
+                ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
+                dact = bf.dA[l]
+
+
+# ================================================================== Discriminators
+_D_CONVS = [(8, 1), (16, 3), (32, 5), (48, 7), (64, 9)]   # (Cout, k) ; Cin of layer 0 is 3 (D) or 2 (D_Qua), padded to 4
+
+
+class _DBuffers:
+    def __init__(self, B, T, dev, cin0):
+        self.B, self.T = B, T
+        H, W, C = 64, T, 4
+        self.dims = [(H, W, C)]
+        self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
+        for (cout, k) in _D_CONVS:
+            Ho, Wo = H - k + 1, W - k + 1
+            if Ho < 1 or Wo < 1:
+                raise ValueError("Discriminator: T=%d is too short (needs T >= 21, model.py:105-109)" % T)
+            self.act.append(_empty((B, Ho, Wo, cout), dev))
+            self.gf.append(Geom(H, W, C, Ho, Wo, k, k, Ho, Wo, cout))
+            p = k - 1
+            self.pad.append(p)
+            # zero-bordered gradient buffer of this layer's OUTPUT
+            self.gbuf.append(_zeros((B, Ho + 2 * p, Wo + 2 * p, cout), dev))
+            self.dims.append((Ho, Wo, cout))
+            H, W, C = Ho, Wo, cout
+        self.ddin = _empty((B, 64, T, 4), dev)
+        for l, (cout, k) in enumerate(_D_CONVS):
+            Hi, Wi, Ci = self.dims[l]
+            Ho, Wo, _ = self.dims[l + 1]
+            p = k - 1
+            if l == 0:
+                OH, OW, OC, o0 = Hi, Wi, 4, 0
+            else:
+                pp = self.pad[l - 1]
+                OH, OW, OC, o0 = Hi + 2 * pp, Wi + 2 * pp, Ci, pp
+            # data gradient: input = gbuf[l] (padded), output positions = layer input positions
+            self.gb.append(Geom(Ho + 2 * p, Wo + 2 * p, cout, Hi, Wi, k, k, OH, OW, OC, 0, 0, o0, o0))
+            # weight gradient: A = layer input, dOut = gbuf[l] interior
+            self.gw.append(Geom(Hi, Wi, Ci, Ho, Wo, k, k, Ho + 2 * p, Wo + 2 * p, cout, 0, 0, p, p))
+        self.P = self.dims[-1][0] * self.dims[-1][1]
+        self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
+        self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
+        nws = max(ops.wgrad_workspace_floats(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gw))
+        self.ws = _empty((nws,), dev)
+        self.tmpw = _empty((64 * 48 * 81 + 64,), dev)   # largest weight tensor (sigma-normalised gradient staging)
+
+
+class _DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, din, anchor, module):
+        ctx.module = module
+        ctx.key = module._forward_impl(din)
+        ctx.need_din = din.requires_grad
+        ctx.score = module._last_score
+        return ctx.score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, ctx.score)
+        return ddin, None, None
+
+
+class _NchwToPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.cin = x.shape[1]
+        return ops.nchw_to_nhwc4(x.float())
+
+    @staticmethod
+    def backward(ctx, ddin):
+        return ops.nhwc4_to_nchw(ddin.contiguous(), ctx.cin)
+
+
+class _DiscriminatorBase(nn.Module):
+    def __init__(self, cin, nout):
+        super().__init__()
+        self._cin, self._nout = cin, nout
+        layers = [spectral_norm(nn.Conv2d(cin, 8, (1, 1))),
+                  spectral_norm(nn.Conv2d(8, 16, (3, 3))),
+                  spectral_norm(nn.Conv2d(16, 32, (5, 5))),
+                  spectral_norm(nn.Conv2d(32, 48, (7, 7))),
+                  spectral_norm(nn.Conv2d(48, 64, (9, 9)))]
+        self.layers = nn.ModuleList(layers)
+        self.GAPool = nn.AdaptiveAvgPool2d((1, 1))
+        self.LReLU = nn.LeakyReLU(0.3)
+        self.fc1 = spectral_norm(nn.Linear(64, 64))
+        self.fc2 = spectral_norm(nn.Linear(64, 16))
+        self.fc3 = spectral_norm(nn.Linear(16, nout))
+        self._flat = FlatParams(self)
+        self._anchor = _Anchor()
+        self._bufs = {}
+        self._w = None
+        self._last_score = None
+        self.weight_grad_enabled = True   # reference computes (unused) D weight grads in the G-step too
+
+    def flat_parameters(self, device=None):
+        device = device or next(self.parameters()).device
+        self._flat.ensure(device)
+        return self._flat
+
+    def _sn_modules(self):
+        return list(self.layers) + [self.fc1, self.fc2, self.fc3]
+
+    def _weights(self, dev):
+        if self._w is None or self._w['sigma'].device != dev:
+            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': []}
+            cin = 4
+            for (cout, k) in _D_CONVS:
+                w['wf'].append(_zeros((cout, k * k * cin), dev))
+                w['wb'].append(_zeros((cin, k * k * cout), dev))
+                cin = cout
+            self._w = w
+        return self._w
+
+    def _get_bufs(self, B, T, dev):
+        key = (B, T, str(dev))
+        if key not in self._bufs:
+            self._bufs[key] = _DBuffers(B, T, dev, self._cin)
+        return key, self._bufs[key]
+
+    def _mlp_ptrs(self, w):
+        arr = (c_void_p * 9)()
+        for i, m in enumerate((self.fc1, self.fc2, self.fc3)):
+            arr[3 * i + 0] = m.weight_orig.data_ptr()
+            arr[3 * i + 1] = m.bias.data_ptr()
+            arr[3 * i + 2] = w['sigma'].data_ptr() + 4 * (5 + i)
+        return arr
+
+    def _forward_impl(self, din):
+        if not din.is_cuda:
+            raise RuntimeError("nele_gan_amd: the discriminator runs on the GPU only (no CPU fallback)")
+        dev = din.device
+        self._flat.ensure(dev)
+        B, H, T, C4 = din.shape
+        assert H == 64 and C4 == 4
+        key, bf = self._get_bufs(B, T, dev)
+        w = self._weights(dev)
+        n_iter = 1 if self.training else 0
+        # spectral norm: power iteration (train mode) + sigma for all 8 layers (model.py:105-116)
+        for i, m in enumerate(self._sn_modules()):
+            N = m.weight_orig.shape[0]
+            K = m.weight_orig.numel() // N
+            call('nele_spectral_norm', ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v), c_void_p(w['sigma'].data_ptr() + 4 * i), N, K,
+                 n_iter, stream())
+        cin, cpad = self._cin, 4
+        for l, (cout, k) in enumerate(_D_CONVS):
+            m = self.layers[l]
+            ops.weight_prep(m.weight_orig, w['sigma'][l:l + 1], cout, cin, cpad, k, k, w['wf'][l], w['wb'][l])
+            cin = cpad = cout
+        a = din.contiguous()
+        bf.din = a
+        for l, (cout, k) in enumerate(_D_CONVS):
+            ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l])
+            a = bf.act[l]
+        score = _empty((B, self._nout), dev)
+        call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),
+             stream())
+        self._last_score = score
+        return key
+
+    def forward_packed(self, din):
+        """din: channels-last [B,64,T,4] (ops.d_pack / energy-norm output)."""
+        if torch.is_grad_enabled() and (din.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DFn.apply(din, self._anchor.get(din.device), self)
+        self._forward_impl(din)
+        return self._last_score
+
+    def forward(self, x):
+        """x: [B, Cin, 64, T] as in the reference (model.py:118)."""
+        if x.dim() != 4 or x.shape[1] != self._cin or x.shape[2] != 64:
+            raise ValueError("%s.forward: x must be [B, %d, 64, T]" % (type(self).__name__, self._cin))
+        return self.forward_packed(_NchwToPacked.apply(x))
+
+    def _backward_impl(self, dscore, key, need_din, score):
+        bf = self._bufs[key]
+        B = bf.B
+        w = self._w
+        nout = self._nout
+        wgrad = self.weight_grad_enabled
+        Ho, Wo, _ = bf.dims[-1]
+        p5 = bf.pad[-1]
+        call('nele_gap_mlp_bwd', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]), self._mlp_ptrs(w), nout,
+             SLOPE, B, Ho, Wo, Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1), ptr(bf.dpooled), ptr(bf.gbuf[-1]),
+             stream())
+        if wgrad:
+            for i, (m, dz, xin, N, K) in enumerate(((self.fc3, bf.dz3, bf.h2, nout, 16), (self.fc2, bf.dz2, bf.h1, 16, 64),
+                                                    (self.fc1, bf.dz1, bf.pooled, 64, 64))):
+                li = 7 - i
+                tmpb = bf.tmpw[N * K:N * K + N]
+                call('nele_mlp_wgrad', ptr(dz), ptr(xin), B, N, K, ptr(bf.tmpw), c_void_p(tmpb.data_ptr()), stream())
+                call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
+                     c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, stream())
+                m.bias.grad.add_(tmpb)
+        ddin = None
+        for l in range(len(_D_CONVS) - 1, -1, -1):
+            cout, k = _D_CONVS[l]
+            m = self.layers[l]
+            Hi, Wi, Ci = bf.dims[l]
+            cin_valid = self._cin if l == 0 else Ci
+            a_in = bf.din if l == 0 else bf.act[l - 1]
+            if wgrad:
+                N, K = cout, cin_valid * k * k
+                tmpb = bf.tmpw[N * K:N * K + N]
+                ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False)
+                call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
+                     c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, stream())
+                m.bias.grad.add_(tmpb)
+            if l > 0:
+                ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l])
+            elif need_din:
+                ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
+                ddin = bf.ddin
+        return ddin
+
+
+class Discriminator(_DiscriminatorBase):
+    """model.py:101-132: input channels (enhanced, noise, clean); outputs (SIIB, HASPI, ESTOI) scores.
+    ``nout`` is configurable (build-side feature) for metric subsets, e.g. 2 for SIIB+ESTOI."""
+
+    def __init__(self, nout=3):
+        super().__init__(3, nout)
+
+
+class Discriminator_Quality(_DiscriminatorBase):
+    """model.py:135-166: input channels (enhanced, clean); outputs (PESQ, ViSQOL) scores."""
+
+    def __init__(self, nout=2):
+        super().__init__(2, nout)
+
+
+# ================================================================== energy normalisation glue (train_nele.py:133-146)
+class _EnergyNormPack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, clean, noise, p, inv_p):
+        beta2, s2, din, _ = ops.energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True)
+        ctx.save_for_backward(mask, clean, beta2, s2)
+        ctx.p, ctx.inv_p = p, inv_p
+        ctx.mark_non_differentiable(beta2)
+        return din, beta2
+
+    @staticmethod
+    def backward(ctx, ddin, dbeta2):
+        mask, clean, beta2, s2 = ctx.saved_tensors
+        dmask = ops.energy_norm_bwd(clean, mask, beta2, s2, ddin.contiguous(), ctx.p, ctx.inv_p)
+        return dmask, None, None, None, None
+
+
+def energy_norm_pack(mask, clean_band, noise_band, p_power=1.0 / 6, inv_p=6.0):
+    """mask, clean_band, noise_band [B,T,64] -> (D input [B,64,T,4] = (enh, noise, clean, 0), beta2 [B]).
+    Utterance-level (per sample) normalisation, as the batch-1 reference (train_nele.py:133-146)."""
+    return _EnergyNormPack.apply(mask.contiguous(), clean_band.contiguous(), noise_band.contiguous(), float(p_power), float(inv_p))
+
+
+def normed_alpha2(mask, clean_band, inv_p=6.0):
+    """mask * beta_2 (train_nele.py:303-307; inference.py:99-104), no autograd."""
+    _, _, _, alpha2 = ops.energy_norm_fwd(clean_band.contiguous(), mask.contiguous(), None, 1.0 / inv_p, float(inv_p), want_din=False,
+                                          want_alpha2=True)
+    return alpha2

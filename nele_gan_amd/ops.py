@@ -1,0 +1,117 @@
+"""Thin Python wrappers over the dense / glue entry points of libnele_hip.so (no arithmetic here)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import c_float, c_int, c_longlong, c_void_p, call, declare, ptr, stream
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MASK_LRELU_GRAD, EPI_BIAS_EXPTANH = 0, 1, 2, 3, 4
+SLOPE = 0.3  # nn.LeakyReLU(0.3), model.py:79,112
+
+_P = c_void_p
+_SIGS = {
+    'nele_conv_gemm': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), _P],
+    'nele_conv_wgrad': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
+    'nele_weight_prep': [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
+    'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_colsum': [_P, c_int, c_int, _P, c_int, _P],
+    'nele_exptanh_bwd': [_P, _P, _P, c_longlong, _P],
+    'nele_energy_norm_fwd': [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, _P],
+    'nele_energy_norm_bwd': [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, c_int, _P],
+    'nele_d_pack': [_P, _P, _P, _P, c_int, c_int, _P],
+    'nele_d_layout': [_P, _P, c_int, c_int, c_int, c_int, _P],
+    'nele_spectral_norm': [_P, _P, _P, _P, c_int, c_int, c_int, _P],
+    'nele_sn_grad': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P],
+    'nele_gap_mlp_fwd': [_P, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_bwd': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_int, _P, _P, _P, _P, _P, _P],
+    'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
+    'nele_adam_step': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P],
+}
+for _n, _a in _SIGS.items():
+    declare(_n, _a)
+    _lib._SIGS[_n] = _a
+_lib.lib.nele_conv_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int)]
+_lib.lib.nele_conv_wgrad_workspace_floats.restype = c_longlong
+_lib._SIGS['nele_conv_wgrad_workspace_floats'] = _lib.lib.nele_conv_wgrad_workspace_floats.argtypes
+
+
+class Geom:
+    """ConvGeom of csrc/dense.hip: how output position (b,ho,wo) maps into the channels-last input
+    buffer [B][H][W][C] and the output buffer [B][OH][OW][OC]."""
+
+    def __init__(self, H, W, C, Hout, Wout, KH, KW, OH, OW, OC, ih0=0, iw0=0, oh0=0, ow0=0):
+        self.KH, self.KW = KH, KW
+        self.Hout, self.Wout = Hout, Wout
+        self.Ktot = KH * KW * C
+        vals = [H, W, C, ih0, iw0, Hout, Wout, KW * C, W * C, self.Ktot, OH, OW, OC, oh0, ow0]
+        self.arr = (c_int * 15)(*vals)
+
+
+def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g):
+    M = B * g.Hout * g.Wout
+    call('nele_conv_gemm', ptr(A), ptr(Wg), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, stream())
+
+
+def wgrad_workspace_floats(B, N, g):
+    M = B * g.Hout * g.Wout
+    return int(_lib.lib.nele_conv_wgrad_workspace_floats(M, N, g.Ktot, None))
+
+
+def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True):
+    M = B * g.Hout * g.Wout
+    call('nele_conv_wgrad', ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db),
+         int(accumulate), stream())
+
+
+def weight_prep(Wt, sigma, N, Cvalid, C, KH, KW, Wf, Wb):
+    call('nele_weight_prep', ptr(Wt), ptr(sigma), N, Cvalid, C, KH, KW, ptr(Wf), ptr(Wb), stream())
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    call('nele_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream())
+
+
+def energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True, want_alpha2=False):
+    B, T, _ = clean.shape
+    dev = clean.device
+    beta2 = torch.empty(B, device=dev)
+    s2 = torch.empty(B, device=dev)
+    din = torch.empty((B, 64, T, 4), device=dev) if want_din else None
+    alpha2 = torch.empty((B, T, 64), device=dev) if want_alpha2 else None
+    call('nele_energy_norm_fwd', ptr(clean), ptr(mask), ptr(noise), p, inv_p, ptr(beta2), ptr(s2), ptr(din), ptr(alpha2), B, T, stream())
+    return beta2, s2, din, alpha2
+
+
+def energy_norm_bwd(clean, mask, beta2, s2, ddin, p, inv_p):
+    B, T, _ = clean.shape
+    dmask = torch.empty_like(mask)
+    call('nele_energy_norm_bwd', ptr(clean), ptr(mask), ptr(beta2), ptr(s2), ptr(ddin), p, inv_p, ptr(dmask), B, T, stream())
+    return dmask
+
+
+def d_pack(c0, c1, c2=None):
+    """three (two) band-feature tensors [B,T,64] -> channels-last D input [B,64,T,4] (dataloader.py:76-84)."""
+    B, T, _ = c0.shape
+    din = torch.empty((B, 64, T, 4), device=c0.device)
+    call('nele_d_pack', ptr(c0.contiguous()), ptr(c1.contiguous()), ptr(c2.contiguous() if c2 is not None else None), ptr(din), B, T,
+         stream())
+    return din
+
+
+def nchw_to_nhwc4(x):
+    B, Cin, H, T = x.shape
+    assert H == 64
+    din = torch.empty((B, 64, T, 4), device=x.device)
+    call('nele_d_layout', ptr(x.contiguous()), ptr(din), B, Cin, T, 1, stream())
+    return din
+
+
+def nhwc4_to_nchw(ddin, Cin):
+    B, H, T, _ = ddin.shape
+    dx = torch.empty((B, Cin, 64, T), device=ddin.device)
+    call('nele_d_layout', ptr(ddin), ptr(dx), B, Cin, T, 0, stream())
+    return dx

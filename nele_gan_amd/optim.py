@@ -1,0 +1,40 @@
+"""torch.optim.Adam semantics (train_nele.py:89-91) as ONE fused HIP pass over a model's flat
+parameter / gradient buffers (csrc/disc.hip: adam_kernel)."""
+import torch
+
+from . import ops
+
+
+class Adam:
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not hasattr(module, 'flat_parameters'):
+            raise TypeError("nele_gan_amd.optim.Adam takes a nele_gan_amd.model module (flat parameter buffer)")
+        self.module = module
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        self.m = None
+        self.v = None
+
+    def _state(self):
+        fp = self.module.flat_parameters()
+        if self.m is None or self.m.device != fp.flat.device or self.m.numel() != fp.flat.numel():
+            self.m = torch.zeros_like(fp.flat)
+            self.v = torch.zeros_like(fp.flat)
+        return fp
+
+    def zero_grad(self):
+        self._state().grad.zero_()
+
+    def step(self):
+        fp = self._state()
+        self.step_count += 1
+        ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.m, 'exp_avg_sq': self.v, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        self._state()
+        self.step_count = int(sd['step'])
+        self.m.copy_(sd['exp_avg'])
+        self.v.copy_(sd['exp_avg_sq'])

@@ -1,0 +1,216 @@
+"""GPU: generator / discriminator HIP paths against the reference goldens and the torch-fp32 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+from weights_recipe import digest, seeded_state_arrays  # noqa: E402
+
+M = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'model.npz'))
+
+
+def load_recipe(module, seed):
+    sd = module.state_dict()
+    arrs = seeded_state_arrays([(k, tuple(v.shape)) for k, v in sd.items()], seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in arrs.items()})
+    return module.cuda()
+
+
+def check_grad(prefix, name, g, rtol=3e-4):
+    g = g.detach().cpu().numpy()
+    if prefix + name in M:
+        ref = M[prefix + name]
+        np.testing.assert_allclose(g, ref, rtol=rtol, atol=2e-5 * np.abs(ref).max())
+    else:
+        s, a, smp = digest(g)
+        ra = float(M[prefix + name + '#abs'])
+        assert s == pytest.approx(float(M[prefix + name + '#sum']), rel=1e-3, abs=2e-5 * ra)
+        assert a == pytest.approx(ra, rel=2e-4)
+        ref = M[prefix + name + '#smp']
+        np.testing.assert_allclose(smp, ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.fixture(scope='module')
+def mods():
+    assert torch.cuda.is_available()
+    from nele_gan_amd import model
+    return model
+
+
+def test_generator_matches_reference_golden(mods):
+    G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+    x = torch.from_numpy(M['x']).cuda()
+    y = torch.from_numpy(M['y']).cuda()
+    mask = G(x, y)
+    assert mask.shape == (2, 40, 64)
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), M['g_mask'], rtol=1e-4)   # f32 MFMA, reordered sums
+    G.flat_parameters().grad.zero_()
+    (mask * torch.from_numpy(M['g_gw']).cuda()).sum().backward()
+    for k, p in G.named_parameters():
+        check_grad('g_grad.', k, p.grad)
+
+
+def test_generator_eval_no_grad_path(mods):
+    G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+    G.eval()
+    with torch.no_grad():
+        mask = G(torch.from_numpy(M['x']).cuda(), torch.from_numpy(M['y']).cuda())
+    assert not mask.requires_grad
+    np.testing.assert_allclose(mask.cpu().numpy(), M['g_mask'], rtol=1e-4)
+
+
+def test_discriminator_eval_matches_reference_golden(mods):
+    D = load_recipe(mods.Discriminator(), 202)
+    D.eval()
+    x = torch.from_numpy(M['d_in']).cuda().requires_grad_(True)
+    sc = D(x)
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), M['d_eval_score'], rtol=2e-5)
+    loss = torch.nn.functional.mse_loss(sc, torch.from_numpy(M['d_tgt']).cuda())
+    assert loss.item() == pytest.approx(float(M['d_eval_loss']), rel=2e-5)
+    D.flat_parameters().grad.zero_()
+    loss.backward()
+    ref = M['d_eval_din_grad']
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max())
+    for k, p in D.named_parameters():
+        check_grad('d_eval_grad.', k, p.grad, rtol=2e-3)
+
+
+def test_discriminator_train_power_iteration(mods):
+    D = load_recipe(mods.Discriminator(), 202)
+    D.train()
+    x = torch.from_numpy(M['d_in']).cuda().requires_grad_(True)
+    sc = D(x)
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), M['d_train_score'], rtol=2e-5)
+    loss = torch.nn.functional.mse_loss(sc, torch.from_numpy(M['d_tgt']).cuda())
+    D.flat_parameters().grad.zero_()
+    loss.backward()
+    for k, v in D.state_dict().items():
+        if k.endswith('_u') or k.endswith('_v'):
+            np.testing.assert_allclose(v.cpu().numpy(), M['d_train_buf.' + k], rtol=2e-5, atol=1e-7)
+    for k, p in D.named_parameters():
+        check_grad('d_train_grad.', k, p.grad, rtol=2e-3)
+    ref = M['d_train_din_grad']
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max())
+
+
+def test_discriminator_quality_eval(mods):
+    Q = load_recipe(mods.Discriminator_Quality(), 303)
+    Q.eval()
+    with torch.no_grad():
+        sc = Q(torch.from_numpy(M['d_in'][:, [0, 2]].copy()).cuda())
+    np.testing.assert_allclose(sc.cpu().numpy(), M['dq_eval_score'], rtol=2e-5)
+
+
+def test_gstep_glue_matches_reference_golden(mods):
+    # train_nele.py:130-155 with the HIP energy-norm + pack kernel in place of the torch ops
+    G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+    D = load_recipe(mods.Discriminator(), 202)
+    Q = load_recipe(mods.Discriminator_Quality(), 303)
+    cb = torch.from_numpy(M['x'][:1]).cuda()
+    nb = torch.from_numpy(M['y'][:1]).cuda()
+    G.flat_parameters().grad.zero_()
+    mask = G(cb, nb)
+    din, beta2 = mods.energy_norm_pack(mask, cb, nb)
+    assert beta2.item() == pytest.approx(float(M['gstep_beta2']), rel=1e-4)
+    d_in_ref = M['gstep_d_inputs']                                     # [1,3,64,T]
+    got = din.detach().cpu().numpy()[0]                                # [64,T,4]
+    np.testing.assert_allclose(np.transpose(got[:, :, :3], (2, 0, 1)), d_in_ref[0], rtol=1e-4)
+    assert np.all(got[:, :, 3] == 0)
+    score = D.forward_packed(din)
+    # D_Qua input (enh, clean): channels 0 and 2 of the packed tensor
+    din_q = torch.zeros_like(din)
+    din_q[..., 0] = din[..., 0]
+    din_q[..., 1] = din[..., 2]
+    score_q = Q.forward_packed(din_q)
+    np.testing.assert_allclose(score.detach().cpu().numpy(), M['gstep_score'], rtol=1e-4)
+    np.testing.assert_allclose(score_q.detach().cpu().numpy(), M['gstep_score_q'], rtol=1e-4)
+    mse = torch.nn.MSELoss()
+    loss = mse(score, torch.ones(1, 3).cuda()) + 0.5 * mse(score_q, torch.ones(1, 2).cuda())
+    assert loss.item() == pytest.approx(float(M['gstep_loss']), rel=1e-4)
+    loss.backward()
+    ref = M['gstep_grad_fc2_w']
+    np.testing.assert_allclose(G.fc2.weight.grad.cpu().numpy(), ref, rtol=5e-3, atol=5e-5 * np.abs(ref).max())
+    ref = M['gstep_grad_c5_b']
+    np.testing.assert_allclose(G.convolutions[5][0].conv.bias.grad.cpu().numpy(), ref, rtol=5e-3, atol=5e-5 * np.abs(ref).max())
+    g0 = G.convolutions[0][0].conv.weight.grad.double()
+    assert g0.abs().sum().item() == pytest.approx(float(M['gstep_grad_c0_w_abs']), rel=2e-3)
+
+
+@pytest.mark.parametrize('B,T', [(3, 57), (1, 132)])
+def test_models_vs_oracle_other_shapes(mods, B, T):
+    from oracle import nets
+    rs = np.random.RandomState(B * 100 + T)
+    G = load_recipe(mods.Generator_Conv1D_cLN(), 7)
+    D = load_recipe(mods.Discriminator(nout=2), 8)
+    x = (0.1 + 0.4 * rs.rand(B, T, 64)).astype(np.float32)
+    y = (0.1 + 0.4 * rs.rand(B, T, 64)).astype(np.float32)
+    tgt = rs.rand(B, 2).astype(np.float32)
+    # oracle
+    sdg = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    sdd = {k: v.detach().cpu().clone().requires_grad_(not (k.endswith('_u') or k.endswith('_v'))) for k, v in D.state_dict().items()}
+    xo, yo = torch.from_numpy(x), torch.from_numpy(y)
+    mo = nets.generator_forward(sdg, xo, yo)
+    eo, b2o = nets.energy_norm(mo, xo)
+    so, nbufs = nets.discriminator_forward(sdd, nets.d_inputs(eo, yo, xo), train=True)
+    lo = torch.nn.functional.mse_loss(so, torch.from_numpy(tgt))
+    lo.backward()
+    # HIP
+    D.train()
+    G.flat_parameters().grad.zero_()
+    D.flat_parameters().grad.zero_()
+    xc, yc = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m = G(xc, yc)
+    np.testing.assert_allclose(m.detach().cpu().numpy(), mo.detach().numpy(), rtol=2e-4)
+    din, b2 = mods.energy_norm_pack(m, xc, yc)
+    np.testing.assert_allclose(b2.cpu().numpy(), b2o.detach().numpy(), rtol=1e-4)
+    s = D.forward_packed(din)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), so.detach().numpy(), rtol=1e-4)
+    loss = torch.nn.functional.mse_loss(s, torch.from_numpy(tgt).cuda())
+    loss.backward()
+    for k, p in G.named_parameters():
+        ref = sdg[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=1e-4 * np.abs(ref).max(), err_msg='G ' + k)
+    for k, p in D.named_parameters():
+        ref = sdd[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=1e-4 * np.abs(ref).max(), err_msg='D ' + k)
+
+
+def test_frozen_discriminator_skips_weight_grads(mods):
+    D = load_recipe(mods.Discriminator(), 202)
+    D.weight_grad_enabled = False
+    x = torch.from_numpy(M['d_in']).cuda().requires_grad_(True)
+    D.flat_parameters().grad.zero_()
+    D(x).sum().backward()
+    assert float(D.flat_parameters().grad.abs().sum()) == 0.0
+    assert float(x.grad.abs().sum()) > 0.0
+
+
+def test_adam_matches_torch_formula(mods):
+    from nele_gan_amd.optim import Adam
+    from oracle.nets import adam_reference
+    G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+    opt = Adam(G, lr=5e-4)
+    fp = G.flat_parameters()
+    rs = np.random.RandomState(0)
+    p = fp.flat.cpu().numpy().copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for step in (1, 2, 3):
+        g = (rs.randn(p.size) * 1e-2).astype(np.float32)
+        fp.grad.copy_(torch.from_numpy(g))
+        opt.step()
+        p, m, v = adam_reference(p, g, m, v, 5e-4, step)
+        np.testing.assert_allclose(fp.flat.cpu().numpy(), p, rtol=1e-6, atol=1e-7)
+    opt.zero_grad()
+    assert float(fp.grad.abs().sum()) == 0.0
+    # parameters are views of the flat buffer: the module sees the update
+    assert G.fc2.weight.data_ptr() >= fp.flat.data_ptr()
+
+
+def test_discriminator_rejects_short_inputs(mods):
+    D = mods.Discriminator().cuda()
+    with pytest.raises(ValueError):
+        D(torch.zeros(1, 3, 64, 20).cuda())
