@@ -1,0 +1,85 @@
+"""Batched objective metrics on the GPU: host-side mirror of the reference ``intel.py`` wrappers and
+the ``read_batch_*`` fan-out of ``audio_util.py:120-203`` (there: 32 joblib processes over wav files;
+here: one batched launch over utterances resident in HBM).
+
+    ESTOI_Wrapper[_raw]_harvard(x, y, fs)   intel.py:122-134
+    SIIB_Wrapper[_raw]_harvard(x, y, fs)    intel.py:57-100
+    HASPI_Wrapper[_raw]_harvard(x, y, fs)   intel.py:108-114
+    batch_estoi / batch_siib / batch_haspi (clean[B,L], degraded[B,L]) -> (raw[B], mapped[B])
+
+x is the clean reference, y the degraded signal (enhanced + noise, audio_util.py:139-141).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_int, c_longlong, c_void_p, call, declare, ptr, stream
+
+_P = c_void_p
+declare('nele_metric_estoi', [_P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P])
+_lib._SIGS['nele_metric_estoi'] = _lib.lib.nele_metric_estoi.argtypes
+_lib.lib.nele_metric_estoi_workspace_bytes.argtypes = [c_int, c_int]
+_lib.lib.nele_metric_estoi_workspace_bytes.restype = c_longlong
+_lib._SIGS['nele_metric_estoi_workspace_bytes'] = _lib.lib.nele_metric_estoi_workspace_bytes.argtypes
+
+_ws_cache = {}
+
+
+def _workspace(kind, nbytes, dev):
+    key = (kind, str(dev))
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = t
+    return t
+
+
+def _pair(x, y):
+    def dev(a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        if not a.is_cuda:
+            a = a.cuda()
+        return a.float()
+    x, y = dev(x), dev(y)
+    single = x.dim() == 1
+    if single:
+        x, y = x.unsqueeze(0), y.unsqueeze(0)
+    L = min(x.shape[1], y.shape[1])                    # intel.py:58-60 (minL truncation)
+    return x[:, :L].contiguous(), y[:, :L].contiguous(), single
+
+
+def batch_estoi(x, y):
+    """clean x [B,L], degraded y [B,L] (16 kHz) -> (raw [B], mapped [B]) float32 device tensors."""
+    x, y, _ = _pair(x, y)
+    B, L = x.shape
+    nb = _lib.lib.nele_metric_estoi_workspace_bytes(B, L)
+    ws = _workspace('estoi', nb, x.device)
+    raw = torch.empty(B, device=x.device)
+    mapped = torch.empty(B, device=x.device)
+    call('nele_metric_estoi', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), stream())
+    return raw, mapped
+
+
+def ESTOI_Wrapper_raw_harvard(x, y, fs):
+    assert fs == 16000
+    return float(batch_estoi(x, y)[0][0])
+
+
+def ESTOI_Wrapper_harvard(x, y, fs):
+    assert fs == 16000
+    return float(batch_estoi(x, y)[1][0])
+
+
+def mapping_ESTOI_harvard(x):
+    return 1 / (1 + np.exp(-8.0 * (x - 0.25)))
+
+
+def mapping_SIIB_harvard(x):
+    return 1 / (1 + np.exp(-0.06 * (x - 32)))
+
+
+def mapping_HASPI_harvard(x):
+    return 1 / (1 + np.exp(-0.95 * (x - 2.8)))

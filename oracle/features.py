@@ -29,8 +29,8 @@ N_BINS = 257
 
 def hann_periodic(n=N_FFT):
     """scipy.signal.get_window('hann', n, fftbins=True), float64."""
-    k = np.arange(n, dtype=np.float64)
-    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+    from scipy.signal import get_window
+    return get_window('hann', n, fftbins=True)
 
 
 def n_frames(L):

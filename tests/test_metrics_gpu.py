@@ -1,0 +1,55 @@
+"""GPU: batched metric kernels (through the C ABI) against the oracle."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+HERE = os.path.dirname(__file__)
+
+
+def toy(name):
+    w = wave.open(os.path.join(HERE, 'golden', 'toy', name))
+    return np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
+
+
+@pytest.fixture(scope='module')
+def mt():
+    assert torch.cuda.is_available()
+    from nele_gan_amd import metrics
+    return metrics
+
+
+def test_estoi_toy_file_vs_oracle(mt):
+    from oracle import estoi
+    x, v = toy('Train_Clean.wav'), toy('Train_Noise.wav')
+    ys = np.stack([x + v, x + np.float32(0.25) * v, x, np.float32(3.0) * (x + v)])
+    xs = np.stack([x] * 4)
+    raw, mapped = mt.batch_estoi(xs, ys)
+    raw, mapped = raw.cpu().numpy(), mapped.cpu().numpy()
+    for b in range(4):
+        ref = estoi.estoi(xs[b], ys[b])
+        assert raw[b] == pytest.approx(ref, rel=1e-4, abs=1e-6)
+        assert mapped[b] == pytest.approx(1 / (1 + np.exp(-8 * (ref - 0.25))), rel=1e-4)
+    assert raw[2] == pytest.approx(1.0, abs=1e-6)
+    assert mt.ESTOI_Wrapper_raw_harvard(x, x + v, 16000) == pytest.approx(float(raw[0]), rel=1e-6)
+
+
+@pytest.mark.parametrize('L', [64000, 20001])
+def test_estoi_synthetic_batch_vs_oracle(mt, L):
+    from nele_gan_amd import synth
+    from oracle import estoi
+    c, v = synth.batch(4, L, start=40)
+    y = c + v
+    raw, _ = mt.batch_estoi(c, y)
+    raw = raw.cpu().numpy()
+    for b in range(4):
+        assert raw[b] == pytest.approx(estoi.estoi(c[b], y[b]), rel=1e-4, abs=1e-6)
+
+
+def test_estoi_too_short_returns_pystoi_constant(mt):
+    x = toy('Train_Clean.wav')[:3000]
+    raw, _ = mt.batch_estoi(x, x)
+    assert float(raw[0]) == pytest.approx(1e-5, rel=1e-6)
