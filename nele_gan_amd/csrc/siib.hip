@@ -1,0 +1,468 @@
+// Batched SIIB^Gauss (reference intel.py:57-106: wrapper VAD + replication rule are the reference's own
+// code; the SIIB core is pysiib's, restated in oracle/siib.py -- PARITY UNPINNED vs pysiib itself).
+//
+// Per utterance (x clean, y degraded, [L] float32 @16 kHz), float64 arithmetic:
+//   s1  VAD on x (intel.py:37-50), active duration -> replication factor M (intel.py:93-97)
+//   s2  VAD on the M-times tiled x (frames index the signal modulo L: nothing is materialised),
+//       k-th order statistic with duplicates, ordered compaction of the active frames
+//   s3  per active frame: Hann(400) window, 400-point DFT of x and y (201 bins), squared gammatone
+//       weights (28 bands), log
+//   s4  per band: minimum, forward temporal masking (serial over frames), mean removal
+//   s5  stack K = 15 frames (420 rows), remove the row means
+//   s6  Cxx = Xs Xs^T / (n-1)                      (tiled float64 GEMM)
+//   s7  eigenvectors of Cxx                        (rocSOLVER dsyevd, strided batched: STOP-GAP)
+//   s8  Xp = U^T Xs, Yp = U^T Ys fused with the per-component sums of Xp^2, Yp^2, Xp Yp
+//   s9  rho, I = -1/2 log2(1 - rho_p^2 rho^2), SIIB = R/K sum I, logistic map
+#include "common.h"
+#include <rocsolver/rocsolver.h>
+
+#define SB_WLEN 400
+#define SB_SHIFT 200
+#define SB_NBIN 201
+#define SB_J 28
+#define SB_K 15
+#define SB_D (SB_J * SB_K)   // 420
+#define SB_TF 16
+#define SB_EPS 2.220446049250313e-16
+#define SB_MMAX 40
+
+struct SiibWs {
+    double* g2;      // [28][201] squared gammatone magnitude responses
+    double* xdb;     // [B][NT]   frame power (dB) of the tiled clean signal
+    int* list;       // [B][NA]   active frame indices (tiled frame numbering)
+    int* info;       // [B][4]    {M, n_tiled_frames, n_active, status}
+    double* XL;      // [B][2][28][NA] log band energies of the active frames (x then y)
+    double* Xs;      // [B][2][420][NA] stacked, mean-removed (zero padded to NA columns)
+    double* C;       // [B][420][420] covariance -> eigenvectors (row j = eigenvector j)
+    double* lam;     // [B][420]
+    double* E;       // [B][420] rocSOLVER scratch
+    double* part;    // [B][420][NTL][3]
+    int NT, NA, NTL;
+};
+
+__device__ __forceinline__ double hann400(int n) { return 0.5 - 0.5 * cospi((double)n / 200.0); }
+
+// ---------------------------------------------------------------- gammatone matrix (oracle/siib.py gammatone_matrix)
+__global__ void siib_g2_kernel(double* __restrict__ g2) {
+    __shared__ double red[8];
+    const int j = blockIdx.x, q = threadIdx.x;  // 256 threads >= 201
+    const double e0 = 21.4 * log10(4.37 * (100.0 / 1000.0) + 1.0), e1 = 21.4 * log10(4.37 * (6500.0 / 1000.0) + 1.0);
+    const double cf_erb = e0 + (e1 - e0) * (double)j / (double)(SB_J - 1);
+    const double cf = (pow(10.0, cf_erb / 21.4) - 1.0) / 4.37 * 1000.0;
+    const double a = 36.0 / (M_PI * 720.0 * 0.015625);  // (3!)^2 / (pi * 6! * 2^-6)
+    const double bw = a * 24.7 * (4.37 * cf / 1000.0 + 1.0);
+    double t = 0.0;
+    if (q < SB_NBIN) {
+        const double f = 16000.0 * (double)q / 400.0;
+        const double d = bw * bw + (f - cf) * (f - cf);
+        t = 1.0 / (d * d);  // order/2 = 2
+    }
+    const double mx = block_max(t, red);
+    if (q < SB_NBIN) {
+        const double g = t / mx;
+        g2[j * SB_NBIN + q] = g * g;
+    }
+}
+
+// frame f of the tiled signal: samples x[(200 f + j) mod L], j < 400 (zero beyond M*L: intel.py:28-31 pads)
+__device__ __forceinline__ double frame_db(const float* __restrict__ x, int L, long long total, int f, int lane) {
+    double s = 0.0;
+    for (int j = lane; j < SB_WLEN; j += 64) {
+        const long long p = (long long)SB_SHIFT * f + j;
+        const double v = (p < total) ? (double)x[p % L] * hann400(j) : 0.0;
+        s += v * v;
+    }
+    s = wave_sum(s);
+    return 10.0 * log10(s / (double)SB_WLEN + SB_EPS);
+}
+
+__device__ __forceinline__ int nframes_of(long long total) {
+    if (total < SB_WLEN + 1) total = SB_WLEN + 1;
+    return (int)((total - SB_WLEN + SB_SHIFT - 1) / SB_SHIFT);
+}
+
+__device__ __forceinline__ int round_half_even_pos(double v) { return (int)rint(v); }
+
+// Threshold of intel.get_vad: the value at sorted position ind = round(n*0.999)-1 (ascending).
+// r = n-1-ind values are strictly above it in sorted order; walk down from the maximum counting duplicates.
+__device__ double kth_largest(const double* __restrict__ v, int n, int r, double* red, int* ired) {
+    double cur = 1e300;
+    int remaining = r;
+    for (int it = 0; it <= r; ++it) {
+        double m = -1e300;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double a = v[i];
+            if (a < cur) m = fmax(m, a);
+        }
+        m = block_max(m, red);
+        int cnt = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) cnt += (v[i] == m) ? 1 : 0;
+        // integer block sum through the double scratch (exact for these counts)
+        const double c = block_sum((double)cnt, red);
+        const int ci = (int)c;
+        if (remaining < ci) return m;
+        remaining -= ci;
+        cur = m;
+    }
+    return cur;
+}
+
+// one block per utterance: s1 + s2
+__global__ __launch_bounds__(256) void siib_vad_kernel(const float* __restrict__ x, int L, SiibWs ws) {
+    __shared__ double red[8];
+    __shared__ int scan[256];
+    __shared__ int base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (size_t)b * L;
+    double* xdb = ws.xdb + (size_t)b * ws.NT;
+    int* info = ws.info + 4 * b;
+    // ---- s1: base signal
+    const int n1 = nframes_of(L);
+    for (int f = wave; f < n1; f += 4) {
+        const double e = frame_db(xb, L, L, f, lane);
+        if (lane == 0) xdb[f] = e;
+    }
+    __syncthreads();
+    int ind = round_half_even_pos((double)n1 * 0.999) - 1;
+    double thr = kth_largest(xdb, n1, n1 - 1 - ind, red, nullptr) - 40.0;
+    int cnt = 0;
+    for (int f = tid; f < n1; f += 256) cnt += (xdb[f] > thr) ? 1 : 0;
+    const int nact1 = (int)block_sum((double)cnt, red);
+    int M = 1;
+    const double dur = (double)nact1 / 80.0;
+    if (dur < 20.0) M = (int)floor(25.0 / dur);
+    int status = 0;
+    if (M > SB_MMAX) { M = SB_MMAX; status = 1; }
+    // ---- s2: tiled signal
+    const long long total = (long long)M * L;
+    const int n2 = nframes_of(total);
+    if (n2 > ws.NT) {  // cannot happen with M <= SB_MMAX and NT sized for it
+        if (tid == 0) { info[0] = M; info[1] = n2; info[2] = 0; info[3] = 2; }
+        return;
+    }
+    __syncthreads();
+    if (M > 1) {
+        for (int f = wave; f < n2; f += 4) {
+            const double e = frame_db(xb, L, total, f, lane);
+            if (lane == 0) xdb[f] = e;
+        }
+        __syncthreads();
+        ind = round_half_even_pos((double)n2 * 0.999) - 1;
+        thr = kth_largest(xdb, n2, n2 - 1 - ind, red, nullptr) - 40.0;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < n2; f0 += 256) {
+        const int f = f0 + tid;
+        const int k = (f < n2 && xdb[f] > thr) ? 1 : 0;
+        scan[tid] = k;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = (tid >= o) ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int pos = base + scan[tid] - 1;
+        if (k && pos < ws.NA) ws.list[(size_t)b * ws.NA + pos] = f;
+        __syncthreads();
+        if (tid == 255) base += scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int na = base;
+        if (na > ws.NA) { na = ws.NA; status |= 4; }
+        if (na < SB_K + 1) status |= 8;  // not enough active frames
+        info[0] = M; info[1] = n2; info[2] = na; info[3] = status;
+    }
+}
+
+// grid (NA, B), block 256: s3
+__global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws) {
+    __shared__ double sx[SB_WLEN], sy[SB_WLEN], cs[SB_WLEN], sn[SB_WLEN];
+    __shared__ double px[SB_NBIN], py[SB_NBIN];
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    const int* info = ws.info + 4 * b;
+    const int na = info[2];
+    if (k >= na) return;
+    const long long total = (long long)info[0] * L;
+    const int f = ws.list[(size_t)b * ws.NA + k];
+    const float* xb = x + (size_t)b * L;
+    const float* yb = y + (size_t)b * L;
+    for (int j = tid; j < SB_WLEN; j += 256) {
+        const long long p = (long long)SB_SHIFT * f + j;
+        const double w = hann400(j);
+        const bool in = p < total;
+        sx[j] = in ? (double)xb[p % L] * w : 0.0;
+        sy[j] = in ? (double)yb[p % L] * w : 0.0;
+        double s_, c_;
+        sincospi((double)j / 200.0, &s_, &c_);
+        cs[j] = c_;
+        sn[j] = s_;
+    }
+    __syncthreads();
+    if (tid < SB_NBIN) {
+        double xr = 0, xi = 0, yr = 0, yi = 0;
+        int idx = 0;  // (tid * n) mod 400
+        for (int n = 0; n < SB_WLEN; ++n) {
+            const double c = cs[idx], s = sn[idx];
+            xr += sx[n] * c; xi -= sx[n] * s;
+            yr += sy[n] * c; yi -= sy[n] * s;
+            idx += tid;
+            if (idx >= SB_WLEN) idx -= SB_WLEN;
+        }
+        px[tid] = xr * xr + xi * xi;
+        py[tid] = yr * yr + yi * yi;
+    }
+    __syncthreads();
+    if (tid < 2 * SB_J) {
+        const int sig = tid / SB_J, j = tid - sig * SB_J;
+        const double* g = ws.g2 + j * SB_NBIN;
+        const double* pp = sig ? py : px;
+        double a = 0.0;
+        for (int q = 0; q < SB_NBIN; ++q) a += g[q] * pp[q];
+        ws.XL[(((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k] = log(a + SB_EPS);
+    }
+}
+
+// grid (B), block 64: lanes 0..55 = (signal, band) rows: s4
+__global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2];
+    if (tid >= 2 * SB_J || na < 1) return;
+    double* row = ws.XL + ((size_t)b * 2 * SB_J + tid) * ws.NA;
+    double eX = row[0];
+    for (int i = 1; i < na; ++i) eX = fmin(eX, row[i]);
+    double lt[SB_TF];
+#pragma unroll
+    for (int m = 0; m < SB_TF; ++m) lt[m] = log((double)(m + 1)) / log((double)SB_TF);
+    // window[m] = current value of row[i+m]
+    double win[SB_TF];
+#pragma unroll
+    for (int m = 0; m < SB_TF; ++m) win[m] = (m < na) ? row[m] : 0.0;
+    double sum = 0.0;
+    for (int i = 0; i < na; ++i) {
+        const double v = win[0];  // final (all earlier maskers applied)
+#pragma unroll
+        for (int m = 1; m < SB_TF; ++m) {
+            const double fm = v - (v - eX) * lt[m];
+            win[m - 1] = fmax(win[m], fm);
+        }
+        win[SB_TF - 1] = (i + SB_TF < na) ? row[i + SB_TF] : 0.0;
+        row[i] = v;
+        sum += v;
+    }
+    const double mu = sum / (double)na;
+    for (int i = 0; i < na; ++i) row[i] -= mu;
+}
+
+// grid (420, B, 2), block 256: s5
+__global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws) {
+    __shared__ double red[8];
+    const int a = blockIdx.x, b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2];
+    const int ncols = na - SB_K + 1;
+    double* dst = ws.Xs + (((size_t)b * 2 + sig) * SB_D + a) * ws.NA;
+    if (ncols < 2) {
+        for (int t = tid; t < ws.NA; t += 256) dst[t] = 0.0;
+        return;
+    }
+    const int k = a / SB_J, j = a - k * SB_J;
+    const double* src = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k;
+    double s = 0.0;
+    for (int t = tid; t < ncols; t += 256) s += src[t];
+    const double mu = block_sum(s, red) / (double)ncols;
+    for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? src[t] - mu : 0.0;
+}
+
+// ---------------------------------------------------------------- float64 tiled GEMMs
+// C[b][i][j] = scale_b * sum_t Xs[b][0][i][t] * Xs[b][0][j][t]   (s6; 64x64 tiles, K step 16)
+__global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
+    __shared__ double As[16][65], Bs[16][65];
+    const int b = blockIdx.z, ti = blockIdx.y * 64, tj = blockIdx.x * 64, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2];
+    const int ncols = na - SB_K + 1;
+    const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4] = {};
+    const int kmax = (ncols > 0) ? ncols : 0;
+    for (int k0 = 0; k0 < kmax; k0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = e & 15;
+            const bool kin = k0 + c < ws.NA;                                            // columns >= ncols are zero padded
+            As[c][r] = (kin && ti + r < SB_D) ? X[(size_t)(ti + r) * ws.NA + k0 + c] : 0.0;
+            Bs[c][r] = (kin && tj + r < SB_D) ? X[(size_t)(tj + r) * ws.NA + k0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = As[c][ty * 4 + u]; bv[u] = Bs[c][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+        }
+        __syncthreads();
+    }
+    const double scale = (ncols > 1) ? 1.0 / (double)(ncols - 1) : 0.0;
+    double* C = ws.C + (size_t)b * SB_D * SB_D;
+    for (int u = 0; u < 4; ++u)
+        for (int v = 0; v < 4; ++v) {
+            const int i = ti + ty * 4 + u, j = tj + tx * 4 + v;
+            if (i < SB_D && j < SB_D) C[(size_t)i * SB_D + j] = acc[u][v] * scale;
+        }
+}
+
+// s8: P = U X for both signals (U rows = eigenvectors, [420][420]; X [420][NA]); per 64x64 tile of P
+// emit the row-wise partial sums of Xp^2, Yp^2, Xp*Yp.  grid (NTL, 7, B)
+__global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
+    __shared__ double Us[16][65], Xt[16][65], Yt[16][65];
+    __shared__ double red[3][64][17];
+    const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const double* U = ws.C + (size_t)b * SB_D * SB_D;
+    const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
+    const double* Y = X + (size_t)SB_D * ws.NA;
+    const int tx = tid & 15, ty = tid >> 4;
+    double ax[4][4] = {}, ay[4][4] = {};
+    for (int k0 = 0; k0 < SB_D; k0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = e & 15;  // U tile: rows ti.., cols k0..
+            Us[c][r] = (ti + r < SB_D && k0 + c < SB_D) ? U[(size_t)(ti + r) * SB_D + k0 + c] : 0.0;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int c = e >> 6, r = e & 63;  // X tile: rows k0.., cols t0..
+            const bool in = (k0 + c < SB_D) && (t0 + r < ws.NA);
+            Xt[c][r] = in ? X[(size_t)(k0 + c) * ws.NA + t0 + r] : 0.0;
+            Yt[c][r] = in ? Y[(size_t)(k0 + c) * ws.NA + t0 + r] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            double uv[4], xv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { uv[u] = Us[c][ty * 4 + u]; xv[u] = Xt[c][tx * 4 + u]; yv[u] = Yt[c][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { ax[u][v] += uv[u] * xv[v]; ay[u][v] += uv[u] * yv[v]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { sxx += ax[u][v] * ax[u][v]; syy += ay[u][v] * ay[u][v]; sxy += ax[u][v] * ay[u][v]; }
+        red[0][ty * 4 + u][tx] = sxx; red[1][ty * 4 + u][tx] = syy; red[2][ty * 4 + u][tx] = sxy;
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int q = tid / 64, r = tid - q * 64;
+        if (ti + r < SB_D) {
+            double s = 0.0;
+            for (int c = 0; c < 16; ++c) s += red[q][r][c];
+            ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = s;
+        }
+    }
+}
+
+// s9: one block (512 threads >= 420) per utterance
+__global__ __launch_bounds__(512) void siib_final_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int* info = ws.info + 4 * b;
+    const double* lam = ws.lam + (size_t)b * SB_D;
+    double lmax = -1e300;
+    if (j < SB_D) lmax = lam[j];
+    lmax = block_max(lmax, red);
+    double I = 0.0;
+    if (j < SB_D && lam[j] > 1e-10 * lmax) {
+        double vx = 0, vy = 0, cxy = 0;
+        const double* p = ws.part + ((size_t)b * SB_D + j) * ws.NTL * 3;
+        for (int t = 0; t < ws.NTL; ++t) { vx += p[3 * t]; vy += p[3 * t + 1]; cxy += p[3 * t + 2]; }
+        const double rho = cxy / sqrt(vx * vy);
+        I = -0.5 * log2(1.0 - 0.5625 * rho * rho);
+    }
+    const double tot = block_sum(I, red);
+    if (j == 0) {
+        double v = fmax(0.0, 80.0 / 15.0 * tot);
+        if (info[3] & 8) v = nan("");  // reference raises: not enough active frames
+        if (raw) raw[b] = (float)v;
+        if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.06 * (v - 32.0))));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static void siib_dims(int L, int* NT, int* NA, int* NTL) {
+    long long total = (long long)SB_MMAX * L;
+    if (total < SB_WLEN + 1) total = SB_WLEN + 1;
+    *NT = (int)((total - SB_WLEN + SB_SHIFT - 1) / SB_SHIFT) + 8;
+    const int n1 = (int)((((long long)L < SB_WLEN + 1 ? SB_WLEN + 1 : L) - SB_WLEN + SB_SHIFT - 1) / SB_SHIFT);
+    // active frames: <= 25 s * 80 fps (+ one base period of slack) when tiled, <= n1 otherwise
+    int na = 2000 + n1 + 2 * SB_MMAX;
+    if (na < n1) na = n1;
+    na = (na + 63) / 64 * 64;
+    *NA = na;
+    *NTL = na / 64;
+}
+
+static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
+    int NT, NA, NTL;
+    siib_dims(L, &NT, &NA, &NTL);
+    size_t o = 0;
+#define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
+    TAKE(g2, double, SB_J * SB_NBIN);
+    TAKE(xdb, double, (size_t)B * NT);
+    TAKE(list, int, (size_t)B * NA);
+    TAKE(info, int, (size_t)B * 4);
+    TAKE(XL, double, (size_t)B * 2 * SB_J * NA);
+    TAKE(Xs, double, (size_t)B * 2 * SB_D * NA);
+    TAKE(C, double, (size_t)B * SB_D * SB_D);
+    TAKE(lam, double, (size_t)B * SB_D);
+    TAKE(E, double, (size_t)B * SB_D);
+    TAKE(part, double, (size_t)B * SB_D * NTL * 3);
+#undef TAKE
+    if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; }
+    return o + al(sizeof(int) * (size_t)B);  // + rocSOLVER info array
+}
+
+extern "C" long long nele_metric_siib_workspace_bytes(int B, int L) { return (long long)siib_layout(B, L, nullptr, nullptr); }
+
+static rocblas_handle g_handle = nullptr;
+
+extern "C" int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                                float* mapped, int* info_out, void* stream) {
+    NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_siib: bad arguments");
+    if (L < SB_WLEN + SB_SHIFT * (SB_K + 1)) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_siib: L=%d too short", L);
+    if (workspace_bytes < nele_metric_siib_workspace_bytes(B, L))
+        return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_siib: workspace too small");
+    SiibWs ws;
+    const size_t used = siib_layout(B, L, &ws, (char*)workspace);
+    int* solver_info = (int*)((char*)workspace + used - al(sizeof(int) * (size_t)B));
+    hipStream_t s = as_stream(stream);
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success)
+            return nele_set_error(NELE_ERR_HIP, "nele_metric_siib: rocblas_create_handle failed");
+    }
+    rocblas_set_stream(g_handle, s);
+    hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
+    hipLaunchKernelGGL(siib_vad_kernel, dim3(B), dim3(256), 0, s, x, L, ws);
+    hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws);
+    hipLaunchKernelGGL(siib_mask_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, 2), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
+    NELE_CHECK_LAUNCH("nele_metric_siib(front)");
+    // C is symmetric: row-major == column-major.  On exit column j (= memory row j) is eigenvector j.
+    rocblas_status st = rocsolver_dsyevd_strided_batched(g_handle, rocblas_evect_original, rocblas_fill_lower, SB_D, ws.C, SB_D,
+                                                         (rocblas_stride)SB_D * SB_D, ws.lam, SB_D, ws.E, SB_D, solver_info, B);
+    if (st != rocblas_status_success) return nele_set_error(NELE_ERR_HIP, "nele_metric_siib: rocsolver_dsyevd status %d", (int)st);
+    hipLaunchKernelGGL(siib_proj_kernel, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
+    if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
+    NELE_CHECK_LAUNCH("nele_metric_siib(back)");
+    return NELE_OK;
+}

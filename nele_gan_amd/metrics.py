@@ -24,6 +24,12 @@ _lib.lib.nele_metric_estoi_workspace_bytes.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_estoi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_estoi_workspace_bytes'] = _lib.lib.nele_metric_estoi_workspace_bytes.argtypes
 
+declare('nele_metric_siib', [_P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P, _P])
+_lib._SIGS['nele_metric_siib'] = _lib.lib.nele_metric_siib.argtypes
+_lib.lib.nele_metric_siib_workspace_bytes.argtypes = [c_int, c_int]
+_lib.lib.nele_metric_siib_workspace_bytes.restype = c_longlong
+_lib._SIGS['nele_metric_siib_workspace_bytes'] = _lib.lib.nele_metric_siib_workspace_bytes.argtypes
+
 _ws_cache = {}
 
 
@@ -61,6 +67,42 @@ def batch_estoi(x, y):
     mapped = torch.empty(B, device=x.device)
     call('nele_metric_estoi', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), stream())
     return raw, mapped
+
+
+def batch_siib(x, y, return_info=False):
+    """clean x [B,L], degraded y [B,L] (16 kHz) -> (raw [B] bits/s, mapped [B]); the replication rule of
+    intel.py:93-97 is applied per utterance on the device.  info [B,4] = (M, tiled frames, active frames, status)."""
+    x, y, _ = _pair(x, y)
+    B, L = x.shape
+    nb = _lib.lib.nele_metric_siib_workspace_bytes(B, L)
+    ws = _workspace('siib', nb, x.device)
+    raw = torch.empty(B, device=x.device)
+    mapped = torch.empty(B, device=x.device)
+    info = torch.zeros((B, 4), dtype=torch.int32, device=x.device)
+    call('nele_metric_siib', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), stream())
+    if return_info:
+        return raw, mapped, info
+    return raw, mapped
+
+
+def _siib_checked(x, y):
+    raw, mapped, info = batch_siib(x, y, return_info=True)
+    st = int(info[0, 3])
+    if st & 8:
+        raise ValueError("SIIB: not enough active speech frames")       # pysiib / reference raise here
+    if st & 1:
+        raise ValueError("SIIB: replication factor above the supported maximum")
+    return raw, mapped
+
+
+def SIIB_Wrapper_raw_harvard(x, y, fs):
+    assert fs == 16000
+    return float(_siib_checked(x, y)[0][0])
+
+
+def SIIB_Wrapper_harvard(x, y, fs):
+    assert fs == 16000
+    return float(_siib_checked(x, y)[1][0])
 
 
 def ESTOI_Wrapper_raw_harvard(x, y, fs):

@@ -53,3 +53,34 @@ def test_estoi_too_short_returns_pystoi_constant(mt):
     x = toy('Train_Clean.wav')[:3000]
     raw, _ = mt.batch_estoi(x, x)
     assert float(raw[0]) == pytest.approx(1e-5, rel=1e-6)
+
+
+def test_siib_toy_file_vs_oracle(mt):
+    from oracle import siib
+    x, v = toy('Train_Clean.wav'), toy('Train_Noise.wav')
+    ys = np.stack([x + v, x + np.float32(0.25) * v, x])
+    xs = np.stack([x] * 3)
+    raw, mapped, info = mt.batch_siib(xs, ys, return_info=True)
+    raw, mapped, info = raw.cpu().numpy(), mapped.cpu().numpy(), info.cpu().numpy()
+    assert list(info[0][:1]) == [14]                                   # replication factor pinned by the reference (intel.npz)
+    for b in range(3):
+        ref = siib.siib_wrapper(xs[b], ys[b], norm=False)
+        assert raw[b] == pytest.approx(ref, rel=1e-4, abs=1e-3)
+        assert mapped[b] == pytest.approx(1 / (1 + np.exp(-0.06 * (ref - 32))), rel=1e-4)
+    assert raw[2] == pytest.approx(80 / 15 * 420 * (-0.5 * np.log2(1 - 0.5625)), rel=1e-5)
+
+
+@pytest.mark.parametrize('L', [64000, 47777])
+def test_siib_synthetic_batch_vs_oracle(mt, L):
+    from nele_gan_amd import synth
+    from oracle import siib
+    c, v = synth.batch(3, L, start=60)
+    y = c + v
+    raw, _, info = mt.batch_siib(c, y, return_info=True)
+    raw, info = raw.cpu().numpy(), info.cpu().numpy()
+    for b in range(3):
+        ref, parts = None, None
+        M, _ = __import__('oracle.intel', fromlist=['x']).siib_replication(c[b])
+        assert info[b][0] == M
+        ref = siib.siib_wrapper(c[b], y[b], norm=False)
+        assert raw[b] == pytest.approx(ref, rel=1e-4, abs=1e-3)
