@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/s per GAN_epoch step (G + D + metric loss) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one canonical GAN_epoch step over one batch of synthetic utterances already
+resident in HBM: features(clean, noise) -> G-step (G fwd+bwd through D, Adam-G) -> generate (G eval,
+gain, iSTFT, PCM_16) -> true metrics (SIIB + ESTOI, logistic maps) -> D-step (D fwd+bwd, Adam-D).
+Workload = BASELINE.json configs[1]: batch 32 synthetic 4 s @ 16 kHz utterances per GPU, SIIB+ESTOI
+targets.  Multi-GPU: utterances shard across ranks (weak scaling: 32 per GPU), one flat RCCL
+all-reduce of the G and of the D gradients per step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
+
+
+def cpu_baseline(metrics, length, n_utt, seed_start=9000):
+    """The oracle's canonical step (CPU port of the reference path) on a bounded sample."""
+    import numpy as np
+    import torch
+    from nele_gan_amd import synth
+    from nele_gan_amd.model import Discriminator, Generator_Conv1D_cLN
+    from oracle.step import CpuStep
+    torch.manual_seed(666)
+    G, D = Generator_Conv1D_cLN(), Discriminator(nout=len(metrics))
+    step = CpuStep(G.state_dict(), D.state_dict(), metrics=metrics)
+    c, v = synth.batch(n_utt, length, start=seed_start)
+    t0 = time.perf_counter()
+    # the reference is batch 1: one utterance per optimiser step
+    for i in range(n_utt):
+        step.canonical_step(c[i:i + 1], v[i:i + 1])
+    dt = time.perf_counter() - t0
+    return {'value': n_utt / dt, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d synthetic %.1f s utterances, canonical step at batch 1 (reference semantics), %s; %.1f s wall; host %d logical cores; '
+                      'stage seconds %s' % (n_utt, length / 16000.0, '+'.join(metrics), dt, os.cpu_count(),
+                                            {k: round(t, 2) for k, t in step.times.items()})}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--length', type=int, default=64000)
+    ap.add_argument('--metrics', default='siib&estoi')
+    ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
+    a = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+
+    from nele_gan_amd import ops, synth
+    from nele_gan_amd.train_nele import GanTrainer, parse_metrics
+    metrics = parse_metrics(a.metrics)
+    tr = GanTrainer(a.metrics, device='cuda:%d' % local)
+    if world > 1:                                     # identical replicas: broadcast rank 0's weights and u/v buffers
+        for m in (tr.G, tr.D):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, 0)
+    c, v = synth.batch(a.batch, a.length, start=rank * a.batch)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.canonical_step(cw, nw)
+    tag = 'D.conv5.fwd'
+    ops.PROFILE = {tag: []}
+    stage_ev = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if a.breakdown:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            ev[0].record(); f = tr.features(cw, nw)
+            ev[1].record(); tr.g_step(f['clean_band'], f['noise_band'])
+            ev[2].record(); enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+            ev[3].record(); tgt = tr.true_metrics(cw, enh, nw)
+            ev[4].record(); tr.d_step(tr.d_inputs(enh, f['noise_band'], f['clean_band']), tgt)
+            ev[5].record(); stage_ev.append(ev)
+        else:
+            tr.canonical_step(cw, nw)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ops.PROFILE[tag]
+    ops.PROFILE = None
+    if rank == 0:
+        T = 1 + a.length // 256
+        kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
+        flops = prof[0][2] if prof else 0.0
+        achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        out = {
+            'metric': 'utterances/sec per GAN_epoch step (G+D+metric loss)',
+            'value': a.batch * world * a.steps / dt,
+            'unit': 'utterances/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
+                                   'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
+                       'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<4> (%s: implicit-GEMM Conv2d 48->64 9x9, M=%d N=64 K=3888)' % (tag, a.batch * 44 * (T - 20)),
+                         'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+                         'traffic': None, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
+        }
+        if a.breakdown and stage_ev:
+            names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
+            br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}
+            sys.stderr.write('stage ms: %s\n' % json.dumps({k: round(x, 3) for k, x in br.items()}))
+        if world == 1 and a.cpu_utts > 0:
+            out['cpu_baseline'] = cpu_baseline(metrics, a.length, a.cpu_utts)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -436,7 +436,7 @@ class _DiscriminatorBase(nn.Module):
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):
-            ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l])
+            ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
         score = _empty((B, self._nout), dev)
         call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),
@@ -492,7 +492,7 @@ class _DiscriminatorBase(nn.Module):
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, stream())
                 m.bias.grad.add_(tmpb)
             if l > 0:
-                ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l])
+                ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
             elif need_din:
                 ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
                 ddin = bf.ddin

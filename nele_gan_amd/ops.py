@@ -51,9 +51,21 @@ class Geom:
         self.arr = (c_int * 15)(*vals)
 
 
-def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g):
+# bench.py sets PROFILE = {tag: [(start_event, end_event), ...]} to time one tagged kernel with HIP events
+# recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
+
+def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g, tag=None):
     M = B * g.Hout * g.Wout
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('nele_conv_gemm', ptr(A), ptr(Wg), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, stream())
+    if prof:
+        e1.record()
+        PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
 
 
 def wgrad_workspace_floats(B, N, g):

@@ -1,0 +1,186 @@
+"""The GAN_epoch loop of the reference ``train_nele.py`` on the MI355X, batched over utterances.
+
+Loop surface kept from the reference (train_nele.py:110-429): per epoch
+  G-step (from epoch 2)  :122-156   -> GanTrainer.g_step
+  checkpoint             :272-277   -> GanTrainer.save_checkpoint ('enhance-model' / 'intel-model')
+  generate D samples     :279-316   -> GanTrainer.generate (G.eval, no grad, mask*beta2, resynthesis, PCM_16)
+  true metric targets    :318-340   -> GanTrainer.true_metrics (batched SIIB / HASPI / ESTOI kernels, logistic maps)
+  D training, 3 passes + 1/30 history replay :342-426 -> GanTrainer.d_epoch / d_step
+What changed on purpose: utterances are processed as batches resident in HBM (the reference is
+batch 1 with wav files on disk as the hand-off between G, the metrics and D), the energy
+normalisation stays per utterance, and gradients are averaged across ranks with one flat RCCL
+all-reduce per model per optimiser step when torch.distributed is initialised.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import audio_util as au
+from . import metrics as mt
+from . import model as M
+from . import ops
+from .optim import Adam
+
+# train_nele.py:30-43
+TargetMetric = 'siib&haspi&estoi'
+GAN_epoch = 500
+num_of_sampling = 300
+num_of_valid_sample = 480
+batch_size = 1
+fs = 16000
+p_power = (1 / 6)
+inv_p = 6
+weight_qua = 0.5
+
+_METRIC_FN = {'siib': 'batch_siib', 'estoi': 'batch_estoi', 'haspi': 'batch_haspi'}
+
+
+def parse_metrics(target_metric):
+    names = [m.strip().lower() for m in target_metric.replace(',', '&').split('&') if m.strip()]
+    for m in names:
+        if m not in _METRIC_FN:
+            raise ValueError("unknown metric %r (supported: siib, haspi, estoi)" % m)
+    return names
+
+
+class GanTrainer:
+    def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666):
+        self.metrics = parse_metrics(target_metric)
+        self.device = torch.device(device)
+        torch.manual_seed(seed)                      # same initial weights on every rank
+        random.seed(seed)                            # train_nele.py:28
+        self.G = M.Generator_Conv1D_cLN().to(self.device)
+        self.D = M.Discriminator(nout=len(self.metrics)).to(self.device)
+        self.D_Qua = M.Discriminator_Quality().to(self.device) if use_quality else None
+        self.optimizer_g = Adam(self.G, lr=lr_g)     # train_nele.py:89-91
+        self.optimizer_d = Adam(self.D, lr=lr_d)
+        self.optimizer_dqua = Adam(self.D_Qua, lr=lr_d) if use_quality else None
+        self.MSELoss = nn.MSELoss()
+        self.pcm16 = pcm16
+        self.step_g = 0
+        self.step_d = 0
+        self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+
+    # ---------------------------------------------------------------- data-parallel glue
+    def _allreduce_grads(self, module):
+        if self.world > 1:
+            g = module.flat_parameters().grad
+            torch.distributed.all_reduce(g)
+            g.mul_(1.0 / self.world)
+
+    # ---------------------------------------------------------------- features (dataloader.py:30-42)
+    def features(self, clean_wav, noise_wav):
+        """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64)."""
+        clean_spec, clean_band = au.stft_band(clean_wav, p_power)
+        noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False)
+        _, noise_band = au.imcra_band(noise_spec, p_power)
+        return {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec}
+
+    # ---------------------------------------------------------------- G-step (train_nele.py:122-156)
+    def g_step(self, clean_band, noise_band):
+        B = clean_band.shape[0]
+        self.D.weight_grad_enabled = False           # D / D_Qua gradients of this step are never applied (train_nele.py:153-155)
+        if self.D_Qua is not None:
+            self.D_Qua.weight_grad_enabled = False
+        self.optimizer_g.zero_grad()
+        mask = self.G(clean_band, noise_band)
+        din, _ = M.energy_norm_pack(mask, clean_band, noise_band, p_power, inv_p)
+        score = self.D.forward_packed(din)
+        loss = self.MSELoss(score, torch.ones_like(score))
+        if self.D_Qua is not None:
+            din_q = torch.zeros_like(din)
+            din_q[..., 0] = din[..., 0]
+            din_q[..., 1] = din[..., 2]
+            score_q = self.D_Qua.forward_packed(din_q)
+            loss = loss + weight_qua * self.MSELoss(score_q, torch.ones_like(score_q))
+        loss.backward()
+        self._allreduce_grads(self.G)
+        self.optimizer_g.step()
+        self.step_g += 1
+        self.D.weight_grad_enabled = True
+        if self.D_Qua is not None:
+            self.D_Qua.weight_grad_enabled = True
+        return loss.detach()
+
+    # ---------------------------------------------------------------- sample generation (train_nele.py:279-316)
+    @torch.no_grad()
+    def generate(self, clean_band, noise_band, clean_spec, rms_target=0.0):
+        self.G.eval()
+        mask = self.G(clean_band, noise_band)
+        alpha2 = M.normed_alpha2(mask, clean_band, inv_p)
+        enh_wav = au.gain_istft(alpha2, clean_spec, rms_target=rms_target, pcm16=self.pcm16)
+        self.G.train()
+        return enh_wav
+
+    # ---------------------------------------------------------------- true metric targets (train_nele.py:318-340)
+    @torch.no_grad()
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True):
+        L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
+        x = clean_wav[:, :L].contiguous()
+        y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
+        cols = []
+        for m in self.metrics:
+            raw, mapped = getattr(mt, _METRIC_FN[m])(x, y)
+            cols.append(mapped if norm else raw)
+        return torch.stack(cols, dim=1)
+
+    # ---------------------------------------------------------------- D-step (train_nele.py:349-367)
+    def d_inputs(self, enh_wav, noise_band, clean_band):
+        """dataloader.py:54-84: features of the enhanced wav, stacked (enhanced, noise, clean)."""
+        _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False)
+        return ops.d_pack(enh_band, noise_band, clean_band)
+
+    def d_step(self, din, target):
+        self.optimizer_d.zero_grad()
+        score = self.D.forward_packed(din)
+        loss = self.MSELoss(score, target)
+        loss.backward()
+        self._allreduce_grads(self.D)
+        self.optimizer_d.step()
+        self.step_d += 1
+        return loss.detach()
+
+    # ---------------------------------------------------------------- one canonical step
+    def canonical_step(self, clean_wav, noise_wav, feats=None):
+        """features -> G-step -> generate -> true metrics -> D-step on the same batch."""
+        f = feats or self.features(clean_wav, noise_wav)
+        lg = self.g_step(f['clean_band'], f['noise_band'])
+        enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+        tgt = self.true_metrics(clean_wav, enh, noise_wav)
+        din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
+        ld = self.d_step(din, tgt)
+        return lg, ld, tgt
+
+    # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
+    def d_epoch(self, samples, batch=32):
+        """samples: list of (din [64,T,4], target [n]) tensors of this epoch (generated + pre-enhanced 'DRC' examples)."""
+        def run(lst):
+            random.shuffle(lst)
+            for i in range(0, len(lst), batch):
+                chunk = lst[i:i + batch]
+                self.d_step(torch.stack([c[0] for c in chunk]), torch.stack([c[1] for c in chunk]))
+        cur = list(samples)
+        run(cur)                                                        # pass A
+        random.shuffle(self.history)
+        run(self.history[0:len(self.history) // 30] + cur)              # pass B: replay 1/30 of the history
+        self.history = self.history + cur
+        run(cur)                                                        # pass C
+
+    # ---------------------------------------------------------------- checkpoints (train_nele.py:272-277)
+    def save_checkpoint(self, path):
+        sd = {'enhance-model': self.G.state_dict(), 'intel-model': self.D.state_dict()}
+        if self.D_Qua is not None:
+            sd['quality-model'] = self.D_Qua.state_dict()
+        torch.save(sd, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location=self.device)
+        self.G.load_state_dict(ck['enhance-model'])
+        if 'intel-model' in ck:
+            self.D.load_state_dict(ck['intel-model'])
+        if self.D_Qua is not None and 'quality-model' in ck:
+            self.D_Qua.load_state_dict(ck['quality-model'])

@@ -1,0 +1,131 @@
+"""Oracle: the canonical GAN_epoch step on the CPU: features -> G-step -> generate ->
+true metrics -> D-step, batch 1 semantics per utterance as in the reference, restated with the
+oracle modules (numpy / scipy / torch-CPU float32).  TEST INFRASTRUCTURE ONLY: used by the tests
+as the checker and by bench.py's ``cpu_baseline`` leg as the timed CPU port."""
+import time
+
+import numpy as np
+import torch
+
+from . import estoi as o_estoi
+from . import features as F
+from . import intel as o_intel
+from . import nets
+from . import siib as o_siib
+
+P_POWER, INV_P = 1 / 6, 6
+
+
+def pcm16_roundtrip(x):
+    """sf.write(..., 'PCM_16') + librosa.load: libsndfile scales by 0x7FFF and rounds to nearest even,
+    reading divides by 0x8000 (PARITY UNPINNED: libsndfile not present)."""
+    q = np.clip(np.rint(np.asarray(x, dtype=np.float32) * np.float32(32767.0)), -32768, 32767)
+    return (q / 32768.0).astype(np.float32)
+
+
+def metric_targets(clean, enh, noise, metrics, norm=True):
+    L = min(len(clean), len(enh))
+    x = clean[:L]
+    y = enh[:L] + noise[:L]
+    out = []
+    for m in metrics:
+        if m == 'siib':
+            out.append(o_siib.siib_wrapper(x, y, norm=norm))
+        elif m == 'estoi':
+            out.append(o_estoi.estoi_wrapper(x, y, norm=norm))
+        elif m == 'haspi':
+            from . import haspi as o_haspi
+            out.append(o_haspi.haspi_wrapper(x, y, norm=norm))
+        else:
+            raise ValueError(m)
+    return np.asarray(out, dtype=np.float32)
+
+
+class CpuStep:
+    """State (weights, Adam moments) + one canonical step over a batch."""
+
+    def __init__(self, g_state, d_state, metrics=('siib', 'estoi'), lr_g=5e-4, lr_d=2.5e-4):
+        self.metrics = tuple(metrics)
+        self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
+        self.d = {k: v.detach().clone().float() for k, v in d_state.items()}
+        for k, v in self.d.items():
+            if not (k.endswith('_u') or k.endswith('_v')):
+                v.requires_grad_(True)
+        self.opt_g = torch.optim.Adam(list(self.g.values()), lr=lr_g)
+        self.opt_d = torch.optim.Adam([v for v in self.d.values() if v.requires_grad], lr=lr_d)
+        self.times = {}
+
+    def _t(self, key, t0):
+        self.times[key] = self.times.get(key, 0.0) + time.perf_counter() - t0
+
+    def features(self, clean, noise):
+        t0 = time.perf_counter()
+        cb, cm, cp = [], [], []
+        nb = []
+        for c, v in zip(clean, noise):
+            b, m, p = F.sp_and_phase_speech(c, P_POWER)
+            cb.append(b); cm.append(m); cp.append(p)
+            nb.append(F.sp_and_phase_noise(v, P_POWER)[0])
+        self._t('features', t0)
+        return np.stack(cb), cm, cp, np.stack(nb)
+
+    def _d_forward(self, x, train=True):
+        s, nb = nets.discriminator_forward(self.d, x, train=train)
+        for k, v in nb.items():
+            self.d[k] = v.detach()
+        return s
+
+    def g_step(self, cb, nb):
+        t0 = time.perf_counter()
+        cbt, nbt = torch.from_numpy(cb), torch.from_numpy(nb)
+        mask = nets.generator_forward(self.g, cbt, nbt)
+        enh, _ = nets.energy_norm(mask, cbt, P_POWER, INV_P)
+        score = self._d_forward(nets.d_inputs(enh, nbt, cbt))
+        loss = torch.nn.functional.mse_loss(score, torch.ones_like(score))
+        self.opt_g.zero_grad()
+        self.opt_d.zero_grad()
+        loss.backward()
+        self.opt_g.step()
+        self._t('g_step', t0)
+        return float(loss)
+
+    def generate(self, cb, nb, cm, cp, pcm16=True):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            cbt = torch.from_numpy(cb)
+            mask = nets.generator_forward(self.g, cbt, torch.from_numpy(nb))
+            cpow = torch.pow(cbt, INV_P)
+            beta2 = cpow.sum(dim=(1, 2), keepdim=True) / (mask * cpow).sum(dim=(1, 2), keepdim=True)
+            alpha2 = (mask * beta2).numpy()
+        out = []
+        for b in range(cb.shape[0]):
+            w = F.sp_to_wav(alpha2[b], cm[b], cp[b])
+            out.append(pcm16_roundtrip(w) if pcm16 else w)
+        self._t('generate', t0)
+        return out
+
+    def targets(self, clean, enh, noise):
+        t0 = time.perf_counter()
+        t = np.stack([metric_targets(c, e, v, self.metrics) for c, e, v in zip(clean, enh, noise)])
+        self._t('metrics', t0)
+        return t
+
+    def d_step(self, enh, nb, cb, tgt):
+        t0 = time.perf_counter()
+        eb = np.stack([F.sp_and_phase_speech(e, P_POWER)[0] for e in enh])
+        x = nets.d_inputs(torch.from_numpy(eb), torch.from_numpy(nb), torch.from_numpy(cb))
+        score = self._d_forward(x)
+        loss = torch.nn.functional.mse_loss(score, torch.from_numpy(tgt))
+        self.opt_d.zero_grad()
+        loss.backward()
+        self.opt_d.step()
+        self._t('d_step', t0)
+        return float(loss)
+
+    def canonical_step(self, clean, noise):
+        cb, cm, cp, nb = self.features(clean, noise)
+        lg = self.g_step(cb, nb)
+        enh = self.generate(cb, nb, cm, cp)
+        tgt = self.targets(clean, enh, noise)
+        ld = self.d_step(enh, nb, cb, tgt)
+        return lg, ld, tgt, enh

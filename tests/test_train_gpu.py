@@ -1,0 +1,57 @@
+"""GPU: one canonical GAN_epoch step (features -> G-step -> generate -> metrics -> D-step) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def test_canonical_step_matches_cpu_oracle():
+    assert torch.cuda.is_available()
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    from oracle.step import CpuStep
+    B, L = 2, 24000
+    c, v = synth.batch(B, L, start=300)
+    tr = GanTrainer('siib&estoi')
+    g0 = {k: t.detach().cpu().clone() for k, t in tr.G.state_dict().items()}
+    d0 = {k: t.detach().cpu().clone() for k, t in tr.D.state_dict().items()}
+    cpu = CpuStep(g0, d0, metrics=('siib', 'estoi'))
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    # --- stage by stage so that a mismatch is attributable
+    f = tr.features(cw, nw)
+    cb, cm, cp, nb = cpu.features(c, v)
+    np.testing.assert_allclose(f['clean_band'].cpu().numpy(), cb, rtol=1e-5)
+    np.testing.assert_allclose(f['noise_band'].cpu().numpy(), nb, rtol=2e-5)
+    lg = tr.g_step(f['clean_band'], f['noise_band'])
+    lg_ref = cpu.g_step(cb, nb)
+    assert float(lg) == pytest.approx(lg_ref, rel=1e-4)
+    for k, t in tr.G.state_dict().items():                             # Adam-updated generator
+        np.testing.assert_allclose(t.cpu().numpy(), cpu.g[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+    enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+    enh_ref = cpu.generate(cb, nb, cm, cp)
+    assert enh.shape == (B, 256 * (1 + L // 256 - 1))
+    for b in range(B):
+        d = np.abs(enh[b].cpu().numpy() - enh_ref[b])
+        assert d.max() <= 1.5 / 32768 and np.mean(d > 1e-7) < 0.02     # PCM_16: rare one-LSB rounding flips
+    tgt = tr.true_metrics(cw, enh, nw)
+    tgt_ref = cpu.targets(c, [e for e in enh.cpu().numpy()], v)       # metrics on the SAME waveform
+    np.testing.assert_allclose(tgt.cpu().numpy(), tgt_ref, rtol=1e-4)
+    din = tr.d_inputs(enh, f['noise_band'], f['clean_band'])
+    ld = tr.d_step(din, tgt)
+    ld_ref = cpu.d_step([e for e in enh.cpu().numpy()], nb, cb, tgt_ref)
+    assert float(ld) == pytest.approx(ld_ref, rel=2e-4)
+    for k, t in tr.D.state_dict().items():
+        np.testing.assert_allclose(t.cpu().numpy(), cpu.d[k].detach().numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_inference_path_rms_and_length():
+    from nele_gan_amd import synth
+    from nele_gan_amd.inference import Enhancer
+    c, v = synth.batch(2, 32000, start=500)
+    torch.manual_seed(1)
+    e = Enhancer()
+    out = e.enhance(torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda(), pcm16=False)
+    assert out.shape == (2, 256 * (32000 // 256))
+    rms = out.pow(2).mean(dim=1).sqrt().cpu().numpy()
+    np.testing.assert_allclose(rms, 0.03, rtol=1e-5)                   # inference.py:109
