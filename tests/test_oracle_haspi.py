@@ -54,7 +54,8 @@ def test_haspi_properties_at_16k():
     assert np.sqrt(np.mean(y24.astype(np.float64) ** 2)) == pytest.approx(np.sqrt(np.mean(c[0].astype(np.float64) ** 2)), rel=1e-6)
 
 
-def test_silent_input_raises_like_reference():
-    x = np.ones(24000, dtype=np.float32)               # DC: removed by the middle-ear high-pass -> nothing above 2.5 dB SL
+def test_below_threshold_raises_like_reference():
+    # pyhaspi2.py:357-358: fewer than two sub-sampled frames above 2.5 dB SL -> exception
+    z = np.zeros((100, 32))
     with pytest.raises(Exception):
-        H.haspi_v2(x, 24000, x, 24000)
+        H.cep_coef(z, z)
