@@ -130,6 +130,39 @@ int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* 
 int nele_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    int step, void* stream);
 
+/* ---- batched objective metrics (csrc/estoi.hip, csrc/siib.hip, csrc/haspi.hip) --------------------
+ * Replace audio_util.py:120-203 read_batch_{STOI,SIIB,HASPI} (32 joblib processes over wav files) and
+ * the intel.py wrappers they call.  x = clean [B][L], y = degraded (enhanced + noise, audio_util.py:139-141)
+ * [B][L], float32 at 16 kHz, equal lengths (the caller truncates to the common length, intel.py:58-60).
+ * raw [B] = metric value, mapped [B] = its logistic map to [0,1] (intel.py:102-106, 116-120, 136-140);
+ * either may be NULL.  workspace: device scratch of at least *_workspace_bytes(B, L). */
+
+/* intel.py:122-134 ESTOI_Wrapper[_raw]_harvard -> pystoi.stoi(x, y, 16000, extended=True) (algorithm
+ * restated, oracle/estoi.py).  Fewer than 30 frames after silence removal -> raw = 1e-5 as pystoi. */
+long long nele_metric_estoi_workspace_bytes(int B, int L);
+int nele_metric_estoi(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                      float* mapped, void* stream);
+
+/* intel.py:57-100 SIIB_Wrapper[_raw]_harvard: VAD (intel.py:37-50), replication rule (intel.py:93-97) and
+ * pysiib.SIIB(x, y, 16000, gauss=True) (algorithm restated, oracle/siib.py).  info [B][4] (may be NULL) =
+ * {replication factor M, frames of the tiled signal, active frames, status bits: 1 M clamped, 4 active-frame
+ * buffer clamped, 8 not enough active frames (reference raises; raw = NaN)}.  The KLT eigenvectors come from
+ * rocSOLVER (dsyevd, strided batched): stop-gap, the only library call in the path. */
+long long nele_metric_siib_workspace_bytes(int B, int L);
+int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                     float* mapped, int* info, void* stream);
+
+/* intel.py:108-114 HASPI_Wrapper[_raw]_harvard -> pyHASPI/pyhaspi2.py:76-107 haspi_v2(x, fs, y, fs), HL = 0.
+ * fs_in 16000 (resampled to 24 kHz as librosa.resample / resampy kaiser_best, pyhaspi2.py:815) or 24000.
+ * dither: NULL (no IHC firing jitter) or float64 standard normals [B][2][nsub][32], nsub =
+ * nele_metric_haspi_nsub(L, fs_in); row k perturbs the k-th ACTIVE sub-sampled frame exactly as the reference's
+ * np.random.randn(n_active, 32) draws (pyhaspi2.py:362-365).  info [B][2] (may be NULL) = {active frames,
+ * status: 1 = signal below threshold (reference raises, pyhaspi2.py:357-358; raw = NaN)}. */
+long long nele_metric_haspi_workspace_bytes(int B, int L, int fs_in);
+int nele_metric_haspi_nsub(int L, int fs_in);
+int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
+                      long long workspace_bytes, float* raw, float* mapped, int* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,571 @@
+// Batched HASPI v2, normal-hearing reference (reference intel.py:108-120 -> pyHASPI/pyhaspi2.py:76-107
+// haspi_v2 and its call tree :1155-1248 eb_EarModel, :378-414 ebm_EnvFilt, :342-375 ebm_CepCoef,
+// :275-339 ebm_ModFilt, :254-273 ebm_ModCorr).  float64 after the middle-ear filter, as the reference.
+//
+// One wave (64 lanes) per utterance for every recurrence: lane = signal*32 + channel, so the 32
+// channels of a signal walk the sample axis together and each step reads / writes one coalesced
+// 256-byte row of the [n][32] channel-minor buffers.  Recurrences (IIR sections, demodulator
+// rotation, IHC adaptation) are true serial dependences over 1.5*L samples; everything that is
+// point-wise (log / pow / sqrt, FIR filters, correlations) runs in wide kernels between them:
+//   h1 rms-normalise (float32) + resampy kaiser_best 16 -> 24 kHz (float32 accumulate) + RMS restore
+//   h2 middle ear IIR (serial, lanes 0..1 = the two signals)
+//   h3 control filter bank: complex demodulation + 2 x 4th-order gammatone IIR -> control envelope,
+//      mean square -> bandwidth adjustment (eb_BWadjust)
+//   h4 signal filter bank with the adjusted bandwidths -> envelope
+//   h5 point-wise OHC compression gain from the control envelope
+//   h6 gain low-pass IIR (serial) * envelope
+//   h7 point-wise dB SL conversion
+//   h8 IHC adaptation (serial) -> envelope in dB SL
+//   h9 group-delay shifts, 52-tap Hann FIR + 9:1 sub-sampling
+//   h10 silence gate + ordered compaction + dither + 6 cepstral bases + mean removal
+//   h11 10 modulation filters (complex demodulation, Hann FIR up to 615 taps) fused with the
+//       normalised cross-correlation of reference and processed sequences
+//   h12 average over bases 2-6, weighted sum, logistic map
+#include "common.h"
+
+#define HP_NCH 32
+#define HP_FS 24000.0
+#define HP_LEVEL 65.0
+#define HP_NBASIS 6
+#define HP_NMOD 10
+#define HP_NWIN 32769      // resampy kaiser_best half window: 64 zero crossings * 512 + 1
+#define HP_NTAB 512
+#define HP_SPACE 9
+#define HP_NFILT 52
+#define HP_NHALF 26
+
+struct HaspiWs {
+    double* win;     // [HP_NWIN] resampler half window
+    float* r24;      // [B][2][n24]   resampled, RMS-restored (float32 as in the reference)
+    double* mid;     // [B][2][n24]   middle-ear output
+    double* ctl;     // [B][2][n24][32] control envelope -> compression gain -> (reused)
+    double* env;     // [B][2][n24][32] signal envelope -> compressed -> dB SL -> adapted dB SL
+    double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
+    int* shift;      // [B][32]
+    double* lp;      // [B][2][nsub][32]
+    int* act;        // [B][nsub]     indices of the active sub-sampled frames
+    int* info;       // [B][2]        {n_active, status}
+    double* cep;     // [B][2][6][nsub] mean-removed cepstral sequences (only the first n_active columns)
+    double* cm;      // [B][6][10]    |rho|
+    int n24, nsub;
+};
+
+__device__ __forceinline__ double i0_series(double x) {
+    double s = 1.0, t = 1.0;
+    const double q = 0.25 * x * x;
+    for (int k = 1; k < 200; ++k) {
+        t *= q / ((double)k * (double)k);
+        s += t;
+        if (t < 1e-18 * s) break;
+    }
+    return s;
+}
+
+// resampy sinc_window(num_zeros=64, precision=9, rolloff=0.9475937167399596) * kaiser(beta=14.769656459379492)
+__global__ void haspi_win_kernel(double* __restrict__ win) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HP_NWIN) return;
+    const double rolloff = 0.9475937167399596, beta = 14.769656459379492;
+    const int n = HP_NWIN - 1;
+    const double t = 64.0 * (double)i / (double)n;          // linspace(0, 64, n+1)
+    const double a = rolloff * t;
+    const double sinc = (i == 0) ? 1.0 : sinpi(a) / (M_PI * a);
+    const double r = (double)i / (double)n;
+    const double kais = i0_series(beta * sqrt(fmax(0.0, 1.0 - r * r))) / i0_series(beta);
+    win[i] = kais * rolloff * sinc;
+}
+
+// ---- h1: one block per (utterance, signal)
+__global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, int fs_in,
+                                                             HaspiWs ws) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, sig = blockIdx.y, tid = threadIdx.x;
+    const float* src = (sig ? y : x) + (size_t)b * L;
+    float* dst = ws.r24 + ((size_t)b * 2 + sig) * ws.n24;
+    // rms normalisation (pyhaspi2.py:81-84), float32 like the reference's arrays
+    double acc = 0.0;
+    for (int i = tid; i < L; i += 256) acc += (double)(src[i] * src[i]);
+    acc = block_sum(acc, red);
+    const float rms = sqrtf((float)acc / (float)L);
+    if (fs_in == 24000) {
+        for (int i = tid; i < L; i += 256) dst[i] = src[i] / rms;
+        return;
+    }
+    // resampy resample_f (ratio 1.5: scale = 1, index_step = num_table)
+    const double time_increment = 1.0 / 1.5;
+    double a2 = 0.0;
+    for (int t = tid; t < ws.n24; t += 256) {
+        const double time_register = (double)t * time_increment;
+        const int n = (int)time_register;
+        double frac = time_register - (double)n;
+        double index_frac = frac * HP_NTAB;
+        int offset = (int)index_frac;
+        double eta = index_frac - offset;
+        int i_max = (HP_NWIN - offset) / HP_NTAB;
+        if (n + 1 < i_max) i_max = n + 1;
+        float yv = 0.f;
+        for (int i = 0; i < i_max; ++i) {
+            const int idx = offset + i * HP_NTAB;
+            const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+            const double w = ws.win[idx] + eta * d;
+            yv = (float)((double)yv + w * (double)(src[n - i] / rms));
+        }
+        frac = 1.0 - frac;
+        index_frac = frac * HP_NTAB;
+        offset = (int)index_frac;
+        eta = index_frac - offset;
+        int k_max = (HP_NWIN - offset) / HP_NTAB;
+        if (L - n - 1 < k_max) k_max = L - n - 1;
+        for (int k = 0; k < k_max; ++k) {
+            const int idx = offset + k * HP_NTAB;
+            const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+            const double w = ws.win[idx] + eta * d;
+            yv = (float)((double)yv + w * (double)(src[n + k + 1] / rms));
+        }
+        dst[t] = yv;
+        a2 += (double)(yv * yv);
+    }
+    // y = (xRMS / yRMS) * y  (pyhaspi2.py:816-818); xRMS of the normalised input
+    double xs = 0.0;
+    for (int i = tid; i < L; i += 256) { const float v = src[i] / rms; xs += (double)(v * v); }
+    xs = block_sum(xs, red);
+    a2 = block_sum(a2, red);
+    const float xr = sqrtf((float)(xs / (double)L)), yr = sqrtf((float)(a2 / (double)ws.n24));
+    const float g = xr / yr;
+    __syncthreads();
+    for (int t = tid; t < ws.n24; t += 256) dst[t] = g * dst[t];
+}
+
+// ---- h2: middle ear (pyhaspi2.py:833-841), scipy lfilter = direct form II transposed. grid B, block 64 (lanes 0,1 active)
+__global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, sig = threadIdx.x;
+    if (sig >= 2) return;
+    const float* src = ws.r24 + ((size_t)b * 2 + sig) * ws.n24;
+    double* dst = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
+    const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
+    const double c0 = 0.937260390269893, c1 = -1.874520780539785, c2 = 0.937260390269893, d1 = -1.870580640735279, d2 = 0.878460920344291;
+    double z = 0.0, w0 = 0.0, w1 = 0.0;
+    for (int n = 0; n < ws.n24; ++n) {
+        const double xin = (double)src[n];
+        const double y1 = b0 * xin + z;
+        z = b1 * xin - a1 * y1;
+        const double y2 = c0 * y1 + w0;
+        w0 = c1 * y1 - d1 * y2 + w1;
+        w1 = c2 * y1 - d2 * y2;
+        dst[n] = y2;
+    }
+}
+
+struct GtCoef { double a1, a2, a3, a4, a5, gain; };
+
+__device__ __forceinline__ double hp_cfreq(int ch) {
+    // pyhaspi2.py:753-777
+    const double lowFreq = 80.0, highFreq = 8000.0, EarQ = 9.26449, minBW = 24.7;
+    const int k = HP_NCH - 1 - ch;  // flipped order: ch 31 is highFreq
+    if (k == 0) return highFreq;
+    return -(EarQ * minBW) + exp((double)k * (-log(highFreq + EarQ * minBW) + log(lowFreq + EarQ * minBW)) / (double)(HP_NCH - 1)) *
+                                 (highFreq + EarQ * minBW);
+}
+
+__device__ __forceinline__ GtCoef hp_gt(double BW, double cf) {
+    const double ERB = 24.7 + cf / 9.26449;
+    const double tpt = 2.0 * M_PI / HP_FS;
+    const double a = exp(-(BW * tpt * ERB * 1.019));
+    GtCoef c;
+    c.a1 = 4.0 * a; c.a2 = -6.0 * a * a; c.a3 = 4.0 * a * a * a; c.a4 = -a * a * a * a; c.a5 = 4.0 * a * a;
+    c.gain = 2.0 * (1 - c.a1 - c.a2 - c.a3 - c.a4) / (1 + c.a1 + c.a5);
+    return c;
+}
+
+// Control bandwidth of channel ch for HL = 100 dB (pyhaspi2.py:779-807 with loss = 100 everywhere)
+__device__ __forceinline__ double hp_bw1(int ch) {
+    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+    const double maxOHC = 70.0 * (1.0 - 1.0 / CR), thrOHC = 1.25 * maxOHC;
+    const double attnOHC = (100.0 < thrOHC) ? 80.0 : 0.8 * thrOHC;
+    const double r = attnOHC / 50.0;
+    return 1.0 + r + 2.0 * r * r * r * r * r * r;
+}
+
+// Gammatone envelope of one stream (lane): demodulate by the rotation recurrence (eb_CosSinCF), filter real and
+// imaginary parts with lfilter([1,a1,a5],[1,-a1,-a2,-a3,-a4]) (DF2T), envelope = gain*|u|.
+// out[n*32] is written; returns the sum of squares of the envelope.
+__device__ __forceinline__ double hp_gammatone_stream(const double* __restrict__ xin, int n24, const GtCoef c, double cf,
+                                                      double* __restrict__ out) {
+    const double tpt = 2.0 * M_PI / HP_FS;
+    const double cn = cos(tpt * cf), sn = sin(tpt * cf);
+    double cold = 1.0, sold = 0.0;
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    double ss = 0.0;
+    for (int n = 0; n < n24; ++n) {
+        if (n > 0) {
+            const double arg = cold * cn + sold * sn;
+            sold = sold * cn - cold * sn;
+            cold = arg;
+        }
+        const double x = xin[n];
+        const double xr = x * cold, xi = x * sold;
+        const double yr = xr + r0;
+        r0 = c.a1 * xr + c.a1 * yr + r1;      // b1*x - a[1]*y with a[1] = -a1
+        r1 = c.a5 * xr + c.a2 * yr + r2;      // b2*x - a[2]*y with a[2] = -a2
+        r2 = c.a3 * yr + r3;
+        r3 = c.a4 * yr;
+        const double yi = xi + i0;
+        i0 = c.a1 * xi + c.a1 * yi + i1;
+        i1 = c.a5 * xi + c.a2 * yi + i2;
+        i2 = c.a3 * yi + i3;
+        i3 = c.a4 * yi;
+        const double e = c.gain * sqrt(yr * yr + yi * yi);
+        out[(size_t)n * HP_NCH] = e;
+        ss += e * e;
+    }
+    return ss;
+}
+
+// ---- h3: control bank + bandwidth adjustment. grid B, block 64
+__global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x, sig = lane >> 5, ch = lane & 31;
+    const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
+    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
+    double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
+    const double ss = hp_gammatone_stream(xin, ws.n24, hp_gt(bw1, cf), cf, out);
+    // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
+    const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
+    double BW;
+    if (cdB < 50.0) BW = 1.0;
+    else if (cdB > 100.0) BW = bw1;
+    else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
+    ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch] = BW;
+}
+
+// ---- h4: signal bank. grid B, block 64
+__global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x, sig = lane >> 5, ch = lane & 31;
+    const double cf = hp_cfreq(ch);
+    const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
+    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
+    double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
+    (void)hp_gammatone_stream(xin, ws.n24, hp_gt(BW, cf), cf, out);
+}
+
+// ---- h5: compression gain from the control envelope (pyhaspi2.py:982-991), point-wise, in place on ctl
+__global__ void haspi_gain_kernel(HaspiWs ws, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 31);
+        const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+        double le = fmax(ws.ctl[i], 1.0e-30);
+        le = HP_LEVEL + 20.0 * log10(le);
+        le = fmin(fmax(le, 30.0), 100.0);
+        const double g = -0.0 - (le - 30.0) * (1.0 - (1.0 / CR));
+        ws.ctl[i] = pow(10.0, g / 20.0);
+    }
+}
+
+// ---- h6: gain low-pass (lfilter([b,b],[1,a])) times envelope, serial. grid B, block 64; result in env
+__global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t base = (((size_t)b * 2 + (lane >> 5)) * ws.n24) * HP_NCH + (lane & 31);
+    const double* g = ws.ctl + base;
+    double* e = ws.env + base;
+    const double b0 = 0.095107983402496, a1 = -0.809784033195007;
+    double z = 0.0;
+    for (int n = 0; n < ws.n24; ++n) {
+        const double x = g[(size_t)n * HP_NCH];
+        const double y = b0 * x + z;
+        z = b0 * x - a1 * y;
+        e[(size_t)n * HP_NCH] = y * e[(size_t)n * HP_NCH];
+    }
+}
+
+// ---- h7: eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise in place on env
+__global__ void haspi_sl_kernel(HaspiWs ws, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const double y = HP_LEVEL + 20.0 * log10(ws.env[i] + 1.0e-30);
+        ws.env[i] = y < 0.0 ? 0.0 : y;
+    }
+}
+
+// ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
+__global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double* e = ws.env + (((size_t)b * 2 + (lane >> 5)) * ws.n24) * HP_NCH + (lane & 31);
+    const double delta = 2.0;
+    const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
+    const double T = 1 / HP_FS;
+    const double R1 = 1 / delta, R2 = 0.5 * (1 - R1), R3 = R2;
+    const double C1 = tau1 * (R1 + R2) / (R1 * R2);
+    const double C2 = tau2 / ((R1 + R2) * R3);
+    const double a11 = R1 + R2 + R1 * R2 * (C1 / T), a12 = -R1, a21 = -R3, a22 = R2 + R3 + R2 * R3 * (C2 / T);
+    const double denom = 1.0 / (a11 * a22 - a21 * a12);
+    const double R1inv = 1.0 / R1, R12C1 = R1 * R2 * (C1 / T), R23C2 = R2 * R3 * (C2 / T);
+    double V1 = 0.0, V2 = 0.0;
+    for (int n = 0; n < ws.n24; ++n) {
+        const double V0 = e[(size_t)n * HP_NCH];
+        const double b1 = V0 * R2 + R12C1 * V1;
+        const double b2 = R23C2 * V2;
+        V1 = denom * (a22 * b1 - a12 * b2);
+        V2 = denom * (-a21 * b1 + a11 * b2);
+        const double out = (V0 - V1) * R1inv;
+        e[(size_t)n * HP_NCH] = out < 0.0 ? 0.0 : out;
+    }
+}
+
+// ---- h9a: group-delay shifts from BWx (pyhaspi2.py:1098-1131; both envelopes use BWx, :1239-1240). grid B, block 64
+__global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, ch = threadIdx.x;
+    double gd = 0.0;
+    if (ch < HP_NCH) {
+        const GtCoef c = hp_gt(ws.bw[(size_t)b * 2 * HP_NCH + ch], hp_cfreq(ch));
+        const double a = 0.25 * c.a1;
+        gd = rint((c.a1 + 2.0 * c.a5) / (1.0 + c.a1 + c.a5) + 4.0 * a / (1.0 - a));   // group delay at w = 0, np.round
+    }
+    double mn = (ch < HP_NCH) ? gd : 1e300, mx = (ch < HP_NCH) ? gd : -1e300;
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
+    if (ch < HP_NCH) ws.shift[(size_t)b * HP_NCH + ch] = (int)((mx - mn) - (gd - mn));
+}
+
+// ---- h9b: ebm_EnvFilt (pyhaspi2.py:378-414): Hann(52)/sum FIR, "same" alignment (nhalf = 26), every 9th sample.
+// grid (ceil(nsub/8), B, 2), block 256 = 8 sub-frames x 32 channels
+__global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
+    __shared__ double benv[HP_NFILT];
+    const int b = blockIdx.y, sig = blockIdx.z, ch = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (threadIdx.x < HP_NFILT) {
+        // np.hanning(52) = 0.5 - 0.5 cos(2 pi n / 51); its sum is 25.5
+        benv[threadIdx.x] = (0.5 - 0.5 * cospi(2.0 * (double)threadIdx.x / 51.0)) / 25.5;
+    }
+    __syncthreads();
+    if (i >= ws.nsub) return;
+    const int s = ws.shift[(size_t)b * HP_NCH + ch];
+    const double* e = ws.env + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
+    double acc = 0.0;
+    const int m0 = HP_SPACE * i + HP_NHALF;
+    for (int k = 0; k < HP_NFILT; ++k) {
+        const int m = m0 - k;                 // index into the group-delay-shifted envelope
+        if (m < 0 || m >= ws.n24) continue;
+        const int src = m - s;
+        if (src < 0) continue;
+        acc += benv[k] * e[(size_t)src * HP_NCH];
+    }
+    ws.lp[(((size_t)b * 2 + sig) * ws.nsub + i) * HP_NCH + ch] = acc;
+}
+
+// ---- h10: ebm_CepCoef (pyhaspi2.py:342-375). one block per utterance
+__global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve) {
+    __shared__ double cepm[HP_NCH][HP_NBASIS];
+    __shared__ int scan[256];
+    __shared__ int base;
+    __shared__ double red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < HP_NBASIS) {
+        double nn = 0.0;
+        for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
+        nn = sqrt(nn);
+        for (int k = 0; k < HP_NCH; ++k) cepm[k][tid] = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)) / nn;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
+    const double* ylp = xlp + (size_t)ws.nsub * HP_NCH;
+    int* act = ws.act + (size_t)b * ws.nsub;
+    // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
+    for (int i0 = 0; i0 < ws.nsub; i0 += 256) {
+        const int i = i0 + tid;
+        int k = 0;
+        if (i < ws.nsub) {
+            double s = 0.0;
+            for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
+            k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+        }
+        scan[tid] = k;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = (tid >= o) ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (k) act[base + scan[tid] - 1] = i;
+        __syncthreads();
+        if (tid == 255) base += scan[255];
+        __syncthreads();
+    }
+    const int na = base;
+    if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
+    if (na <= 1) return;
+    // cepstra of the active frames (+ dither), then remove the mean of each sequence
+    for (int sig = 0; sig < 2; ++sig) {
+        const double* lp = sig ? ylp : xlp;
+        const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
+        double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
+        double sums[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+        for (int k = tid; k < na; k += 256) {
+            const int i = act[k];
+            double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < HP_NCH; ++c) {
+                double v = lp[(size_t)i * HP_NCH + c];
+                if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
+#pragma unroll
+                for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
+            }
+#pragma unroll
+            for (int q = 0; q < HP_NBASIS; ++q) { cep[(size_t)q * ws.nsub + k] = c6[q]; sums[q] += c6[q]; }
+        }
+        for (int q = 0; q < HP_NBASIS; ++q) {
+            const double mu = block_sum(sums[q], red) / (double)na;
+            for (int k = tid; k < na; k += 256) cep[(size_t)q * ws.nsub + k] -= mu;
+            __syncthreads();
+        }
+    }
+}
+
+// ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
+__constant__ double c_modcf[HP_NMOD] = {2, 6, 10, 16, 25, 40, 64, 100, 160, 256};
+__constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
+#define HP_TILE 256
+#define HP_MAXFIR 614
+
+__global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
+    __shared__ double bk[HP_MAXFIR + 1];
+    __shared__ double sxc[HP_TILE + HP_MAXFIR], sxs[HP_TILE + HP_MAXFIR], syc[HP_TILE + HP_MAXFIR], sys_[HP_TILE + HP_MAXFIR];
+    __shared__ double red[8];
+    const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
+    const int na = ws.info[2 * b];
+    if (ws.info[2 * b + 1]) return;
+    const int nfir = c_modnfir[k], nh = nfir / 2;
+    // np.hanning(nfir+1) / sum ; sum of a symmetric Hann window of M points = (M-1)/2
+    for (int i = tid; i <= nfir; i += 256) bk[i] = (0.5 - 0.5 * cospi(2.0 * (double)i / (double)nfir)) / (0.5 * (double)nfir);
+    const double* xc = ws.cep + (((size_t)b * 2 + 0) * HP_NBASIS + basis) * ws.nsub;
+    const double* yc = ws.cep + (((size_t)b * 2 + 1) * HP_NBASIS + basis) * ws.nsub;
+    const double cf = c_modcf[k];
+    const double SQ2 = 1.4142135623730951;
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int t0 = 0; t0 < na; t0 += HP_TILE) {
+        __syncthreads();
+        // demodulated inputs for output samples t0 .. t0+255: input index j = t + nh - i, i = 0..nfir -> j in [t0 - nh, t0 + 255 + nh]
+        for (int e = tid; e < HP_TILE + nfir; e += 256) {
+            const int j = t0 - nh + e;
+            double vx = 0.0, vy = 0.0, c = 1.0, s = 0.0;
+            if (j >= 0 && j < na) {
+                vx = xc[j];
+                vy = yc[j];
+                if (k > 0) {
+                    // sqrt(2) cos(pi n cf / fNyq), n = j + 1, fNyq = 1280
+                    const double ang = M_PI * (double)(j + 1) * cf / 1280.0;
+                    c = SQ2 * cos(ang);
+                    s = SQ2 * sin(ang);
+                }
+            }
+            sxc[e] = vx * c; sxs[e] = vx * s; syc[e] = vy * c; sys_[e] = vy * s;
+        }
+        __syncthreads();
+        const int t = t0 + tid;
+        if (t < na) {
+            // u[t] = sum_i b[i] * z[t + nh - i], z = x c - i x s
+            double ur = 0, ui = 0, vr = 0, vi = 0;
+            const int e0 = tid + nfir;     // LDS index of input j = t + nh
+            for (int i = 0; i <= nfir; ++i) {
+                const double w = bk[i];
+                ur += w * sxc[e0 - i]; ui -= w * sxs[e0 - i];
+                vr += w * syc[e0 - i]; vi -= w * sys_[e0 - i];
+            }
+            double c = 1.0, s = 0.0;
+            if (k > 0) {
+                const double ang = M_PI * (double)(t + 1) * cf / 1280.0;
+                c = SQ2 * cos(ang);
+                s = SQ2 * sin(ang);
+            }
+            const double xf = ur * c - ui * s, yf = vr * c - vi * s;
+            sx += xf; sy += yf; sxx += xf * xf; syy += yf * yf; sxy += xf * yf;
+        }
+    }
+    sx = block_sum(sx, red); sy = block_sum(sy, red); sxx = block_sum(sxx, red); syy = block_sum(syy, red); sxy = block_sum(sxy, red);
+    if (tid == 0) {
+        const double n = (double)na;
+        const double xsum = sxx - sx * sx / n, ysum = syy - sy * sy / n, xy = sxy - sx * sy / n;
+        double cm = 0.0;
+        if (!(xsum < 1.0e-30 || ysum < 1.0e-30)) cm = fabs(xy) / sqrt(xsum * ysum);
+        ws.cm[((size_t)b * HP_NBASIS + basis) * HP_NMOD + k] = cm;
+    }
+}
+
+__global__ void haspi_final_kernel(HaspiWs ws, float* __restrict__ raw, float* __restrict__ mapped, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double w[HP_NMOD] = {1.361, 1.521, 1.164, 0.492, 0.436, 0.690, 1.142, 0.816, 1.576, 2.269};
+    double v = 0.0;
+    if (ws.info[2 * b + 1]) {
+        v = nan("");   // reference raises 'Signal below threshold'
+    } else {
+        for (int k = 0; k < HP_NMOD; ++k) {
+            double a = 0.0;
+            for (int j = 1; j < HP_NBASIS; ++j) a += ws.cm[((size_t)b * HP_NBASIS + j) * HP_NMOD + k];
+            v += w[k] * (a / 5.0);
+        }
+    }
+    if (raw) raw[b] = (float)v;
+    if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.95 * (v - 2.8))));
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
+    const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
+    const int nsub = (n24 + HP_SPACE - 1) / HP_SPACE;
+    size_t o = 0;
+#define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
+    TAKE(win, double, HP_NWIN);
+    TAKE(r24, float, (size_t)B * 2 * n24);
+    TAKE(mid, double, (size_t)B * 2 * n24);
+    TAKE(ctl, double, (size_t)B * 2 * n24 * HP_NCH);
+    TAKE(env, double, (size_t)B * 2 * n24 * HP_NCH);
+    TAKE(bw, double, (size_t)B * 2 * HP_NCH);
+    TAKE(shift, int, (size_t)B * HP_NCH);
+    TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
+    TAKE(act, int, (size_t)B * nsub);
+    TAKE(info, int, (size_t)B * 2);
+    TAKE(cep, double, (size_t)B * 2 * HP_NBASIS * nsub);
+    TAKE(cm, double, (size_t)B * HP_NBASIS * HP_NMOD);
+#undef TAKE
+    if (w) { w->n24 = n24; w->nsub = nsub; }
+    return o;
+}
+
+extern "C" long long nele_metric_haspi_workspace_bytes(int B, int L, int fs_in) { return (long long)haspi_layout(B, L, fs_in, nullptr, nullptr); }
+
+extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
+    const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
+    return (n24 + HP_SPACE - 1) / HP_SPACE;
+}
+
+// dither: NULL (no dither: deterministic) or standard normals [B][2][nsub][32]; row k perturbs the k-th ACTIVE
+// frame (the reference draws randn(n_active, 32) for x, then for y: pyhaspi2.py:362-365).
+extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
+                                 long long workspace_bytes, float* raw, float* mapped, int* info_out, void* stream) {
+    NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_haspi: bad arguments");
+    NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi: fs must be 16000 or 24000 (got %d)", fs_in);
+    if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi: L=%d too short", L);
+    if (workspace_bytes < nele_metric_haspi_workspace_bytes(B, L, fs_in))
+        return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_haspi: workspace too small");
+    HaspiWs ws;
+    haspi_layout(B, L, fs_in, &ws, (char*)workspace);
+    hipStream_t s = as_stream(stream);
+    const size_t total = (size_t)B * 2 * ws.n24 * HP_NCH;
+    const unsigned pw_blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
+    hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, 2), dim3(256), 0, s, x, y, L, fs_in, ws);
+    hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_control_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_signal_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
+    hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_sl_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
+    hipLaunchKernelGGL(haspi_ihc_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + 7) / 8, B, 2), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1);
+    hipLaunchKernelGGL(haspi_mod_kernel, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(haspi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
+    if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 2 * (size_t)B, hipMemcpyDeviceToDevice, s);
+    NELE_CHECK_LAUNCH("nele_metric_haspi");
+    return NELE_OK;
+}

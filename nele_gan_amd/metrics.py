@@ -30,6 +30,15 @@ _lib.lib.nele_metric_siib_workspace_bytes.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_siib_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_siib_workspace_bytes'] = _lib.lib.nele_metric_siib_workspace_bytes.argtypes
 
+declare('nele_metric_haspi', [_P, _P, c_int, c_int, c_int, _P, _P, c_longlong, _P, _P, _P, _P])
+_lib._SIGS['nele_metric_haspi'] = _lib.lib.nele_metric_haspi.argtypes
+_lib.lib.nele_metric_haspi_workspace_bytes.argtypes = [c_int, c_int, c_int]
+_lib.lib.nele_metric_haspi_workspace_bytes.restype = c_longlong
+_lib._SIGS['nele_metric_haspi_workspace_bytes'] = _lib.lib.nele_metric_haspi_workspace_bytes.argtypes
+_lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
+_lib.lib.nele_metric_haspi_nsub.restype = c_int
+_lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
+
 _ws_cache = {}
 
 
@@ -103,6 +112,50 @@ def SIIB_Wrapper_raw_harvard(x, y, fs):
 def SIIB_Wrapper_harvard(x, y, fs):
     assert fs == 16000
     return float(_siib_checked(x, y)[1][0])
+
+
+def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False):
+    """clean x [B,L], degraded y [B,L] -> (raw HASPI v2 [B], mapped [B]).
+    dither: None -> no IHC firing jitter (deterministic score); True -> standard normals drawn on the device
+    (torch generator, optional ``seed``) as the reference does with np.random.randn (pyhaspi2.py:362-365); or a
+    float64 tensor [B,2,nsub,32] whose row k perturbs the k-th active frame (used by the parity tests)."""
+    x, y, _ = _pair(x, y)
+    B, L = x.shape
+    nsub = _lib.lib.nele_metric_haspi_nsub(L, fs)
+    if dither is True:
+        g = None
+        if seed is not None:
+            g = torch.Generator(device=x.device)
+            g.manual_seed(int(seed))
+        dither = torch.randn((B, 2, nsub, 32), dtype=torch.float64, device=x.device, generator=g)
+    if dither is not None:
+        if tuple(dither.shape) != (B, 2, nsub, 32) or dither.dtype != torch.float64:
+            raise ValueError("batch_haspi: dither must be float64 [B, 2, %d, 32]" % nsub)
+        dither = dither.to(x.device).contiguous()
+    nb = _lib.lib.nele_metric_haspi_workspace_bytes(B, L, fs)
+    ws = _workspace('haspi', nb, x.device)
+    raw = torch.empty(B, device=x.device)
+    mapped = torch.empty(B, device=x.device)
+    info = torch.zeros((B, 2), dtype=torch.int32, device=x.device)
+    call('nele_metric_haspi', ptr(x), ptr(y), B, L, int(fs), ptr(dither), ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), stream())
+    if return_info:
+        return raw, mapped, info
+    return raw, mapped
+
+
+def _haspi_checked(x, y, fs):
+    raw, mapped, info = batch_haspi(x, y, fs, dither=True, return_info=True)
+    if int(info[0, 1]):
+        raise Exception('Function ebm_CepCoef: Signal below threshold')     # pyhaspi2.py:357-358
+    return raw, mapped
+
+
+def HASPI_Wrapper_raw_harvard(x, y, fs):
+    return float(_haspi_checked(x, y, fs)[0][0])
+
+
+def HASPI_Wrapper_harvard(x, y, fs):
+    return float(_haspi_checked(x, y, fs)[1][0])
 
 
 def ESTOI_Wrapper_raw_harvard(x, y, fs):

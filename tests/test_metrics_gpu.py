@@ -84,3 +84,44 @@ def test_siib_synthetic_batch_vs_oracle(mt, L):
         assert info[b][0] == M
         ref = siib.siib_wrapper(c[b], y[b], norm=False)
         assert raw[b] == pytest.approx(ref, rel=1e-4, abs=1e-3)
+
+
+def test_haspi_matches_reference_golden_24k(mt):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from make_golden_haspi import golden_dither
+    G = np.load(os.path.join(HERE, 'golden', 'haspi.npz'))
+    x, y = G['x'], G['y']
+    dx, dy = golden_dither(int(G['seed']), len(x), int(G['n_active']))
+    nsub = int(G['n_sub'])
+    d = np.zeros((1, 2, nsub, 32))
+    d[0, 0, :dx.shape[0]] = dx
+    d[0, 1, :dy.shape[0]] = dy
+    raw, mapped, info = mt.batch_haspi(x, y, fs=24000, dither=torch.from_numpy(d), return_info=True)
+    assert int(info[0, 0]) == int(G['n_active']) and int(info[0, 1]) == 0     # silence gate: integer-exact
+    assert float(raw[0]) == pytest.approx(float(G['intel']), rel=1e-4)
+    assert float(mapped[0]) == pytest.approx(1 / (1 + np.exp(-0.95 * (float(G['intel']) - 2.8))), rel=1e-4)
+
+
+def test_haspi_16k_batch_vs_oracle(mt):
+    from nele_gan_amd import synth
+    from oracle import haspi as H
+    c, v = synth.batch(3, 24000, start=80)
+    y = c + v
+    y[2] = c[2]                                                        # identical pair: every |rho| = 1
+    raw, mapped = mt.batch_haspi(c, y, fs=16000, dither=None)
+    raw = raw.cpu().numpy()
+    for b in range(3):
+        ref, _ = H.haspi_v2(c[b], 16000, y[b], 16000)
+        assert raw[b] == pytest.approx(ref, rel=1e-4)
+    assert raw[2] == pytest.approx(float(np.sum(H.WEIGHTS)), rel=1e-6)
+
+
+def test_haspi_random_dither_is_small_and_seeded(mt):
+    from nele_gan_amd import synth
+    c, v = synth.batch(1, 24000, start=90)
+    r0, _ = mt.batch_haspi(c, c + v, dither=None)
+    r1, _ = mt.batch_haspi(c, c + v, dither=True, seed=7)
+    r2, _ = mt.batch_haspi(c, c + v, dither=True, seed=7)
+    assert float(r1[0]) == float(r2[0])
+    assert abs(float(r1[0]) - float(r0[0])) < 0.02 * abs(float(r0[0]))    # N(0, 0.1 dB) jitter: per-mille level effect
