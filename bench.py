@@ -73,10 +73,6 @@ def main():
     from nele_gan_amd.train_nele import GanTrainer, parse_metrics
     metrics = parse_metrics(a.metrics)
     tr = GanTrainer(a.metrics, device='cuda:%d' % local)
-    if world > 1:                                     # identical replicas: broadcast rank 0's weights and u/v buffers
-        for m in (tr.G, tr.D):
-            for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, 0)
     c, v = synth.batch(a.batch, a.length, start=rank * a.batch)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 

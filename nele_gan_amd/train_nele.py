@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import audio_util as au
+from . import dist as ndist
 from . import metrics as mt
 from . import model as M
 from . import ops
@@ -63,14 +64,15 @@ class GanTrainer:
         self.step_g = 0
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        self.world = ndist.world_size()
+        for m in (self.G, self.D, self.D_Qua):
+            if m is not None:
+                ndist.broadcast_module_(m, 0)
 
     # ---------------------------------------------------------------- data-parallel glue
     def _allreduce_grads(self, module):
         if self.world > 1:
-            g = module.flat_parameters().grad
-            torch.distributed.all_reduce(g)
-            g.mul_(1.0 / self.world)
+            ndist.allreduce_mean_(module.flat_parameters().grad)
 
     # ---------------------------------------------------------------- features (dataloader.py:30-42)
     def features(self, clean_wav, noise_wav):
