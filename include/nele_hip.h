@@ -80,13 +80,14 @@ int nele_g_pack(const float* x, const float* y, float* out, int B, int T, int pa
 
 /* model.py:168-205 cLN followed by LeakyReLU (model.py:88-91): Y [B][T][C] -> out (rows pad.. of
  * [B][T+pad][C]); saves the cumulative mean / 1/std per frame for the backward pass. */
-int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, int B, int T,
-                 int C, int pad, float slope, void* stream);
+int nele_cln_chunks(int T);  /* frame chunks per utterance: rows of the partial buffers = B * nele_cln_chunks(T) */
+int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, double* scratch,
+                 int B, int T, int C, int pad, float slope, void* stream);   /* scratch: float64 [B][T][2] */
 /* Backward of the above: dAct [B][T][C] -> dY (rows 0..T-1 of the END-padded [B][T+pade][C]),
- * per-utterance gain/bias gradient partials [B][C] (reduce with nele_colsum). */
+ * gain/bias gradient partials [B * nele_cln_chunks(T)][C] (reduce with nele_colsum). */
 int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
-                 const float* rstd, float* dY, float* dgain_part, float* dbias_part, int B, int T, int C, int pade,
-                 float slope, void* stream);
+                 const float* rstd, float* dY, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
+                 int pade, float slope, void* stream);
 int nele_colsum(const float* part, int rows, int cols, float* out, int accumulate, void* stream);
 
 /* Gradient of model.py:98 exp(3.2*tanh(o)) given the mask itself. */
@@ -112,13 +113,14 @@ int nele_d_layout(const float* src, float* dst, int B, int Cin, int T, int to_nh
  * iterations updating u [N], v [K] in place, then sigma = u . (W v); W = weight_orig as [N][K]. */
 int nele_spectral_norm(const float* W, float* u, float* v, float* sigma, int N, int K, int n_iter, void* stream);
 /* dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma : gradient through W/sigma with u, v constant. */
+int nele_sn_grad_scratch_doubles(int total);
 int nele_sn_grad(const float* dW, const float* W, const float* u, const float* v, const float* sigma, int N, int K,
-                 float* dst, int accumulate, void* stream);
+                 float* dst, int accumulate, double* scratch, void* stream);
 
 /* model.py:123-132: AdaptiveAvgPool2d(1) over act [B][P][64] + fc1/fc2/fc3 (spectral-norm Linear) +
  * LeakyReLU + sigmoid.  mlp_host: HOST array of 9 device pointers {w1,b1,sigma1,w2,b2,sigma2,w3,b3,sigma3}. */
 int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled,
-                     float* h1, float* h2, float* score, void* stream);
+                     float* h1, float* h2, float* score, double* scratch /* float64 [B][32][64] */, void* stream);
 /* Backward of the head: dscore [B][nout] -> dz3, dz2, dz1, dpooled and (gbuf != NULL) the gradient of
  * the last conv activation written into the zero-bordered buffer [B][OH][OW][64] at (oh0, ow0). */
 int nele_gap_mlp_bwd(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,

@@ -56,18 +56,28 @@ __global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restr
 }
 
 // dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma      ([N][K] parameter layout)
-__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ dW, const float* __restrict__ W, const float* __restrict__ u,
-                                                      const float* __restrict__ v, const float* __restrict__ sigma, int N, int K,
-                                                      float* __restrict__ dst, int accumulate) {
+// two passes: per-block partial dot products (fixed order), then the element-wise update.
+#define SNG_CHUNK 4096
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ dW, const float* __restrict__ W,
+                                                     const float* __restrict__ sigma, int total, double* __restrict__ partial) {
     __shared__ double red[8];
-    const int tid = threadIdx.x;
+    const float inv = 1.f / sigma[0];
+    const int i0 = blockIdx.x * SNG_CHUNK;
+    double d = 0.0;
+    for (int i = i0 + threadIdx.x; i < min(total, i0 + SNG_CHUNK); i += 256) d += (double)dW[i] * (double)(W[i] * inv);
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = d;
+}
+
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* __restrict__ dW, const float* __restrict__ u, const float* __restrict__ v,
+                                                      const float* __restrict__ sigma, const double* __restrict__ partial, int nblk, int N,
+                                                      int K, float* __restrict__ dst, int accumulate) {
     const float inv = 1.f / sigma[0];
     double d = 0.0;
-    const int total = N * K;
-    for (int i = tid; i < total; i += 256) d += (double)dW[i] * (double)(W[i] * inv);
-    d = block_sum(d, red);
+    for (int i = 0; i < nblk; ++i) d += partial[i];
     const float dot = (float)d;
-    for (int i = tid; i < total; i += 256) {
+    const int total = N * K, i0 = blockIdx.x * SNG_CHUNK;
+    for (int i = i0 + threadIdx.x; i < min(total, i0 + SNG_CHUNK); i += 256) {
         const int n = i / K, k = i - n * K;
         const float val = (dW[i] - dot * u[n] * v[k]) * inv;
         dst[i] = accumulate ? dst[i] + val : val;
@@ -81,20 +91,30 @@ struct MlpW {
     const float *w3, *b3, *s3;  // [nout][16]
 };
 
-// One block per utterance. act [B][P][64] (P = Hout*Wout positions, channels-last).
-__global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const float* __restrict__ act, int P, MlpW w, int nout, float slope,
-                                                          float* __restrict__ pooled, float* __restrict__ h1, float* __restrict__ h2,
-                                                          float* __restrict__ score) {
-    __shared__ double part[4][64];
-    __shared__ float sp[64], sh1[64], sh2[16];
-    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+// Pooling partial sums: grid (GAP_CHUNKS, B), block 256: act [B][P][64] -> part [B][GAP_CHUNKS][64] (float64)
+#define GAP_CHUNKS 32
+__global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ act, int P, double* __restrict__ part) {
+    __shared__ double sp[4][64];
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+    const int per = (P + GAP_CHUNKS - 1) / GAP_CHUNKS, p0 = ch * per, p1 = min(P, p0 + per);
     const float* a = act + (size_t)b * P * 64;
     double s = 0.0;
-    for (int pos = g; pos < P; pos += 4) s += (double)a[(size_t)pos * 64 + c];
-    part[g][c] = s;
+    for (int pos = p0 + g; pos < p1; pos += 4) s += (double)a[(size_t)pos * 64 + c];
+    sp[g][c] = s;
     __syncthreads();
+    if (tid < 64) part[((size_t)b * GAP_CHUNKS + ch) * 64 + tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+}
+
+// One block per utterance: finish the pooling from the partial sums, then the 3-layer head.
+__global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const double* __restrict__ part, int P, MlpW w, int nout, float slope,
+                                                          float* __restrict__ pooled, float* __restrict__ h1, float* __restrict__ h2,
+                                                          float* __restrict__ score) {
+    __shared__ float sp[64], sh1[64], sh2[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < 64) {
-        const float m = (float)((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / (double)P);
+        double s = 0.0;
+        for (int ch = 0; ch < GAP_CHUNKS; ++ch) s += part[((size_t)b * GAP_CHUNKS + ch) * 64 + tid];
+        const float m = (float)(s / (double)P);
         sp[tid] = m;
         pooled[(size_t)b * 64 + tid] = m;
     }
@@ -226,21 +246,29 @@ extern "C" int nele_spectral_norm(const float* W, float* u, float* v, float* sig
     return NELE_OK;
 }
 
+// scratch: float64 [nele_sn_grad_scratch_doubles(N*K)]
+extern "C" int nele_sn_grad_scratch_doubles(int total) { return (total + SNG_CHUNK - 1) / SNG_CHUNK; }
+
 extern "C" int nele_sn_grad(const float* dW, const float* W, const float* u, const float* v, const float* sigma, int N, int K,
-                            float* dst, int accumulate, void* stream) {
-    NELE_CHECK_ARG(dW && W && u && v && sigma && dst && N > 0 && K > 0, "nele_sn_grad: bad arguments");
-    hipLaunchKernelGGL(sn_grad_kernel, dim3(1), dim3(256), 0, as_stream(stream), dW, W, u, v, sigma, N, K, dst, accumulate);
+                            float* dst, int accumulate, double* scratch, void* stream) {
+    NELE_CHECK_ARG(dW && W && u && v && sigma && dst && scratch && N > 0 && K > 0, "nele_sn_grad: bad arguments");
+    const int total = N * K, nblk = (total + SNG_CHUNK - 1) / SNG_CHUNK;
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), dW, W, sigma, total, scratch);
+    hipLaunchKernelGGL(sn_grad_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), dW, u, v, sigma, scratch, nblk, N, K, dst, accumulate);
     NELE_CHECK_LAUNCH("nele_sn_grad");
     return NELE_OK;
 }
 
 // mlp: 9 device pointers {w1,b1,sigma1,w2,b2,sigma2,w3,b3,sigma3}
+// scratch: float64 [B][32][64] pooling partial sums
 extern "C" int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled, float* h1,
-                                float* h2, float* score, void* stream) {
-    NELE_CHECK_ARG(act && mlp_host && pooled && h1 && h2 && score && B > 0 && P > 0 && nout >= 1 && nout <= 4, "nele_gap_mlp_fwd: bad arguments");
+                                float* h2, float* score, double* scratch, void* stream) {
+    NELE_CHECK_ARG(act && mlp_host && pooled && h1 && h2 && score && scratch && B > 0 && P > 0 && nout >= 1 && nout <= 4,
+                   "nele_gap_mlp_fwd: bad arguments");
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
-    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), act, P, w, nout, slope, pooled, h1, h2, score);
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, as_stream(stream), act, P, scratch);
+    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), scratch, P, w, nout, slope, pooled, h1, h2, score);
     NELE_CHECK_LAUNCH("nele_gap_mlp_fwd");
     return NELE_OK;
 }

@@ -15,54 +15,84 @@ __global__ void g_pack_kernel(const float* __restrict__ x, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------ cLN
-// One block (256 threads) per utterance.
-//   phase 1: wave per frame: s_t = sum_c y, q_t = sum_c y^2 (float32 lanes, float64 wave reduce)
-//   phase 2: cumulative sums over t (float64, serial: T <= a few hundred)
-//   phase 3: normalise, affine, LeakyReLU, store into the next layer's padded buffer
 // cum_mean = S/n, cum_var = (Q - 2 mean S)/n + mean^2, n = C (t+1), eps = 1e-8 (model.py:188-199).
+//   stats kernel : wave per frame, s_t = sum_c y, q_t = sum_c y^2 (float64)              grid (ceil(T/4), B)
+//   apply kernel : block-wide float64 prefix sum over the T frame sums (every block redoes it: T <= 1024 adds),
+//                  then normalise + affine + LeakyReLU a chunk of CLN_FR frames               grid (ceil(T/CLN_FR), B)
 #define CLN_MAX_T 1024
+#define CLN_FR 16
 
-__global__ __launch_bounds__(256) void cln_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ gain,
-                                                      const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ mean,
-                                                      float* __restrict__ rstd, int T, int C, int pad, float slope) {
+__global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict__ Y, double* __restrict__ stats, int T, int C) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* y = Y + ((size_t)b * T + t) * C;
+    double s = 0.0, q = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        const float v = y[c];
+        s += (double)v;
+        q += (double)v * (double)v;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) { stats[((size_t)b * T + t) * 2] = s; stats[((size_t)b * T + t) * 2 + 1] = q; }
+}
+
+// inclusive prefix sums of two float64 sequences of length T (<= 1024) held in LDS; 256 threads, 4 items each
+__device__ __forceinline__ void block_scan2(double* a, double* b2, int T, bool reverse) {
+    __shared__ double ta[256], tb[256];
+    const int tid = threadIdx.x;
+    const int per = (T + 255) / 256;
+    const int lo = tid * per, hi = min(T, lo + per);
+    double sa = 0.0, sb = 0.0;
+    for (int i = lo; i < hi; ++i) {
+        const int j = reverse ? T - 1 - i : i;
+        sa += a[j]; sb += b2[j];
+        a[j] = sa; b2[j] = sb;
+    }
+    ta[tid] = sa; tb[tid] = sb;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const double va = (tid >= o) ? ta[tid - o] : 0.0, vb = (tid >= o) ? tb[tid - o] : 0.0;
+        __syncthreads();
+        ta[tid] += va; tb[tid] += vb;
+        __syncthreads();
+    }
+    const double oa = (tid > 0) ? ta[tid - 1] : 0.0, ob = (tid > 0) ? tb[tid - 1] : 0.0;
+    for (int i = lo; i < hi; ++i) {
+        const int j = reverse ? T - 1 - i : i;
+        a[j] += oa; b2[j] += ob;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void cln_fwd_kernel(const float* __restrict__ Y, const double* __restrict__ stats,
+                                                      const float* __restrict__ gain, const float* __restrict__ bias,
+                                                      float* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int T,
+                                                      int C, int pad, float slope) {
     __shared__ double ss[CLN_MAX_T], qq[CLN_MAX_T];
-    __shared__ float smean[CLN_MAX_T], srstd[CLN_MAX_T];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* y = Y + (size_t)b * T * C;
-    for (int t = wave; t < T; t += 4) {
-        double s = 0.0, q = 0.0;
-        for (int c = lane; c < C; c += 64) {
-            const float v = y[(size_t)t * C + c];
-            s += (double)v;
-            q += (double)v * (double)v;
-        }
-        s = wave_sum(s);
-        q = wave_sum(q);
-        if (lane == 0) { ss[t] = s; qq[t] = q; }
+    __shared__ float smean[CLN_FR], srstd[CLN_FR];
+    const int b = blockIdx.y, tid = threadIdx.x, t0 = blockIdx.x * CLN_FR;
+    for (int t = tid; t < T; t += 256) { ss[t] = stats[((size_t)b * T + t) * 2]; qq[t] = stats[((size_t)b * T + t) * 2 + 1]; }
+    __syncthreads();
+    block_scan2(ss, qq, T, false);
+    if (tid < CLN_FR && t0 + tid < T) {
+        const int t = t0 + tid;
+        const double n = (double)C * (double)(t + 1);
+        const double m = ss[t] / n;
+        const double var = (qq[t] - 2.0 * m * ss[t]) / n + m * m;
+        smean[tid] = (float)m;
+        srstd[tid] = (float)(1.0 / sqrt(var + 1e-8));
+        mean[(size_t)b * T + t] = smean[tid];
+        rstd[(size_t)b * T + t] = srstd[tid];
     }
     __syncthreads();
-    if (tid == 0) {
-        double S = 0.0, Q = 0.0;
-        for (int t = 0; t < T; ++t) {
-            S += ss[t];
-            Q += qq[t];
-            const double n = (double)C * (double)(t + 1);
-            const double m = S / n;
-            const double var = (Q - 2.0 * m * S) / n + m * m;
-            smean[t] = (float)m;
-            srstd[t] = (float)(1.0 / sqrt(var + 1e-8));
-        }
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += 256) {
-        mean[(size_t)b * T + t] = smean[t];
-        rstd[(size_t)b * T + t] = srstd[t];
-    }
-    float* o = out + ((size_t)b * (T + pad) + pad) * C;
-    const int total = T * C;
+    const int nfr = min(CLN_FR, T - t0);
+    const float* y = Y + ((size_t)b * T + t0) * C;
+    float* o = out + ((size_t)b * (T + pad) + pad + t0) * C;
+    const int total = nfr * C;
     for (int i = tid; i < total; i += 256) {
-        const int t = i / C, c = i - t * C;
-        float v = (y[i] - smean[t]) * srstd[t] * gain[c] + bias[c];
+        const int f = i / C, c = i - f * C;
+        float v = (y[i] - smean[f]) * srstd[f] * gain[c] + bias[c];
         v = v > 0.f ? v : slope * v;
         o[i] = v;
     }
@@ -73,63 +103,66 @@ __global__ __launch_bounds__(256) void cln_fwd_kernel(const float* __restrict__ 
 //   dL/dS_t = (-A_t r_t + B_t mu_t r_t^2) / n_t,   dL/dQ_t = -B_t r_t^2 / (2 n_t)
 //   RS_t = sum_{t'>=t} dL/dS_t', RQ_t likewise;   dy[t,c] = dxh r_t + RS_t + 2 y RQ_t.
 // dY is written into an END-padded buffer [B][T+pade][C] (rows >= T stay zero) for the data-gradient GEMM.
+__global__ __launch_bounds__(256) void cln_bwd_stats_kernel(const float* __restrict__ dAct, const float* __restrict__ Y,
+                                                            const float* __restrict__ gain, const float* __restrict__ bias,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            double* __restrict__ ab, int T, int C, float slope) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* y = Y + ((size_t)b * T + t) * C;
+    const float* da = dAct + ((size_t)b * T + t) * C;
+    const float mu = mean[(size_t)b * T + t], r = rstd[(size_t)b * T + t];
+    double a = 0.0, bb = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (y[c] - mu) * r;
+        const float x = xh * gain[c] + bias[c];
+        const float d = da[c] * (x > 0.f ? 1.f : slope) * gain[c];
+        a += (double)d;
+        bb += (double)d * (double)xh;
+    }
+    a = wave_sum(a);
+    bb = wave_sum(bb);
+    if (lane == 0) { ab[((size_t)b * T + t) * 2] = a; ab[((size_t)b * T + t) * 2 + 1] = bb; }
+}
+
+// grid (ceil(T/CLN_FR), B); dgain/dbias partials per (utterance, chunk): [B*nchunks][C]
 __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ dAct, const float* __restrict__ Y,
-                                                      const float* __restrict__ gain, const float* __restrict__ bias,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      float* __restrict__ dY, float* __restrict__ dgain_part,
-                                                      float* __restrict__ dbias_part, int T, int C, int pade, float slope) {
-    __shared__ double sa[CLN_MAX_T], sb[CLN_MAX_T];
-    __shared__ float rs[CLN_MAX_T], rq[CLN_MAX_T], smean[CLN_MAX_T], srstd[CLN_MAX_T];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* y = Y + (size_t)b * T * C;
-    const float* da = dAct + (size_t)b * T * C;
+                                                      const double* __restrict__ ab, const float* __restrict__ gain,
+                                                      const float* __restrict__ bias, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dY,
+                                                      float* __restrict__ dgain_part, float* __restrict__ dbias_part, int T, int C, int pade,
+                                                      float slope) {
+    __shared__ double ds[CLN_MAX_T], dq[CLN_MAX_T];
+    const int b = blockIdx.y, tid = threadIdx.x, t0 = blockIdx.x * CLN_FR;
     for (int t = tid; t < T; t += 256) {
-        smean[t] = mean[(size_t)b * T + t];
-        srstd[t] = rstd[(size_t)b * T + t];
+        const double n = (double)C * (double)(t + 1), r = (double)rstd[(size_t)b * T + t], mu = (double)mean[(size_t)b * T + t];
+        const double A = ab[((size_t)b * T + t) * 2], Bv = ab[((size_t)b * T + t) * 2 + 1];
+        ds[t] = (-A * r + Bv * mu * r * r) / n;
+        dq[t] = -Bv * r * r / (2.0 * n);
     }
     __syncthreads();
-    for (int t = wave; t < T; t += 4) {
-        double a = 0.0, bb = 0.0;
-        const float mu = smean[t], r = srstd[t];
-        for (int c = lane; c < C; c += 64) {
-            const float xh = (y[(size_t)t * C + c] - mu) * r;
-            const float x = xh * gain[c] + bias[c];
-            const float d = da[(size_t)t * C + c] * (x > 0.f ? 1.f : slope) * gain[c];
-            a += (double)d;
-            bb += (double)d * (double)xh;
-        }
-        a = wave_sum(a);
-        bb = wave_sum(bb);
-        if (lane == 0) { sa[t] = a; sb[t] = bb; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double RS = 0.0, RQ = 0.0;
-        for (int t = T - 1; t >= 0; --t) {
-            const double n = (double)C * (double)(t + 1), r = (double)srstd[t], mu = (double)smean[t];
-            RS += (-sa[t] * r + sb[t] * mu * r * r) / n;
-            RQ += -sb[t] * r * r / (2.0 * n);
-            rs[t] = (float)RS;
-            rq[t] = (float)RQ;
-        }
-    }
-    __syncthreads();
-    float* o = dY + (size_t)b * (T + pade) * C;
-    // thread per channel (C <= 256): walks t, accumulates dgain / dbias, writes dy
+    block_scan2(ds, dq, T, true);   // suffix sums
+    const int nfr = min(CLN_FR, T - t0);
+    const float* y = Y + ((size_t)b * T + t0) * C;
+    const float* da = dAct + ((size_t)b * T + t0) * C;
+    float* o = dY + ((size_t)b * (T + pade) + t0) * C;
+    const size_t prow = (size_t)b * gridDim.x + blockIdx.x;
     for (int c = tid; c < C; c += 256) {
         const float g = gain[c], bs = bias[c];
         double dg = 0.0, db = 0.0;
-        for (int t = 0; t < T; ++t) {
-            const float yy = y[(size_t)t * C + c];
-            const float xh = (yy - smean[t]) * srstd[t];
+        for (int f = 0; f < nfr; ++f) {
+            const int t = t0 + f;
+            const float mu = mean[(size_t)b * T + t], r = rstd[(size_t)b * T + t];
+            const float yy = y[(size_t)f * C + c];
+            const float xh = (yy - mu) * r;
             const float x = xh * g + bs;
-            const float dx = da[(size_t)t * C + c] * (x > 0.f ? 1.f : slope);
+            const float dx = da[(size_t)f * C + c] * (x > 0.f ? 1.f : slope);
             dg += (double)dx * (double)xh;
             db += (double)dx;
-            o[(size_t)t * C + c] = dx * g * srstd[t] + rs[t] + 2.f * yy * rq[t];
+            o[(size_t)f * C + c] = dx * g * r + (float)ds[t] + 2.f * yy * (float)dq[t];
         }
-        dgain_part[(size_t)b * C + c] = (float)dg;
-        dbias_part[(size_t)b * C + c] = (float)db;
+        dgain_part[prow * C + c] = (float)dg;
+        dbias_part[prow * C + c] = (float)db;
     }
 }
 
@@ -262,22 +295,31 @@ extern "C" int nele_g_pack(const float* x, const float* y, float* out, int B, in
     return NELE_OK;
 }
 
-extern "C" int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, int B, int T,
-                            int C, int pad, float slope, void* stream) {
-    NELE_CHECK_ARG(Y && gain && bias && out && mean && rstd && B > 0, "nele_cln_fwd: bad arguments");
+// scratch: float64 [B][T][2]; part buffers: [B * nele_cln_chunks(T)][C]
+extern "C" int nele_cln_chunks(int T) { return (T + CLN_FR - 1) / CLN_FR; }
+
+extern "C" int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, double* scratch,
+                            int B, int T, int C, int pad, float slope, void* stream) {
+    NELE_CHECK_ARG(Y && gain && bias && out && mean && rstd && scratch && B > 0, "nele_cln_fwd: bad arguments");
     if (T > CLN_MAX_T) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_cln_fwd: T=%d > %d", T, CLN_MAX_T);
-    hipLaunchKernelGGL(cln_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), Y, gain, bias, out, mean, rstd, T, C, pad, slope);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, Y, scratch, T, C);
+    hipLaunchKernelGGL(cln_fwd_kernel, dim3((T + CLN_FR - 1) / CLN_FR, B), dim3(256), 0, s, Y, scratch, gain, bias, out, mean, rstd, T, C, pad,
+                       slope);
     NELE_CHECK_LAUNCH("nele_cln_fwd");
     return NELE_OK;
 }
 
 extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
-                            const float* rstd, float* dY, float* dgain_part, float* dbias_part, int B, int T, int C, int pade,
-                            float slope, void* stream) {
-    NELE_CHECK_ARG(dAct && Y && gain && bias && mean && rstd && dY && dgain_part && dbias_part && B > 0, "nele_cln_bwd: bad arguments");
+                            const float* rstd, float* dY, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
+                            int pade, float slope, void* stream) {
+    NELE_CHECK_ARG(dAct && Y && gain && bias && mean && rstd && dY && dgain_part && dbias_part && scratch && B > 0,
+                   "nele_cln_bwd: bad arguments");
     if (T > CLN_MAX_T) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_cln_bwd: T=%d > %d", T, CLN_MAX_T);
-    hipLaunchKernelGGL(cln_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dAct, Y, gain, bias, mean, rstd, dY, dgain_part,
-                       dbias_part, T, C, pade, slope);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(cln_bwd_stats_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, dAct, Y, gain, bias, mean, rstd, scratch, T, C, slope);
+    hipLaunchKernelGGL(cln_bwd_kernel, dim3((T + CLN_FR - 1) / CLN_FR, B), dim3(256), 0, s, dAct, Y, scratch, gain, bias, mean, rstd, dY,
+                       dgain_part, dbias_part, T, C, pade, slope);
     NELE_CHECK_LAUNCH("nele_cln_bwd");
     return NELE_OK;
 }

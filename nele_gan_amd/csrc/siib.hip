@@ -67,9 +67,12 @@ __global__ void siib_g2_kernel(double* __restrict__ g2) {
 // frame f of the tiled signal: samples x[(200 f + j) mod L], j < 400 (zero beyond M*L: intel.py:28-31 pads)
 __device__ __forceinline__ double frame_db(const float* __restrict__ x, int L, long long total, int f, int lane) {
     double s = 0.0;
+    const long long p0 = (long long)SB_SHIFT * f;
+    int q = (int)(p0 % L);
     for (int j = lane; j < SB_WLEN; j += 64) {
-        const long long p = (long long)SB_SHIFT * f + j;
-        const double v = (p < total) ? (double)x[p % L] * hann400(j) : 0.0;
+        int qq = q + j;
+        while (qq >= L) qq -= L;
+        const double v = (p0 + j < total) ? (double)x[qq] * hann400(j) : 0.0;
         s += v * v;
     }
     s = wave_sum(s);
@@ -107,24 +110,29 @@ __device__ double kth_largest(const double* __restrict__ v, int n, int r, double
     return cur;
 }
 
-// one block per utterance: s1 + s2
-__global__ __launch_bounds__(256) void siib_vad_kernel(const float* __restrict__ x, int L, SiibWs ws) {
-    __shared__ double red[8];
-    __shared__ int scan[256];
-    __shared__ int base;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xb = x + (size_t)b * L;
-    double* xdb = ws.xdb + (size_t)b * ws.NT;
-    int* info = ws.info + 4 * b;
-    // ---- s1: base signal
-    const int n1 = nframes_of(L);
-    for (int f = wave; f < n1; f += 4) {
-        const double e = frame_db(xb, L, L, f, lane);
-        if (lane == 0) xdb[f] = e;
+// s1a / s2a: frame power (dB) of the base (tiled = 0) or M-times tiled (tiled = 1) clean signal.
+// grid (ceil(NT/4), B), block 256 (one wave per frame)
+__global__ __launch_bounds__(256) void siib_db_kernel(const float* __restrict__ x, int L, SiibWs ws, int tiled) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long total = L;
+    int nf = nframes_of(L);
+    if (tiled) {
+        total = (long long)ws.info[4 * b] * L;
+        nf = ws.info[4 * b + 1];
     }
-    __syncthreads();
-    int ind = round_half_even_pos((double)n1 * 0.999) - 1;
-    double thr = kth_largest(xdb, n1, n1 - 1 - ind, red, nullptr) - 40.0;
+    if (f >= nf || f >= ws.NT) return;
+    const double e = frame_db(x + (size_t)b * L, L, total, f, lane);
+    if (lane == 0) ws.xdb[(size_t)b * ws.NT + f] = e;
+}
+
+// s1b: VAD on the base signal -> active duration -> replication factor M (intel.py:84-97). grid B, block 256
+__global__ __launch_bounds__(256) void siib_m_kernel(int L, SiibWs ws) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* xdb = ws.xdb + (size_t)b * ws.NT;
+    const int n1 = nframes_of(L);
+    const int ind = round_half_even_pos((double)n1 * 0.999) - 1;
+    const double thr = kth_largest(xdb, n1, n1 - 1 - ind, red, nullptr) - 40.0;
     int cnt = 0;
     for (int f = tid; f < n1; f += 256) cnt += (xdb[f] > thr) ? 1 : 0;
     const int nact1 = (int)block_sum((double)cnt, red);
@@ -133,23 +141,25 @@ __global__ __launch_bounds__(256) void siib_vad_kernel(const float* __restrict__
     if (dur < 20.0) M = (int)floor(25.0 / dur);
     int status = 0;
     if (M > SB_MMAX) { M = SB_MMAX; status = 1; }
-    // ---- s2: tiled signal
-    const long long total = (long long)M * L;
-    const int n2 = nframes_of(total);
-    if (n2 > ws.NT) {  // cannot happen with M <= SB_MMAX and NT sized for it
-        if (tid == 0) { info[0] = M; info[1] = n2; info[2] = 0; info[3] = 2; }
-        return;
+    if (tid == 0) {
+        int* info = ws.info + 4 * b;
+        info[0] = M; info[1] = nframes_of((long long)M * L); info[2] = 0; info[3] = status;
     }
-    __syncthreads();
-    if (M > 1) {
-        for (int f = wave; f < n2; f += 4) {
-            const double e = frame_db(xb, L, total, f, lane);
-            if (lane == 0) xdb[f] = e;
-        }
-        __syncthreads();
-        ind = round_half_even_pos((double)n2 * 0.999) - 1;
-        thr = kth_largest(xdb, n2, n2 - 1 - ind, red, nullptr) - 40.0;
-    }
+}
+
+// s2b: VAD on the tiled signal + ordered compaction of the active frames. grid B, block 256
+__global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
+    __shared__ double red[8];
+    __shared__ int scan[256];
+    __shared__ int base;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* xdb = ws.xdb + (size_t)b * ws.NT;
+    int* info = ws.info + 4 * b;
+    int n2 = info[1];
+    int status = info[3];
+    if (n2 > ws.NT) { n2 = ws.NT; status |= 2; }
+    const int ind = round_half_even_pos((double)n2 * 0.999) - 1;
+    const double thr = kth_largest(xdb, n2, n2 - 1 - ind, red, nullptr) - 40.0;
     if (tid == 0) base = 0;
     __syncthreads();
     for (int f0 = 0; f0 < n2; f0 += 256) {
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256) void siib_vad_kernel(const float* __restrict__
         int na = base;
         if (na > ws.NA) { na = ws.NA; status |= 4; }
         if (na < SB_K + 1) status |= 8;  // not enough active frames
-        info[0] = M; info[1] = n2; info[2] = na; info[3] = status;
+        info[2] = na; info[3] = status;
     }
 }
 
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(256) void siib_vad_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws) {
     __shared__ double sx[SB_WLEN], sy[SB_WLEN], cs[SB_WLEN], sn[SB_WLEN];
     __shared__ double px[SB_NBIN], py[SB_NBIN];
+    __shared__ double2 Ax[SB_WLEN], Ay[SB_WLEN];
     const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     const int* info = ws.info + 4 * b;
     const int na = info[2];
@@ -189,30 +200,53 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     const int f = ws.list[(size_t)b * ws.NA + k];
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
+    const long long p0 = (long long)SB_SHIFT * f;
+    const int q0 = (int)(p0 % L);
     for (int j = tid; j < SB_WLEN; j += 256) {
-        const long long p = (long long)SB_SHIFT * f + j;
+        int q = q0 + j;
+        while (q >= L) q -= L;
         const double w = hann400(j);
-        const bool in = p < total;
-        sx[j] = in ? (double)xb[p % L] * w : 0.0;
-        sy[j] = in ? (double)yb[p % L] * w : 0.0;
+        const bool in = p0 + j < total;
+        sx[j] = in ? (double)xb[q] * w : 0.0;
+        sy[j] = in ? (double)yb[q] * w : 0.0;
         double s_, c_;
         sincospi((double)j / 200.0, &s_, &c_);
         cs[j] = c_;
         sn[j] = s_;
     }
     __syncthreads();
-    if (tid < SB_NBIN) {
-        double xr = 0, xi = 0, yr = 0, yi = 0;
-        int idx = 0;  // (tid * n) mod 400
-        for (int n = 0; n < SB_WLEN; ++n) {
-            const double c = cs[idx], s = sn[idx];
-            xr += sx[n] * c; xi -= sx[n] * s;
-            yr += sy[n] * c; yi -= sy[n] * s;
-            idx += tid;
-            if (idx >= SB_WLEN) idx -= SB_WLEN;
+    // 400-point DFT as 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2):
+    //   A[n2][k1] = W400^(n2 k1) * sum_n1 x[20 n1 + n2] W20^(n1 k1);   X[k] = sum_n2 A[n2][k1] W20^(n2 k2)
+    for (int o = tid; o < 2 * SB_WLEN; o += 256) {
+        const int sig = o / SB_WLEN, idx = o - sig * SB_WLEN, n2 = idx / 20, k1 = idx - n2 * 20;
+        const double* src = sig ? sy : sx;
+        double ar = 0.0, ai = 0.0;
+        int t = 0;  // (n1 * k1) mod 20
+        for (int n1 = 0; n1 < 20; ++n1) {
+            const double v = src[20 * n1 + n2];
+            ar += v * cs[20 * t];
+            ai -= v * sn[20 * t];
+            t += k1;
+            if (t >= 20) t -= 20;
         }
-        px[tid] = xr * xr + xi * xi;
-        py[tid] = yr * yr + yi * yi;
+        const double c2 = cs[n2 * k1], s2 = sn[n2 * k1];
+        (sig ? Ay : Ax)[idx] = make_double2(ar * c2 + ai * s2, ai * c2 - ar * s2);
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * SB_NBIN; o += 256) {
+        const int sig = o / SB_NBIN, kk = o - sig * SB_NBIN, k2 = kk / 20, k1 = kk - k2 * 20;
+        const double2* A = sig ? Ay : Ax;
+        double xr = 0.0, xi = 0.0;
+        int t = 0;  // (n2 * k2) mod 20
+        for (int n2 = 0; n2 < 20; ++n2) {
+            const double2 a = A[n2 * 20 + k1];
+            const double c = cs[20 * t], s_ = sn[20 * t];
+            xr += a.x * c + a.y * s_;
+            xi += a.y * c - a.x * s_;
+            t += k2;
+            if (t >= 20) t -= 20;
+        }
+        (sig ? py : px)[kk] = xr * xr + xi * xi;
     }
     __syncthreads();
     if (tid < 2 * SB_J) {
@@ -225,35 +259,57 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     }
 }
 
-// grid (B), block 64: lanes 0..55 = (signal, band) rows: s4
+// grid (B), block 64: lanes 0..55 = (signal, band) rows: s4.  Rows are streamed through LDS in chunks of 64
+// frames (coalesced loads/stores); the masking recurrence itself is serial over frames per row.
+#define SB_CH 64
 __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws) {
+    __shared__ double buf[2 * SB_J][SB_CH + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
-    if (tid >= 2 * SB_J || na < 1) return;
-    double* row = ws.XL + ((size_t)b * 2 * SB_J + tid) * ws.NA;
-    double eX = row[0];
-    for (int i = 1; i < na; ++i) eX = fmin(eX, row[i]);
+    if (na < 1) return;
+    double* base = ws.XL + (size_t)b * 2 * SB_J * ws.NA;
+    // band minima (before masking)
+    double eX = 1e300;
+    for (int r = 0; r < 2 * SB_J; ++r) {
+        double m = 1e300;
+        for (int i = tid; i < na; i += 64) m = fmin(m, base[(size_t)r * ws.NA + i]);
+        for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+        if (tid == r) eX = m;
+    }
     double lt[SB_TF];
 #pragma unroll
     for (int m = 0; m < SB_TF; ++m) lt[m] = log((double)(m + 1)) / log((double)SB_TF);
-    // window[m] = current value of row[i+m]
-    double win[SB_TF];
+    // pend[m] = masking level already imposed on frame (i + 1 + m) by frames <= i
+    double pend[SB_TF - 1];
 #pragma unroll
-    for (int m = 0; m < SB_TF; ++m) win[m] = (m < na) ? row[m] : 0.0;
+    for (int m = 0; m < SB_TF - 1; ++m) pend[m] = -1e300;
     double sum = 0.0;
-    for (int i = 0; i < na; ++i) {
-        const double v = win[0];  // final (all earlier maskers applied)
+    for (int c0 = 0; c0 < na; c0 += SB_CH) {
+        const int n = min(SB_CH, na - c0);
+        __syncthreads();
+        for (int r = 0; r < 2 * SB_J; ++r)
+            if (tid < n) buf[r][tid] = base[(size_t)r * ws.NA + c0 + tid];
+        __syncthreads();
+        if (tid < 2 * SB_J) {
+            for (int i = 0; i < n; ++i) {
+                const double v = fmax(buf[tid][i], pend[0]);
 #pragma unroll
-        for (int m = 1; m < SB_TF; ++m) {
-            const double fm = v - (v - eX) * lt[m];
-            win[m - 1] = fmax(win[m], fm);
+                for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = fmax(pend[m], v - (v - eX) * lt[m]);
+                pend[SB_TF - 2] = v - (v - eX) * lt[SB_TF - 1];
+                buf[tid][i] = v;
+                sum += v;
+            }
         }
-        win[SB_TF - 1] = (i + SB_TF < na) ? row[i + SB_TF] : 0.0;
-        row[i] = v;
-        sum += v;
+        __syncthreads();
+        for (int r = 0; r < 2 * SB_J; ++r)
+            if (tid < n) base[(size_t)r * ws.NA + c0 + tid] = buf[r][tid];
     }
+    // mean removal
     const double mu = sum / (double)na;
-    for (int i = 0; i < na; ++i) row[i] -= mu;
+    for (int r = 0; r < 2 * SB_J; ++r) {
+        const double mr = __shfl(mu, r, 64);
+        for (int i = tid; i < na; i += 64) base[(size_t)r * ws.NA + i] -= mr;
+    }
 }
 
 // grid (420, B, 2), block 256: s5
@@ -321,6 +377,13 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     __shared__ double Us[16][65], Xt[16][65], Yt[16][65];
     __shared__ double red[3][64][17];
     const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    if (t0 >= ws.info[4 * b + 2] - SB_K + 1) {      // tile beyond n_cols: all zero padding
+        if (tid < 192) {
+            const int q = tid / 64, r = tid - q * 64;
+            if (ti + r < SB_D) ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = 0.0;
+        }
+        return;
+    }
     const double* U = ws.C + (size_t)b * SB_D * SB_D;
     const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
     const double* Y = X + (size_t)SB_D * ws.NA;
@@ -450,7 +513,10 @@ extern "C" int nele_metric_siib(const float* x, const float* y, int B, int L, vo
     }
     rocblas_set_stream(g_handle, s);
     hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
-    hipLaunchKernelGGL(siib_vad_kernel, dim3(B), dim3(256), 0, s, x, L, ws);
+    hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
+    hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
+    hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
+    hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws);
     hipLaunchKernelGGL(siib_mask_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, 2), dim3(256), 0, s, ws);

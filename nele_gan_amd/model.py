@@ -145,8 +145,10 @@ class _GBuffers:
         self.da5 = _empty((B, T, 64), dev)
         self.do2 = _empty((B, T, 64), dev)
         self.dpre1 = _empty((B, T, 64), dev)
-        self.gpart = _empty((B, 256), dev)
-        self.bpart = _empty((B, 256), dev)
+        self.nchunks = int(ops._lib.lib.nele_cln_chunks(T))
+        self.gpart = _empty((B * self.nchunks, 256), dev)
+        self.bpart = _empty((B * self.nchunks, 256), dev)
+        self.cln_scratch = torch.empty((B, T, 2), dtype=torch.float64, device=dev)
         # data-gradient geometries: input = END-padded dY_l [B][T+k-1][cout], output = dA_l [B][T][cin]
         self.gb = [Geom(1, T + k - 1, cout, 1, T, 1, k, 1, T, cin) for (cin, cout, k) in _G_LAYERS]
         # weight-gradient geometries: A = padded input of layer l, dOut = dY_l (buffer width T+k-1)
@@ -247,8 +249,8 @@ class Generator_Conv1D_cLN(nn.Module):
                 nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
             else:
                 nxt, pad = bf.a5, 0
-            call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]), B, T,
-                 cout, pad, SLOPE, stream())
+            call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
+                 ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
         ops.conv_gemm(bf.a5, wf[6], self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
         mask = _empty((B, T, 64), dev)
         ops.conv_gemm(bf.h1, wf[7], self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
@@ -278,9 +280,9 @@ class Generator_Conv1D_cLN(nn.Module):
             cin, cout, k = _G_LAYERS[l]
             seq = self.convolutions[l]
             call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
-                 ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), B, T, cout, k - 1, SLOPE, stream())
-            call('nele_colsum', ptr(bf.gpart), B, cout, ptr(seq[2].gain0.grad), 1, stream())
-            call('nele_colsum', ptr(bf.bpart), B, cout, ptr(seq[2].bias0.grad), 1, stream())
+                 ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
+            call('nele_colsum', ptr(bf.gpart), B * bf.nchunks, cout, ptr(seq[2].gain0.grad), 1, stream())
+            call('nele_colsum', ptr(bf.bpart), B * bf.nchunks, cout, ptr(seq[2].bias0.grad), 1, stream())
             ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad)
             if l > 0:
                 ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
@@ -328,7 +330,8 @@ class _DBuffers:
         self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
         nws = max(ops.wgrad_workspace_floats(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gw))
         self.ws = _empty((nws,), dev)
-        self.tmpw = _empty((64 * 48 * 81 + 64,), dev)   # largest weight tensor (sigma-normalised gradient staging)
+        self.tmpw = _empty((64 * 48 * 81 + 64,), dev)
+        self.scratch64 = torch.empty((max(B * 32 * 64, 128),), dtype=torch.float64, device=dev)   # largest weight tensor (sigma-normalised gradient staging)
 
 
 class _DFn(torch.autograd.Function):
@@ -440,7 +443,7 @@ class _DiscriminatorBase(nn.Module):
             a = bf.act[l]
         score = _empty((B, self._nout), dev)
         call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),
-             stream())
+             ptr(bf.scratch64), stream())
         self._last_score = score
         return key
 
@@ -475,7 +478,7 @@ class _DiscriminatorBase(nn.Module):
                 tmpb = bf.tmpw[N * K:N * K + N]
                 call('nele_mlp_wgrad', ptr(dz), ptr(xin), B, N, K, ptr(bf.tmpw), c_void_p(tmpb.data_ptr()), stream())
                 call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
-                     c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, stream())
+                     c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
         ddin = None
         for l in range(len(_D_CONVS) - 1, -1, -1):
@@ -489,7 +492,7 @@ class _DiscriminatorBase(nn.Module):
                 tmpb = bf.tmpw[N * K:N * K + N]
                 ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False)
                 call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
-                     c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, stream())
+                     c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
             if l > 0:
                 ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))

@@ -15,8 +15,9 @@ _SIGS = {
     'nele_conv_wgrad': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep': [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
-    'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
-    'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_cln_chunks': [c_int],
     'nele_colsum': [_P, c_int, c_int, _P, c_int, _P],
     'nele_exptanh_bwd': [_P, _P, _P, c_longlong, _P],
     'nele_energy_norm_fwd': [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, _P],
@@ -24,8 +25,9 @@ _SIGS = {
     'nele_d_pack': [_P, _P, _P, _P, c_int, c_int, _P],
     'nele_d_layout': [_P, _P, c_int, c_int, c_int, c_int, _P],
     'nele_spectral_norm': [_P, _P, _P, _P, c_int, c_int, c_int, _P],
-    'nele_sn_grad': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P],
-    'nele_gap_mlp_fwd': [_P, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P],
+    'nele_sn_grad': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P],
+    'nele_sn_grad_scratch_doubles': [c_int],
+    'nele_gap_mlp_fwd': [_P, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P, _P],
     'nele_gap_mlp_bwd': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, _P, _P, _P, _P, _P, _P],
     'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
