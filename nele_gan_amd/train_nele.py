@@ -64,6 +64,7 @@ class GanTrainer:
         self.step_g = 0
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
+        self._side = None
         self.world = ndist.world_size()
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
@@ -139,6 +140,9 @@ class GanTrainer:
     def d_step(self, din, target):
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din)
+        return self._d_finish(score, target)
+
+    def _d_finish(self, score, target):
         loss = self.MSELoss(score, target)
         loss.backward()
         self._allreduce_grads(self.D)
@@ -152,9 +156,25 @@ class GanTrainer:
         f = feats or self.features(clean_wav, noise_wav)
         lg = self.g_step(f['clean_band'], f['noise_band'])
         enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
-        tgt = self.true_metrics(clean_wav, enh, noise_wav)
+        # D's forward pass does not need the targets: enqueue it first (main stream), then the metric kernels on
+        # a side stream so that both run concurrently; the loss waits for the targets
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
-        ld = self.d_step(din, tgt)
+        self.optimizer_d.zero_grad()
+        score = self.D.forward_packed(din)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            tgt = self.true_metrics(clean_wav, enh, noise_wav)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        tgt.record_stream(main)
+        enh.record_stream(self._side)
+        main.wait_event(done)
+        ld = self._d_finish(score, tgt)
         return lg, ld, tgt
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
