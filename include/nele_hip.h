@@ -60,6 +60,15 @@ int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* s
 int nele_conv_gemm(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
                    int epi, float slope, const int* geom_host, void* stream);
 
+/* Span-staged variant of nele_conv_gemm for 2-D convolutions with long output rows (Wout >= 64, N <= 64): per kernel
+ * row the input span of a block's 256 output positions is staged in LDS once and re-read KW times.  Wfrag is Wg
+ * [N][Ktot] re-ordered by nele_weight_prep_frag to [Ktot/8][ceil(N/16)][64 lanes][2] (one coalesced load per MFMA
+ * operand).  a_elems = elements of the input buffer (32-bit offsets are used inside).  Same epilogues. */
+int nele_weight_prep_frag(const float* Wg, int N, int Ktot, float* Wfrag, void* stream);
+int nele_conv_span_supported(int M, int N, const int* geom_host, int KH, int KW);
+int nele_conv_span(const float* A, const float* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                   float slope, const int* geom_host, int KH, int KW, long long a_elems, void* stream);
+
 /* Weight gradient dW[n][ci][kh][kw] (+)= sum_m dOut[m][n] * A_view[m][(kh,kw,ci)], db[n] (+)= sum_m dOut[m][n]
  * (autograd of the layers above).  Split over m across workgroups, partials summed in fixed order.
  * workspace_floats >= nele_conv_wgrad_workspace_floats(M, N, Ktot, &splits). */

@@ -127,10 +127,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -161,6 +162,157 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
                 p.out[o_off + n] = v;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ span-staged conv
+// Same product as conv_gemm_kernel, for 2-D convolutions whose output rows are long (Wout >= 64):
+// the 256 consecutive output positions of a block form <= SPAN_MAXRUN runs inside output rows; for the
+// current kernel row kh each run needs ONE contiguous input span of (len + KW - 1) * C floats, which is
+// staged in LDS once and then read KW times with shifted addresses (im2col traffic / KW).  Weights
+// arrive in "fragment-major" order (one coalesced 512 B load per MFMA operand: nele_weight_prep_frag),
+// so the K loop has no barrier; barriers only bracket the span staging (KH times per block).
+#define SPAN_MAXRUN 8
+
+struct SpanArgs {
+    const float* A;
+    const float* Wfrag;  // [Ktot/8][NT][64] float2, NT = number of 16-wide n tiles
+    const float* bias;
+    const float* aux;
+    float* out;
+    int M, N, NT;
+    int epi;
+    float slope;
+    int KH, KW;
+    ConvGeom g;
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_span_kernel(SpanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float span[];
+    __shared__ int run_gbase[SPAN_MAXRUN];   // element offset of the run's span origin in A, for kh = 0
+    __shared__ int run_len[SPAN_MAXRUN];     // output positions in the run
+    __shared__ int run_off[SPAN_MAXRUN + 1]; // float offset of the run's span in LDS
+    __shared__ int posbase[GEMM_BM];
+    __shared__ int nrun_s;
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * GEMM_BM;
+    const int mcount = min(GEMM_BM, p.M - m0);
+    const int halo = (p.KW - 1) * g.C;
+
+    if (tid == 0) {
+        int b, ho, wo;
+        decode_m(m0, g, b, ho, wo);
+        int left = mcount, r = 0, off = 0, done = 0;
+        while (left > 0 && r < SPAN_MAXRUN) {
+            const int len = min(left, g.Wout - wo);
+            run_gbase[r] = (int)((((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C);  // fits int: checked on the host
+            run_len[r] = len;
+            run_off[r] = off;
+            for (int i = 0; i < len; ++i) posbase[done + i] = off + i * g.C;
+            off += len * g.C + halo;
+            done += len;
+            left -= len;
+            wo = 0;
+            if (++ho == g.Hout) { ho = 0; ++b; }
+            ++r;
+        }
+        run_off[r] = off;
+        nrun_s = r;
+        for (int i = done; i < GEMM_BM; ++i) posbase[i] = 0;
+    }
+    __syncthreads();
+    const int nrun = nrun_s;
+    int pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = posbase[wave * 64 + i * 16 + (lane & 15)];
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int lg = lane >> 4;
+    const int steps_per_seg = g.seglen / GEMM_BK;
+    const float2* wf = reinterpret_cast<const float2*>(p.Wfrag) + lane;
+    int ks = 0;
+    for (int kh = 0; kh < p.KH; ++kh) {
+        __syncthreads();  // previous segment fully consumed
+        for (int r = 0; r < nrun; ++r) {
+            const int nfl = run_len[r] * g.C + halo;
+            const float* src = p.A + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
+            float* dst = span + run_off[r];
+            for (int e = tid * 4; e < nfl; e += 1024) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
+        }
+        __syncthreads();
+        float2 bf[TN], bn[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = wf[((size_t)ks * p.NT + j) * 64];
+        for (int s = 0; s < steps_per_seg; ++s, ++ks) {
+            const bool more = (s + 1 < steps_per_seg) || (kh + 1 < p.KH);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bn[j] = wf[((size_t)(ks + 1) * p.NT + j) * 64];
+            }
+            float2 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const float2*>(span + pb[i] + s * GEMM_BK + 2 * lg);
+            // two passes over the tiles so that the two MFMAs of one accumulator are 4*TN issues apart
+            // (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = bn[j];
+            }
+        }
+    }
+
+    const int li = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wave * 64 + i * 16 + 4 * lg + reg;
+            if (m >= p.M) continue;
+            int b, ho, wo;
+            decode_m(m, g, b, ho, wo);
+            const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+            const size_t x_off = (size_t)m * g.OC;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = j * 16 + li;
+                if (n >= p.N) continue;
+                float v = acc[i][j][reg];
+                switch (p.epi) {
+                    case EPI_BIAS: v += p.bias[n]; break;
+                    case EPI_BIAS_LRELU: v += p.bias[n]; v = v > 0.f ? v : p.slope * v; break;
+                    case EPI_MASK_LRELU_GRAD: v = p.aux[x_off + n] > 0.f ? v : p.slope * v; break;
+                    case EPI_BIAS_EXPTANH: v += p.bias[n]; v = expf(3.2f * tanhf(v)); break;
+                    default: break;
+                }
+                p.out[o_off + n] = v;
+            }
+        }
+    }
+}
+
+// W in GEMM layout [N][Ktot] -> fragment-major [Ktot/8][NT][64][2]: element (ks, j, lane, e) =
+// W[j*16 + (lane&15)][ks*8 + 2*(lane>>4) + e] (zero for n >= N).
+__global__ void weight_frag_kernel(const float* __restrict__ Wg, int N, int Ktot, int NT, float* __restrict__ Wfrag) {
+    const int total = (Ktot / 8) * NT * 64 * 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 1, lane = (idx >> 1) & 63, t = idx >> 7, j = t % NT, ks = t / NT;
+        const int n = j * 16 + (lane & 15), kk = ks * 8 + 2 * (lane >> 4) + e;
+        Wfrag[idx] = (n < N) ? Wg[(size_t)n * Ktot + kk] : 0.f;
     }
 }
 
@@ -351,6 +503,60 @@ extern "C" int nele_conv_gemm(const float* A, const float* Wg, const float* bias
     else if (N <= 48) hipLaunchKernelGGL(conv_gemm_kernel<3>, dim3(gx, 1), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_gemm_kernel<4>, dim3(gx, (N + 63) / 64), dim3(256), 0, s, p);
     NELE_CHECK_LAUNCH("nele_conv_gemm");
+    return NELE_OK;
+}
+
+extern "C" int nele_weight_prep_frag(const float* Wg, int N, int Ktot, float* Wfrag, void* stream) {
+    NELE_CHECK_ARG(Wg && Wfrag && N > 0 && Ktot > 0 && Ktot % 8 == 0, "nele_weight_prep_frag: bad arguments (Ktot must be a multiple of 8)");
+    const int NT = (N + 15) / 16;
+    const int total = (Ktot / 8) * NT * 128;
+    hipLaunchKernelGGL(weight_frag_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, as_stream(stream), Wg, N, Ktot, NT, Wfrag);
+    NELE_CHECK_LAUNCH("nele_weight_prep_frag");
+    return NELE_OK;
+}
+
+// 1 if nele_conv_span supports this geometry (long output rows, span fits in LDS twice per CU), else 0
+extern "C" int nele_conv_span_supported(int M, int N, const int* geom, int KH, int KW) {
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    if (N > 64 || g.seglen % 8 || g.C % 4 || g.Wout < 64 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
+    const int maxrun = (GEMM_BM + g.Wout - 1) / g.Wout + 1;
+    if (maxrun > SPAN_MAXRUN) return 0;
+    const long long fl = (long long)GEMM_BM * g.C + (long long)maxrun * (KW - 1) * g.C;
+    if (fl * 4 > 76 * 1024) return 0;
+    return 1;
+}
+
+extern "C" int nele_conv_span(const float* A, const float* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                              float slope, const int* geom, int KH, int KW, long long a_elems, void* stream) {
+    NELE_CHECK_ARG(A && Wfrag && out && geom, "nele_conv_span: null pointer");
+    if (!nele_conv_span_supported(M, N, geom, KH, KW)) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_span: geometry not supported");
+    NELE_CHECK_ARG(a_elems < 2147483647LL, "nele_conv_span: input buffer too large for 32-bit offsets");
+    SpanArgs p;
+    p.A = A; p.Wfrag = Wfrag; p.bias = bias; p.aux = aux; p.out = out; p.M = M; p.N = N; p.NT = (N + 15) / 16; p.epi = epi; p.slope = slope;
+    p.KH = KH; p.KW = KW;
+    memcpy(&p.g, geom, sizeof(ConvGeom));
+    NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_span: epilogue needs bias");
+    NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_span: epilogue needs aux");
+    const int maxrun = (GEMM_BM + p.g.Wout - 1) / p.g.Wout + 1;
+    const size_t lds = ((size_t)GEMM_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C) * sizeof(float);
+    const int gx = (M + GEMM_BM - 1) / GEMM_BM;
+    hipStream_t s = as_stream(stream);
+    static bool attr_done = false;
+    if (!attr_done) {  // allow > 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    switch (p.NT) {
+        case 1: hipLaunchKernelGGL(conv_span_kernel<1>, dim3(gx), dim3(256), lds, s, p); break;
+        case 2: hipLaunchKernelGGL(conv_span_kernel<2>, dim3(gx), dim3(256), lds, s, p); break;
+        case 3: hipLaunchKernelGGL(conv_span_kernel<3>, dim3(gx), dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL(conv_span_kernel<4>, dim3(gx), dim3(256), lds, s, p); break;
+    }
+    NELE_CHECK_LAUNCH("nele_conv_span");
     return NELE_OK;
 }
 

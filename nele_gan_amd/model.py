@@ -325,6 +325,9 @@ class _DBuffers:
             self.gb.append(Geom(Ho + 2 * p, Wo + 2 * p, cout, Hi, Wi, k, k, OH, OW, OC, 0, 0, o0, o0))
             # weight gradient: A = layer input, dOut = gbuf[l] interior
             self.gw.append(Geom(Hi, Wi, Ci, Ho, Wo, k, k, Ho + 2 * p, Wo + 2 * p, cout, 0, 0, p, p))
+        cins = [4] + [c for (c, k) in _D_CONVS[:-1]]
+        self.span_f = [ops.span_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
+        self.span_b = [ops.span_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
         self.P = self.dims[-1][0] * self.dims[-1][1]
         self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
         self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
@@ -392,11 +395,13 @@ class _DiscriminatorBase(nn.Module):
 
     def _weights(self, dev):
         if self._w is None or self._w['sigma'].device != dev:
-            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': []}
+            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': []}
             cin = 4
             for (cout, k) in _D_CONVS:
                 w['wf'].append(_zeros((cout, k * k * cin), dev))
                 w['wb'].append(_zeros((cin, k * k * cout), dev))
+                w['wff'].append(_zeros((ops.frag_floats(cout, k * k * cin),), dev) if (k * k * cin) % 8 == 0 else None)
+                w['wbf'].append(_zeros((ops.frag_floats(cin, k * k * cout),), dev) if (k * k * cout) % 8 == 0 else None)
                 cin = cout
             self._w = w
         return self._w
@@ -435,11 +440,18 @@ class _DiscriminatorBase(nn.Module):
         for l, (cout, k) in enumerate(_D_CONVS):
             m = self.layers[l]
             ops.weight_prep(m.weight_orig, w['sigma'][l:l + 1], cout, cin, cpad, k, k, w['wf'][l], w['wb'][l])
+            if bf.span_f[l]:
+                ops.weight_prep_frag(w['wf'][l], cout, k * k * cpad, w['wff'][l])
+            if bf.span_b[l]:
+                ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
             cin = cpad = cout
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):
-            ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+            if bf.span_f[l]:
+                ops.conv_span(a, w['wff'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+            else:
+                ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
         score = _empty((B, self._nout), dev)
         call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),
@@ -495,7 +507,10 @@ class _DiscriminatorBase(nn.Module):
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
             if l > 0:
-                ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
+                if bf.span_b[l]:
+                    ops.conv_span(bf.gbuf[l], w['wbf'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
+                else:
+                    ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
             elif need_din:
                 ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
                 ddin = bf.ddin

@@ -14,6 +14,9 @@ _SIGS = {
     'nele_conv_gemm': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), _P],
     'nele_conv_wgrad': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep': [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    'nele_weight_prep_frag': [_P, c_int, c_int, _P, _P],
+    'nele_conv_span_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_conv_span': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
@@ -65,6 +68,30 @@ def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g, tag=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call('nele_conv_gemm', ptr(A), ptr(Wg), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, stream())
+    if prof:
+        e1.record()
+        PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
+
+
+def span_supported(B, N, g):
+    return bool(_lib.lib.nele_conv_span_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
+
+
+def frag_floats(N, Ktot):
+    return (Ktot // 8) * ((N + 15) // 16) * 128
+
+
+def weight_prep_frag(Wg, N, Ktot, Wfrag):
+    call('nele_weight_prep_frag', ptr(Wg), N, Ktot, ptr(Wfrag), stream())
+
+
+def conv_span(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
+    M = B * g.Hout * g.Wout
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call('nele_conv_span', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, g.KH, g.KW, A.numel(), stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
