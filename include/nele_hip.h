@@ -158,10 +158,21 @@ int nele_metric_estoi(const float* x, const float* y, int B, int L, void* worksp
  * pysiib.SIIB(x, y, 16000, gauss=True) (algorithm restated, oracle/siib.py).  info [B][4] (may be NULL) =
  * {replication factor M, frames of the tiled signal, active frames, status bits: 1 M clamped, 4 active-frame
  * buffer clamped, 8 not enough active frames (reference raises; raw = NaN)}.  The KLT eigenvectors come from
- * rocSOLVER (dsyevd, strided batched): stop-gap, the only library call in the path. */
+ * nele_eigh_sym_batched below. */
 long long nele_metric_siib_workspace_bytes(int B, int L);
 int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                      float* mapped, int* info, void* stream);
+/* Same, split so that the caller can interleave independent work: phase 1 = wide front kernels (VAD .. covariance),
+ * phase 2 = latency-bound back end (eigenvectors, projections, score) on the same workspace; phase 0 = both. */
+int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                           float* mapped, int* info, int phase, void* stream);
+
+/* Batched symmetric eigen-decomposition, float64, n <= 512 (np.linalg.eigh in pysiib's KLT): A [B][n][n] symmetric
+ * (destroyed) -> lam [B][n] ascending, U [B][n][n] with ROW j = eigenvector j.  Householder tridiagonalisation,
+ * Sturm bisection, inverse iteration, back-transformation (csrc/eigh.hip). */
+long long nele_eigh_workspace_bytes(int B, int n);
+int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
+                          void* stream);
 
 /* intel.py:108-114 HASPI_Wrapper[_raw]_harvard -> pyHASPI/pyhaspi2.py:76-107 haspi_v2(x, fs, y, fs), HL = 0.
  * fs_in 16000 (resampled to 24 kHz as librosa.resample / resampy kaiser_best, pyhaspi2.py:815) or 24000.

@@ -19,6 +19,11 @@
 
 int nele_set_error(int code, const char* fmt, ...);
 
+// csrc/eigh.hip (also part of the public C ABI)
+extern "C" long long nele_eigh_workspace_bytes(int B, int n);
+extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
+                                     void* stream);
+
 #define NELE_CHECK_ARG(cond, ...)                                   \
     do {                                                            \
         if (!(cond)) return nele_set_error(NELE_ERR_INVALID_ARG, __VA_ARGS__); \

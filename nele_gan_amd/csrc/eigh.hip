@@ -1,0 +1,397 @@
+// Batched symmetric eigen-decomposition (float64) for the SIIB Karhunen-Loeve transform (oracle/siib.py:
+// np.linalg.eigh(cov)); replaces the rocSOLVER stop-gap.  n <= 512 (SIIB: n = 420), B matrices, row-major.
+//
+//   e1  Householder tridiagonalisation, one 1024-thread workgroup per matrix (LAPACK dsytd2 recurrences;
+//       matrix-vector product wave-per-row, rank-2 update thread-per-element; reflectors kept in the rows of A)
+//   e2  eigenvalues of the tridiagonal matrix by Sturm-sequence bisection, one thread per eigenvalue
+//       (LAPACK dstebz recurrences: embarrassingly parallel, every eigenvalue to ~1 ulp of ||T||)
+//   e3  eigenvectors of the tridiagonal matrix by inverse iteration, one thread per eigenvector
+//       (LAPACK dlagtf / dlagts / dstein recurrences; work arrays laid out [step][thread] so that the
+//       threads of a wave touch one coalesced row per step)
+//   e4  back-transformation with the Householder reflectors, a slab of 30 eigenvectors per workgroup held in LDS
+//
+// Close eigenvalues are separated by dstein's perturbation (10 eps |lambda|); vectors are NOT re-orthogonalised
+// against each other: for spectra without (numerically) repeated eigenvalues inverse iteration already delivers
+// eigenvectors orthogonal to ~eps ||T|| / gap, and for repeated eigenvalues the individual vectors are arbitrary in any
+// solver (SIIB drops the only systematic such cluster, the rank-deficient null space, by its eigenvalue tolerance).
+#include "common.h"
+
+#define EG_MAXN 512
+#define EG_SLAB 30
+
+struct EighWs {
+    double* d;      // [B][n]
+    double* e;      // [B][n]
+    double* tau;    // [B][n]
+    double* lamp;   // [B][n] perturbed eigenvalues used as shifts
+    double* zt;     // [B][n][EG_MAXN]  zt[i][j] = component i of eigenvector j (of T, then of A)
+    double* lu;     // [B][5][n][EG_MAXN]
+    int* pin;       // [B][n][EG_MAXN]
+};
+
+// ------------------------------------------------------------------------------------------ e1
+__global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
+    __shared__ double v[EG_MAXN], w[EG_MAXN];
+    __shared__ double red[16];
+    __shared__ double s_tau, s_beta;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    for (int k = 0; k < n - 1; ++k) {
+        const int m = n - k - 1;
+        double* rowk = A + (size_t)k * n + k + 1;   // = column k below the diagonal (symmetric)
+        // x -> v, ||x[1:]||
+        double ss = 0.0;
+        for (int i = tid; i < m; i += 1024) {
+            const double x = rowk[i];
+            v[i] = x;
+            if (i > 0) ss += x * x;
+        }
+        ss = block_sum(ss, red);
+        if (tid == 0) {
+            const double alpha = v[0];
+            double t = 0.0, beta = alpha;
+            if (ss > 0.0) {
+                const double nrm = sqrt(alpha * alpha + ss);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                t = (beta - alpha) / beta;
+                s_beta = 1.0 / (alpha - beta);     // scale for v[1:]
+            } else {
+                s_beta = 0.0;
+            }
+            s_tau = t;
+            d[k] = A[(size_t)k * n + k];
+            e[k] = beta;
+            tau[k] = t;
+        }
+        __syncthreads();
+        const double t = s_tau;
+        if (t != 0.0) {
+            const double sc = s_beta;
+            for (int i = tid; i < m; i += 1024) {
+                const double vi = (i == 0) ? 1.0 : v[i] * sc;
+                v[i] = vi;
+                rowk[i] = vi;                       // reflector kept in row k
+            }
+            __syncthreads();
+            // p = tau * A22 v  (wave per row)
+            double* A22 = A + (size_t)(k + 1) * n + (k + 1);
+            for (int i = wave; i < m; i += 16) {
+                const double* r = A22 + (size_t)i * n;
+                double a = 0.0;
+                for (int j = lane; j < m; j += 64) a += r[j] * v[j];
+                a = wave_sum(a);
+                if (lane == 0) w[i] = t * a;
+            }
+            __syncthreads();
+            double pv = 0.0;
+            for (int i = tid; i < m; i += 1024) pv += w[i] * v[i];
+            pv = block_sum(pv, red);
+            const double al = -0.5 * t * pv;
+            for (int i = tid; i < m; i += 1024) w[i] += al * v[i];
+            __syncthreads();
+            // A22 -= v w^T + w v^T
+            const int tx = tid & 63, ty = tid >> 6;
+            for (int i = ty; i < m; i += 16) {
+                double* r = A22 + (size_t)i * n;
+                const double vi = v[i], wi = w[i];
+                for (int j = tx; j < m; j += 64) r[j] -= vi * w[j] + wi * v[j];
+            }
+        } else {
+            for (int i = tid; i < m; i += 1024) rowk[i] = (i == 0) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
+}
+
+// ------------------------------------------------------------------------------------------ e2
+// grid B, block EG_MAXN.  Thread j -> j-th smallest eigenvalue.
+__global__ __launch_bounds__(EG_MAXN) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
+    __shared__ double sd[EG_MAXN], se2[EG_MAXN];
+    __shared__ double red[8];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const double* d = ws.d + (size_t)b * n;
+    const double* e = ws.e + (size_t)b * n;
+    double gl = 1e300, gu = -1e300, tn = 0.0;
+    if (j < n) {
+        sd[j] = d[j];
+        const double ej = (j < n - 1) ? e[j] : 0.0;
+        se2[j] = ej * ej;
+        const double em = (j > 0) ? fabs(e[j - 1]) : 0.0;
+        const double r = fabs(ej) + em;
+        gl = d[j] - r;
+        gu = d[j] + r;
+        tn = fabs(d[j]) + r;
+    }
+    __syncthreads();
+    const double glo = -block_max(-gl, red), ghi = block_max(gu, red), tnorm = block_max(tn, red);
+    const double eps = 2.220446049250313e-16, safemn = 2.2250738585072014e-308;
+    const double pivmin = fmax(safemn, safemn * block_max((j < n) ? se2[j] : 0.0, red));
+    double lo = glo - 2.0 * tnorm * eps * n - 2.0 * pivmin, hi = ghi + 2.0 * tnorm * eps * n + 2.0 * pivmin;
+    if (j < n) {
+        for (int it = 0; it < 128; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (!(hi - lo > 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) || mid <= lo || mid >= hi) break;
+            // Sturm count: number of eigenvalues < mid
+            double q = sd[0] - mid;
+            if (fabs(q) < pivmin) q = -pivmin;
+            int cnt = q < 0.0 ? 1 : 0;
+            for (int i = 1; i < n; ++i) {
+                q = sd[i] - mid - se2[i - 1] / q;
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt += q < 0.0 ? 1 : 0;
+            }
+            if (cnt <= j) lo = mid; else hi = mid;
+        }
+    }
+    const double lamj = 0.5 * (lo + hi);
+    __syncthreads();               // every thread is done reading the diagonal from LDS
+    if (j < n) sd[j] = lamj;       // reuse LDS for the eigenvalues
+    __syncthreads();
+    // ascending already; dstein's separation of close shifts (serial scan)
+    if (j == 0) {
+        double* lamp = ws.lamp + (size_t)b * n;
+        double prev = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double x = sd[i];
+            const double pertol = 10.0 * fabs(eps * x);
+            if (i > 0 && x - prev < pertol) x = prev + pertol;
+            lamp[i] = x;
+            prev = x;
+        }
+    }
+    if (j < n) lam_out[(size_t)b * n + j] = sd[j];
+}
+
+// ------------------------------------------------------------------------------------------ e3
+// grid (ceil(n/64), B), block 64.  Thread -> one eigenvector of T by inverse iteration.
+#define LU(arr, i) lu[((size_t)(arr) * n + (i)) * EG_MAXN]
+__global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
+    const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n) return;
+    const double* d = ws.d + (size_t)b * n;
+    const double* e = ws.e + (size_t)b * n;
+    double* lu = ws.lu + (size_t)b * 5 * n * EG_MAXN + j;       // arrays: 0 a, 1 b, 2 c, 3 d2, 4 x
+    int* pin = ws.pin + (size_t)b * n * EG_MAXN + j;
+    double* z = ws.zt + (size_t)b * n * EG_MAXN + j;
+    const double eps = 2.220446049250313e-16, sfmin = 2.2250738585072014e-308, bignum = 1.0 / sfmin;
+    const double xj = ws.lamp[(size_t)b * n + j];
+    // onenrm
+    double onenrm = fabs(d[0]) + (n > 1 ? fabs(e[0]) : 0.0);
+    if (n > 1) onenrm = fmax(onenrm, fabs(d[n - 1]) + fabs(e[n - 2]));
+    for (int i = 1; i < n - 1; ++i) onenrm = fmax(onenrm, fabs(d[i]) + fabs(e[i - 1]) + fabs(e[i]));
+    const double dtpcrt = sqrt(0.1 / (double)n);
+    // ---- dlagtf: LU of T - xj I with partial pivoting; the recurrence values live in registers, every output
+    // element is stored once (arrays: 0 a, 1 b, 2 c, 3 d2)
+    {
+        const double tl = eps;
+        double acur = d[0] - xj;                        // a[k] as modified by step k-1
+        double bcur = (n > 1) ? e[0] : 0.0;             // b[k] as modified by step k-1
+        double scale1 = fabs(acur) + fabs(bcur);
+        for (int k = 0; k < n - 1; ++k) {
+            const double ak = acur, bk = bcur, ak1 = d[k + 1] - xj, ck = e[k];
+            const double bk1 = (k < n - 2) ? e[k + 1] : 0.0;
+            double scale2 = fabs(ck) + fabs(ak1);
+            if (k < n - 2) scale2 += fabs(bk1);
+            const double piv1 = (ak == 0.0) ? 0.0 : fabs(ak) / scale1;
+            int pk = 0;
+            double a_out = ak, b_out = bk, c_out = ck, d2_out = 0.0, a_next = ak1, b_next = bk1;
+            if (ck == 0.0) {
+                scale1 = scale2;
+            } else {
+                const double piv2 = fabs(ck) / scale2;
+                if (piv2 <= piv1) {
+                    scale1 = scale2;
+                    c_out = ck / ak;
+                    a_next = ak1 - c_out * bk;
+                } else {
+                    pk = 1;
+                    const double mult = ak / ck;
+                    a_out = ck;
+                    a_next = bk - mult * ak1;
+                    d2_out = bk1;
+                    b_next = -mult * bk1;
+                    b_out = ak1;
+                    c_out = mult;
+                }
+            }
+            (void)tl;
+            LU(0, k) = a_out;
+            LU(1, k) = b_out;
+            LU(2, k) = c_out;
+            if (k < n - 2) LU(3, k) = d2_out;
+            pin[(size_t)k * EG_MAXN] = pk;
+            acur = a_next;
+            bcur = b_next;
+        }
+        LU(0, n - 1) = acur;
+    }
+    // dlagts tolerance
+    double tol = fabs(LU(0, 0));
+    if (n > 1) tol = fmax(tol, fmax(fabs(LU(0, 1)), fabs(LU(1, 0))));
+    for (int k = 2; k < n; ++k) tol = fmax(fmax(tol, fabs(LU(0, k))), fmax(fabs(LU(1, k - 1)), fabs(LU(3, k - 2))));
+    tol *= eps;
+    if (tol == 0.0) tol = eps;
+    // ---- start vector: deterministic pseudo-random in (-1, 1)
+    unsigned int rs = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
+    for (int i = 0; i < n; ++i) {
+        rs = rs * 1664525u + 1013904223u;
+        LU(4, i) = ((double)(rs >> 8) / 8388608.0) - 1.0;
+    }
+    const double alast = fabs(LU(0, n - 1));
+    int nrmchk = 0;
+    for (int its = 0; its < 8; ++its) {
+        // scale: ||x||_1 -> n * onenrm * max(eps, |a_n|)
+        double asum = 0.0;
+        for (int i = 0; i < n; ++i) asum += fabs(LU(4, i));
+        const double scl = (double)n * onenrm * fmax(eps, alast) / asum;
+        for (int i = 0; i < n; ++i) LU(4, i) *= scl;
+        // forward elimination with the recorded row interchanges (running value in a register)
+        {
+            double yprev = LU(4, 0);
+            for (int k = 1; k < n; ++k) {
+                const double yk = LU(4, k), ck = LU(2, k - 1);
+                if (pin[(size_t)(k - 1) * EG_MAXN] == 0) {
+                    LU(4, k - 1) = yprev;
+                    yprev = yk - ck * yprev;
+                } else {
+                    LU(4, k - 1) = yk;
+                    yprev = yprev - ck * yk;
+                }
+            }
+            LU(4, n - 1) = yprev;
+        }
+        // back substitution, perturbing tiny pivots (job = -1)
+        double y1 = 0.0, y2 = 0.0;   // x[k+1], x[k+2]
+        double nrm = 0.0;
+        for (int k = n - 1; k >= 0; --k) {
+            double temp = LU(4, k);
+            if (k <= n - 2) temp -= LU(1, k) * y1;
+            if (k <= n - 3) temp -= LU(3, k) * y2;
+            double ak = LU(0, k);
+            double pert = copysign(tol, ak);
+            for (int guard = 0; guard < 200; ++guard) {
+                const double absak = fabs(ak);
+                if (absak < 1.0) {
+                    if (absak < sfmin) {
+                        if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
+                        temp *= bignum;
+                        ak *= bignum;
+                    } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
+                }
+                break;
+            }
+            const double xk = temp / ak;
+            LU(4, k) = xk;
+            y2 = y1;
+            y1 = xk;
+            nrm = fmax(nrm, fabs(xk));
+        }
+        if (nrm < dtpcrt) continue;
+        if (++nrmchk < 3) continue;
+        break;
+    }
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) { const double x = LU(4, i); s2 += x * x; }
+    const double inv = 1.0 / sqrt(s2);
+    for (int i = 0; i < n; ++i) z[(size_t)i * EG_MAXN] = LU(4, i) * inv;
+}
+#undef LU
+
+// ------------------------------------------------------------------------------------------ e4
+// Eigenvectors of A = Q z, Q = H_0 H_1 ... H_{n-2}, H_k = I - tau_k v_k v_k^T acting on rows k+1..n-1.
+// grid (ceil(n/EG_SLAB), B), block 256: a slab of EG_SLAB eigenvectors lives in LDS for all n-1 steps; the
+// result is written as U[j][i] (row j = eigenvector j), the layout the SIIB projection reads.
+__global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
+    extern __shared__ double zs[];            // [n][EG_SLAB + 1]
+    __shared__ double v[EG_MAXN];
+    __shared__ double part[8][EG_SLAB + 2];
+    __shared__ double tj[EG_SLAB + 2];
+    const int b = blockIdx.y, j0 = blockIdx.x * EG_SLAB, tid = threadIdx.x;
+    const int nj = min(EG_SLAB, n - j0);
+    const int ld = EG_SLAB + 1;
+    const double* A = Aall + (size_t)b * n * n;
+    const double* tau = ws.tau + (size_t)b * n;
+    const double* zt = ws.zt + (size_t)b * n * EG_MAXN;
+    for (int idx = tid; idx < n * nj; idx += 256) {
+        const int i = idx / nj, c = idx - i * nj;
+        zs[i * ld + c] = zt[(size_t)i * EG_MAXN + j0 + c];
+    }
+    __syncthreads();
+    const int c = tid % 32, g = tid / 32;     // column c (< nj), row group g (8 groups)
+    for (int k = n - 2; k >= 0; --k) {
+        const double t = tau[k];
+        if (t == 0.0) continue;               // block-uniform
+        const int m = n - k - 1;
+        for (int i = tid; i < m; i += 256) v[i] = A[(size_t)k * n + k + 1 + i];
+        __syncthreads();
+        double a = 0.0;
+        if (c < nj)
+            for (int i = g; i < m; i += 8) a += v[i] * zs[(k + 1 + i) * ld + c];
+        if (c < nj) part[g][c] = a;
+        __syncthreads();
+        if (tid < nj) {
+            double s = 0.0;
+            for (int q = 0; q < 8; ++q) s += part[q][tid];
+            tj[tid] = t * s;
+        }
+        __syncthreads();
+        if (c < nj) {
+            const double tc = tj[c];
+            for (int i = g; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * v[i];
+        }
+        __syncthreads();
+    }
+    double* Ub = U + (size_t)b * n * n;
+    for (int idx = tid; idx < n * nj; idx += 256) {
+        const int cc = idx / n, i = idx - cc * n;
+        Ub[(size_t)(j0 + cc) * n + i] = zs[i * ld + cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
+    size_t o = 0;
+#define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al256(sizeof(type) * (size_t)(count)); } while (0)
+    TAKE(d, double, (size_t)B * n);
+    TAKE(e, double, (size_t)B * n);
+    TAKE(tau, double, (size_t)B * n);
+    TAKE(lamp, double, (size_t)B * n);
+    TAKE(zt, double, (size_t)B * n * EG_MAXN);
+    TAKE(lu, double, (size_t)B * 5 * n * EG_MAXN);
+    TAKE(pin, int, (size_t)B * n * EG_MAXN);
+#undef TAKE
+    return o;
+}
+
+extern "C" long long nele_eigh_workspace_bytes(int B, int n) { return (long long)eigh_layout(B, n, nullptr, nullptr); }
+
+// A [B][n][n] symmetric (destroyed: holds the Householder reflectors on exit) -> lam [B][n] ascending,
+// U [B][n][n] with row j = eigenvector j.  U may alias A? No: U must be a different buffer.
+extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
+                                     void* stream) {
+    NELE_CHECK_ARG(A && lam && U && workspace && B > 0 && n >= 2, "nele_eigh_sym_batched: bad arguments");
+    NELE_CHECK_ARG(A != U, "nele_eigh_sym_batched: U must not alias A");
+    if (n > EG_MAXN) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_eigh_sym_batched: n=%d > %d", n, EG_MAXN);
+    if (workspace_bytes < nele_eigh_workspace_bytes(B, n)) return nele_set_error(NELE_ERR_WORKSPACE, "nele_eigh_sym_batched: workspace too small");
+    EighWs ws;
+    eigh_layout(B, n, &ws, (char*)workspace);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
+    hipLaunchKernelGGL(eigh_bisect_kernel, dim3(B), dim3(EG_MAXN), 0, s, n, ws, lam);
+    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws);
+    const size_t lds = sizeof(double) * (size_t)n * (EG_SLAB + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(eigh_backtransform_kernel, dim3((n + EG_SLAB - 1) / EG_SLAB, B), dim3(256), lds, s, A, n, ws, U);
+    NELE_CHECK_LAUNCH("nele_eigh_sym_batched");
+    return NELE_OK;
+}

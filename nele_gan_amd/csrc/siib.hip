@@ -10,11 +10,10 @@
 //   s4  per band: minimum, forward temporal masking (serial over frames), mean removal
 //   s5  stack K = 15 frames (420 rows), remove the row means
 //   s6  Cxx = Xs Xs^T / (n-1)                      (tiled float64 GEMM)
-//   s7  eigenvectors of Cxx                        (rocSOLVER dsyevd, strided batched: STOP-GAP)
+//   s7  eigenvectors of Cxx                        (csrc/eigh.hip: tridiagonalisation + bisection + inverse iteration)
 //   s8  Xp = U^T Xs, Yp = U^T Ys fused with the per-component sums of Xp^2, Yp^2, Xp Yp
 //   s9  rho, I = -1/2 log2(1 - rho_p^2 rho^2), SIIB = R/K sum I, logistic map
 #include "common.h"
-#include <rocsolver/rocsolver.h>
 
 #define SB_WLEN 400
 #define SB_SHIFT 200
@@ -33,9 +32,10 @@ struct SiibWs {
     int* info;       // [B][4]    {M, n_tiled_frames, n_active, status}
     double* XL;      // [B][2][28][NA] log band energies of the active frames (x then y)
     double* Xs;      // [B][2][420][NA] stacked, mean-removed (zero padded to NA columns)
-    double* C;       // [B][420][420] covariance -> eigenvectors (row j = eigenvector j)
+    double* C;       // [B][420][420] covariance (destroyed by the eigensolver)
+    double* U;       // [B][420][420] eigenvectors (row j = eigenvector j)
+    char* eigws;     // eigensolver workspace
     double* lam;     // [B][420]
-    double* E;       // [B][420] rocSOLVER scratch
     double* part;    // [B][420][NTL][3]
     int NT, NA, NTL;
 };
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
         }
         return;
     }
-    const double* U = ws.C + (size_t)b * SB_D * SB_D;
+    const double* U = ws.U + (size_t)b * SB_D * SB_D;
     const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
     const double* Y = X + (size_t)SB_D * ws.NA;
     const int tx = tid & 15, ty = tid >> 4;
@@ -486,49 +486,53 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(Xs, double, (size_t)B * 2 * SB_D * NA);
     TAKE(C, double, (size_t)B * SB_D * SB_D);
     TAKE(lam, double, (size_t)B * SB_D);
-    TAKE(E, double, (size_t)B * SB_D);
+    TAKE(U, double, (size_t)B * SB_D * SB_D);
+    TAKE(eigws, char, (size_t)nele_eigh_workspace_bytes(B, SB_D));
     TAKE(part, double, (size_t)B * SB_D * NTL * 3);
 #undef TAKE
     if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; }
-    return o + al(sizeof(int) * (size_t)B);  // + rocSOLVER info array
+    return o;
 }
 
 extern "C" long long nele_metric_siib_workspace_bytes(int B, int L) { return (long long)siib_layout(B, L, nullptr, nullptr); }
 
-static rocblas_handle g_handle = nullptr;
-
-extern "C" int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
-                                float* mapped, int* info_out, void* stream) {
+// phase: 0 = everything, 1 = front only (VAD .. covariance), 2 = back only (eigenvectors .. score).  The split lets the
+// caller put independent work between the wide front kernels and the latency-bound eigen-decomposition.
+extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                                      float* mapped, int* info_out, int phase, void* stream) {
     NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_siib: bad arguments");
+    NELE_CHECK_ARG(phase >= 0 && phase <= 2, "nele_metric_siib: phase must be 0, 1 or 2");
     if (L < SB_WLEN + SB_SHIFT * (SB_K + 1)) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_siib: L=%d too short", L);
     if (workspace_bytes < nele_metric_siib_workspace_bytes(B, L))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_siib: workspace too small");
     SiibWs ws;
     const size_t used = siib_layout(B, L, &ws, (char*)workspace);
-    int* solver_info = (int*)((char*)workspace + used - al(sizeof(int) * (size_t)B));
+    (void)used;
     hipStream_t s = as_stream(stream);
-    if (!g_handle) {
-        if (rocblas_create_handle(&g_handle) != rocblas_status_success)
-            return nele_set_error(NELE_ERR_HIP, "nele_metric_siib: rocblas_create_handle failed");
+    if (phase != 2) {
+        hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
+        hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
+        hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
+        hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
+        hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws);
+        hipLaunchKernelGGL(siib_mask_kernel, dim3(B), dim3(64), 0, s, ws);
+        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, 2), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
+        NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
-    rocblas_set_stream(g_handle, s);
-    hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
-    hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
-    hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
-    hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
-    hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws);
-    hipLaunchKernelGGL(siib_mask_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, 2), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
-    NELE_CHECK_LAUNCH("nele_metric_siib(front)");
-    // C is symmetric: row-major == column-major.  On exit column j (= memory row j) is eigenvector j.
-    rocblas_status st = rocsolver_dsyevd_strided_batched(g_handle, rocblas_evect_original, rocblas_fill_lower, SB_D, ws.C, SB_D,
-                                                         (rocblas_stride)SB_D * SB_D, ws.lam, SB_D, ws.E, SB_D, solver_info, B);
-    if (st != rocblas_status_success) return nele_set_error(NELE_ERR_HIP, "nele_metric_siib: rocsolver_dsyevd status %d", (int)st);
-    hipLaunchKernelGGL(siib_proj_kernel, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
-    if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
-    NELE_CHECK_LAUNCH("nele_metric_siib(back)");
+    if (phase != 1) {
+        int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
+        if (st) return st;
+        hipLaunchKernelGGL(siib_proj_kernel, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
+        if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
+        NELE_CHECK_LAUNCH("nele_metric_siib(back)");
+    }
     return NELE_OK;
+}
+
+extern "C" int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                                float* mapped, int* info_out, void* stream) {
+    return nele_metric_siib_phase(x, y, B, L, workspace, workspace_bytes, raw, mapped, info_out, 0, stream);
 }

@@ -25,6 +25,8 @@ _lib.lib.nele_metric_estoi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_estoi_workspace_bytes'] = _lib.lib.nele_metric_estoi_workspace_bytes.argtypes
 
 declare('nele_metric_siib', [_P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P, _P])
+declare('nele_metric_siib_phase', [_P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P, c_int, _P])
+_lib._SIGS['nele_metric_siib_phase'] = _lib.lib.nele_metric_siib_phase.argtypes
 _lib._SIGS['nele_metric_siib'] = _lib.lib.nele_metric_siib.argtypes
 _lib.lib.nele_metric_siib_workspace_bytes.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_siib_workspace_bytes.restype = c_longlong
@@ -39,6 +41,12 @@ _lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_haspi_nsub.restype = c_int
 _lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
 
+declare('nele_eigh_sym_batched', [_P, c_int, c_int, _P, _P, _P, c_longlong, _P])
+_lib._SIGS['nele_eigh_sym_batched'] = _lib.lib.nele_eigh_sym_batched.argtypes
+_lib.lib.nele_eigh_workspace_bytes.argtypes = [c_int, c_int]
+_lib.lib.nele_eigh_workspace_bytes.restype = c_longlong
+_lib._SIGS['nele_eigh_workspace_bytes'] = _lib.lib.nele_eigh_workspace_bytes.argtypes
+
 _ws_cache = {}
 
 
@@ -49,6 +57,17 @@ def _workspace(kind, nbytes, dev):
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         _ws_cache[key] = t
     return t
+
+
+def eigh_batched(A):
+    """A [B,n,n] float64 symmetric (device) -> (eigenvalues [B,n] ascending, U [B,n,n] with rows = eigenvectors)."""
+    A = A.clone().contiguous()
+    B, n, _ = A.shape
+    lam = torch.empty((B, n), dtype=torch.float64, device=A.device)
+    U = torch.empty_like(A)
+    ws = _workspace('eigh', _lib.lib.nele_eigh_workspace_bytes(B, n), A.device)
+    call('nele_eigh_sym_batched', ptr(A), n, B, ptr(lam), ptr(U), ptr(ws), ws.numel(), stream())
+    return lam, U
 
 
 def _pair(x, y):
@@ -76,6 +95,31 @@ def batch_estoi(x, y):
     mapped = torch.empty(B, device=x.device)
     call('nele_metric_estoi', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), stream())
     return raw, mapped
+
+
+class SiibSplit:
+    """batch_siib in two halves: front() enqueues the wide kernels (VAD .. covariance), back() the latency-bound
+    eigen-decomposition .. score, so that independent work can be enqueued in between on another stream."""
+
+    def __init__(self, x, y):
+        self.x, self.y, _ = _pair(x, y)
+        B, L = self.x.shape
+        self.ws = _workspace('siib', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
+        self.raw = torch.empty(B, device=self.x.device)
+        self.mapped = torch.empty(B, device=self.x.device)
+        self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
+
+    def _call(self, phase):
+        B, L = self.x.shape
+        call('nele_metric_siib_phase', ptr(self.x), ptr(self.y), B, L, ptr(self.ws), self.ws.numel(), ptr(self.raw), ptr(self.mapped),
+             ptr(self.info), phase, stream())
+
+    def front(self):
+        self._call(1)
+
+    def back(self):
+        self._call(2)
+        return self.raw, self.mapped
 
 
 def batch_siib(x, y, return_info=False):

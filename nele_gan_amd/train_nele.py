@@ -156,23 +156,43 @@ class GanTrainer:
         f = feats or self.features(clean_wav, noise_wav)
         lg = self.g_step(f['clean_band'], f['noise_band'])
         enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
-        # D's forward pass does not need the targets: enqueue it first (main stream), then the metric kernels on
-        # a side stream so that both run concurrently; the loss waits for the targets
+        # The metric kernels run on a side stream.  D's forward pass does not need the targets, so it is enqueued on
+        # the main stream to run beside the latency-bound part of the metrics (SIIB's eigen-decomposition keeps only a
+        # few CUs busy); the loss waits for the targets.
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
         ready = torch.cuda.Event()
         ready.record(main)
+        L = min(clean_wav.shape[1], enh.shape[1])
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            x = clean_wav[:, :L].contiguous()
+            y = (enh[:, :L] + noise_wav[:, :L]).contiguous()
+            cols = {}
+            split = None
+            for m in self.metrics:                         # wide kernels first
+                if m == 'siib':
+                    split = mt.SiibSplit(x, y)
+                    split.front()
+                else:
+                    cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
+            wide_done = torch.cuda.Event()
+            wide_done.record(side)
+        main.wait_event(wide_done)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din)
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(ready)
-            tgt = self.true_metrics(clean_wav, enh, noise_wav)
+        with torch.cuda.stream(side):
+            if split is not None:
+                cols['siib'] = split.back()[1]
+            tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
             done = torch.cuda.Event()
-            done.record(self._side)
-        tgt.record_stream(main)
-        enh.record_stream(self._side)
+            done.record(side)
+        for t in (tgt, x, y):
+            t.record_stream(main)
+        enh.record_stream(side)
         main.wait_event(done)
         ld = self._d_finish(score, tgt)
         return lg, ld, tgt

@@ -125,3 +125,20 @@ def test_haspi_random_dither_is_small_and_seeded(mt):
     r2, _ = mt.batch_haspi(c, c + v, dither=True, seed=7)
     assert float(r1[0]) == float(r2[0])
     assert abs(float(r1[0]) - float(r0[0])) < 0.02 * abs(float(r0[0]))    # N(0, 0.1 dB) jitter: per-mille level effect
+
+
+@pytest.mark.parametrize('n,B', [(420, 3), (97, 2), (16, 4)])
+def test_batched_eigensolver_vs_numpy(mt, n, B):
+    rs = np.random.RandomState(n)
+    A = np.zeros((B, n, n))
+    for b in range(B):
+        G = rs.randn(n, 3 * n) * np.exp(-0.01 * np.arange(3 * n))[None, :]       # covariance-like, decaying spectrum
+        A[b] = G @ G.T / (3 * n)
+    lam, U = mt.eigh_batched(torch.from_numpy(A).cuda())
+    lam, U = lam.cpu().numpy(), U.cpu().numpy()
+    for b in range(B):
+        ref = np.linalg.eigvalsh(A[b])
+        np.testing.assert_allclose(lam[b], ref, rtol=0, atol=1e-13 * ref.max())
+        V = U[b].T                                                             # columns = eigenvectors
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-8
+        assert np.abs(A[b] @ V - V * lam[b][None, :]).max() < 1e-11 * ref.max()
