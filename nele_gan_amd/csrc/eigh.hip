@@ -30,78 +30,121 @@ struct EighWs {
 };
 
 // ------------------------------------------------------------------------------------------ e1
+// Step k: Householder vector v_k of column k, p = tau A22 v, w = p - (tau/2)(p.v) v, A22 -= v w^T + w v^T.
+// The trailing matrix is streamed ONCE per step: while a wave writes back the updated row i it also accumulates
+// that row's dot product with the NEXT Householder vector (known as soon as the first updated row is), which is the
+// next step's matrix-vector product.  Per-CU L2 bandwidth bounds this kernel (sum_k 2 m_k^2 * 8 B per matrix).
+__device__ __forceinline__ void eigh_house(double* v, int m, double* red, double* s_tau, double* s_scale, double* s_beta) {
+    // v[0..m) holds x; on exit v = Householder vector (v[0] = 1), *s_tau = tau, *s_beta = beta
+    double ss = 0.0;
+    for (int i = 1 + threadIdx.x; i < m; i += blockDim.x) ss += v[i] * v[i];
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        const double alpha = v[0];
+        double t = 0.0, beta = alpha, sc = 0.0;
+        if (ss > 0.0) {
+            const double nrm = sqrt(alpha * alpha + ss);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            t = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        *s_tau = t; *s_scale = sc; *s_beta = beta;
+    }
+    __syncthreads();
+    const double sc = *s_scale;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) v[i] = (i == 0) ? 1.0 : v[i] * sc;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
-    __shared__ double v[EG_MAXN], w[EG_MAXN];
+    __shared__ double v[EG_MAXN], w[EG_MAXN], vn[EG_MAXN], pn[EG_MAXN];
     __shared__ double red[16];
-    __shared__ double s_tau, s_beta;
+    __shared__ double s_tau, s_scale, s_beta;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
     double* tau = ws.tau + (size_t)b * n;
+    // step 0: v from row 0, p = A22 v by a plain pass
+    {
+        const int m = n - 1;
+        for (int i = tid; i < m; i += 1024) v[i] = A[1 + i];
+        __syncthreads();
+        eigh_house(v, m, red, &s_tau, &s_scale, &s_beta);
+        double* A22 = A + (size_t)n + 1;
+        const int c = tid & 511, grp = tid >> 9;
+        double acc = 0.0;
+        if (c < m)
+            for (int r = grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * v[r];
+        if (grp == 1 && c < m) w[c] = acc;
+        __syncthreads();
+        if (grp == 0 && c < m) w[c] += acc;       // A22 v (tau applied below)
+        __syncthreads();
+    }
     for (int k = 0; k < n - 1; ++k) {
         const int m = n - k - 1;
-        double* rowk = A + (size_t)k * n + k + 1;   // = column k below the diagonal (symmetric)
-        // x -> v, ||x[1:]||
-        double ss = 0.0;
-        for (int i = tid; i < m; i += 1024) {
-            const double x = rowk[i];
-            v[i] = x;
-            if (i > 0) ss += x * x;
+        double* rowk = A + (size_t)k * n + k + 1;
+        double* A22 = A + (size_t)(k + 1) * n + (k + 1);
+        const double t = s_tau;
+        if (tid == 0) { d[k] = A[(size_t)k * n + k]; e[k] = s_beta; tau[k] = t; }
+        for (int i = tid; i < m; i += 1024) rowk[i] = v[i];      // keep the reflector in row k
+        // w = tau*(A22 v) - (tau/2)(p.v) v      (w currently holds A22 v)
+        double pv = 0.0;
+        for (int i = tid; i < m; i += 1024) pv += t * w[i] * v[i];
+        pv = block_sum(pv, red);
+        const double al = -0.5 * t * pv;
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) w[i] = t * w[i] + al * v[i];
+        __syncthreads();
+        if (m == 1) {   // last step: 1x1 trailing block
+            if (tid == 0) A22[0] -= 2.0 * v[0] * w[0];
+            __syncthreads();
+            break;
         }
-        ss = block_sum(ss, red);
-        if (tid == 0) {
-            const double alpha = v[0];
-            double t = 0.0, beta = alpha;
-            if (ss > 0.0) {
-                const double nrm = sqrt(alpha * alpha + ss);
-                beta = alpha >= 0.0 ? -nrm : nrm;
-                t = (beta - alpha) / beta;
-                s_beta = 1.0 / (alpha - beta);     // scale for v[1:]
-            } else {
-                s_beta = 0.0;
+        // first updated row of A22 -> next Householder vector (its elements 1..m-1)
+        const int m2 = m - 1;
+        for (int j = tid; j < m2; j += 1024) vn[j] = A22[1 + j] - v[0] * w[1 + j] - w[0] * v[1 + j];
+        if (tid == 0) A22[0] -= 2.0 * v[0] * w[0];
+        __syncthreads();
+        __shared__ double n_tau, n_scale, n_beta;
+        eigh_house(vn, m2, red, &n_tau, &n_scale, &n_beta);
+        // fused pass: thread = column c (symmetric matrix: column c == row c), two thread groups split the rows.
+        // x = A22[r][c] - v_r w_c - w_r v_c is written back and accumulated into (A' vn)_c; row reads are coalesced
+        // across the threads and need no cross-lane reduction.
+        {
+            const int c = tid & 511, grp = tid >> 9;
+            double acc = 0.0;
+            if (c >= 1 && c < m) {
+                const double vc = v[c], wc = w[c];
+                if (t != 0.0) {
+                    int r = 1 + grp;
+                    for (; r + 6 < m; r += 8) {
+                        double x0 = A22[(size_t)r * n + c], x1 = A22[(size_t)(r + 2) * n + c], x2 = A22[(size_t)(r + 4) * n + c],
+                               x3 = A22[(size_t)(r + 6) * n + c];
+                        x0 -= v[r] * wc + w[r] * vc; x1 -= v[r + 2] * wc + w[r + 2] * vc;
+                        x2 -= v[r + 4] * wc + w[r + 4] * vc; x3 -= v[r + 6] * wc + w[r + 6] * vc;
+                        A22[(size_t)r * n + c] = x0; A22[(size_t)(r + 2) * n + c] = x1; A22[(size_t)(r + 4) * n + c] = x2;
+                        A22[(size_t)(r + 6) * n + c] = x3;
+                        acc += x0 * vn[r - 1] + x1 * vn[r + 1] + x2 * vn[r + 3] + x3 * vn[r + 5];
+                    }
+                    for (; r < m; r += 2) {
+                        double x0 = A22[(size_t)r * n + c];
+                        x0 -= v[r] * wc + w[r] * vc;
+                        A22[(size_t)r * n + c] = x0;
+                        acc += x0 * vn[r - 1];
+                    }
+                } else {
+                    for (int r = 1 + grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * vn[r - 1];
+                }
             }
-            s_tau = t;
-            d[k] = A[(size_t)k * n + k];
-            e[k] = beta;
-            tau[k] = t;
+            __syncthreads();                 // pn is free (copied to w at the end of the previous step)
+            if (grp == 1 && c >= 1 && c < m) pn[c - 1] = acc;
+            __syncthreads();
+            if (grp == 0 && c >= 1 && c < m) pn[c - 1] += acc;
         }
         __syncthreads();
-        const double t = s_tau;
-        if (t != 0.0) {
-            const double sc = s_beta;
-            for (int i = tid; i < m; i += 1024) {
-                const double vi = (i == 0) ? 1.0 : v[i] * sc;
-                v[i] = vi;
-                rowk[i] = vi;                       // reflector kept in row k
-            }
-            __syncthreads();
-            // p = tau * A22 v  (wave per row)
-            double* A22 = A + (size_t)(k + 1) * n + (k + 1);
-            for (int i = wave; i < m; i += 16) {
-                const double* r = A22 + (size_t)i * n;
-                double a = 0.0;
-                for (int j = lane; j < m; j += 64) a += r[j] * v[j];
-                a = wave_sum(a);
-                if (lane == 0) w[i] = t * a;
-            }
-            __syncthreads();
-            double pv = 0.0;
-            for (int i = tid; i < m; i += 1024) pv += w[i] * v[i];
-            pv = block_sum(pv, red);
-            const double al = -0.5 * t * pv;
-            for (int i = tid; i < m; i += 1024) w[i] += al * v[i];
-            __syncthreads();
-            // A22 -= v w^T + w v^T
-            const int tx = tid & 63, ty = tid >> 6;
-            for (int i = ty; i < m; i += 16) {
-                double* r = A22 + (size_t)i * n;
-                const double vi = v[i], wi = w[i];
-                for (int j = tx; j < m; j += 64) r[j] -= vi * w[j] + wi * v[j];
-            }
-        } else {
-            for (int i = tid; i < m; i += 1024) rowk[i] = (i == 0) ? 1.0 : 0.0;
-        }
+        for (int i = tid; i < m2; i += 1024) { v[i] = vn[i]; w[i] = pn[i]; }
+        if (tid == 0) { s_tau = n_tau; s_beta = n_beta; }
         __syncthreads();
     }
     if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
@@ -134,15 +177,21 @@ __global__ __launch_bounds__(EG_MAXN) void eigh_bisect_kernel(int n, EighWs ws, 
     if (j < n) {
         for (int it = 0; it < 128; ++it) {
             const double mid = 0.5 * (lo + hi);
-            if (!(hi - lo > 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) || mid <= lo || mid >= hi) break;
-            // Sturm count: number of eigenvalues < mid
-            double q = sd[0] - mid;
-            if (fabs(q) < pivmin) q = -pivmin;
-            int cnt = q < 0.0 ? 1 : 0;
+            if (!(hi - lo > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || mid <= lo || mid >= hi) break;
+            // Sturm count (number of eigenvalues < mid) by the division-free three-term recurrence
+            // p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, counting sign changes; rescaled to stay in range
+            double p0 = 1.0, p1 = sd[0] - mid;
+            if (p1 == 0.0) p1 = -pivmin;
+            int cnt = (p1 < 0.0) ? 1 : 0;
             for (int i = 1; i < n; ++i) {
-                q = sd[i] - mid - se2[i - 1] / q;
-                if (fabs(q) < pivmin) q = -pivmin;
-                cnt += q < 0.0 ? 1 : 0;
+                double p2 = (sd[i] - mid) * p1 - se2[i - 1] * p0;
+                if (p2 == 0.0) p2 = -copysign(pivmin, p1) ;          // as q = -pivmin in the quotient form
+                cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                p0 = p1;
+                p1 = p2;
+                const double ap = fabs(p1);
+                if (ap > 1e150) { p0 *= 1e-150; p1 *= 1e-150; }
+                else if (ap < 1e-150) { p0 *= 1e150; p1 *= 1e150; }
             }
             if (cnt <= j) lo = mid; else hi = mid;
         }
@@ -170,10 +219,11 @@ __global__ __launch_bounds__(EG_MAXN) void eigh_bisect_kernel(int n, EighWs ws, 
 // grid (ceil(n/64), B), block 64.  Thread -> one eigenvector of T by inverse iteration.
 #define LU(arr, i) lu[((size_t)(arr) * n + (i)) * EG_MAXN]
 __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
+    __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < n; i += 64) { d[i] = ws.d[(size_t)b * n + i]; e[i] = ws.e[(size_t)b * n + i]; }
+    __syncthreads();
     if (j >= n) return;
-    const double* d = ws.d + (size_t)b * n;
-    const double* e = ws.e + (size_t)b * n;
     double* lu = ws.lu + (size_t)b * 5 * n * EG_MAXN + j;       // arrays: 0 a, 1 b, 2 c, 3 d2, 4 x
     int* pin = ws.pin + (size_t)b * n * EG_MAXN + j;
     double* z = ws.zt + (size_t)b * n * EG_MAXN + j;
@@ -249,17 +299,24 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
         for (int i = 0; i < n; ++i) asum += fabs(LU(4, i));
         const double scl = (double)n * onenrm * fmax(eps, alast) / asum;
         for (int i = 0; i < n; ++i) LU(4, i) *= scl;
-        // forward elimination with the recorded row interchanges (running value in a register)
+        // forward elimination with the recorded row interchanges (running value in a register, operands prefetched)
         {
             double yprev = LU(4, 0);
-            for (int k = 1; k < n; ++k) {
-                const double yk = LU(4, k), ck = LU(2, k - 1);
-                if (pin[(size_t)(k - 1) * EG_MAXN] == 0) {
-                    LU(4, k - 1) = yprev;
-                    yprev = yk - ck * yprev;
-                } else {
-                    LU(4, k - 1) = yk;
-                    yprev = yprev - ck * yk;
+            for (int k0 = 1; k0 < n; k0 += 4) {
+                double yk[4], ck[4];
+                int pk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + u, n - 1);
+                    yk[u] = LU(4, k); ck[u] = LU(2, k - 1); pk[u] = pin[(size_t)(k - 1) * EG_MAXN];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u;
+                    if (k < n) {
+                        if (pk[u] == 0) { LU(4, k - 1) = yprev; yprev = yk[u] - ck[u] * yprev; }
+                        else { LU(4, k - 1) = yk[u]; yprev = yprev - ck[u] * yk[u]; }
+                    }
                 }
             }
             LU(4, n - 1) = yprev;
@@ -267,28 +324,39 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
         // back substitution, perturbing tiny pivots (job = -1)
         double y1 = 0.0, y2 = 0.0;   // x[k+1], x[k+2]
         double nrm = 0.0;
-        for (int k = n - 1; k >= 0; --k) {
-            double temp = LU(4, k);
-            if (k <= n - 2) temp -= LU(1, k) * y1;
-            if (k <= n - 3) temp -= LU(3, k) * y2;
-            double ak = LU(0, k);
-            double pert = copysign(tol, ak);
-            for (int guard = 0; guard < 200; ++guard) {
-                const double absak = fabs(ak);
-                if (absak < 1.0) {
-                    if (absak < sfmin) {
-                        if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
-                        temp *= bignum;
-                        ak *= bignum;
-                    } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
-                }
-                break;
+        for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
+            double xr[4], br[4], d2r[4], ar[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = max(k0 - u, 0);
+                xr[u] = LU(4, k); ar[u] = LU(0, k);
+                br[u] = (k <= n - 2) ? LU(1, k) : 0.0;
+                d2r[u] = (k <= n - 3) ? LU(3, k) : 0.0;
             }
-            const double xk = temp / ak;
-            LU(4, k) = xk;
-            y2 = y1;
-            y1 = xk;
-            nrm = fmax(nrm, fabs(xk));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 - u;
+                if (k < 0) continue;
+                double temp = xr[u] - br[u] * y1 - d2r[u] * y2;
+                double ak = ar[u];
+                double pert = copysign(tol, ak);
+                for (int guard = 0; guard < 200; ++guard) {
+                    const double absak = fabs(ak);
+                    if (absak < 1.0) {
+                        if (absak < sfmin) {
+                            if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
+                            temp *= bignum;
+                            ak *= bignum;
+                        } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
+                    }
+                    break;
+                }
+                const double xk = temp / ak;
+                LU(4, k) = xk;
+                y2 = y1;
+                y1 = xk;
+                nrm = fmax(nrm, fabs(xk));
+            }
         }
         if (nrm < dtpcrt) continue;
         if (++nrmchk < 3) continue;
@@ -307,7 +375,6 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
 // result is written as U[j][i] (row j = eigenvector j), the layout the SIIB projection reads.
 __global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
     extern __shared__ double zs[];            // [n][EG_SLAB + 1]
-    __shared__ double v[EG_MAXN];
     __shared__ double part[8][EG_SLAB + 2];
     __shared__ double tj[EG_SLAB + 2];
     const int b = blockIdx.y, j0 = blockIdx.x * EG_SLAB, tid = threadIdx.x;
@@ -322,28 +389,41 @@ __global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* _
     }
     __syncthreads();
     const int c = tid % 32, g = tid / 32;     // column c (< nj), row group g (8 groups)
+    __shared__ double vbuf[2][EG_MAXN];
+    int cur = 0;
+    {   // reflector of the first step
+        const int k = n - 2, m = 1;
+        for (int i = tid; i < m; i += 256) vbuf[0][i] = A[(size_t)k * n + k + 1 + i];
+    }
+    __syncthreads();
     for (int k = n - 2; k >= 0; --k) {
-        const double t = tau[k];
-        if (t == 0.0) continue;               // block-uniform
         const int m = n - k - 1;
-        for (int i = tid; i < m; i += 256) v[i] = A[(size_t)k * n + k + 1 + i];
-        __syncthreads();
-        double a = 0.0;
-        if (c < nj)
-            for (int i = g; i < m; i += 8) a += v[i] * zs[(k + 1 + i) * ld + c];
-        if (c < nj) part[g][c] = a;
-        __syncthreads();
-        if (tid < nj) {
-            double s = 0.0;
-            for (int q = 0; q < 8; ++q) s += part[q][tid];
-            tj[tid] = t * s;
+        const double t = tau[k];
+        const double* vv = vbuf[cur];
+        // prefetch the next step's reflector (row k-1) while this one is applied
+        if (k > 0) {
+            double* nx = vbuf[cur ^ 1];
+            for (int i = tid; i < m + 1; i += 256) nx[i] = A[(size_t)(k - 1) * n + k + i];
+        }
+        if (t != 0.0) {                       // block-uniform
+            double a = 0.0;
+            if (c < nj)
+                for (int i = g; i < m; i += 8) a += vv[i] * zs[(k + 1 + i) * ld + c];
+            if (c < nj) part[g][c] = a;
+            __syncthreads();
+            if (tid < nj) {
+                double s = 0.0;
+                for (int q = 0; q < 8; ++q) s += part[q][tid];
+                tj[tid] = t * s;
+            }
+            __syncthreads();
+            if (c < nj) {
+                const double tc = tj[c];
+                for (int i = g; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * vv[i];
+            }
         }
         __syncthreads();
-        if (c < nj) {
-            const double tc = tj[c];
-            for (int i = g; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * v[i];
-        }
-        __syncthreads();
+        cur ^= 1;
     }
     double* Ub = U + (size_t)b * n * n;
     for (int idx = tid; idx < n * nj; idx += 256) {
