@@ -118,9 +118,10 @@ int nele_d_layout(const float* src, float* dst, int B, int Cin, int T, int to_nh
 
 /* ---- discriminator glue + optimiser (csrc/disc.hip) --------------------------------------------- */
 
-/* torch.nn.utils.spectral_norm as used at model.py:105-116: n_iter (1 in train mode, 0 in eval) power
- * iterations updating u [N], v [K] in place, then sigma = u . (W v); W = weight_orig as [N][K]. */
-int nele_spectral_norm(const float* W, float* u, float* v, float* sigma, int N, int K, int n_iter, void* stream);
+/* torch.nn.utils.spectral_norm as used at model.py:105-116, all layers of a discriminator in one launch: n_iter (1 in
+ * train mode, 0 in eval) power iterations updating u [N], v [K] in place, then sigma[l] = u . (W v); W = weight_orig as
+ * [N][K].  ptrs_host: HOST array of 3*layers device pointers {W, u, v}; dims_host: HOST array {N, K} per layer. */
+int nele_spectral_norm(const void* const* ptrs_host, const int* dims_host, int layers, float* sigma, int n_iter, void* stream);
 /* dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma : gradient through W/sigma with u, v constant. */
 int nele_sn_grad_scratch_doubles(int total);
 int nele_sn_grad(const float* dW, const float* W, const float* u, const float* v, const float* sigma, int N, int K,

@@ -10,16 +10,30 @@
 // ------------------------------------------------------------------------------------------ spectral norm
 // W [N][K] row-major (weight_orig viewed as (out, -1)); u [N], v [K] updated in place when n_iter == 1.
 // v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); normalize(x) = x / max(||x||, 1e-12).
-__global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
-                                                            float* __restrict__ sigma, int N, int K, int n_iter) {
-    __shared__ double red[8];
+// One 1024-thread block per layer; all layers of a discriminator go in ONE launch (grid = layers).
+#define SN_MAXL 8
+struct SnLayers {
+    const float* W[SN_MAXL];
+    float* u[SN_MAXL];
+    float* v[SN_MAXL];
+    int N[SN_MAXL], K[SN_MAXL];
+    float* sigma;   // [layers]
+};
+
+__global__ __launch_bounds__(1024) void spectral_norm_kernel(SnLayers L, int n_iter) {
+    __shared__ double red[16];
     __shared__ float su[64], swv[64];
+    const int l = blockIdx.x;
+    const float* __restrict__ W = L.W[l];
+    float* u = L.u[l];
+    float* v = L.v[l];
+    const int N = L.N[l], K = L.K[l];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < N) su[tid] = u[tid];
     __syncthreads();
     if (n_iter > 0) {
         double nrm = 0.0;
-        for (int k = tid; k < K; k += 256) {
+        for (int k = tid; k < K; k += 1024) {
             float a = 0.f;
             for (int n = 0; n < N; ++n) a += W[(size_t)n * K + k] * su[n];
             v[k] = a;
@@ -27,11 +41,10 @@ __global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restr
         }
         nrm = block_sum(nrm, red);
         const float inv = 1.f / fmaxf((float)sqrt(nrm), 1e-12f);
-        for (int k = tid; k < K; k += 256) v[k] *= inv;
+        for (int k = tid; k < K; k += 1024) v[k] *= inv;
         __syncthreads();
     }
-    // W v
-    for (int n = wave; n < N; n += 4) {
+    for (int n = wave; n < N; n += 16) {
         float a = 0.f;
         for (int k = lane; k < K; k += 64) a += W[(size_t)n * K + k] * v[k];
         a = wave_sum(a);
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restr
     double s = 0.0;
     if (tid < N) s = (double)su[tid] * (double)swv[tid];
     s = block_sum(s, red);
-    if (tid == 0) sigma[0] = (float)s;
+    if (tid == 0) L.sigma[l] = (float)s;
 }
 
 // dst (+)= (dWsn - <dWsn, W/sigma> u v^T) / sigma      ([N][K] parameter layout)
@@ -239,9 +252,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-extern "C" int nele_spectral_norm(const float* W, float* u, float* v, float* sigma, int N, int K, int n_iter, void* stream) {
-    NELE_CHECK_ARG(W && u && v && sigma && N > 0 && N <= 64 && K > 0, "nele_spectral_norm: bad arguments (N must be <= 64)");
-    hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(256), 0, as_stream(stream), W, u, v, sigma, N, K, n_iter);
+// ptrs_host: HOST array of 3*layers device pointers {W, u, v} per layer; dims_host: HOST array of 2*layers ints {N, K};
+// sigma: device [layers].
+extern "C" int nele_spectral_norm(const void* const* ptrs_host, const int* dims_host, int layers, float* sigma, int n_iter, void* stream) {
+    NELE_CHECK_ARG(ptrs_host && dims_host && sigma && layers >= 1 && layers <= SN_MAXL, "nele_spectral_norm: bad arguments (layers <= 8)");
+    SnLayers L;
+    for (int l = 0; l < layers; ++l) {
+        L.W[l] = (const float*)ptrs_host[3 * l];
+        L.u[l] = (float*)ptrs_host[3 * l + 1];
+        L.v[l] = (float*)ptrs_host[3 * l + 2];
+        L.N[l] = dims_host[2 * l];
+        L.K[l] = dims_host[2 * l + 1];
+        NELE_CHECK_ARG(L.W[l] && L.u[l] && L.v[l] && L.N[l] > 0 && L.N[l] <= 64 && L.K[l] > 0, "nele_spectral_norm: layer %d invalid (N must be <= 64)", l);
+    }
+    L.sigma = sigma;
+    hipLaunchKernelGGL(spectral_norm_kernel, dim3(layers), dim3(1024), 0, as_stream(stream), L, n_iter);
     NELE_CHECK_LAUNCH("nele_spectral_norm");
     return NELE_OK;
 }

@@ -151,74 +151,65 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ e2
-// grid B, block EG_MAXN.  Thread j -> j-th smallest eigenvalue.
-__global__ __launch_bounds__(EG_MAXN) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
+// grid (EG_BSPLIT, B), block 128.  Thread -> one eigenvalue (j-th smallest) by bisection on the Sturm count, evaluated with the
+// division-free three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes = eigenvalues below x).
+#define EG_BSPLIT 4
+__global__ __launch_bounds__(128) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
     __shared__ double sd[EG_MAXN], se2[EG_MAXN];
     __shared__ double red[8];
-    const int b = blockIdx.x, j = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int j = blockIdx.x * 128 + tid;
     const double* d = ws.d + (size_t)b * n;
     const double* e = ws.e + (size_t)b * n;
-    double gl = 1e300, gu = -1e300, tn = 0.0;
-    if (j < n) {
-        sd[j] = d[j];
-        const double ej = (j < n - 1) ? e[j] : 0.0;
-        se2[j] = ej * ej;
-        const double em = (j > 0) ? fabs(e[j - 1]) : 0.0;
+    double gl = 1e300, gu = -1e300, tn = 0.0, e2m = 0.0;
+    for (int i = tid; i < n; i += 128) {
+        const double di = d[i];
+        sd[i] = di;
+        const double ej = (i < n - 1) ? e[i] : 0.0;
+        se2[i] = ej * ej;
+        const double em = (i > 0) ? fabs(e[i - 1]) : 0.0;
         const double r = fabs(ej) + em;
-        gl = d[j] - r;
-        gu = d[j] + r;
-        tn = fabs(d[j]) + r;
+        gl = fmin(gl, di - r);
+        gu = fmax(gu, di + r);
+        tn = fmax(tn, fabs(di) + r);
+        e2m = fmax(e2m, ej * ej);
     }
     __syncthreads();
     const double glo = -block_max(-gl, red), ghi = block_max(gu, red), tnorm = block_max(tn, red);
     const double eps = 2.220446049250313e-16, safemn = 2.2250738585072014e-308;
-    const double pivmin = fmax(safemn, safemn * block_max((j < n) ? se2[j] : 0.0, red));
+    const double pivmin = fmax(safemn, safemn * block_max(e2m, red));
     double lo = glo - 2.0 * tnorm * eps * n - 2.0 * pivmin, hi = ghi + 2.0 * tnorm * eps * n + 2.0 * pivmin;
     if (j < n) {
         for (int it = 0; it < 128; ++it) {
             const double mid = 0.5 * (lo + hi);
             if (!(hi - lo > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || mid <= lo || mid >= hi) break;
-            // Sturm count (number of eigenvalues < mid) by the division-free three-term recurrence
-            // p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, counting sign changes; rescaled to stay in range
             double p0 = 1.0, p1 = sd[0] - mid;
             if (p1 == 0.0) p1 = -pivmin;
             int cnt = (p1 < 0.0) ? 1 : 0;
-            for (int i = 1; i < n; ++i) {
-                double p2 = (sd[i] - mid) * p1 - se2[i - 1] * p0;
-                if (p2 == 0.0) p2 = -copysign(pivmin, p1) ;          // as q = -pivmin in the quotient form
-                cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
-                p0 = p1;
-                p1 = p2;
-                const double ap = fabs(p1);
-                if (ap > 1e150) { p0 *= 1e-150; p1 *= 1e-150; }
-                else if (ap < 1e-150) { p0 *= 1e150; p1 *= 1e150; }
+            int i = 1;
+            while (i < n) {
+                const int iend = min(n, i + 8);
+                for (; i < iend; ++i) {
+                    double p2 = (sd[i] - mid) * p1 - se2[i - 1] * p0;
+                    if (p2 == 0.0) p2 = -copysign(pivmin, p1);
+                    cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                    p0 = p1;
+                    p1 = p2;
+                }
+                const double ap = fabs(p1);                    // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
+                if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
+                else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
             }
             if (cnt <= j) lo = mid; else hi = mid;
         }
+        lam_out[(size_t)b * n + j] = 0.5 * (lo + hi);
     }
-    const double lamj = 0.5 * (lo + hi);
-    __syncthreads();               // every thread is done reading the diagonal from LDS
-    if (j < n) sd[j] = lamj;       // reuse LDS for the eigenvalues
-    __syncthreads();
-    // ascending already; dstein's separation of close shifts (serial scan)
-    if (j == 0) {
-        double* lamp = ws.lamp + (size_t)b * n;
-        double prev = 0.0;
-        for (int i = 0; i < n; ++i) {
-            double x = sd[i];
-            const double pertol = 10.0 * fabs(eps * x);
-            if (i > 0 && x - prev < pertol) x = prev + pertol;
-            lamp[i] = x;
-            prev = x;
-        }
-    }
-    if (j < n) lam_out[(size_t)b * n + j] = sd[j];
 }
 
 // ------------------------------------------------------------------------------------------ e3
 // grid (ceil(n/64), B), block 64.  Thread -> one eigenvector of T by inverse iteration.
 #define LU(arr, i) lu[((size_t)(arr) * n + (i)) * EG_MAXN]
-__global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
+__global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in) {
     __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
     for (int i = threadIdx.x; i < n; i += 64) { d[i] = ws.d[(size_t)b * n + i]; e[i] = ws.e[(size_t)b * n + i]; }
@@ -228,7 +219,20 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
     int* pin = ws.pin + (size_t)b * n * EG_MAXN + j;
     double* z = ws.zt + (size_t)b * n * EG_MAXN + j;
     const double eps = 2.220446049250313e-16, sfmin = 2.2250738585072014e-308, bignum = 1.0 / sfmin;
-    const double xj = ws.lamp[(size_t)b * n + j];
+    double xj;
+    {   // dstein: shifts closer than 10 eps |x| to their (already separated) predecessor are pushed apart
+        const double* lam = lam_in + (size_t)b * n;
+        int s0 = j;
+        while (s0 > 0 && lam[s0] - lam[s0 - 1] < 10.0 * fabs(eps * lam[s0]) && j - s0 < 64) --s0;
+        double prev = lam[s0];
+        for (int i = s0 + 1; i <= j; ++i) {
+            double x = lam[i];
+            const double pertol = 10.0 * fabs(eps * x);
+            if (x - prev < pertol) x = prev + pertol;
+            prev = x;
+        }
+        xj = prev;
+    }
     // onenrm
     double onenrm = fabs(d[0]) + (n > 1 ? fabs(e[0]) : 0.0);
     if (n > 1) onenrm = fmax(onenrm, fabs(d[n - 1]) + fabs(e[n - 2]));
@@ -375,8 +379,6 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws) {
 // result is written as U[j][i] (row j = eigenvector j), the layout the SIIB projection reads.
 __global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
     extern __shared__ double zs[];            // [n][EG_SLAB + 1]
-    __shared__ double part[8][EG_SLAB + 2];
-    __shared__ double tj[EG_SLAB + 2];
     const int b = blockIdx.y, j0 = blockIdx.x * EG_SLAB, tid = threadIdx.x;
     const int nj = min(EG_SLAB, n - j0);
     const int ld = EG_SLAB + 1;
@@ -388,39 +390,36 @@ __global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* _
         zs[i * ld + c] = zt[(size_t)i * EG_MAXN + j0 + c];
     }
     __syncthreads();
-    const int c = tid % 32, g = tid / 32;     // column c (< nj), row group g (8 groups)
+    // wave w owns columns 8w..8w+7 of the slab: lane = (row lane rl) * 8 + (column cl); the dot products reduce over
+    // the 8 row lanes with shuffles, so the only barrier per step is the one that publishes the prefetched reflector
+    const int lane = tid & 63, wv = tid >> 6, cl = lane & 7, rl = lane >> 3;
+    const int c = wv * 8 + cl;
     __shared__ double vbuf[2][EG_MAXN];
     int cur = 0;
-    {   // reflector of the first step
-        const int k = n - 2, m = 1;
-        for (int i = tid; i < m; i += 256) vbuf[0][i] = A[(size_t)k * n + k + 1 + i];
-    }
+    if (tid == 0) vbuf[0][0] = A[(size_t)(n - 2) * n + (n - 1)];
     __syncthreads();
     for (int k = n - 2; k >= 0; --k) {
         const int m = n - k - 1;
         const double t = tau[k];
         const double* vv = vbuf[cur];
-        // prefetch the next step's reflector (row k-1) while this one is applied
+        double pre0 = 0.0, pre1 = 0.0;         // next step's reflector (row k-1): loads issued now, published after the compute
+        if (k > 0) {
+            if (tid < m + 1) pre0 = A[(size_t)(k - 1) * n + k + tid];
+            if (tid + 256 < m + 1) pre1 = A[(size_t)(k - 1) * n + k + tid + 256];
+        }
+        if (t != 0.0 && c < nj) {
+            double a = 0.0;
+            for (int i = rl; i < m; i += 8) a += vv[i] * zs[(k + 1 + i) * ld + c];
+            a += __shfl_xor(a, 8, 64);
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            const double tc = t * a;
+            for (int i = rl; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * vv[i];
+        }
         if (k > 0) {
             double* nx = vbuf[cur ^ 1];
-            for (int i = tid; i < m + 1; i += 256) nx[i] = A[(size_t)(k - 1) * n + k + i];
-        }
-        if (t != 0.0) {                       // block-uniform
-            double a = 0.0;
-            if (c < nj)
-                for (int i = g; i < m; i += 8) a += vv[i] * zs[(k + 1 + i) * ld + c];
-            if (c < nj) part[g][c] = a;
-            __syncthreads();
-            if (tid < nj) {
-                double s = 0.0;
-                for (int q = 0; q < 8; ++q) s += part[q][tid];
-                tj[tid] = t * s;
-            }
-            __syncthreads();
-            if (c < nj) {
-                const double tc = tj[c];
-                for (int i = g; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * vv[i];
-            }
+            if (tid < m + 1) nx[tid] = pre0;
+            if (tid + 256 < m + 1) nx[tid + 256] = pre1;
         }
         __syncthreads();
         cur ^= 1;
@@ -463,8 +462,8 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     eigh_layout(B, n, &ws, (char*)workspace);
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
-    hipLaunchKernelGGL(eigh_bisect_kernel, dim3(B), dim3(EG_MAXN), 0, s, n, ws, lam);
-    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws);
+    hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 127) / 128, B), dim3(128), 0, s, n, ws, lam);
+    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam);
     const size_t lds = sizeof(double) * (size_t)n * (EG_SLAB + 1);
     static bool attr_done = false;
     if (!attr_done) {

@@ -166,12 +166,19 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] (+)= sum_r part[r][c]: block = 64 columns x 4 row groups, fixed summation order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out, int accumulate) {
+    __shared__ float sp[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += part[(size_t)r * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int r = g; r < rows; r += 4) s += part[(size_t)r * cols + c];
+    sp[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        const float t = (sp[0][threadIdx.x] + sp[1][threadIdx.x]) + (sp[2][threadIdx.x] + sp[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ tail
@@ -326,7 +333,7 @@ extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain
 
 extern "C" int nele_colsum(const float* part, int rows, int cols, float* out, int accumulate, void* stream) {
     NELE_CHECK_ARG(part && out && rows > 0 && cols > 0, "nele_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, as_stream(stream), part, rows, cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), part, rows, cols, out, accumulate);
     NELE_CHECK_LAUNCH("nele_colsum");
     return NELE_OK;
 }

@@ -430,12 +430,15 @@ class _DiscriminatorBase(nn.Module):
         key, bf = self._get_bufs(B, T, dev)
         w = self._weights(dev)
         n_iter = 1 if self.training else 0
-        # spectral norm: power iteration (train mode) + sigma for all 8 layers (model.py:105-116)
-        for i, m in enumerate(self._sn_modules()):
-            N = m.weight_orig.shape[0]
-            K = m.weight_orig.numel() // N
-            call('nele_spectral_norm', ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v), c_void_p(w['sigma'].data_ptr() + 4 * i), N, K,
-                 n_iter, stream())
+        # spectral norm: power iteration (train mode) + sigma for all 8 layers in one launch (model.py:105-116)
+        mods = self._sn_modules()
+        pp = (c_void_p * (3 * len(mods)))()
+        dd = (ctypes.c_int * (2 * len(mods)))()
+        for i, m in enumerate(mods):
+            pp[3 * i], pp[3 * i + 1], pp[3 * i + 2] = m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr()
+            dd[2 * i] = m.weight_orig.shape[0]
+            dd[2 * i + 1] = m.weight_orig.numel() // m.weight_orig.shape[0]
+        call('nele_spectral_norm', pp, dd, len(mods), ptr(w['sigma']), n_iter, stream())
         cin, cpad = self._cin, 4
         for l, (cout, k) in enumerate(_D_CONVS):
             m = self.layers[l]

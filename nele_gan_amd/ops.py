@@ -27,7 +27,7 @@ _SIGS = {
     'nele_energy_norm_bwd': [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, c_int, _P],
     'nele_d_pack': [_P, _P, _P, _P, c_int, c_int, _P],
     'nele_d_layout': [_P, _P, c_int, c_int, c_int, c_int, _P],
-    'nele_spectral_norm': [_P, _P, _P, _P, c_int, c_int, c_int, _P],
+    'nele_spectral_norm': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P, c_int, _P],
     'nele_sn_grad': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     'nele_sn_grad_scratch_doubles': [c_int],
     'nele_gap_mlp_fwd': [_P, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P, _P],
