@@ -56,6 +56,7 @@ def main():
     ap.add_argument('--metrics', default='siib&estoi')
     ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='MFMA operand type of the discriminator conv fwd/dgrad passes')
     a = ap.parse_args()
 
     import torch
@@ -73,6 +74,7 @@ def main():
     from nele_gan_amd.train_nele import GanTrainer, parse_metrics
     metrics = parse_metrics(a.metrics)
     tr = GanTrainer(a.metrics, device='cuda:%d' % local)
+    tr.D.precision = a.precision
     c, v = synth.batch(a.batch, a.length, start=rank * a.batch)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 
@@ -119,7 +121,7 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': a.precision, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
                                    'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},

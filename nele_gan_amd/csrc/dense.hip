@@ -316,6 +316,162 @@ __global__ void weight_frag_kernel(const float* __restrict__ Wg, int N, int Ktot
     }
 }
 
+// ------------------------------------------------------------------------------------------ span-staged conv, bf16 operands
+// Same structure as conv_span_kernel with bf16 operands and float32 accumulation (v_mfma_f32_16x16x32_bf16): the input
+// span is converted to bf16 while it is staged in LDS; a lane's A fragment is 8 consecutive channels (one ds_read_b128),
+// the weights arrive fragment-major in bf16.  Wave tile 128 x (16*TN), block = 4 waves = 512 output positions.
+// Each kernel row is padded to a multiple of 32 k-values with zero weights (the A side then reads finite neighbouring data).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define SPAN16_BM 512
+#define SPAN16_MAXRUN 10
+
+struct Span16Args {
+    const float* A;
+    const __bf16* Wfrag;   // [KH*steps_per_seg][NT][64][8]
+    const float* bias;
+    const float* aux;
+    float* out;
+    int M, N, NT;
+    int epi;
+    float slope;
+    int KH, KW, steps_per_seg;
+    ConvGeom g;
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 span16[];
+    __shared__ int run_gbase[SPAN16_MAXRUN];
+    __shared__ int run_len[SPAN16_MAXRUN];
+    __shared__ int run_off[SPAN16_MAXRUN + 1];
+    __shared__ int posbase[SPAN16_BM];
+    __shared__ int nrun_s;
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * SPAN16_BM;
+    const int mcount = min(SPAN16_BM, p.M - m0);
+    const int halo = (p.KW - 1) * g.C;
+
+    if (tid == 0) {
+        int b, ho, wo;
+        decode_m(m0, g, b, ho, wo);
+        int left = mcount, r = 0, off = 0, done = 0;
+        while (left > 0 && r < SPAN16_MAXRUN) {
+            const int len = min(left, g.Wout - wo);
+            run_gbase[r] = (int)((((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C);
+            run_len[r] = len;
+            run_off[r] = off;
+            for (int i = 0; i < len; ++i) posbase[done + i] = off + i * g.C;
+            off += len * g.C + halo;
+            done += len;
+            left -= len;
+            wo = 0;
+            if (++ho == g.Hout) { ho = 0; ++b; }
+            ++r;
+        }
+        run_off[r] = off;
+        nrun_s = r;
+        for (int i = done; i < SPAN16_BM; ++i) posbase[i] = 0;
+    }
+    __syncthreads();
+    const int nrun = nrun_s;
+    // k-padding slack after the last span is read with zero weights: it must hold finite values
+    if (tid < 64) span16[run_off[nrun] + tid] = (__bf16)0.f;
+    const int li = lane & 15, lg = lane >> 4;
+    int pb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pb[i] = posbase[wave * 128 + i * 16 + li] + 8 * lg;
+
+    f32x4 acc[8][TN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.Wfrag) + lane;
+    int ks = 0;
+    for (int kh = 0; kh < p.KH; ++kh) {
+        __syncthreads();
+        for (int r = 0; r < nrun; ++r) {
+            const int nfl = run_len[r] * g.C + halo;          // multiple of 8
+            const float* src = p.A + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
+            __bf16* dst = span16 + run_off[r];
+            for (int e = tid * 8; e < nfl; e += 2048) {
+                const float4 a = *reinterpret_cast<const float4*>(src + e);
+                const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
+                bf16x8 v;
+                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+                *reinterpret_cast<bf16x8*>(dst + e) = v;
+            }
+        }
+        __syncthreads();
+        bf16x8 bfr[TN], bnx[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = wf[((size_t)ks * p.NT + j) * 64];
+        for (int s = 0; s < p.steps_per_seg; ++s, ++ks) {
+            const bool more = (s + 1 < p.steps_per_seg) || (kh + 1 < p.KH);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bnx[j] = wf[((size_t)(ks + 1) * p.NT + j) * 64];
+            }
+            bf16x8 af[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(span16 + pb[i] + s * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = bnx[j];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wave * 128 + i * 16 + 4 * lg + reg;
+            if (m >= p.M) continue;
+            int b, ho, wo;
+            decode_m(m, g, b, ho, wo);
+            const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+            const size_t x_off = (size_t)m * g.OC;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = j * 16 + li;
+                if (n >= p.N) continue;
+                float v = acc[i][j][reg];
+                switch (p.epi) {
+                    case EPI_BIAS: v += p.bias[n]; break;
+                    case EPI_BIAS_LRELU: v += p.bias[n]; v = v > 0.f ? v : p.slope * v; break;
+                    case EPI_MASK_LRELU_GRAD: v = p.aux[x_off + n] > 0.f ? v : p.slope * v; break;
+                    case EPI_BIAS_EXPTANH: v += p.bias[n]; v = expf(3.2f * tanhf(v)); break;
+                    default: break;
+                }
+                p.out[o_off + n] = v;
+            }
+        }
+    }
+}
+
+// Wg [N][Ktot] f32 -> bf16 fragment-major [KH*sps][NT][64][8], sps = ceil(seglen/32); element (ks = kh*sps + s, j, lane, e) =
+// Wg[j*16 + (lane&15)][kh*seglen + s*32 + 8*(lane>>4) + e], zero where n >= N or the in-segment index >= seglen.
+__global__ void weight_frag16_kernel(const float* __restrict__ Wg, int N, int Ktot, int seglen, int KH, int NT, int sps,
+                                     __bf16* __restrict__ Wfrag) {
+    const int total = KH * sps * NT * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9, j = t % NT, ks = t / NT;
+        const int kh = ks / sps, s_ = ks - kh * sps;
+        const int n = j * 16 + (lane & 15), kin = s_ * 32 + 8 * (lane >> 4) + e;
+        float v = 0.f;
+        if (n < N && kin < seglen) v = Wg[(size_t)n * Ktot + (size_t)kh * seglen + kin];
+        Wfrag[idx] = (__bf16)v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const float* A;      // forward input activations (geometry g: H,W,C,ih0,iw0,seglen,segstride,Ktot,Hout,Wout)
@@ -557,6 +713,66 @@ extern "C" int nele_conv_span(const float* A, const float* Wfrag, const float* b
         default: hipLaunchKernelGGL(conv_span_kernel<4>, dim3(gx), dim3(256), lds, s, p); break;
     }
     NELE_CHECK_LAUNCH("nele_conv_span");
+    return NELE_OK;
+}
+
+// elements (bf16) of the fragment-major weight buffer for nele_conv_span_bf16
+extern "C" long long nele_weight_frag16_elems(int N, int seglen, int KH) {
+    return (long long)KH * ((seglen + 31) / 32) * ((N + 15) / 16) * 512;
+}
+
+extern "C" int nele_weight_prep_frag16(const float* Wg, int N, int Ktot, int seglen, int KH, void* Wfrag, void* stream) {
+    NELE_CHECK_ARG(Wg && Wfrag && N > 0 && KH > 0 && seglen > 0 && KH * seglen == Ktot, "nele_weight_prep_frag16: bad arguments");
+    const int NT = (N + 15) / 16, sps = (seglen + 31) / 32;
+    const long long total = nele_weight_frag16_elems(N, seglen, KH);
+    hipLaunchKernelGGL(weight_frag16_kernel, dim3((unsigned)min(2048LL, (total + 255) / 256)), dim3(256), 0, as_stream(stream), Wg, N, Ktot, seglen,
+                       KH, NT, sps, (__bf16*)Wfrag);
+    NELE_CHECK_LAUNCH("nele_weight_prep_frag16");
+    return NELE_OK;
+}
+
+extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int KH, int KW) {
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    if (N > 64 || g.C % 8 || g.Wout < 64 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
+    const int maxrun = (SPAN16_BM + g.Wout - 1) / g.Wout + 1;
+    if (maxrun > SPAN16_MAXRUN) return 0;
+    const long long el = (long long)SPAN16_BM * g.C + (long long)maxrun * (KW - 1) * g.C + 64;
+    if (el * 2 > 76 * 1024) return 0;
+    return 1;
+}
+
+extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                                   float slope, const int* geom, int KH, int KW, long long a_elems, void* stream) {
+    NELE_CHECK_ARG(A && Wfrag && out && geom, "nele_conv_span_bf16: null pointer");
+    if (!nele_conv_span_bf16_supported(M, N, geom, KH, KW)) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_span_bf16: geometry not supported");
+    NELE_CHECK_ARG(a_elems < 2147483647LL, "nele_conv_span_bf16: input buffer too large for 32-bit offsets");
+    Span16Args p;
+    p.A = A; p.Wfrag = (const __bf16*)Wfrag; p.bias = bias; p.aux = aux; p.out = out; p.M = M; p.N = N; p.NT = (N + 15) / 16; p.epi = epi;
+    p.slope = slope; p.KH = KH; p.KW = KW;
+    memcpy(&p.g, geom, sizeof(ConvGeom));
+    p.steps_per_seg = (p.g.seglen + 31) / 32;
+    NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_span_bf16: epilogue needs bias");
+    NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_span_bf16: epilogue needs aux");
+    const int maxrun = (SPAN16_BM + p.g.Wout - 1) / p.g.Wout + 1;
+    const size_t lds = ((size_t)SPAN16_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C + 64) * 2;
+    const int gx = (M + SPAN16_BM - 1) / SPAN16_BM;
+    hipStream_t s = as_stream(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    switch (p.NT) {
+        case 1: hipLaunchKernelGGL(conv_span16_kernel<1>, dim3(gx), dim3(256), lds, s, p); break;
+        case 2: hipLaunchKernelGGL(conv_span16_kernel<2>, dim3(gx), dim3(256), lds, s, p); break;
+        case 3: hipLaunchKernelGGL(conv_span16_kernel<3>, dim3(gx), dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL(conv_span16_kernel<4>, dim3(gx), dim3(256), lds, s, p); break;
+    }
+    NELE_CHECK_LAUNCH("nele_conv_span_bf16");
     return NELE_OK;
 }
 

@@ -328,6 +328,8 @@ class _DBuffers:
         cins = [4] + [c for (c, k) in _D_CONVS[:-1]]
         self.span_f = [ops.span_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
         self.span_b = [ops.span_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
+        self.span16_f = [ops.span16_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
+        self.span16_b = [ops.span16_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
         self.P = self.dims[-1][0] * self.dims[-1][1]
         self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
         self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
@@ -384,6 +386,7 @@ class _DiscriminatorBase(nn.Module):
         self._w = None
         self._last_score = None
         self.weight_grad_enabled = True   # reference computes (unused) D weight grads in the G-step too
+        self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the conv forward / data-gradient passes
 
     def flat_parameters(self, device=None):
         device = device or next(self.parameters()).device
@@ -395,13 +398,15 @@ class _DiscriminatorBase(nn.Module):
 
     def _weights(self, dev):
         if self._w is None or self._w['sigma'].device != dev:
-            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': []}
+            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': [], 'wff16': [], 'wbf16': []}
             cin = 4
             for (cout, k) in _D_CONVS:
                 w['wf'].append(_zeros((cout, k * k * cin), dev))
                 w['wb'].append(_zeros((cin, k * k * cout), dev))
                 w['wff'].append(_zeros((ops.frag_floats(cout, k * k * cin),), dev) if (k * k * cin) % 8 == 0 else None)
                 w['wbf'].append(_zeros((ops.frag_floats(cin, k * k * cout),), dev) if (k * k * cout) % 8 == 0 else None)
+                w['wff16'].append(torch.zeros(ops.frag16_elems(cout, k * cin, k), dtype=torch.bfloat16, device=dev))
+                w['wbf16'].append(torch.zeros(ops.frag16_elems(cin, k * cout, k), dtype=torch.bfloat16, device=dev))
                 cin = cout
             self._w = w
         return self._w
@@ -443,15 +448,22 @@ class _DiscriminatorBase(nn.Module):
         for l, (cout, k) in enumerate(_D_CONVS):
             m = self.layers[l]
             ops.weight_prep(m.weight_orig, w['sigma'][l:l + 1], cout, cin, cpad, k, k, w['wf'][l], w['wb'][l])
-            if bf.span_f[l]:
+            use16 = self.precision == 'bf16'
+            if use16 and bf.span16_f[l]:
+                ops.weight_prep_frag16(w['wf'][l], cout, k * k * cpad, k * cpad, k, w['wff16'][l])
+            elif bf.span_f[l]:
                 ops.weight_prep_frag(w['wf'][l], cout, k * k * cpad, w['wff'][l])
-            if bf.span_b[l]:
+            if use16 and bf.span16_b[l]:
+                ops.weight_prep_frag16(w['wb'][l], cpad, k * k * cout, k * cout, k, w['wbf16'][l])
+            elif bf.span_b[l]:
                 ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
             cin = cpad = cout
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):
-            if bf.span_f[l]:
+            if self.precision == 'bf16' and bf.span16_f[l]:
+                ops.conv_span_bf16(a, w['wff16'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+            elif bf.span_f[l]:
                 ops.conv_span(a, w['wff'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
             else:
                 ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
@@ -510,7 +522,9 @@ class _DiscriminatorBase(nn.Module):
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
             if l > 0:
-                if bf.span_b[l]:
+                if self.precision == 'bf16' and bf.span16_b[l]:
+                    ops.conv_span_bf16(bf.gbuf[l], w['wbf16'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
+                elif bf.span_b[l]:
                     ops.conv_span(bf.gbuf[l], w['wbf'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
                 else:
                     ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))

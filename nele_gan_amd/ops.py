@@ -17,6 +17,9 @@ _SIGS = {
     'nele_weight_prep_frag': [_P, c_int, c_int, _P, _P],
     'nele_conv_span_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
     'nele_conv_span': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
+    'nele_conv_span_bf16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
+    'nele_conv_span_bf16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_weight_prep_frag16': [_P, c_int, c_int, c_int, c_int, _P, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
@@ -39,6 +42,9 @@ _SIGS = {
 for _n, _a in _SIGS.items():
     declare(_n, _a)
     _lib._SIGS[_n] = _a
+_lib.lib.nele_weight_frag16_elems.argtypes = [c_int, c_int, c_int]
+_lib.lib.nele_weight_frag16_elems.restype = c_longlong
+_lib._SIGS['nele_weight_frag16_elems'] = _lib.lib.nele_weight_frag16_elems.argtypes
 _lib.lib.nele_conv_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int)]
 _lib.lib.nele_conv_wgrad_workspace_floats.restype = c_longlong
 _lib._SIGS['nele_conv_wgrad_workspace_floats'] = _lib.lib.nele_conv_wgrad_workspace_floats.argtypes
@@ -92,6 +98,30 @@ def conv_span(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call('nele_conv_span', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, g.KH, g.KW, A.numel(), stream())
+    if prof:
+        e1.record()
+        PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
+
+
+def span16_supported(B, N, g):
+    return bool(_lib.lib.nele_conv_span_bf16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
+
+
+def frag16_elems(N, seglen, KH):
+    return int(_lib.lib.nele_weight_frag16_elems(N, seglen, KH))
+
+
+def weight_prep_frag16(Wg, N, Ktot, seglen, KH, Wfrag):
+    call('nele_weight_prep_frag16', ptr(Wg), N, Ktot, seglen, KH, ptr(Wfrag), stream())
+
+
+def conv_span_bf16(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
+    M = B * g.Hout * g.Wout
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call('nele_conv_span_bf16', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, g.KH, g.KW, A.numel(), stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))

@@ -214,3 +214,28 @@ def test_discriminator_rejects_short_inputs(mods):
     D = mods.Discriminator().cuda()
     with pytest.raises(ValueError):
         D(torch.zeros(1, 3, 64, 20).cuda())
+
+
+def test_bf16_operand_mode_close_to_f32(mods):
+    # bf16 MFMA operands, float32 accumulation: documented tolerance 3e-2 relative (8-bit mantissa), scores 2e-3 absolute
+    from nele_gan_amd import synth
+    rs = np.random.RandomState(4)
+    B, T = 2, 132
+    din = torch.from_numpy((0.2 + 0.5 * rs.rand(B, 3, 64, T)).astype(np.float32)).cuda()
+    tgt = torch.from_numpy(rs.rand(B, 3).astype(np.float32)).cuda()
+    outs = {}
+    for prec in ('f32', 'bf16'):
+        D = load_recipe(mods.Discriminator(), 202)
+        D.precision = prec
+        D.train()
+        x = din.clone().requires_grad_(True)
+        D.flat_parameters().grad.zero_()
+        sc = D(x)
+        torch.nn.functional.mse_loss(sc, tgt).backward()
+        outs[prec] = (sc.detach().cpu().numpy(), x.grad.cpu().numpy(), D.layers[4].weight_orig.grad.cpu().numpy().copy(),
+                      D.layers[1].weight_orig.grad.cpu().numpy().copy())
+    a, b = outs['f32'], outs['bf16']
+    assert np.abs(a[0] - b[0]).max() < 2e-3
+    for i in (1, 2, 3):
+        scale = np.abs(a[i]).max()
+        assert np.abs(a[i] - b[i]).max() < 3e-2 * scale, i
