@@ -54,49 +54,50 @@ __device__ __forceinline__ void decode_m(int m, const ConvGeom& g, int& b, int& 
 #define GEMM_BK 8
 #define LDS_STRIDE 8
 
-template <int TN>
+// TM = 16-row tiles per wave (block rows BM = 64*TM): TM = 4 for big M, smaller TM when M alone cannot fill the chip.
+template <int TN, int TM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
     constexpr int BN = 16 * TN;
-    __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM * LDS_STRIDE];
+    constexpr int BM = 64 * TM;
+    constexpr int ALOADS = (BM * 2 + 255) / 256;   // float4 loads of the A tile per thread
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDS_STRIDE];
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-    // ---- loader roles: A: 2 float4 per thread (rows tid>>1 and 128+(tid>>1), k-quad tid&1)
     const int kq = tid & 1;
-    size_t a_off[2];
-    bool a_ok[2];
+    size_t a_off[ALOADS];
+    bool a_ok[ALOADS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 1) + 128 * i;
-        a_ok[i] = m < p.M;
+    for (int i = 0; i < ALOADS; ++i) {
+        const int row = (tid >> 1) + 128 * i;
+        const int m = m0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
         int b = 0, ho = 0, wo = 0;
         if (a_ok[i]) decode_m(m, g, b, ho, wo);
         a_off[i] = (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C;
     }
-    // B: 64 rows x 2 quads = 128 float4: threads < 2*BN
     const int bn = tid >> 1;
     const bool b_ok = (tid < 2 * BN) && (n0 + bn < p.N);
     const float* wrow = p.Wg + (size_t)(n0 + bn) * g.Ktot;
 
-    // this thread's k position: kk = step*8 + 4*kq -> (segment kh, offset r)
     int kk = 4 * kq, kh = 0, r = 4 * kq;
     while (r >= g.seglen) { r -= g.seglen; ++kh; }
 
-    f32x4 acc[4][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (g.Ktot + GEMM_BK - 1) / GEMM_BK;
-    float4 ra[2], rb;
+    float4 ra[ALOADS], rb;
     auto gload = [&]() {
         const bool kin = kk < g.Ktot;
         const size_t koff = (size_t)kh * g.segstride + r;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < ALOADS; ++i)
             ra[i] = (a_ok[i] && kin) ? *reinterpret_cast<const float4*>(p.A + a_off[i] + koff) : make_float4(0, 0, 0, 0);
         rb = (b_ok && kin) ? *reinterpret_cast<const float4*>(wrow + kk) : make_float4(0, 0, 0, 0);
         kk += GEMM_BK;
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 1) + 128 * i) * LDS_STRIDE + 4 * kq]) = ra[i];
+        for (int i = 0; i < ALOADS; ++i) {
+            const int row = (tid >> 1) + 128 * i;
+            if (row < BM) *reinterpret_cast<float4*>(&As[buf][row * LDS_STRIDE + 4 * kq]) = ra[i];
+        }
         if (tid < 2 * BN) *reinterpret_cast<float4*>(&Bs[buf][bn * LDS_STRIDE + 4 * kq]) = rb;
     };
 
@@ -117,31 +120,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) gload();
-        // fragments: lane group lg takes k = 2*lg, 2*lg+1 of this step (same permutation for A and B)
-        float2 af[4], bf[TN];
+        float2 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            af[i] = *reinterpret_cast<const float2*>(&As[buf][(wave * 64 + i * 16 + li) * LDS_STRIDE + 2 * lg]);
+        for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const float2*>(&As[buf][(wave * 16 * TM + i * 16 + li) * LDS_STRIDE + 2 * lg]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float2*>(&Bs[buf][(j * 16 + li) * LDS_STRIDE + 2 * lg]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: acc[i][j][reg] is (row = 16 i + 4 lg + reg, col = 16 j + li) of the wave tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int m = m0 + wave * 64 + i * 16 + 4 * lg + reg;
+            const int m = m0 + wave * 16 * TM + i * 16 + 4 * lg + reg;
             if (m >= p.M) continue;
             int b, ho, wo;
             decode_m(m, g, b, ho, wo);
@@ -486,24 +487,26 @@ struct WgradArgs {
 #define WG_BKK 128
 #define WG_BN 64
 
+#define WG_MS 16   // reduction rows per step (4 MFMA k-steps of 4)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
-    __shared__ __attribute__((aligned(16))) float Ds[2][8 * WG_BN];
-    __shared__ __attribute__((aligned(16))) float Av[2][8 * WG_BKK];
+    // row strides padded by 16 floats: the 4 k-rows read by one MFMA fragment load fall on disjoint banks
+    constexpr int DSS = WG_BN + 16, AVS = WG_BKK + 16;
+    __shared__ __attribute__((aligned(16))) float Ds[2][WG_MS * DSS];
+    __shared__ __attribute__((aligned(16))) float Av[2][WG_MS * AVS];
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk0 = blockIdx.x * WG_BKK, split = blockIdx.y, n0 = blockIdx.z * WG_BN;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
-    // Av loader: row tid>>5 (0..7), quad tid&31 -> kk fixed for the whole loop
+    // Av loader: rows (tid>>5) and 8 + (tid>>5), quad tid&31 -> kk fixed for the whole loop
     const int arow = tid >> 5, akk = kk0 + 4 * (tid & 31);
     const bool a_kin = akk < g.Ktot;
     int kh = 0, r = akk;
     if (a_kin) { kh = akk / g.seglen; r = akk - kh * g.seglen; }
     const size_t a_koff = (size_t)kh * g.segstride + r;
-    // Ds loader: threads < 128: row tid>>4, quad tid&15
+    // Ds loader: row tid>>4 (0..15), quad tid&15
     const int drow = tid >> 4, dn = n0 + 4 * (tid & 15);
-    const bool d_role = tid < 128;
     const bool d_nin = dn < p.N;  // N is a multiple of 4 for every layer
 
     f32x4 acc[4][2];
@@ -513,32 +516,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    float4 ra, rd;
+    // positions of this thread's three loader rows, advanced by WG_MS per step (no divisions in the loop)
+    int pb_[3], ph_[3], pw_[3];
+    {
+        const int rows[3] = {arow, arow + 8, drow};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) decode_m(min(m_begin + rows[q], p.M - 1), g, pb_[q], ph_[q], pw_[q]);
+    }
+    float4 ra[2], rd;
     auto gload = [&](int mbase) {
-        {
-            const int m = mbase + arow;
-            ra = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = mbase + arow + 8 * h;
+            ra[h] = make_float4(0, 0, 0, 0);
             if (a_kin && m < m_end) {
-                int b, ho, wo;
-                decode_m(m, g, b, ho, wo);
-                const size_t off = (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C;
-                ra = *reinterpret_cast<const float4*>(p.A + off + a_koff);
+                const size_t off = (((size_t)pb_[h] * g.H + ph_[h] + g.ih0) * g.W + pw_[h] + g.iw0) * g.C;
+                ra[h] = *reinterpret_cast<const float4*>(p.A + off + a_koff);
             }
         }
-        if (d_role) {
+        {
             const int m = mbase + drow;
             rd = make_float4(0, 0, 0, 0);
             if (d_nin && m < m_end) {
-                int b, ho, wo;
-                decode_m(m, g, b, ho, wo);
-                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+                const size_t off = (((size_t)pb_[2] * g.OH + ph_[2] + g.oh0) * g.OW + pw_[2] + g.ow0) * g.OC;
                 rd = *reinterpret_cast<const float4*>(p.dOut + off + dn);
             }
         }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            pw_[q] += WG_MS;
+            while (pw_[q] >= g.Wout) { pw_[q] -= g.Wout; if (++ph_[q] == g.Hout) { ph_[q] = 0; ++pb_[q]; } }
+        }
     };
     auto lstore = [&](int buf) {
-        *reinterpret_cast<float4*>(&Av[buf][arow * WG_BKK + 4 * (tid & 31)]) = ra;
-        if (d_role) *reinterpret_cast<float4*>(&Ds[buf][drow * WG_BN + 4 * (tid & 15)]) = rd;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(&Av[buf][(arow + 8 * h) * AVS + 4 * (tid & 31)]) = ra[h];
+        *reinterpret_cast<float4*>(&Ds[buf][drow * DSS + 4 * (tid & 15)]) = rd;
     };
 
     const int li = lane & 15, lg = lane >> 4;
@@ -548,16 +561,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
     }
     __syncthreads();
     int buf = 0;
-    for (int mb = m_begin; mb < m_end; mb += 8, buf ^= 1) {
-        const bool more = mb + 8 < m_end;
-        if (more) gload(mb + 8);
+    for (int mb = m_begin; mb < m_end; mb += WG_MS, buf ^= 1) {
+        const bool more = mb + WG_MS < m_end;
+        if (more) gload(mb + WG_MS);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < WG_MS / 4; ++s) {
             float af[4], bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = Ds[buf][(4 * s + lg) * WG_BN + i * 16 + li];
+            for (int i = 0; i < 4; ++i) af[i] = Ds[buf][(4 * s + lg) * DSS + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Av[buf][(4 * s + lg) * WG_BKK + wave * 32 + j * 16 + li];
+            for (int j = 0; j < 2; ++j) bf[j] = Av[buf][(4 * s + lg) * AVS + wave * 32 + j * 16 + li];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
         }
         if (p.bpart && blockIdx.x == 0 && tid < WG_BN) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) bsum += Ds[buf][rr * WG_BN + tid];
+            for (int rr = 0; rr < WG_MS; ++rr) bsum += Ds[buf][rr * DSS + tid];
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
@@ -652,12 +665,24 @@ extern "C" int nele_conv_gemm(const float* A, const float* Wg, const float* bias
     if (st) return st;
     NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_gemm: epilogue needs bias");
     NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_gemm: epilogue needs aux");
-    const int gx = (M + GEMM_BM - 1) / GEMM_BM;
     hipStream_t s = as_stream(stream);
-    if (N <= 16) hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3(gx, 1), dim3(256), 0, s, p);
-    else if (N <= 32) hipLaunchKernelGGL(conv_gemm_kernel<2>, dim3(gx, 1), dim3(256), 0, s, p);
-    else if (N <= 48) hipLaunchKernelGGL(conv_gemm_kernel<3>, dim3(gx, 1), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv_gemm_kernel<4>, dim3(gx, (N + 63) / 64), dim3(256), 0, s, p);
+    // rows per block: 256 when M alone yields >= 2 blocks per CU, else 128 / 64 so that the grid still covers the chip
+    const int ny = (N + 63) / 64;
+    int TMsel = 4;
+    if ((long long)((M + 255) / 256) * ny < 512) TMsel = 2;
+    if ((long long)((M + 127) / 128) * ny < 512) TMsel = 1;
+    const int BM = 64 * TMsel, gx = (M + BM - 1) / BM;
+#define LAUNCH_GEMM(TN_) \
+    do { \
+        if (TMsel == 4) hipLaunchKernelGGL((conv_gemm_kernel<TN_, 4>), dim3(gx, (TN_ == 4) ? ny : 1), dim3(256), 0, s, p); \
+        else if (TMsel == 2) hipLaunchKernelGGL((conv_gemm_kernel<TN_, 2>), dim3(gx, (TN_ == 4) ? ny : 1), dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((conv_gemm_kernel<TN_, 1>), dim3(gx, (TN_ == 4) ? ny : 1), dim3(256), 0, s, p); \
+    } while (0)
+    if (N <= 16) LAUNCH_GEMM(1);
+    else if (N <= 32) LAUNCH_GEMM(2);
+    else if (N <= 48) LAUNCH_GEMM(3);
+    else LAUNCH_GEMM(4);
+#undef LAUNCH_GEMM
     NELE_CHECK_LAUNCH("nele_conv_gemm");
     return NELE_OK;
 }
@@ -804,7 +829,7 @@ extern "C" int nele_conv_wgrad(const float* A, const float* dOut, float* workspa
     p.part = workspace;
     p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
     int rps = (M + splits - 1) / splits;
-    rps = (rps + 7) / 8 * 8;
+    rps = (rps + WG_MS - 1) / WG_MS * WG_MS;
     p.rows_per_split = rps;
     hipStream_t s = as_stream(stream);
     dim3 grid((p.g.Ktot + WG_BKK - 1) / WG_BKK, splits, (N + WG_BN - 1) / WG_BN);
