@@ -56,18 +56,22 @@ __device__ __forceinline__ void eigh_house(double* v, int m, double* red, double
     __syncthreads();
 }
 
+// Six workgroup barriers per step: (1,2) reduce p.v, (3,4) reduce ||x'||^2 of the next pivot row, (5) publish the next
+// Householder vector, (6) end of the fused pass.  Vectors ping-pong between two LDS slots; the two row groups of the pass
+// leave their partial matrix-vector products in separate arrays that the next step adds on the fly.
 __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
-    __shared__ double v[EG_MAXN], w[EG_MAXN], vn[EG_MAXN], pn[EG_MAXN];
+    __shared__ double vb[2][EG_MAXN], wv[EG_MAXN], pa[EG_MAXN], pb2[EG_MAXN];
     __shared__ double red[16];
     __shared__ double s_tau, s_scale, s_beta;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
     double* tau = ws.tau + (size_t)b * n;
-    // step 0: v from row 0, p = A22 v by a plain pass
+    // step 0: v from row 0, p = A22 v by a plain pass (two row groups -> pa, pb2)
     {
         const int m = n - 1;
+        double* v = vb[0];
         for (int i = tid; i < m; i += 1024) v[i] = A[1 + i];
         __syncthreads();
         eigh_house(v, m, red, &s_tau, &s_scale, &s_beta);
@@ -76,76 +80,92 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
         double acc = 0.0;
         if (c < m)
             for (int r = grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * v[r];
-        if (grp == 1 && c < m) w[c] = acc;
-        __syncthreads();
-        if (grp == 0 && c < m) w[c] += acc;       // A22 v (tau applied below)
+        if (c < m) (grp ? pb2 : pa)[c] = acc;
         __syncthreads();
     }
+    double tk = s_tau, betak = s_beta;     // every thread carries tau_k / beta_k in registers
     for (int k = 0; k < n - 1; ++k) {
-        const int m = n - k - 1;
+        const int m = n - k - 1, cur = k & 1;
+        double* v = vb[cur];
+        double* vn = vb[cur ^ 1];
         double* rowk = A + (size_t)k * n + k + 1;
         double* A22 = A + (size_t)(k + 1) * n + (k + 1);
-        const double t = s_tau;
-        if (tid == 0) { d[k] = A[(size_t)k * n + k]; e[k] = s_beta; tau[k] = t; }
-        for (int i = tid; i < m; i += 1024) rowk[i] = v[i];      // keep the reflector in row k
-        // w = tau*(A22 v) - (tau/2)(p.v) v      (w currently holds A22 v)
+        if (tid == 0) { d[k] = A[(size_t)k * n + k]; e[k] = betak; tau[k] = tk; }
+        // (1,2) p.v with p = tau * (pa + pb2)
         double pv = 0.0;
-        for (int i = tid; i < m; i += 1024) pv += t * w[i] * v[i];
+        for (int i = tid; i < m; i += 1024) {
+            const double vi = v[i];
+            rowk[i] = vi;                                  // keep the reflector in row k
+            pv += tk * (pa[i] + pb2[i]) * vi;
+        }
         pv = block_sum(pv, red);
-        const double al = -0.5 * t * pv;
-        __syncthreads();
-        for (int i = tid; i < m; i += 1024) w[i] = t * w[i] + al * v[i];
-        __syncthreads();
-        if (m == 1) {   // last step: 1x1 trailing block
-            if (tid == 0) A22[0] -= 2.0 * v[0] * w[0];
+        const double al = -0.5 * tk * pv;
+        const double w0 = tk * (pa[0] + pb2[0]) + al * v[0];
+        if (m == 1) {                                      // last step: 1x1 trailing block
+            if (tid == 0) A22[0] -= 2.0 * v[0] * w0;
             __syncthreads();
             break;
         }
-        // first updated row of A22 -> next Householder vector (its elements 1..m-1)
+        // w, first updated row -> x' (next pivot row), ||x'[1:]||^2
         const int m2 = m - 1;
-        for (int j = tid; j < m2; j += 1024) vn[j] = A22[1 + j] - v[0] * w[1 + j] - w[0] * v[1 + j];
-        if (tid == 0) A22[0] -= 2.0 * v[0] * w[0];
-        __syncthreads();
-        __shared__ double n_tau, n_scale, n_beta;
-        eigh_house(vn, m2, red, &n_tau, &n_scale, &n_beta);
-        // fused pass: thread = column c (symmetric matrix: column c == row c), two thread groups split the rows.
-        // x = A22[r][c] - v_r w_c - w_r v_c is written back and accumulated into (A' vn)_c; row reads are coalesced
-        // across the threads and need no cross-lane reduction.
+        const double v0 = v[0];
+        double ss = 0.0;
+        for (int i = tid; i < m; i += 1024) {
+            const double wi = tk * (pa[i] + pb2[i]) + al * v[i];
+            wv[i] = wi;
+            if (i >= 1) {
+                const double x = A22[i] - v0 * wi - w0 * v[i];
+                vn[i - 1] = x;
+                if (i >= 2) ss += x * x;
+            }
+        }
+        if (tid == 0) A22[0] -= 2.0 * v0 * w0;
+        ss = block_sum(ss, red);                           // (3,4); also publishes wv and the raw vn
+        double tn_ = 0.0, betan = vn[0], scn = 0.0;
+        {
+            const double alpha = vn[0];
+            if (ss > 0.0) {
+                const double nrm = sqrt(alpha * alpha + ss);
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn_ = (betan - alpha) / betan;
+                scn = 1.0 / (alpha - betan);
+            }
+        }
+        __syncthreads();                                   // everyone has read vn[0] before it is overwritten
+        for (int i = tid; i < m2; i += 1024) vn[i] = (i == 0) ? 1.0 : vn[i] * scn;
+        __syncthreads();                                   // (5)
+        // fused pass: thread = column c, two row groups; x = A22[r][c] - v_r w_c - w_r v_c; acc += x * vn[r-1]
         {
             const int c = tid & 511, grp = tid >> 9;
             double acc = 0.0;
             if (c >= 1 && c < m) {
-                const double vc = v[c], wc = w[c];
-                if (t != 0.0) {
+                const double vc = v[c], wc = wv[c];
+                if (tk != 0.0) {
                     int r = 1 + grp;
                     for (; r + 6 < m; r += 8) {
                         double x0 = A22[(size_t)r * n + c], x1 = A22[(size_t)(r + 2) * n + c], x2 = A22[(size_t)(r + 4) * n + c],
                                x3 = A22[(size_t)(r + 6) * n + c];
-                        x0 -= v[r] * wc + w[r] * vc; x1 -= v[r + 2] * wc + w[r + 2] * vc;
-                        x2 -= v[r + 4] * wc + w[r + 4] * vc; x3 -= v[r + 6] * wc + w[r + 6] * vc;
+                        x0 -= v[r] * wc + wv[r] * vc; x1 -= v[r + 2] * wc + wv[r + 2] * vc;
+                        x2 -= v[r + 4] * wc + wv[r + 4] * vc; x3 -= v[r + 6] * wc + wv[r + 6] * vc;
                         A22[(size_t)r * n + c] = x0; A22[(size_t)(r + 2) * n + c] = x1; A22[(size_t)(r + 4) * n + c] = x2;
                         A22[(size_t)(r + 6) * n + c] = x3;
                         acc += x0 * vn[r - 1] + x1 * vn[r + 1] + x2 * vn[r + 3] + x3 * vn[r + 5];
                     }
                     for (; r < m; r += 2) {
                         double x0 = A22[(size_t)r * n + c];
-                        x0 -= v[r] * wc + w[r] * vc;
+                        x0 -= v[r] * wc + wv[r] * vc;
                         A22[(size_t)r * n + c] = x0;
                         acc += x0 * vn[r - 1];
                     }
                 } else {
                     for (int r = 1 + grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * vn[r - 1];
                 }
+                (grp ? pb2 : pa)[c - 1] = acc;
             }
-            __syncthreads();                 // pn is free (copied to w at the end of the previous step)
-            if (grp == 1 && c >= 1 && c < m) pn[c - 1] = acc;
-            __syncthreads();
-            if (grp == 0 && c >= 1 && c < m) pn[c - 1] += acc;
         }
-        __syncthreads();
-        for (int i = tid; i < m2; i += 1024) { v[i] = vn[i]; w[i] = pn[i]; }
-        if (tid == 0) { s_tau = n_tau; s_beta = n_beta; }
-        __syncthreads();
+        __syncthreads();                                   // (6)
+        tk = tn_;
+        betak = betan;
     }
     if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
 }
