@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def cpu_baseline(metrics, length, n_utt, seed_start=9000):
@@ -56,7 +57,8 @@ def main():
     ap.add_argument('--metrics', default='siib&estoi')
     ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='MFMA operand type of the discriminator conv fwd/dgrad passes')
+    ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'],
+                    help='MFMA operand type of the discriminator conv forward / data-gradient passes (f32 accumulate; BASELINE configs[1] names bf16)')
     a = ap.parse_args()
 
     import torch
@@ -113,6 +115,7 @@ def main():
         T = 1 + a.length // 256
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
+        peak = BF16_MFMA_PEAK_TFLOPS if a.precision == 'bf16' else F32_MFMA_PEAK_TFLOPS
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         out = {
             'metric': 'utterances/sec per GAN_epoch step (G+D+metric loss)',
@@ -125,8 +128,10 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
                                    'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<4> (%s: implicit-GEMM Conv2d 48->64 9x9, M=%d N=64 K=3888)' % (tag, a.batch * 44 * (T - 20)),
-                         'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+            'roofline': {'bound': 'mfma',
+                         'kernel': '%s (%s: span-staged implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
+                             'conv_span16_kernel<4>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': None, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
         if a.breakdown and stage_ev:
