@@ -48,6 +48,7 @@ struct HaspiWs {
     double* cep;     // [B][2][6][nsub] mean-removed cepstral sequences (only the first n_active columns)
     double* cm;      // [B][6][10]    |rho|
     int n24, nsub;
+    int n24p;        // n24 rounded up to a multiple of HP_CH: row stride of the per-sample buffers (chunked kernels read/write whole chunks)
 };
 
 __device__ __forceinline__ double i0_series(double x) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     __shared__ double red[8];
     const int b = blockIdx.x, sig = blockIdx.y, tid = threadIdx.x;
     const float* src = (sig ? y : x) + (size_t)b * L;
-    float* dst = ws.r24 + ((size_t)b * 2 + sig) * ws.n24;
+    float* dst = ws.r24 + ((size_t)b * 2 + sig) * ws.n24p;
     // rms normalisation (pyhaspi2.py:81-84), float32 like the reference's arrays
     double acc = 0.0;
     for (int i = tid; i < L; i += 256) acc += (double)(src[i] * src[i]);
@@ -136,23 +137,35 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     for (int t = tid; t < ws.n24; t += 256) dst[t] = g * dst[t];
 }
 
-// ---- h2: middle ear (pyhaspi2.py:833-841), scipy lfilter = direct form II transposed. grid B, block 64 (lanes 0,1 active)
+// ---- h2: middle ear (pyhaspi2.py:833-841), scipy lfilter = direct form II transposed. grid B, block 64 (lanes 0,1 active).
+// All serial kernels below move samples in register chunks of HP_CH: the loads of a chunk are issued back to back (one
+// memory latency per chunk instead of one per sample), then the recurrence runs out of registers.
+#define HP_CH 32
 __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws) {
     const int b = blockIdx.x, sig = threadIdx.x;
     if (sig >= 2) return;
-    const float* src = ws.r24 + ((size_t)b * 2 + sig) * ws.n24;
-    double* dst = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
+    const float* src = ws.r24 + ((size_t)b * 2 + sig) * ws.n24p;
+    double* dst = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
     const double c0 = 0.937260390269893, c1 = -1.874520780539785, c2 = 0.937260390269893, d1 = -1.870580640735279, d2 = 0.878460920344291;
     double z = 0.0, w0 = 0.0, w1 = 0.0;
-    for (int n = 0; n < ws.n24; ++n) {
-        const double xin = (double)src[n];
-        const double y1 = b0 * xin + z;
-        z = b1 * xin - a1 * y1;
-        const double y2 = c0 * y1 + w0;
-        w0 = c1 * y1 - d1 * y2 + w1;
-        w1 = c2 * y1 - d2 * y2;
-        dst[n] = y2;
+    for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
+        float xin[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) xin[u] = src[n0 + u];        // buffers are padded to whole chunks: no per-element guards
+        double yo[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) {
+            const double x = (double)xin[u];
+            const double y1 = b0 * x + z;
+            z = b1 * x - a1 * y1;
+            const double y2 = c0 * y1 + w0;
+            w0 = c1 * y1 - d1 * y2 + w1;
+            w1 = c2 * y1 - d2 * y2;
+            yo[u] = y2;
+        }
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) dst[n0 + u] = yo[u];
     }
 }
 
@@ -186,65 +199,74 @@ __device__ __forceinline__ double hp_bw1(int ch) {
     return 1.0 + r + 2.0 * r * r * r * r * r * r;
 }
 
-// Gammatone envelope of one stream (lane): demodulate by the rotation recurrence (eb_CosSinCF), filter real and
-// imaginary parts with lfilter([1,a1,a5],[1,-a1,-a2,-a3,-a4]) (DF2T), envelope = gain*|u|.
-// out[n*32] is written; returns the sum of squares of the envelope.
-__device__ __forceinline__ double hp_gammatone_stream(const double* __restrict__ xin, int n24, const GtCoef c, double cf,
-                                                      double* __restrict__ out) {
+// Gammatone envelope: demodulate by the rotation recurrence (eb_CosSinCF), filter real and imaginary parts with
+// lfilter([1,a1,a5],[1,-a1,-a2,-a3,-a4]) (DF2T), envelope = gain*|u|.  One wave per (utterance, signal): lane = part*32 +
+// channel, part 0 filters x*cos, part 1 filters x*sin; the two halves meet through one cross-lane swap per sample.
+// Returns (on the part-0 lanes) the sum of squares of the envelope; out[n*32 + ch] is written by the part-0 lanes.
+__device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ xin, int n24, const GtCoef c, double cf, int part,
+                                                    double* __restrict__ out) {
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
     double cold = 1.0, sold = 0.0;
-    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     double ss = 0.0;
-    for (int n = 0; n < n24; ++n) {
-        if (n > 0) {
-            const double arg = cold * cn + sold * sn;
-            sold = sold * cn - cold * sn;
-            cold = arg;
+    for (int n0 = 0; n0 < n24; n0 += HP_CH) {
+        double xc[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) xc[u] = xin[n0 + u];
+        double eo[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) {
+            if (n0 + u > 0) {
+                const double arg = cold * cn + sold * sn;
+                sold = sold * cn - cold * sn;
+                cold = arg;
+            }
+            const double xr = xc[u] * (part ? sold : cold);
+            const double yr = xr + r0;
+            r0 = c.a1 * xr + c.a1 * yr + r1;
+            r1 = c.a5 * xr + c.a2 * yr + r2;
+            r2 = c.a3 * yr + r3;
+            r3 = c.a4 * yr;
+            const double yo = __shfl_xor(yr, 32, 64);
+            const double e = c.gain * sqrt(yr * yr + yo * yo);
+            eo[u] = e;
+            ss += (n0 + u < n24) ? e * e : 0.0;
         }
-        const double x = xin[n];
-        const double xr = x * cold, xi = x * sold;
-        const double yr = xr + r0;
-        r0 = c.a1 * xr + c.a1 * yr + r1;      // b1*x - a[1]*y with a[1] = -a1
-        r1 = c.a5 * xr + c.a2 * yr + r2;      // b2*x - a[2]*y with a[2] = -a2
-        r2 = c.a3 * yr + r3;
-        r3 = c.a4 * yr;
-        const double yi = xi + i0;
-        i0 = c.a1 * xi + c.a1 * yi + i1;
-        i1 = c.a5 * xi + c.a2 * yi + i2;
-        i2 = c.a3 * yi + i3;
-        i3 = c.a4 * yi;
-        const double e = c.gain * sqrt(yr * yr + yi * yi);
-        out[(size_t)n * HP_NCH] = e;
-        ss += e * e;
+        if (part == 0) {
+#pragma unroll
+            for (int u = 0; u < HP_CH; ++u) out[(size_t)(n0 + u) * HP_NCH] = eo[u];
+        }
     }
     return ss;
 }
 
-// ---- h3: control bank + bandwidth adjustment. grid B, block 64
+// ---- h3: control bank + bandwidth adjustment. grid (2, B), block 64
 __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws) {
-    const int b = blockIdx.x, lane = threadIdx.x, sig = lane >> 5, ch = lane & 31;
+    const int b = blockIdx.y, sig = blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
-    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
-    double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
-    const double ss = hp_gammatone_stream(xin, ws.n24, hp_gt(bw1, cf), cf, out);
-    // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
-    const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
-    double BW;
-    if (cdB < 50.0) BW = 1.0;
-    else if (cdB > 100.0) BW = bw1;
-    else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
-    ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch] = BW;
+    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
+    double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    const double ss = hp_gammatone_wave(xin, ws.n24, hp_gt(bw1, cf), cf, part, out);
+    if (part == 0) {
+        // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
+        const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
+        double BW;
+        if (cdB < 50.0) BW = 1.0;
+        else if (cdB > 100.0) BW = bw1;
+        else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
+        ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch] = BW;
+    }
 }
 
-// ---- h4: signal bank. grid B, block 64
+// ---- h4: signal bank. grid (2, B), block 64
 __global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws) {
-    const int b = blockIdx.x, lane = threadIdx.x, sig = lane >> 5, ch = lane & 31;
+    const int b = blockIdx.y, sig = blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch);
     const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
-    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24;
-    double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
-    (void)hp_gammatone_stream(xin, ws.n24, hp_gt(BW, cf), cf, out);
+    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
+    double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    (void)hp_gammatone_wave(xin, ws.n24, hp_gt(BW, cf), cf, part, out);
 }
 
 // ---- h5: compression gain from the control envelope (pyhaspi2.py:982-991), point-wise, in place on ctl
@@ -256,30 +278,36 @@ __global__ void haspi_gain_kernel(HaspiWs ws, size_t total) {
         le = HP_LEVEL + 20.0 * log10(le);
         le = fmin(fmax(le, 30.0), 100.0);
         const double g = -0.0 - (le - 30.0) * (1.0 - (1.0 / CR));
-        ws.ctl[i] = pow(10.0, g / 20.0);
+        ws.ctl[i] = exp(g * (2.302585092994046 / 20.0));   // 10^(g/20)
     }
 }
 
-// ---- h6: gain low-pass (lfilter([b,b],[1,a])) times envelope, serial. grid B, block 64; result in env
+// ---- h6: gain low-pass lfilter([b,b],[1,a]) (pyhaspi2.py:992-995), serial, in place on ctl (one stream per lane). grid B, block 64
 __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const size_t base = (((size_t)b * 2 + (lane >> 5)) * ws.n24) * HP_NCH + (lane & 31);
-    const double* g = ws.ctl + base;
-    double* e = ws.env + base;
+    double* g = ws.ctl + (((size_t)b * 2 + (lane >> 5)) * ws.n24p) * HP_NCH + (lane & 31);
     const double b0 = 0.095107983402496, a1 = -0.809784033195007;
     double z = 0.0;
-    for (int n = 0; n < ws.n24; ++n) {
-        const double x = g[(size_t)n * HP_NCH];
-        const double y = b0 * x + z;
-        z = b0 * x - a1 * y;
-        e[(size_t)n * HP_NCH] = y * e[(size_t)n * HP_NCH];
+    for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
+        double gx[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) gx[u] = g[(size_t)(n0 + u) * HP_NCH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) {
+            const double y = b0 * gx[u] + z;
+            z = b0 * gx[u] - a1 * y;
+            gx[u] = y;
+        }
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) g[(size_t)(n0 + u) * HP_NCH] = gx[u];
     }
 }
 
-// ---- h7: eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise in place on env
+// ---- h7: compressed envelope = filtered gain * envelope (pyhaspi2.py:997) and eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise
 __global__ void haspi_sl_kernel(HaspiWs ws, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const double y = HP_LEVEL + 20.0 * log10(ws.env[i] + 1.0e-30);
+        const double c = ws.ctl[i] * ws.env[i];
+        const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
         ws.env[i] = y < 0.0 ? 0.0 : y;
     }
 }
@@ -287,7 +315,7 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t total) {
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
 __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    double* e = ws.env + (((size_t)b * 2 + (lane >> 5)) * ws.n24) * HP_NCH + (lane & 31);
+    double* e = ws.env + (((size_t)b * 2 + (lane >> 5)) * ws.n24p) * HP_NCH + (lane & 31);
     const double delta = 2.0;
     const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
     const double T = 1 / HP_FS;
@@ -298,14 +326,22 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
     const double denom = 1.0 / (a11 * a22 - a21 * a12);
     const double R1inv = 1.0 / R1, R12C1 = R1 * R2 * (C1 / T), R23C2 = R2 * R3 * (C2 / T);
     double V1 = 0.0, V2 = 0.0;
-    for (int n = 0; n < ws.n24; ++n) {
-        const double V0 = e[(size_t)n * HP_NCH];
-        const double b1 = V0 * R2 + R12C1 * V1;
-        const double b2 = R23C2 * V2;
-        V1 = denom * (a22 * b1 - a12 * b2);
-        V2 = denom * (-a21 * b1 + a11 * b2);
-        const double out = (V0 - V1) * R1inv;
-        e[(size_t)n * HP_NCH] = out < 0.0 ? 0.0 : out;
+    for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
+        double ex[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) ex[u] = e[(size_t)(n0 + u) * HP_NCH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) {
+            const double V0 = ex[u];
+            const double b1 = V0 * R2 + R12C1 * V1;
+            const double b2 = R23C2 * V2;
+            V1 = denom * (a22 * b1 - a12 * b2);
+            V2 = denom * (-a21 * b1 + a11 * b2);
+            const double out = (V0 - V1) * R1inv;
+            ex[u] = out < 0.0 ? 0.0 : out;
+        }
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) e[(size_t)(n0 + u) * HP_NCH] = ex[u];
     }
 }
 
@@ -324,28 +360,46 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
 }
 
 // ---- h9b: ebm_EnvFilt (pyhaspi2.py:378-414): Hann(52)/sum FIR, "same" alignment (nhalf = 26), every 9th sample.
-// grid (ceil(nsub/8), B, 2), block 256 = 8 sub-frames x 32 channels
+// grid (ceil(nsub/EF_SUB), B, 2), block 256: the EF_SUB*9 + 52 input samples of a block (per channel, group-delay shift
+// applied while loading) are staged in LDS once; thread = (sub-frame, channel).
+#define EF_SUB 32
+#define EF_SPAN (EF_SUB * HP_SPACE + HP_NFILT)
 __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
     __shared__ double benv[HP_NFILT];
-    const int b = blockIdx.y, sig = blockIdx.z, ch = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (threadIdx.x < HP_NFILT) {
-        // np.hanning(52) = 0.5 - 0.5 cos(2 pi n / 51); its sum is 25.5
-        benv[threadIdx.x] = (0.5 - 0.5 * cospi(2.0 * (double)threadIdx.x / 51.0)) / 25.5;
+    __shared__ double xs[EF_SPAN][HP_NCH + 1];
+    const int b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x, ch = tid & 31;
+    const int i0 = blockIdx.x * EF_SUB;
+    if (tid < HP_NFILT) benv[tid] = (0.5 - 0.5 * cospi(2.0 * (double)tid / 51.0)) / 25.5;   // np.hanning(52) / sum
+    const int s = ws.shift[(size_t)b * HP_NCH + ch];
+    const double* e = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    // LDS row q <-> shifted-envelope index m = 9*i0 + 26 - 51 + q
+    const int mbase = HP_SPACE * i0 + HP_NHALF - (HP_NFILT - 1);
+    {   // all loads of the thread are issued before the first LDS store (unconditional, clamped index, then select)
+        constexpr int NQ = (EF_SPAN + 7) / 8;
+        double val[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = (tid >> 5) + 8 * u;
+            const int src = mbase + q - s;
+            val[u] = e[(size_t)min(max(src, 0), ws.n24 - 1) * HP_NCH];
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = (tid >> 5) + 8 * u;
+            const int m = mbase + q, src = m - s;
+            if (q < EF_SPAN) xs[q][ch] = (m >= 0 && m < ws.n24 && src >= 0) ? val[u] : 0.0;
+        }
     }
     __syncthreads();
-    if (i >= ws.nsub) return;
-    const int s = ws.shift[(size_t)b * HP_NCH + ch];
-    const double* e = ws.env + (((size_t)b * 2 + sig) * ws.n24) * HP_NCH + ch;
-    double acc = 0.0;
-    const int m0 = HP_SPACE * i + HP_NHALF;
-    for (int k = 0; k < HP_NFILT; ++k) {
-        const int m = m0 - k;                 // index into the group-delay-shifted envelope
-        if (m < 0 || m >= ws.n24) continue;
-        const int src = m - s;
-        if (src < 0) continue;
-        acc += benv[k] * e[(size_t)src * HP_NCH];
+    for (int li = tid >> 5; li < EF_SUB; li += 8) {
+        const int i = i0 + li;
+        if (i >= ws.nsub) break;
+        double acc = 0.0;
+        // out[i] = sum_k benv[k] * x[9 i + 26 - k]  ->  LDS row (9 li + 51 - k)
+#pragma unroll 4
+        for (int k = 0; k < HP_NFILT; ++k) acc += benv[k] * xs[HP_SPACE * li + (HP_NFILT - 1) - k][ch];
+        ws.lp[(((size_t)b * 2 + sig) * ws.nsub + i) * HP_NCH + ch] = acc;
     }
-    ws.lp[(((size_t)b * 2 + sig) * ws.nsub + i) * HP_NCH + ch] = acc;
 }
 
 // ---- h10: ebm_CepCoef (pyhaspi2.py:342-375). one block per utterance
@@ -420,12 +474,12 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
 // ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
 __constant__ double c_modcf[HP_NMOD] = {2, 6, 10, 16, 25, 40, 64, 100, 160, 256};
 __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
-#define HP_TILE 256
+#define HP_TILE 1024          // outputs per tile: 256 threads x 4 consecutive outputs (sliding register window over the taps)
 #define HP_MAXFIR 614
 
 __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     __shared__ double bk[HP_MAXFIR + 1];
-    __shared__ double sxc[HP_TILE + HP_MAXFIR], sxs[HP_TILE + HP_MAXFIR], syc[HP_TILE + HP_MAXFIR], sys_[HP_TILE + HP_MAXFIR];
+    __shared__ double sxc[HP_TILE + HP_MAXFIR + 4], sxs[HP_TILE + HP_MAXFIR + 4], syc[HP_TILE + HP_MAXFIR + 4], sys_[HP_TILE + HP_MAXFIR + 4];
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[2 * b];
@@ -440,41 +494,54 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
     for (int t0 = 0; t0 < na; t0 += HP_TILE) {
         __syncthreads();
-        // demodulated inputs for output samples t0 .. t0+255: input index j = t + nh - i, i = 0..nfir -> j in [t0 - nh, t0 + 255 + nh]
+        // demodulated inputs for outputs t0 .. t0+1023: input index j = t + nh - i, i = 0..nfir -> j in [t0 - nh, t0 + 1023 + nh]
         for (int e = tid; e < HP_TILE + nfir; e += 256) {
             const int j = t0 - nh + e;
-            double vx = 0.0, vy = 0.0, c = 1.0, s = 0.0;
-            if (j >= 0 && j < na) {
-                vx = xc[j];
-                vy = yc[j];
-                if (k > 0) {
-                    // sqrt(2) cos(pi n cf / fNyq), n = j + 1, fNyq = 1280
-                    const double ang = M_PI * (double)(j + 1) * cf / 1280.0;
-                    c = SQ2 * cos(ang);
-                    s = SQ2 * sin(ang);
-                }
+            const int jc = min(max(j, 0), na - 1);
+            double vx = xc[jc], vy = yc[jc], c = 1.0, s = 0.0;
+            if (!(j >= 0 && j < na)) { vx = 0.0; vy = 0.0; }
+            if (k > 0) {
+                // sqrt(2) cos(pi n cf / fNyq), n = j + 1, fNyq = 1280
+                const double ang = M_PI * (double)(j + 1) * cf / 1280.0;
+                c = SQ2 * cos(ang);
+                s = SQ2 * sin(ang);
             }
             sxc[e] = vx * c; sxs[e] = vx * s; syc[e] = vy * c; sys_[e] = vy * s;
         }
         __syncthreads();
-        const int t = t0 + tid;
-        if (t < na) {
-            // u[t] = sum_i b[i] * z[t + nh - i], z = x c - i x s
-            double ur = 0, ui = 0, vr = 0, vi = 0;
-            const int e0 = tid + nfir;     // LDS index of input j = t + nh
+        // thread -> outputs t = t0 + 4 tid + q, q = 0..3:  u[t] = sum_i b[i] z[t + nh - i]  (LDS index 4 tid + q + nfir - i)
+        const int tb = t0 + 4 * tid;
+        if (tb < na) {
+            double ur[4] = {0, 0, 0, 0}, ui[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
+            const int e0 = 4 * tid + nfir;
+            // window registers hold z[e0 - i + q] for q = 0..3
+            double wxc[4], wxs[4], wyc[4], wys[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { wxc[q] = sxc[e0 + q]; wxs[q] = sxs[e0 + q]; wyc[q] = syc[e0 + q]; wys[q] = sys_[e0 + q]; }
             for (int i = 0; i <= nfir; ++i) {
                 const double w = bk[i];
-                ur += w * sxc[e0 - i]; ui -= w * sxs[e0 - i];
-                vr += w * syc[e0 - i]; vi -= w * sys_[e0 - i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ur[q] += w * wxc[q]; ui[q] -= w * wxs[q]; vr[q] += w * wyc[q]; vi[q] -= w * wys[q]; }
+                // slide: next tap reads one element lower
+#pragma unroll
+                for (int q = 3; q > 0; --q) { wxc[q] = wxc[q - 1]; wxs[q] = wxs[q - 1]; wyc[q] = wyc[q - 1]; wys[q] = wys[q - 1]; }
+                const int en = e0 - i - 1;
+                if (en >= 0) { wxc[0] = sxc[en]; wxs[0] = sxs[en]; wyc[0] = syc[en]; wys[0] = sys_[en]; }
             }
-            double c = 1.0, s = 0.0;
-            if (k > 0) {
-                const double ang = M_PI * (double)(t + 1) * cf / 1280.0;
-                c = SQ2 * cos(ang);
-                s = SQ2 * sin(ang);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = tb + q;
+                if (t < na) {
+                    double c = 1.0, s = 0.0;
+                    if (k > 0) {
+                        const double ang = M_PI * (double)(t + 1) * cf / 1280.0;
+                        c = SQ2 * cos(ang);
+                        s = SQ2 * sin(ang);
+                    }
+                    const double xf = ur[q] * c - ui[q] * s, yf = vr[q] * c - vi[q] * s;
+                    sx += xf; sy += yf; sxx += xf * xf; syy += yf * yf; sxy += xf * yf;
+                }
             }
-            const double xf = ur * c - ui * s, yf = vr * c - vi * s;
-            sx += xf; sy += yf; sxx += xf * xf; syy += yf * yf; sxy += xf * yf;
         }
     }
     sx = block_sum(sx, red); sy = block_sum(sy, red); sxx = block_sum(sxx, red); syy = block_sum(syy, red); sxy = block_sum(sxy, red);
@@ -511,13 +578,14 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
     const int nsub = (n24 + HP_SPACE - 1) / HP_SPACE;
+    const int n24p = (n24 + 31) / 32 * 32;
     size_t o = 0;
 #define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
     TAKE(win, double, HP_NWIN);
-    TAKE(r24, float, (size_t)B * 2 * n24);
-    TAKE(mid, double, (size_t)B * 2 * n24);
-    TAKE(ctl, double, (size_t)B * 2 * n24 * HP_NCH);
-    TAKE(env, double, (size_t)B * 2 * n24 * HP_NCH);
+    TAKE(r24, float, (size_t)B * 2 * n24p);
+    TAKE(mid, double, (size_t)B * 2 * n24p);
+    TAKE(ctl, double, (size_t)B * 2 * n24p * HP_NCH);
+    TAKE(env, double, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(shift, int, (size_t)B * HP_NCH);
     TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
@@ -526,7 +594,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(cep, double, (size_t)B * 2 * HP_NBASIS * nsub);
     TAKE(cm, double, (size_t)B * HP_NBASIS * HP_NMOD);
 #undef TAKE
-    if (w) { w->n24 = n24; w->nsub = nsub; }
+    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; }
     return o;
 }
 
@@ -549,19 +617,19 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     HaspiWs ws;
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
     hipStream_t s = as_stream(stream);
-    const size_t total = (size_t)B * 2 * ws.n24 * HP_NCH;
+    const size_t total = (size_t)B * 2 * ws.n24p * HP_NCH;
     const unsigned pw_blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
     hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, 2), dim3(256), 0, s, x, y, L, fs_in, ws);
     hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_control_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_signal_kernel, dim3(B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_control_kernel, dim3(2, B), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
     hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_sl_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
     hipLaunchKernelGGL(haspi_ihc_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + 7) / 8, B, 2), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, 2), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1);
     hipLaunchKernelGGL(haspi_mod_kernel, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(haspi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
