@@ -77,6 +77,7 @@ def main():
     metrics = parse_metrics(a.metrics)
     tr = GanTrainer(a.metrics, device='cuda:%d' % local)
     tr.D.precision = a.precision
+    tr.G.precision = a.precision
     c, v = synth.batch(a.batch, a.length, start=rank * a.batch)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 

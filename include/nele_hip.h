@@ -73,6 +73,16 @@ int nele_conv_span(const float* A, const float* Wfrag, const float* bias, const 
  * (autograd of the layers above).  Split over m across workgroups, partials summed in fixed order.
  * workspace_floats >= nele_conv_wgrad_workspace_floats(M, N, Ktot, &splits). */
 long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, int* splits_out_host);
+/* nele_conv_wgrad_bf16: same contract with bf16 MFMA operands (inputs are rounded to bf16 while staged; float32 accumulation). */
+int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                         const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
+/* bf16-operand variants of the span-staged convolution (float32 in / out, bf16 MFMA operands, float32 accumulation):
+ * weights re-ordered by nele_weight_prep_frag16 into nele_weight_frag16_elems(N, KW*C, KH) bf16 elements. */
+long long nele_weight_frag16_elems(int N, int seglen, int KH);
+int nele_weight_prep_frag16(const float* Wg, int N, int Ktot, int seglen, int KH, void* Wfrag, void* stream);
+int nele_conv_span_bf16_supported(int M, int N, const int* geom_host, int KH, int KW);
+int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                        float slope, const int* geom_host, int KH, int KW, long long a_elems, void* stream);
 int nele_conv_wgrad(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                     const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
 

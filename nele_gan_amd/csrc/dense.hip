@@ -600,6 +600,151 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
     if (p.bpart && blockIdx.x == 0 && tid < WG_BN && n0 + tid < p.N) p.bpart[(size_t)split * p.N + n0 + tid] = bsum;
 }
 
+// bf16-operand weight gradient (v_mfma_f32_16x16x32_bf16, f32 accumulate).  Both MFMA operands want the reduction
+// index m contiguous per lane while memory has n / kk contiguous; the tiles are therefore staged row-major as loaded
+// ([m][n], one 8-byte LDS store per float4) and read back with the hardware transpose read ds_read_b64_tr_b16
+// (per 16-lane group: a 4-row x 16-column block, lane i receives column i): two reads = the 8 consecutive m of a lane's
+// fragment.  32 reduction rows per step.
+#define WG16_MS 32
+#define WG16_LDD (WG_BN + 8)     // bf16 elements per LDS row of the dOut tile
+#define WG16_LDA (WG_BKK + 8)    // ... of the A_view tile
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int lane) {
+    // rows 8g..8g+7 (g = lane>>4) of columns col0..col0+15: lane 4q+p of a group addresses (row q, cols 4p..4p+3)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const __bf16* a0 = tile + (8 * g + q) * ld + col0 + 4 * pq;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * ld));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ds16[2][WG16_MS * WG16_LDD];
+    __shared__ __attribute__((aligned(16))) __bf16 Av16[2][WG16_MS * WG16_LDA];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk0 = blockIdx.x * WG_BKK, split = blockIdx.y, n0 = blockIdx.z * WG_BN;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    const int arow = tid >> 5, akq = tid & 31, akk = kk0 + 4 * akq;      // Av loader: rows arow + 8h (h < 4), kk quad akq
+    const bool a_kin = akk < g.Ktot;
+    int kh = 0, r = akk;
+    if (a_kin) { kh = akk / g.seglen; r = akk - kh * g.seglen; }
+    const size_t a_koff = (size_t)kh * g.segstride + r;
+    const int drow = tid >> 4, dnq = tid & 15, dn = n0 + 4 * dnq;          // Ds loader: rows drow + 16h (h < 2), n quad dnq
+    const bool d_nin = dn < p.N;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int pb_[6], ph_[6], pw_[6];
+    {
+        const int rows[6] = {arow, arow + 8, arow + 16, arow + 24, drow, drow + 16};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) decode_m(min(m_begin + rows[q], p.M - 1), g, pb_[q], ph_[q], pw_[q]);
+    }
+    float4 ra[4], rd[2];
+    auto gload = [&](int mbase) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int m = mbase + arow + 8 * h;
+            ra[h] = make_float4(0, 0, 0, 0);
+            if (a_kin && m < m_end) {
+                const size_t off = (((size_t)pb_[h] * g.H + ph_[h] + g.ih0) * g.W + pw_[h] + g.iw0) * g.C;
+                ra[h] = *reinterpret_cast<const float4*>(p.A + off + a_koff);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = mbase + drow + 16 * h;
+            rd[h] = make_float4(0, 0, 0, 0);
+            if (d_nin && m < m_end) {
+                const size_t off = (((size_t)pb_[4 + h] * g.OH + ph_[4 + h] + g.oh0) * g.OW + pw_[4 + h] + g.ow0) * g.OC;
+                rd[h] = *reinterpret_cast<const float4*>(p.dOut + off + dn);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            pw_[q] += WG16_MS;
+            while (pw_[q] >= g.Wout) { pw_[q] -= g.Wout; if (++ph_[q] == g.Hout) { ph_[q] = 0; ++pb_[q]; } }
+        }
+    };
+    float bcol = 0.f;   // bias gradient: this thread's partial of column dn..dn+3 is folded at the end (threads with equal dnq)
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            bf16x4 v;
+            v[0] = (__bf16)ra[h].x; v[1] = (__bf16)ra[h].y; v[2] = (__bf16)ra[h].z; v[3] = (__bf16)ra[h].w;
+            *reinterpret_cast<bf16x4*>(&Av16[buf][(arow + 8 * h) * WG16_LDA + 4 * akq]) = v;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x4 v;
+            v[0] = (__bf16)rd[h].x; v[1] = (__bf16)rd[h].y; v[2] = (__bf16)rd[h].z; v[3] = (__bf16)rd[h].w;
+            *reinterpret_cast<bf16x4*>(&Ds16[buf][(drow + 16 * h) * WG16_LDD + 4 * dnq]) = v;
+            bq[0] += rd[h].x; bq[1] += rd[h].y; bq[2] += rd[h].z; bq[3] += rd[h].w;     // float32 column sums for the bias gradient
+        }
+    };
+    (void)bcol;
+
+    if (m_begin < m_end) {
+        gload(m_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += WG16_MS, buf ^= 1) {
+        const bool more = mb + WG16_MS < m_end;
+        if (more) gload(mb + WG16_MS);
+        bf16x8 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = tr_frag(Ds16[buf], WG16_LDD, i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = tr_frag(Av16[buf], WG16_LDA, wave * 32 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int li = lane & 15, lg = lane >> 4;
+    float* part = p.part + (size_t)split * p.N * g.Ktot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int n = n0 + i * 16 + 4 * lg + reg;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kk = kk0 + wave * 32 + j * 16 + li;
+                if (kk < g.Ktot) part[(size_t)n * g.Ktot + kk] = acc[i][j][reg];
+            }
+        }
+    // bias gradient: fold the 16 row-lanes (tid>>4) of each n quad through LDS (reuse Ds16 as float scratch)
+    if (p.bpart && blockIdx.x == 0) {
+        float* scr = reinterpret_cast<float*>(&Ds16[0][0]);     // 256 threads x 4 floats = 4 KB <= sizeof(Ds16[0])
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scr[(tid >> 4) * 64 + 4 * dnq + q] = bq[q];
+        __syncthreads();
+        if (tid < WG_BN && n0 + tid < p.N) {
+            float sacc = 0.f;
+            for (int rr = 0; rr < 16; ++rr) sacc += scr[rr * 64 + tid];
+            p.bpart[(size_t)split * p.N + n0 + tid] = sacc;
+        }
+    }
+}
+
 // Sum the split partials in fixed order and scatter from GEMM layout [n][kh][kw][ci] to the
 // PyTorch parameter layout [n][ci][kh][kw] (flip != 0: the partials are in the flipped data-gradient
 // layout, never used for weights).  One thread per weight element.
@@ -813,8 +958,22 @@ extern "C" long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, in
     return (long long)splits * ((long long)N * Ktot + N);
 }
 
+static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                           const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, int bf16, void* stream);
+
 extern "C" int nele_conv_wgrad(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                                const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
+    return conv_wgrad_impl(A, dOut, workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 0, stream);
+}
+
+// same with bf16 MFMA operands (float32 accumulation, float32 partials and result)
+extern "C" int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                                    const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
+    return conv_wgrad_impl(A, dOut, workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 1, stream);
+}
+
+static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
+                           const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, int bf16, void* stream) {
     NELE_CHECK_ARG(A && dOut && workspace && geom && dW, "nele_conv_wgrad: null pointer");
     WgradArgs p;
     memcpy(&p.g, geom, sizeof(ConvGeom));
@@ -829,11 +988,12 @@ extern "C" int nele_conv_wgrad(const float* A, const float* dOut, float* workspa
     p.part = workspace;
     p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
     int rps = (M + splits - 1) / splits;
-    rps = (rps + WG_MS - 1) / WG_MS * WG_MS;
+    rps = (rps + WG16_MS - 1) / WG16_MS * WG16_MS;
     p.rows_per_split = rps;
     hipStream_t s = as_stream(stream);
     dim3 grid((p.g.Ktot + WG_BKK - 1) / WG_BKK, splits, (N + WG_BN - 1) / WG_BN);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
+    if (bf16) hipLaunchKernelGGL(conv_wgrad16_kernel, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
     NELE_CHECK_LAUNCH("nele_conv_wgrad");
     const int total = N * p.g.Ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, s, p.part, p.bpart, splits, N, KH, KW,

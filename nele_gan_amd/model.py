@@ -197,6 +197,7 @@ class Generator_Conv1D_cLN(nn.Module):
         self._bufs = {}
         self._wf = None
         self._last_mask = None
+        self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the conv weight-gradient passes
 
     # ---- plumbing
     def flat_parameters(self, device=None):
@@ -283,7 +284,7 @@ class Generator_Conv1D_cLN(nn.Module):
                  ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
             call('nele_colsum', ptr(bf.gpart), B * bf.nchunks, cout, ptr(seq[2].gain0.grad), 1, stream())
             call('nele_colsum', ptr(bf.bpart), B * bf.nchunks, cout, ptr(seq[2].bias0.grad), 1, stream())
-            ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad)
+            ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=(self.precision == 'bf16'))
             if l > 0:
                 ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
                 dact = bf.dA[l]
@@ -517,7 +518,7 @@ class _DiscriminatorBase(nn.Module):
             if wgrad:
                 N, K = cout, cin_valid * k * k
                 tmpb = bf.tmpw[N * K:N * K + N]
-                ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False)
+                ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0))
                 call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)

@@ -13,6 +13,7 @@ _P = c_void_p
 _SIGS = {
     'nele_conv_gemm': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), _P],
     'nele_conv_wgrad': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
+    'nele_conv_wgrad_bf16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep': [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     'nele_weight_prep_frag': [_P, c_int, c_int, _P, _P],
     'nele_conv_span_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
@@ -132,9 +133,9 @@ def wgrad_workspace_floats(B, N, g):
     return int(_lib.lib.nele_conv_wgrad_workspace_floats(M, N, g.Ktot, None))
 
 
-def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True):
+def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True, bf16=False):
     M = B * g.Hout * g.Wout
-    call('nele_conv_wgrad', ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db),
+    call('nele_conv_wgrad_bf16' if bf16 else 'nele_conv_wgrad', ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db),
          int(accumulate), stream())
 
 

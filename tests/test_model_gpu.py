@@ -236,6 +236,19 @@ def test_bf16_operand_mode_close_to_f32(mods):
                       D.layers[1].weight_orig.grad.cpu().numpy().copy())
     a, b = outs['f32'], outs['bf16']
     assert np.abs(a[0] - b[0]).max() < 2e-3
+    # generator: bf16 mode only affects its weight-gradient passes
+    rs = np.random.RandomState(9)
+    xg = torch.from_numpy((0.1 + 0.4 * rs.rand(2, 60, 64)).astype(np.float32)).cuda()
+    yg = torch.from_numpy((0.1 + 0.4 * rs.rand(2, 60, 64)).astype(np.float32)).cuda()
+    gw = torch.from_numpy(rs.randn(2, 60, 64).astype(np.float32)).cuda()
+    gg = {}
+    for prec in ('f32', 'bf16'):
+        G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+        G.precision = prec
+        G.flat_parameters().grad.zero_()
+        (G(xg, yg) * gw).sum().backward()
+        gg[prec] = G.flat_parameters().grad.cpu().numpy().copy()
+    assert np.abs(gg['f32'] - gg['bf16']).max() < 3e-2 * np.abs(gg['f32']).max()
     for i in (1, 2, 3):
         scale = np.abs(a[i]).max()
         assert np.abs(a[i] - b[i]).max() < 3e-2 * scale, i
