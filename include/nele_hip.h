@@ -60,6 +60,10 @@ int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* s
 int nele_conv_gemm(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
                    int epi, float slope, const int* geom_host, void* stream);
 
+/* nele_conv_gemm_bf16: nele_conv_gemm with bf16 MFMA operands (inputs rounded while staged, float32 accumulation), N > 48. */
+int nele_conv_gemm_bf16(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
+                        int epi, float slope, const int* geom_host, void* stream);
+
 /* Span-staged variant of nele_conv_gemm for 2-D convolutions with long output rows (Wout >= 64, N <= 64): per kernel
  * row the input span of a block's 256 output positions is staged in LDS once and re-read KW times.  Wfrag is Wg
  * [N][Ktot] re-ordered by nele_weight_prep_frag to [Ktot/8][ceil(N/16)][64 lanes][2] (one coalesced load per MFMA

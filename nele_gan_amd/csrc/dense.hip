@@ -323,6 +323,7 @@ __global__ void weight_frag_kernel(const float* __restrict__ Wg, int N, int Ktot
 // the weights arrive fragment-major in bf16.  Wave tile 128 x (16*TN), block = 4 waves = 512 output positions.
 // Each kernel row is padded to a multiple of 32 k-values with zero weights (the A side then reads finite neighbouring data).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define SPAN16_BM 512
 #define SPAN16_MAXRUN 10
 
@@ -473,6 +474,136 @@ __global__ void weight_frag16_kernel(const float* __restrict__ Wg, int N, int Kt
     }
 }
 
+// ------------------------------------------------------------------------------------------ generic implicit GEMM, bf16 operands
+// conv_gemm_kernel with bf16 MFMA operands (inputs rounded to bf16 while staged, float32 accumulation): K step 32 = one
+// v_mfma_f32_16x16x32_bf16 per tile.  Used for the generator's Conv1d / Linear layers in bf16 mode.
+#define G16_BK 32
+#define G16_LD 40     // LDS row stride (bf16 elements): 80 B keeps the 16-byte fragment reads aligned and staggers banks
+template <int TN, int TM>
+__global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(GemmArgs p) {
+    constexpr int BN = 16 * TN;
+    constexpr int BM = 64 * TM;
+    constexpr int ALOADS = (BM * 8 + 255) / 256;    // float4 loads of the A tile per thread (BM rows x 8 quads)
+    constexpr int BLOADS = (BN * 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * G16_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][64 * G16_LD];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int kq = tid & 7;                          // k quad (4 floats) inside the 32-wide step
+    size_t a_off[ALOADS];
+    bool a_ok[ALOADS];
+#pragma unroll
+    for (int i = 0; i < ALOADS; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
+        int b = 0, ho = 0, wo = 0;
+        if (a_ok[i]) decode_m(m, g, b, ho, wo);
+        a_off[i] = (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C;
+    }
+    bool b_ok[BLOADS];
+    const float* wrow[BLOADS];
+#pragma unroll
+    for (int i = 0; i < BLOADS; ++i) {
+        const int bn = (tid >> 3) + 32 * i;
+        b_ok[i] = (bn < BN) && (n0 + bn < p.N);
+        wrow[i] = p.Wg + (size_t)(n0 + bn) * g.Ktot;
+    }
+    int kk = 4 * kq, kh = 0, r = 4 * kq;
+    while (r >= g.seglen) { r -= g.seglen; ++kh; }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (g.Ktot + G16_BK - 1) / G16_BK;
+    float4 ra[ALOADS], rb[BLOADS];
+    auto gload = [&]() {
+        const bool kin = kk < g.Ktot;
+        const size_t koff = (size_t)kh * g.segstride + r;
+#pragma unroll
+        for (int i = 0; i < ALOADS; ++i)
+            ra[i] = (a_ok[i] && kin) ? *reinterpret_cast<const float4*>(p.A + a_off[i] + koff) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BLOADS; ++i)
+            rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const float4*>(wrow[i] + kk) : make_float4(0, 0, 0, 0);
+        kk += G16_BK;
+        r += G16_BK;
+        while (r >= g.seglen) { r -= g.seglen; ++kh; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ALOADS; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            if (row < BM) {
+                bf16x4 v;
+                v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+                *reinterpret_cast<bf16x4*>(&As[buf][row * G16_LD + 4 * kq]) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BLOADS; ++i) {
+            const int bn = (tid >> 3) + 32 * i;
+            if (bn < BN) {
+                bf16x4 v;
+                v[0] = (__bf16)rb[i].x; v[1] = (__bf16)rb[i].y; v[2] = (__bf16)rb[i].z; v[3] = (__bf16)rb[i].w;
+                *reinterpret_cast<bf16x4*>(&Bs[buf][bn * G16_LD + 4 * kq]) = v;
+            }
+        }
+    };
+
+    gload();
+    lstore(0);
+    __syncthreads();
+    const int li = lane & 15, lg = lane >> 4;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload();
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(wave * 16 * TM + i * 16 + li) * G16_LD + 8 * lg]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(j * 16 + li) * G16_LD + 8 * lg]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wave * 16 * TM + i * 16 + 4 * lg + reg;
+            if (m >= p.M) continue;
+            int b, ho, wo;
+            decode_m(m, g, b, ho, wo);
+            const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+            const size_t x_off = (size_t)m * g.OC;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 16 + li;
+                if (n >= p.N) continue;
+                float v = acc[i][j][reg];
+                switch (p.epi) {
+                    case EPI_BIAS: v += p.bias[n]; break;
+                    case EPI_BIAS_LRELU: v += p.bias[n]; v = v > 0.f ? v : p.slope * v; break;
+                    case EPI_MASK_LRELU_GRAD: v = p.aux[x_off + n] > 0.f ? v : p.slope * v; break;
+                    case EPI_BIAS_EXPTANH: v += p.bias[n]; v = expf(3.2f * tanhf(v)); break;
+                    default: break;
+                }
+                p.out[o_off + n] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const float* A;      // forward input activations (geometry g: H,W,C,ih0,iw0,seglen,segstride,Ktot,Hout,Wout)
@@ -608,7 +739,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
 #define WG16_MS 32
 #define WG16_LDD (WG_BN + 8)     // bf16 elements per LDS row of the dOut tile
 #define WG16_LDA (WG_BKK + 8)    // ... of the A_view tile
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int lane) {
     // rows 8g..8g+7 (g = lane>>4) of columns col0..col0+15: lane 4q+p of a group addresses (row q, cols 4p..4p+3)
@@ -829,6 +959,27 @@ extern "C" int nele_conv_gemm(const float* A, const float* Wg, const float* bias
     else LAUNCH_GEMM(4);
 #undef LAUNCH_GEMM
     NELE_CHECK_LAUNCH("nele_conv_gemm");
+    return NELE_OK;
+}
+
+// nele_conv_gemm with bf16 MFMA operands (N > 48 only: the generator's layers)
+extern "C" int nele_conv_gemm_bf16(const float* A, const float* Wg, const float* bias, const float* aux, float* out, int M, int N,
+                                   int epi, float slope, const int* geom, void* stream) {
+    NELE_CHECK_ARG(A && Wg && out && geom, "nele_conv_gemm_bf16: null pointer");
+    GemmArgs p;
+    p.A = A; p.Wg = Wg; p.bias = bias; p.aux = aux; p.out = out; p.M = M; p.N = N; p.epi = epi; p.slope = slope;
+    memcpy(&p.g, geom, sizeof(ConvGeom));
+    int st = check_geom("nele_conv_gemm_bf16", p.g, M, N);
+    if (st) return st;
+    NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_gemm_bf16: epilogue needs bias");
+    NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_gemm_bf16: epilogue needs aux");
+    hipStream_t s = as_stream(stream);
+    const int ny = (N + 63) / 64;
+    const int TMsel = ((long long)((M + 127) / 128) * ny >= 512) ? 2 : 1;
+    const int BM = 64 * TMsel, gx = (M + BM - 1) / BM;
+    if (TMsel == 2) hipLaunchKernelGGL((conv_gemm16_kernel<4, 2>), dim3(gx, ny), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm16_kernel<4, 1>), dim3(gx, ny), dim3(256), 0, s, p);
+    NELE_CHECK_LAUNCH("nele_conv_gemm_bf16");
     return NELE_OK;
 }
 

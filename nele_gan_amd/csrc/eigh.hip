@@ -15,6 +15,7 @@
 // eigenvectors orthogonal to ~eps ||T|| / gap, and for repeated eigenvalues the individual vectors are arbitrary in any
 // solver (SIIB drops the only systematic such cluster, the rank-deficient null space, by its eigenvalue tolerance).
 #include "common.h"
+#include <cstdlib>
 
 #define EG_MAXN 512
 #define EG_SLAB 30
@@ -27,6 +28,7 @@ struct EighWs {
     double* zt;     // [B][n][EG_MAXN]  zt[i][j] = component i of eigenvector j (of T, then of A)
     double* lu;     // [B][5][n][EG_MAXN]
     int* pin;       // [B][n][EG_MAXN]
+    uint4* xch;     // [B][2][2][EG_MAXN] cluster tridiagonalisation: tagged exchange slots (zeroed per call)
 };
 
 // ------------------------------------------------------------------------------------------ e1
@@ -168,6 +170,234 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
         betak = betan;
     }
     if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
+}
+
+
+// ------------------------------------------------------------------------------------------ e1, cluster variant
+// EC_P workgroups per matrix keep the whole trailing matrix in REGISTERS (column-cyclic over the workgroups: workgroup
+// p owns columns c = p + 8 * lane; wave rg of a workgroup owns rows r = rg + 16 * ri), so the per-step pass never touches
+// memory: the single-workgroup kernel above streams sum_k 2 m_k^2 * 8 B per matrix through one CU's L2 port.
+// Per step the workgroups exchange 2n doubles (each contributes the matrix-vector products of its own columns; the owner
+// of the next pivot column publishes it); the O(n) vector work of a step is done redundantly by every workgroup.
+// The exchange is a data-flow handshake without a separate barrier: every double travels as one 16-byte slot
+// {lo32, tag, hi32, tag} written with a single cache-bypassing store and polled by its consumer until both tags carry the
+// step number (each 8-byte half is self-validating, as in the LL protocol of the collectives libraries), so a step
+// costs one store -> load propagation instead of store / atomic / poll / load round trips.  Slots are double-buffered by
+// step parity: a workgroup can only publish step s+2 after it consumed step s+1 from every peer, which in turn published
+// it after consuming step s.  All EC_P * (matrices per launch) workgroups must be co-resident: the host sizes the launch
+// from the device's CU count.  blockIdx -> (XCD, matrix, p) keeps the workgroups of one matrix on one XCD.
+#define EC_P 8
+#define EC_RI (EG_MAXN / 16)
+#define EC_SPIN_LIMIT (1u << 22)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st_tagged(u32x4* p, double v, unsigned tag) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    u32x4 q;
+    q.x = (unsigned)u; q.y = tag; q.z = (unsigned)(u >> 32); q.w = tag;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ double tagged_value(u32x4 q) {
+    return __longlong_as_double((long long)(((unsigned long long)q.z << 32) | q.x));
+}
+// wave64 sum with DPP row operations + readlane (fixed order; ~4x shorter dependency chain than the ds_bpermute butterflies)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)u, l), hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);    // row_half_mirror
+    v += dpp_move<0x140>(v);    // row_mirror: every lane of a 16-lane row holds the row sum
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ double block_sum1(double v, double* slot) {   // one barrier; slot[16] is not reused before 2 more barriers
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += slot[i];
+    return t;
+}
+
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws) {
+    __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
+    __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
+    __shared__ double accb[16][64];
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = g >> 3, p = slot & 7, mloc = (g & 7) + 8 * (slot >> 3);
+    if (mloc >= Bc) return;
+    const int b = b0 + mloc;
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;   // [parity][0: A v | 1: raw pivot column][EG_MAXN]
+
+    // thread tile: 2 columns x 32 rows.  column slots cl0 = lane & 31, cl0 + 32 (c = p + 8 * slot); row slot rs = 2 * wave + (lane >> 5),
+    // rows r = rs + 16 * ri: the 32 lanes of a half-wave share their row values (LDS broadcast), each row value feeds 2 columns.
+    const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
+    const int c0 = p + EC_P * cl0, c1 = c0 + EC_P * 32;
+    double a0[EC_RI], a1[EC_RI];
+#pragma unroll
+    for (int ri = 0; ri < EC_RI; ++ri) {
+        const int r = rs + 16 * ri;
+        a0[ri] = (r < n && c0 < n) ? A[(size_t)r * n + c0] : 0.0;
+        a1[ri] = (r < n && c1 < n) ? A[(size_t)r * n + c1] : 0.0;
+    }
+    const int i = tid;                                     // vector element owned in the O(n) phase
+    const int pi = (i & 15) * 32 + (i >> 4);
+    double v_i = 0.0, tk = 0.0, p_i = 0.0;
+    double col_i = (i < n) ? A[i] : 0.0;                   // column 0 (= row 0)
+#ifdef EC_PROF
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+#define EC_T(j) do { t1 = clock64(); tacc[j] += t1 - t0; t0 = t1; } while (0)
+#else
+#define EC_T(j)
+#endif
+    for (int s = -1; s <= n - 2; ++s) {
+        // ---- O(n) phase: w_s, pivot column s+1 of the updated matrix, Householder vector s+1
+        const bool in = (i >= s + 1) && (i < n);
+        double w_i = 0.0, wpiv = 0.0;
+        if (s >= 0) {
+            if (i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wv] = pv;
+            __syncthreads();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            EC_T(0);
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;                       // v[s+1] = 1
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (i == s + 2) s_alpha = x_i;
+            double ss = (i >= s + 3 && i < n) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wv] = ss;
+            __syncthreads();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            EC_T(1);
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double nrm = sqrt(alpha * alpha + ss);
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = (betan - alpha) / betan;
+                scn = 1.0 / (alpha - betan);
+            }
+            vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
+        }
+        if (p == ((s + 1) & 7)) {                          // one workgroup records the step
+            if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+            if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
+        }
+        if (s == n - 2) break;
+        vnat[i] = v_i; wnat[i] = w_i;
+        vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
+        __syncthreads();
+        EC_T(2);
+        // ---- fused pass over the registers: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r
+        double acc0 = 0.0, acc1 = 0.0;
+        if (c0 >= s + 2 - EC_P * 32 && c0 < n) {           // at least one of the two columns is live (dead ones only see zeros)
+            const double vc0 = vnat[c0], wc0 = wnat[c0];
+            const double vc1 = (c1 < n) ? vnat[c1 & (EG_MAXN - 1)] : 0.0, wc1 = (c1 < n) ? wnat[c1 & (EG_MAXN - 1)] : 0.0;
+            const int ri0 = (s + 2 - rs + 15) >> 4;        // first row slot with r >= s + 2 (may be <= 0)
+            const double2* pv0 = reinterpret_cast<const double2*>(&vperm[0][rs * 32]);
+            const double2* pv1 = reinterpret_cast<const double2*>(&vperm[1][rs * 32]);
+            const double2* pv2 = reinterpret_cast<const double2*>(&vperm[2][rs * 32]);
+#pragma unroll
+            for (int q = 0; q < EC_RI / 8; ++q) {
+                if (8 * q + 7 >= ri0) {
+                    double2 vr[4], wr[4], nr[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { vr[h] = pv0[4 * q + h]; wr[h] = pv1[4 * q + h]; nr[h] = pv2[4 * q + h]; }
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int k0 = 8 * q + 2 * h;
+                        double x0 = a0[k0], x1 = a0[k0 + 1], y0 = a1[k0], y1 = a1[k0 + 1];
+                        x0 -= vr[h].x * wc0 + wr[h].x * vc0;
+                        x1 -= vr[h].y * wc0 + wr[h].y * vc0;
+                        y0 -= vr[h].x * wc1 + wr[h].x * vc1;
+                        y1 -= vr[h].y * wc1 + wr[h].y * vc1;
+                        a0[k0] = x0; a0[k0 + 1] = x1; a1[k0] = y0; a1[k0 + 1] = y1;
+                        acc0 += x0 * nr[h].x + x1 * nr[h].y;
+                        acc1 += y0 * nr[h].x + y1 * nr[h].y;
+                    }
+                }
+            }
+        }
+        EC_T(3);
+        accb[rs][cl0] = acc0;
+        accb[rs][cl0 + 32] = acc1;
+        const unsigned tag = (unsigned)(s + 3);
+        u32x4* xp = xch + (size_t)((s + 1) & 1) * 2 * EG_MAXN;
+        if (rs == ((s + 2) & 15)) {                        // every workgroup publishes its part of pivot row s+2 (= column, by symmetry)
+            double r0 = 0.0, r1 = 0.0;
+            switch ((s + 2) >> 4) {
+#define EC_CASE(k) case k: r0 = a0[k]; r1 = a1[k]; break;
+                EC_CASE(0) EC_CASE(1) EC_CASE(2) EC_CASE(3) EC_CASE(4) EC_CASE(5) EC_CASE(6) EC_CASE(7)
+                EC_CASE(8) EC_CASE(9) EC_CASE(10) EC_CASE(11) EC_CASE(12) EC_CASE(13) EC_CASE(14) EC_CASE(15)
+                EC_CASE(16) EC_CASE(17) EC_CASE(18) EC_CASE(19) EC_CASE(20) EC_CASE(21) EC_CASE(22) EC_CASE(23)
+                EC_CASE(24) EC_CASE(25) EC_CASE(26) EC_CASE(27) EC_CASE(28) EC_CASE(29) EC_CASE(30) EC_CASE(31)
+#undef EC_CASE
+            }
+            if (c0 >= s + 2 && c0 < n) st_tagged(&xp[EG_MAXN + c0], r0, tag);
+            if (c1 >= s + 2 && c1 < n) st_tagged(&xp[EG_MAXN + c1], r1, tag);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += accb[q][tid];
+            const int cc = p + EC_P * tid;
+            if (cc >= s + 2 && cc < n) st_tagged(&xp[cc], t, tag);
+        }
+        EC_T(4);
+        // ---- consume the peers' slots for step s + 1
+        const bool need = (i >= s + 2) && (i < n);
+        if (__any(need)) {
+            u32x4 qp, qc;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (need) {
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(qp), "=&v"(qc) : "v"(&xp[i]), "v"(&xp[EG_MAXN + i]) : "memory");
+                    ok = (qp.y == tag) && (qp.w == tag) && (qc.y == tag) && (qc.w == tag);
+                }
+                if (__all(ok)) break;
+                if (++spins > EC_SPIN_LIMIT) {             // never hang the device: poison the output instead
+                    if (i < n) d[i] = __builtin_nan("");
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
+        }
+        v_i = vn_i;
+        tk = tn;
+        EC_T(5);
+    }
+#ifdef EC_PROF
+    if (tid == 0 && g == 0) for (int j = 0; j < 6; ++j) ws.lamp[j] = (double)tacc[j];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ e2
@@ -464,6 +694,7 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     TAKE(zt, double, (size_t)B * n * EG_MAXN);
     TAKE(lu, double, (size_t)B * 5 * n * EG_MAXN);
     TAKE(pin, int, (size_t)B * n * EG_MAXN);
+    TAKE(xch, uint4, (size_t)B * 4 * EG_MAXN);
 #undef TAKE
     return o;
 }
@@ -481,7 +712,27 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     EighWs ws;
     eigh_layout(B, n, &ws, (char*)workspace);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
+    // cluster tridiagonalisation when at least 8 matrices' worth of workgroups can be co-resident, else one workgroup per matrix
+    static int cluster_cap = -1;                           // matrices per cluster launch (multiple of 8), 0 = unavailable
+    if (cluster_cap < 0) {
+        int dev = 0, ncu = 0, occ = 0;
+        const char* env = getenv("NELE_EIGH_CLUSTER");
+        if (env && env[0] == '0') cluster_cap = 0;
+        else if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(eigh_tridiag_cluster_kernel), 512, 0) == hipSuccess)
+            cluster_cap = ((long long)ncu * (occ > 0 ? 1 : 0) / (8 * EC_P)) * 8;   // one workgroup per CU: never rely on sharing a CU
+        else cluster_cap = 0;
+        if (cluster_cap > 32) cluster_cap = 32;
+    }
+    if (cluster_cap >= 8) {
+        if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
+        for (int b0 = 0; b0 < B; b0 += cluster_cap) {
+            const int Bc = (B - b0 < cluster_cap) ? B - b0 : cluster_cap;
+            hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
+        }
+    } else {
+        hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
+    }
     hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 127) / 128, B), dim3(128), 0, s, n, ws, lam);
     hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam);
     const size_t lds = sizeof(double) * (size_t)n * (EG_SLAB + 1);

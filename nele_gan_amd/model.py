@@ -197,7 +197,7 @@ class Generator_Conv1D_cLN(nn.Module):
         self._bufs = {}
         self._wf = None
         self._last_mask = None
-        self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the conv weight-gradient passes
+        self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the Conv1d / Linear GEMMs (fwd, dgrad, wgrad)
 
     # ---- plumbing
     def flat_parameters(self, device=None):
@@ -242,19 +242,20 @@ class Generator_Conv1D_cLN(nn.Module):
         B, T, _ = x.shape
         key, bf = self._get_bufs(B, T, dev)
         wf, wb = self._prep_weights(dev)
+        b16 = self.precision == 'bf16'
         call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
         for l, (cin, cout, k) in enumerate(_G_LAYERS):
             seq = self.convolutions[l]
-            ops.conv_gemm(bf.inp[l], wf[l], seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l])
+            ops.conv_gemm(bf.inp[l], wf[l], seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l], bf16=b16)
             if l + 1 < len(_G_LAYERS):
                 nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
             else:
                 nxt, pad = bf.a5, 0
             call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
                  ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
-        ops.conv_gemm(bf.a5, wf[6], self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
+        ops.conv_gemm(bf.a5, wf[6], self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc, bf16=b16)
         mask = _empty((B, T, 64), dev)
-        ops.conv_gemm(bf.h1, wf[7], self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
+        ops.conv_gemm(bf.h1, wf[7], self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc, bf16=b16)
         self._last_mask = mask
         return key
 
@@ -272,10 +273,11 @@ class Generator_Conv1D_cLN(nn.Module):
         call('nele_exptanh_bwd', ptr(dmask), ptr(mask), ptr(bf.do2), dmask.numel(), stream())
         # fc2
         ops.conv_wgrad(bf.h1, bf.do2, bf.ws, B, 64, bf.gwfc, 64, self.fc2.weight.grad, self.fc2.bias.grad)
-        ops.conv_gemm(bf.do2, wb[7], None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc)
+        b16 = self.precision == 'bf16'
+        ops.conv_gemm(bf.do2, wb[7], None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc, bf16=b16)
         # fc1
         ops.conv_wgrad(bf.a5, bf.dpre1, bf.ws, B, 64, bf.gwfc, 64, self.fc1.weight.grad, self.fc1.bias.grad)
-        ops.conv_gemm(bf.dpre1, wb[6], None, None, bf.da5, B, 64, EPI_NONE, bf.gfc)
+        ops.conv_gemm(bf.dpre1, wb[6], None, None, bf.da5, B, 64, EPI_NONE, bf.gfc, bf16=b16)
         dact = bf.da5
         for l in range(len(_G_LAYERS) - 1, -1, -1):
             cin, cout, k = _G_LAYERS[l]
@@ -286,7 +288,7 @@ class Generator_Conv1D_cLN(nn.Module):
             call('nele_colsum', ptr(bf.bpart), B * bf.nchunks, cout, ptr(seq[2].bias0.grad), 1, stream())
             ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=(self.precision == 'bf16'))
             if l > 0:
-                ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
+                ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l], bf16=b16)
                 dact = bf.dA[l]
 
 

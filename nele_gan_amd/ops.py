@@ -12,6 +12,7 @@ SLOPE = 0.3  # nn.LeakyReLU(0.3), model.py:79,112
 _P = c_void_p
 _SIGS = {
     'nele_conv_gemm': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), _P],
+    'nele_conv_gemm_bf16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), _P],
     'nele_conv_wgrad': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_conv_wgrad_bf16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep': [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
@@ -68,13 +69,13 @@ class Geom:
 PROFILE = None
 
 
-def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g, tag=None):
+def conv_gemm(A, Wg, bias, aux, out, B, N, epi, g, tag=None, bf16=False):
     M = B * g.Hout * g.Wout
     prof = PROFILE is not None and tag in PROFILE
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('nele_conv_gemm', ptr(A), ptr(Wg), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, stream())
+    call('nele_conv_gemm_bf16' if (bf16 and N > 48) else 'nele_conv_gemm', ptr(A), ptr(Wg), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
