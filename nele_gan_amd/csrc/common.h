@@ -60,6 +60,35 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// wave64 sum with DPP row operations + readlane (fixed order; ~4x shorter dependency chain than the ds_bpermute butterflies)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)u, l), hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);    // row_half_mirror
+    v += dpp_move<0x140>(v);    // row_mirror: every lane of a 16-lane row holds the row sum
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+// sum over each 16-lane row (every lane of the row receives it)
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+
 // Block-wide sum of doubles through LDS scratch (>= blockDim/64 doubles); result to all threads.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     v = wave_sum(v);

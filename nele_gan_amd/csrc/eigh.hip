@@ -200,26 +200,6 @@ __device__ __forceinline__ void st_tagged(u32x4* p, double v, unsigned tag) {
 __device__ __forceinline__ double tagged_value(u32x4 q) {
     return __longlong_as_double((long long)(((unsigned long long)q.z << 32) | q.x));
 }
-// wave64 sum with DPP row operations + readlane (fixed order; ~4x shorter dependency chain than the ds_bpermute butterflies)
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double lane_value(double v, int l) {
-    const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)u, l), hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_move<0x141>(v);    // row_half_mirror
-    v += dpp_move<0x140>(v);    // row_mirror: every lane of a 16-lane row holds the row sum
-    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
-}
 __device__ __forceinline__ double block_sum1(double v, double* slot) {   // one barrier; slot[16] is not reused before 2 more barriers
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;

@@ -331,52 +331,80 @@ __global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws) {
     for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? src[t] - mu : 0.0;
 }
 
-// ---------------------------------------------------------------- float64 tiled GEMMs
-// C[b][i][j] = scale_b * sum_t Xs[b][0][i][t] * Xs[b][0][j][t]   (s6; 64x64 tiles, K step 16)
+// ---------------------------------------------------------------- float64 MFMA GEMMs
+// v_mfma_f64_16x16x4_f64: A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15], D reg q of lane l = D[(l>>4) + 4q][l&15].
+// One double per lane and operand feeds 2048 flops, so LDS traffic is negligible next to the vector-FMA formulation (which
+// was LDS-bound at ~15 TFLOP/s); tiles are double-buffered in LDS with the next tile's global loads in flight.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define SG_LD 68    // LDS row stride (doubles) of a [16][64] k-major tile
+
+// C[b][i][j] = scale_b * sum_t Xs[b][0][i][t] * Xs[b][0][j][t]   (s6).  grid (7, 7, B): lower-triangle 64x64 tiles only, mirrored
+// on store.  Waves 2x2, 32x32 per wave.  Columns >= n_cols of Xs are zero padded and NA is a multiple of 64, so K needs no guard;
+// rows >= 420 are clamped (they only reach outputs that are never stored).
 __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
-    __shared__ double As[16][65], Bs[16][65];
-    const int b = blockIdx.z, ti = blockIdx.y * 64, tj = blockIdx.x * 64, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double As[2][16][SG_LD], Bs[2][16][SG_LD];
+    const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (bj > bi) return;
+    const int ti = bi * 64, tj = bj * 64;
     const int na = ws.info[4 * b + 2];
     const int ncols = na - SB_K + 1;
     const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
-    const int tx = tid & 15, ty = tid >> 4;
-    double acc[4][4] = {};
-    const int kmax = (ncols > 0) ? ncols : 0;
-    for (int k0 = 0; k0 < kmax; k0 += 16) {
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int r = e >> 4, c = e & 15;
-            const bool kin = k0 + c < ws.NA;                                            // columns >= ncols are zero padded
-            As[c][r] = (kin && ti + r < SB_D) ? X[(size_t)(ti + r) * ws.NA + k0 + c] : 0.0;
-            Bs[c][r] = (kin && tj + r < SB_D) ? X[(size_t)(tj + r) * ws.NA + k0 + c] : 0.0;
-        }
+    const int kmax = (ncols > 0) ? ((ncols + 15) & ~15) : 0;
+    const int lr = tid >> 2, lq = (tid & 3) * 4;
+    const double* pa = X + (size_t)min(ti + lr, SB_D - 1) * ws.NA + lq;
+    const double* pb = X + (size_t)min(tj + lr, SB_D - 1) * ws.NA + lq;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32, li = lane & 15, lk = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double4 ra, rb;
+    if (kmax > 0) { ra = *reinterpret_cast<const double4*>(pa); rb = *reinterpret_cast<const double4*>(pb); }
+    for (int k0 = 0, it = 0; k0 < kmax; k0 += 16, ++it) {
+        const int buf = it & 1;
+        As[buf][lq][lr] = ra.x; As[buf][lq + 1][lr] = ra.y; As[buf][lq + 2][lr] = ra.z; As[buf][lq + 3][lr] = ra.w;
+        Bs[buf][lq][lr] = rb.x; Bs[buf][lq + 1][lr] = rb.y; Bs[buf][lq + 2][lr] = rb.z; Bs[buf][lq + 3][lr] = rb.w;
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = As[c][ty * 4 + u]; bv[u] = Bs[c][tx * 4 + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+        if (k0 + 16 < kmax) {
+            ra = *reinterpret_cast<const double4*>(pa + k0 + 16);
+            rb = *reinterpret_cast<const double4*>(pb + k0 + 16);
         }
-        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = 4 * kk + lk;
+            const double a0 = As[buf][k][wr + li], a1 = As[buf][k][wr + 16 + li];
+            const double b0 = Bs[buf][k][wc + li], b1 = Bs[buf][k][wc + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
     const double scale = (ncols > 1) ? 1.0 / (double)(ncols - 1) : 0.0;
     double* C = ws.C + (size_t)b * SB_D * SB_D;
-    for (int u = 0; u < 4; ++u)
-        for (int v = 0; v < 4; ++v) {
-            const int i = ti + ty * 4 + u, j = tj + tx * 4 + v;
-            if (i < SB_D && j < SB_D) C[(size_t)i * SB_D + j] = acc[u][v] * scale;
-        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gi = ti + wr + 16 * i + lk + 4 * q, gj = tj + wc + 16 * j + li;
+                if (gi < SB_D && gj < SB_D) {
+                    const double v = acc[i][j][q] * scale;
+                    C[(size_t)gi * SB_D + gj] = v;
+                    if (bi != bj) C[(size_t)gj * SB_D + gi] = v;
+                }
+            }
 }
 
-// s8: P = U X for both signals (U rows = eigenvectors, [420][420]; X [420][NA]); per 64x64 tile of P
-// emit the row-wise partial sums of Xp^2, Yp^2, Xp*Yp.  grid (NTL, 7, B)
+// s8: P = U X for both signals (U rows = eigenvectors, [420][420]; X [420][NA]); per 64x64 tile of P emit the row-wise partial
+// sums of Xp^2, Yp^2, Xp*Yp.  grid (NTL, 7, B).  Waves 4x1: a wave owns 16 eigenvectors x 64 frames of both signals, so the row
+// sums stay inside the wave (in-lane over the 4 column tiles, then a DPP reduction over the 16 lanes of a row).
 __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
-    __shared__ double Us[16][65], Xt[16][65], Yt[16][65];
-    __shared__ double red[3][64][17];
-    const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(32))) double Us[2][16][SG_LD], Xt[2][16][SG_LD], Yt[2][16][SG_LD];
+    const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     if (t0 >= ws.info[4 * b + 2] - SB_K + 1) {      // tile beyond n_cols: all zero padding
         if (tid < 192) {
             const int q = tid / 64, r = tid - q * 64;
@@ -387,46 +415,51 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     const double* U = ws.U + (size_t)b * SB_D * SB_D;
     const double* X = ws.Xs + (size_t)b * 2 * SB_D * ws.NA;
     const double* Y = X + (size_t)SB_D * ws.NA;
-    const int tx = tid & 15, ty = tid >> 4;
-    double ax[4][4] = {}, ay[4][4] = {};
-    for (int k0 = 0; k0 < SB_D; k0 += 16) {
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int r = e >> 4, c = e & 15;  // U tile: rows ti.., cols k0..
-            Us[c][r] = (ti + r < SB_D && k0 + c < SB_D) ? U[(size_t)(ti + r) * SB_D + k0 + c] : 0.0;
-        }
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int c = e >> 6, r = e & 63;  // X tile: rows k0.., cols t0..
-            const bool in = (k0 + c < SB_D) && (t0 + r < ws.NA);
-            Xt[c][r] = in ? X[(size_t)(k0 + c) * ws.NA + t0 + r] : 0.0;
-            Yt[c][r] = in ? Y[(size_t)(k0 + c) * ws.NA + t0 + r] : 0.0;
-        }
+    const int ur = tid >> 2, uq = (tid & 3) * 4;                 // U tile: 64 rows x 16 k, one double4 per thread
+    const double* pu = U + (size_t)min(ti + ur, SB_D - 1) * SB_D + uq;
+    const int xc = tid >> 4, xq = (tid & 15) * 4;                // X / Y tiles: 16 k x 64 frames, one double4 per thread
+    const double* px = X + (size_t)xc * ws.NA + t0 + xq;
+    const double* py = Y + (size_t)xc * ws.NA + t0 + xq;
+    f64x4 ax[4], ay[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ax[j] = (f64x4){0.0, 0.0, 0.0, 0.0}; ay[j] = (f64x4){0.0, 0.0, 0.0, 0.0}; }
+    const double4 z4 = make_double4(0.0, 0.0, 0.0, 0.0);
+    auto gload = [&](int k0, double4& ru, double4& rx, double4& ry) {
+        ru = (k0 + uq < SB_D) ? *reinterpret_cast<const double4*>(pu + k0) : z4;          // 420 = 4 * 105: quads are all-in or all-out
+        const bool kin = k0 + xc < SB_D;
+        rx = kin ? *reinterpret_cast<const double4*>(px + (size_t)k0 * ws.NA) : z4;
+        ry = kin ? *reinterpret_cast<const double4*>(py + (size_t)k0 * ws.NA) : z4;
+    };
+    double4 ru, rx, ry;
+    gload(0, ru, rx, ry);
+    for (int k0 = 0, it = 0; k0 < SB_D; k0 += 16, ++it) {
+        const int buf = it & 1;
+        Us[buf][uq][ur] = ru.x; Us[buf][uq + 1][ur] = ru.y; Us[buf][uq + 2][ur] = ru.z; Us[buf][uq + 3][ur] = ru.w;
+        *reinterpret_cast<double4*>(&Xt[buf][xc][xq]) = rx;
+        *reinterpret_cast<double4*>(&Yt[buf][xc][xq]) = ry;
         __syncthreads();
+        if (k0 + 16 < SB_D) gload(k0 + 16, ru, rx, ry);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            double uv[4], xv[4], yv[4];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = 4 * kk + lk;
+            const double a = Us[buf][k][16 * w + li];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { uv[u] = Us[c][ty * 4 + u]; xv[u] = Xt[c][tx * 4 + u]; yv[u] = Yt[c][tx * 4 + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { ax[u][v] += uv[u] * xv[v]; ay[u][v] += uv[u] * yv[v]; }
+            for (int j = 0; j < 4; ++j) {
+                ax[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[buf][k][16 * j + li], ax[j], 0, 0, 0);
+                ay[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yt[buf][k][16 * j + li], ay[j], 0, 0, 0);
+            }
         }
-        __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        double sxx = 0, syy = 0, sxy = 0;
+    for (int q = 0; q < 4; ++q) {
+        double sxx = 0.0, syy = 0.0, sxy = 0.0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { sxx += ax[u][v] * ax[u][v]; syy += ay[u][v] * ay[u][v]; sxy += ax[u][v] * ay[u][v]; }
-        red[0][ty * 4 + u][tx] = sxx; red[1][ty * 4 + u][tx] = syy; red[2][ty * 4 + u][tx] = sxy;
-    }
-    __syncthreads();
-    if (tid < 192) {
-        const int q = tid / 64, r = tid - q * 64;
-        if (ti + r < SB_D) {
-            double s = 0.0;
-            for (int c = 0; c < 16; ++c) s += red[q][r][c];
-            ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = s;
+        for (int j = 0; j < 4; ++j) { sxx += ax[j][q] * ax[j][q]; syy += ay[j][q] * ay[j][q]; sxy += ax[j][q] * ay[j][q]; }
+        sxx = row16_sum_dpp(sxx); syy = row16_sum_dpp(syy); sxy = row16_sum_dpp(sxy);
+        const int gi = ti + 16 * w + lk + 4 * q;
+        if (li == 0 && gi < SB_D) {
+            double* dst = ws.part + (((size_t)b * SB_D + gi) * ws.NTL + blockIdx.x) * 3;
+            dst[0] = sxx; dst[1] = syy; dst[2] = sxy;
         }
     }
 }
