@@ -18,7 +18,6 @@
 #include <cstdlib>
 
 #define EG_MAXN 512
-#define EG_SLAB 30
 
 struct EighWs {
     double* d;      // [B][n]
@@ -381,18 +380,19 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 }
 
 // ------------------------------------------------------------------------------------------ e2
-// grid (EG_BSPLIT, B), block 128.  Thread -> one eigenvalue (j-th smallest) by bisection on the Sturm count, evaluated with the
-// division-free three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes = eigenvalues below x).
-#define EG_BSPLIT 4
-__global__ __launch_bounds__(128) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
+// grid (ceil(n/16), B), block 256.  A 16-lane row -> one eigenvalue (j-th smallest) by 17-section on the Sturm count: every
+// round the 16 lanes evaluate the count at 16 interior points of the current interval, so ~13 rounds (instead of 53 bisection
+// steps) of the n-step serial recurrence reach 1 ulp, and 16x more lanes are in flight to hide the recurrence latency.
+// Count: division-free three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes = eigenvalues below x).
+__global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
     __shared__ double sd[EG_MAXN], se2[EG_MAXN];
     __shared__ double red[8];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int j = blockIdx.x * 128 + tid;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, t = lane & 15;
+    const int j = blockIdx.x * 16 + (tid >> 4);
     const double* d = ws.d + (size_t)b * n;
     const double* e = ws.e + (size_t)b * n;
     double gl = 1e300, gu = -1e300, tn = 0.0, e2m = 0.0;
-    for (int i = tid; i < n; i += 128) {
+    for (int i = tid; i < n; i += 256) {
         const double di = d[i];
         sd[i] = di;
         const double ej = (i < n - 1) ? e[i] : 0.0;
@@ -409,31 +409,40 @@ __global__ __launch_bounds__(128) void eigh_bisect_kernel(int n, EighWs ws, doub
     const double eps = 2.220446049250313e-16, safemn = 2.2250738585072014e-308;
     const double pivmin = fmax(safemn, safemn * block_max(e2m, red));
     double lo = glo - 2.0 * tnorm * eps * n - 2.0 * pivmin, hi = ghi + 2.0 * tnorm * eps * n + 2.0 * pivmin;
-    if (j < n) {
-        for (int it = 0; it < 128; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (!(hi - lo > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || mid <= lo || mid >= hi) break;
-            double p0 = 1.0, p1 = sd[0] - mid;
-            if (p1 == 0.0) p1 = -pivmin;
-            int cnt = (p1 < 0.0) ? 1 : 0;
-            int i = 1;
-            while (i < n) {
-                const int iend = min(n, i + 8);
-                for (; i < iend; ++i) {
-                    double p2 = (sd[i] - mid) * p1 - se2[i - 1] * p0;
-                    if (p2 == 0.0) p2 = -copysign(pivmin, p1);
-                    cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
-                    p0 = p1;
-                    p1 = p2;
-                }
-                const double ap = fabs(p1);                    // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
-                if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
-                else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
+    bool active = j < n;
+    for (int it = 0; it < 64; ++it) {
+        const double w = hi - lo;
+        const double x = lo + w * (double)(t + 1) * (1.0 / 17.0);
+        const double x1 = lo + w * (1.0 / 17.0), x16 = lo + w * 16.0 * (1.0 / 17.0);
+        if (!(w > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || x1 <= lo || x16 >= hi) active = false;
+        if (!__any(active)) break;
+        double p0 = 1.0, p1 = sd[0] - x;
+        if (p1 == 0.0) p1 = -pivmin;
+        int cnt = (p1 < 0.0) ? 1 : 0;
+        int i = 1;
+        while (i < n) {
+            const int iend = min(n, i + 8);
+            for (; i < iend; ++i) {
+                double p2 = (sd[i] - x) * p1 - se2[i - 1] * p0;
+                if (p2 == 0.0) p2 = -copysign(pivmin, p1);
+                cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                p0 = p1;
+                p1 = p2;
             }
-            if (cnt <= j) lo = mid; else hi = mid;
+            const double ap = fabs(p1);                    // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
+            if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
+            else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
         }
-        lam_out[(size_t)b * n + j] = 0.5 * (lo + hi);
+        const unsigned long long bal = __ballot(cnt <= j);
+        const int m = __popc((unsigned)((bal >> (lane & 48)) & 0xffffull));   // points of this row with count <= j
+        if (active) {
+            const double nlo = (m == 0) ? lo : lo + w * (double)m * (1.0 / 17.0);
+            const double nhi = (m == 16) ? hi : lo + w * (double)(m + 1) * (1.0 / 17.0);
+            lo = nlo;
+            hi = nhi;
+        }
     }
+    if (j < n && t == 0) lam_out[(size_t)b * n + j] = 0.5 * (lo + hi);
 }
 
 // ------------------------------------------------------------------------------------------ e3
@@ -605,59 +614,103 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
 
 // ------------------------------------------------------------------------------------------ e4
 // Eigenvectors of A = Q z, Q = H_0 H_1 ... H_{n-2}, H_k = I - tau_k v_k v_k^T acting on rows k+1..n-1.
-// grid (ceil(n/EG_SLAB), B), block 256: a slab of EG_SLAB eigenvectors lives in LDS for all n-1 steps; the
-// result is written as U[j][i] (row j = eigenvector j), the layout the SIIB projection reads.
-__global__ __launch_bounds__(256) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
-    extern __shared__ double zs[];            // [n][EG_SLAB + 1]
-    const int b = blockIdx.y, j0 = blockIdx.x * EG_SLAB, tid = threadIdx.x;
-    const int nj = min(EG_SLAB, n - j0);
-    const int ld = EG_SLAB + 1;
+// grid (ceil(n/32), B), block 256.  Eigenvectors live in REGISTERS: a 16-lane row holds two eigenvectors, lane t the rows
+// t + 16 q, so a reflector costs 2 x 2 FMAs per held row, a 4-step DPP row reduction and no barrier.  Reflectors are staged
+// through LDS eight at a time (zeroed below their first row, next chunk's loads in flight during the compute), so there
+// is one barrier per 8 reflectors.  The result is written as U[j][i] (row j = eigenvector j), the layout the SIIB
+// projection reads.
+#define BT_CH 8
+template <int BT_Q>     // 16-row groups held per lane: 28 covers n <= 448 (SIIB: 420), 32 covers EG_MAXN
+__global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
+    extern __shared__ double bt_sm[];         // vch[2][BT_CH][nld], tch[2][BT_CH]
+    const int nld = (n + 15) & ~15;
+    double* vch = bt_sm;
+    double* tch = bt_sm + 2 * BT_CH * nld;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = lane & 15, g = lane >> 4;
+    const int j0 = blockIdx.x * 32 + w * 8 + g * 2;
     const double* A = Aall + (size_t)b * n * n;
     const double* tau = ws.tau + (size_t)b * n;
     const double* zt = ws.zt + (size_t)b * n * EG_MAXN;
-    for (int idx = tid; idx < n * nj; idx += 256) {
-        const int i = idx / nj, c = idx - i * nj;
-        zs[i * ld + c] = zt[(size_t)i * EG_MAXN + j0 + c];
+    double z0[BT_Q], z1[BT_Q];
+#pragma unroll
+    for (int q = 0; q < BT_Q; ++q) {
+        const int i = t + 16 * q;
+        z0[q] = (i < n && j0 < n) ? zt[(size_t)i * EG_MAXN + j0] : 0.0;
+        z1[q] = (i < n && j0 + 1 < n) ? zt[(size_t)i * EG_MAXN + j0 + 1] : 0.0;
     }
+    const int nchunks = (n - 1 + BT_CH - 1) / BT_CH;
+    const int per = BT_CH * nld;              // <= 8 * 512 = 16 * 256
+    constexpr int NPRE = BT_Q / 2;            // 8 * 16 * BT_Q staged values / 256 threads
+    double pre[NPRE];
+    double pret = 0.0;
+    auto gload = [&](int c) {
+        const int kc = n - 2 - BT_CH * c;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            const int r = idx / nld, i = idx - r * nld, k = kc - r;
+            pre[u] = (idx < per && k >= 0 && i > k && i < n) ? A[(size_t)k * n + i] : 0.0;
+        }
+        if (tid < BT_CH) pret = (kc - tid >= 0) ? tau[kc - tid] : 0.0;
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < per) vch[buf * per + idx] = pre[u];
+        }
+        if (tid < BT_CH) tch[buf * BT_CH + tid] = pret;
+    };
+    gload(0);
+    lstore(0);
     __syncthreads();
-    // wave w owns columns 8w..8w+7 of the slab: lane = (row lane rl) * 8 + (column cl); the dot products reduce over
-    // the 8 row lanes with shuffles, so the only barrier per step is the one that publishes the prefetched reflector
-    const int lane = tid & 63, wv = tid >> 6, cl = lane & 7, rl = lane >> 3;
-    const int c = wv * 8 + cl;
-    __shared__ double vbuf[2][EG_MAXN];
-    int cur = 0;
-    if (tid == 0) vbuf[0][0] = A[(size_t)(n - 2) * n + (n - 1)];
-    __syncthreads();
-    for (int k = n - 2; k >= 0; --k) {
-        const int m = n - k - 1;
-        const double t = tau[k];
-        const double* vv = vbuf[cur];
-        double pre0 = 0.0, pre1 = 0.0;         // next step's reflector (row k-1): loads issued now, published after the compute
-        if (k > 0) {
-            if (tid < m + 1) pre0 = A[(size_t)(k - 1) * n + k + tid];
-            if (tid + 256 < m + 1) pre1 = A[(size_t)(k - 1) * n + k + tid + 256];
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1, kc = n - 2 - BT_CH * c;
+        if (c + 1 < nchunks) gload(c + 1);
+        for (int r = 0; r < BT_CH; ++r) {
+            const int k = kc - r;
+            if (k < 0) break;
+            const double tk = tch[buf * BT_CH + r];
+            if (tk == 0.0) continue;
+            const double* vr = vch + buf * per + r * nld + t;
+            const int q0 = (k + 1) >> 4;      // rows below 16 q0 are zero in this reflector
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < BT_Q / 4; ++qq) {
+                if (4 * qq + 3 >= q0) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int q = 4 * qq + h;
+                        const double vq = (16 * q < nld) ? vr[16 * q] : 0.0;
+                        d0 += vq * z0[q];
+                        d1 += vq * z1[q];
+                    }
+                }
+            }
+            d0 = tk * row16_sum_dpp(d0);
+            d1 = tk * row16_sum_dpp(d1);
+#pragma unroll
+            for (int qq = 0; qq < BT_Q / 4; ++qq) {
+                if (4 * qq + 3 >= q0) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int q = 4 * qq + h;
+                        const double vq = (16 * q < nld) ? vr[16 * q] : 0.0;
+                        z0[q] -= d0 * vq;
+                        z1[q] -= d1 * vq;
+                    }
+                }
+            }
         }
-        if (t != 0.0 && c < nj) {
-            double a = 0.0;
-            for (int i = rl; i < m; i += 8) a += vv[i] * zs[(k + 1 + i) * ld + c];
-            a += __shfl_xor(a, 8, 64);
-            a += __shfl_xor(a, 16, 64);
-            a += __shfl_xor(a, 32, 64);
-            const double tc = t * a;
-            for (int i = rl; i < m; i += 8) zs[(k + 1 + i) * ld + c] -= tc * vv[i];
-        }
-        if (k > 0) {
-            double* nx = vbuf[cur ^ 1];
-            if (tid < m + 1) nx[tid] = pre0;
-            if (tid + 256 < m + 1) nx[tid + 256] = pre1;
-        }
+        if (c + 1 < nchunks) lstore(buf ^ 1);
         __syncthreads();
-        cur ^= 1;
     }
     double* Ub = U + (size_t)b * n * n;
-    for (int idx = tid; idx < n * nj; idx += 256) {
-        const int cc = idx / n, i = idx - cc * n;
-        Ub[(size_t)(j0 + cc) * n + i] = zs[i * ld + cc];
+#pragma unroll
+    for (int q = 0; q < BT_Q; ++q) {
+        const int i = t + 16 * q;
+        if (i < n && j0 < n) Ub[(size_t)j0 * n + i] = z0[q];
+        if (i < n && j0 + 1 < n) Ub[(size_t)(j0 + 1) * n + i] = z1[q];
     }
 }
 
@@ -713,15 +766,17 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }
-    hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 127) / 128, B), dim3(128), 0, s, n, ws, lam);
+    hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 15) / 16, B), dim3(256), 0, s, n, ws, lam);
     hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam);
-    const size_t lds = sizeof(double) * (size_t)n * (EG_SLAB + 1);
+    const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * ((n + 15) & ~15) + 2 * BT_CH);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(eigh_backtransform_kernel, dim3((n + EG_SLAB - 1) / EG_SLAB, B), dim3(256), lds, s, A, n, ws, U);
+    if (n <= 448) hipLaunchKernelGGL(eigh_backtransform_kernel<28>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
+    else hipLaunchKernelGGL(eigh_backtransform_kernel<32>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
     NELE_CHECK_LAUNCH("nele_eigh_sym_batched");
     return NELE_OK;
 }
