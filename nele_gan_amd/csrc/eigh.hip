@@ -25,7 +25,7 @@ struct EighWs {
     double* tau;    // [B][n]
     double* lamp;   // [B][n] perturbed eigenvalues used as shifts
     double* zt;     // [B][n][EG_MAXN]  zt[i][j] = component i of eigenvector j (of T, then of A)
-    double* lu;     // [B][5][n][EG_MAXN]
+    double* lu;     // [B][6][(n+2)/2][EG_MAXN][2]
     int* pin;       // [B][n][EG_MAXN]
     uint4* xch;     // [B][2][2][EG_MAXN] cluster tridiagonalisation: tagged exchange slots (zeroed per call)
 };
@@ -446,17 +446,28 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
 }
 
 // ------------------------------------------------------------------------------------------ e3
-// grid (ceil(n/64), B), block 64.  Thread -> one eigenvector of T by inverse iteration.
-#define LU(arr, i) lu[((size_t)(arr) * n + (i)) * EG_MAXN]
+// grid (ceil(n/64), B), block 64.  Thread -> one eigenvector of T by inverse iteration (dlagtf / dlagts / dstein
+// recurrences).  The factors and the iterate live in global work arrays laid out [step pair][thread][2]: a thread's two
+// consecutive steps are one 16-byte load and a wave's loads are contiguous.  Every sweep walks the arrays in chunks whose
+// operands are loaded into registers one chunk ahead, so the serial recurrence runs from registers and the HBM latency
+// of a chunk hides behind the previous chunk.  Row interchanges are one 32-bit mask per 32 steps; 1/pivot is stored at
+// factorisation time so that the back-substitution chain is two FMAs and a multiply (the reference's tiny-pivot perturbation
+// runs on a slow path when that product is not finite or too large).
+// arrays: 0 a, 1 b, 2 c (stored at step+1, next to the iterate element it meets in the forward sweep), 3 d2, 4 x, 5 1/a
+#define IV_F 32     // forward-sweep chunk (steps)
+#define IV_B 16     // backward-sweep chunk (steps)
 __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in) {
     __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
     for (int i = threadIdx.x; i < n; i += 64) { d[i] = ws.d[(size_t)b * n + i]; e[i] = ws.e[(size_t)b * n + i]; }
     __syncthreads();
     if (j >= n) return;
-    double* lu = ws.lu + (size_t)b * 5 * n * EG_MAXN + j;       // arrays: 0 a, 1 b, 2 c, 3 d2, 4 x
-    int* pin = ws.pin + (size_t)b * n * EG_MAXN + j;
+    const int npairs = (n + 2) >> 1;
+    double2* lub = reinterpret_cast<double2*>(ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN);
+    int* pinm = ws.pin + (size_t)b * n * EG_MAXN;               // [chunk of 32 steps][thread] interchange masks
     double* z = ws.zt + (size_t)b * n * EG_MAXN + j;
+#define LUP(arr, pr) lub[((size_t)(arr) * npairs + (pr)) * EG_MAXN + j]
+#define LUE(arr, i) (reinterpret_cast<double*>(&LUP(arr, (i) >> 1))[(i) & 1])
     const double eps = 2.220446049250313e-16, sfmin = 2.2250738585072014e-308, bignum = 1.0 / sfmin;
     double xj;
     {   // dstein: shifts closer than 10 eps |x| to their (already separated) predecessor are pushed apart
@@ -472,145 +483,198 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
         }
         xj = prev;
     }
-    // onenrm
     double onenrm = fabs(d[0]) + (n > 1 ? fabs(e[0]) : 0.0);
     if (n > 1) onenrm = fmax(onenrm, fabs(d[n - 1]) + fabs(e[n - 2]));
     for (int i = 1; i < n - 1; ++i) onenrm = fmax(onenrm, fabs(d[i]) + fabs(e[i - 1]) + fabs(e[i]));
     const double dtpcrt = sqrt(0.1 / (double)n);
-    // ---- dlagtf: LU of T - xj I with partial pivoting; the recurrence values live in registers, every output
-    // element is stored once (arrays: 0 a, 1 b, 2 c, 3 d2)
+    // ---- dlagtf: LU of T - xj I with partial pivoting; the recurrence values live in registers, every output element is
+    // stored once.  The pivot test |c|/scale2 <= |a|/scale1 is evaluated cross-multiplied (no divisions on the chain).
+    double tol = 0.0, alast;
     {
-        const double tl = eps;
         double acur = d[0] - xj;                        // a[k] as modified by step k-1
         double bcur = (n > 1) ? e[0] : 0.0;             // b[k] as modified by step k-1
         double scale1 = fabs(acur) + fabs(bcur);
+        unsigned mask = 0;
         for (int k = 0; k < n - 1; ++k) {
             const double ak = acur, bk = bcur, ak1 = d[k + 1] - xj, ck = e[k];
             const double bk1 = (k < n - 2) ? e[k + 1] : 0.0;
-            double scale2 = fabs(ck) + fabs(ak1);
-            if (k < n - 2) scale2 += fabs(bk1);
-            const double piv1 = (ak == 0.0) ? 0.0 : fabs(ak) / scale1;
-            int pk = 0;
-            double a_out = ak, b_out = bk, c_out = ck, d2_out = 0.0, a_next = ak1, b_next = bk1;
+            const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
+            double a_out = ak, b_out = bk, c_out = ck, d2_out = 0.0, a_next = ak1, b_next = bk1, r;
             if (ck == 0.0) {
                 scale1 = scale2;
+                r = 1.0 / ak;
+            } else if (ak != 0.0 && fabs(ck) * scale1 <= fabs(ak) * scale2) {
+                scale1 = scale2;
+                r = 1.0 / ak;
+                c_out = ck * r;
+                a_next = ak1 - c_out * bk;
             } else {
-                const double piv2 = fabs(ck) / scale2;
-                if (piv2 <= piv1) {
-                    scale1 = scale2;
-                    c_out = ck / ak;
-                    a_next = ak1 - c_out * bk;
-                } else {
-                    pk = 1;
-                    const double mult = ak / ck;
-                    a_out = ck;
-                    a_next = bk - mult * ak1;
-                    d2_out = bk1;
-                    b_next = -mult * bk1;
-                    b_out = ak1;
-                    c_out = mult;
-                }
+                mask |= 1u << ((k + 1) & 31);
+                r = 1.0 / ck;
+                const double mult = ak * r;
+                a_out = ck;
+                a_next = bk - mult * ak1;
+                d2_out = bk1;
+                b_next = -mult * bk1;
+                b_out = ak1;
+                c_out = mult;
             }
-            (void)tl;
-            LU(0, k) = a_out;
-            LU(1, k) = b_out;
-            LU(2, k) = c_out;
-            if (k < n - 2) LU(3, k) = d2_out;
-            pin[(size_t)k * EG_MAXN] = pk;
+            LUE(0, k) = a_out;
+            LUE(1, k) = b_out;
+            LUE(2, k + 1) = c_out;
+            LUE(3, k) = d2_out;
+            LUE(5, k) = r;
+            tol = fmax(fmax(tol, fabs(a_out)), fmax(fabs(b_out), fabs(d2_out)));
+            if (((k + 1) & 31) == 31 || k == n - 2) { pinm[(size_t)((k + 1) >> 5) * EG_MAXN + j] = (int)mask; mask = 0; }
             acur = a_next;
             bcur = b_next;
         }
-        LU(0, n - 1) = acur;
+        LUE(0, n - 1) = acur;
+        LUE(5, n - 1) = 1.0 / acur;
+        alast = fabs(acur);
+        tol = fmax(tol, alast) * eps;
+        if (tol == 0.0) tol = eps;
     }
-    // dlagts tolerance
-    double tol = fabs(LU(0, 0));
-    if (n > 1) tol = fmax(tol, fmax(fabs(LU(0, 1)), fabs(LU(1, 0))));
-    for (int k = 2; k < n; ++k) tol = fmax(fmax(tol, fabs(LU(0, k))), fmax(fabs(LU(1, k - 1)), fabs(LU(3, k - 2))));
-    tol *= eps;
-    if (tol == 0.0) tol = eps;
     // ---- start vector: deterministic pseudo-random in (-1, 1)
-    unsigned int rs = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
-    for (int i = 0; i < n; ++i) {
-        rs = rs * 1664525u + 1013904223u;
-        LU(4, i) = ((double)(rs >> 8) / 8388608.0) - 1.0;
+    double asum = 0.0, s2 = 0.0;
+    {
+        unsigned int rs = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
+        for (int i = 0; i < n; ++i) {
+            rs = rs * 1664525u + 1013904223u;
+            const double v = ((double)(rs >> 8) / 8388608.0) - 1.0;
+            LUE(4, i) = v;
+            asum += fabs(v);
+        }
     }
-    const double alast = fabs(LU(0, n - 1));
+    const int nf = (n + IV_F - 1) / IV_F;             // forward chunks over t = step + 1 in [1, n)
+    const int cbtop = (n - 1) / IV_B;                 // backward chunks over k, cb = cbtop .. 0
     int nrmchk = 0;
     for (int its = 0; its < 8; ++its) {
-        // scale: ||x||_1 -> n * onenrm * max(eps, |a_n|)
-        double asum = 0.0;
-        for (int i = 0; i < n; ++i) asum += fabs(LU(4, i));
+        // scale: ||x||_1 -> n * onenrm * max(eps, |a_n|)   (folded into the loads of the forward sweep)
         const double scl = (double)n * onenrm * fmax(eps, alast) / asum;
-        for (int i = 0; i < n; ++i) LU(4, i) *= scl;
-        // forward elimination with the recorded row interchanges (running value in a register, operands prefetched)
+        // ---- forward elimination with the recorded row interchanges; element t = step + 1 meets c[t] (= c of step t-1)
         {
-            double yprev = LU(4, 0);
-            for (int k0 = 1; k0 < n; k0 += 4) {
-                double yk[4], ck[4];
-                int pk[4];
+            double yprev = scl * LUE(4, 0);
+            auto fload = [&](int ci, double2 (&yk)[IV_F / 2], double2 (&ck)[IV_F / 2], int& m) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = min(k0 + u, n - 1);
-                    yk[u] = LU(4, k); ck[u] = LU(2, k - 1); pk[u] = pin[(size_t)(k - 1) * EG_MAXN];
+                for (int u = 0; u < IV_F / 2; ++u) {
+                    const int pr = min((IV_F / 2) * ci + u, npairs - 1);
+                    yk[u] = LUP(4, pr);
+                    ck[u] = LUP(2, pr);
                 }
+                m = pinm[(size_t)ci * EG_MAXN + j];
+            };
+            auto fstep = [&](int t, double yraw, double c, int bit) {
+                if (t >= 1 && t <= n - 1) {
+                    const double y = scl * yraw;
+                    if (bit == 0) { LUE(4, t - 1) = yprev; yprev = y - c * yprev; }
+                    else { LUE(4, t - 1) = y; yprev = yprev - c * y; }
+                }
+            };
+            auto fproc = [&](int ci, const double2 (&yk)[IV_F / 2], const double2 (&ck)[IV_F / 2], int m) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u;
-                    if (k < n) {
-                        if (pk[u] == 0) { LU(4, k - 1) = yprev; yprev = yk[u] - ck[u] * yprev; }
-                        else { LU(4, k - 1) = yk[u]; yprev = yprev - ck[u] * yk[u]; }
-                    }
+                for (int u = 0; u < IV_F / 2; ++u) {
+                    const int t = IV_F * ci + 2 * u;
+                    fstep(t, yk[u].x, ck[u].x, (m >> (2 * u)) & 1);
+                    fstep(t + 1, yk[u].y, ck[u].y, (m >> (2 * u + 1)) & 1);
+                }
+            };
+            double2 yA[IV_F / 2], cA[IV_F / 2], yB[IV_F / 2], cB[IV_F / 2];
+            int mA = 0, mB = 0;
+            fload(0, yA, cA, mA);
+            for (int ci = 0; ci < nf; ci += 2) {
+                if (ci + 1 < nf) fload(ci + 1, yB, cB, mB);
+                fproc(ci, yA, cA, mA);
+                if (ci + 1 < nf) {
+                    if (ci + 2 < nf) fload(ci + 2, yA, cA, mA);
+                    fproc(ci + 1, yB, cB, mB);
                 }
             }
-            LU(4, n - 1) = yprev;
+            LUE(4, n - 1) = yprev;
         }
-        // back substitution, perturbing tiny pivots (job = -1)
+        // ---- back substitution, perturbing tiny pivots (job = -1)
         double y1 = 0.0, y2 = 0.0;   // x[k+1], x[k+2]
         double nrm = 0.0;
-        for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
-            double xr[4], br[4], d2r[4], ar[4];
+        asum = 0.0;
+        s2 = 0.0;
+        {
+            auto bload = [&](int cb, double2 (&xr)[IV_B / 2], double2 (&rr)[IV_B / 2], double2 (&br)[IV_B / 2], double2 (&dr)[IV_B / 2]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = max(k0 - u, 0);
-                xr[u] = LU(4, k); ar[u] = LU(0, k);
-                br[u] = (k <= n - 2) ? LU(1, k) : 0.0;
-                d2r[u] = (k <= n - 3) ? LU(3, k) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 - u;
-                if (k < 0) continue;
-                double temp = xr[u] - br[u] * y1 - d2r[u] * y2;
-                double ak = ar[u];
-                double pert = copysign(tol, ak);
-                for (int guard = 0; guard < 200; ++guard) {
-                    const double absak = fabs(ak);
-                    if (absak < 1.0) {
-                        if (absak < sfmin) {
-                            if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
-                            temp *= bignum;
-                            ak *= bignum;
-                        } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
-                    }
-                    break;
+                for (int u = 0; u < IV_B / 2; ++u) {
+                    const int pr = min((IV_B / 2) * cb + u, npairs - 1);
+                    xr[u] = LUP(4, pr);
+                    rr[u] = LUP(5, pr);
+                    br[u] = LUP(1, pr);
+                    dr[u] = LUP(3, pr);
                 }
-                const double xk = temp / ak;
-                LU(4, k) = xk;
-                y2 = y1;
-                y1 = xk;
-                nrm = fmax(nrm, fabs(xk));
+            };
+            auto bstep = [&](int k, double xv, double rv, double bv, double dv) {
+                if (k <= n - 1) {
+                    double temp = xv - ((k <= n - 2) ? bv : 0.0) * y1 - ((k <= n - 3) ? dv : 0.0) * y2;
+                    double xk = temp * rv;
+                    if (!(fabs(xk) <= bignum)) {                   // slow path: the reference's pivot perturbation
+                        double ak = LUE(0, k);
+                        double pert = copysign(tol, ak);
+                        for (int guard = 0; guard < 200; ++guard) {
+                            const double absak = fabs(ak);
+                            if (absak < 1.0) {
+                                if (absak < sfmin) {
+                                    if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
+                                    temp *= bignum;
+                                    ak *= bignum;
+                                } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
+                            }
+                            break;
+                        }
+                        xk = temp / ak;
+                    }
+                    LUE(4, k) = xk;
+                    y2 = y1;
+                    y1 = xk;
+                    nrm = fmax(nrm, fabs(xk));
+                    asum += fabs(xk);
+                    s2 += xk * xk;
+                }
+            };
+            auto bproc = [&](int cb, const double2 (&xr)[IV_B / 2], const double2 (&rr)[IV_B / 2], const double2 (&br)[IV_B / 2],
+                             const double2 (&dr)[IV_B / 2]) {
+#pragma unroll
+                for (int u = IV_B / 2 - 1; u >= 0; --u) {
+                    const int k = IV_B * cb + 2 * u;
+                    bstep(k + 1, xr[u].y, rr[u].y, br[u].y, dr[u].y);
+                    bstep(k, xr[u].x, rr[u].x, br[u].x, dr[u].x);
+                }
+            };
+            double2 xA[IV_B / 2], rA[IV_B / 2], bA[IV_B / 2], dA[IV_B / 2], xB[IV_B / 2], rB[IV_B / 2], bB[IV_B / 2], dB[IV_B / 2];
+            bload(cbtop, xA, rA, bA, dA);
+            for (int cb = cbtop; cb >= 0; cb -= 2) {
+                if (cb - 1 >= 0) bload(cb - 1, xB, rB, bB, dB);
+                bproc(cb, xA, rA, bA, dA);
+                if (cb - 1 >= 0) {
+                    if (cb - 2 >= 0) bload(cb - 2, xA, rA, bA, dA);
+                    bproc(cb - 1, xB, rB, bB, dB);
+                }
             }
         }
         if (nrm < dtpcrt) continue;
         if (++nrmchk < 3) continue;
         break;
     }
-    double s2 = 0.0;
-    for (int i = 0; i < n; ++i) { const double x = LU(4, i); s2 += x * x; }
     const double inv = 1.0 / sqrt(s2);
-    for (int i = 0; i < n; ++i) z[(size_t)i * EG_MAXN] = LU(4, i) * inv;
+    for (int p0 = 0; p0 < npairs; p0 += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = LUP(4, min(p0 + u, npairs - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 2 * (p0 + u);
+            if (i < n) z[(size_t)i * EG_MAXN] = t[u].x * inv;
+            if (i + 1 < n) z[(size_t)(i + 1) * EG_MAXN] = t[u].y * inv;
+        }
+    }
+#undef LUP
+#undef LUE
 }
-#undef LU
 
 // ------------------------------------------------------------------------------------------ e4
 // Eigenvectors of A = Q z, Q = H_0 H_1 ... H_{n-2}, H_k = I - tau_k v_k v_k^T acting on rows k+1..n-1.
@@ -725,7 +789,7 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     TAKE(tau, double, (size_t)B * n);
     TAKE(lamp, double, (size_t)B * n);
     TAKE(zt, double, (size_t)B * n * EG_MAXN);
-    TAKE(lu, double, (size_t)B * 5 * n * EG_MAXN);
+    TAKE(lu, double, (size_t)B * 6 * (n + 2) * EG_MAXN);
     TAKE(pin, int, (size_t)B * n * EG_MAXN);
     TAKE(xch, uint4, (size_t)B * 4 * EG_MAXN);
 #undef TAKE
