@@ -390,43 +390,55 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The weight fragments come straight from L2 (every wave of every workgroup reads the same stream, 16 B per lane and
+    // fragment): a 4-deep register ring keeps the loads three k-steps (~1500 MFMA cycles per wave) ahead of their use, which is
+    // what it takes to cover the L2 round trip with only two waves per SIMD.  The ring runs across kernel-row boundaries.
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.Wfrag) + lane;
-    int ks = 0;
-    for (int kh = 0; kh < p.KH; ++kh) {
-        __syncthreads();
-        for (int r = 0; r < nrun; ++r) {
-            const int nfl = run_len[r] * g.C + halo;          // multiple of 8
-            const float* src = p.A + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
-            __bf16* dst = span16 + run_off[r];
-            for (int e = tid * 8; e < nfl; e += 2048) {
-                const float4 a = *reinterpret_cast<const float4*>(src + e);
-                const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
-                bf16x8 v;
-                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-                v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-                *reinterpret_cast<bf16x8*>(dst + e) = v;
-            }
-        }
-        __syncthreads();
-        bf16x8 bfr[TN], bnx[TN];
+    const int KS = p.KH * p.steps_per_seg;
+    bf16x8 bq[4][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = wf[((size_t)ks * p.NT + j) * 64];
-        for (int s = 0; s < p.steps_per_seg; ++s, ++ks) {
-            const bool more = (s + 1 < p.steps_per_seg) || (kh + 1 < p.KH);
-            if (more) {
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bnx[j] = wf[((size_t)(ks + 1) * p.NT + j) * 64];
-            }
-            bf16x8 af[8];
+        for (int j = 0; j < TN; ++j) bq[u][j] = wf[((size_t)min(u, KS - 1) * p.NT + j) * 64];
+    int s = 0, kh = 0;
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(span16 + pb[i] + s * 32);
+        for (int u = 0; u < 4; ++u) {
+            const int ks = ks0 + u;
+            if (ks < KS) {
+                if (s == 0) {                                  // new kernel row: stage its input span (bf16) in LDS
+                    __syncthreads();
+                    for (int r = 0; r < nrun; ++r) {
+                        const int nfl = run_len[r] * g.C + halo;          // multiple of 8
+                        const float* src = p.A + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
+                        __bf16* dst = span16 + run_off[r];
+                        for (int e = tid * 8; e < nfl; e += 2048) {
+                            const float4 a = *reinterpret_cast<const float4*>(src + e);
+                            const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
+                            bf16x8 v;
+                            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+                            *reinterpret_cast<bf16x8*>(dst + e) = v;
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (ks + 3 < KS) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                    for (int j = 0; j < TN; ++j) bq[(u + 3) & 3][j] = wf[((size_t)(ks + 3) * p.NT + j) * 64];
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            if (more) {
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 af[4];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[j] = bnx[j];
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(span16 + pb[4 * h + i] + s * 32);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[4 * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bq[u][j], acc[4 * h + i][j], 0, 0, 0);
+                }
+                if (++s == p.steps_per_seg) { s = 0; ++kh; }
             }
         }
     }
