@@ -14,6 +14,8 @@
 // Tiling: 256 threads = 4 waves stacked along M; wave tile 64 x (16*TN); block tile 256 x (16*TN);
 // K step 8 (two 16x16x4 MFMAs per tile), LDS double-buffered, one barrier per step.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 #include <cstring>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -469,6 +471,269 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ 2-D tile conv, bf16 operands
+// conv_span16_kernel re-stages every input row once per kernel row and lets each wave stream the weights from L2: at bf16 MFMA
+// rates that L2->CU traffic (7 MB per CU and launch for D.conv5), not the matrix pipe, bounds it.  Here a workgroup owns a 2-D
+// tile of TH x 64 output positions and keeps the tile's whole input halo ((TH+KH-1) x (64+KW-1) x C, bf16) resident in LDS:
+// every input element is fetched once per tile (2.25x redundancy instead of 9x) - the first TH rows before the k loop, row
+// TH+kh while kernel row kh is being multiplied.  The weight fragments are shared through LDS in chunks of SB k-steps
+// (SB divides the steps of a kernel row): the next chunk's global loads are issued before the chunk's MFMA loop and only
+// consumed after it, so the loop itself contains nothing but ds_read_b128 and MFMA - no global-load wait can stall it.
+// Position tile (row i, column tile c) belongs to wave (i + c) & 3, so edge tiles (rows >= Hout, columns >= Wout) drop out
+// evenly; their MFMAs are skipped.
+struct Tile16Args {
+    const float* A;
+    const __bf16* Wfrag;   // [KH*steps_per_seg][NT][64][8]
+    const float* bias;
+    const float* aux;
+    float* out;
+    int N, NT;
+    int epi;
+    float slope;
+    int KH, KW, steps_per_seg, SB;
+    ConvGeom g;
+    long long* dbg;        // optional per-phase clock totals of workgroup 0 (benchmark harness only)
+};
+#define TILE16_TW 64
+#define TILE16_SBMAX 9
+
+template <int TN, int TH>
+__global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 halo[];    // [TH+KH-1][RS] + 64 slack, then the weight chunk [SB][TN][64][8]
+#ifdef T16_PROF
+    const long long t16_wstart = wall_clock64();
+#endif
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int wo0 = blockIdx.x * TILE16_TW, ho0 = blockIdx.y * TH, b = blockIdx.z;
+    const int wcols = TILE16_TW + p.KW - 1;            // halo columns
+    const int RS = wcols * g.C;                        // halo row stride (elements)
+    const int nrows = TH + p.KH - 1;
+    const int hi0 = ho0 + g.ih0, wi0 = wo0 + g.iw0;    // window origin in the input buffer
+    const int vcols = max(0, min(wcols, g.W - wi0));   // columns that exist in the input
+    const float* abase = p.A + (((size_t)b * g.H + hi0) * g.W + wi0) * g.C;
+    __bf16* wbuf = halo + nrows * RS + 64;
+    const int SB = p.SB, cps = p.steps_per_seg / SB, nchunk = p.KH * cps;
+    const int cfrag = SB * TN * 64;                    // 16-byte fragments per chunk
+
+    // stage halo row r (float32 -> bf16); elements beyond the input are zero
+    auto stage_row = [&](int r) {
+        const bool rin = hi0 + r < g.H;
+        const float* src = abase + (size_t)r * g.W * g.C;
+        __bf16* dst = halo + r * RS;
+        const int nval = rin ? vcols * g.C : 0;        // multiple of 8
+        for (int e = tid * 8; e < RS; e += 2048) {
+            bf16x8 v;
+            if (e < nval) {
+                const float4 a = *reinterpret_cast<const float4*>(src + e);
+                const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
+                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(dst + e) = v;
+        }
+    };
+    for (int r = 0; r < TH; ++r) stage_row(r);
+    // k-padding reads run up to 31 elements past a position's window: into the slack behind the last row, and into the head of
+    // the next halo row, which may not have arrived yet (zero weights there, but the data must be finite)
+    if (tid < 64)
+        for (int r = TH; r <= nrows; ++r) halo[r * RS + tid] = (__bf16)0.f;
+
+    constexpr int NBR = (TILE16_SBMAX * TN + 3) / 4;   // 16-byte weight fragments per thread and chunk
+    bf16x8 breg[NBR];
+    const int nq = (cfrag + 255) >> 8;                 // groups of 256 fragments per chunk (the last one may run into the next chunk / slack)
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.Wfrag) + tid;
+    auto wload = [&]() {                               // loads the chunk at wp, then advances wp
+#pragma unroll
+        for (int q = 0; q < NBR; ++q)
+            if (q < nq) breg[q] = wp[256 * q];
+        wp += cfrag;
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NBR; ++q)
+            if (q < nq) reinterpret_cast<bf16x8*>(wbuf)[tid + 256 * q] = breg[q];
+    };
+    wload();
+    wstore();
+
+    // this wave's position tiles: row i, column tile (wave - i) & 3
+    int pb[TH];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+        const int c = (wave - i) & 3;
+        pb[i] = i * RS + (16 * c + li) * g.C + 8 * lg;
+        if (ho0 + i < g.Hout && wo0 + 16 * c < g.Wout) valid |= 1u << i;
+    }
+    f32x4 acc[TH][TN];
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    constexpr int RR = 2;                              // bf16x8 groups per thread and halo row: covers RS <= 4096 elements
+    float4 ra[RR], rc[RR];
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf) + lane;
+#ifdef T16_PROF
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tq0 = clock64(), tq1;
+    const long long tw0 = wall_clock64(), tc0 = tq0;
+    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) p.dbg[8] = tw0 - t16_wstart;
+#define T16_T(j) do { tq1 = clock64(); tacc[j] += tq1 - tq0; tq0 = tq1; } while (0)
+#else
+#define T16_T(j)
+#endif
+    T16_T(0);
+    auto mainloop = [&](auto all_valid) {
+        for (int c = 0; c < nchunk; ++c) {
+            const int kh = c / cps, s0 = (c - kh * cps) * SB;
+            const bool seg_first = (s0 == 0), seg_last = (s0 + SB == p.steps_per_seg);
+            if (c + 1 < nchunk) wload();
+            if (seg_first && kh + 1 < p.KH) {          // issue the loads of halo row TH + kh
+                const int r = TH + kh;
+                const bool rin = hi0 + r < g.H;
+                const float* src = abase + (size_t)r * g.W * g.C;
+                const int nval = rin ? vcols * g.C : 0;
+#pragma unroll
+                for (int q = 0; q < RR; ++q) {
+                    const int e = tid * 8 + 2048 * q;
+                    if (e < nval) {
+                        ra[q] = *reinterpret_cast<const float4*>(src + e);
+                        rc[q] = *reinterpret_cast<const float4*>(src + e + 4);
+                    } else {
+                        ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        rc[q] = ra[q];
+                    }
+                }
+            }
+            T16_T(1);
+            // ---- SB k-steps from LDS only.  Fragments are double buffered in registers: the ds_reads of step u+1 are issued
+            // before the 8*TN MFMAs of step u (sched_barrier keeps the compiler from sinking them back next to their use).
+            const __bf16* hk = halo + kh * RS + s0 * 32;
+            auto ldfrag = [&](int u, bf16x8 (&af)[TH], bf16x8 (&bfr)[TN]) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = wl[(u * TN + j) * 64];
+#pragma unroll
+                for (int i = 0; i < TH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hk + pb[i] + u * 32);
+            };
+            auto mm = [&](const bf16x8 (&af)[TH], const bf16x8 (&bfr)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TH; ++i) {
+                    if (decltype(all_valid)::value || (valid & (1u << i))) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            };
+            bf16x8 a0[TH], b0[TN], a1[TH], b1[TN];
+            ldfrag(0, a0, b0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            int u = 0;
+            // One wave per SIMD: while a wave sits in its 8*TN back-to-back MFMA issues nothing else of it can issue, and while it
+            // issues the next step's ds_reads the matrix pipe drains.  The sched_group_barrier pattern interleaves one ds_read (and
+            // its address VALU op) after every two MFMAs, so the reads issue in the MFMAs' 16-cycle shadows.
+#define T16_INTERLEAVE()                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < TH + TN; ++q_) {                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                \
+    }                                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, TH * TN - 2 * (TH + TN) > 0 ? TH * TN - 2 * (TH + TN) : 0, 0)
+            for (; u + 1 < SB; u += 2) {               // branch-free body: a conditional load would force lgkmcnt(0) at the join
+                ldfrag(u + 1, a1, b1);
+                mm(a0, b0);
+                T16_INTERLEAVE();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0) AFTER the MFMAs were issued: the loads above had their shadow;
+                __builtin_amdgcn_sched_barrier(0);     // without it the compiler puts the wait in front of the MFMAs (loop-header join)
+                ldfrag(min(u + 2, SB - 1), a0, b0);
+                mm(a1, b1);
+                T16_INTERLEAVE();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef T16_INTERLEAVE
+            if (u < SB) mm(a0, b0);
+            T16_T(2);
+            if (c + 1 < nchunk) {
+                __syncthreads();                       // every wave is done with this weight chunk
+                T16_T(3);
+                wstore();
+                if (seg_last && kh + 1 < p.KH) {       // publish halo row TH + kh for the next kernel row
+                    __bf16* dst = halo + (TH + kh) * RS;
+#pragma unroll
+                    for (int q = 0; q < RR; ++q) {
+                        const int e = tid * 8 + 2048 * q;
+                        if (e < RS) {
+                            bf16x8 v;
+                            v[0] = (__bf16)ra[q].x; v[1] = (__bf16)ra[q].y; v[2] = (__bf16)ra[q].z; v[3] = (__bf16)ra[q].w;
+                            v[4] = (__bf16)rc[q].x; v[5] = (__bf16)rc[q].y; v[6] = (__bf16)rc[q].z; v[7] = (__bf16)rc[q].w;
+                            *reinterpret_cast<bf16x8*>(dst + e) = v;
+                        }
+                    }
+                }
+                T16_T(4);
+                __syncthreads();
+                T16_T(5);
+            }
+        }
+    };
+    if (valid == (1u << TH) - 1u) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
+#ifdef T16_PROF
+    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0)
+    { for (int j = 0; j < 6; ++j) p.dbg[j] = tacc[j]; p.dbg[6] = wall_clock64() - tw0; p.dbg[7] = clock64() - tc0; }
+#endif
+
+    // ---- epilogue: each position tile (16 positions x 16*TN channels) is transposed through this wave's private 4 KB of LDS
+    // (the halo is dead now) so that the stores are float4 runs along the channels: 16 positions x OC floats are contiguous.
+    __syncthreads();
+    float* ep = reinterpret_cast<float*>(halo) + wave * (16 * 68);          // [16 positions][64 + 4] floats
+    constexpr int NQ = TN * 4;                                            // float4 groups per position
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+        if (!(valid & (1u << i))) continue;
+        const int c = (wave - i) & 3;
+        const int ho = ho0 + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ep[(4 * lg + reg) * 68 + 16 * j + li] = acc[i][j][reg];
+        // lane -> (position row, float4 column); TN*4 float4 per position, 16 positions: TN passes of 64 lanes
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+            const int idx = q * 64 + lane, pr = idx / NQ, cq = idx - pr * NQ;
+            const int wo = wo0 + 16 * c + pr, n = 4 * cq;
+            if (wo < g.Wout && n < p.N) {
+                float4 v = *reinterpret_cast<const float4*>(&ep[pr * 68 + n]);
+                const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + n;
+                if (p.epi == EPI_BIAS || p.epi == EPI_BIAS_LRELU || p.epi == EPI_BIAS_EXPTANH) {
+                    v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3];   // bias may be only 4-byte aligned
+                }
+                if (p.epi == EPI_BIAS_LRELU) {
+                    v.x = v.x > 0.f ? v.x : p.slope * v.x; v.y = v.y > 0.f ? v.y : p.slope * v.y;
+                    v.z = v.z > 0.f ? v.z : p.slope * v.z; v.w = v.w > 0.f ? v.w : p.slope * v.w;
+                } else if (p.epi == EPI_MASK_LRELU_GRAD) {
+                    const float4 x = *reinterpret_cast<const float4*>(p.aux + (((size_t)b * g.Hout + ho) * g.Wout + wo) * g.OC + n);
+                    v.x = x.x > 0.f ? v.x : p.slope * v.x; v.y = x.y > 0.f ? v.y : p.slope * v.y;
+                    v.z = x.z > 0.f ? v.z : p.slope * v.z; v.w = x.w > 0.f ? v.w : p.slope * v.w;
+                } else if (p.epi == EPI_BIAS_EXPTANH) {
+                    v.x = expf(3.2f * tanhf(v.x)); v.y = expf(3.2f * tanhf(v.y)); v.z = expf(3.2f * tanhf(v.z)); v.w = expf(3.2f * tanhf(v.w));
+                }
+                *reinterpret_cast<float4*>(p.out + o_off) = v;
+            }
+        }
+    }
+#ifdef T16_PROF
+    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) p.dbg[9] = wall_clock64() - t16_wstart;
+#endif
 }
 
 // Wg [N][Ktot] f32 -> bf16 fragment-major [KH*sps][NT][64][8], sps = ceil(seglen/32); element (ks = kh*sps + s, j, lane, e) =
@@ -1051,7 +1316,7 @@ extern "C" int nele_conv_span(const float* A, const float* Wfrag, const float* b
 
 // elements (bf16) of the fragment-major weight buffer for nele_conv_span_bf16
 extern "C" long long nele_weight_frag16_elems(int N, int seglen, int KH) {
-    return (long long)KH * ((seglen + 31) / 32) * ((N + 15) / 16) * 512;
+    return (long long)KH * ((seglen + 31) / 32) * ((N + 15) / 16) * 512 + 2048;   // + one 256-fragment group of read slack
 }
 
 extern "C" int nele_weight_prep_frag16(const float* Wg, int N, int Ktot, int seglen, int KH, void* Wfrag, void* stream) {
@@ -1064,9 +1329,32 @@ extern "C" int nele_weight_prep_frag16(const float* Wg, int N, int Ktot, int seg
     return NELE_OK;
 }
 
-extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int KH, int KW) {
-    ConvGeom g;
-    memcpy(&g, geom, sizeof(ConvGeom));
+// LDS bytes of the 2-D tile kernel, or 0 when the geometry does not fit it
+static size_t tile16_lds(const ConvGeom& g, int N, int KH, int KW, int TH) {
+    if (N > 64 || N % 4 || g.OC % 4 || g.C % 8 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
+    const long long RS = (long long)(TILE16_TW + KW - 1) * g.C;
+    if (RS > 4096) return 0;                                            // one row travels as 2 x 8 floats per thread
+    const int sps = (g.seglen + 31) / 32, NT = (N + 15) / 16;
+    int SB = 1;
+    for (int d = 1; d <= TILE16_SBMAX; ++d)
+        if (sps % d == 0) SB = d;
+    const long long bytes = ((long long)(TH + KH - 1) * RS + 64) * 2 + (((long long)SB * NT * 1024 + 4095) & ~4095LL);
+    if (bytes > 158 * 1024) return 0;
+    return (size_t)(bytes < 4 * 16 * 68 * 4 ? 4 * 16 * 68 * 4 : bytes);        // the epilogue transposes through 4 x 4352 B
+}
+static int tile16_sb(const ConvGeom& g) {
+    const int sps = (g.seglen + 31) / 32;
+    int SB = 1;
+    for (int d = 1; d <= TILE16_SBMAX; ++d)
+        if (sps % d == 0) SB = d;
+    return SB;
+}
+static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
+    if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
+    if (tile16_lds(g, N, KH, KW, 4)) return 4;
+    return 0;
+}
+static int span16_supported(int M, int N, const ConvGeom& g, int KH, int KW) {
     if (N > 64 || g.C % 8 || g.Wout < 64 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
     const int maxrun = (SPAN16_BM + g.Wout - 1) / g.Wout + 1;
     if (maxrun > SPAN16_MAXRUN) return 0;
@@ -1074,7 +1362,12 @@ extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int 
     if (el * 2 > 76 * 1024) return 0;
     return 1;
 }
-
+extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int KH, int KW) {
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    if (g.Wout >= 32 && tile16_th(g, N, KH, KW)) return 1;
+    return span16_supported(M, N, g, KH, KW);
+}
 extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
                                    float slope, const int* geom, int KH, int KW, long long a_elems, void* stream) {
     NELE_CHECK_ARG(A && Wfrag && out && geom, "nele_conv_span_bf16: null pointer");
@@ -1087,10 +1380,38 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
     p.steps_per_seg = (p.g.seglen + 31) / 32;
     NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_span_bf16: epilogue needs bias");
     NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_span_bf16: epilogue needs aux");
+    hipStream_t s = as_stream(stream);
+    static int tile_on = -1;
+    if (tile_on < 0) { const char* e = getenv("NELE_CONV_TILE"); tile_on = !(e && e[0] == '0'); }
+    const int th = (tile_on && p.g.Wout >= 32) ? tile16_th(p.g, N, KH, KW) : 0;
+    if (th) {
+        Tile16Args t;
+        t.A = A; t.Wfrag = p.Wfrag; t.bias = bias; t.aux = aux; t.out = out; t.N = N; t.NT = p.NT; t.epi = epi; t.slope = slope;
+        t.KH = KH; t.KW = KW; t.steps_per_seg = p.steps_per_seg; t.g = p.g; t.SB = tile16_sb(p.g); t.dbg = nullptr;
+        const int B_ = M / (p.g.Hout * p.g.Wout);
+        const size_t lds = tile16_lds(p.g, N, KH, KW, th);
+        static bool tattr = false;
+        if (!tattr) {
+#define TILE16_ATTR(TN_, TH_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<TN_, TH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            TILE16_ATTR(1, 8); TILE16_ATTR(2, 8); TILE16_ATTR(3, 8); TILE16_ATTR(4, 8);
+            TILE16_ATTR(1, 4); TILE16_ATTR(2, 4); TILE16_ATTR(3, 4); TILE16_ATTR(4, 4);
+#undef TILE16_ATTR
+            tattr = true;
+        }
+        const dim3 grid((p.g.Wout + TILE16_TW - 1) / TILE16_TW, (p.g.Hout + th - 1) / th, B_);
+#define TILE16_LAUNCH(TN_, TH_) hipLaunchKernelGGL((conv_tile16_kernel<TN_, TH_>), grid, dim3(256), lds, s, t)
+        if (th == 8) {
+            switch (p.NT) { case 1: TILE16_LAUNCH(1, 8); break; case 2: TILE16_LAUNCH(2, 8); break; case 3: TILE16_LAUNCH(3, 8); break; default: TILE16_LAUNCH(4, 8); break; }
+        } else {
+            switch (p.NT) { case 1: TILE16_LAUNCH(1, 4); break; case 2: TILE16_LAUNCH(2, 4); break; case 3: TILE16_LAUNCH(3, 4); break; default: TILE16_LAUNCH(4, 4); break; }
+        }
+#undef TILE16_LAUNCH
+        NELE_CHECK_LAUNCH("nele_conv_span_bf16(tile)");
+        return NELE_OK;
+    }
     const int maxrun = (SPAN16_BM + p.g.Wout - 1) / p.g.Wout + 1;
     const size_t lds = ((size_t)SPAN16_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C + 64) * 2;
     const int gx = (M + SPAN16_BM - 1) / SPAN16_BM;
-    hipStream_t s = as_stream(stream);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
