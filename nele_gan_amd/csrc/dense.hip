@@ -578,8 +578,12 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    constexpr int RR = 2;                              // bf16x8 groups per thread and halo row: covers RS <= 4096 elements
-    float4 ra[RR], rc[RR];
+    // the next halo row travels through 4 float4 registers per thread (2 groups of 8 elements: covers RS <= 4096); plain scalars,
+    // unconditional loads from clamped addresses + select: an indexed array here ends up in scratch with a vmcnt(0) behind it
+    float4 r0a, r0c, r1a, r1c;
+    r0a = r0c = r1a = r1c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int e0 = tid * 8, e1 = tid * 8 + 2048;
+    int rnval = 0;
     const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf) + lane;
 #ifdef T16_PROF
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tq0 = clock64(), tq1;
@@ -598,19 +602,14 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
             if (seg_first && kh + 1 < p.KH) {          // issue the loads of halo row TH + kh
                 const int r = TH + kh;
                 const bool rin = hi0 + r < g.H;
-                const float* src = abase + (size_t)r * g.W * g.C;
+                const float* src = rin ? abase + (size_t)r * g.W * g.C : abase;
                 const int nval = rin ? vcols * g.C : 0;
-#pragma unroll
-                for (int q = 0; q < RR; ++q) {
-                    const int e = tid * 8 + 2048 * q;
-                    if (e < nval) {
-                        ra[q] = *reinterpret_cast<const float4*>(src + e);
-                        rc[q] = *reinterpret_cast<const float4*>(src + e + 4);
-                    } else {
-                        ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        rc[q] = ra[q];
-                    }
-                }
+                const int emax = max(vcols * g.C - 8, 0);
+                const float* s0p = src + min(e0, emax);
+                const float* s1p = src + min(e1, emax);
+                r0a = *reinterpret_cast<const float4*>(s0p); r0c = *reinterpret_cast<const float4*>(s0p + 4);   // raw: the zero
+                r1a = *reinterpret_cast<const float4*>(s1p); r1c = *reinterpret_cast<const float4*>(s1p + 4);   // select happens at publish time
+                rnval = nval;
             }
             T16_T(1);
             // ---- SB k-steps from LDS only.  Fragments are double buffered in registers: the ds_reads of step u+1 are issued
@@ -668,15 +667,20 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
                 wstore();
                 if (seg_last && kh + 1 < p.KH) {       // publish halo row TH + kh for the next kernel row
                     __bf16* dst = halo + (TH + kh) * RS;
-#pragma unroll
-                    for (int q = 0; q < RR; ++q) {
-                        const int e = tid * 8 + 2048 * q;
-                        if (e < RS) {
-                            bf16x8 v;
-                            v[0] = (__bf16)ra[q].x; v[1] = (__bf16)ra[q].y; v[2] = (__bf16)ra[q].z; v[3] = (__bf16)ra[q].w;
-                            v[4] = (__bf16)rc[q].x; v[5] = (__bf16)rc[q].y; v[6] = (__bf16)rc[q].z; v[7] = (__bf16)rc[q].w;
-                            *reinterpret_cast<bf16x8*>(dst + e) = v;
-                        }
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(e0 < rnval)) { r0a = z; r0c = z; }
+                    if (!(e1 < rnval)) { r1a = z; r1c = z; }
+                    if (e0 < RS) {
+                        bf16x8 v;
+                        v[0] = (__bf16)r0a.x; v[1] = (__bf16)r0a.y; v[2] = (__bf16)r0a.z; v[3] = (__bf16)r0a.w;
+                        v[4] = (__bf16)r0c.x; v[5] = (__bf16)r0c.y; v[6] = (__bf16)r0c.z; v[7] = (__bf16)r0c.w;
+                        *reinterpret_cast<bf16x8*>(dst + e0) = v;
+                    }
+                    if (e1 < RS) {
+                        bf16x8 v;
+                        v[0] = (__bf16)r1a.x; v[1] = (__bf16)r1a.y; v[2] = (__bf16)r1a.z; v[3] = (__bf16)r1a.w;
+                        v[4] = (__bf16)r1c.x; v[5] = (__bf16)r1c.y; v[6] = (__bf16)r1c.z; v[7] = (__bf16)r1c.w;
+                        *reinterpret_cast<bf16x8*>(dst + e1) = v;
                     }
                 }
                 T16_T(4);
