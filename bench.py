@@ -88,7 +88,7 @@ def main():
 
     for _ in range(a.warmup):
         tr.canonical_step(cw, nw)
-    tag = 'D.conv5.fwd'
+    tag = 'gstep.D.conv5.fwd'     # D's 5th conv forward as launched in the G-step (the D-step's launches share the GPU with the metric stream)
     ops.PROFILE = {tag: []}
     stage_ev = []
     barrier()
@@ -130,8 +130,8 @@ def main():
                                    'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma',
-                         'kernel': '%s (%s: span-staged implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
-                             'conv_span16_kernel<4>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
+                         'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
+                             'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': None, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
         }

@@ -388,6 +388,7 @@ class _DiscriminatorBase(nn.Module):
         self._bufs = {}
         self._w = None
         self._last_score = None
+        self.profile_prefix = ''           # prepended to the ops.PROFILE tags of this module's launches (bench.py)
         self.weight_grad_enabled = True   # reference computes (unused) D weight grads in the G-step too
         self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the conv forward / data-gradient passes
 
@@ -465,11 +466,11 @@ class _DiscriminatorBase(nn.Module):
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):
             if self.precision == 'bf16' and bf.span16_f[l]:
-                ops.conv_span_bf16(a, w['wff16'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+                ops.conv_span_bf16(a, w['wff16'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             elif bf.span_f[l]:
-                ops.conv_span(a, w['wff'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+                ops.conv_span(a, w['wff'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             else:
-                ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag='D.conv%d.fwd' % (l + 1))
+                ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
         score = _empty((B, self._nout), dev)
         call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),

@@ -92,7 +92,9 @@ class GanTrainer:
         self.optimizer_g.zero_grad()
         mask = self.G(clean_band, noise_band)
         din, _ = M.energy_norm_pack(mask, clean_band, noise_band, p_power, inv_p)
+        self.D.profile_prefix = 'gstep.'             # bench.py times these launches: no other stream is active in the G-step
         score = self.D.forward_packed(din)
+        self.D.profile_prefix = ''
         loss = self.MSELoss(score, torch.ones_like(score))
         if self.D_Qua is not None:
             din_q = torch.zeros_like(din)
