@@ -178,7 +178,10 @@ long long nele_metric_siib_workspace_bytes(int B, int L);
 int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                      float* mapped, int* info, void* stream);
 /* Same, split so that the caller can interleave independent work: phase 1 = wide front kernels (VAD .. covariance),
- * phase 2 = latency-bound back end (eigenvectors, projections, score) on the same workspace; phase 0 = both. */
+ * phase 2 = latency-bound back end (eigenvectors, projections, score) on the same workspace; phase 0 = both.
+ * Alternative split by data dependence: phase 3 = everything that needs only the CLEAN signal x (VAD, active frames, x spectra /
+ * masking / stacking, covariance and its eigen-decomposition - SIIB's KLT basis is the clean signal's; y may be NULL),
+ * phase 4 = the rest (y spectra / masking / stacking, projections, score).  Phase 3 can run before y exists. */
 int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                            float* mapped, int* info, int phase, void* stream);
 

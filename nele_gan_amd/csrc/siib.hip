@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
 }
 
 // grid (NA, B), block 256: s3
-__global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws) {
+__global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
+                                                        int sig1) {   // signals sig0..sig1 (0 = clean x, 1 = degraded y)
     __shared__ double sx[SB_WLEN], sy[SB_WLEN], cs[SB_WLEN], sn[SB_WLEN];
     __shared__ double px[SB_NBIN], py[SB_NBIN];
     __shared__ double2 Ax[SB_WLEN], Ay[SB_WLEN];
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     if (k >= na) return;
     const long long total = (long long)info[0] * L;
     const int f = ws.list[(size_t)b * ws.NA + k];
-    const float* xb = x + (size_t)b * L;
-    const float* yb = y + (size_t)b * L;
+    const float* xb = (sig0 == 0) ? x + (size_t)b * L : nullptr;
+    const float* yb = (sig1 == 1) ? y + (size_t)b * L : nullptr;
     const long long p0 = (long long)SB_SHIFT * f;
     const int q0 = (int)(p0 % L);
     for (int j = tid; j < SB_WLEN; j += 256) {
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
         while (q >= L) q -= L;
         const double w = hann400(j);
         const bool in = p0 + j < total;
-        sx[j] = in ? (double)xb[q] * w : 0.0;
-        sy[j] = in ? (double)yb[q] * w : 0.0;
+        sx[j] = (in && xb) ? (double)xb[q] * w : 0.0;
+        sy[j] = (in && yb) ? (double)yb[q] * w : 0.0;
         double s_, c_;
         sincospi((double)j / 200.0, &s_, &c_);
         cs[j] = c_;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     __syncthreads();
     // 400-point DFT as 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2):
     //   A[n2][k1] = W400^(n2 k1) * sum_n1 x[20 n1 + n2] W20^(n1 k1);   X[k] = sum_n2 A[n2][k1] W20^(n2 k2)
-    for (int o = tid; o < 2 * SB_WLEN; o += 256) {
+    for (int o = sig0 * SB_WLEN + tid; o < (sig1 + 1) * SB_WLEN; o += 256) {
         const int sig = o / SB_WLEN, idx = o - sig * SB_WLEN, n2 = idx / 20, k1 = idx - n2 * 20;
         const double* src = sig ? sy : sx;
         double ar = 0.0, ai = 0.0;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
         (sig ? Ay : Ax)[idx] = make_double2(ar * c2 + ai * s2, ai * c2 - ar * s2);
     }
     __syncthreads();
-    for (int o = tid; o < 2 * SB_NBIN; o += 256) {
+    for (int o = sig0 * SB_NBIN + tid; o < (sig1 + 1) * SB_NBIN; o += 256) {
         const int sig = o / SB_NBIN, kk = o - sig * SB_NBIN, k2 = kk / 20, k1 = kk - k2 * 20;
         const double2* A = sig ? Ay : Ax;
         double xr = 0.0, xi = 0.0;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
         (sig ? py : px)[kk] = xr * xr + xi * xi;
     }
     __syncthreads();
-    if (tid < 2 * SB_J) {
+    if (tid >= sig0 * SB_J && tid < (sig1 + 1) * SB_J) {
         const int sig = tid / SB_J, j = tid - sig * SB_J;
         const double* g = ws.g2 + j * SB_NBIN;
         const double* pp = sig ? py : px;
@@ -259,18 +260,19 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     }
 }
 
-// grid (B), block 64: lanes 0..55 = (signal, band) rows: s4.  Rows are streamed through LDS in chunks of 64
-// frames (coalesced loads/stores); the masking recurrence itself is serial over frames per row.
+// grid (B, signals), block 64: lanes 0..27 = band rows of one signal: s4.  Rows are streamed through LDS in chunks of 64 frames
+// (coalesced loads/stores); the masking recurrence itself is serial over frames per row, 8 frames per trip with their inputs
+// read from LDS ahead of the dependent chain.
 #define SB_CH 64
-__global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws) {
-    __shared__ double buf[2 * SB_J][SB_CH + 1];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
+    __shared__ double buf[SB_J][SB_CH + 1];
+    const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
     if (na < 1) return;
-    double* base = ws.XL + (size_t)b * 2 * SB_J * ws.NA;
+    double* base = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
     // band minima (before masking)
     double eX = 1e300;
-    for (int r = 0; r < 2 * SB_J; ++r) {
+    for (int r = 0; r < SB_J; ++r) {
         double m = 1e300;
         for (int i = tid; i < na; i += 64) m = fmin(m, base[(size_t)r * ws.NA + i]);
         for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
@@ -287,35 +289,49 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws) {
     for (int c0 = 0; c0 < na; c0 += SB_CH) {
         const int n = min(SB_CH, na - c0);
         __syncthreads();
-        for (int r = 0; r < 2 * SB_J; ++r)
-            if (tid < n) buf[r][tid] = base[(size_t)r * ws.NA + c0 + tid];
-        __syncthreads();
-        if (tid < 2 * SB_J) {
-            for (int i = 0; i < n; ++i) {
-                const double v = fmax(buf[tid][i], pend[0]);
+        {
+            double t[SB_J];
 #pragma unroll
-                for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = fmax(pend[m], v - (v - eX) * lt[m]);
-                pend[SB_TF - 2] = v - (v - eX) * lt[SB_TF - 1];
-                buf[tid][i] = v;
-                sum += v;
+            for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + min(c0 + tid, ws.NA - 1)];
+#pragma unroll
+            for (int r = 0; r < SB_J; ++r) buf[r][tid] = t[r];
+        }
+        __syncthreads();
+        if (tid < SB_J) {
+            for (int i0 = 0; i0 < n; i0 += 8) {
+                double xs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xs[u] = buf[tid][min(i0 + u, SB_CH - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i0 + u < n) {
+                        const double v = fmax(xs[u], pend[0]);
+#pragma unroll
+                        for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = fmax(pend[m], v - (v - eX) * lt[m]);
+                        pend[SB_TF - 2] = v - (v - eX) * lt[SB_TF - 1];
+                        buf[tid][i0 + u] = v;
+                        sum += v;
+                    }
+                }
             }
         }
         __syncthreads();
-        for (int r = 0; r < 2 * SB_J; ++r)
+#pragma unroll 4
+        for (int r = 0; r < SB_J; ++r)
             if (tid < n) base[(size_t)r * ws.NA + c0 + tid] = buf[r][tid];
     }
     // mean removal
     const double mu = sum / (double)na;
-    for (int r = 0; r < 2 * SB_J; ++r) {
+    for (int r = 0; r < SB_J; ++r) {
         const double mr = __shfl(mu, r, 64);
         for (int i = tid; i < na; i += 64) base[(size_t)r * ws.NA + i] -= mr;
     }
 }
 
 // grid (420, B, 2), block 256: s5
-__global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws) {
+__global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws, int sig0) {
     __shared__ double red[8];
-    const int a = blockIdx.x, b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x;
+    const int a = blockIdx.x, b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
     const int ncols = na - SB_K + 1;
     double* dst = ws.Xs + (((size_t)b * 2 + sig) * SB_D + a) * ws.NA;
@@ -529,12 +545,17 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
 
 extern "C" long long nele_metric_siib_workspace_bytes(int B, int L) { return (long long)siib_layout(B, L, nullptr, nullptr); }
 
-// phase: 0 = everything, 1 = front only (VAD .. covariance), 2 = back only (eigenvectors .. score).  The split lets the
-// caller put independent work between the wide front kernels and the latency-bound eigen-decomposition.
+// phase: 0 = everything, 1 = front only (VAD .. covariance), 2 = back only (eigenvectors .. score): the split lets the caller put
+// independent work between the wide front kernels and the latency-bound eigen-decomposition.
+// 3 = everything that depends on the CLEAN signal only (VAD, active-frame list, x spectra / masking / stacking, covariance,
+// eigen-decomposition; y is not read and may be null), 4 = the rest (y spectra / masking / stacking, projections, score) on the
+// same workspace: the Karhunen-Loeve basis of SIIB is that of the clean signal, so phase 3 can run before the degraded signal
+// exists (GanTrainer runs it beside the G-step).
 extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                                       float* mapped, int* info_out, int phase, void* stream) {
-    NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_siib: bad arguments");
-    NELE_CHECK_ARG(phase >= 0 && phase <= 2, "nele_metric_siib: phase must be 0, 1 or 2");
+    NELE_CHECK_ARG(x && workspace && (raw || mapped) && B > 0, "nele_metric_siib: bad arguments");
+    NELE_CHECK_ARG(phase >= 0 && phase <= 4, "nele_metric_siib: phase must be 0..4");
+    NELE_CHECK_ARG(y || phase == 3, "nele_metric_siib: degraded signal missing");
     if (L < SB_WLEN + SB_SHIFT * (SB_K + 1)) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_siib: L=%d too short", L);
     if (workspace_bytes < nele_metric_siib_workspace_bytes(B, L))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_siib: workspace too small");
@@ -542,21 +563,30 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     const size_t used = siib_layout(B, L, &ws, (char*)workspace);
     (void)used;
     hipStream_t s = as_stream(stream);
-    if (phase != 2) {
+    const bool vad = (phase == 0 || phase == 1 || phase == 3);
+    const bool sx = vad, sy = (phase == 0 || phase == 1 || phase == 4);
+    const bool eig = (phase == 0 || phase == 2 || phase == 3);
+    const bool fin = (phase == 0 || phase == 2 || phase == 4);
+    if (vad) {
         hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
         hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws);
-        hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws);
-        hipLaunchKernelGGL(siib_mask_kernel, dim3(B), dim3(64), 0, s, ws);
-        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, 2), dim3(256), 0, s, ws);
-        hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
+    }
+    if (sx || sy) {
+        const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
+        hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws, sig0, sig1);
+        hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);
+        if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
-    if (phase != 1) {
+    if (eig) {
         int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
         if (st) return st;
+    }
+    if (fin) {
         hipLaunchKernelGGL(siib_proj_kernel, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
         hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);

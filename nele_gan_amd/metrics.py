@@ -98,11 +98,17 @@ def batch_estoi(x, y):
 
 
 class SiibSplit:
-    """batch_siib in two halves: front() enqueues the wide kernels (VAD .. covariance), back() the latency-bound
-    eigen-decomposition .. score, so that independent work can be enqueued in between on another stream."""
+    """batch_siib in pieces.  front()/back(): wide kernels (VAD .. covariance) / latency-bound eigen-decomposition .. score, so
+    that independent work can be enqueued in between on another stream.  clean_part()/degraded_part(y): split by data
+    dependence - SIIB's Karhunen-Loeve basis comes from the clean signal alone, so VAD, the clean spectra, the covariance and its
+    eigen-decomposition can run before the degraded signal exists."""
 
-    def __init__(self, x, y):
-        self.x, self.y, _ = _pair(x, y)
+    def __init__(self, x, y=None):
+        if y is None:
+            self.x = x.contiguous().float()
+            self.y = None
+        else:
+            self.x, self.y, _ = _pair(x, y)
         B, L = self.x.shape
         self.ws = _workspace('siib', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
         self.raw = torch.empty(B, device=self.x.device)
@@ -119,6 +125,15 @@ class SiibSplit:
 
     def back(self):
         self._call(2)
+        return self.raw, self.mapped
+
+    def clean_part(self):
+        self._call(3)
+
+    def degraded_part(self, y):
+        assert y.shape == self.x.shape
+        self.y = y.contiguous().float()
+        self._call(4)
         return self.raw, self.mapped
 
 

@@ -155,46 +155,50 @@ class GanTrainer:
     # ---------------------------------------------------------------- one canonical step
     def canonical_step(self, clean_wav, noise_wav, feats=None):
         """features -> G-step -> generate -> true metrics -> D-step on the same batch."""
-        f = feats or self.features(clean_wav, noise_wav)
-        lg = self.g_step(f['clean_band'], f['noise_band'])
-        enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
-        # The metric kernels run on a side stream.  D's forward pass does not need the targets, so it is enqueued on
-        # the main stream to run beside the latency-bound part of the metrics (SIIB's eigen-decomposition keeps only a
-        # few CUs busy); the loss waits for the targets.
+        # The metric kernels run on a side stream.  (1) Everything SIIB derives from the CLEAN signal alone - VAD, clean spectra,
+        # the covariance and its eigen-decomposition (the KLT basis) - is enqueued first and runs beside features / G-step /
+        # generate.  (2) Once the enhanced signal exists the remaining metric work follows on the side stream while the main
+        # stream runs D's forward pass, which does not need the targets; the loss waits for them.
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         side = self._side
+        L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
+        start = torch.cuda.Event()
+        start.record(main)
+        split = None
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            x = clean_wav[:, :L].contiguous()
+            if 'siib' in self.metrics:
+                split = mt.SiibSplit(x)
+                split.clean_part()
+        f = feats or self.features(clean_wav, noise_wav)
+        lg = self.g_step(f['clean_band'], f['noise_band'])
+        enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+        assert enh.shape[1] == L
         ready = torch.cuda.Event()
         ready.record(main)
-        L = min(clean_wav.shape[1], enh.shape[1])
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            x = clean_wav[:, :L].contiguous()
-            y = (enh[:, :L] + noise_wav[:, :L]).contiguous()
+            y = (enh + noise_wav[:, :L]).contiguous()
             cols = {}
-            split = None
-            for m in self.metrics:                         # wide kernels first
+            for m in self.metrics:
                 if m == 'siib':
-                    split = mt.SiibSplit(x, y)
-                    split.front()
+                    cols[m] = split.degraded_part(y)[1]
                 else:
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
-            wide_done = torch.cuda.Event()
-            wide_done.record(side)
-        main.wait_event(wide_done)
-        din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
-        self.optimizer_d.zero_grad()
-        score = self.D.forward_packed(din)
-        with torch.cuda.stream(side):
-            if split is not None:
-                cols['siib'] = split.back()[1]
             tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
             done = torch.cuda.Event()
             done.record(side)
+        din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
+        self.optimizer_d.zero_grad()
+        score = self.D.forward_packed(din)
         for t in (tgt, x, y):
             t.record_stream(main)
         enh.record_stream(side)
+        clean_wav.record_stream(side)
+        noise_wav.record_stream(side)
         main.wait_event(done)
         ld = self._d_finish(score, tgt)
         return lg, ld, tgt
