@@ -112,6 +112,8 @@ int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const flo
                  const float* rstd, float* dY, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
                  int pade, float slope, void* stream);
 int nele_colsum(const float* part, int rows, int cols, float* out, int accumulate, void* stream);
+/* two column sums of equal shape in one launch (cLN gain and bias partials) */
+int nele_colsum2(const float* part0, float* out0, const float* part1, float* out1, int rows, int cols, int accumulate, void* stream);
 
 /* Gradient of model.py:98 exp(3.2*tanh(o)) given the mask itself. */
 int nele_exptanh_bwd(const float* dmask, const float* mask, float* dout, long long n, void* stream);

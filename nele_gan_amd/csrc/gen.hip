@@ -166,17 +166,23 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// out[c] (+)= sum_r part[r][c]: block = 64 columns x 4 row groups, fixed summation order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out, int accumulate) {
-    __shared__ float sp[4][64];
+// out[c] (+)= sum_r part[r][c]: block = 64 columns x 16 row groups, fixed summation order; blockIdx.y selects one of two
+// (part, out) pairs so that the gain and bias partials of a cLN layer reduce in one launch
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part0, float* __restrict__ out0, const float* __restrict__ part1,
+                                                      float* __restrict__ out1, int rows, int cols, int accumulate) {
+    __shared__ float sp[16][64];
+    const float* part = blockIdx.y ? part1 : part0;
+    float* out = blockIdx.y ? out1 : out0;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float s = 0.f;
     if (c < cols)
-        for (int r = g; r < rows; r += 4) s += part[(size_t)r * cols + c];
+        for (int r = g; r < rows; r += 16) s += part[(size_t)r * cols + c];
     sp[g][threadIdx.x & 63] = s;
     __syncthreads();
     if (g == 0 && c < cols) {
-        const float t = (sp[0][threadIdx.x] + sp[1][threadIdx.x]) + (sp[2][threadIdx.x] + sp[3][threadIdx.x]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) t += (sp[q][threadIdx.x] + sp[q + 1][threadIdx.x]) + (sp[q + 2][threadIdx.x] + sp[q + 3][threadIdx.x]);
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -333,8 +339,15 @@ extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain
 
 extern "C" int nele_colsum(const float* part, int rows, int cols, float* out, int accumulate, void* stream) {
     NELE_CHECK_ARG(part && out && rows > 0 && cols > 0, "nele_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), part, rows, cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, as_stream(stream), part, out, part, out, rows, cols, accumulate);
     NELE_CHECK_LAUNCH("nele_colsum");
+    return NELE_OK;
+}
+
+extern "C" int nele_colsum2(const float* part0, float* out0, const float* part1, float* out1, int rows, int cols, int accumulate, void* stream) {
+    NELE_CHECK_ARG(part0 && out0 && part1 && out1 && rows > 0 && cols > 0, "nele_colsum2: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, 2), dim3(1024), 0, as_stream(stream), part0, out0, part1, out1, rows, cols, accumulate);
+    NELE_CHECK_LAUNCH("nele_colsum2");
     return NELE_OK;
 }
 

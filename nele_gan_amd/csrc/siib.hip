@@ -27,6 +27,8 @@
 
 struct SiibWs {
     double* g2;      // [28][201] squared gammatone magnitude responses
+    double* tab;     // [3][400] cos(2 pi j / 400), sin(2 pi j / 400), hann400(j)
+    double* rowstat; // [B][2][28][2] per (signal, band) row of XL: minimum before masking, mean after masking
     double* xdb;     // [B][NT]   frame power (dB) of the tiled clean signal
     int* list;       // [B][NA]   active frame indices (tiled frame numbering)
     int* info;       // [B][4]    {M, n_tiled_frames, n_active, status}
@@ -43,9 +45,15 @@ struct SiibWs {
 __device__ __forceinline__ double hann400(int n) { return 0.5 - 0.5 * cospi((double)n / 200.0); }
 
 // ---------------------------------------------------------------- gammatone matrix (oracle/siib.py gammatone_matrix)
-__global__ void siib_g2_kernel(double* __restrict__ g2) {
+__global__ void siib_g2_kernel(double* __restrict__ g2, double* __restrict__ tab) {
     __shared__ double red[8];
     const int j = blockIdx.x, q = threadIdx.x;  // 256 threads >= 201
+    if (j == 0)
+        for (int i = q; i < SB_WLEN; i += 256) {
+            double s_, c_;
+            sincospi((double)i / 200.0, &s_, &c_);
+            tab[i] = c_; tab[SB_WLEN + i] = s_; tab[2 * SB_WLEN + i] = hann400(i);
+        }
     const double e0 = 21.4 * log10(4.37 * (100.0 / 1000.0) + 1.0), e1 = 21.4 * log10(4.37 * (6500.0 / 1000.0) + 1.0);
     const double cf_erb = e0 + (e1 - e0) * (double)j / (double)(SB_J - 1);
     const double cf = (pow(10.0, cf_erb / 21.4) - 1.0) / 4.37 * 1000.0;
@@ -206,14 +214,12 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     for (int j = tid; j < SB_WLEN; j += 256) {
         int q = q0 + j;
         while (q >= L) q -= L;
-        const double w = hann400(j);
+        const double w = ws.tab[2 * SB_WLEN + j];
         const bool in = p0 + j < total;
         sx[j] = (in && xb) ? (double)xb[q] * w : 0.0;
         sy[j] = (in && yb) ? (double)yb[q] * w : 0.0;
-        double s_, c_;
-        sincospi((double)j / 200.0, &s_, &c_);
-        cs[j] = c_;
-        sn[j] = s_;
+        cs[j] = ws.tab[j];
+        sn[j] = ws.tab[SB_WLEN + j];
     }
     __syncthreads();
     // 400-point DFT as 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2):
@@ -260,24 +266,37 @@ __global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict_
     }
 }
 
-// grid (B, signals), block 64: lanes 0..27 = band rows of one signal: s4.  Rows are streamed through LDS in chunks of 64 frames
-// (coalesced loads/stores); the masking recurrence itself is serial over frames per row, 8 frames per trip with their inputs
-// read from LDS ahead of the dependent chain.
+// s4a: band minima before masking.  grid (28, B, signals), block 256
+__global__ __launch_bounds__(256) void siib_rowmin_kernel(SiibWs ws, int sig0) {
+    __shared__ double red[8];
+    const int j = blockIdx.x, b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2];
+    const double* row = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA;
+    double m = 1e300;
+    for (int i = tid; i < na; i += 256) m = fmin(m, row[i]);
+    m = -block_max(-m, red);
+    if (tid == 0) ws.rowstat[(((size_t)b * 2 + sig) * SB_J + j) * 2] = m;
+}
+
+// s4b: forward masking.  grid (B, signals), block 64: lanes 0..27 = band rows of one signal.  The recurrence is serial over frames
+// per row; rows are streamed through LDS in chunks of 64 frames (coalesced loads/stores), the next chunk's loads are in flight
+// while the current one is processed, and 8 frames' inputs are read from LDS ahead of the dependent chain.  The row means of
+// the masked values go to rowstat; siib_stack_kernel subtracts them on the fly (same arithmetic as a separate pass).
 #define SB_CH 64
+// fmax() on doubles compiles to two canonicalising v_max_f64 plus the max itself (IEEE sNaN quieting); the values here are never NaN
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
     __shared__ double buf[SB_J][SB_CH + 1];
     const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
     if (na < 1) return;
     double* base = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
-    // band minima (before masking)
-    double eX = 1e300;
-    for (int r = 0; r < SB_J; ++r) {
-        double m = 1e300;
-        for (int i = tid; i < na; i += 64) m = fmin(m, base[(size_t)r * ws.NA + i]);
-        for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
-        if (tid == r) eX = m;
-    }
+    double* rstat = ws.rowstat + ((size_t)b * 2 + sig) * SB_J * 2;
+    const double eX = (tid < SB_J) ? rstat[2 * tid] : 0.0;
     double lt[SB_TF];
 #pragma unroll
     for (int m = 0; m < SB_TF; ++m) lt[m] = log((double)(m + 1)) / log((double)SB_TF);
@@ -286,17 +305,19 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
 #pragma unroll
     for (int m = 0; m < SB_TF - 1; ++m) pend[m] = -1e300;
     double sum = 0.0;
+    double t[SB_J];
+#pragma unroll
+    for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + min(tid, ws.NA - 1)];
     for (int c0 = 0; c0 < na; c0 += SB_CH) {
         const int n = min(SB_CH, na - c0);
         __syncthreads();
-        {
-            double t[SB_J];
 #pragma unroll
-            for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + min(c0 + tid, ws.NA - 1)];
-#pragma unroll
-            for (int r = 0; r < SB_J; ++r) buf[r][tid] = t[r];
-        }
+        for (int r = 0; r < SB_J; ++r) buf[r][tid] = t[r];
         __syncthreads();
+        if (c0 + SB_CH < na) {
+#pragma unroll
+            for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + min(c0 + SB_CH + tid, ws.NA - 1)];
+        }
         if (tid < SB_J) {
             for (int i0 = 0; i0 < n; i0 += 8) {
                 double xs[8];
@@ -305,9 +326,9 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (i0 + u < n) {
-                        const double v = fmax(xs[u], pend[0]);
+                        const double v = max_f64(xs[u], pend[0]);
 #pragma unroll
-                        for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = fmax(pend[m], v - (v - eX) * lt[m]);
+                        for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = max_f64(pend[m], v - (v - eX) * lt[m]);
                         pend[SB_TF - 2] = v - (v - eX) * lt[SB_TF - 1];
                         buf[tid][i0 + u] = v;
                         sum += v;
@@ -320,12 +341,7 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
         for (int r = 0; r < SB_J; ++r)
             if (tid < n) base[(size_t)r * ws.NA + c0 + tid] = buf[r][tid];
     }
-    // mean removal
-    const double mu = sum / (double)na;
-    for (int r = 0; r < SB_J; ++r) {
-        const double mr = __shfl(mu, r, 64);
-        for (int i = tid; i < na; i += 64) base[(size_t)r * ws.NA + i] -= mr;
-    }
+    if (tid < SB_J) rstat[2 * tid + 1] = sum / (double)na;
 }
 
 // grid (420, B, 2), block 256: s5
@@ -341,10 +357,11 @@ __global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws, int sig0) {
     }
     const int k = a / SB_J, j = a - k * SB_J;
     const double* src = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k;
+    const double mr = ws.rowstat[(((size_t)b * 2 + sig) * SB_J + j) * 2 + 1];     // row mean of the masked band (removed here)
     double s = 0.0;
-    for (int t = tid; t < ncols; t += 256) s += src[t];
+    for (int t = tid; t < ncols; t += 256) s += src[t] - mr;
     const double mu = block_sum(s, red) / (double)ncols;
-    for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? src[t] - mu : 0.0;
+    for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? (src[t] - mr) - mu : 0.0;
 }
 
 // ---------------------------------------------------------------- float64 MFMA GEMMs
@@ -528,6 +545,8 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     size_t o = 0;
 #define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
     TAKE(g2, double, SB_J * SB_NBIN);
+    TAKE(tab, double, 3 * SB_WLEN);
+    TAKE(rowstat, double, (size_t)B * 2 * SB_J * 2);
     TAKE(xdb, double, (size_t)B * NT);
     TAKE(list, int, (size_t)B * NA);
     TAKE(info, int, (size_t)B * 4);
@@ -568,7 +587,7 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     const bool eig = (phase == 0 || phase == 2 || phase == 3);
     const bool fin = (phase == 0 || phase == 2 || phase == 4);
     if (vad) {
-        hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2);
+        hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2, ws.tab);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
@@ -577,6 +596,7 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     if (sx || sy) {
         const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
         hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws, sig0, sig1);
+        hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);
         if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);

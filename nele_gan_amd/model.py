@@ -284,8 +284,7 @@ class Generator_Conv1D_cLN(nn.Module):
             seq = self.convolutions[l]
             call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
                  ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
-            call('nele_colsum', ptr(bf.gpart), B * bf.nchunks, cout, ptr(seq[2].gain0.grad), 1, stream())
-            call('nele_colsum', ptr(bf.bpart), B * bf.nchunks, cout, ptr(seq[2].bias0.grad), 1, stream())
+            call('nele_colsum2', ptr(bf.gpart), ptr(seq[2].gain0.grad), ptr(bf.bpart), ptr(seq[2].bias0.grad), B * bf.nchunks, cout, 1, stream())
             ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=(self.precision == 'bf16'))
             if l > 0:
                 ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l], bf16=b16)

@@ -65,6 +65,7 @@ class GanTrainer:
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
         self._side = None
+        self._side2 = None
         self.world = ndist.world_size()
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
@@ -179,18 +180,34 @@ class GanTrainer:
         assert enh.shape[1] == L
         ready = torch.cuda.Event()
         ready.record(main)
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream(device=self.device)
+        side2 = self._side2
+        cols = {}
         with torch.cuda.stream(side):
             side.wait_event(ready)
             y = (enh + noise_wav[:, :L]).contiguous()
-            cols = {}
+            y_ready = torch.cuda.Event()
+            y_ready.record(side)
+            if split is not None:
+                cols['siib'] = split.degraded_part(y)[1]
+        with torch.cuda.stream(side2):                     # the cheaper metrics beside SIIB's degraded-signal part
+            side2.wait_event(start)
+            side2.wait_event(y_ready)
             for m in self.metrics:
-                if m == 'siib':
-                    cols[m] = split.degraded_part(y)[1]
-                else:
+                if m != 'siib':
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
+            others = torch.cuda.Event()
+            others.record(side2)
+        with torch.cuda.stream(side):
+            side.wait_event(others)
+            for v in cols.values():
+                v.record_stream(side)
             tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
             done = torch.cuda.Event()
             done.record(side)
+        for t in (x, y):
+            t.record_stream(side2)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din)
