@@ -126,7 +126,7 @@ def main():
             'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.precision, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
+            'config': {'workload': ('BASELINE configs[2]' if 'haspi' in a.metrics.lower() else 'BASELINE configs[1]') + ': batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
                                    'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma',
