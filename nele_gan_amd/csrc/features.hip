@@ -136,11 +136,15 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
     double S = 0, tS = 0, Smin = 0, tSmin = 0, Smin_sw = 0, tSmin_sw = 0, ovL = 0, Lam64 = 1e-6, G = 1.0, Gamma = 1.0;
     float Lam32 = 0.f;
     int j = 0, u = 0;
+    // the spectrum of frame l+1 is loaded while frame l is processed: the recursion is serial over frames and would otherwise pay
+    // a full global-load latency per frame
+    float2 ynext = act ? Y[k] : make_float2(0.f, 0.f);
     for (int l = 0; l < T; ++l) {
         float Y2f = 0.f, outv = 0.f;
         double xi = 0.0, I = 0.0;
+        const float2 y = ynext;
+        if (act && l + 1 < T) ynext = Y[(size_t)(l + 1) * NELE_NBINS + k];
         if (act) {
-            const float2 y = Y[(size_t)l * NELE_NBINS + k];
             const float h = np_cabsf(y.x, y.y);                                   // np.abs(complex64)
             Y2f = h * h;                                                          // **2 on a float32 array
             s.a[k + 1] = (double)Y2f;
