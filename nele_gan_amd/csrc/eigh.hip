@@ -820,11 +820,16 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             cluster_cap = ((long long)ncu * (occ > 0 ? 1 : 0) / (8 * EC_P)) * 8;   // one workgroup per CU: never rely on sharing a CU
         else cluster_cap = 0;
         if (cluster_cap > 32) cluster_cap = 32;
+        const char* capenv = getenv("NELE_EIGH_CLUSTER_CAP");    // matrices per launch (multiple of 8): fewer leaves CUs to other streams
+        if (capenv && atoi(capenv) >= 8 && atoi(capenv) < cluster_cap) cluster_cap = atoi(capenv) / 8 * 8;
     }
     if (cluster_cap >= 8) {
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
-        for (int b0 = 0; b0 < B; b0 += cluster_cap) {
-            const int Bc = (B - b0 < cluster_cap) ? B - b0 : cluster_cap;
+        // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
+        // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
+        const int per = (B <= 32 && cluster_cap >= 32) ? 16 : cluster_cap;
+        for (int b0 = 0; b0 < B; b0 += per) {
+            const int Bc = (B - b0 < per) ? B - b0 : per;
             hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
         }
     } else {
