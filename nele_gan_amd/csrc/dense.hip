@@ -1156,6 +1156,143 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient, 2-D tiles, bf16
+// conv_wgrad16_kernel gathers the im2col view: every input element is read KH*KW times per launch (5 GB for D.conv5 at B = 32)
+// and the kernel runs at the memory system's speed.  Here a workgroup owns ONE kernel row kh and accumulates
+// dW[n][kh][kw][c] = sum_pos dOut[pos][n] * X[pos + (kh, kw)][c] for all (kw, c) of that row in registers while it walks over
+// position tiles of 4 x 64 outputs: per tile it stages the 4 input rows it needs (shifted by kh, 64 + KW - 1 columns, bf16) and
+// the dOut tile ([256 positions][N], bf16) in LDS.  The (kw, c) index is contiguous in the staged rows (Toeplitz view, row
+// stride C), so both MFMA operands come from the hardware transpose read exactly as in conv_wgrad16_kernel, and the input is
+// read KH * 1.1 times instead of KH*KW times.  Partials per workgroup group, reduced by wgrad_reduce_kernel.
+#define WT_TH 4
+#define WT_TW 64
+#define WT_NP (64 + 8)       // LDS row stride (bf16) of the dOut tile
+
+struct WgradTileArgs {
+    const float* A;
+    const float* dOut;
+    float* part;         // [G][N][Ktot]
+    float* bpart;        // [G][N] or null
+    int N, B, KH, KW;
+    int nth, ntw, ntiles, G;
+    ConvGeom g;
+};
+
+template <int NT, int KTW>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 wt_lds[];     // halo rows [WT_TH][RS] + 64 slack, then dOut tile [256][WT_NP]
+    __shared__ float bred[16][64];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = blockIdx.x, grp = blockIdx.y;
+    const int wcols = WT_TW + p.KW - 1, RS = wcols * g.C;
+    __bf16* halo = wt_lds;
+    __bf16* dt = wt_lds + WT_TH * RS + 64;
+    const int nkt = (g.seglen + 15) >> 4;               // kk tiles of this kernel row
+    f32x4 acc[NT][KTW];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < KTW; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) halo[WT_TH * RS + tid] = (__bf16)0.f;
+    const int dnq = tid & 15, dp0 = tid >> 4;            // dOut staging: n quad, first position
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = (p.bpart != nullptr) && (kh == 0);
+
+    for (int t = grp; t < p.ntiles; t += p.G) {
+        const int tw_i = t % p.ntw, rem = t / p.ntw, th_i = rem % p.nth, b = rem / p.nth;
+        const int ho0 = th_i * WT_TH, wo0 = tw_i * WT_TW;
+        const int wi0 = wo0 + g.iw0;
+        const int vcols = max(0, min(wcols, g.W - wi0));
+        __syncthreads();                                 // previous tile fully consumed
+        // ---- input rows ho0 + r + kh (float32 -> bf16), zero outside the input
+#pragma unroll
+        for (int r = 0; r < WT_TH; ++r) {
+            const int hi = ho0 + r + kh + g.ih0;
+            const bool rin = hi < g.H;
+            const float* src = p.A + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
+            const int nval = rin ? vcols * g.C : 0;
+            const int emax = max(vcols * g.C - 8, 0);
+            for (int e = tid * 8; e < RS; e += 2048) {
+                const float* sp = src + min(e, emax);
+                const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
+                bf16x8 v;
+                const bool in = e < nval;
+                v[0] = (__bf16)(in ? a.x : 0.f); v[1] = (__bf16)(in ? a.y : 0.f); v[2] = (__bf16)(in ? a.z : 0.f); v[3] = (__bf16)(in ? a.w : 0.f);
+                v[4] = (__bf16)(in ? c.x : 0.f); v[5] = (__bf16)(in ? c.y : 0.f); v[6] = (__bf16)(in ? c.z : 0.f); v[7] = (__bf16)(in ? c.w : 0.f);
+                *reinterpret_cast<bf16x8*>(halo + r * RS + e) = v;
+            }
+        }
+        // ---- dOut tile [256 positions][N] (zero for positions outside the output and n >= N)
+        {
+            float4 rd[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
+                const int ho = min(ho0 + r, g.Hout - 1), wo = min(wo0 + c, g.Wout - 1);
+                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + min(4 * dnq, p.N - 4);
+                rd[it] = *reinterpret_cast<const float4*>(p.dOut + off);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
+                const bool ok = (ho0 + r < g.Hout) && (wo0 + c < g.Wout) && (4 * dnq < p.N);
+                const float4 v4 = ok ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bf16x4 v;
+                v[0] = (__bf16)v4.x; v[1] = (__bf16)v4.y; v[2] = (__bf16)v4.z; v[3] = (__bf16)v4.w;
+                *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
+                if (want_bias) { bq[0] += v4.x; bq[1] += v4.y; bq[2] += v4.z; bq[3] += v4.w; }
+            }
+        }
+        __syncthreads();
+        // ---- 8 reduction steps of 32 positions (row r, columns 32 * half ..)
+#pragma unroll 2
+        for (int ks = 0; ks < WT_TH * 2; ++ks) {
+            const int r = ks >> 1, half = ks & 1;
+            bf16x8 af[NT], bfr[KTW];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) af[i] = tr_frag(dt + (ks * 32) * WT_NP, WT_NP, 16 * i, lane);
+            const __bf16* hb = halo + r * RS + half * 32 * g.C;
+#pragma unroll
+            for (int jj = 0; jj < KTW; ++jj) bfr[jj] = tr_frag(hb, g.C, 16 * min(wave + 4 * jj, nkt - 1), lane);
+#pragma unroll
+            for (int jj = 0; jj < KTW; ++jj) {
+                if (wave + 4 * jj < nkt) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partials: acc[i][jj][reg] = dW[n = 16 i + 4 lg + reg][kk = kh * seglen + 16 (wave + 4 jj) + li]
+    const int li = lane & 15, lg = lane >> 4;
+    float* part = p.part + (size_t)grp * p.N * g.Ktot;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int n = 16 * i + 4 * lg + reg;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int jj = 0; jj < KTW; ++jj) {
+                const int kk = 16 * (wave + 4 * jj) + li;
+                if (wave + 4 * jj < nkt && kk < g.seglen) part[(size_t)n * g.Ktot + kh * g.seglen + kk] = acc[i][jj][reg];
+            }
+        }
+    if (want_bias) {                                      // fold the 16 threads that share an n quad
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bred[dp0][4 * dnq + q] = bq[q];
+        __syncthreads();
+        if (tid < 64 && tid < p.N) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += bred[q][tid];
+            p.bpart[(size_t)grp * p.N + tid] = sum;
+        }
+    }
+}
+
 // Sum the split partials in fixed order and scatter from GEMM layout [n][kh][kw][ci] to the
 // PyTorch parameter layout [n][ci][kh][kw] (flip != 0: the partials are in the flipped data-gradient
 // layout, never used for weights).  One thread per weight element.
@@ -1443,7 +1580,9 @@ extern "C" long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, in
     if (splits < 1) splits = 1;
     if (splits > 256) splits = 256;
     if (splits_out) *splits_out = splits;
-    return (long long)splits * ((long long)N * Ktot + N);
+    int slots = splits;                                    // the 2-D tile kernel uses up to 64 workgroup groups
+    if (slots < 64) slots = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
+    return (long long)slots * ((long long)N * Ktot + N);
 }
 
 static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
@@ -1475,14 +1614,54 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     p.A = A; p.dOut = dOut; p.M = M; p.N = N;
     p.part = workspace;
     p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
+    hipStream_t s = as_stream(stream);
+    // 2-D tile kernel (bf16): one kernel row per workgroup, accumulators in registers over all position tiles
+    static int wt_on = -1;
+    if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
+    const int nkt = (p.g.seglen + 15) / 16, NT = (N + 15) / 16;
+    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * p.g.C + 64 + 256 * WT_NP) * 2;
+    const int max_splits = (M + 511) / 512;
+    int G = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
+    if (G < splits) G = splits;
+    bool tiled = false;
+    if (bf16 && wt_on && N <= 64 && p.g.C % 8 == 0 && KW * p.g.C == p.g.seglen && nkt <= 28 && p.g.Wout >= 32 && wt_lds <= 64 * 1024 &&
+        M % (p.g.Hout * p.g.Wout) == 0) {
+        WgradTileArgs t;
+        t.A = A; t.dOut = dOut; t.part = workspace; t.N = N; t.B = M / (p.g.Hout * p.g.Wout); t.KH = KH; t.KW = KW;
+        t.nth = (p.g.Hout + WT_TH - 1) / WT_TH; t.ntw = (p.g.Wout + WT_TW - 1) / WT_TW; t.ntiles = t.B * t.nth * t.ntw;
+        if (G > t.ntiles) G = t.ntiles;
+        t.G = G; t.g = p.g;
+        t.bpart = db ? workspace + (size_t)G * N * p.g.Ktot : nullptr;
+        const dim3 grid(KH, G);
+        const int ktw = (nkt + 3) / 4;
+        static bool wattr = false;
+        if (!wattr) {
+#define WT_ATTR(NT_, K_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+            WT_ATTR(1, 2); WT_ATTR(2, 2); WT_ATTR(3, 2); WT_ATTR(4, 2); WT_ATTR(1, 4); WT_ATTR(2, 4); WT_ATTR(3, 4); WT_ATTR(4, 4);
+            WT_ATTR(1, 7); WT_ATTR(2, 7); WT_ATTR(3, 7); WT_ATTR(4, 7);
+#undef WT_ATTR
+            wattr = true;
+        }
+#define WT_LAUNCH(NT_, K_) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_>), grid, dim3(256), (size_t)wt_lds, s, t)
+#define WT_PICK(K_) switch (NT) { case 1: WT_LAUNCH(1, K_); break; case 2: WT_LAUNCH(2, K_); break; case 3: WT_LAUNCH(3, K_); break; default: WT_LAUNCH(4, K_); break; }
+        if (ktw <= 2) { WT_PICK(2) } else if (ktw <= 4) { WT_PICK(4) } else { WT_PICK(7) }
+#undef WT_PICK
+#undef WT_LAUNCH
+        NELE_CHECK_LAUNCH("nele_conv_wgrad(tile)");
+        tiled = true;
+        splits = G;
+        p.part = workspace;
+        p.bpart = t.bpart;
+    }
+    if (!tiled) {
     int rps = (M + splits - 1) / splits;
     rps = (rps + WG16_MS - 1) / WG16_MS * WG16_MS;
     p.rows_per_split = rps;
-    hipStream_t s = as_stream(stream);
     dim3 grid((p.g.Ktot + WG_BKK - 1) / WG_BKK, splits, (N + WG_BN - 1) / WG_BN);
     if (bf16) hipLaunchKernelGGL(conv_wgrad16_kernel, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, p);
     NELE_CHECK_LAUNCH("nele_conv_wgrad");
+    }
     const int total = N * p.g.Ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, s, p.part, p.bpart, splits, N, KH, KW,
                        p.g.C, Cvalid, dW, db, accumulate);
