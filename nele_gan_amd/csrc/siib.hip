@@ -28,6 +28,7 @@
 struct SiibWs {
     double* g2;      // [28][201] squared gammatone magnitude responses
     double* tab;     // [3][400] cos(2 pi j / 400), sin(2 pi j / 400), hann400(j)
+    double* g2t;     // [201][28] g2 transposed (bands contiguous)
     double* rowstat; // [B][2][28][2] per (signal, band) row of XL: minimum before masking, mean after masking
     double* xdb;     // [B][NT]   frame power (dB) of the tiled clean signal
     int* list;       // [B][NA]   active frame indices (tiled frame numbering)
@@ -45,7 +46,7 @@ struct SiibWs {
 __device__ __forceinline__ double hann400(int n) { return 0.5 - 0.5 * cospi((double)n / 200.0); }
 
 // ---------------------------------------------------------------- gammatone matrix (oracle/siib.py gammatone_matrix)
-__global__ void siib_g2_kernel(double* __restrict__ g2, double* __restrict__ tab) {
+__global__ void siib_g2_kernel(double* __restrict__ g2, double* __restrict__ tab, double* __restrict__ g2t) {
     __shared__ double red[8];
     const int j = blockIdx.x, q = threadIdx.x;  // 256 threads >= 201
     if (j == 0)
@@ -69,6 +70,7 @@ __global__ void siib_g2_kernel(double* __restrict__ g2, double* __restrict__ tab
     if (q < SB_NBIN) {
         const double g = t / mx;
         g2[j * SB_NBIN + q] = g * g;
+        g2t[q * SB_J + j] = g * g;
     }
 }
 
@@ -195,74 +197,133 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
     }
 }
 
-// grid (NA, B), block 256: s3
-__global__ __launch_bounds__(256) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
+// s3: 400-point spectra of the active frames -> 28 log band energies.  grid (ceil(NA / 6), B), block 128: six frames per workgroup.
+// 400 = 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2).  Both 20-point stages run from REGISTERS with compile-time twiddles: a thread
+// loads its 20 inputs once and produces all its outputs (stage 1: thread = (frame, n2), real input, k1 = 0..10 + conjugate
+// symmetry; stage 2: thread = (frame, k1), k2 = 0..10 since only bins <= 200 are used).  LDS only carries the windowed frame, the
+// 20 x 20 intermediate and |X|^2 - about 6x less LDS traffic than a thread-per-output formulation, which was LDS-bound.
+#define SP_F 6
+struct Tw20 { double c[20], s[20]; };
+__device__ constexpr Tw20 make_tw20() {
+    // cos / sin (2 pi t / 20), exact symmetries written out so that the table is a compile-time constant
+    Tw20 t{};
+    const double c1 = 0.95105651629515357212, c2 = 0.80901699437494742410, c3 = 0.58778525229247312917, c4 = 0.30901699437494742410;
+    const double cc[20] = {1.0, c1, c2, c3, c4, 0.0, -c4, -c3, -c2, -c1, -1.0, -c1, -c2, -c3, -c4, 0.0, c4, c3, c2, c1};
+    const double ss[20] = {0.0, c4, c3, c2, c1, 1.0, c1, c2, c3, c4, 0.0, -c4, -c3, -c2, -c1, -1.0, -c1, -c2, -c3, -c4};
+    for (int i = 0; i < 20; ++i) { t.c[i] = cc[i]; t.s[i] = ss[i]; }
+    return t;
+}
+__global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
                                                         int sig1) {   // signals sig0..sig1 (0 = clean x, 1 = degraded y)
-    __shared__ double sx[SB_WLEN], sy[SB_WLEN], cs[SB_WLEN], sn[SB_WLEN];
-    __shared__ double px[SB_NBIN], py[SB_NBIN];
-    __shared__ double2 Ax[SB_WLEN], Ay[SB_WLEN];
-    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    constexpr Tw20 tw = make_tw20();
+    __shared__ double sx[SP_F][SB_WLEN];              // windowed frames; reused as |X|^2 [SP_F][201]
+    __shared__ double2 Aq[SP_F][SB_WLEN];             // stage-1 output [n2][k1]
+    const int b = blockIdx.y, k0 = blockIdx.x * SP_F, tid = threadIdx.x;
     const int* info = ws.info + 4 * b;
     const int na = info[2];
-    if (k >= na) return;
+    if (k0 >= na) return;
     const long long total = (long long)info[0] * L;
-    const int f = ws.list[(size_t)b * ws.NA + k];
-    const float* xb = (sig0 == 0) ? x + (size_t)b * L : nullptr;
-    const float* yb = (sig1 == 1) ? y + (size_t)b * L : nullptr;
-    const long long p0 = (long long)SB_SHIFT * f;
-    const int q0 = (int)(p0 % L);
-    for (int j = tid; j < SB_WLEN; j += 256) {
-        int q = q0 + j;
-        while (q >= L) q -= L;
-        const double w = ws.tab[2 * SB_WLEN + j];
-        const bool in = p0 + j < total;
-        sx[j] = (in && xb) ? (double)xb[q] * w : 0.0;
-        sy[j] = (in && yb) ? (double)yb[q] * w : 0.0;
-        cs[j] = ws.tab[j];
-        sn[j] = ws.tab[SB_WLEN + j];
-    }
-    __syncthreads();
-    // 400-point DFT as 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2):
-    //   A[n2][k1] = W400^(n2 k1) * sum_n1 x[20 n1 + n2] W20^(n1 k1);   X[k] = sum_n2 A[n2][k1] W20^(n2 k2)
-    for (int o = sig0 * SB_WLEN + tid; o < (sig1 + 1) * SB_WLEN; o += 256) {
-        const int sig = o / SB_WLEN, idx = o - sig * SB_WLEN, n2 = idx / 20, k1 = idx - n2 * 20;
-        const double* src = sig ? sy : sx;
-        double ar = 0.0, ai = 0.0;
-        int t = 0;  // (n1 * k1) mod 20
-        for (int n1 = 0; n1 < 20; ++n1) {
-            const double v = src[20 * n1 + n2];
-            ar += v * cs[20 * t];
-            ai -= v * sn[20 * t];
-            t += k1;
-            if (t >= 20) t -= 20;
+    const int fs = tid / 20, lane20 = tid - fs * 20;   // frame slot, n2 (stage 1) / k1 (stage 2)
+    __shared__ double tcs[SB_WLEN], tsn[SB_WLEN];     // W400 twiddles (LDS copy of ws.tab: 31 dependent-latency reads per thread otherwise)
+    for (int e = tid; e < SB_WLEN; e += 128) { tcs[e] = ws.tab[e]; tsn[e] = ws.tab[SB_WLEN + e]; }
+    __shared__ int fq0[SP_F], fvalid[SP_F];           // first sample (mod L) of each frame or -1; samples before the tiled signal ends
+    if (tid < SP_F) {
+        int q0 = -1, nv = 0;
+        if (k0 + tid < na) {
+            const long long p0 = (long long)SB_SHIFT * ws.list[(size_t)b * ws.NA + k0 + tid];
+            q0 = (int)(p0 % L);
+            const long long left = total - p0;
+            nv = left >= SB_WLEN ? SB_WLEN : (left > 0 ? (int)left : 0);
         }
-        const double c2 = cs[n2 * k1], s2 = sn[n2 * k1];
-        (sig ? Ay : Ax)[idx] = make_double2(ar * c2 + ai * s2, ai * c2 - ar * s2);
+        fq0[tid] = q0; fvalid[tid] = nv;
     }
-    __syncthreads();
-    for (int o = sig0 * SB_NBIN + tid; o < (sig1 + 1) * SB_NBIN; o += 256) {
-        const int sig = o / SB_NBIN, kk = o - sig * SB_NBIN, k2 = kk / 20, k1 = kk - k2 * 20;
-        const double2* A = sig ? Ay : Ax;
-        double xr = 0.0, xi = 0.0;
-        int t = 0;  // (n2 * k2) mod 20
-        for (int n2 = 0; n2 < 20; ++n2) {
-            const double2 a = A[n2 * 20 + k1];
-            const double c = cs[20 * t], s_ = sn[20 * t];
-            xr += a.x * c + a.y * s_;
-            xi += a.y * c - a.x * s_;
-            t += k2;
-            if (t >= 20) t -= 20;
+    const bool act = fs < SP_F && k0 + fs < na;
+    for (int sig = sig0; sig <= sig1; ++sig) {
+        const float* sb = (sig ? y : x) + (size_t)b * L;
+        __syncthreads();
+        for (int e = tid; e < SP_F * SB_WLEN; e += 128) {
+            const int f_ = e / SB_WLEN, j = e - f_ * SB_WLEN;
+            double v = 0.0;
+            if (fq0[f_] >= 0 && j < fvalid[f_]) {
+                int q = fq0[f_] + j;
+                if (q >= L) q -= L;                         // L >= 400 (checked on the host): one wrap at most
+                v = (double)sb[q] * ws.tab[2 * SB_WLEN + j];
+            }
+            sx[f_][j] = v;
         }
-        (sig ? py : px)[kk] = xr * xr + xi * xi;
-    }
-    __syncthreads();
-    if (tid >= sig0 * SB_J && tid < (sig1 + 1) * SB_J) {
-        const int sig = tid / SB_J, j = tid - sig * SB_J;
-        const double* g = ws.g2 + j * SB_NBIN;
-        const double* pp = sig ? py : px;
-        double a = 0.0;
-        for (int q = 0; q < SB_NBIN; ++q) a += g[q] * pp[q];
-        ws.XL[(((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k] = log(a + SB_EPS);
+        __syncthreads();
+        if (act) {      // stage 1: a[k1] = sum_n1 v[n1] W20^(n1 k1), then * W400^(n2 k1)
+            const int n2 = lane20;
+            double v[20];
+#pragma unroll
+            for (int n1 = 0; n1 < 20; ++n1) v[n1] = sx[fs][20 * n1 + n2];
+#pragma unroll
+            for (int k1 = 0; k1 <= 10; ++k1) {
+                double ar = 0.0, ai = 0.0;
+#pragma unroll
+                for (int n1 = 0; n1 < 20; ++n1) {
+                    ar += v[n1] * tw.c[(n1 * k1) % 20];
+                    ai -= v[n1] * tw.s[(n1 * k1) % 20];
+                }
+                {
+                    const double c2 = tcs[n2 * k1], s2 = tsn[n2 * k1];
+                    Aq[fs][n2 * 20 + k1] = make_double2(ar * c2 + ai * s2, ai * c2 - ar * s2);
+                }
+                if (k1 >= 1 && k1 <= 9) {              // a[20 - k1] = conj(a[k1])
+                    const int kc = 20 - k1;
+                    const double c2 = tcs[n2 * kc], s2 = tsn[n2 * kc];
+                    Aq[fs][n2 * 20 + kc] = make_double2(ar * c2 - ai * s2, -ai * c2 - ar * s2);
+                }
+            }
+        }
+        __syncthreads();
+        if (act) {      // stage 2: X[k1 + 20 k2] = sum_n2 A[n2][k1] W20^(n2 k2); |X|^2 into sx (the frames are dead)
+            const int k1 = lane20;
+            double2 a[20];
+#pragma unroll
+            for (int n2 = 0; n2 < 20; ++n2) a[n2] = Aq[fs][n2 * 20 + k1];
+#pragma unroll
+            for (int k2 = 0; k2 <= 10; ++k2) {
+                double xr = 0.0, xi = 0.0;
+#pragma unroll
+                for (int n2 = 0; n2 < 20; ++n2) {
+                    const double c = tw.c[(n2 * k2) % 20], s_ = tw.s[(n2 * k2) % 20];
+                    xr += a[n2].x * c + a[n2].y * s_;
+                    xi += a[n2].y * c - a[n2].x * s_;
+                }
+                const int kk = k1 + 20 * k2;
+                if (kk < SB_NBIN) sx[fs][kk] = xr * xr + xi * xi;
+            }
+        }
+        __syncthreads();
+        // band energies: out[f][j] = sum_q |X_f[q]|^2 g2[j][q].  thread = (band j, quarter of the bins), all six frames per thread:
+        // one coalesced read of the transposed filter row per bin, the six spectra are LDS broadcasts
+        {
+            double (*bpart)[SP_F][SB_J] = reinterpret_cast<double (*)[SP_F][SB_J]>(&Aq[0][0]);   // [4][SP_F][28], Aq is dead here
+            if (tid < 4 * SB_J) {
+                const int j = tid % SB_J, qp = tid / SB_J;
+                const int q0 = qp * 51, q1 = min(SB_NBIN, q0 + 51);
+                double acc[SP_F];
+#pragma unroll
+                for (int f_ = 0; f_ < SP_F; ++f_) acc[f_] = 0.0;
+#pragma unroll 4
+                for (int q = q0; q < q1; ++q) {
+                    const double gq = ws.g2t[q * SB_J + j];
+#pragma unroll
+                    for (int f_ = 0; f_ < SP_F; ++f_) acc[f_] += gq * sx[f_][q];
+                }
+#pragma unroll
+                for (int f_ = 0; f_ < SP_F; ++f_) bpart[qp][f_][j] = acc[f_];
+            }
+            __syncthreads();
+            for (int o = tid; o < SP_F * SB_J; o += 128) {
+                const int f_ = o / SB_J, j = o - f_ * SB_J;
+                if (k0 + f_ < na) {
+                    const double a = (bpart[0][f_][j] + bpart[1][f_][j]) + (bpart[2][f_][j] + bpart[3][f_][j]);
+                    ws.XL[(((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k0 + f_] = log(a + SB_EPS);
+                }
+            }
+        }
     }
 }
 
@@ -546,6 +607,7 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
 #define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
     TAKE(g2, double, SB_J * SB_NBIN);
     TAKE(tab, double, 3 * SB_WLEN);
+    TAKE(g2t, double, SB_NBIN * SB_J);
     TAKE(rowstat, double, (size_t)B * 2 * SB_J * 2);
     TAKE(xdb, double, (size_t)B * NT);
     TAKE(list, int, (size_t)B * NA);
@@ -587,7 +649,7 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     const bool eig = (phase == 0 || phase == 2 || phase == 3);
     const bool fin = (phase == 0 || phase == 2 || phase == 4);
     if (vad) {
-        hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2, ws.tab);
+        hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2, ws.tab, ws.g2t);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
@@ -595,7 +657,7 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     }
     if (sx || sy) {
         const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
-        hipLaunchKernelGGL(siib_spec_kernel, dim3(ws.NA, B), dim3(256), 0, s, x, y, L, ws, sig0, sig1);
+        hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);
