@@ -114,6 +114,14 @@ def main():
     ops.PROFILE = None
     if rank == 0:
         T = 1 + a.length // 256
+        traffic = None      # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01/traffic.json), B = 32 bf16 only
+        try:
+            import json as _json
+            tj = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'traffic.json')))
+            if a.precision == 'bf16' and a.batch == 32 and a.length == 64000:
+                traffic = [v['hbm_bytes_corrected'] for k, v in tj['kernels'].items() if k.startswith('conv_tile16_kernel<4,8>')][0]
+        except Exception:
+            traffic = None
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
         peak = BF16_MFMA_PEAK_TFLOPS if a.precision == 'bf16' else F32_MFMA_PEAK_TFLOPS
@@ -133,7 +141,7 @@ def main():
                          'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
                              'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
+                         'traffic': traffic, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']

@@ -276,10 +276,21 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
             double scn = 0.0;
             betan = alpha;
             if (ss > 0.0) {
-                const double nrm = sqrt(alpha * alpha + ss);
+                // beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta = 1 + |alpha| / ||x||, scale = 1 / (alpha - beta) =
+                // sign(alpha) / (|alpha| + ||x||): one rsqrt and one rcp with two Newton steps each instead of sqrt + two divisions
+                // (this sits on the serial critical path of every step; the results agree with the divisions to ~1 ulp)
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
                 betan = alpha >= 0.0 ? -nrm : nrm;
-                tn = (betan - alpha) / betan;
-                scn = 1.0 / (alpha - betan);
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
             }
             vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
         }
@@ -366,7 +377,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
                     if (i < n) d[i] = __builtin_nan("");
                     return;
                 }
+#ifndef EC_NOSLEEP
                 __builtin_amdgcn_s_sleep(1);
+#endif
             }
             if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
         }
