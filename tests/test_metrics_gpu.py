@@ -127,7 +127,7 @@ def test_haspi_random_dither_is_small_and_seeded(mt):
     assert abs(float(r1[0]) - float(r0[0])) < 0.02 * abs(float(r0[0]))    # N(0, 0.1 dB) jitter: per-mille level effect
 
 
-@pytest.mark.parametrize('n,B', [(420, 3), (97, 2), (16, 4)])
+@pytest.mark.parametrize('n,B', [(420, 3), (97, 2), (16, 4), (420, 17), (420, 33), (512, 9)])   # 17 / 33: ragged cluster launches
 def test_batched_eigensolver_vs_numpy(mt, n, B):
     rs = np.random.RandomState(n)
     A = np.zeros((B, n, n))
@@ -142,3 +142,22 @@ def test_batched_eigensolver_vs_numpy(mt, n, B):
         V = U[b].T                                                             # columns = eigenvectors
         assert np.abs(V.T @ V - np.eye(n)).max() < 1e-8
         assert np.abs(A[b] @ V - V * lam[b][None, :]).max() < 1e-11 * ref.max()
+
+
+def test_siib_split_by_data_dependence_equals_one_shot(mt):
+    """clean_part() + degraded_part(y) (the order GanTrainer uses) must give exactly the one-shot result."""
+    from nele_gan_amd import synth
+    c, v = synth.batch(3, 40000, start=11)
+    x = torch.from_numpy(c).cuda()
+    y = torch.from_numpy(c + v).cuda()
+    raw0, map0 = mt.batch_siib(x, y)
+    raw0, map0 = raw0.clone(), map0.clone()
+    sp = mt.SiibSplit(x)
+    sp.clean_part()
+    raw1, map1 = sp.degraded_part(y)
+    assert torch.equal(raw0, raw1) and torch.equal(map0, map1)
+    y2 = torch.from_numpy(c + 2.0 * v).cuda()           # a second degraded signal against the same clean part
+    raw2, _ = sp.degraded_part(y2)
+    raw2 = raw2.clone()
+    raw3, _ = mt.batch_siib(x, y2)
+    assert torch.equal(raw2, raw3)

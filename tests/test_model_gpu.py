@@ -256,3 +256,26 @@ def test_bf16_operand_mode_close_to_f32(mods):
     for i in (1, 2, 3):
         scale = np.abs(a[i]).max()
         assert np.abs(a[i] - b[i]).max() < 3e-2 * scale, i
+
+
+@pytest.mark.parametrize('T', [41, 77, 100, 133])
+def test_bf16_tile_kernels_on_ragged_frame_counts(mods, T):
+    """The 2-D tile conv / weight-gradient kernels on output widths that are not multiples of their 64-column tiles (and heights
+    that are not multiples of 8): D forward + backward in bf16 against the float32 kernels, eval-mode spectral norm."""
+    rs = np.random.RandomState(T)
+    x = torch.from_numpy((0.2 + 0.5 * rs.rand(2, 3, 64, T)).astype(np.float32)).cuda()
+    outs = {}
+    for prec in ('f32', 'bf16'):
+        D = load_recipe(mods.Discriminator(), 202).eval()
+        D.precision = prec
+        xi = x.clone().requires_grad_(True)
+        D.flat_parameters().grad.zero_()
+        sc = D(xi)
+        (sc * torch.tensor([[1.0, -2.0, 0.5]], device='cuda')).sum().backward()
+        outs[prec] = (sc.detach().cpu().numpy(), xi.grad.cpu().numpy(), D.flat_parameters().grad.cpu().numpy().copy())
+    a, b = outs['f32'], outs['bf16']
+    assert np.abs(a[0] - b[0]).max() < 3e-3
+    for i in (1, 2):                                   # bf16 operand noise: a few % of the largest element, direction preserved
+        assert np.isfinite(b[i]).all()
+        assert np.abs(a[i] - b[i]).max() < 5e-2 * np.abs(a[i]).max(), i
+        assert (a[i] * b[i]).sum() > 0.9999 * np.linalg.norm(a[i]) * np.linalg.norm(b[i]), i
