@@ -92,39 +92,79 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
         for (int i = tid; i < L; i += 256) dst[i] = src[i] / rms;
         return;
     }
-    // resampy resample_f (ratio 1.5: scale = 1, index_step = num_table)
+    // resampy resample_f (ratio 1.5: scale = 1, index_step = num_table).  For this ratio the fractional position takes three
+    // values, so the interpolated-window taps start at table offsets 0, 170, 341 (left wing) and 512, 341, 170 (right wing):
+    // those four tap columns (value and forward difference) are staged in LDS once, the normalised input of each chunk of
+    // outputs is staged in LDS, and the per-tap work is two LDS reads and the reference's float32-rounded accumulate.  Same
+    // arithmetic as indexing the 32769-entry window in memory (offsets outside the four columns fall back to it).
+    constexpr int RS_CH = 768, RS_IN = RS_CH * 2 / 3 + 2 * 66 + 4;
+    __shared__ double wv[4][66], wd[4][66];
+    __shared__ float xsn[RS_IN];
+    for (int e = tid; e < 4 * 66; e += 256) {
+        const int slot = e / 66, i = e - slot * 66;
+        const int off = (slot == 0) ? 0 : (slot == 1) ? 170 : (slot == 2) ? 341 : 512;
+        const int idx = off + i * HP_NTAB;
+        double v = 0.0, d = 0.0;
+        if (idx < HP_NWIN) {
+            v = ws.win[idx];
+            d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - v : 0.0;
+        }
+        wv[slot][i] = v; wd[slot][i] = d;
+    }
     const double time_increment = 1.0 / 1.5;
     double a2 = 0.0;
-    for (int t = tid; t < ws.n24; t += 256) {
-        const double time_register = (double)t * time_increment;
-        const int n = (int)time_register;
-        double frac = time_register - (double)n;
-        double index_frac = frac * HP_NTAB;
-        int offset = (int)index_frac;
-        double eta = index_frac - offset;
-        int i_max = (HP_NWIN - offset) / HP_NTAB;
-        if (n + 1 < i_max) i_max = n + 1;
-        float yv = 0.f;
-        for (int i = 0; i < i_max; ++i) {
-            const int idx = offset + i * HP_NTAB;
-            const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
-            const double w = ws.win[idx] + eta * d;
-            yv = (float)((double)yv + w * (double)(src[n - i] / rms));
+    for (int t0 = 0; t0 < ws.n24; t0 += RS_CH) {
+        const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
+        __syncthreads();
+        for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? src[nbase + e] / rms : 0.f;
+        __syncthreads();
+        for (int t = t0 + tid; t < min(ws.n24, t0 + RS_CH); t += 256) {
+            const double time_register = (double)t * time_increment;
+            const int n = (int)time_register;
+            double frac = time_register - (double)n;
+            double index_frac = frac * HP_NTAB;
+            int offset = (int)index_frac;
+            double eta = index_frac - offset;
+            int i_max = (HP_NWIN - offset) / HP_NTAB;
+            if (n + 1 < i_max) i_max = n + 1;
+            float yv = 0.f;
+            int slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
+            if (slot >= 0 && n - (i_max - 1) >= nbase) {
+                for (int i = 0; i < i_max; ++i) {
+                    const double w = wv[slot][i] + eta * wd[slot][i];
+                    yv = (float)((double)yv + w * (double)xsn[n - i - nbase]);
+                }
+            } else {
+                for (int i = 0; i < i_max; ++i) {
+                    const int idx = offset + i * HP_NTAB;
+                    const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+                    const double w = ws.win[idx] + eta * d;
+                    yv = (float)((double)yv + w * (double)(src[n - i] / rms));
+                }
+            }
+            frac = 1.0 - frac;
+            index_frac = frac * HP_NTAB;
+            offset = (int)index_frac;
+            eta = index_frac - offset;
+            int k_max = (HP_NWIN - offset) / HP_NTAB;
+            if (L - n - 1 < k_max) k_max = L - n - 1;
+            slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
+            if (slot >= 0 && n + k_max - nbase < RS_IN) {
+                for (int k = 0; k < k_max; ++k) {
+                    const double w = wv[slot][k] + eta * wd[slot][k];
+                    yv = (float)((double)yv + w * (double)xsn[n + k + 1 - nbase]);
+                }
+            } else {
+                for (int k = 0; k < k_max; ++k) {
+                    const int idx = offset + k * HP_NTAB;
+                    const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+                    const double w = ws.win[idx] + eta * d;
+                    yv = (float)((double)yv + w * (double)(src[n + k + 1] / rms));
+                }
+            }
+            dst[t] = yv;
+            a2 += (double)(yv * yv);
         }
-        frac = 1.0 - frac;
-        index_frac = frac * HP_NTAB;
-        offset = (int)index_frac;
-        eta = index_frac - offset;
-        int k_max = (HP_NWIN - offset) / HP_NTAB;
-        if (L - n - 1 < k_max) k_max = L - n - 1;
-        for (int k = 0; k < k_max; ++k) {
-            const int idx = offset + k * HP_NTAB;
-            const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
-            const double w = ws.win[idx] + eta * d;
-            yv = (float)((double)yv + w * (double)(src[n + k + 1] / rms));
-        }
-        dst[t] = yv;
-        a2 += (double)(yv * yv);
     }
     // y = (xRMS / yRMS) * y  (pyhaspi2.py:816-818); xRMS of the normalised input
     double xs = 0.0;
