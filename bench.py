@@ -111,6 +111,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = ops.PROFILE[tag]
+    # the same launch on an otherwise idle GPU (after the timed region): inside the step the kernel shares the CUs with the metric
+    # stream (SIIB's clean-signal part, incl. the all-CU tridiagonalisation, runs beside the G-step), which inflates its duration
+    iso_tag = 'iso.D.conv5.fwd'
+    ops.PROFILE = {iso_tag: []}
+    torch.cuda.synchronize()
+    tr.D.eval()
+    tr.D.profile_prefix = 'iso.'
+    with torch.no_grad():
+        for _ in range(6):
+            tr.D.forward_packed(tr._last_din)
+    torch.cuda.synchronize()
+    iso = ops.PROFILE[iso_tag][1:]
+    tr.D.profile_prefix = ''
+    tr.D.train()
     ops.PROFILE = None
     if rank == 0:
         T = 1 + a.length // 256
@@ -124,6 +138,7 @@ def main():
             traffic = None
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
+        iso_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in iso) / max(1, len(iso))
         peak = BF16_MFMA_PEAK_TFLOPS if a.precision == 'bf16' else F32_MFMA_PEAK_TFLOPS
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         out = {
@@ -141,7 +156,9 @@ def main():
                          'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
                              'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'launch_ms': kernel_ms, 'launches_timed': len(prof), 'flops_per_launch': flops},
+                         'traffic': traffic, 'launch_ms': kernel_ms,
+                         'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
+                         'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']

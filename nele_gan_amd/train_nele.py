@@ -93,7 +93,8 @@ class GanTrainer:
         self.optimizer_g.zero_grad()
         mask = self.G(clean_band, noise_band)
         din, _ = M.energy_norm_pack(mask, clean_band, noise_band, p_power, inv_p)
-        self.D.profile_prefix = 'gstep.'             # bench.py times these launches: no other stream is active in the G-step
+        self._last_din = din                         # bench.py re-launches D's forward on it for the isolated roofline figure
+        self.D.profile_prefix = 'gstep.'             # bench.py times these launches
         score = self.D.forward_packed(din)
         self.D.profile_prefix = ''
         loss = self.MSELoss(score, torch.ones_like(score))
