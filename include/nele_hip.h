@@ -84,6 +84,11 @@ int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* workspace, lo
  * weights re-ordered by nele_weight_prep_frag16 into nele_weight_frag16_elems(N, KW*C, KH) bf16 elements. */
 long long nele_weight_frag16_elems(int N, int seglen, int KH);
 int nele_weight_prep_frag16(const float* Wg, int N, int Ktot, int seglen, int KH, void* Wfrag, void* stream);
+/* Batched variants: every layer of a model in one launch each.  ptrs / dims are HOST arrays (as for nele_spectral_norm):
+ * prep: ptrs [4*jobs] = (Wt, sigma or NULL, Wf, Wb or NULL), dims [5*jobs] = (N, Cvalid, C, KH, KW);
+ * frag16: ptrs [2*jobs] = (Wg, Wfrag), dims [4*jobs] = (N, Ktot, seglen, KH).  jobs <= 16. */
+int nele_weight_prep_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream);
+int nele_weight_prep_frag16_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream);
 int nele_conv_span_bf16_supported(int M, int N, const int* geom_host, int KH, int KW);
 int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
                         float slope, const int* geom_host, int KH, int KW, long long a_elems, void* stream);

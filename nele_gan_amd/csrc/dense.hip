@@ -1669,6 +1669,82 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     return NELE_OK;
 }
 
+// ---- batched variants: all layers of a model in one launch each (blockIdx.y = job); host pointer / dims arrays as in nele_spectral_norm
+#define WB_MAXJ 16
+struct PrepJobs { const float* Wt[WB_MAXJ]; const float* sigma[WB_MAXJ]; float* Wf[WB_MAXJ]; float* Wb[WB_MAXJ]; int N[WB_MAXJ], Cv[WB_MAXJ], C[WB_MAXJ], KH[WB_MAXJ], KW[WB_MAXJ]; };
+__global__ void weight_prep_batch_kernel(PrepJobs J) {
+    const int q = blockIdx.y;
+    const float* __restrict__ Wt = J.Wt[q];
+    float* __restrict__ Wf = J.Wf[q];
+    float* __restrict__ Wb = J.Wb[q];
+    const int N = J.N[q], Cvalid = J.Cv[q], C = J.C[q], KH = J.KH[q], KW = J.KW[q];
+    const int total = N * Cvalid * KH * KW;
+    const float inv = J.sigma[q] ? 1.f / J.sigma[q][0] : 1.f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int kw = t % KW; t /= KW;
+        const int kh = t % KH; t /= KH;
+        const int ci = t % Cvalid;
+        const int n = t / Cvalid;
+        const float v = Wt[idx] * inv;
+        Wf[(((size_t)n * KH + kh) * KW + kw) * C + ci] = v;
+        if (Wb) Wb[(((size_t)ci * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * N + n] = v;
+    }
+}
+struct Frag16Jobs { const float* Wg[WB_MAXJ]; __bf16* Wfrag[WB_MAXJ]; int N[WB_MAXJ], Ktot[WB_MAXJ], seglen[WB_MAXJ], KH[WB_MAXJ]; };
+__global__ void weight_frag16_batch_kernel(Frag16Jobs J) {
+    const int q = blockIdx.y;
+    const float* __restrict__ Wg = J.Wg[q];
+    __bf16* __restrict__ Wfrag = J.Wfrag[q];
+    const int N = J.N[q], Ktot = J.Ktot[q], seglen = J.seglen[q], KH = J.KH[q];
+    const int NT = (N + 15) / 16, sps = (seglen + 31) / 32;
+    const int total = KH * sps * NT * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9, j = t % NT, ks = t / NT;
+        const int kh = ks / sps, s_ = ks - kh * sps;
+        const int n = j * 16 + (lane & 15), kin = s_ * 32 + 8 * (lane >> 4) + e;
+        float v = 0.f;
+        if (n < N && kin < seglen) v = Wg[(size_t)n * Ktot + (size_t)kh * seglen + kin];
+        Wfrag[idx] = (__bf16)v;
+    }
+}
+
+// ptrs_host [4 * jobs] = (Wt, sigma or null, Wf, Wb or null), dims_host [5 * jobs] = (N, Cvalid, C, KH, KW): nele_weight_prep per job
+extern "C" int nele_weight_prep_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream) {
+    NELE_CHECK_ARG(ptrs_host && dims_host && jobs >= 1 && jobs <= WB_MAXJ, "nele_weight_prep_batch: bad arguments (jobs <= 16)");
+    PrepJobs J;
+    int maxtotal = 1;
+    for (int q = 0; q < jobs; ++q) {
+        J.Wt[q] = (const float*)ptrs_host[4 * q]; J.sigma[q] = (const float*)ptrs_host[4 * q + 1];
+        J.Wf[q] = (float*)ptrs_host[4 * q + 2]; J.Wb[q] = (float*)ptrs_host[4 * q + 3];
+        J.N[q] = dims_host[5 * q]; J.Cv[q] = dims_host[5 * q + 1]; J.C[q] = dims_host[5 * q + 2]; J.KH[q] = dims_host[5 * q + 3]; J.KW[q] = dims_host[5 * q + 4];
+        NELE_CHECK_ARG(J.Wt[q] && J.Wf[q] && J.N[q] > 0 && J.Cv[q] > 0 && J.C[q] >= J.Cv[q], "nele_weight_prep_batch: job %d invalid", q);
+        const int total = J.N[q] * J.Cv[q] * J.KH[q] * J.KW[q];
+        if (total > maxtotal) maxtotal = total;
+    }
+    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3(min(256, (maxtotal + 255) / 256), jobs), dim3(256), 0, as_stream(stream), J);
+    NELE_CHECK_LAUNCH("nele_weight_prep_batch");
+    return NELE_OK;
+}
+
+// ptrs_host [2 * jobs] = (Wg [N][Ktot] f32, Wfrag), dims_host [4 * jobs] = (N, Ktot, seglen, KH): nele_weight_prep_frag16 per job
+extern "C" int nele_weight_prep_frag16_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream) {
+    NELE_CHECK_ARG(ptrs_host && dims_host && jobs >= 1 && jobs <= WB_MAXJ, "nele_weight_prep_frag16_batch: bad arguments (jobs <= 16)");
+    Frag16Jobs J;
+    long long maxtotal = 1;
+    for (int q = 0; q < jobs; ++q) {
+        J.Wg[q] = (const float*)ptrs_host[2 * q]; J.Wfrag[q] = (__bf16*)ptrs_host[2 * q + 1];
+        J.N[q] = dims_host[4 * q]; J.Ktot[q] = dims_host[4 * q + 1]; J.seglen[q] = dims_host[4 * q + 2]; J.KH[q] = dims_host[4 * q + 3];
+        NELE_CHECK_ARG(J.Wg[q] && J.Wfrag[q] && J.N[q] > 0 && J.KH[q] > 0 && J.seglen[q] > 0 && J.KH[q] * J.seglen[q] == J.Ktot[q],
+                       "nele_weight_prep_frag16_batch: job %d invalid", q);
+        const long long total = nele_weight_frag16_elems(J.N[q], J.seglen[q], J.KH[q]) - 2048;
+        if (total > maxtotal) maxtotal = total;
+    }
+    hipLaunchKernelGGL(weight_frag16_batch_kernel, dim3((unsigned)min(512LL, (maxtotal + 255) / 256), jobs), dim3(256), 0, as_stream(stream), J);
+    NELE_CHECK_LAUNCH("nele_weight_prep_frag16_batch");
+    return NELE_OK;
+}
+
 extern "C" int nele_weight_prep(const float* Wt, const float* sigma, int N, int Cvalid, int C, int KH, int KW, float* Wf, float* Wb,
                                 void* stream) {
     NELE_CHECK_ARG(Wt && Wf && N > 0 && Cvalid > 0 && C >= Cvalid, "nele_weight_prep: bad arguments");

@@ -218,11 +218,19 @@ class Generator_Conv1D_cLN(nn.Module):
 
     def _prep_weights(self, dev):
         wf, wb = self._weights(dev)
-        for l, (cin, cout, k) in enumerate(_G_LAYERS):
-            w = self.convolutions[l][0].conv.weight
-            ops.weight_prep(w, None, cout, cin, cin, 1, k, wf[l], wb[l])
-        ops.weight_prep(self.fc1.weight, None, 64, 64, 64, 1, 1, wf[6], wb[6])
-        ops.weight_prep(self.fc2.weight, None, 64, 64, 64, 1, 1, wf[7], wb[7])
+        ws = [self.convolutions[l][0].conv.weight for l in range(len(_G_LAYERS))] + [self.fc1.weight, self.fc2.weight]
+        ck = (ws[0].data_ptr(), ws[-1].data_ptr(), wf[0].data_ptr())
+        if getattr(self, '_prepjobs', None) is None or self._prepjobs[0] != ck:
+            pj, dj = [], []
+            for l, (cin, cout, k) in enumerate(_G_LAYERS):
+                pj += [ws[l].data_ptr(), None, wf[l].data_ptr(), wb[l].data_ptr()]
+                dj += [cout, cin, cin, 1, k]
+            for q in (6, 7):
+                pj += [ws[q].data_ptr(), None, wf[q].data_ptr(), wb[q].data_ptr()]
+                dj += [64, 64, 64, 1, 1]
+            self._prepjobs = (ck, (c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5)
+        _, pja, dja, npj = self._prepjobs
+        call('nele_weight_prep_batch', pja, dja, npj, stream())       # all 8 layers in one launch
         return wf, wb
 
     def _get_bufs(self, B, T, dev):
@@ -447,20 +455,48 @@ class _DiscriminatorBase(nn.Module):
             dd[2 * i] = m.weight_orig.shape[0]
             dd[2 * i + 1] = m.weight_orig.numel() // m.weight_orig.shape[0]
         call('nele_spectral_norm', pp, dd, len(mods), ptr(w['sigma']), n_iter, stream())
-        cin, cpad = self._cin, 4
-        for l, (cout, k) in enumerate(_D_CONVS):
-            m = self.layers[l]
-            ops.weight_prep(m.weight_orig, w['sigma'][l:l + 1], cout, cin, cpad, k, k, w['wf'][l], w['wb'][l])
-            use16 = self.precision == 'bf16'
-            if use16 and bf.span16_f[l]:
-                ops.weight_prep_frag16(w['wf'][l], cout, k * k * cpad, k * cpad, k, w['wff16'][l])
-            elif bf.span_f[l]:
-                ops.weight_prep_frag(w['wf'][l], cout, k * k * cpad, w['wff'][l])
-            if use16 and bf.span16_b[l]:
-                ops.weight_prep_frag16(w['wb'][l], cpad, k * k * cout, k * cout, k, w['wbf16'][l])
-            elif bf.span_b[l]:
-                ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
-            cin = cpad = cout
+        use16 = self.precision == 'bf16'
+        if use16:
+            # every layer's weight layouts in two launches (float32 GEMM / data-gradient layouts, then the bf16 fragment streams)
+            jk = ('prepjobs', key, self.layers[0].weight_orig.data_ptr(), self.layers[-1].weight_orig.data_ptr())
+            if jk not in w:
+                cin, cpad = self._cin, 4
+                pj, dj, fj, ej = [], [], [], []
+                for l, (cout, k) in enumerate(_D_CONVS):
+                    m = self.layers[l]
+                    pj += [m.weight_orig.data_ptr(), w['sigma'][l:l + 1].data_ptr(), w['wf'][l].data_ptr(), w['wb'][l].data_ptr()]
+                    dj += [cout, cin, cpad, k, k]
+                    if bf.span16_f[l]:
+                        fj += [w['wf'][l].data_ptr(), w['wff16'][l].data_ptr()]
+                        ej += [cout, k * k * cpad, k * cpad, k]
+                    if bf.span16_b[l]:
+                        fj += [w['wb'][l].data_ptr(), w['wbf16'][l].data_ptr()]
+                        ej += [cpad, k * k * cout, k * cout, k]
+                    cin = cpad = cout
+                w[jk] = ((c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5,
+                         (c_void_p * max(1, len(fj)))(*fj), (ctypes.c_int * max(1, len(ej)))(*ej), len(ej) // 4)
+            pja, dja, npj, fja, eja, nfj = w[jk]
+            call('nele_weight_prep_batch', pja, dja, npj, stream())
+            if nfj:
+                call('nele_weight_prep_frag16_batch', fja, eja, nfj, stream())
+            # layers the bf16 kernels decline still need the float32 fragment layout
+            cin, cpad = self._cin, 4
+            for l, (cout, k) in enumerate(_D_CONVS):
+                if not bf.span16_f[l] and bf.span_f[l]:
+                    ops.weight_prep_frag(w['wf'][l], cout, k * k * cpad, w['wff'][l])
+                if not bf.span16_b[l] and bf.span_b[l]:
+                    ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
+                cin = cpad = cout
+        else:
+            cin, cpad = self._cin, 4
+            for l, (cout, k) in enumerate(_D_CONVS):
+                m = self.layers[l]
+                ops.weight_prep(m.weight_orig, w['sigma'][l:l + 1], cout, cin, cpad, k, k, w['wf'][l], w['wb'][l])
+                if bf.span_f[l]:
+                    ops.weight_prep_frag(w['wf'][l], cout, k * k * cpad, w['wff'][l])
+                if bf.span_b[l]:
+                    ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
+                cin = cpad = cout
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):

@@ -27,6 +27,8 @@ _SIGS = {
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_chunks': [c_int],
     'nele_colsum': [_P, c_int, c_int, _P, c_int, _P],
+    'nele_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
+    'nele_weight_prep_frag16_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
     'nele_colsum2': [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     'nele_exptanh_bwd': [_P, _P, _P, c_longlong, _P],
     'nele_energy_norm_fwd': [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, _P],
