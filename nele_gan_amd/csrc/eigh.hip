@@ -840,7 +840,9 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
         // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
-        const int per = (B <= 32 && cluster_cap >= 32) ? 16 : cluster_cap;
+        static int split_small = -1;
+        if (split_small < 0) { const char* e = getenv("NELE_EIGH_SPLIT"); split_small = !(e && e[0] == '0'); }
+        const int per = (split_small && B <= 32 && cluster_cap >= 32) ? 16 : cluster_cap;
         for (int b0 = 0; b0 < B; b0 += per) {
             const int Bc = (B - b0 < per) ? B - b0 : per;
             hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
