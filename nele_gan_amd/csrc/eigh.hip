@@ -393,25 +393,30 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 }
 
 // ------------------------------------------------------------------------------------------ e2
-// grid (ceil(n/16), B), block 256.  A 16-lane row -> one eigenvalue (j-th smallest) by 17-section on the Sturm count: every
-// round the 16 lanes evaluate the count at 16 interior points of the current interval, so ~13 rounds (instead of 53 bisection
-// steps) of the n-step serial recurrence reach 1 ulp, and 16x more lanes are in flight to hide the recurrence latency.
+// grid (ceil(n / (256/NL)), B), block 256.  NL lanes -> one eigenvalue (j-th smallest) by (NL+1)-section on the Sturm count: every
+// round the NL lanes evaluate the count at NL interior points of the current interval, so ~17 rounds at NL = 8 (instead of 53
+// bisection steps) of the n-step serial recurrence reach 1 ulp.  NL trades the serial depth (rounds) against the total work
+// (NL x rounds sweeps per eigenvalue): the kernel is issue-bound at NL = 16 and latency-bound at NL = 4 for 32 x 420 eigenvalues.
 // Count: division-free three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes = eigenvalues below x).
+#ifndef EG_NL
+#define EG_NL 8      // lanes per eigenvalue: (EG_NL + 1)-section per round
+#endif
 __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
-    __shared__ double sd[EG_MAXN], se2[EG_MAXN];
+    __shared__ double2 sde[EG_MAXN];          // {d_i, e_{i-1}^2}: one 16-byte broadcast read per recurrence step
     __shared__ double red[8];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, t = lane & 15;
-    const int j = blockIdx.x * 16 + (tid >> 4);
+    constexpr int NL = EG_NL, PER = 256 / NL;
+    constexpr double inv = 1.0 / (double)(NL + 1);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, t = lane & (NL - 1);
+    const int j = blockIdx.x * PER + tid / NL;
     const double* d = ws.d + (size_t)b * n;
     const double* e = ws.e + (size_t)b * n;
     double gl = 1e300, gu = -1e300, tn = 0.0, e2m = 0.0;
     for (int i = tid; i < n; i += 256) {
         const double di = d[i];
-        sd[i] = di;
         const double ej = (i < n - 1) ? e[i] : 0.0;
-        se2[i] = ej * ej;
-        const double em = (i > 0) ? fabs(e[i - 1]) : 0.0;
-        const double r = fabs(ej) + em;
+        const double em = (i > 0) ? e[i - 1] : 0.0;
+        sde[i] = make_double2(di, em * em);
+        const double r = fabs(ej) + fabs(em);
         gl = fmin(gl, di - r);
         gu = fmax(gu, di + r);
         tn = fmax(tn, fabs(di) + r);
@@ -423,22 +428,23 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
     const double pivmin = fmax(safemn, safemn * block_max(e2m, red));
     double lo = glo - 2.0 * tnorm * eps * n - 2.0 * pivmin, hi = ghi + 2.0 * tnorm * eps * n + 2.0 * pivmin;
     bool active = j < n;
-    for (int it = 0; it < 64; ++it) {
+    for (int it = 0; it < 96; ++it) {
         const double w = hi - lo;
-        const double x = lo + w * (double)(t + 1) * (1.0 / 17.0);
-        const double x1 = lo + w * (1.0 / 17.0), x16 = lo + w * 16.0 * (1.0 / 17.0);
-        if (!(w > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || x1 <= lo || x16 >= hi) active = false;
+        const double x = lo + w * (double)(t + 1) * inv;
+        const double x1 = lo + w * inv, xl = lo + w * (double)NL * inv;
+        if (!(w > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || x1 <= lo || xl >= hi) active = false;
         if (!__any(active)) break;
-        double p0 = 1.0, p1 = sd[0] - x;
+        double p0 = 1.0, p1 = sde[0].x - x;
         if (p1 == 0.0) p1 = -pivmin;
         int cnt = (p1 < 0.0) ? 1 : 0;
         int i = 1;
         while (i < n) {
             const int iend = min(n, i + 8);
             for (; i < iend; ++i) {
-                double p2 = (sd[i] - x) * p1 - se2[i - 1] * p0;
+                const double2 de = sde[i];
+                double p2 = (de.x - x) * p1 - de.y * p0;
                 if (p2 == 0.0) p2 = -copysign(pivmin, p1);
-                cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);   // sign change (no zeros, no NaNs here)
                 p0 = p1;
                 p1 = p2;
             }
@@ -447,10 +453,10 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
             else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
         }
         const unsigned long long bal = __ballot(cnt <= j);
-        const int m = __popc((unsigned)((bal >> (lane & 48)) & 0xffffull));   // points of this row with count <= j
+        const int m = __popc((unsigned)((bal >> (lane & (64 - NL))) & ((1ull << NL) - 1ull)));   // points of this group with count <= j
         if (active) {
-            const double nlo = (m == 0) ? lo : lo + w * (double)m * (1.0 / 17.0);
-            const double nhi = (m == 16) ? hi : lo + w * (double)(m + 1) * (1.0 / 17.0);
+            const double nlo = (m == 0) ? lo : lo + w * (double)m * inv;
+            const double nhi = (m == NL) ? hi : lo + w * (double)(m + 1) * inv;
             lo = nlo;
             hi = nhi;
         }
@@ -850,7 +856,7 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }
-    hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 15) / 16, B), dim3(256), 0, s, n, ws, lam);
+    hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 256 / EG_NL - 1) / (256 / EG_NL), B), dim3(256), 0, s, n, ws, lam);
     hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam);
     const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * ((n + 15) & ~15) + 2 * BT_CH);
     static bool attr_done = false;
