@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
     double v_i = 0.0, tk = 0.0, p_i = 0.0;
     double col_i = (i < n) ? A[i] : 0.0;                   // column 0 (= row 0)
 #ifdef EC_PROF
-    long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+    long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
 #define EC_T(j) do { t1 = clock64(); tacc[j] += t1 - t0; t0 = t1; } while (0)
 #else
 #define EC_T(j)
@@ -294,13 +294,16 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
             }
             vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
         }
+        EC_T(6);
         if (p == ((s + 1) & 7)) {                          // one workgroup records the step
             if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
             if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
         }
+        EC_T(7);
         if (s == n - 2) break;
         vnat[i] = v_i; wnat[i] = w_i;
         vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
+        EC_T(8);
         __syncthreads();
         EC_T(2);
         // ---- fused pass over the registers: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r
@@ -372,6 +375,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
                                  : "=&v"(qp), "=&v"(qc) : "v"(&xp[i]), "v"(&xp[EG_MAXN + i]) : "memory");
                     ok = (qp.y == tag) && (qp.w == tag) && (qc.y == tag) && (qc.w == tag);
                 }
+#ifdef EC_NOPOLL
+                break;
+#endif
                 if (__all(ok)) break;
                 if (++spins > EC_SPIN_LIMIT) {             // never hang the device: poison the output instead
                     if (i < n) d[i] = __builtin_nan("");
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
         EC_T(5);
     }
 #ifdef EC_PROF
-    if (tid == 0 && g == 0) for (int j = 0; j < 6; ++j) ws.lamp[j] = (double)tacc[j];
+    if (tid == 0 && g == 0) for (int j = 0; j < 9; ++j) ws.lamp[j] = (double)tacc[j];
 #endif
 }
 
