@@ -2,7 +2,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from nele_gan_amd import model as M, ops
 torch.manual_seed(0)
-B, T = 32, 251
+B, T = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 251
 D = M.Discriminator(nout=2).cuda()
 D.precision = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 din = torch.rand(B, 64, T, 4, device='cuda', requires_grad=False)
