@@ -110,7 +110,8 @@ class SiibSplit:
         else:
             self.x, self.y, _ = _pair(x, y)
         B, L = self.x.shape
-        self.ws = _workspace('siib', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
+        # own workspace: the clean-signal state must survive until degraded_part(), whatever else calls batch_siib() meanwhile
+        self.ws = _workspace('siib_split', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
