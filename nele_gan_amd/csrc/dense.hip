@@ -1623,6 +1623,11 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     const int max_splits = (M + 511) / 512;
     int G = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
     if (G < splits) G = splits;
+    {   // experiment knob: fewer groups = fewer partials to reduce, but fewer workgroups to pull the memory system
+        static int genv = -1;
+        if (genv < 0) { const char* e = getenv("NELE_WGRAD_GROUPS"); genv = e ? atoi(e) : 0; }
+        if (genv > 0 && genv < G) G = genv;
+    }
     bool tiled = false;
     if (bf16 && wt_on && N <= 64 && p.g.C % 8 == 0 && KW * p.g.C == p.g.seglen && nkt <= 28 && p.g.Wout >= 32 && wt_lds <= 64 * 1024 &&
         M % (p.g.Hout * p.g.Wout) == 0) {
