@@ -398,6 +398,194 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ e1, cluster variant with 4 workgroups
+// Same algorithm as eigh_tridiag_cluster_kernel with FOUR workgroups per matrix (n <= 448): a spinning workgroup owns its CU, and
+// the step time is dominated by latencies that do not depend on the share of the matrix a workgroup holds, so halving the
+// workgroups per matrix halves the CU time of the whole tridiagonalisation and lets 32 matrices run in one launch on half of the
+// chip.  A thread holds 3 columns x 28 rows in registers; the 4th column slot of lanes 0..15 (112 = 3.5 x 32 column slots per
+// workgroup) lives in LDS.
+#define E4_P 4
+#define E4_RI 28
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws) {
+    __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
+    __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
+    __shared__ double accb[16][128];
+    __shared__ double aL[E4_RI][16][16];                   // 4th column slot of lanes 0..15: [ri][row slot][lane]
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = g >> 3, p = slot & 3, mloc = (g & 7) + 8 * (slot >> 2);
+    if (mloc >= Bc) return;
+    const int b = b0 + mloc;
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;
+
+    const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
+    const int c0 = p + E4_P * cl0, c1 = c0 + E4_P * 32, c2 = c0 + E4_P * 64, c3 = c0 + E4_P * 96;
+    const bool has3 = cl0 < 16;
+    double a0[E4_RI], a1[E4_RI], a2[E4_RI];
+#pragma unroll
+    for (int ri = 0; ri < E4_RI; ++ri) {
+        const int r = rs + 16 * ri;
+        a0[ri] = (r < n && c0 < n) ? A[(size_t)r * n + c0] : 0.0;
+        a1[ri] = (r < n && c1 < n) ? A[(size_t)r * n + c1] : 0.0;
+        a2[ri] = (r < n && c2 < n) ? A[(size_t)r * n + c2] : 0.0;
+        if (has3) aL[ri][rs][cl0] = (r < n && c3 < n) ? A[(size_t)r * n + c3] : 0.0;
+    }
+    const int i = tid;
+    const int pi = (i & 15) * 32 + (i >> 4);
+    double v_i = 0.0, tk = 0.0, p_i = 0.0;
+    double col_i = (i < n) ? A[i] : 0.0;
+    for (int s = -1; s <= n - 2; ++s) {
+        const bool in = (i >= s + 1) && (i < n);
+        double w_i = 0.0, wpiv = 0.0;
+        if (s >= 0) {
+            if (i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wv] = pv;
+            __syncthreads();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (i == s + 2) s_alpha = x_i;
+            double ss = (i >= s + 3 && i < n) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wv] = ss;
+            __syncthreads();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
+            }
+            vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
+        }
+        if (p == ((s + 1) & 3)) {
+            if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+            if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
+        }
+        if (s == n - 2) break;
+        vnat[i] = v_i; wnat[i] = w_i;
+        vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
+        __syncthreads();
+        // ---- fused pass: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r  (3 register columns + 1 LDS column)
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        if (c0 < n) {
+            const double vc0 = vnat[c0], wc0 = wnat[c0];
+            const double vc1 = (c1 < n) ? vnat[c1 & (EG_MAXN - 1)] : 0.0, wc1 = (c1 < n) ? wnat[c1 & (EG_MAXN - 1)] : 0.0;
+            const double vc2 = (c2 < n) ? vnat[c2 & (EG_MAXN - 1)] : 0.0, wc2 = (c2 < n) ? wnat[c2 & (EG_MAXN - 1)] : 0.0;
+            const bool l3 = has3 && c3 < n;
+            const double vc3 = l3 ? vnat[c3 & (EG_MAXN - 1)] : 0.0, wc3 = l3 ? wnat[c3 & (EG_MAXN - 1)] : 0.0;
+            const int ri0 = (s + 2 - rs + 15) >> 4;
+            const double2* pv0 = reinterpret_cast<const double2*>(&vperm[0][rs * 32]);
+            const double2* pv1 = reinterpret_cast<const double2*>(&vperm[1][rs * 32]);
+            const double2* pv2 = reinterpret_cast<const double2*>(&vperm[2][rs * 32]);
+#pragma unroll
+            for (int q = 0; q < E4_RI / 2; ++q) {
+                if (2 * q + 1 >= ri0) {                    // rows rs + 16 (2q), rs + 16 (2q + 1)
+                    const double2 vr = pv0[q], wr = pv1[q], nr = pv2[q];
+                    const int k0 = 2 * q;
+                    double x0 = a0[k0], x1 = a0[k0 + 1];
+                    x0 -= vr.x * wc0 + wr.x * vc0;
+                    x1 -= vr.y * wc0 + wr.y * vc0;
+                    a0[k0] = x0; a0[k0 + 1] = x1;
+                    acc0 += x0 * nr.x + x1 * nr.y;
+                    double y0 = a1[k0], y1 = a1[k0 + 1];
+                    y0 -= vr.x * wc1 + wr.x * vc1;
+                    y1 -= vr.y * wc1 + wr.y * vc1;
+                    a1[k0] = y0; a1[k0 + 1] = y1;
+                    acc1 += y0 * nr.x + y1 * nr.y;
+                    double z0 = a2[k0], z1 = a2[k0 + 1];
+                    z0 -= vr.x * wc2 + wr.x * vc2;
+                    z1 -= vr.y * wc2 + wr.y * vc2;
+                    a2[k0] = z0; a2[k0 + 1] = z1;
+                    acc2 += z0 * nr.x + z1 * nr.y;
+                    if (l3) {
+                        double u0 = aL[k0][rs][cl0], u1 = aL[k0 + 1][rs][cl0];
+                        u0 -= vr.x * wc3 + wr.x * vc3;
+                        u1 -= vr.y * wc3 + wr.y * vc3;
+                        aL[k0][rs][cl0] = u0; aL[k0 + 1][rs][cl0] = u1;
+                        acc3 += u0 * nr.x + u1 * nr.y;
+                    }
+                }
+            }
+        }
+        accb[rs][cl0] = acc0;
+        accb[rs][cl0 + 32] = acc1;
+        accb[rs][cl0 + 64] = acc2;
+        accb[rs][cl0 + 96] = acc3;
+        const unsigned tag = (unsigned)(s + 3);
+        u32x4* xp = xch + (size_t)((s + 1) & 1) * 2 * EG_MAXN;
+        if (rs == ((s + 2) & 15)) {                        // every workgroup publishes its part of pivot row s+2
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+            const int rq = (s + 2) >> 4;
+            switch (rq) {
+#define EC_CASE(k) case k: r0 = a0[k]; r1 = a1[k]; r2 = a2[k]; break;
+                EC_CASE(0) EC_CASE(1) EC_CASE(2) EC_CASE(3) EC_CASE(4) EC_CASE(5) EC_CASE(6) EC_CASE(7)
+                EC_CASE(8) EC_CASE(9) EC_CASE(10) EC_CASE(11) EC_CASE(12) EC_CASE(13) EC_CASE(14) EC_CASE(15)
+                EC_CASE(16) EC_CASE(17) EC_CASE(18) EC_CASE(19) EC_CASE(20) EC_CASE(21) EC_CASE(22) EC_CASE(23)
+                EC_CASE(24) EC_CASE(25) EC_CASE(26) EC_CASE(27)
+#undef EC_CASE
+            }
+            if (c0 >= s + 2 && c0 < n) st_tagged(&xp[EG_MAXN + c0], r0, tag);
+            if (c1 >= s + 2 && c1 < n) st_tagged(&xp[EG_MAXN + c1], r1, tag);
+            if (c2 >= s + 2 && c2 < n) st_tagged(&xp[EG_MAXN + c2], r2, tag);
+            if (has3 && c3 >= s + 2 && c3 < n) st_tagged(&xp[EG_MAXN + c3], aL[rq][rs][cl0], tag);
+        }
+        __syncthreads();
+        if (tid < 128) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += accb[q][tid];
+            const int cc = p + E4_P * tid;
+            if (tid < 112 && cc >= s + 2 && cc < n) st_tagged(&xp[cc], t, tag);
+        }
+        const bool need = (i >= s + 2) && (i < n);
+        if (__any(need)) {
+            u32x4 qp, qc;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (need) {
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(qp), "=&v"(qc) : "v"(&xp[i]), "v"(&xp[EG_MAXN + i]) : "memory");
+                    ok = (qp.y == tag) && (qp.w == tag) && (qc.y == tag) && (qc.w == tag);
+                }
+                if (__all(ok)) break;
+                if (++spins > EC_SPIN_LIMIT) {
+                    if (i < n) d[i] = __builtin_nan("");
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
+        }
+        v_i = vn_i;
+        tk = tn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ e2
 // grid (ceil(n / (256/NL)), B), block 256.  NL lanes -> one eigenvalue (j-th smallest) by (NL+1)-section on the Sturm count: every
 // round the NL lanes evaluate the count at NL interior points of the current interval, so ~17 rounds at NL = 8 (instead of 53
@@ -852,12 +1040,22 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
         // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
+        static int p4_on = -1;
+        if (p4_on < 0) { const char* e = getenv("NELE_EIGH_P4"); p4_on = !(e && e[0] == '0'); }
+        if (p4_on && n <= 16 * E4_RI && cluster_cap >= 32) {
+            // four workgroups per matrix: 64 matrices per launch would fill the chip; 32 use half of it
+            for (int b0 = 0; b0 < B; b0 += 64) {
+                const int Bc = (B - b0 < 64) ? B - b0 : 64;
+                hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
+            }
+        } else {
         static int split_small = -1;
         if (split_small < 0) { const char* e = getenv("NELE_EIGH_SPLIT"); split_small = !(e && e[0] == '0'); }
         const int per = (split_small && B <= 32 && cluster_cap >= 32) ? 16 : cluster_cap;
         for (int b0 = 0; b0 < B; b0 += per) {
             const int Bc = (B - b0 < per) ? B - b0 : per;
             hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
+        }
         }
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
