@@ -740,6 +740,145 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ Conv1d / Linear tile kernel, bf16
+// The generator's causal Conv1d layers (and any KH = 1 conv): M = B*T is small (8032 rows at B = 32), K = k*C is long (up to
+// 1792) and N up to 256, so the generic GEMM ran 504 tiny workgroups with a barrier every 32 k-values (46 us per layer).  Here a
+// workgroup owns 128 consecutive output positions x 64 output channels: the im2col rows of consecutive positions overlap
+// (row t is the contiguous run inp[t*C .. t*C + k*C)), so the tile's WHOLE A operand is the contiguous strip of 128 + k - 1 input
+// positions, staged once in LDS (bf16) and addressed Toeplitz-style; the weight fragments of the workgroup's 4 n-tiles stream
+// through LDS in chunks of SB k-steps as in conv_tile16_kernel.  grid (ceil(Wout/128), N/64 chunks, B*Hout).
+#define C1D_TW 128
+template <int TN>
+__global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 halo[];    // [RS] + 64 slack, then the weight chunk [SB][TN][64][8]
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int wo0 = blockIdx.x * C1D_TW, nb = blockIdx.y, bz = blockIdx.z;
+    const int b = bz / g.Hout, ho = bz - b * g.Hout;
+    const int wcols = C1D_TW + p.KW - 1;
+    const int RS = wcols * g.C;
+    const int wi0 = wo0 + g.iw0;
+    const int vcols = max(0, min(wcols, g.W - wi0));
+    const float* src = p.A + (((size_t)b * g.H + ho + g.ih0) * g.W + wi0) * g.C;
+    __bf16* wbuf = halo + RS + 64;
+    const int SB = p.SB, nchunk = p.steps_per_seg / SB;
+    const int cfrag = SB * TN * 64;
+    {   // stage the input strip (float32 -> bf16), zero beyond the input
+        const int nval = vcols * g.C;
+        for (int e = tid * 8; e < RS; e += 2048) {
+            bf16x8 v;
+            if (e < nval) {
+                const float4 a = *reinterpret_cast<const float4*>(src + e);
+                const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
+                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(halo + e) = v;
+        }
+        if (tid < 64) halo[RS + tid] = (__bf16)0.f;
+    }
+    // weight chunk c: steps [c SB, (c+1) SB) x this workgroup's TN n-tiles (stride NT tiles per step in the fragment stream)
+    constexpr int NBR = (TILE16_SBMAX * TN + 3) / 4;
+    bf16x8 breg[NBR];
+    const int nq = (cfrag + 255) >> 8;
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(p.Wfrag) + (size_t)nb * 4 * 64;
+    auto wload = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < NBR; ++q) {
+            if (q < nq) {
+                const int f = min(tid + 256 * q, cfrag - 1), u = f / (TN * 64), r = f - u * (TN * 64);
+                breg[q] = wsrc[((size_t)(c * SB + u) * p.NT) * 64 + r];
+            }
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NBR; ++q)
+            if (q < nq) reinterpret_cast<bf16x8*>(wbuf)[tid + 256 * q] = breg[q];
+    };
+    wload(0);
+    wstore();
+    // this wave's two position tiles: columns 16 (wave + 4 t)
+    int pb[2];
+    unsigned valid = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = wave + 4 * t;
+        pb[t] = (16 * c + li) * g.C + 8 * lg;
+        if (wo0 + 16 * c < g.Wout) valid |= 1u << t;
+    }
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf) + lane;
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) wload(c + 1);
+        const __bf16* hk = halo + c * SB * 32;
+        for (int u = 0; u < SB; ++u) {
+            bf16x8 bfr[TN], af[2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = wl[(u * TN + j) * 64];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hk + pb[i] + u * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (valid & (1u << i)) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (c + 1 < nchunk) {
+            __syncthreads();
+            wstore();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue through LDS (float4 stores along the channels)
+    __syncthreads();
+    float* ep = reinterpret_cast<float*>(halo) + wave * (16 * 68);
+    constexpr int NQ = TN * 4;
+    const int n0 = nb * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!(valid & (1u << i))) continue;
+        const int c = wave + 4 * i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ep[(4 * lg + reg) * 68 + 16 * j + li] = acc[i][j][reg];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+            const int idx = q * 64 + lane, pr = idx / NQ, cq = idx - pr * NQ;
+            const int wo = wo0 + 16 * c + pr, n = n0 + 4 * cq;
+            if (wo < g.Wout && n < p.N) {
+                float4 v = *reinterpret_cast<const float4*>(&ep[pr * 68 + 4 * cq]);
+                const size_t o_off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + n;
+                if (p.epi == EPI_BIAS || p.epi == EPI_BIAS_LRELU || p.epi == EPI_BIAS_EXPTANH) {
+                    v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3];
+                }
+                if (p.epi == EPI_BIAS_LRELU) {
+                    v.x = v.x > 0.f ? v.x : p.slope * v.x; v.y = v.y > 0.f ? v.y : p.slope * v.y;
+                    v.z = v.z > 0.f ? v.z : p.slope * v.z; v.w = v.w > 0.f ? v.w : p.slope * v.w;
+                } else if (p.epi == EPI_MASK_LRELU_GRAD) {
+                    const float4 x = *reinterpret_cast<const float4*>(p.aux + (((size_t)b * g.Hout + ho) * g.Wout + wo) * g.OC + n);
+                    v.x = x.x > 0.f ? v.x : p.slope * v.x; v.y = x.y > 0.f ? v.y : p.slope * v.y;
+                    v.z = x.z > 0.f ? v.z : p.slope * v.z; v.w = x.w > 0.f ? v.w : p.slope * v.w;
+                } else if (p.epi == EPI_BIAS_EXPTANH) {
+                    v.x = expf(3.2f * tanhf(v.x)); v.y = expf(3.2f * tanhf(v.y)); v.z = expf(3.2f * tanhf(v.z)); v.w = expf(3.2f * tanhf(v.w));
+                }
+                *reinterpret_cast<float4*>(p.out + o_off) = v;
+            }
+        }
+    }
+}
+
 // Wg [N][Ktot] f32 -> bf16 fragment-major [KH*sps][NT][64][8], sps = ceil(seglen/32); element (ks = kh*sps + s, j, lane, e) =
 // Wg[j*16 + (lane&15)][kh*seglen + s*32 + 8*(lane>>4) + e], zero where n >= N or the in-segment index >= seglen.
 __global__ void weight_frag16_kernel(const float* __restrict__ Wg, int N, int Ktot, int seglen, int KH, int NT, int sps,
@@ -1490,6 +1629,22 @@ static int tile16_sb(const ConvGeom& g) {
         if (sps % d == 0) SB = d;
     return SB;
 }
+// Conv1d / Linear tile kernel: steps per weight chunk and LDS bytes, or 0
+static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out) {
+    if (KH != 1 || N % 4 || g.OC % 4 || g.C % 8 || KW * g.C != g.seglen || g.seglen != g.Ktot || g.seglen % 32) return 0;
+    if (N > 64 && N % 64) return 0;
+    const long long RS = (long long)(C1D_TW + KW - 1) * g.C;
+    const int sps = g.seglen / 32, TNsel = (N >= 64) ? 4 : (N + 15) / 16;
+    for (int d = TILE16_SBMAX; d >= 1; --d) {
+        if (sps % d) continue;
+        const long long bytes = (RS + 64) * 2 + (((long long)d * TNsel * 1024 + 4095) & ~4095LL);
+        if (bytes <= 158 * 1024) {
+            if (lds_out) *lds_out = (size_t)(bytes < 4 * 16 * 68 * 4 ? 4 * 16 * 68 * 4 : bytes);
+            return d;
+        }
+    }
+    return 0;
+}
 static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
     if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
     if (tile16_lds(g, N, KH, KW, 4)) return 4;
@@ -1507,6 +1662,7 @@ extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int 
     ConvGeom g;
     memcpy(&g, geom, sizeof(ConvGeom));
     if (g.Wout >= 32 && tile16_th(g, N, KH, KW)) return 1;
+    if (g.Wout >= 32 && conv1d16_sb(g, N, KH, KW, nullptr)) return 1;
     return span16_supported(M, N, g, KH, KW);
 }
 extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
@@ -1525,6 +1681,33 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
     static int tile_on = -1;
     if (tile_on < 0) { const char* e = getenv("NELE_CONV_TILE"); tile_on = !(e && e[0] == '0'); }
     const int th = (tile_on && p.g.Wout >= 32) ? tile16_th(p.g, N, KH, KW) : 0;
+    {   // Conv1d / Linear geometry (KH = 1): strip kernel
+        size_t clds = 0;
+        const int csb = (tile_on && KH == 1 && p.g.Wout >= 32) ? conv1d16_sb(p.g, N, KH, KW, &clds) : 0;
+        if (csb) {
+            Tile16Args t;
+            t.A = A; t.Wfrag = p.Wfrag; t.bias = bias; t.aux = aux; t.out = out; t.N = N; t.NT = p.NT; t.epi = epi; t.slope = slope;
+            t.KH = KH; t.KW = KW; t.steps_per_seg = p.g.seglen / 32; t.g = p.g; t.SB = csb; t.dbg = nullptr;
+            const int BH = M / p.g.Wout;
+            static bool cattr = false;
+            if (!cattr) {
+#define C1D_ATTR(TN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_tile16_kernel<TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                C1D_ATTR(1); C1D_ATTR(2); C1D_ATTR(3); C1D_ATTR(4);
+#undef C1D_ATTR
+                cattr = true;
+            }
+            const int nchunksN = (N > 64) ? N / 64 : 1, TNsel = (N >= 64) ? 4 : p.NT;
+            const dim3 grid((p.g.Wout + C1D_TW - 1) / C1D_TW, nchunksN, BH);
+            switch (TNsel) {
+                case 1: hipLaunchKernelGGL((conv1d_tile16_kernel<1>), grid, dim3(256), clds, s, t); break;
+                case 2: hipLaunchKernelGGL((conv1d_tile16_kernel<2>), grid, dim3(256), clds, s, t); break;
+                case 3: hipLaunchKernelGGL((conv1d_tile16_kernel<3>), grid, dim3(256), clds, s, t); break;
+                default: hipLaunchKernelGGL((conv1d_tile16_kernel<4>), grid, dim3(256), clds, s, t); break;
+            }
+            NELE_CHECK_LAUNCH("nele_conv_span_bf16(conv1d)");
+            return NELE_OK;
+        }
+    }
     if (th) {
         Tile16Args t;
         t.A = A; t.Wfrag = p.Wfrag; t.bias = bias; t.aux = aux; t.out = out; t.N = N; t.NT = p.NT; t.epi = epi; t.slope = slope;

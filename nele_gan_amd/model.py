@@ -196,6 +196,7 @@ class Generator_Conv1D_cLN(nn.Module):
         self._anchor = _Anchor()
         self._bufs = {}
         self._wf = None
+        self._span_ok = {}
         self._last_mask = None
         self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the Conv1d / Linear GEMMs (fwd, dgrad, wgrad)
 
@@ -214,6 +215,11 @@ class Generator_Conv1D_cLN(nn.Module):
             wf.append(_zeros((64, 64), dev)); wb.append(_zeros((64, 64), dev))   # fc1
             wf.append(_zeros((64, 64), dev)); wb.append(_zeros((64, 64), dev))   # fc2
             self._wf = (wf, wb)
+            # bf16 fragment streams for the Conv1d / Linear tile kernel: (N, seglen) per layer, forward and data-gradient
+            dims = [(cout, k * cin, cin, k * cout) for (cin, cout, k) in _G_LAYERS] + [(64, 64, 64, 64), (64, 64, 64, 64)]
+            self._wf16 = ([torch.zeros(ops.frag16_elems(nf, sf, 1), dtype=torch.bfloat16, device=dev) for (nf, sf, nb_, sb_) in dims],
+                          [torch.zeros(ops.frag16_elems(nb_, sb_, 1), dtype=torch.bfloat16, device=dev) for (nf, sf, nb_, sb_) in dims])
+            self._wf16dims = dims
         return self._wf
 
     def _prep_weights(self, dev):
@@ -231,6 +237,18 @@ class Generator_Conv1D_cLN(nn.Module):
             self._prepjobs = (ck, (c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5)
         _, pja, dja, npj = self._prepjobs
         call('nele_weight_prep_batch', pja, dja, npj, stream())       # all 8 layers in one launch
+        if self.precision == 'bf16':
+            if getattr(self, '_fragjobs', None) is None or self._fragjobs[0] != ck:
+                fj, ej = [], []
+                for q, (nf, sf, nb_, sb_) in enumerate(self._wf16dims):
+                    fj += [wf[q].data_ptr(), self._wf16[0][q].data_ptr()]
+                    ej += [nf, sf, sf, 1]
+                for q, (nf, sf, nb_, sb_) in enumerate(self._wf16dims):
+                    fj += [wb[q].data_ptr(), self._wf16[1][q].data_ptr()]
+                    ej += [nb_, sb_, sb_, 1]
+                self._fragjobs = (ck, (c_void_p * len(fj))(*fj), (ctypes.c_int * len(ej))(*ej), len(ej) // 4)
+            _, fja, eja, nfj = self._fragjobs
+            call('nele_weight_prep_frag16_batch', fja, eja, nfj, stream())   # 16 fragment streams in one launch
         return wf, wb
 
     def _get_bufs(self, B, T, dev):
@@ -238,6 +256,19 @@ class Generator_Conv1D_cLN(nn.Module):
         if key not in self._bufs:
             self._bufs[key] = _GBuffers(B, T, dev)
         return key, self._bufs[key]
+
+    def _gemm(self, A, q, back, bias, aux, out, B, N, epi, g):
+        """Conv1d / Linear GEMM of layer q (forward or data-gradient weights): the strip tile kernel in bf16 mode where the
+        geometry fits it, the generic implicit GEMM otherwise."""
+        b16 = self.precision == 'bf16'
+        if b16:
+            sk = (q, back, B, g.Wout)
+            if sk not in self._span_ok:
+                self._span_ok[sk] = ops.span16_supported(B, N, g)
+            if self._span_ok[sk]:
+                ops.conv_span_bf16(A, self._wf16[1 if back else 0][q], bias, aux, out, B, N, epi, g)
+                return
+        ops.conv_gemm(A, (self._wf[1] if back else self._wf[0])[q], bias, aux, out, B, N, epi, g, bf16=b16)
 
     # ---- forward (model.py:83-98)
     def _forward_impl(self, x, y):
@@ -254,16 +285,16 @@ class Generator_Conv1D_cLN(nn.Module):
         call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
         for l, (cin, cout, k) in enumerate(_G_LAYERS):
             seq = self.convolutions[l]
-            ops.conv_gemm(bf.inp[l], wf[l], seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l], bf16=b16)
+            self._gemm(bf.inp[l], l, False, seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l])
             if l + 1 < len(_G_LAYERS):
                 nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
             else:
                 nxt, pad = bf.a5, 0
             call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
                  ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
-        ops.conv_gemm(bf.a5, wf[6], self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc, bf16=b16)
+        self._gemm(bf.a5, 6, False, self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
         mask = _empty((B, T, 64), dev)
-        ops.conv_gemm(bf.h1, wf[7], self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc, bf16=b16)
+        self._gemm(bf.h1, 7, False, self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
         self._last_mask = mask
         return key
 
@@ -282,10 +313,10 @@ class Generator_Conv1D_cLN(nn.Module):
         # fc2
         ops.conv_wgrad(bf.h1, bf.do2, bf.ws, B, 64, bf.gwfc, 64, self.fc2.weight.grad, self.fc2.bias.grad)
         b16 = self.precision == 'bf16'
-        ops.conv_gemm(bf.do2, wb[7], None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc, bf16=b16)
+        self._gemm(bf.do2, 7, True, None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc)
         # fc1
         ops.conv_wgrad(bf.a5, bf.dpre1, bf.ws, B, 64, bf.gwfc, 64, self.fc1.weight.grad, self.fc1.bias.grad)
-        ops.conv_gemm(bf.dpre1, wb[6], None, None, bf.da5, B, 64, EPI_NONE, bf.gfc, bf16=b16)
+        self._gemm(bf.dpre1, 6, True, None, None, bf.da5, B, 64, EPI_NONE, bf.gfc)
         dact = bf.da5
         for l in range(len(_G_LAYERS) - 1, -1, -1):
             cin, cout, k = _G_LAYERS[l]
@@ -295,7 +326,7 @@ class Generator_Conv1D_cLN(nn.Module):
             call('nele_colsum2', ptr(bf.gpart), ptr(seq[2].gain0.grad), ptr(bf.bpart), ptr(seq[2].bias0.grad), B * bf.nchunks, cout, 1, stream())
             ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=(self.precision == 'bf16'))
             if l > 0:
-                ops.conv_gemm(bf.dY[l], wb[l], None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l], bf16=b16)
+                self._gemm(bf.dY[l], l, True, None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
                 dact = bf.dA[l]
 
 
