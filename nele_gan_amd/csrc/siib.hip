@@ -40,6 +40,7 @@ struct SiibWs {
     char* eigws;     // eigensolver workspace
     double* lam;     // [B][420]
     double* part;    // [B][420][NTL][3]
+    double* px;      // [B][7][NTL][16][256] projections of the clean signal in accumulator order (split mode: phase 3 -> phase 4)
     int NT, NA, NTL;
 };
 
@@ -495,6 +496,10 @@ __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
 // s8: P = U X for both signals (U rows = eigenvectors, [420][420]; X [420][NA]); per 64x64 tile of P emit the row-wise partial
 // sums of Xp^2, Yp^2, Xp*Yp.  grid (NTL, 7, B).  Waves 4x1: a wave owns 16 eigenvectors x 64 frames of both signals, so the row
 // sums stay inside the wave (in-lane over the 4 column tiles, then a DPP reduction over the 16 lanes of a row).
+// MODE 0: both signals (one-shot call).  MODE 1: clean signal only - its projections are kept (ws.px, accumulator order) together
+// with the sum of squares; MODE 2: degraded signal only, the clean projections are read back.  1 + 2 perform exactly the MFMA
+// sequences of 0, so the split is bit-identical; it takes half of the projection off the path that waits for the enhanced signal.
+template <int MODE>
 __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     __shared__ __attribute__((aligned(32))) double Us[2][16][SG_LD], Xt[2][16][SG_LD], Yt[2][16][SG_LD];
     const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -502,7 +507,8 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     if (t0 >= ws.info[4 * b + 2] - SB_K + 1) {      // tile beyond n_cols: all zero padding
         if (tid < 192) {
             const int q = tid / 64, r = tid - q * 64;
-            if (ti + r < SB_D) ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = 0.0;
+            const bool mine = (MODE == 0) || (MODE == 1 && q == 0) || (MODE == 2 && q != 0);
+            if (mine && ti + r < SB_D) ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = 0.0;
         }
         return;
     }
@@ -521,16 +527,16 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     auto gload = [&](int k0, double4& ru, double4& rx, double4& ry) {
         ru = (k0 + uq < SB_D) ? *reinterpret_cast<const double4*>(pu + k0) : z4;          // 420 = 4 * 105: quads are all-in or all-out
         const bool kin = k0 + xc < SB_D;
-        rx = kin ? *reinterpret_cast<const double4*>(px + (size_t)k0 * ws.NA) : z4;
-        ry = kin ? *reinterpret_cast<const double4*>(py + (size_t)k0 * ws.NA) : z4;
+        rx = (kin && MODE != 2) ? *reinterpret_cast<const double4*>(px + (size_t)k0 * ws.NA) : z4;
+        ry = (kin && MODE != 1) ? *reinterpret_cast<const double4*>(py + (size_t)k0 * ws.NA) : z4;
     };
     double4 ru, rx, ry;
     gload(0, ru, rx, ry);
     for (int k0 = 0, it = 0; k0 < SB_D; k0 += 16, ++it) {
         const int buf = it & 1;
         Us[buf][uq][ur] = ru.x; Us[buf][uq + 1][ur] = ru.y; Us[buf][uq + 2][ur] = ru.z; Us[buf][uq + 3][ur] = ru.w;
-        *reinterpret_cast<double4*>(&Xt[buf][xc][xq]) = rx;
-        *reinterpret_cast<double4*>(&Yt[buf][xc][xq]) = ry;
+        if (MODE != 2) *reinterpret_cast<double4*>(&Xt[buf][xc][xq]) = rx;
+        if (MODE != 1) *reinterpret_cast<double4*>(&Yt[buf][xc][xq]) = ry;
         __syncthreads();
         if (k0 + 16 < SB_D) gload(k0 + 16, ru, rx, ry);
 #pragma unroll
@@ -539,10 +545,22 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
             const double a = Us[buf][k][16 * w + li];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ax[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[buf][k][16 * j + li], ax[j], 0, 0, 0);
-                ay[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yt[buf][k][16 * j + li], ay[j], 0, 0, 0);
+                if (MODE != 2) ax[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[buf][k][16 * j + li], ax[j], 0, 0, 0);
+                if (MODE != 1) ay[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yt[buf][k][16 * j + li], ay[j], 0, 0, 0);
             }
         }
+    }
+    double* pxs = ws.px + ((((size_t)b * 7 + blockIdx.y) * ws.NTL + blockIdx.x) * 16) * 256 + tid;
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pxs[(4 * j + q) * 256] = ax[j][q];
+    } else if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ax[j][q] = pxs[(4 * j + q) * 256];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -553,7 +571,8 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
         const int gi = ti + 16 * w + lk + 4 * q;
         if (li == 0 && gi < SB_D) {
             double* dst = ws.part + (((size_t)b * SB_D + gi) * ws.NTL + blockIdx.x) * 3;
-            dst[0] = sxx; dst[1] = syy; dst[2] = sxy;
+            if (MODE != 2) dst[0] = sxx;
+            if (MODE != 1) { dst[1] = syy; dst[2] = sxy; }
         }
     }
 }
@@ -619,6 +638,7 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(U, double, (size_t)B * SB_D * SB_D);
     TAKE(eigws, char, (size_t)nele_eigh_workspace_bytes(B, SB_D));
     TAKE(part, double, (size_t)B * SB_D * NTL * 3);
+    TAKE(px, double, (size_t)B * 7 * NTL * 16 * 256);
 #undef TAKE
     if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; }
     return o;
@@ -667,9 +687,14 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     if (eig) {
         int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
         if (st) return st;
+        if (phase == 3) {                                   // clean-signal half of the projections, beside whatever the caller overlaps
+            hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+            NELE_CHECK_LAUNCH("nele_metric_siib(clean projections)");
+        }
     }
     if (fin) {
-        hipLaunchKernelGGL(siib_proj_kernel, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+        if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+        else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
         hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
         NELE_CHECK_LAUNCH("nele_metric_siib(back)");
