@@ -244,9 +244,16 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
             s.tmp[k] = r * r;
         }
         __syncthreads();
-        if (band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = pow_f32(band_energy(s.tmp, k), power);
+        // the band energy goes out raw: the float64 pow (a few hundred instructions on the wave that paces the serial loop) is applied by
+        // band_pow_kernel over all frames at once
+        if (band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = band_energy(s.tmp, k);
         // next iteration's first barrier orders these reads of s.tmp / s.a against its writes
     }
+}
+
+// band[i] = band[i] ** power in place (the tail of imcra_band_kernel, parallel over frames)
+__global__ void band_pow_kernel(float* __restrict__ band, size_t n, float power) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) band[i] = pow_f32(band[i], power);
 }
 
 // ------------------------------------------------------------------------------------------ iSTFT
@@ -345,6 +352,10 @@ extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, floa
     NELE_CHECK_ARG(psd || band, "nele_imcra_band: no output requested");
     hipLaunchKernelGGL(imcra_band_kernel, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power,
                        psd, band);
+    if (band) {
+        const size_t nb = (size_t)B * T * NELE_NBANDS;
+        hipLaunchKernelGGL(band_pow_kernel, dim3((unsigned)((nb + 255) / 256 < 2048 ? (nb + 255) / 256 : 2048)), dim3(256), 0, as_stream(stream), band, nb, power);
+    }
     NELE_CHECK_LAUNCH("nele_imcra_band");
     return NELE_OK;
 }
