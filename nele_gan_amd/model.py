@@ -426,6 +426,8 @@ class _DiscriminatorBase(nn.Module):
         self._bufs = {}
         self._w = None
         self._last_score = None
+        self._wstream = None
+        self.overlap_wgrad = True          # weight gradients on a second stream beside the data-gradient chain
         self.profile_prefix = ''           # prepended to the ops.PROFILE tags of this module's launches (bench.py)
         self.weight_grad_enabled = True   # reference computes (unused) D weight grads in the G-step too
         self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the conv forward / data-gradient passes
@@ -578,6 +580,15 @@ class _DiscriminatorBase(nn.Module):
                      c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
         ddin = None
+        # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
+        # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on a second stream
+        # beside the chain and join at the end.  In the D-step this tail is fully exposed (nothing else is left to overlap).
+        main = torch.cuda.current_stream()
+        wst = None
+        if wgrad and self.overlap_wgrad:
+            if self._wstream is None:
+                self._wstream = torch.cuda.Stream(device=dscore.device)
+            wst = self._wstream
         for l in range(len(_D_CONVS) - 1, -1, -1):
             cout, k = _D_CONVS[l]
             m = self.layers[l]
@@ -587,10 +598,18 @@ class _DiscriminatorBase(nn.Module):
             if wgrad:
                 N, K = cout, cin_valid * k * k
                 tmpb = bf.tmpw[N * K:N * K + N]
+                if wst is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)                      # gbuf[l] is complete at this point of the current stream
+                    ctx = torch.cuda.stream(wst)
+                    ctx.__enter__()
+                    wst.wait_event(ev)
                 ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0))
                 call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
                 m.bias.grad.add_(tmpb)
+                if wst is not None:
+                    ctx.__exit__(None, None, None)
             if l > 0:
                 if self.precision == 'bf16' and bf.span16_b[l]:
                     ops.conv_span_bf16(bf.gbuf[l], w['wbf16'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
@@ -601,6 +620,10 @@ class _DiscriminatorBase(nn.Module):
             elif need_din:
                 ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
                 ddin = bf.ddin
+        if wst is not None:
+            done = torch.cuda.Event()
+            done.record(wst)
+            main.wait_event(done)
         return ddin
 
 
