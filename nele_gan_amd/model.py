@@ -197,6 +197,8 @@ class Generator_Conv1D_cLN(nn.Module):
         self._bufs = {}
         self._wf = None
         self._span_ok = {}
+        self._wstream = None
+        self.overlap_wgrad = True          # weight gradients on a second stream beside the data-gradient chain
         self._last_mask = None
         self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the Conv1d / Linear GEMMs (fwd, dgrad, wgrad)
 
@@ -308,14 +310,33 @@ class Generator_Conv1D_cLN(nn.Module):
     def _backward_impl(self, dmask, key, mask):
         bf = self._bufs[key]
         B, T = bf.B, bf.T
-        wf, wb = self._wf
+        # data-gradient chain on the current stream, weight gradients on a second stream beside it (see _DiscriminatorBase)
+        main = torch.cuda.current_stream()
+        wst = None
+        if self.overlap_wgrad:
+            if self._wstream is None:
+                self._wstream = torch.cuda.Stream(device=dmask.device)
+            wst = self._wstream
+        b16w = self.precision == 'bf16'
+
+        def wgrad(A, dOut, N, g, Cvalid, dW, db, bf16=False):
+            if wst is None:
+                ops.conv_wgrad(A, dOut, bf.ws, B, N, g, Cvalid, dW, db, bf16=bf16)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ctx = torch.cuda.stream(wst)
+            ctx.__enter__()
+            wst.wait_event(ev)
+            ops.conv_wgrad(A, dOut, bf.ws, B, N, g, Cvalid, dW, db, bf16=bf16)
+            ctx.__exit__(None, None, None)
+
         call('nele_exptanh_bwd', ptr(dmask), ptr(mask), ptr(bf.do2), dmask.numel(), stream())
         # fc2
-        ops.conv_wgrad(bf.h1, bf.do2, bf.ws, B, 64, bf.gwfc, 64, self.fc2.weight.grad, self.fc2.bias.grad)
-        b16 = self.precision == 'bf16'
+        wgrad(bf.h1, bf.do2, 64, bf.gwfc, 64, self.fc2.weight.grad, self.fc2.bias.grad)
         self._gemm(bf.do2, 7, True, None, bf.h1, bf.dpre1, B, 64, EPI_MASK_LRELU_GRAD, bf.gfc)
         # fc1
-        ops.conv_wgrad(bf.a5, bf.dpre1, bf.ws, B, 64, bf.gwfc, 64, self.fc1.weight.grad, self.fc1.bias.grad)
+        wgrad(bf.a5, bf.dpre1, 64, bf.gwfc, 64, self.fc1.weight.grad, self.fc1.bias.grad)
         self._gemm(bf.dpre1, 6, True, None, None, bf.da5, B, 64, EPI_NONE, bf.gfc)
         dact = bf.da5
         for l in range(len(_G_LAYERS) - 1, -1, -1):
@@ -324,10 +345,14 @@ class Generator_Conv1D_cLN(nn.Module):
             call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
                  ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
             call('nele_colsum2', ptr(bf.gpart), ptr(seq[2].gain0.grad), ptr(bf.bpart), ptr(seq[2].bias0.grad), B * bf.nchunks, cout, 1, stream())
-            ops.conv_wgrad(bf.inp[l], bf.dY[l], bf.ws, B, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=(self.precision == 'bf16'))
+            wgrad(bf.inp[l], bf.dY[l], cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=b16w)
             if l > 0:
                 self._gemm(bf.dY[l], l, True, None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
                 dact = bf.dA[l]
+        if wst is not None:
+            done = torch.cuda.Event()
+            done.record(wst)
+            main.wait_event(done)
 
 
 # ================================================================== Discriminators
