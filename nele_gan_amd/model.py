@@ -403,6 +403,10 @@ class _DBuffers:
         self.ws = _empty((nws,), dev)
         self.tmpw = _empty((64 * 48 * 81 + 64,), dev)
         self.scratch64 = torch.empty((max(B * 32 * 64, 128),), dtype=torch.float64, device=dev)   # largest weight tensor (sigma-normalised gradient staging)
+        # second set of weight-gradient temporaries: the backward pass runs the layers' weight gradients on two streams
+        self.ws2 = _empty((nws,), dev)
+        self.tmpw2 = _empty((64 * 48 * 81 + 64,), dev)
+        self.scratch64b = torch.empty((max(B * 32 * 64, 128),), dtype=torch.float64, device=dev)
 
 
 class _DFn(torch.autograd.Function):
@@ -609,11 +613,15 @@ class _DiscriminatorBase(nn.Module):
         # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on a second stream
         # beside the chain and join at the end.  In the D-step this tail is fully exposed (nothing else is left to overlap).
         main = torch.cuda.current_stream()
-        wst = None
+        wsts = None
         if wgrad and self.overlap_wgrad:
             if self._wstream is None:
-                self._wstream = torch.cuda.Stream(device=dscore.device)
-            wst = self._wstream
+                self._wstream = (torch.cuda.Stream(device=dscore.device), torch.cuda.Stream(device=dscore.device))
+            wsts = self._wstream
+            ev0 = torch.cuda.Event()
+            ev0.record(main)                             # both streams start after the MLP part above (shared temporaries)
+            for q in wsts:
+                q.wait_event(ev0)
         for l in range(len(_D_CONVS) - 1, -1, -1):
             cout, k = _D_CONVS[l]
             m = self.layers[l]
@@ -622,16 +630,19 @@ class _DiscriminatorBase(nn.Module):
             a_in = bf.din if l == 0 else bf.act[l - 1]
             if wgrad:
                 N, K = cout, cin_valid * k * k
-                tmpb = bf.tmpw[N * K:N * K + N]
+                # two streams alternate over the layers, each with its own temporaries
+                tw, wsb, sc = (bf.tmpw, bf.ws, bf.scratch64) if (l & 1) == 0 else (bf.tmpw2, bf.ws2, bf.scratch64b)
+                tmpb = tw[N * K:N * K + N]
+                wst = wsts[l & 1] if wsts is not None else None
                 if wst is not None:
                     ev = torch.cuda.Event()
                     ev.record(main)                      # gbuf[l] is complete at this point of the current stream
                     ctx = torch.cuda.stream(wst)
                     ctx.__enter__()
                     wst.wait_event(ev)
-                ops.conv_wgrad(a_in, bf.gbuf[l], bf.ws, B, cout, bf.gw[l], cin_valid, bf.tmpw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0))
-                call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
-                     c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
+                ops.conv_wgrad(a_in, bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0))
+                call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
+                     c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
                 m.bias.grad.add_(tmpb)
                 if wst is not None:
                     ctx.__exit__(None, None, None)
@@ -645,10 +656,11 @@ class _DiscriminatorBase(nn.Module):
             elif need_din:
                 ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
                 ddin = bf.ddin
-        if wst is not None:
-            done = torch.cuda.Event()
-            done.record(wst)
-            main.wait_event(done)
+        if wsts is not None:
+            for q in wsts:
+                done = torch.cuda.Event()
+                done.record(q)
+                main.wait_event(done)
         return ddin
 
 
