@@ -455,6 +455,7 @@ class _DiscriminatorBase(nn.Module):
         self._bufs = {}
         self._w = None
         self._last_score = None
+        self._prepared = None
         self._wstream = None
         self.overlap_wgrad = True          # weight gradients on a second stream beside the data-gradient chain
         self.profile_prefix = ''           # prepended to the ops.PROFILE tags of this module's launches (bench.py)
@@ -498,15 +499,20 @@ class _DiscriminatorBase(nn.Module):
             arr[3 * i + 2] = w['sigma'].data_ptr() + 4 * (5 + i)
         return arr
 
-    def _forward_impl(self, din):
-        if not din.is_cuda:
-            raise RuntimeError("nele_gan_amd: the discriminator runs on the GPU only (no CPU fallback)")
-        dev = din.device
+    def prepare(self, B, T, dev):
+        """Spectral-norm power iteration + sigma (model.py:105-116) and every weight layout of a forward / backward pass at batch B,
+        frames T, enqueued on the CURRENT stream.  The next forward of that shape waits for it instead of doing it inline:
+        this work only depends on the parameters, so a training loop can run it on another stream ahead of the forward pass
+        (GanTrainer does, beside the generator's forward pass and beside generate)."""
         self._flat.ensure(dev)
-        B, H, T, C4 = din.shape
-        assert H == 64 and C4 == 4
         key, bf = self._get_bufs(B, T, dev)
         w = self._weights(dev)
+        self._prepare_inline(key, bf, w)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._prepared = (key, self.training, ev)
+
+    def _prepare_inline(self, key, bf, w):
         n_iter = 1 if self.training else 0
         # spectral norm: power iteration (train mode) + sigma for all 8 layers in one launch (model.py:105-116)
         mods = self._sn_modules()
@@ -559,6 +565,21 @@ class _DiscriminatorBase(nn.Module):
                 if bf.span_b[l]:
                     ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
                 cin = cpad = cout
+
+    def _forward_impl(self, din):
+        if not din.is_cuda:
+            raise RuntimeError("nele_gan_amd: the discriminator runs on the GPU only (no CPU fallback)")
+        dev = din.device
+        self._flat.ensure(dev)
+        B, H, T, C4 = din.shape
+        assert H == 64 and C4 == 4
+        key, bf = self._get_bufs(B, T, dev)
+        w = self._weights(dev)
+        prep, self._prepared = self._prepared, None
+        if prep is not None and prep[0] == key and prep[1] == self.training:
+            torch.cuda.current_stream().wait_event(prep[2])
+        else:
+            self._prepare_inline(key, bf, w)
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):

@@ -175,8 +175,21 @@ class GanTrainer:
             if 'siib' in self.metrics:
                 split = mt.SiibSplit(x)
                 split.clean_part()
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream(device=self.device)
+        B_, T_ = clean_wav.shape[0], 1 + clean_wav.shape[1] // 256
+        # D's spectral-norm iteration and weight layouts depend on its parameters only: they run on a side stream ahead of each of D's two
+        # forward passes (beside the generator's forward pass / beside generate) instead of at the head of those passes
+        with torch.cuda.stream(self._side2):
+            self._side2.wait_event(start)                  # after the previous step's D update
+            self.D.prepare(B_, T_, self.device)
         f = feats or self.features(clean_wav, noise_wav)
         lg = self.g_step(f['clean_band'], f['noise_band'])
+        gdone = torch.cuda.Event()
+        gdone.record(main)                                 # the G-step's backward pass is the last reader of D's current weight layouts
+        with torch.cuda.stream(self._side2):
+            self._side2.wait_event(gdone)
+            self.D.prepare(B_, T_, self.device)
         enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
         assert enh.shape[1] == L
         ready = torch.cuda.Event()
