@@ -33,6 +33,7 @@ struct SiibWs {
     double* xdb;     // [B][NT]   frame power (dB) of the tiled clean signal
     int* list;       // [B][NA]   active frame indices (tiled frame numbering)
     int* info;       // [B][4]    {M, n_tiled_frames, n_active, status}
+    int* nprim;      // [B]       active frames inside the first frame period of the tiled signal (their spectra are computed, the rest copied)
     double* XL;      // [B][2][28][NA] log band energies of the active frames (x then y)
     double* Xs;      // [B][2][420][NA] stacked, mean-removed (zero padded to NA columns)
     double* C;       // [B][420][420] covariance (destroyed by the eigensolver)
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void siib_m_kernel(int L, SiibWs ws) {
 }
 
 // s2b: VAD on the tiled signal + ordered compaction of the active frames. grid B, block 256
-__global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
+__global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws, int Pf) {
     __shared__ double red[8];
     __shared__ int scan[256];
     __shared__ int base;
@@ -173,9 +174,11 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
     const double thr = kth_largest(xdb, n2, n2 - 1 - ind, red, nullptr) - 40.0;
     if (tid == 0) base = 0;
     __syncthreads();
+    int cprim = 0;
     for (int f0 = 0; f0 < n2; f0 += 256) {
         const int f = f0 + tid;
         const int k = (f < n2 && xdb[f] > thr) ? 1 : 0;
+        cprim += (k && f < Pf) ? 1 : 0;
         scan[tid] = k;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -190,11 +193,13 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws) {
         if (tid == 255) base += scan[255];
         __syncthreads();
     }
+    const int nprim = (int)block_sum((double)cprim, red);
     if (tid == 0) {
         int na = base;
         if (na > ws.NA) { na = ws.NA; status |= 4; }
         if (na < SB_K + 1) status |= 8;  // not enough active frames
         info[2] = na; info[3] = status;
+        ws.nprim[b] = min(nprim, na);
     }
 }
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
     __shared__ double2 Aq[SP_F][SB_WLEN];             // stage-1 output [n2][k1]
     const int b = blockIdx.y, k0 = blockIdx.x * SP_F, tid = threadIdx.x;
     const int* info = ws.info + 4 * b;
-    const int na = info[2];
+    const int na = ws.nprim[b];                        // frames of the first period only: siib_spread_kernel copies the repeats
     if (k0 >= na) return;
     const long long total = (long long)info[0] * L;
     const int fs = tid / 20, lane20 = tid - fs * 20;   // frame slot, n2 (stage 1) / k1 (stage 2)
@@ -325,6 +330,31 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
                 }
             }
         }
+    }
+}
+
+// s3b: the tiled signal repeats every Pf = L / gcd(L, 200) frames (frame f starts at sample 200 f mod L; every frame lies wholly inside
+// the tiled signal), so the band energies of an active frame f >= Pf are those of frame f mod Pf, which is active too (same samples,
+// same arithmetic, same dB value).  One thread per active frame beyond the first period: binary search of f mod Pf in the sorted list
+// of first-period frames, then copy the 28 band values of each signal.  grid (ceil(NA / 256), B), block 256
+__global__ __launch_bounds__(256) void siib_spread_kernel(SiibWs ws, int Pf, int sig0, int sig1) {
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    int* info = ws.info + 4 * b;
+    const int na = info[2], np_ = ws.nprim[b];
+    if (a < np_ || a >= na) return;
+    const int* list = ws.list + (size_t)b * ws.NA;
+    const int fr = list[a] % Pf;
+    int lo = 0, hi = np_ - 1, src = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1, v = list[mid];
+        if (v == fr) { src = mid; break; }
+        if (v < fr) lo = mid + 1; else hi = mid - 1;
+    }
+    if (src < 0) { atomicOr(&info[3], 16); return; }   // cannot happen (see above); the score becomes NaN if it does
+    for (int sig = sig0; sig <= sig1; ++sig) {
+        double* row = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
+#pragma unroll 4
+        for (int j = 0; j < SB_J; ++j) row[(size_t)j * ws.NA + a] = row[(size_t)j * ws.NA + src];
     }
 }
 
@@ -597,7 +627,7 @@ __global__ __launch_bounds__(512) void siib_final_kernel(SiibWs ws, float* __res
     const double tot = block_sum(I, red);
     if (j == 0) {
         double v = fmax(0.0, 80.0 / 15.0 * tot);
-        if (info[3] & 8) v = nan("");  // reference raises: not enough active frames
+        if (info[3] & (8 | 16)) v = nan("");  // reference raises: not enough active frames (16: internal inconsistency)
         if (raw) raw[b] = (float)v;
         if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.06 * (v - 32.0))));
     }
@@ -631,6 +661,7 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(xdb, double, (size_t)B * NT);
     TAKE(list, int, (size_t)B * NA);
     TAKE(info, int, (size_t)B * 4);
+    TAKE(nprim, int, (size_t)B);
     TAKE(XL, double, (size_t)B * 2 * SB_J * NA);
     TAKE(Xs, double, (size_t)B * 2 * SB_D * NA);
     TAKE(C, double, (size_t)B * SB_D * SB_D);
@@ -664,6 +695,9 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     const size_t used = siib_layout(B, L, &ws, (char*)workspace);
     (void)used;
     hipStream_t s = as_stream(stream);
+    int g = L, r = SB_SHIFT;
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int Pf = L / g;                                    // frame period of the tiled signal
     const bool vad = (phase == 0 || phase == 1 || phase == 3);
     const bool sx = vad, sy = (phase == 0 || phase == 1 || phase == 4);
     const bool eig = (phase == 0 || phase == 2 || phase == 3);
@@ -673,11 +707,12 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
         hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
-        hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws, Pf);
     }
     if (sx || sy) {
         const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
         hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
+        hipLaunchKernelGGL(siib_spread_kernel, dim3((ws.NA + 255) / 256, B), dim3(256), 0, s, ws, Pf, sig0, sig1);
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);

@@ -70,7 +70,7 @@ def test_siib_toy_file_vs_oracle(mt):
     assert raw[2] == pytest.approx(80 / 15 * 420 * (-0.5 * np.log2(1 - 0.5625)), rel=1e-5)
 
 
-@pytest.mark.parametrize('L', [64000, 47777])
+@pytest.mark.parametrize('L', [64000, 47777, 48200])
 def test_siib_synthetic_batch_vs_oracle(mt, L):
     from nele_gan_amd import synth
     from oracle import siib
