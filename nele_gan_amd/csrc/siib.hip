@@ -14,6 +14,7 @@
 //   s8  Xp = U^T Xs, Yp = U^T Ys fused with the per-component sums of Xp^2, Yp^2, Xp Yp
 //   s9  rho, I = -1/2 log2(1 - rho_p^2 rho^2), SIIB = R/K sum I, logistic map
 #include "common.h"
+#include <cstdlib>
 
 #define SB_WLEN 400
 #define SB_SHIFT 200
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void siib_spread_kernel(SiibWs ws, int Pf, int
         if (v == fr) { src = mid; break; }
         if (v < fr) lo = mid + 1; else hi = mid - 1;
     }
-    if (src < 0) { atomicOr(&info[3], 16); return; }   // cannot happen (see above); the score becomes NaN if it does
+    if (src != a % np_) { atomicOr(&info[3], 16); return; }   // cannot happen (see above); the score becomes NaN if it does
     for (int sig = sig0; sig <= sig1; ++sig) {
         double* row = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
 #pragma unroll 4
@@ -386,6 +387,11 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
     const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
     if (na < 1) return;
+    // Periodic input (siib_spread_kernel: XL[a] = XL[a mod npr] when npr < na).  The recurrence's whole state is pend[]; when the
+    // state at a period boundary equals the state one period earlier, every later period repeats the last one bit for bit, so the
+    // serial recurrence stops there and the rest is a copy (the row sum still accumulates in frame order).
+    const int npr = ws.nprim[b];
+    const bool periodic = npr < na && npr >= SB_CH;
     double* base = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
     double* rstat = ws.rowstat + ((size_t)b * 2 + sig) * SB_J * 2;
     const double eX = (tid < SB_J) ? rstat[2 * tid] : 0.0;
@@ -393,14 +399,17 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
 #pragma unroll
     for (int m = 0; m < SB_TF; ++m) lt[m] = log((double)(m + 1)) / log((double)SB_TF);
     // pend[m] = masking level already imposed on frame (i + 1 + m) by frames <= i
-    double pend[SB_TF - 1];
+    double pend[SB_TF - 1], snap[SB_TF - 1];
 #pragma unroll
-    for (int m = 0; m < SB_TF - 1; ++m) pend[m] = -1e300;
+    for (int m = 0; m < SB_TF - 1; ++m) { pend[m] = -1e300; snap[m] = 0.0; }
+    int nextb = periodic ? npr : 0x7fffffff;   // next period boundary (frame index)
+    int steady = 0, bsteady = 0;               // this row's state repeated at boundary bsteady
     double sum = 0.0;
     double t[SB_J];
 #pragma unroll
     for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + min(tid, ws.NA - 1)];
-    for (int c0 = 0; c0 < na; c0 += SB_CH) {
+    int c0 = 0;
+    for (; c0 < na; c0 += SB_CH) {
         const int n = min(SB_CH, na - c0);
         __syncthreads();
 #pragma unroll
@@ -415,6 +424,26 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
                 double xs[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) xs[u] = buf[tid][min(i0 + u, SB_CH - 1)];
+                if (c0 + i0 + 8 > nextb) {     // a period boundary inside these 8 frames: handle it frame by frame
+                    for (int u = 0; u < 8; ++u) {
+                        if (i0 + u < n) {
+                            if (c0 + i0 + u == nextb) {
+                                int eq = 1;
+#pragma unroll
+                                for (int m = 0; m < SB_TF - 1; ++m) { eq &= (pend[m] == snap[m]) ? 1 : 0; snap[m] = pend[m]; }
+                                if (eq && nextb > npr && !steady) { steady = 1; bsteady = nextb; }
+                                nextb += npr;
+                            }
+                            const double v = max_f64(xs[u], pend[0]);
+#pragma unroll
+                            for (int m = 1; m < SB_TF - 1; ++m) pend[m - 1] = max_f64(pend[m], v - (v - eX) * lt[m]);
+                            pend[SB_TF - 2] = v - (v - eX) * lt[SB_TF - 1];
+                            buf[tid][i0 + u] = v;
+                            sum += v;
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (i0 + u < n) {
@@ -432,6 +461,34 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
 #pragma unroll 4
         for (int r = 0; r < SB_J; ++r)
             if (tid < n) base[(size_t)r * ws.NA + c0 + tid] = buf[r][tid];
+        if (periodic && __all(tid >= SB_J || steady)) { c0 += SB_CH; break; }
+    }
+    if (c0 < na) {
+        // every row repeats with period npr from its boundary on; the latest boundary bq <= c0 serves all rows: frame i >= bq equals
+        // frame bq - npr + (i - bq) mod npr, all of which are final in memory (written before the last barrier)
+        int bq = bsteady;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bq = max(bq, __shfl_xor(bq, o, 64));
+        __syncthreads();
+        auto src = [&](int i) { return bq - npr + (i - bq) % npr; };
+#pragma unroll
+        for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + src(min(c0 + tid, na - 1))];
+        for (; c0 < na; c0 += SB_CH) {
+            const int n = min(SB_CH, na - c0);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SB_J; ++r) {
+                buf[r][tid] = t[r];
+                if (tid < n) base[(size_t)r * ws.NA + c0 + tid] = t[r];
+            }
+            __syncthreads();
+            if (c0 + SB_CH < na) {
+#pragma unroll
+                for (int r = 0; r < SB_J; ++r) t[r] = base[(size_t)r * ws.NA + src(min(c0 + SB_CH + tid, na - 1))];
+            }
+            if (tid < SB_J)
+                for (int i = 0; i < n; ++i) sum += buf[tid][i];
+        }
     }
     if (tid < SB_J) rstat[2 * tid + 1] = sum / (double)na;
 }
@@ -697,7 +754,8 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     hipStream_t s = as_stream(stream);
     int g = L, r = SB_SHIFT;
     while (r) { const int t = g % r; g = r; r = t; }
-    const int Pf = L / g;                                    // frame period of the tiled signal
+    static const bool dedup = [] { const char* e = getenv("NELE_SIIB_DEDUP"); return !(e && e[0] == '0'); }();
+    const int Pf = dedup ? L / g : 0x7fffffff;               // frame period of the tiled signal (NELE_SIIB_DEDUP=0: A/B switch, every frame computed)
     const bool vad = (phase == 0 || phase == 1 || phase == 3);
     const bool sx = vad, sy = (phase == 0 || phase == 1 || phase == 4);
     const bool eig = (phase == 0 || phase == 2 || phase == 3);

@@ -161,3 +161,30 @@ def test_siib_split_by_data_dependence_equals_one_shot(mt):
     raw2 = raw2.clone()
     raw3, _ = mt.batch_siib(x, y2)
     assert torch.equal(raw2, raw3)
+
+
+_AB_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for L in (64000, 48200, 32000):
+    c, v = synth.batch(3, L, start=60)
+    raw, _, info = mt.batch_siib(c, c + v, return_info=True)
+    out += [raw.cpu().numpy().view(np.uint32), info.cpu().numpy().astype(np.uint32).ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_siib_period_shortcut_is_bit_identical_to_computing_every_frame(tmp_path):
+    """L a multiple of 200: the tiled signal is frame-periodic; spectra / masking of the repeats are copied, not recomputed.
+    A/B against the same library with the shortcut switched off (separate processes: the switch is read once)."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('siib_%s.npy' % flag))
+        env = dict(os.environ, NELE_SIIB_DEDUP=flag)
+        subprocess.run([sys.executable, '-c', _AB_CHILD, os.path.dirname(HERE), out], check=True, env=env, timeout=240)
+        res.append(np.load(out))
+    assert res[0].tobytes() == res[1].tobytes()
