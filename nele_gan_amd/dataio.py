@@ -1,0 +1,291 @@
+"""On-disk hand-off formats of the reference loop, host side.
+
+The reference exchanges everything between its stages through files: enhanced speech is written as PCM_16
+wav (``train_nele.py:198,313``, ``inference.py:115``) under ``name@epoch.wav``, the metric fan-out reads the
+(clean, noise, enhanced) triple back per file (``audio_util.py:120-203``, ``267-321``), and the D-step consumes
+``"s0,s1,s2,s3,s4,path"`` strings (``audio_util.py:367-389``, ``dataloader.py:54-84``).  This module reads and
+writes those formats so that folders and lists produced by either implementation are interchangeable, and it
+feeds the batched GPU kernels from them: files are decoded on the host, grouped by length, and each group is
+one batched launch (the reference: one joblib process per file, ``audio_util.py:146``).
+
+No third-party audio library: RIFF/WAVE PCM is parsed here (libsndfile / librosa are not in the image).
+PCM_16 semantics follow libsndfile: write ``rint(x * 0x7FFF)`` (round half to even), read ``s / 0x8000``
+(PARITY UNPINNED: libsndfile itself is absent; same rule as ``nele_wav_post`` on the device).
+"""
+import os
+import struct
+
+import numpy as np
+
+fs = 16000
+power_law = (1 / 6)
+
+
+# ------------------------------------------------------------------------------------------------ wav files
+def read_wav(path):
+    """-> (float32 [L] mono, sample_rate).  PCM 8/16/24/32-bit and IEEE float32/64 RIFF files; multi-channel
+    files are averaged to mono (librosa.load(mono=True))."""
+    with open(path, 'rb') as f:
+        data = f.read()
+    if len(data) < 12 or data[0:4] != b'RIFF' or data[8:12] != b'WAVE':
+        raise ValueError('%s: not a RIFF/WAVE file' % path)
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack('<I', data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b'fmt ':
+            fmt = struct.unpack('<HHIIHH', body[:16])
+            if fmt[0] == 0xFFFE and len(body) >= 26:                     # WAVE_FORMAT_EXTENSIBLE: sub-format tag
+                fmt = (struct.unpack('<H', body[24:26])[0],) + fmt[1:]
+        elif cid == b'data':
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError('%s: missing fmt or data chunk' % path)
+    tag, nch, sr, _, _, bits = fmt
+    if tag == 1:
+        if bits == 16:
+            x = np.frombuffer(pcm[:len(pcm) // 2 * 2], dtype='<i2').astype(np.float32) / np.float32(32768.0)
+        elif bits == 8:
+            x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / np.float32(128.0)
+        elif bits == 24:
+            b = np.frombuffer(pcm[:len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = (b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16))
+            v = np.where(v & 0x800000, v - 0x1000000, v)
+            x = v.astype(np.float32) / np.float32(8388608.0)
+        elif bits == 32:
+            x = (np.frombuffer(pcm[:len(pcm) // 4 * 4], dtype='<i4').astype(np.float64) / 2147483648.0).astype(np.float32)
+        else:
+            raise ValueError('%s: unsupported PCM width %d' % (path, bits))
+    elif tag == 3:
+        x = np.frombuffer(pcm, dtype='<f4' if bits == 32 else '<f8').astype(np.float32)
+    else:
+        raise ValueError('%s: unsupported wav format tag %d' % (path, tag))
+    if nch > 1:
+        x = x[:len(x) // nch * nch].reshape(-1, nch).mean(axis=1).astype(np.float32)
+    return x, sr
+
+
+def load(path, sr=None):
+    """librosa.load(path, sr=...) as the reference uses it: native rate only (every call site asserts 16 kHz)."""
+    x, file_sr = read_wav(path)
+    if sr is not None and sr != file_sr:
+        raise ValueError('%s: sample rate %d, expected %d (resampling on load is not part of the path)' % (path, file_sr, sr))
+    return x, file_sr
+
+
+def pcm16_quantise(wav):
+    """float -> int16 as libsndfile's PCM_16 writer without clipping control: rint(x * 32767), saturated."""
+    q = np.rint(np.asarray(wav, dtype=np.float32) * np.float32(32767.0))
+    return np.clip(q, -32768, 32767).astype('<i2')
+
+
+def write_wav_pcm16(path, wav, sr=fs, quantised=False):
+    """sf.write(path, wav, sr, 'PCM_16').  ``quantised=True``: ``wav`` already went through the device-side PCM_16
+    emulation (values k / 32768), so the samples are recovered exactly instead of being rounded a second time."""
+    if hasattr(wav, 'detach'):
+        wav = wav.detach().cpu().numpy()
+    wav = np.asarray(wav, dtype=np.float32).reshape(-1)
+    s = np.rint(wav * np.float32(32768.0)).clip(-32768, 32767).astype('<i2') if quantised else pcm16_quantise(wav)
+    body = s.tobytes()
+    hdr = b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVE' + b'fmt ' + struct.pack('<IHHIIHH', 16, 1, 1, sr, sr * 2, 2, 16)
+    with open(path, 'wb') as f:
+        f.write(hdr + b'data' + struct.pack('<I', len(body)) + body)
+
+
+# ------------------------------------------------------------------------------------------------ names and lists
+def wave_name_of(enhanced_file):
+    """audio_util.py:121-126: 'dir/name@12.wav' -> 'name', 'dir/name.wav' -> 'name'."""
+    f = enhanced_file.split('/')[-1]
+    return f.split('@')[0] if '@' in f else f[:-4]
+
+
+def enhanced_name(directory, wave_name, gan_epoch):
+    """train_nele.py:190-193, 309-312: '<directory>/<stem>@<epoch><ext>'."""
+    return directory + '/' + wave_name[0:-4] + '@' + str(gan_epoch) + wave_name[-4:]
+
+
+def List_concat(score, enhanced_list):
+    """audio_util.py:367-371."""
+    return [str(score[i]) + ',' + enhanced_list[i] for i in range(len(score))]
+
+
+def List_concat_score(score, score2):
+    return [str(score[i]) + ',' + str(score2[i]) for i in range(len(score))]
+
+
+def List_concat_3scores(score1, score2, score3):
+    return [str(score1[i]) + ',' + str(score2[i]) + ',' + str(score3[i]) for i in range(len(score1))]
+
+
+def List_concat_5scores(score1, score2, score3, score4, score5):
+    """audio_util.py:385-389: the 's0,s1,s2,s3,s4' prefix of a D training item."""
+    return [','.join(str(s[i]) for s in (score1, score2, score3, score4, score5)) for i in range(len(score1))]
+
+
+def parse_score_line(line):
+    """dataloader.py:56-77: 's0,s1,s2,s3,s4,path' -> (intel targets [3], quality targets [2], path)."""
+    p = line.split(',')
+    if len(p) < 6:
+        raise ValueError('D training item needs five scores and a path: %r' % line)
+    return (np.asarray([float(p[0]), float(p[1]), float(p[2])], dtype=np.float32),
+            np.asarray([float(p[3]), float(p[4])], dtype=np.float32), p[5])
+
+
+def creatdir(directory):
+    os.makedirs(directory, exist_ok=True)
+
+
+def ListRead(filelist):
+    with open(filelist, 'r') as f:
+        return [line[0:-1] for line in f]
+
+
+def get_filepaths(directory):
+    out = []
+    for root, _, files in os.walk(directory):
+        out += [os.path.join(root, n) for n in files if '.wav' in n]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ metric fan-out from files
+def _triple(clean_root, noise_root, enhanced_file, drc):
+    name = enhanced_file.split('/')[-1] if drc else wave_name_of(enhanced_file) + '.wav'
+    clean, sr = load(clean_root + name, sr=fs)
+    assert sr == 16000
+    enh, _ = load(enhanced_file, sr=fs)
+    noise, _ = load(noise_root + name, sr=fs)
+    n = min(len(clean), len(enh))                                          # audio_util.py:134-137
+    return clean[:n], enh[:n] + noise[:n]
+
+
+def _read_batch(kind, clean_root, noise_root, enhanced_list, norm, drc=False, max_batch=256):
+    import torch
+    from . import metrics as mt
+    fn = {'estoi': mt.batch_estoi, 'siib': mt.batch_siib, 'haspi': mt.batch_haspi}[kind]
+    pairs = [_triple(clean_root, noise_root, en, drc) for en in enhanced_list]
+    groups = {}
+    for i, (x, _) in enumerate(pairs):
+        groups.setdefault(len(x), []).append(i)
+    out = [None] * len(pairs)
+    for _, idx in sorted(groups.items()):
+        for k in range(0, len(idx), max_batch):
+            sel = idx[k:k + max_batch]
+            x = torch.from_numpy(np.stack([pairs[i][0] for i in sel])).cuda()
+            y = torch.from_numpy(np.stack([pairs[i][1] for i in sel])).cuda()
+            raw, mapped = fn(x, y)[:2]
+            vals = (mapped if norm else raw).double().cpu().numpy()
+            for i, v in zip(sel, vals):
+                if not np.isfinite(v):
+                    raise ValueError('%s: metric undefined for %s (the reference raises here)' % (kind, enhanced_list[i]))
+                out[i] = float(v)
+    return out
+
+
+def read_batch_STOI(clean_root, noise_root, enhanced_list, norm=True):
+    """audio_util.py:120-147.  One batched launch per group of equal-length files; values in list order."""
+    return _read_batch('estoi', clean_root, noise_root, enhanced_list, norm)
+
+
+def read_batch_SIIB(clean_root, noise_root, enhanced_list, norm=True):
+    """audio_util.py:149-175."""
+    return _read_batch('siib', clean_root, noise_root, enhanced_list, norm)
+
+
+def read_batch_HASPI(clean_root, noise_root, enhanced_list, norm=True):
+    """audio_util.py:177-203."""
+    return _read_batch('haspi', clean_root, noise_root, enhanced_list, norm)
+
+
+def read_batch_STOI_DRC(clean_root, noise_root, enhanced_list):
+    """audio_util.py:267-284 (pre-enhanced examples: the enhanced file carries the clean file's name)."""
+    return _read_batch('estoi', clean_root, noise_root, enhanced_list, True, drc=True)
+
+
+def read_batch_SIIB_DRC(clean_root, noise_root, enhanced_list):
+    """audio_util.py:286-303."""
+    return _read_batch('siib', clean_root, noise_root, enhanced_list, True, drc=True)
+
+
+def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
+    """audio_util.py:305-322."""
+    return _read_batch('haspi', clean_root, noise_root, enhanced_list, True, drc=True)
+
+
+# ------------------------------------------------------------------------------------------------ datasets (dataloader.py)
+class Generator_train_dataset:
+    """dataloader.py:19-42: item = (clean_band [T,64], clean_mag [257,T], clean_phase [257,T], noise_band, noise_mag,
+    noise_phase, target_score [3], target_qua [2], filename); features come from the GPU kernels (device tensors)."""
+
+    def __init__(self, file_list, noise_path, rir_path=None):
+        self.file_list, self.noise_path, self.rir_path = file_list, noise_path, rir_path
+        self.target_score = np.asarray([1.0, 1.0, 1.0], dtype=np.float32)
+        self.target_qua = np.asarray([1.0, 1.0], dtype=np.float32)
+
+    def __len__(self):
+        return len(self.file_list)
+
+    def __getitem__(self, idx):
+        from . import audio_util as au
+        filename = self.file_list[idx].split('/')[-1]
+        clean_wav, sr = load(self.file_list[idx])
+        assert sr == 16000
+        noise_wav, sr = load(self.noise_path + filename)
+        assert sr == 16000
+        cb, cm, cp = au.Sp_and_phase_Speech(clean_wav, power=power_law, Normalization=True)
+        nb, nm, np_ = au.Sp_and_phase_Noise(noise_wav, power=power_law, Normalization=True)
+        return cb, cm, cp, nb, nm, np_, self.target_score, self.target_qua, filename
+
+
+class Discriminator_train_dataset:
+    """dataloader.py:44-84: item = ([enh, noise, clean] [3,64,T], [enh, clean] [2,64,T], True_score [3], True_score_Qua [2])."""
+
+    def __init__(self, file_list, noise_path, clean_path, rir_path=None):
+        self.file_list, self.noise_path, self.clean_path, self.rir_path = file_list, noise_path, clean_path, rir_path
+
+    def __len__(self):
+        return len(self.file_list)
+
+    def __getitem__(self, idx):
+        import torch
+        from . import audio_util as au
+        score, score_qua, path = parse_score_line(self.file_list[idx])
+        enh, sr = load(path)
+        assert sr == 16000
+        f = self.file_list[idx].split('/')[-1]
+        if '@' in f:
+            f = f.split('@')[0] + '.wav'
+        noise, sr = load(self.noise_path + f)
+        assert sr == 16000
+        clean, sr = load(self.clean_path + f)
+        assert sr == 16000
+        eb = au.Sp_and_phase_Speech(enh, power=power_law)[0].transpose(0, 1)
+        nb = au.Sp_and_phase_Noise(noise, power=power_law)[0].transpose(0, 1)
+        cb = au.Sp_and_phase_Speech(clean, power=power_law)[0].transpose(0, 1)
+        return torch.stack((eb, nb, cb)), torch.stack((eb, cb)), score, score_qua
+
+
+class _Loader:
+    """batch_size = 1, shuffle = True, drop_last = True (dataloader.py:86-101).  No worker processes: the features are
+    computed by the GPU kernels, the host only decodes wav files."""
+
+    def __init__(self, dataset, seed=None):
+        self.dataset, self.rng = dataset, np.random.RandomState(seed)
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __iter__(self):
+        import torch
+        for i in self.rng.permutation(len(self.dataset)):
+            item = self.dataset[int(i)]
+            yield tuple(v.unsqueeze(0) if isinstance(v, torch.Tensor) else
+                        (torch.from_numpy(v).unsqueeze(0) if isinstance(v, np.ndarray) else [v]) for v in item)
+
+
+def create_dataloader(filelist, noise_path, clean_path=None, rir_path=None, loader='G', seed=None):
+    if loader == 'G':
+        return _Loader(Generator_train_dataset(filelist, noise_path, rir_path), seed)
+    if loader == 'D':
+        return _Loader(Discriminator_train_dataset(filelist, noise_path, clean_path, rir_path), seed)
+    raise Exception("No such dataloader type!")

@@ -249,6 +249,36 @@ class GanTrainer:
         self.history = self.history + cur
         run(cur)                                                        # pass C
 
+    # ---------------------------------------------------------------- file hand-off (train_nele.py:303-340, 224-225)
+    def write_samples(self, enh_wav, wave_names, directory, gan_epoch):
+        """Enhanced batch -> '<directory>/<name>@<epoch>.wav' PCM_16 files, as the reference stores its generated D samples
+        (train_nele.py:309-313).  ``enh_wav`` is what ``generate`` returned (already PCM_16-quantised when ``self.pcm16``)."""
+        from . import dataio
+        dataio.creatdir(directory)
+        host = enh_wav.detach().cpu().numpy()
+        out = []
+        for w, name in zip(host, wave_names):
+            path = dataio.enhanced_name(directory, name, gan_epoch)
+            dataio.write_wav_pcm16(path, w, fs, quantised=self.pcm16)
+            out.append(path)
+        return out
+
+    def score_lines(self, targets, enhanced_names):
+        """[B, n_metrics] targets -> 's_siib,s_haspi,s_estoi,s_pesq,s_visqol,path' items of the reference's D training list
+        (train_nele.py:334-340: unused metrics are zero)."""
+        from . import dataio
+        t = targets.detach().double().cpu().numpy()
+        col = {m: t[:, i] for i, m in enumerate(self.metrics)}
+        zero = np.zeros(len(t))
+        five = [col.get('siib', zero), col.get('haspi', zero), col.get('estoi', zero), zero, zero]
+        return dataio.List_concat(dataio.List_concat_5scores(*[list(map(float, c)) for c in five]), enhanced_names)
+
+    @staticmethod
+    def validation_log_line(siib, haspi, estoi, gan_epoch):
+        """The learning-curve line of train_nele.py:224-225 (PESQ / ViSQOL are reported as 0 there too)."""
+        return 'SIIB is %.3f, HASPI is %.3f, ESTOI is %.3f, PESQ is %.3f, VISQOL is %.3f, EPOCH:%d \n' % (
+            float(np.mean(siib)), float(np.mean(haspi)), float(np.mean(estoi)), 0, 0, gan_epoch)
+
     # ---------------------------------------------------------------- checkpoints (train_nele.py:272-277)
     def save_checkpoint(self, path):
         sd = {'enhance-model': self.G.state_dict(), 'intel-model': self.D.state_dict()}

@@ -1,0 +1,92 @@
+"""CPU: the on-disk hand-off formats (wav PCM_16, name@epoch convention, score lists) of nele_gan_amd.dataio."""
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from nele_gan_amd import dataio
+
+HERE = os.path.dirname(__file__)
+TOY = os.path.join(HERE, 'golden', 'toy')
+
+
+@pytest.mark.parametrize('name', ['Train_Clean.wav', 'Train_Noise.wav', 'Test_Clean.wav'])
+def test_read_wav_matches_the_stdlib_parser_on_the_reference_toy_files(name):
+    x, sr = dataio.read_wav(os.path.join(TOY, name))
+    w = wave.open(os.path.join(TOY, name))
+    ref = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
+    assert sr == w.getframerate() == 16000 and x.dtype == np.float32
+    assert np.array_equal(x, ref)
+
+
+def test_pcm16_write_read_is_the_oracle_round_trip(tmp_path):
+    from oracle.step import pcm16_roundtrip
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(5000) * 0.2).astype(np.float32)
+    x[:6] = [0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, 1.2, -1.2]       # ties round to even; overload saturates
+    p = str(tmp_path / 'a.wav')
+    dataio.write_wav_pcm16(p, x)
+    y, sr = dataio.read_wav(p)
+    assert sr == 16000 and np.array_equal(y, pcm16_roundtrip(x))
+    assert list(np.rint(y[:4] * 32768)) == [0, 2, 2, 0]
+    # a signal that already went through the device-side emulation is stored without a second rounding
+    p2 = str(tmp_path / 'b.wav')
+    dataio.write_wav_pcm16(p2, y, quantised=True)
+    assert np.array_equal(dataio.read_wav(p2)[0], y)
+    with open(p, 'rb') as f:
+        head = f.read(44)
+    assert head[:4] == b'RIFF' and struct.unpack('<HHI', head[20:28]) == (1, 1, 16000) and struct.unpack('<H', head[34:36])[0] == 16
+
+
+def test_other_sample_formats_and_stereo(tmp_path):
+    v = np.array([0.25, -0.5, 0.75, -1.0], dtype=np.float64)
+
+    def riff(tag, bits, nch, body):
+        fmt = struct.pack('<HHIIHH', tag, nch, 16000, 16000 * nch * bits // 8, nch * bits // 8, bits)
+        return b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVE' + b'fmt ' + struct.pack('<I', 16) + fmt + b'data' + struct.pack('<I', len(body)) + body
+    cases = {
+        'f32.wav': riff(3, 32, 1, v.astype('<f4').tobytes()),
+        'i32.wav': riff(1, 32, 1, (v * 2 ** 31).clip(-2 ** 31, 2 ** 31 - 1).astype('<i4').tobytes()),
+        'i24.wav': riff(1, 24, 1, b''.join(struct.pack('<i', int(s * 2 ** 23))[:3] for s in v.clip(-1, 1 - 2 ** -23))),
+        'st16.wav': riff(1, 16, 2, np.stack([v, v], 1).reshape(-1).__mul__(32768).clip(-32768, 32767).astype('<i2').tobytes()),
+    }
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        x, sr = dataio.read_wav(str(p))
+        assert sr == 16000 and x.shape == (4,)
+        np.testing.assert_allclose(x[:3], v[:3], atol=2e-7)
+    with pytest.raises(ValueError):
+        (tmp_path / 'bad.wav').write_bytes(b'RIFX' + b'\0' * 40)
+        dataio.read_wav(str(tmp_path / 'bad.wav'))
+    with pytest.raises(ValueError):
+        dataio.load(os.path.join(TOY, 'Train_Clean.wav'), sr=8000)
+
+
+def test_name_convention_and_score_lists():
+    assert dataio.wave_name_of('/out/epoch3/Train_epoch3/Train_Clean@3.wav') == 'Train_Clean'       # audio_util.py:121-126
+    assert dataio.wave_name_of('/data/Train_Clean.wav') == 'Train_Clean'
+    assert dataio.enhanced_name('/out/temp', 'Train_Clean.wav', 12) == '/out/temp/Train_Clean@12.wav'  # train_nele.py:312
+    s = [0.25, 0.5], [0.125, 1.0], [0.75, 0.0], [0.0, 0.0], [0.0, 0.0]
+    paths = ['/o/a@1.wav', '/o/b@1.wav']
+    lines = dataio.List_concat(dataio.List_concat_5scores(*s), paths)
+    assert lines[0] == '0.25,0.125,0.75,0.0,0.0,/o/a@1.wav'
+    intel, qua, path = dataio.parse_score_line(lines[1])
+    assert list(intel) == [0.5, 1.0, 0.0] and list(qua) == [0.0, 0.0] and path == '/o/b@1.wav'
+    assert dataio.List_concat_3scores([1], [2], [3]) == ['1,2,3'] and dataio.List_concat_score([1], [2]) == ['1,2']
+    with pytest.raises(ValueError):
+        dataio.parse_score_line('0.5,/o/a.wav')
+
+
+def test_listread_and_get_filepaths(tmp_path):
+    (tmp_path / 'sub').mkdir()
+    for n in ('x.wav', 'sub/y.wav', 'z.txt'):
+        (tmp_path / n).write_bytes(b'')
+    assert sorted(os.path.basename(p) for p in dataio.get_filepaths(str(tmp_path))) == ['x.wav', 'y.wav']
+    lst = tmp_path / 'list.txt'
+    lst.write_text('a.wav\nb.wav\n')
+    assert dataio.ListRead(str(lst)) == ['a.wav', 'b.wav']
+    dataio.creatdir(str(tmp_path / 'p' / 'q'))
+    assert (tmp_path / 'p' / 'q').is_dir()

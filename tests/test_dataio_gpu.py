@@ -1,0 +1,128 @@
+"""GPU: metric fan-out and D training items read from reference-format folders (wav PCM_16, name@epoch, score lists)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+HERE = os.path.dirname(__file__)
+TOY = os.path.join(HERE, 'golden', 'toy')
+
+
+@pytest.fixture(scope='module')
+def tree(tmp_path_factory):
+    """Clean/ Noise/ Enhanced/ folders as train_nele.py lays them out: two source files of different lengths, the
+    enhanced versions written as PCM_16 under name@epoch.wav."""
+    from nele_gan_amd import dataio
+    assert torch.cuda.is_available()
+    root = tmp_path_factory.mktemp('set')
+    for d in ('Clean', 'Noise', 'Enh'):
+        (root / d).mkdir()
+    names = []
+    for split in ('Train', 'Test'):
+        shutil.copy(os.path.join(TOY, split + '_Clean.wav'), root / 'Clean' / (split + '.wav'))
+        shutil.copy(os.path.join(TOY, split + '_Noise.wav'), root / 'Noise' / (split + '.wav'))
+        c, _ = dataio.load(str(root / 'Clean' / (split + '.wav')))
+        enh = (c * np.float32(1.7))[:len(c) // 256 * 256]                 # stands for a resynthesised signal (shorter than the clean file)
+        for ep in (1, 2):
+            p = dataio.enhanced_name(str(root / 'Enh'), split + '.wav', ep)
+            dataio.write_wav_pcm16(p, enh * np.float32(ep))
+            names.append(p)
+    return str(root / 'Clean') + '/', str(root / 'Noise') + '/', names
+
+
+def test_read_batch_metrics_from_files_vs_oracle(tree):
+    from nele_gan_amd import dataio
+    from oracle import step
+    clean_root, noise_root, names = tree
+    got = {
+        ('estoi', True): dataio.read_batch_STOI(clean_root, noise_root, names, norm=True),
+        ('estoi', False): dataio.read_batch_STOI(clean_root, noise_root, names, norm=False),
+        ('siib', True): dataio.read_batch_SIIB(clean_root, noise_root, names, norm=True),
+    }
+    for (m, norm), vals in got.items():
+        assert len(vals) == len(names) and all(isinstance(v, float) for v in vals)
+        for en, v in zip(names, vals):
+            name = dataio.wave_name_of(en) + '.wav'
+            c, _ = dataio.load(clean_root + name)
+            n, _ = dataio.load(noise_root + name)
+            e, _ = dataio.load(en)
+            ref = step.metric_targets(c, e, n, [m], norm=norm)[0]
+            assert v == pytest.approx(ref, rel=2e-4, abs=2e-4)
+
+
+def test_drc_variant_uses_the_enhanced_files_own_name(tree, tmp_path):
+    from nele_gan_amd import dataio
+    clean_root, noise_root, names = tree
+    p = str(tmp_path / 'Train.wav')                                      # audio_util.py:267-284: same file name as the clean file
+    shutil.copy(names[0], p)
+    a = dataio.read_batch_STOI_DRC(clean_root, noise_root, [p])
+    b = dataio.read_batch_STOI(clean_root, noise_root, [names[0]], norm=True)
+    assert a == b
+
+
+def test_discriminator_items_from_a_score_list_vs_oracle(tree):
+    from nele_gan_amd import dataio
+    from oracle import features as F
+    clean_root, noise_root, names = tree
+    scores = [[0.1 * (i + 1) for i in range(len(names))] for _ in range(5)]
+    lines = dataio.List_concat(dataio.List_concat_5scores(*scores), names)
+    ds = dataio.Discriminator_train_dataset(lines, noise_root, clean_root)
+    assert len(ds) == len(names)
+    x3, x2, s, q = ds[2]
+    e, _ = dataio.load(names[2])
+    name = dataio.wave_name_of(names[2]) + '.wav'
+    c, _ = dataio.load(clean_root + name)
+    n, _ = dataio.load(noise_root + name)
+    Te, Tc = 1 + len(e) // 256, 1 + len(c) // 256
+    assert x3[0].shape == (64, Te) and x3.shape[0] == 3 if Te == Tc else True
+    np.testing.assert_allclose(x2[0].cpu().numpy(), F.sp_and_phase_speech(e, 1 / 6)[0].T, rtol=2e-5)
+    np.testing.assert_allclose(x2[1].cpu().numpy(), F.sp_and_phase_speech(c, 1 / 6)[0].T, rtol=2e-5)
+    np.testing.assert_allclose(x3[1].cpu().numpy(), F.sp_and_phase_noise(n, 1 / 6)[0].T, rtol=1e-4)
+    assert list(s) == pytest.approx([0.3] * 3) and list(q) == pytest.approx([0.3] * 2)
+    batches = list(dataio.create_dataloader(lines, noise_root, clean_root, loader='D', seed=0))
+    assert len(batches) == len(names) and batches[0][0].shape[:3] == (1, 3, 64) and batches[0][2].shape == (1, 3)
+    g = dataio.create_dataloader([clean_root + 'Train.wav'], noise_root, loader='G')
+    item = next(iter(g))
+    assert item[0].shape[0] == 1 and item[0].shape[2] == 64 and item[8] == ['Train.wav']
+
+
+def test_generated_samples_through_files_give_the_in_memory_targets(tmp_path):
+    """generate -> PCM_16 files -> read_batch_* (the reference's hand-off, train_nele.py:303-340) must give the targets the
+    in-HBM path computes from the same batch, and the D items parsed back from the score list must be the D inputs."""
+    from nele_gan_amd import dataio, synth
+    from nele_gan_amd.train_nele import GanTrainer
+    B, L = 3, 24000
+    c, v = synth.batch(B, L, start=40)
+    names = ['utt%d.wav' % i for i in range(B)]
+    clean_root, noise_root = str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/'
+    for d in (clean_root, noise_root):
+        dataio.creatdir(d)
+    # the sources themselves must be PCM_16-exact for the two paths to see identical samples
+    q = lambda a: (np.rint(a * 32767).clip(-32768, 32767) / 32768).astype(np.float32)
+    c, v = q(c), q(v)
+    for i, n in enumerate(names):
+        dataio.write_wav_pcm16(clean_root + n, c[i], quantised=True)
+        dataio.write_wav_pcm16(noise_root + n, v[i], quantised=True)
+    tr = GanTrainer('siib&estoi')
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    f = tr.features(cw, nw)
+    enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+    tgt = tr.true_metrics(cw, enh, nw).cpu().numpy()
+    files = tr.write_samples(enh, names, str(tmp_path / 'out' / 'temp'), 7)
+    assert files[0].endswith('/temp/utt0@7.wav')
+    back, _ = dataio.load(files[1])
+    assert np.array_equal(back, enh[1].cpu().numpy())                        # bit-exact through the file
+    siib = dataio.read_batch_SIIB(clean_root, noise_root, files, norm=True)
+    estoi = dataio.read_batch_STOI(clean_root, noise_root, files, norm=True)
+    np.testing.assert_allclose(np.stack([siib, estoi], 1), tgt, rtol=1e-6)
+    lines = tr.score_lines(torch.from_numpy(tgt), files)
+    intel, qua, path = dataio.parse_score_line(lines[2])
+    assert path == files[2] and intel[0] == pytest.approx(tgt[2, 0]) and intel[2] == pytest.approx(tgt[2, 1]) and intel[1] == 0
+    ds = dataio.Discriminator_train_dataset(lines, noise_root, clean_root)
+    x3 = ds[2][0]                                                            # [3, 64, T] = enh, noise, clean
+    din = tr.d_inputs(enh, f['noise_band'], f['clean_band'])                 # packed [B, 64, T, 4]
+    np.testing.assert_allclose(x3.permute(1, 2, 0).cpu().numpy(), din[2, :, :, :3].float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert 'EPOCH:7' in tr.validation_log_line(siib, [0.0], estoi, 7)
