@@ -210,6 +210,18 @@ int nele_metric_haspi_nsub(int L, int fs_in);
 int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
                       long long workspace_bytes, float* raw, float* mapped, int* info, void* stream);
 
+/* ---- evaluation path (csrc/reverb.hip) ---------------------------------------------------------------------- */
+
+/* eval_metrics.py:132,137 scipy.signal.lfilter(h, [1], x): room impulse response h [Lh] (float64) applied to x [B][L] (float32),
+ * y [B][L] float64 (lfilter promotes: a = [1] is an integer array), terms added from the oldest tap to the newest. */
+int nele_fir_filter(const float* x, int B, int L, const double* h, int Lh, double* y, void* stream);
+
+/* eval_metrics.py:104,133-134,138-139,143-144 + audio_util.py:67-74: v = a (+ add); v = v / rms(v) * target_rms when target_rms > 0;
+ * clip(v) (divide by 1.05, 1.10, ... while max >= 1 or min < -1).  Exactly one of a64 / a32 [B][N]; add [B][N] or NULL;
+ * out (float32) and / or out64; nclip [B] (may be NULL) = number of clip divisions applied. */
+int nele_norm_clip(const double* a64, const float* a32, const float* add, int B, int N, double target_rms, float* out, double* out64,
+                   int* nclip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

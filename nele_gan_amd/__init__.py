@@ -9,7 +9,7 @@ __version__ = '0.1.0'
 def load_all_bindings():
     """Import every module that declares ctypes signatures (so _lib._SIGS covers include/nele_hip.h)."""
     import importlib
-    for m in ('ops', 'audio_util', 'metrics'):
+    for m in ('ops', 'audio_util', 'metrics', 'eval_metrics'):
         try:
             importlib.import_module('.' + m, __name__)
         except ModuleNotFoundError:
