@@ -128,7 +128,8 @@ int nele_exptanh_bwd(const float* dmask, const float* mask, float* dout, long lo
  * alpha2 = mask*beta2 (train_nele.py:307, inference.py:104; may be NULL); s2 = sum(mask*clean^inv_p). */
 int nele_energy_norm_fwd(const float* clean, const float* mask, const float* noise, float p, float inv_p, float* beta2,
                          float* s2, float* din, float* alpha2, int B, int T, void* stream);
-int nele_energy_norm_bwd(const float* clean, const float* mask, const float* beta2, const float* s2, const float* ddin,
+/* Gradient w.r.t. the mask given d(din).  din = the forward pass's output (may be NULL: the enhanced band is then recomputed). */
+int nele_energy_norm_bwd(const float* clean, const float* mask, const float* beta2, const float* s2, const float* ddin, const float* din,
                          float p, float inv_p, float* dmask, int B, int T, void* stream);
 
 /* dataloader.py:76-84: band features (enhanced, noise, clean) [B][T][64] -> D input [B][64][T][4]

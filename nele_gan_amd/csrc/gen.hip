@@ -201,16 +201,21 @@ __global__ void exptanh_bwd_kernel(const float* __restrict__ dmask, const float*
 //   cp = clean^inv_p; beta2 = sum(cp) / sum(mask*cp); enh = clean * mask^p * beta2^p
 //   D input channels-last [B][64][T][4] = (enh, noise, clean, 0) transposed to (band, frame).
 // Also emits alpha2 = mask*beta2 (train_nele.py:307) for the resynthesis path.
-__global__ __launch_bounds__(256) void energy_norm_fwd_kernel(const float* __restrict__ clean, const float* __restrict__ mask,
-                                                              const float* __restrict__ noise, float p, float inv_p,
-                                                              float* __restrict__ beta2_out, float* __restrict__ s2_out,
-                                                              float* __restrict__ din, float* __restrict__ alpha2, int T) {
-    __shared__ double red[8];
+// One workgroup of 1024 threads per utterance (the sums are per utterance).  Frames are processed in tiles of 64: the band features
+// are [t][c] (c contiguous) and the D input is [c][t][4], so each tile goes through LDS and both sides are accessed in their
+// contiguous direction (the scattered 16-byte stores of a thread-per-element version made this kernel 70 us, its backward 136 us).
+#define EN_TT 64
+__global__ __launch_bounds__(1024) void energy_norm_fwd_kernel(const float* __restrict__ clean, const float* __restrict__ mask,
+                                                               const float* __restrict__ noise, float p, float inv_p,
+                                                               float* __restrict__ beta2_out, float* __restrict__ s2_out,
+                                                               float* __restrict__ din, float* __restrict__ alpha2, int T) {
+    __shared__ double red[16];
+    __shared__ float te[EN_TT][65], tn[EN_TT][65], tc[EN_TT][65];
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)b * T * 64;
     const int n = T * 64;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += 1024) {
         const float cp = powf(clean[base + i], inv_p);
         s1 += (double)cp;
         s2 += (double)(mask[base + i] * cp);
@@ -223,17 +228,30 @@ __global__ __launch_bounds__(256) void energy_norm_fwd_kernel(const float* __res
         if (s2_out) s2_out[b] = (float)s2;
     }
     const float beta_p = powf(beta2, p);
-    for (int i = tid; i < n; i += 256) {
-        const int t = i >> 6, c = i & 63;
-        const float cb = clean[base + i], m = mask[base + i];
-        if (alpha2) alpha2[base + i] = m * beta2;
-        if (din) {
-            float4 v;
-            v.x = cb * powf(m, p) * beta_p;
-            v.y = noise[base + i];
-            v.z = cb;
-            v.w = 0.f;
-            *reinterpret_cast<float4*>(din + (((size_t)b * 64 + c) * T + t) * 4) = v;
+    for (int t0 = 0; t0 < T; t0 += EN_TT) {
+        const int nt = min(EN_TT, T - t0);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 1024 * e, tl = idx >> 6, c = idx & 63;
+            if (tl < nt) {
+                const size_t g = base + (size_t)(t0 + tl) * 64 + c;
+                const float cb = clean[g], m = mask[g];
+                if (alpha2) alpha2[g] = m * beta2;
+                if (din) {
+                    te[tl][c] = cb * powf(m, p) * beta_p;
+                    tn[tl][c] = noise[g];
+                    tc[tl][c] = cb;
+                }
+            }
+        }
+        if (!din) continue;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 1024 * e, c = idx >> 6, tl = idx & 63;
+            if (tl < nt)
+                *reinterpret_cast<float4*>(din + (((size_t)b * 64 + c) * T + t0 + tl) * 4) = make_float4(te[tl][c], tn[tl][c], tc[tl][c], 0.f);
         }
     }
 }
@@ -241,28 +259,55 @@ __global__ __launch_bounds__(256) void energy_norm_fwd_kernel(const float* __res
 // dmask from d(din): only channel 0 (enh) depends on the mask.
 //   enh = cb m^p bp,  bp = (S1/S2)^p,  S2 = sum m cp
 //   dm = dE cb p m^(p-1) bp  -  (sum dE cb m^p) p bp / S2 * cp
-__global__ __launch_bounds__(256) void energy_norm_bwd_kernel(const float* __restrict__ clean, const float* __restrict__ mask,
-                                                              const float* __restrict__ beta2_in, const float* __restrict__ s2_in,
-                                                              const float* __restrict__ ddin, float p, float inv_p,
-                                                              float* __restrict__ dmask, int T) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(1024) void energy_norm_bwd_kernel(const float* __restrict__ clean, const float* __restrict__ mask,
+                                                               const float* __restrict__ beta2_in, const float* __restrict__ s2_in,
+                                                               const float* __restrict__ ddin, const float* __restrict__ din, float p,
+                                                               float inv_p, float* __restrict__ dmask, int T) {
+    // With the forward pass's D input at hand, enh = cb m^p bp is read back instead of recomputed: cb m^p = enh / bp and
+    // cb m^(p-1) bp = enh / m, which leaves one powf per element (cb^inv_p) instead of four (this kernel was powf-bound).
+    __shared__ double red[16];
+    __shared__ float td[EN_TT][65], te[EN_TT][65];
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)b * T * 64;
-    const int n = T * 64;
     const float beta_p = powf(beta2_in[b], p);
     double r = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        const int t = i >> 6, c = i & 63;
-        const float dE = ddin[(((size_t)b * 64 + c) * T + t) * 4];
-        r += (double)(dE * clean[base + i] * powf(mask[base + i], p));
-    }
-    r = block_sum(r, red);
-    const float k2 = (float)(r * (double)p * (double)beta_p / (double)s2_in[b]);
-    for (int i = tid; i < n; i += 256) {
-        const int t = i >> 6, c = i & 63;
-        const float dE = ddin[(((size_t)b * 64 + c) * T + t) * 4];
-        const float cb = clean[base + i], m = mask[base + i];
-        dmask[base + i] = dE * cb * p * powf(m, p - 1.f) * beta_p - k2 * powf(cb, inv_p);
+    for (int pass = 0; pass < 2; ++pass) {
+        float k2 = 0.f;
+        if (pass == 1) {
+            r = block_sum(r, red);
+            k2 = (float)(r * (double)p * (double)beta_p / (double)s2_in[b]);
+        }
+        for (int t0 = 0; t0 < T; t0 += EN_TT) {
+            const int nt = min(EN_TT, T - t0);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                       // dE (and enh) of the tile, read along t (contiguous in [c][t][4])
+                const int idx = tid + 1024 * e, c = idx >> 6, tl = idx & 63;
+                if (tl < nt) {
+                    const size_t g = (((size_t)b * 64 + c) * T + t0 + tl) * 4;
+                    td[tl][c] = ddin[g];
+                    if (din) te[tl][c] = din[g];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = tid + 1024 * e, tl = idx >> 6, c = idx & 63;
+                if (tl < nt) {
+                    const size_t g = base + (size_t)(t0 + tl) * 64 + c;
+                    const float dE = td[tl][c];
+                    if (din) {
+                        const float enh = te[tl][c];
+                        if (pass == 0) r += (double)(dE * (enh / beta_p));
+                        else dmask[g] = dE * p * (enh / mask[g]) - k2 * powf(clean[g], inv_p);
+                    } else {
+                        const float cb = clean[g], m = mask[g];
+                        if (pass == 0) r += (double)(dE * cb * powf(m, p));
+                        else dmask[g] = dE * cb * p * powf(m, p - 1.f) * beta_p - k2 * powf(cb, inv_p);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -363,16 +408,16 @@ extern "C" int nele_energy_norm_fwd(const float* clean, const float* mask, const
                                     float* s2, float* din, float* alpha2, int B, int T, void* stream) {
     NELE_CHECK_ARG(clean && mask && beta2 && B > 0 && T > 0, "nele_energy_norm_fwd: bad arguments");
     NELE_CHECK_ARG(!din || noise, "nele_energy_norm_fwd: din requested without noise features");
-    hipLaunchKernelGGL(energy_norm_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), clean, mask, noise, p, inv_p, beta2, s2, din,
+    hipLaunchKernelGGL(energy_norm_fwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), clean, mask, noise, p, inv_p, beta2, s2, din,
                        alpha2, T);
     NELE_CHECK_LAUNCH("nele_energy_norm_fwd");
     return NELE_OK;
 }
 
-extern "C" int nele_energy_norm_bwd(const float* clean, const float* mask, const float* beta2, const float* s2, const float* ddin,
+extern "C" int nele_energy_norm_bwd(const float* clean, const float* mask, const float* beta2, const float* s2, const float* ddin, const float* din,
                                     float p, float inv_p, float* dmask, int B, int T, void* stream) {
     NELE_CHECK_ARG(clean && mask && beta2 && s2 && ddin && dmask && B > 0, "nele_energy_norm_bwd: bad arguments");
-    hipLaunchKernelGGL(energy_norm_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), clean, mask, beta2, s2, ddin, p, inv_p, dmask, T);
+    hipLaunchKernelGGL(energy_norm_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), clean, mask, beta2, s2, ddin, din, p, inv_p, dmask, T);
     NELE_CHECK_LAUNCH("nele_energy_norm_bwd");
     return NELE_OK;
 }

@@ -705,15 +705,15 @@ class _EnergyNormPack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, clean, noise, p, inv_p):
         beta2, s2, din, _ = ops.energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True)
-        ctx.save_for_backward(mask, clean, beta2, s2)
+        ctx.save_for_backward(mask, clean, beta2, s2, din)
         ctx.p, ctx.inv_p = p, inv_p
         ctx.mark_non_differentiable(beta2)
         return din, beta2
 
     @staticmethod
     def backward(ctx, ddin, dbeta2):
-        mask, clean, beta2, s2 = ctx.saved_tensors
-        dmask = ops.energy_norm_bwd(clean, mask, beta2, s2, ddin.contiguous(), ctx.p, ctx.inv_p)
+        mask, clean, beta2, s2, din = ctx.saved_tensors
+        dmask = ops.energy_norm_bwd(clean, mask, beta2, s2, ddin.contiguous(), ctx.p, ctx.inv_p, din=din)
         return dmask, None, None, None, None
 
 

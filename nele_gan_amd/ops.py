@@ -32,7 +32,7 @@ _SIGS = {
     'nele_colsum2': [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     'nele_exptanh_bwd': [_P, _P, _P, c_longlong, _P],
     'nele_energy_norm_fwd': [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, _P],
-    'nele_energy_norm_bwd': [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, c_int, _P],
+    'nele_energy_norm_bwd': [_P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, c_int, _P],
     'nele_d_pack': [_P, _P, _P, _P, c_int, c_int, _P],
     'nele_d_layout': [_P, _P, c_int, c_int, c_int, c_int, _P],
     'nele_spectral_norm': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P, c_int, _P],
@@ -162,10 +162,10 @@ def energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True, want_alpha2=Fal
     return beta2, s2, din, alpha2
 
 
-def energy_norm_bwd(clean, mask, beta2, s2, ddin, p, inv_p):
+def energy_norm_bwd(clean, mask, beta2, s2, ddin, p, inv_p, din=None):
     B, T, _ = clean.shape
     dmask = torch.empty_like(mask)
-    call('nele_energy_norm_bwd', ptr(clean), ptr(mask), ptr(beta2), ptr(s2), ptr(ddin), p, inv_p, ptr(dmask), B, T, stream())
+    call('nele_energy_norm_bwd', ptr(clean), ptr(mask), ptr(beta2), ptr(s2), ptr(ddin), ptr(din), p, inv_p, ptr(dmask), B, T, stream())
     return dmask
 
 
