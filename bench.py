@@ -88,8 +88,8 @@ def main():
 
     for _ in range(a.warmup):
         tr.canonical_step(cw, nw)
-    tag = 'gstep.D.conv5.fwd'     # D's 5th conv forward as launched in the G-step (the D-step's launches share the GPU with the metric stream)
-    ops.PROFILE = {tag: []}
+    tag = 'D.conv5.fwd'           # D's 5th conv forward: every launch of the timed region (one in the G-step, one in the D-step per step)
+    ops.PROFILE = {'gstep.' + tag: [], tag: []}
     stage_ev = []
     barrier()
     t0 = time.perf_counter()
@@ -110,7 +110,8 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof = ops.PROFILE[tag]
+    prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
+    prof = prof_g + prof_d
     # the same launch on an otherwise idle GPU (after the timed region): inside the step the kernel shares the CUs with the metric
     # stream (SIIB's clean-signal part, incl. the all-CU tridiagonalisation, runs beside the G-step), which inflates its duration
     iso_tag = 'iso.D.conv5.fwd'
@@ -157,6 +158,8 @@ def main():
                              'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'launch_ms': kernel_ms,
+                         'launch_ms_gstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_g) / max(1, len(prof_g)),   # beside the half-GPU tridiagonalisation
+                         'launch_ms_dstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_d) / max(1, len(prof_d)),
                          'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
