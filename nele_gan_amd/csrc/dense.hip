@@ -1432,6 +1432,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     }
 }
 
+// Pointwise (1 x 1) layer with 4 input channels and N <= 8 outputs (D's first layer: 3 -> 8): the weight gradient is a plain reduction
+// over the M output positions, 16 B + 32 B per row - memory bound, no matrix cores.  grid = splits workgroups of 1024 threads,
+// rows strided over all threads, 4N + N accumulators per thread, fixed-order wave / workgroup reduction.  part [splits][N][4].
+#define WP_NMAX 8
+__global__ __launch_bounds__(1024) void conv_wgrad_pointwise_kernel(WgradArgs p) {
+    __shared__ float red[16][WP_NMAX * 5];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = p.N;
+    float acc[WP_NMAX][4], bacc[WP_NMAX];
+#pragma unroll
+    for (int n = 0; n < WP_NMAX; ++n) { bacc[n] = 0.f; acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
+    for (int m = blockIdx.x * 1024 + tid; m < p.M; m += gridDim.x * 1024) {
+        int b, ho, wo;
+        decode_m(m, g, b, ho, wo);
+        const float4 a = *reinterpret_cast<const float4*>(p.A + (((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C);
+        const float* dp = p.dOut + (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC;
+        float d[WP_NMAX];
+        const float4 d0 = *reinterpret_cast<const float4*>(dp);
+        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w;
+        if (N > 4) {
+            const float4 d1 = *reinterpret_cast<const float4*>(dp + 4);
+            d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+        } else { d[4] = d[5] = d[6] = d[7] = 0.f; }
+#pragma unroll
+        for (int n = 0; n < WP_NMAX; ++n) {
+            acc[n][0] += d[n] * a.x; acc[n][1] += d[n] * a.y; acc[n][2] += d[n] * a.z; acc[n][3] += d[n] * a.w;
+            bacc[n] += d[n];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < WP_NMAX; ++n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float v = wave_sum(acc[n][c]); if (lane == 0) red[wave][n * 5 + c] = v; }
+        const float v = wave_sum(bacc[n]);
+        if (lane == 0) red[wave][n * 5 + 4] = v;
+    }
+    __syncthreads();
+    if (tid < WP_NMAX * 5) {
+        float s_ = 0.f;
+        for (int w_ = 0; w_ < 16; ++w_) s_ += red[w_][tid];
+        const int n = tid / 5, c = tid - n * 5;
+        if (n < N) {
+            if (c < 4) p.part[((size_t)blockIdx.x * N + n) * 4 + c] = s_;
+            else if (p.bpart) p.bpart[(size_t)blockIdx.x * N + n] = s_;
+        }
+    }
+}
+
 // Sum the split partials in fixed order and scatter from GEMM layout [n][kh][kw][ci] to the
 // PyTorch parameter layout [n][ci][kh][kw] (flip != 0: the partials are in the flipped data-gradient
 // layout, never used for weights).  One thread per weight element.
@@ -1444,15 +1492,31 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float*
         const int n = idx / Ktot, kk = idx - n * Ktot;
         const int ci = kk % C, t = kk / C, kw = t % KW, kh = t / KW;
         if (ci >= Cvalid) continue;
+        // eight partials in flight per round (a dependent load per partial made the small layers' reductions 100 us latency chains);
+        // fixed summation order
         float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
+        int sp = 0;
+        for (; sp + 8 <= splits; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(sp + u) * total + idx];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
         const size_t o = (((size_t)n * Cvalid + ci) * KH + kh) * KW + kw;
         dW[o] = accumulate ? dW[o] + s : s;
     }
     if (db && bpart) {
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
             float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += bpart[(size_t)sp * N + n];
+            int sp = 0;
+            for (; sp + 8 <= splits; sp += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = bpart[(size_t)(sp + u) * N + n];
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; sp < splits; ++sp) s += bpart[(size_t)sp * N + n];
             db[n] = accumulate ? db[n] + s : s;
         }
     }
@@ -1840,6 +1904,15 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         splits = G;
         p.part = workspace;
         p.bpart = t.bpart;
+    }
+    if (!tiled && KH == 1 && KW == 1 && p.g.C == 4 && p.g.Ktot == 4 && (N == 4 || N == 8) && p.g.OC % 4 == 0 && splits >= 1) {
+        // pointwise layer (D conv1): memory-bound row reduction; as many workgroups as there are partial slots, at most 64
+        int sp = splits < 64 ? splits : 64;
+        p.bpart = db ? workspace + (size_t)sp * N * p.g.Ktot : nullptr;
+        hipLaunchKernelGGL(conv_wgrad_pointwise_kernel, dim3(sp), dim3(1024), 0, s, p);
+        NELE_CHECK_LAUNCH("nele_conv_wgrad(pointwise)");
+        splits = sp;
+        tiled = true;
     }
     if (!tiled) {
     int rps = (M + splits - 1) / splits;

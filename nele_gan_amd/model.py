@@ -315,7 +315,7 @@ class Generator_Conv1D_cLN(nn.Module):
         wst = None
         if self.overlap_wgrad:
             if self._wstream is None:
-                self._wstream = torch.cuda.Stream(device=dmask.device)
+                self._wstream = ops.side_stream(dmask.device)
             wst = self._wstream
         b16w = self.precision == 'bf16'
 
@@ -620,29 +620,36 @@ class _DiscriminatorBase(nn.Module):
         call('nele_gap_mlp_bwd', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]), self._mlp_ptrs(w), nout,
              SLOPE, B, Ho, Wo, Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1), ptr(bf.dpooled), ptr(bf.gbuf[-1]),
              stream())
-        if wgrad:
-            for i, (m, dz, xin, N, K) in enumerate(((self.fc3, bf.dz3, bf.h2, nout, 16), (self.fc2, bf.dz2, bf.h1, 16, 64),
-                                                    (self.fc1, bf.dz1, bf.pooled, 64, 64))):
-                li = 7 - i
-                tmpb = bf.tmpw[N * K:N * K + N]
-                call('nele_mlp_wgrad', ptr(dz), ptr(xin), B, N, K, ptr(bf.tmpw), c_void_p(tmpb.data_ptr()), stream())
-                call('nele_sn_grad', ptr(bf.tmpw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
-                     c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, ptr(bf.scratch64), stream())
-                m.bias.grad.add_(tmpb)
         ddin = None
         # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
-        # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on a second stream
+        # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on two more streams
         # beside the chain and join at the end.  In the D-step this tail is fully exposed (nothing else is left to overlap).
         main = torch.cuda.current_stream()
         wsts = None
         if wgrad and self.overlap_wgrad:
             if self._wstream is None:
-                self._wstream = (torch.cuda.Stream(device=dscore.device), torch.cuda.Stream(device=dscore.device))
+                self._wstream = (ops.side_stream(dscore.device), ops.side_stream(dscore.device))
             wsts = self._wstream
             ev0 = torch.cuda.Event()
-            ev0.record(main)                             # both streams start after the MLP part above (shared temporaries)
+            ev0.record(main)                             # dz1..dz3 and gbuf[-1] exist
             for q in wsts:
                 q.wait_event(ev0)
+        if wgrad:
+            # the three FC layers' weight gradients: a dozen small launches, on the second weight-gradient stream (its temporaries)
+            if wsts is not None:
+                ctx = torch.cuda.stream(wsts[1])
+                ctx.__enter__()
+            tw, sc = (bf.tmpw2, bf.scratch64b) if wsts is not None else (bf.tmpw, bf.scratch64)
+            for i, (m, dz, xin, N, K) in enumerate(((self.fc3, bf.dz3, bf.h2, nout, 16), (self.fc2, bf.dz2, bf.h1, 16, 64),
+                                                    (self.fc1, bf.dz1, bf.pooled, 64, 64))):
+                li = 7 - i
+                tmpb = tw[N * K:N * K + N]
+                call('nele_mlp_wgrad', ptr(dz), ptr(xin), B, N, K, ptr(tw), c_void_p(tmpb.data_ptr()), stream())
+                call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
+                     c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
+                m.bias.grad.add_(tmpb)
+            if wsts is not None:
+                ctx.__exit__(None, None, None)
         for l in range(len(_D_CONVS) - 1, -1, -1):
             cout, k = _D_CONVS[l]
             m = self.layers[l]
@@ -652,9 +659,11 @@ class _DiscriminatorBase(nn.Module):
             if wgrad:
                 N, K = cout, cin_valid * k * k
                 # two streams alternate over the layers, each with its own temporaries
-                tw, wsb, sc = (bf.tmpw, bf.ws, bf.scratch64) if (l & 1) == 0 else (bf.tmpw2, bf.ws2, bf.scratch64b)
+                # (conv5, conv3) on one, (conv4, conv2, conv1) on the other: about equal isolated time, both shorter than the data-gradient chain
+                q = 1 if l == 0 else (l & 1)
+                tw, wsb, sc = (bf.tmpw, bf.ws, bf.scratch64) if q == 0 else (bf.tmpw2, bf.ws2, bf.scratch64b)
                 tmpb = tw[N * K:N * K + N]
-                wst = wsts[l & 1] if wsts is not None else None
+                wst = wsts[q] if wsts is not None else None
                 if wst is not None:
                     ev = torch.cuda.Event()
                     ev.record(main)                      # gbuf[l] is complete at this point of the current stream

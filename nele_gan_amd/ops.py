@@ -1,5 +1,6 @@
 """Thin Python wrappers over the dense / glue entry points of libnele_hip.so (no arithmetic here)."""
 import ctypes
+import os
 
 import torch
 
@@ -65,6 +66,14 @@ class Geom:
         self.Ktot = KH * KW * C
         vals = [H, W, C, ih0, iw0, Hout, Wout, KW * C, W * C, self.Ktot, OH, OW, OC, oh0, ow0]
         self.arr = (c_int * 15)(*vals)
+
+
+def side_stream(device):
+    """A new side stream - or, with NELE_SERIAL=1 (diagnostic: every kernel then runs alone and a rocprofv3 kernel trace shows
+    isolated durations), the current stream itself, which serialises the whole step."""
+    if os.environ.get('NELE_SERIAL', '0') == '1':
+        return torch.cuda.current_stream(device)
+    return torch.cuda.Stream(device=device)
 
 
 # bench.py sets PROFILE = {tag: [(start_event, end_event), ...]} to time one tagged kernel with HIP events

@@ -66,6 +66,7 @@ class GanTrainer:
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
         self._side = None
         self._side2 = None
+        self._fside = None
         self.world = ndist.world_size()
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
@@ -78,10 +79,27 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- features (dataloader.py:30-42)
     def features(self, clean_wav, noise_wav):
-        """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64)."""
-        clean_spec, clean_band = au.stft_band(clean_wav, p_power)
+        """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64).
+        The noise branch (STFT -> IMCRA, a 1.1 ms scan that is serial over frames and fills 1/8 of the GPU) heads the step's critical
+        path, so it is issued first; the clean STFT + band energies run beside it on their own stream."""
+        main = torch.cuda.current_stream()
+        if self._fside is None:
+            self._fside = ops.side_stream(self.device)
+        fs_ = self._fside
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        with torch.cuda.stream(fs_):
+            fs_.wait_event(ev0)
+            clean_spec, clean_band = au.stft_band(clean_wav, p_power)
+            evc = torch.cuda.Event()
+            evc.record(fs_)
         noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False)
         _, noise_band = au.imcra_band(noise_spec, p_power)
+        main.wait_event(evc)
+        clean_spec.record_stream(main)
+        clean_band.record_stream(main)
+        if clean_wav.is_cuda:
+            clean_wav.record_stream(fs_)
         return {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec}
 
     # ---------------------------------------------------------------- G-step (train_nele.py:122-156)
@@ -163,7 +181,7 @@ class GanTrainer:
         # stream runs D's forward pass, which does not need the targets; the loss waits for them.
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = ops.side_stream(self.device)
         side = self._side
         L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
         start = torch.cuda.Event()
@@ -176,7 +194,7 @@ class GanTrainer:
                 split = mt.SiibSplit(x)
                 split.clean_part()
         if self._side2 is None:
-            self._side2 = torch.cuda.Stream(device=self.device)
+            self._side2 = ops.side_stream(self.device)
         B_, T_ = clean_wav.shape[0], 1 + clean_wav.shape[1] // 256
         # D's spectral-norm iteration and weight layouts depend on its parameters only: they run on a side stream ahead of each of D's two
         # forward passes (beside the generator's forward pass / beside generate) instead of at the head of those passes
@@ -195,7 +213,7 @@ class GanTrainer:
         ready = torch.cuda.Event()
         ready.record(main)
         if self._side2 is None:
-            self._side2 = torch.cuda.Stream(device=self.device)
+            self._side2 = ops.side_stream(self.device)
         side2 = self._side2
         cols = {}
         with torch.cuda.stream(side):
