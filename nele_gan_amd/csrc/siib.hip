@@ -124,14 +124,18 @@ __device__ double kth_largest(const double* __restrict__ v, int n, int r, double
 }
 
 // s1a / s2a: frame power (dB) of the base (tiled = 0) or M-times tiled (tiled = 1) clean signal.
-// grid (ceil(NT/4), B), block 256 (one wave per frame)
-__global__ __launch_bounds__(256) void siib_db_kernel(const float* __restrict__ x, int L, SiibWs ws, int tiled) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63, f = blockIdx.x * 4 + (threadIdx.x >> 6);
+// grid (ceil(frames / 4), B), block 256 (one wave per frame).  The tiled pass only computes what the base pass has not: frames
+// f < n1 of the tiled signal ARE the base frames (no wrap-around, same samples, same arithmetic), and frames f >= Pf repeat frame
+// f - Pf (siib_compact_kernel fills them in), so it covers n1 <= f < min(n_tiled, Pf) - two frames when L is a multiple of 200.
+__global__ __launch_bounds__(256) void siib_db_kernel(const float* __restrict__ x, int L, SiibWs ws, int tiled, int Pf) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     long long total = L;
     int nf = nframes_of(L);
     if (tiled) {
+        f += nf;                                           // first frame the base pass did not produce
         total = (long long)ws.info[4 * b] * L;
-        nf = ws.info[4 * b + 1];
+        nf = min(ws.info[4 * b + 1], Pf);
     }
     if (f >= nf || f >= ws.NT) return;
     const double e = frame_db(x + (size_t)b * L, L, total, f, lane);
@@ -166,11 +170,14 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws, int Pf) {
     __shared__ int scan[256];
     __shared__ int base;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const double* xdb = ws.xdb + (size_t)b * ws.NT;
+    double* xdb = ws.xdb + (size_t)b * ws.NT;
     int* info = ws.info + 4 * b;
     int n2 = info[1];
     int status = info[3];
     if (n2 > ws.NT) { n2 = ws.NT; status |= 2; }
+    if (Pf < n2)
+        for (int f = Pf + tid; f < n2; f += 256) xdb[f] = xdb[f % Pf];   // frame f repeats frame f - Pf (sources are all < Pf: no hazard)
+    __syncthreads();
     const int ind = round_half_even_pos((double)n2 * 0.999) - 1;
     const double thr = kth_largest(xdb, n2, n2 - 1 - ind, red, nullptr) - 40.0;
     if (tid == 0) base = 0;
@@ -756,15 +763,19 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     while (r) { const int t = g % r; g = r; r = t; }
     static const bool dedup = [] { const char* e = getenv("NELE_SIIB_DEDUP"); return !(e && e[0] == '0'); }();
     const int Pf = dedup ? L / g : 0x7fffffff;               // frame period of the tiled signal (NELE_SIIB_DEDUP=0: A/B switch, every frame computed)
+    const int n1 = (int)(((long long)L - SB_WLEN + SB_SHIFT - 1) / SB_SHIFT);   // frames of the un-tiled signal (L > 400 checked above)
     const bool vad = (phase == 0 || phase == 1 || phase == 3);
     const bool sx = vad, sy = (phase == 0 || phase == 1 || phase == 4);
     const bool eig = (phase == 0 || phase == 2 || phase == 3);
     const bool fin = (phase == 0 || phase == 2 || phase == 4);
     if (vad) {
         hipLaunchKernelGGL(siib_g2_kernel, dim3(SB_J), dim3(256), 0, s, ws.g2, ws.tab, ws.g2t);
-        hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0);
+        hipLaunchKernelGGL(siib_db_kernel, dim3((n1 + 3) / 4, B), dim3(256), 0, s, x, L, ws, 0, Pf);
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
-        hipLaunchKernelGGL(siib_db_kernel, dim3((ws.NT + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1);
+        {
+            const int last = Pf < ws.NT ? Pf : ws.NT;            // tiled frames the base pass and the period do not give
+            if (last > n1) hipLaunchKernelGGL(siib_db_kernel, dim3((last - n1 + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1, Pf);
+        }
         hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws, Pf);
     }
     if (sx || sy) {
