@@ -368,9 +368,24 @@ extern "C" int nele_gain_istft(const float* alpha2, const void* spec, int B, int
     return NELE_OK;
 }
 
+// PCM_16 round trip alone (no level normalisation: nothing per utterance to reduce): plain element-wise pass over the whole batch
+__global__ void wav_quant_kernel(float* __restrict__ wav, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float q = rintf(wav[i] * 32767.f);
+        q = fminf(fmaxf(q, -32768.f), 32767.f);
+        wav[i] = q / 32768.f;
+    }
+}
+
 extern "C" int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream) {
     NELE_CHECK_ARG(wav && B > 0 && N > 0, "nele_wav_post: bad arguments");
     if (target_rms <= 0.f && !pcm16) return NELE_OK;
+    if (target_rms <= 0.f) {
+        const size_t n = (size_t)B * N;
+        hipLaunchKernelGGL(wav_quant_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, as_stream(stream), wav, n);
+        NELE_CHECK_LAUNCH("nele_wav_post");
+        return NELE_OK;
+    }
     hipLaunchKernelGGL(wav_post_kernel, dim3(B), dim3(256), 0, as_stream(stream), wav, N, target_rms, pcm16);
     NELE_CHECK_LAUNCH("nele_wav_post");
     return NELE_OK;
