@@ -60,7 +60,8 @@ def imcra_band(spec, power=1.0 / 6, want_psd=False):
         raise ValueError("imcra_band: spec must be [B, T, 257] complex64")
     spec = spec.contiguous()
     B, T, _ = spec.shape
-    psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=spec.device) if want_psd else None
+    # the PSD buffer is always handed over: with it the kernel computes the band feature from the PSD after the serial scan instead of inside it
+    psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=spec.device)
     band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=spec.device)
     call('nele_imcra_band', ptr(spec), B, T, float(power), ptr(psd), ptr(band), stream())
     return psd, band

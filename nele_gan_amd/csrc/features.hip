@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
 // neighbour bins exchanged through LDS.  float32 / float64 staging follows numpy (see oracle/features.py).
 #define IMCRA_THREADS 320
 struct ImcraLds {
+    double y2[2][NELE_NBINS + 2];   // |Y|^2 of the frame, by frame parity
     double a[NELE_NBINS + 2];
     double b[NELE_NBINS + 2];
     double st[8][NELE_NBINS];
@@ -119,6 +120,9 @@ __device__ __forceinline__ double fsmooth3(const double* v, int k, double w0, do
     return (w0 * v[k] + w1 * v[k + 1]) + w2 * v[k + 2];  // v is offset by one: v[k+1] is bin k
 }
 
+// BAND_IN_LOOP = false: the band feature is left to band_from_psd_kernel (parallel over frames); the serial loop then has two
+// barriers per frame instead of four and no 64-band reduction on the wave that paces it.
+template <bool BAND_IN_LOOP>
 __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2* __restrict__ spec, int T, float power,
                                                                    float* __restrict__ psd, float* __restrict__ band) {
     __shared__ ImcraLds s;
@@ -147,14 +151,15 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
         if (act) {
             const float h = np_cabsf(y.x, y.y);                                   // np.abs(complex64)
             Y2f = h * h;                                                          // **2 on a float32 array
-            s.a[k + 1] = (double)Y2f;
-            if (edge_lo) s.a[0] = (double)Y2f;
-            if (edge_hi) s.a[NELE_NBINS + 1] = (double)Y2f;
+            double* y2 = s.y2[l & 1];
+            y2[k + 1] = (double)Y2f;
+            if (edge_lo) y2[0] = (double)Y2f;
+            if (edge_hi) y2[NELE_NBINS + 1] = (double)Y2f;
         }
         __syncthreads();
         if (act) {
             const double Y2 = (double)Y2f;
-            const double Sf = fsmooth3(s.a, k, w0, w1, w2);
+            const double Sf = fsmooth3(s.y2[l & 1], k, w0, w1, w2);
             // ---- decision-directed a-priori SNR (imcra.py:543-557)
             const double xi_G = (l == 0) ? 1.0 : (G * G) * Gamma;
             double term;
@@ -192,7 +197,6 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
             }
         }
         if (l >= 15) {  // block-uniform branch
-            __syncthreads();  // everyone is done reading s.a (|Y|^2)
             if (act) {
                 const double IY = I * (double)Y2f;
                 s.a[k + 1] = IY;
@@ -237,18 +241,37 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
             }
             if (++j == 15) { j = 0; ++u; }
         }
-        // ---- band feature of sqrt(PSD) (audio_util.py:446-451)
-        if (act) {
-            if (psd) psd[((size_t)b * T + l) * NELE_NBINS + k] = outv;
-            const float r = sqrtf(outv);
-            s.tmp[k] = r * r;
+        if (act && psd) psd[((size_t)b * T + l) * NELE_NBINS + k] = outv;
+        if (BAND_IN_LOOP) {
+            // ---- band feature of sqrt(PSD) (audio_util.py:446-451)
+            if (act) {
+                const float r = sqrtf(outv);
+                s.tmp[k] = r * r;
+            }
+            __syncthreads();
+            // the band energy goes out raw: the float64 pow (a few hundred instructions on the wave that paces the serial loop) is applied by
+            // band_pow_kernel over all frames at once
+            if (band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = band_energy(s.tmp, k);
         }
-        __syncthreads();
-        // the band energy goes out raw: the float64 pow (a few hundred instructions on the wave that paces the serial loop) is applied by
-        // band_pow_kernel over all frames at once
-        if (band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = band_energy(s.tmp, k);
-        // next iteration's first barrier orders these reads of s.tmp / s.a against its writes
+        // LDS hazards without those barriers: |Y|^2 is double-buffered by frame parity; s.a / s.b of frame l are read after frame l's
+        // second barrier and rewritten after frame l+1's first one, which every reader has to reach first
     }
+}
+
+// band feature of sqrt(PSD) for every frame at once (audio_util.py:446-451): grid (ceil(T / 4), B), block 256 = 4 frames x 64 bands
+__global__ __launch_bounds__(256) void band_from_psd_kernel(const float* __restrict__ psd, int T, float power, float* __restrict__ band) {
+    __shared__ float tmp[4][NELE_NBINS + 3];
+    const int b = blockIdx.y, l0 = blockIdx.x * 4;
+    for (int e = threadIdx.x; e < 4 * NELE_NBINS; e += 256) {
+        const int f = e / NELE_NBINS, k = e - f * NELE_NBINS;
+        if (l0 + f < T) {
+            const float r = sqrtf(psd[((size_t)b * T + l0 + f) * NELE_NBINS + k]);
+            tmp[f][k] = r * r;
+        }
+    }
+    __syncthreads();
+    const int f = threadIdx.x >> 6, i = threadIdx.x & 63;
+    if (l0 + f < T) band[((size_t)b * T + l0 + f) * NELE_NBANDS + i] = pow_f32(band_energy(tmp[f], i), power);
 }
 
 // band[i] = band[i] ** power in place (the tail of imcra_band_kernel, parallel over frames)
@@ -350,7 +373,13 @@ extern "C" int nele_stft_band(const float* wav, int B, int L, float power, void*
 extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream) {
     NELE_CHECK_ARG(spec && B > 0 && T > 0, "nele_imcra_band: bad arguments");
     NELE_CHECK_ARG(psd || band, "nele_imcra_band: no output requested");
-    hipLaunchKernelGGL(imcra_band_kernel, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power,
+    if (psd && band) {      // noise PSD kept: the band feature is computed from it afterwards, off the serial loop
+        hipLaunchKernelGGL(imcra_band_kernel<false>, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power, psd, band);
+        hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
+        NELE_CHECK_LAUNCH("nele_imcra_band");
+        return NELE_OK;
+    }
+    hipLaunchKernelGGL(imcra_band_kernel<true>, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power,
                        psd, band);
     if (band) {
         const size_t nb = (size_t)B * T * NELE_NBANDS;
