@@ -439,6 +439,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
     const int pi = (i & 15) * 32 + (i >> 4);
     double v_i = 0.0, tk = 0.0, p_i = 0.0;
     double col_i = (i < n) ? A[i] : 0.0;
+#ifdef EC_PROF
+    long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+#endif
     for (int s = -1; s <= n - 2; ++s) {
         const bool in = (i >= s + 1) && (i < n);
         double w_i = 0.0, wpiv = 0.0;
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             if (lane == 0) red0[wv] = pv;
             __syncthreads();
             pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            EC_T(0);
             const double al = -0.5 * tk * pv;
             w_i = in ? tk * p_i + al * v_i : 0.0;
             wpiv = tk * s_ppiv + al;
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             if (lane == 0) red1[wv] = ss;
             __syncthreads();
             ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            EC_T(1);
             const double alpha = s_alpha;
             double scn = 0.0;
             betan = alpha;
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
         vnat[i] = v_i; wnat[i] = w_i;
         vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
         __syncthreads();
+        EC_T(2);
         // ---- fused pass: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r  (3 register columns + 1 LDS column)
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         if (c0 < n) {
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
                 }
             }
         }
+        EC_T(3);
         accb[rs][cl0] = acc0;
         accb[rs][cl0 + 32] = acc1;
         accb[rs][cl0 + 64] = acc2;
@@ -561,6 +568,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             const int cc = p + E4_P * tid;
             if (tid < 112 && cc >= s + 2 && cc < n) st_tagged(&xp[cc], t, tag);
         }
+        EC_T(4);
         const bool need = (i >= s + 2) && (i < n);
         if (__any(need)) {
             u32x4 qp, qc;
@@ -581,9 +589,13 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             }
             if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
         }
+        EC_T(5);
         v_i = vn_i;
         tk = tn;
     }
+#ifdef EC_PROF
+    if (tid == 0 && g == 0) for (int j = 0; j < 9; ++j) ws.lamp[j] = (double)tacc[j];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ e2

@@ -19,14 +19,15 @@ int main(int argc, char** argv) {
     hipMemcpy(A0, h.data(), sizeof(double)*h.size(), hipMemcpyHostToDevice);
     EighWs ws; eigh_layout(B, n, &ws, (char*)wsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 1; mode < 2; ++mode) {
+    for (int mode = (argc > 3 ? atoi(argv[3]) : 1); mode < (argc > 3 ? atoi(argv[3]) + 1 : 2); ++mode) {   // 1 = 8 workgroups per matrix, 4 = 4
         float best = 1e9;
         for (int it = 0; it < 4; ++it) {
             hipMemcpy(A, A0, sizeof(double)*h.size(), hipMemcpyDeviceToDevice);
             hipMemset(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            for (int b0 = 0; b0 < B; b0 += 32) { int Bc = B - b0 < 32 ? B - b0 : 32; hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws); }
+            if (mode == 4) { for (int b0 = 0; b0 < B; b0 += 64) { int Bc = B - b0 < 64 ? B - b0 : 64; hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws); } }
+            else for (int b0 = 0; b0 < B; b0 += 32) { int Bc = B - b0 < 32 ? B - b0 : 32; hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws); }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (it > 0 && ms < best) best = ms;
