@@ -3,12 +3,12 @@ f=sorted(glob.glob('gpurun_out/prof_r01c/*/*_kernel_trace.csv'))[-1]
 rows=list(csv.DictReader(open(f)))
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split('(')[0][-40:],r['Queue_Id']) for r in rows]
 ev.sort()
-im=[i for i,e in enumerate(ev) if e[2].startswith('imcra_band')]
+im=[i for i,e in enumerate(ev) if ('imcra_band' in e[2])]
 k=len(im)-2
 def step_start(idx):
     i=idx
-    while i>0 and not ev[i][2].startswith('stft_band'): i-=1
-    while i>0 and ev[i-1][2].startswith('stft_band'): i-=1
+    while i>0 and not ('stft_band' in ev[i][2]): i-=1
+    while i>0 and ('stft_band' in ev[i-1][2]): i-=1
     return i
 a=step_start(im[k]); b=step_start(im[k+1])
 t0=ev[a][0]

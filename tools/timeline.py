@@ -4,13 +4,13 @@ rows=list(csv.DictReader(open(f)))
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split('(')[0][-42:],r['Queue_Id']) for r in rows]
 ev.sort()
 # step boundaries: first stft_band of each group of 3 -> use imcra kernel (1 per step)
-im=[i for i,e in enumerate(ev) if e[2].startswith('imcra_band')]
+im=[i for i,e in enumerate(ev) if ('imcra_band' in e[2])]
 # step = from the stft preceding imcra k to the one preceding imcra k+1
 k=len(im)-2
 def step_start(idx):
     i=idx
-    while i>0 and not ev[i][2].startswith('stft_band'): i-=1
-    while i>0 and ev[i-1][2].startswith('stft_band'): i-=1
+    while i>0 and not ('stft_band' in ev[i][2]): i-=1
+    while i>0 and ('stft_band' in ev[i-1][2]): i-=1
     return i
 a=step_start(im[k]); b=step_start(im[k+1])
 t0=ev[a][0]
