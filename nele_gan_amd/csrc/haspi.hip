@@ -243,6 +243,9 @@ __device__ __forceinline__ double hp_bw1(int ch) {
 // lfilter([1,a1,a5],[1,-a1,-a2,-a3,-a4]) (DF2T), envelope = gain*|u|.  One wave per (utterance, signal): lane = part*32 +
 // channel, part 0 filters x*cos, part 1 filters x*sin; the two halves meet through one cross-lane swap per sample.
 // Returns (on the part-0 lanes) the sum of squares of the envelope; out[n*32 + ch] is written by the part-0 lanes.
+// The stored value is the SQUARED magnitude |u|^2 and the return value its plain sum: gain * sqrt(.) is applied by the point-wise
+// consumers (haspi_gain_kernel / haspi_sl_kernel, wide and memory-bound), where it is free; inside this loop - one wave per
+// (utterance, signal), issue-bound - the float64 square root was half of the instructions of a sample.
 __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ xin, int n24, const GtCoef c, double cf, int part,
                                                     double* __restrict__ out) {
     const double tpt = 2.0 * M_PI / HP_FS;
@@ -269,9 +272,9 @@ __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ x
             r2 = c.a3 * yr + r3;
             r3 = c.a4 * yr;
             const double yo = __shfl_xor(yr, 32, 64);
-            const double e = c.gain * sqrt(yr * yr + yo * yo);
-            eo[u] = e;
-            ss += (n0 + u < n24) ? e * e : 0.0;
+            const double e2 = yr * yr + yo * yo;
+            eo[u] = e2;
+            ss += (n0 + u < n24) ? e2 : 0.0;
         }
         if (part == 0) {
 #pragma unroll
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws) {
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    const double ss = hp_gammatone_wave(xin, ws.n24, hp_gt(bw1, cf), cf, part, out);
+    const GtCoef cc = hp_gt(bw1, cf);
+    const double ss = (cc.gain * cc.gain) * hp_gammatone_wave(xin, ws.n24, cc, cf, part, out);   // sum of (gain |u|)^2
     if (part == 0) {
         // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
         const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
@@ -311,10 +315,12 @@ __global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws) {
 
 // ---- h5: compression gain from the control envelope (pyhaspi2.py:982-991), point-wise, in place on ctl
 __global__ void haspi_gain_kernel(HaspiWs ws, size_t total) {
+    // the grid stride is a multiple of 32, so a thread stays on one channel: its control-filter gain is computed once
+    const int ch = (int)(threadIdx.x & 31);
+    const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
+    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i & 31);
-        const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
-        double le = fmax(ws.ctl[i], 1.0e-30);
+        double le = fmax(cgain * sqrt(ws.ctl[i]), 1.0e-30);          // control envelope = gain |u| (ctl holds |u|^2)
         le = HP_LEVEL + 20.0 * log10(le);
         le = fmin(fmax(le, 30.0), 100.0);
         const double g = -0.0 - (le - 30.0) * (1.0 - (1.0 / CR));
@@ -344,9 +350,14 @@ __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws) {
 }
 
 // ---- h7: compressed envelope = filtered gain * envelope (pyhaspi2.py:997) and eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise
-__global__ void haspi_sl_kernel(HaspiWs ws, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const double c = ws.ctl[i] * ws.env[i];
+// grid (blocks, 2 B): blockIdx.y = (utterance, signal), whose adjusted bandwidth fixes the signal filter's gain per channel
+__global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row) {
+    const int ch = (int)(threadIdx.x & 31);
+    const double sgain = hp_gt(ws.bw[(size_t)blockIdx.y * HP_NCH + ch], hp_cfreq(ch)).gain;
+    const size_t base = (size_t)blockIdx.y * per_row;
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < per_row; r += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + r;
+        const double c = ws.ctl[i] * (sgain * sqrt(ws.env[i]));      // signal envelope = gain |u| (env holds |u|^2)
         const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
         ws.env[i] = y < 0.0 ? 0.0 : y;
     }
@@ -666,7 +677,11 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
     hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_sl_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
+    {
+        const size_t per_row = (size_t)ws.n24p * HP_NCH;
+        const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
+        hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, 2 * B), dim3(256), 0, s, ws, per_row);
+    }
     hipLaunchKernelGGL(haspi_ihc_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, 2), dim3(256), 0, s, ws);
