@@ -22,6 +22,7 @@
 //       normalised cross-correlation of reference and processed sequences
 //   h12 average over bases 2-6, weighted sum, logistic map
 #include "common.h"
+#include <cstdlib>
 
 #define HP_NCH 32
 #define HP_FS 24000.0
@@ -363,6 +364,61 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row) {
     }
 }
 
+// ---- h5-h7 fused: compression gain (point-wise) -> gain low-pass lfilter([b,b],[1,a]) -> compressed envelope in dB SL, one pass.
+// The three separate kernels moved 12.6 GB arrays (B = 256) through HBM seven times for 22 ms.  The low-pass is a first-order
+// recursion with pole 0.81: its state forgets the past as 0.81^n, so a thread can start 256 samples before its chunk from a zero
+// state - the neglected history is below 0.81^256 = 4e-24 of the signal, far under the float64 rounding of the values themselves -
+// which makes the recursion parallel over chunks.  Thread = (chunk of 2048 samples, channel); block = 8 chunks x 32 channels;
+// grid (ceil(n24p / 16384), 2 B).  ctl (|u|^2 of the control bank) is only read, env (|u|^2 of the signal bank) is rewritten in place.
+#define GL_N 2048
+#define GL_W 256
+#define GL_U 8
+__global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws) {
+    const int ch = threadIdx.x & 31, row = blockIdx.y;
+    const int n0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * GL_N;
+    if (n0 >= ws.n24p) return;
+    const int n1 = min(n0 + GL_N, ws.n24p);
+    const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
+    const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
+    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1), slope = 1.0 - (1.0 / CR);
+    const double b0 = 0.095107983402496, a1 = -0.809784033195007;
+    const double* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
+    double* env = ws.env + (size_t)row * ws.n24p * HP_NCH + ch;
+    double z = 0.0;
+    for (int n = max(0, n0 - GL_W); n < n1; n += GL_U) {       // n0, GL_W and n24p are multiples of GL_U
+        double gx[GL_U], ev[GL_U];
+        const bool live = n >= n0;
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) gx[u] = ctl[(size_t)(n + u) * HP_NCH];
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < GL_U; ++u) ev[u] = env[(size_t)(n + u) * HP_NCH];
+        }
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:982-991
+            double le = fmax(cgain * sqrt(gx[u]), 1.0e-30);
+            le = HP_LEVEL + 20.0 * log10(le);
+            le = fmin(fmax(le, 30.0), 100.0);
+            const double g = -0.0 - (le - 30.0) * slope;
+            gx[u] = exp(g * (2.302585092994046 / 20.0));
+        }
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:992-995
+            const double y = b0 * gx[u] + z;
+            z = b0 * gx[u] - a1 * y;
+            gx[u] = y;
+        }
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < GL_U; ++u) {                   // pyhaspi2.py:997, 1080-1088
+                const double c = gx[u] * (sgain * sqrt(ev[u]));
+                const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
+                env[(size_t)(n + u) * HP_NCH] = y < 0.0 ? 0.0 : y;
+            }
+        }
+    }
+}
+
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
 __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -675,9 +731,13 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_control_kernel, dim3(2, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
-    hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
-    {
+    static int fused_gain = -1;
+    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
+    if (fused_gain) {
+        hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), 2 * B), dim3(256), 0, s, ws);
+    } else {                                                   // the three passes of the first version (A/B switch; serial low-pass)
+        hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
+        hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
         const size_t per_row = (size_t)ws.n24p * HP_NCH;
         const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
         hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, 2 * B), dim3(256), 0, s, ws, per_row);
