@@ -89,6 +89,16 @@ __device__ __forceinline__ double row16_sum_dpp(double v) {
     return v;
 }
 
+// value held by lane (l ^ 32): one v_permlane32_swap per 32-bit half (gfx950) instead of two ds_bpermute through the LDS crossbar
+__device__ __forceinline__ double lane_xor32(double v) {
+    const long long u = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    const bool up = (threadIdx.x & 32) != 0;
+    const unsigned l = up ? lo[0] : lo[1], h = up ? hi[0] : hi[1];
+    return __longlong_as_double(((long long)h << 32) | (long long)l);
+}
+
 // Block-wide sum of doubles through LDS scratch (>= blockDim/64 doubles); result to all threads.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     v = wave_sum(v);

@@ -272,7 +272,7 @@ __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ x
             r1 = c.a5 * xr + c.a2 * yr + r2;
             r2 = c.a3 * yr + r3;
             r3 = c.a4 * yr;
-            const double yo = __shfl_xor(yr, 32, 64);
+            const double yo = lane_xor32(yr);
             const double e2 = yr * yr + yo * yo;
             eo[u] = e2;
             ss += (n0 + u < n24) ? e2 : 0.0;
