@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
 // ---- h9b: ebm_EnvFilt (pyhaspi2.py:378-414): Hann(52)/sum FIR, "same" alignment (nhalf = 26), every 9th sample.
 // grid (ceil(nsub/EF_SUB), B, 2), block 256: the EF_SUB*9 + 52 input samples of a block (per channel, group-delay shift
 // applied while loading) are staged in LDS once; thread = (sub-frame, channel).
-#define EF_SUB 32
+#define EF_SUB 16
 #define EF_SPAN (EF_SUB * HP_SPACE + HP_NFILT)
 __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
     __shared__ double benv[HP_NFILT];
