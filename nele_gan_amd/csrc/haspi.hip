@@ -625,6 +625,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
             double wxc[4], wxs[4], wyc[4], wys[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { wxc[q] = sxc[e0 + q]; wxs[q] = sxs[e0 + q]; wyc[q] = syc[e0 + q]; wys[q] = sys_[e0 + q]; }
+#pragma unroll 4                                               // the register window then rotates by renaming instead of 24 moves per tap
             for (int i = 0; i <= nfir; ++i) {
                 const double w = bk[i];
 #pragma unroll
