@@ -210,6 +210,45 @@ __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws) {
     }
 }
 
+// The same filter, parallel over chunks: the slowest pole of the cascade has modulus 0.937 (high-pass section) and 0.937^1024 = 2e-29,
+// so a thread that starts 1024 samples before its 2048-sample chunk from a zero state reproduces the serial filter to well below the
+// rounding of the samples (two active lanes per utterance made the serial kernel 7 ms at B = 256).  grid (ceil(chunks / 64), 2 B).
+#define ME_N 2048
+#define ME_W 1024
+__global__ __launch_bounds__(64) void haspi_midear_par_kernel(HaspiWs ws) {
+    const int row = blockIdx.y, n0 = (blockIdx.x * 64 + threadIdx.x) * ME_N;
+    if (n0 >= ws.n24p) return;
+    const int n1 = min(n0 + ME_N, ws.n24p);
+    const float* src = ws.r24 + (size_t)row * ws.n24p;
+    double* dst = ws.mid + (size_t)row * ws.n24p;
+    const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
+    const double c0 = 0.937260390269893, c1 = -1.874520780539785, c2 = 0.937260390269893, d1 = -1.870580640735279, d2 = 0.878460920344291;
+    double z = 0.0, w0 = 0.0, w1 = 0.0;
+    for (int n = max(0, n0 - ME_W); n < n1; n += HP_CH) {
+        float xin[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH / 4; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(src + n + 4 * u);
+            xin[4 * u] = v.x; xin[4 * u + 1] = v.y; xin[4 * u + 2] = v.z; xin[4 * u + 3] = v.w;
+        }
+        double yo[HP_CH];
+#pragma unroll
+        for (int u = 0; u < HP_CH; ++u) {
+            const double x = (double)xin[u];
+            const double y1 = b0 * x + z;
+            z = b1 * x - a1 * y1;
+            const double y2 = c0 * y1 + w0;
+            w0 = c1 * y1 - d1 * y2 + w1;
+            w1 = c2 * y1 - d2 * y2;
+            yo[u] = y2;
+        }
+        if (n >= n0) {
+#pragma unroll
+            for (int u = 0; u < HP_CH / 2; ++u) *reinterpret_cast<double2*>(dst + n + 2 * u) = make_double2(yo[2 * u], yo[2 * u + 1]);
+        }
+    }
+}
+
 struct GtCoef { double a1, a2, a3, a4, a5, gain; };
 
 __device__ __forceinline__ double hp_cfreq(int ch) {
@@ -729,7 +768,10 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     const unsigned pw_blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
     hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, 2), dim3(256), 0, s, x, y, L, fs_in, ws);
-    hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
+    static int par_iir = -1;
+    if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
+    if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, 2 * B), dim3(64), 0, s, ws);
+    else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_control_kernel, dim3(2, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
     static int fused_gain = -1;
