@@ -322,13 +322,12 @@ __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ x
     return ss;
 }
 
-// The same banks parallel over chunks of GT_LC samples.  Each wave (utterance, signal, chunk) (i) replays the demodulator's rotation
+// The same banks parallel over chunks of lc samples (chosen by the host: about two waves per SIMD).  Each wave (utterance, signal, chunk) (i) replays the demodulator's rotation
 // recurrence from sample 0 up to its start - three operations per sample, the identical sequence, so cos / sin carry the same
 // accumulated rounding as in the serial kernel - and (ii) runs the filters from a zero state GT_W = 8192 samples before its chunk: the
 // slowest channel (80 Hz, BW = 1) has the quadruple pole a = 0.99115, whose response n^3 a^n / 6 is 2e-21 at n = 8192, 1e-27 of the
-// filter's gain.  1.34 x the work on 4 x the waves: the serial kernels kept one wave on a quarter of the SIMDs.
+// filter's gain.  The serial kernels keep one wave on 2 B of the 1024 SIMDs.
 // ss partials go to ws.ssp [row][chunk][32] and are added in chunk order by haspi_bw_kernel.
-#define GT_LC 24576
 #define GT_W 8192
 #define GT_MAXC 16
 __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn, double sn) {
@@ -337,10 +336,10 @@ __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn,
     cold = arg;
 }
 __device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ xin, int n24, int n24p, const GtCoef c, double cf, int part,
-                                                     double* __restrict__ out, int chunk) {
+                                                     double* __restrict__ out, int chunk, int lc) {
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
-    const int n0 = chunk * GT_LC, n1 = min(n0 + GT_LC, n24p), start = max(0, n0 - GT_W);
+    const int n0 = chunk * lc, n1 = min(n0 + lc, n24p), start = max(0, n0 - GT_W);
     double cold = 1.0, sold = 0.0;
     for (int n = 1; n < start; ++n) hp_rotate(cold, sold, cn, sn);      // state before sample `start` = R^(start-1)
     double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -373,12 +372,12 @@ __device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ 
     return ss;
 }
 // grid (chunks, 2, B), block 64
-__global__ __launch_bounds__(64) void haspi_control_par_kernel(HaspiWs ws) {
+__global__ __launch_bounds__(64) void haspi_control_par_kernel(HaspiWs ws, int lc) {
     const int b = blockIdx.z, sig = blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    const double ss = hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(bw1, cf), cf, part, out, blockIdx.x);
+    const double ss = hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(bw1, cf), cf, part, out, blockIdx.x, lc);
     if (part == 0) ws.ssp[(((size_t)b * 2 + sig) * GT_MAXC + blockIdx.x) * HP_NCH + ch] = ss;
 }
 // eb_BWadjust from the chunk partials.  grid 2 B, block 32
@@ -396,13 +395,13 @@ __global__ void haspi_bw_kernel(HaspiWs ws, int nchunks) {
     else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
     ws.bw[(size_t)row * HP_NCH + ch] = BW;
 }
-__global__ __launch_bounds__(64) void haspi_signal_par_kernel(HaspiWs ws) {
+__global__ __launch_bounds__(64) void haspi_signal_par_kernel(HaspiWs ws, int lc) {
     const int b = blockIdx.z, sig = blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch);
     const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    (void)hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(BW, cf), cf, part, out, blockIdx.x);
+    (void)hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(BW, cf), cf, part, out, blockIdx.x, lc);
 }
 
 // ---- h3: control bank + bandwidth adjustment. grid (2, B), block 64
@@ -854,11 +853,15 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
     if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, 2 * B), dim3(64), 0, s, ws);
     else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
-    const int gt_chunks = (ws.n24p + GT_LC - 1) / GT_LC;
-    if (par_iir && gt_chunks > 1 && gt_chunks <= GT_MAXC) {
-        hipLaunchKernelGGL(haspi_control_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws);
+    int gt_chunks = 2048 / (2 * B);                         // about two waves per SIMD (256 CUs x 4 SIMDs); measured at B = 256: 2 chunks 124.8, 4 chunks 122.0 ms/step
+    if (gt_chunks > GT_MAXC) gt_chunks = GT_MAXC;
+    if (gt_chunks > ws.n24p / GT_W) gt_chunks = ws.n24p / GT_W;   // a chunk shorter than its warm-up only multiplies the work
+    int gt_lc = ws.n24p;
+    if (gt_chunks > 1) { gt_lc = ((ws.n24p + gt_chunks - 1) / gt_chunks + HP_CH - 1) / HP_CH * HP_CH; gt_chunks = (ws.n24p + gt_lc - 1) / gt_lc; }
+    if (par_iir && gt_chunks > 1) {
+        hipLaunchKernelGGL(haspi_control_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws, gt_lc);
         hipLaunchKernelGGL(haspi_bw_kernel, dim3(2 * B), dim3(32), 0, s, ws, gt_chunks);
-        hipLaunchKernelGGL(haspi_signal_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws);
+        hipLaunchKernelGGL(haspi_signal_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws, gt_lc);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(2, B), dim3(64), 0, s, ws);
         hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
