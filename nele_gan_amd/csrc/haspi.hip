@@ -702,10 +702,14 @@ __constant__ double c_modcf[HP_NMOD] = {2, 6, 10, 16, 25, 40, 64, 100, 160, 256}
 __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
 #define HP_TILE 1024          // outputs per tile: 256 threads x 4 consecutive outputs (sliding register window over the taps)
 #define HP_MAXFIR 614
+// LDS position of sequence element e: a thread reads elements 4 tid + c, so the four residues mod 4 live in four sub-arrays and a
+// wave's reads are consecutive (the plain layout put a wave's 64 reads on 8 banks)
+#define MF_L4 ((HP_TILE + HP_MAXFIR + 4 + 3) / 4 + 1)
+#define MF_POS(e) ((((e) & 3) * MF_L4) + ((e) >> 2))
 
 __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     __shared__ double bk[HP_MAXFIR + 1];
-    __shared__ double sxc[HP_TILE + HP_MAXFIR + 4], sxs[HP_TILE + HP_MAXFIR + 4], syc[HP_TILE + HP_MAXFIR + 4], sys_[HP_TILE + HP_MAXFIR + 4];
+    __shared__ double sxc[4 * MF_L4], sxs[4 * MF_L4], syc[4 * MF_L4], sys_[4 * MF_L4];
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[2 * b];
@@ -732,7 +736,8 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
                 c = SQ2 * cos(ang);
                 s = SQ2 * sin(ang);
             }
-            sxc[e] = vx * c; sxs[e] = vx * s; syc[e] = vy * c; sys_[e] = vy * s;
+            const int se = MF_POS(e);
+            sxc[se] = vx * c; sxs[se] = vx * s; syc[se] = vy * c; sys_[se] = vy * s;
         }
         __syncthreads();
         // thread -> outputs t = t0 + 4 tid + q, q = 0..3:  u[t] = sum_i b[i] z[t + nh - i]  (LDS index 4 tid + q + nfir - i)
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
             // window registers hold z[e0 - i + q] for q = 0..3
             double wxc[4], wxs[4], wyc[4], wys[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { wxc[q] = sxc[e0 + q]; wxs[q] = sxs[e0 + q]; wyc[q] = syc[e0 + q]; wys[q] = sys_[e0 + q]; }
+            for (int q = 0; q < 4; ++q) { const int se = MF_POS(e0 + q); wxc[q] = sxc[se]; wxs[q] = sxs[se]; wyc[q] = syc[se]; wys[q] = sys_[se]; }
 #pragma unroll 4                                               // the register window then rotates by renaming instead of 24 moves per tap
             for (int i = 0; i <= nfir; ++i) {
                 const double w = bk[i];
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
 #pragma unroll
                 for (int q = 3; q > 0; --q) { wxc[q] = wxc[q - 1]; wxs[q] = wxs[q - 1]; wyc[q] = wyc[q - 1]; wys[q] = wys[q - 1]; }
                 const int en = e0 - i - 1;
-                if (en >= 0) { wxc[0] = sxc[en]; wxs[0] = sxs[en]; wyc[0] = syc[en]; wys[0] = sys_[en]; }
+                if (en >= 0) { const int se = MF_POS(en); wxc[0] = sxc[se]; wxs[0] = sxs[se]; wyc[0] = syc[se]; wys[0] = sys_[se]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
