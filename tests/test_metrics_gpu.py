@@ -188,3 +188,27 @@ def test_siib_period_shortcut_is_bit_identical_to_computing_every_frame(tmp_path
         subprocess.run([sys.executable, '-c', _AB_CHILD, os.path.dirname(HERE), out], check=True, env=env, timeout=240)
         res.append(np.load(out))
     assert res[0].tobytes() == res[1].tobytes()
+
+
+_HASPI_AB_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+c, v = synth.batch(4, 40000, start=33)
+raw, mapped = mt.batch_haspi(c, c + v, dither=None)
+np.save(sys.argv[2], raw.double().cpu().numpy())
+'''
+
+
+def test_haspi_chunk_parallel_filters_equal_the_serial_ones(tmp_path):
+    """The linear recurrences (middle ear, gammatone banks, gain low-pass) run parallel over chunks with a warm-up that makes the
+    neglected history < 1e-20 of the signal; A/B against the serial kernels of the same library (switches are read once per process)."""
+    import subprocess
+    import sys
+    res = []
+    for env in ({}, {'NELE_HASPI_PAR_IIR': '0', 'NELE_HASPI_FUSED_GAIN': '0'}):
+        out = str(tmp_path / ('haspi_%d.npy' % len(res)))
+        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **env), timeout=240)
+        res.append(np.load(out))
+    assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
+    np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
