@@ -47,6 +47,35 @@ def cpu_baseline(metrics, length, n_utt, seed_start=9000):
                                             {k: round(t, 2) for k, t in step.times.items()})}
 
 
+def epoch_equivalent(tr, cw, nw, K, utts):
+    """The reference's per-utterance work mix of one GAN epoch (train_nele.py:110-429): one G-step, one generated sample, true targets of
+    the generated and of the pre-enhanced 'DRC' example, and 2 x 3 D-steps (both examples in each of the three passes; the 1/30 history
+    replay of pass B is left out).  Plain sequence on the current stream - no cross-stage overlap - so this is a lower bound."""
+    import torch
+    drc = (cw * 1.5).contiguous()                       # stands for the pre-enhanced example of the same utterances
+    def unit():
+        f = tr.features(cw, nw)
+        tr.g_step(f['clean_band'], f['noise_band'])
+        enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+        L = enh.shape[1]
+        t_gen = tr.true_metrics(cw, enh, nw)
+        t_drc = tr.true_metrics(cw, drc[:, :L], nw)
+        d_gen = tr.d_inputs(enh, f['noise_band'], f['clean_band'])
+        d_drc = tr.d_inputs(drc[:, :L].contiguous(), f['noise_band'], f['clean_band'])
+        for _ in range(3):
+            tr.d_step(d_gen, t_gen)
+            tr.d_step(d_drc, t_drc)
+    unit()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        unit()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    return {'value': utts / dt, 'unit': 'utterances/s', 'ms_per_unit': dt * 1e3,
+            'mix': '1 G-step + generate + 2 x targets + 6 D-steps per batch, sequential'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -57,6 +86,9 @@ def main():
     ap.add_argument('--metrics', default='siib&estoi')
     ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
+    ap.add_argument('--epoch-equivalent', type=int, default=0, metavar='K',
+                    help='also time K units of the reference epoch mix per batch (SURVEY 8d): 1 G-step, generate, targets of the generated and of the\n'
+                         'pre-enhanced (DRC) example, 6 D-steps (2 examples x 3 passes, train_nele.py:342-426); reported as "epoch_equivalent"')
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'],
                     help='MFMA operand type of the discriminator conv forward / data-gradient passes (f32 accumulate; BASELINE configs[1] names bf16)')
     a = ap.parse_args()
@@ -167,6 +199,8 @@ def main():
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}
             sys.stderr.write('stage ms: %s\n' % json.dumps({k: round(x, 3) for k, x in br.items()}))
+        if a.epoch_equivalent > 0:
+            out['epoch_equivalent'] = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)
         if world == 1 and a.cpu_utts > 0:
             out['cpu_baseline'] = cpu_baseline(metrics, a.length, a.cpu_utts)
         print(json.dumps(out))
