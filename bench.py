@@ -47,6 +47,27 @@ def cpu_baseline(metrics, length, n_utt, seed_start=9000):
                                             {k: round(t, 2) for k, t in step.times.items()})}
 
 
+def inference_rate(tr, batch, K, rank):
+    """inference.py:79-117 on a batch of 8 s utterances (BASELINE configs[4] per GPU: pure replicas, no collective)."""
+    import torch
+    from nele_gan_amd import synth
+    from nele_gan_amd.inference import Enhancer
+    c, v = synth.batch(batch, 128000, start=5000 + rank * batch)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    enh = Enhancer(G=tr.G)
+    enh.G.precision = tr.G.precision
+    enh.enhance(cw, nw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = enh.enhance(cw, nw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    tr.G.train()
+    return {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_batch': dt * 1e3, 'utterance_seconds': 8.0, 'batch': batch,
+            'realtime_factor': batch * 8.0 / dt}
+
+
 def epoch_equivalent(tr, cw, nw, K, utts):
     """The reference's per-utterance work mix of one GAN epoch (train_nele.py:110-429): one G-step, one generated sample, true targets of
     the generated and of the pre-enhanced 'DRC' example, and 2 x 3 D-steps (both examples in each of the three passes; the 1/30 history
@@ -86,6 +107,8 @@ def main():
     ap.add_argument('--metrics', default='siib&estoi')
     ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
+    ap.add_argument('--inference', type=int, default=0, metavar='K',
+                    help='also time K batches of the inference path (BASELINE configs[4]: 8 s utterances, features -> G -> resynthesis -> RMS 0.03 -> PCM_16); reported as "inference"')
     ap.add_argument('--epoch-equivalent', type=int, default=0, metavar='K',
                     help='also time K units of the reference epoch mix per batch (SURVEY 8d): 1 G-step, generate, targets of the generated and of the\n'
                          'pre-enhanced (DRC) example, 6 D-steps (2 examples x 3 passes, train_nele.py:342-426); reported as "epoch_equivalent"')
@@ -199,6 +222,8 @@ def main():
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}
             sys.stderr.write('stage ms: %s\n' % json.dumps({k: round(x, 3) for k, x in br.items()}))
+        if a.inference > 0:
+            out['inference'] = inference_rate(tr, a.batch, a.inference, rank)
         if a.epoch_equivalent > 0:
             out['epoch_equivalent'] = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)
         if world == 1 and a.cpu_utts > 0:
