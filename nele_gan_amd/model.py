@@ -164,12 +164,15 @@ class _GFn(torch.autograd.Function):
     def forward(ctx, x, y, anchor, module):
         ctx.module = module
         ctx.key = module._forward_impl(x, y)
-        ctx.mask = module._last_mask
-        return ctx.mask
+        mask = module._last_mask
+        module._last_mask = None             # the output must not stay reachable from ctx except through save_for_backward:
+        ctx.save_for_backward(mask)          # output -> grad_fn -> ctx -> output is a cycle the collector cannot free (2 MB per G-step)
+        return mask
 
     @staticmethod
     def backward(ctx, dmask):
-        ctx.module._backward_impl(dmask.contiguous(), ctx.key, ctx.mask)
+        (mask,) = ctx.saved_tensors
+        ctx.module._backward_impl(dmask.contiguous(), ctx.key, mask)
         return None, None, None, None
 
 
@@ -304,7 +307,8 @@ class Generator_Conv1D_cLN(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _GFn.apply(x, y, self._anchor.get(x.device), self)
         self._forward_impl(x, y)
-        return self._last_mask
+        mask, self._last_mask = self._last_mask, None
+        return mask
 
     # ---- backward: accumulates into the flat gradient buffer
     def _backward_impl(self, dmask, key, mask):
@@ -415,12 +419,15 @@ class _DFn(torch.autograd.Function):
         ctx.module = module
         ctx.key = module._forward_impl(din)
         ctx.need_din = din.requires_grad
-        ctx.score = module._last_score
-        return ctx.score
+        score = module._last_score
+        module._last_score = None
+        ctx.save_for_backward(score)
+        return score
 
     @staticmethod
     def backward(ctx, dscore):
-        ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, ctx.score)
+        (score,) = ctx.saved_tensors
+        ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, score)
         return ddin, None, None
 
 
@@ -601,7 +608,8 @@ class _DiscriminatorBase(nn.Module):
         if torch.is_grad_enabled() and (din.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _DFn.apply(din, self._anchor.get(din.device), self)
         self._forward_impl(din)
-        return self._last_score
+        score, self._last_score = self._last_score, None
+        return score
 
     def forward(self, x):
         """x: [B, Cin, 64, T] as in the reference (model.py:118)."""

@@ -55,3 +55,22 @@ def test_inference_path_rms_and_length():
     assert out.shape == (2, 256 * (32000 // 256))
     rms = out.pow(2).mean(dim=1).sqrt().cpu().numpy()
     np.testing.assert_allclose(rms, 0.03, rtol=1e-5)                   # inference.py:109
+
+
+def test_steps_do_not_accumulate_device_memory():
+    """A custom autograd Function that keeps its own output on ctx forms an uncollectable cycle (2 MB per G-step once)."""
+    import gc
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(4, 24000, start=5)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    tr = GanTrainer('estoi')
+    for _ in range(3):
+        tr.canonical_step(cw, nw)
+    torch.cuda.synchronize(); gc.collect()
+    m0 = torch.cuda.memory_allocated()
+    for _ in range(40):
+        tr.canonical_step(cw, nw)
+    torch.cuda.synchronize(); gc.collect()
+    growth = torch.cuda.memory_allocated() - m0
+    assert growth < 40 * 4096, "device memory grows by %d bytes per step" % (growth // 40)
