@@ -74,3 +74,27 @@ def test_steps_do_not_accumulate_device_memory():
     torch.cuda.synchronize(); gc.collect()
     growth = torch.cuda.memory_allocated() - m0
     assert growth < 40 * 4096, "device memory grows by %d bytes per step" % (growth // 40)
+
+
+def test_d_epoch_three_passes_and_history_replay():
+    """train_nele.py:342-426: pass A on the current list, pass B on 1/30 of the (shuffled) history + current, history += current,
+    pass C on the current list again."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(2, 16000, start=9)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    tr = GanTrainer('estoi')
+    f = tr.features(cw, nw)
+    din = tr.d_inputs(cw, f['noise_band'], f['clean_band'])
+    item = lambda i: (din[i % 2].clone(), torch.tensor([0.25 + 0.01 * i], device='cuda'))
+    seen = []
+    orig = tr.d_step
+    tr.d_step = lambda d, t: (seen.append(d.shape[0]), orig(d, t))[1]
+    tr.history = [item(i) for i in range(60)]                       # 60 // 30 = 2 replayed items
+    cur = [item(100 + i) for i in range(5)]
+    w0 = tr.D.layers[4].weight_orig.detach().clone()
+    tr.d_epoch(cur, batch=4)
+    assert sum(seen) == 5 + (2 + 5) + 5                             # items seen by D in passes A, B, C
+    assert seen == [4, 1, 4, 3, 4, 1]                               # batches of at most 4
+    assert len(tr.history) == 65
+    assert not torch.equal(w0, tr.D.layers[4].weight_orig.detach())
