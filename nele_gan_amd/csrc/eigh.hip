@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
 // arrays: 0 a, 1 b, 2 c (stored at step+1, next to the iterate element it meets in the forward sweep), 3 d2, 4 x, 5 1/a
 #define IV_F 32     // forward-sweep chunk (steps)
 #define IV_B 16     // backward-sweep chunk (steps)
-__global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in) {
+__global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in, int extra) {
     __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
     for (int i = threadIdx.x; i < n; i += 64) { d[i] = ws.d[(size_t)b * n + i]; e[i] = ws.e[(size_t)b * n + i]; }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
             }
         }
         if (nrm < dtpcrt) continue;
-        if (++nrmchk < 3) continue;
+        if (++nrmchk < extra + 1) continue;   // dstein: EXTRA = 2 more sweeps after the growth criterion is met
         break;
     }
     const double inv = 1.0 / sqrt(s2);
@@ -1073,7 +1073,9 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }
     hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 256 / EG_NL - 1) / (256 / EG_NL), B), dim3(256), 0, s, n, ws, lam);
-    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam);
+    static int iv_extra = -1;
+    if (iv_extra < 0) { const char* e_ = getenv("NELE_EIGH_INVIT_EXTRA"); iv_extra = e_ ? atoi(e_) : 2; }
+    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);
     const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * ((n + 15) & ~15) + 2 * BT_CH);
     static bool attr_done = false;
     if (!attr_done) {
