@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 // workgroup) lives in LDS.
 #define E4_P 4
 #define E4_RI 28
-__global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws) {
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop) {
     __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
     __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
     __shared__ double accb[16][128];
@@ -592,10 +592,136 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
         EC_T(5);
         v_i = vn_i;
         tk = tn;
+        if (s == s_stop) {
+            // hand-over to eigh_tridiag_tail_kernel: the trailing block (rows / columns >= s + 2, updated through reflector s) goes back
+            // to A in place - those rows only receive reflector rows later - and the per-element state of the next iteration to ws.zt
+            const int base = s + 2;
+#pragma unroll
+            for (int ri = 0; ri < E4_RI; ++ri) {
+                const int r = rs + 16 * ri;
+                if (r >= base && r < n) {
+                    if (c0 >= base && c0 < n) A[(size_t)r * n + c0] = a0[ri];
+                    if (c1 >= base && c1 < n) A[(size_t)r * n + c1] = a1[ri];
+                    if (c2 >= base && c2 < n) A[(size_t)r * n + c2] = a2[ri];
+                    if (has3 && c3 >= base && c3 < n) A[(size_t)r * n + c3] = aL[ri][rs][cl0];
+                }
+            }
+            if (p == 0 && i < n) {
+                double* st = ws.zt + (size_t)b * n * EG_MAXN;
+                st[i] = v_i; st[EG_MAXN + i] = p_i; st[2 * EG_MAXN + i] = col_i;
+                if (i == 0) st[3 * EG_MAXN] = tk;
+            }
+            break;
+        }
     }
 #ifdef EC_PROF
     if (tid == 0 && g == 0) for (int j = 0; j < 9; ++j) ws.lamp[j] = (double)tacc[j];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------ e1, tail
+// The last ET_M = 128 steps of the tridiagonalisation (and whole matrices with n <= 128) in ONE workgroup per matrix with the trailing
+// block in LDS: the cluster kernel's step costs 5 us whatever is left of the matrix (exchange, peer wait), and a 128 x 128 block needs
+// neither.  Same recurrences as the cluster kernel; state handed over through ws.zt (v, p = A v, pivot column, tau) when s_first >= 0.
+// grid B, block 512, dynamic LDS m * m doubles.
+#define ET_M 128
+__global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
+    extern __shared__ double et_sm[];                    // Am[m][m]
+    __shared__ double vs[ET_M], wv[ET_M], vn[ET_M], part[4][ET_M];
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+    const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    double* Am = et_sm;
+    for (int idx = tid; idx < m * m; idx += 512) {
+        const int r = idx / m, c = idx - r * m;
+        Am[idx] = A[(size_t)(base + r) * n + base + c];
+    }
+    const int i = base + tid;                            // vector element owned by this thread (tid < m)
+    const bool own = tid < m;
+    double v_i = 0.0, tk = 0.0, p_i = 0.0, col_i = 0.0;
+    if (s_first >= 0) {
+        const double* st = ws.zt + (size_t)b * n * EG_MAXN;
+        if (own) { v_i = st[i]; p_i = st[EG_MAXN + i]; col_i = st[2 * EG_MAXN + i]; }
+        tk = st[3 * EG_MAXN];
+    } else if (own) col_i = A[i];                        // whole matrix: column 0
+    __syncthreads();
+    const int cq = tid & (ET_M - 1), q = tid >> 7;       // pass: column cq, row quarter q
+    for (int s = s_first; s <= n - 2; ++s) {
+        const bool in = own && (i >= s + 1);
+        double w_i = 0.0, wpiv = 0.0;
+        if (s >= 0) {
+            if (own && i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wvi] = pv;
+            __syncthreads();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (own && i == s + 2) s_alpha = x_i;
+            double ss = (own && i >= s + 3) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wvi] = ss;
+            __syncthreads();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
+            }
+            vn_i = (own && i == s + 2) ? 1.0 : ((own && i > s + 2) ? x_i * scn : 0.0);
+        }
+        if (own && i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+        if (own && i >= s + 2) A[(size_t)(s + 1) * n + i] = vn_i;
+        if (s == n - 2) break;
+        if (own) { vs[tid] = v_i; wv[tid] = w_i; vn[tid] = vn_i; }
+        __syncthreads();
+        // ---- fused pass on the LDS block: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r   (rows / columns >= s + 2)
+        const int lo = s + 2 - base;                     // first live local index (>= 0)
+        double acc = 0.0;
+        if (cq < m && cq >= lo) {
+            const double vc = vs[cq], wc = wv[cq];
+            const int r0 = max(lo, q * (ET_M / 4)), r1 = min(m, (q + 1) * (ET_M / 4));
+            for (int r = r0; r < r1; ++r) {
+                double x = Am[r * m + cq];
+                x -= vs[r] * wc + wv[r] * vc;
+                Am[r * m + cq] = x;
+                acc += x * vn[r];
+            }
+        }
+        part[q][cq] = acc;
+        __syncthreads();
+        if (own) {
+            p_i = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            col_i = (tid >= lo) ? Am[lo * m + tid] : 0.0;          // pivot row s + 2 of the updated block
+        }
+        v_i = vn_i;
+        tk = tn;
+        // the next iteration's first barrier orders these reads against its LDS writes (s_ppiv / red0 are written before it, but
+        // nothing reads them after this point of the current iteration)
+    }
 }
 
 // ------------------------------------------------------------------------------------------ e2
@@ -1055,10 +1181,23 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
         static int p4_on = -1;
         if (p4_on < 0) { const char* e = getenv("NELE_EIGH_P4"); p4_on = !(e && e[0] == '0'); }
         if (p4_on && n <= 16 * E4_RI && cluster_cap >= 32) {
-            // four workgroups per matrix: 64 matrices per launch would fill the chip; 32 use half of it
+            // four workgroups per matrix: 64 matrices per launch would fill the chip; 32 use half of it.  The last ET_M steps run in
+            // eigh_tridiag_tail_kernel (one workgroup per matrix, block in LDS): s_stop = last iteration of the cluster kernel
+            static int tail_on = -1;
+            if (tail_on < 0) {
+                const char* e_ = getenv("NELE_EIGH_TAIL");
+                tail_on = !(e_ && e_[0] == '0');
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(sizeof(double) * ET_M * ET_M));
+            }
+            const int s_stop = (tail_on && n > ET_M + 2) ? n - ET_M - 2 : -2;
             for (int b0 = 0; b0 < B; b0 += 64) {
                 const int Bc = (B - b0 < 64) ? B - b0 : 64;
-                hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
+                hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop);
+            }
+            if (s_stop >= -1) {
+                const int mt = n - (s_stop + 2);
+                hipLaunchKernelGGL(eigh_tridiag_tail_kernel, dim3(B), dim3(512), sizeof(double) * (size_t)mt * mt, s, A, n, ws, s_stop + 1);
             }
         } else {
         static int split_small = -1;

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
             hipMemset(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            if (mode == 4) { for (int b0 = 0; b0 < B; b0 += 64) { int Bc = B - b0 < 64 ? B - b0 : 64; hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws); } }
+            if (mode == 4) { for (int b0 = 0; b0 < B; b0 += 64) { int Bc = B - b0 < 64 ? B - b0 : 64; hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws, -2); } }
             else for (int b0 = 0; b0 < B; b0 += 32) { int Bc = B - b0 < 32 ? B - b0 : 32; hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, 0, A, n, b0, Bc, ws); }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
