@@ -625,6 +625,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 // neither.  Same recurrences as the cluster kernel; state handed over through ws.zt (v, p = A v, pivot column, tau) when s_first >= 0.
 // grid B, block 512, dynamic LDS m * m doubles.
 #define ET_M 128
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL stores (vmcnt(0)); in the
+// step loop below those are the reflector row and d / e / tau, which nothing in the kernel reads back - waiting for their
+// acknowledgement at every barrier is a store round trip per step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
     extern __shared__ double et_sm[];                    // Am[m][m]
     __shared__ double vs[ET_M], wv[ET_M], vn[ET_M], part[4][ET_M];
@@ -651,6 +655,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
     } else if (own) col_i = A[i];                        // whole matrix: column 0
     __syncthreads();
     const int cq = tid & (ET_M - 1), q = tid >> 7;       // pass: column cq, row quarter q
+#ifdef EC_PROF
+    long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+#endif
     for (int s = s_first; s <= n - 2; ++s) {
         const bool in = own && (i >= s + 1);
         double w_i = 0.0, wpiv = 0.0;
@@ -659,8 +666,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
             double pv = in ? tk * p_i * v_i : 0.0;
             pv = wave_sum_dpp(pv);
             if (lane == 0) red0[wvi] = pv;
-            __syncthreads();
+            lds_barrier();
             pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            EC_T(0);
             const double al = -0.5 * tk * pv;
             w_i = in ? tk * p_i + al * v_i : 0.0;
             wpiv = tk * s_ppiv + al;
@@ -672,8 +680,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
             double ss = (own && i >= s + 3) ? x_i * x_i : 0.0;
             ss = wave_sum_dpp(ss);
             if (lane == 0) red1[wvi] = ss;
-            __syncthreads();
+            lds_barrier();
             ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            EC_T(1);
             const double alpha = s_alpha;
             double scn = 0.0;
             betan = alpha;
@@ -697,31 +706,49 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
         if (own && i >= s + 2) A[(size_t)(s + 1) * n + i] = vn_i;
         if (s == n - 2) break;
         if (own) { vs[tid] = v_i; wv[tid] = w_i; vn[tid] = vn_i; }
-        __syncthreads();
+        lds_barrier();
+        EC_T(2);
         // ---- fused pass on the LDS block: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r   (rows / columns >= s + 2)
         const int lo = s + 2 - base;                     // first live local index (>= 0)
         double acc = 0.0;
         if (cq < m && cq >= lo) {
+            // rows lo + q, lo + q + 4, ... (the live rows are dealt round-robin to the four row groups), eight at a time: all LDS reads of
+            // a group are issued before the first dependent operation (one read latency per eight rows instead of per row)
             const double vc = vs[cq], wc = wv[cq];
-            const int r0 = max(lo, q * (ET_M / 4)), r1 = min(m, (q + 1) * (ET_M / 4));
-            for (int r = r0; r < r1; ++r) {
-                double x = Am[r * m + cq];
-                x -= vs[r] * wc + wv[r] * vc;
-                Am[r * m + cq] = x;
-                acc += x * vn[r];
+            for (int r = lo + q; r < m; r += 32) {
+                double a[8], vr[8], wr[8], nr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rr = min(r + 4 * u, m - 1);
+                    a[u] = Am[rr * m + cq]; vr[u] = vs[rr]; wr[u] = wv[rr]; nr[u] = vn[rr];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (r + 4 * u < m) {
+                        const double x = a[u] - (vr[u] * wc + wr[u] * vc);
+                        Am[(r + 4 * u) * m + cq] = x;
+                        acc += x * nr[u];
+                    }
+                }
             }
         }
+        EC_T(3);
         part[q][cq] = acc;
-        __syncthreads();
+        lds_barrier();
+        EC_T(4);
         if (own) {
             p_i = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
             col_i = (tid >= lo) ? Am[lo * m + tid] : 0.0;          // pivot row s + 2 of the updated block
         }
+        EC_T(5);
         v_i = vn_i;
         tk = tn;
         // the next iteration's first barrier orders these reads against its LDS writes (s_ppiv / red0 are written before it, but
         // nothing reads them after this point of the current iteration)
     }
+#ifdef EC_PROF
+    if (tid == 0 && b == 0) for (int j = 0; j < 9; ++j) ws.lamp[j] = (double)tacc[j];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ e2
