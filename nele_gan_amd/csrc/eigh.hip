@@ -631,7 +631,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
     extern __shared__ double et_sm[];                    // Am[m][m]
-    __shared__ double vs[ET_M], wv[ET_M], vn[ET_M], part[4][ET_M];
+    __shared__ double vs[ET_M], wv[ET_M], vn[ET_M], part[8][ET_M];
     __shared__ double red0[8], red1[8];
     __shared__ double s_alpha, s_ppiv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
         tk = st[3 * EG_MAXN];
     } else if (own) col_i = A[i];                        // whole matrix: column 0
     __syncthreads();
-    const int cq = tid & (ET_M - 1), q = tid >> 7;       // pass: column cq, row quarter q
+    const int c2 = (tid & 63) * 2, q = tid >> 6;         // pass: columns c2, c2 + 1 (m = ET_M is even), row group q
 #ifdef EC_PROF
     long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
 #endif
@@ -710,34 +710,37 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
         EC_T(2);
         // ---- fused pass on the LDS block: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r   (rows / columns >= s + 2)
         const int lo = s + 2 - base;                     // first live local index (>= 0)
-        double acc = 0.0;
-        if (cq < m && cq >= lo) {
-            // rows lo + q, lo + q + 4, ... (the live rows are dealt round-robin to the four row groups), eight at a time: all LDS reads of
-            // a group are issued before the first dependent operation (one read latency per eight rows instead of per row)
-            const double vc = vs[cq], wc = wv[cq];
-            for (int r = lo + q; r < m; r += 32) {
-                double a[8], vr[8], wr[8], nr[8];
+        // thread = (column pair c2, row group q of 8): rows lo + q, lo + q + 8, ..., eight at a time; one 16-byte LDS access serves two
+        // columns and the row's three vector values are shared by them (the pass is bound by LDS instruction issue)
+        double acc0 = 0.0, acc1 = 0.0;
+        if (c2 + 1 >= lo) {
+            const double vc0 = vs[c2], wc0 = wv[c2], vc1 = vs[c2 + 1], wc1 = wv[c2 + 1];
+            for (int r = lo + q; r < m; r += 64) {
+                double2 a[8];
+                double vr[8], wr[8], nr[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int rr = min(r + 4 * u, m - 1);
-                    a[u] = Am[rr * m + cq]; vr[u] = vs[rr]; wr[u] = wv[rr]; nr[u] = vn[rr];
+                    const int rr = min(r + 8 * u, m - 1);
+                    a[u] = *reinterpret_cast<const double2*>(&Am[rr * m + c2]); vr[u] = vs[rr]; wr[u] = wv[rr]; nr[u] = vn[rr];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (r + 4 * u < m) {
-                        const double x = a[u] - (vr[u] * wc + wr[u] * vc);
-                        Am[(r + 4 * u) * m + cq] = x;
-                        acc += x * nr[u];
+                    if (r + 8 * u < m) {
+                        const double x0 = a[u].x - (vr[u] * wc0 + wr[u] * vc0), x1 = a[u].y - (vr[u] * wc1 + wr[u] * vc1);
+                        *reinterpret_cast<double2*>(&Am[(r + 8 * u) * m + c2]) = make_double2(x0, x1);
+                        acc0 += x0 * nr[u];
+                        acc1 += x1 * nr[u];
                     }
                 }
             }
         }
         EC_T(3);
-        part[q][cq] = acc;
+        part[q][c2] = acc0;
+        part[q][c2 + 1] = acc1;
         lds_barrier();
         EC_T(4);
         if (own) {
-            p_i = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            p_i = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + ((part[4][tid] + part[5][tid]) + (part[6][tid] + part[7][tid]));
             col_i = (tid >= lo) ? Am[lo * m + tid] : 0.0;          // pivot row s + 2 of the updated block
         }
         EC_T(5);
