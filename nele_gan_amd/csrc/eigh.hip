@@ -1067,10 +1067,14 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
 #define BT_CH 8
 template <int BT_Q>     // 16-row groups held per lane: 28 covers n <= 448 (SIIB: 420), 32 covers EG_MAXN
 __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
-    extern __shared__ double bt_sm[];         // vch[2][BT_CH][nld], tch[2][BT_CH]
+    // reflector chunk in LDS, PERMUTED: element i of reflector r at r * RS + (i & 15) * BT_Q + (i >> 4), so the BT_Q values a lane needs
+    // (rows t, t + 16, ...) are contiguous and go out as 16-byte reads (the kernel is bound by LDS instruction issue: 2 x BT_Q reads per
+    // reflector and wave in the plain layout)
+    extern __shared__ double bt_sm[];         // vch[2][BT_CH][16][BT_Q], tch[2][BT_CH]
     const int nld = (n + 15) & ~15;
+    constexpr int RS = 16 * BT_Q;
     double* vch = bt_sm;
-    double* tch = bt_sm + 2 * BT_CH * nld;
+    double* tch = bt_sm + 2 * BT_CH * RS;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = lane & 15, g = lane >> 4;
     const int j0 = blockIdx.x * 32 + w * 8 + g * 2;
     const double* A = Aall + (size_t)b * n * n;
@@ -1102,10 +1106,13 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int idx = tid + 256 * u;
-            if (idx < per) vch[buf * per + idx] = pre[u];
+            const int r = idx / nld, i = idx - r * nld;
+            if (idx < per) vch[buf * BT_CH * RS + r * RS + (i & 15) * BT_Q + (i >> 4)] = pre[u];
         }
         if (tid < BT_CH) tch[buf * BT_CH + tid] = pret;
     };
+    for (int e_ = tid; e_ < 2 * BT_CH * RS; e_ += 256) vch[e_] = 0.0;      // slots of rows >= nld are never staged: they must read as zero
+    __syncthreads();
     gload(0);
     lstore(0);
     __syncthreads();
@@ -1117,19 +1124,15 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
             if (k < 0) break;
             const double tk = tch[buf * BT_CH + r];
             if (tk == 0.0) continue;
-            const double* vr = vch + buf * per + r * nld + t;
+            const double2* vr2 = reinterpret_cast<const double2*>(vch + buf * BT_CH * RS + r * RS + t * BT_Q);
             const int q0 = (k + 1) >> 4;      // rows below 16 q0 are zero in this reflector
             double d0 = 0.0, d1 = 0.0;
 #pragma unroll
             for (int qq = 0; qq < BT_Q / 4; ++qq) {
                 if (4 * qq + 3 >= q0) {
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int q = 4 * qq + h;
-                        const double vq = (16 * q < nld) ? vr[16 * q] : 0.0;
-                        d0 += vq * z0[q];
-                        d1 += vq * z1[q];
-                    }
+                    const double2 va = vr2[2 * qq], vb = vr2[2 * qq + 1];
+                    d0 += va.x * z0[4 * qq] + va.y * z0[4 * qq + 1] + vb.x * z0[4 * qq + 2] + vb.y * z0[4 * qq + 3];
+                    d1 += va.x * z1[4 * qq] + va.y * z1[4 * qq + 1] + vb.x * z1[4 * qq + 2] + vb.y * z1[4 * qq + 3];
                 }
             }
             d0 = tk * row16_sum_dpp(d0);
@@ -1137,13 +1140,9 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
 #pragma unroll
             for (int qq = 0; qq < BT_Q / 4; ++qq) {
                 if (4 * qq + 3 >= q0) {
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int q = 4 * qq + h;
-                        const double vq = (16 * q < nld) ? vr[16 * q] : 0.0;
-                        z0[q] -= d0 * vq;
-                        z1[q] -= d1 * vq;
-                    }
+                    const double2 va = vr2[2 * qq], vb = vr2[2 * qq + 1];
+                    z0[4 * qq] -= d0 * va.x; z0[4 * qq + 1] -= d0 * va.y; z0[4 * qq + 2] -= d0 * vb.x; z0[4 * qq + 3] -= d0 * vb.y;
+                    z1[4 * qq] -= d1 * va.x; z1[4 * qq + 1] -= d1 * va.y; z1[4 * qq + 2] -= d1 * vb.x; z1[4 * qq + 3] -= d1 * vb.y;
                 }
             }
         }
@@ -1245,7 +1244,7 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     static int iv_extra = -1;
     if (iv_extra < 0) { const char* e_ = getenv("NELE_EIGH_INVIT_EXTRA"); iv_extra = e_ ? atoi(e_) : 2; }
     hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);
-    const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * ((n + 15) & ~15) + 2 * BT_CH);
+    const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * 16 * (n <= 448 ? 28 : 32) + 2 * BT_CH);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
