@@ -43,6 +43,7 @@ struct HaspiWs {
     double* env;     // [B][2][n24][32] signal envelope -> compressed -> dB SL -> adapted dB SL
     double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
     double* ssp;     // [B][2][16][32] control-bank sum-of-squares partials per chunk (chunk-parallel banks)
+    double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
     int* shift;      // [B][32]
     double* lp;      // [B][2][nsub][32]
     int* act;        // [B][nsub]     indices of the active sub-sampled frames
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
     double mn = (ch < HP_NCH) ? gd : 1e300, mx = (ch < HP_NCH) ? gd : -1e300;
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
     if (ch < HP_NCH) ws.shift[(size_t)b * HP_NCH + ch] = (int)((mx - mn) - (gd - mn));
+    if (b == 0 && ch < HP_NFILT) ws.benv[ch] = (0.5 - 0.5 * cospi(2.0 * (double)ch / 51.0)) / 25.5;   // np.hanning(52) / sum, for haspi_envfilt_kernel
 }
 
 // ---- h9b: ebm_EnvFilt (pyhaspi2.py:378-414): Hann(52)/sum FIR, "same" alignment (nhalf = 26), every 9th sample.
@@ -591,11 +593,10 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
 #define EF_SUB 16
 #define EF_SPAN (EF_SUB * HP_SPACE + HP_NFILT)
 __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
-    __shared__ double benv[HP_NFILT];
     __shared__ double xs[EF_SPAN][HP_NCH + 1];
     const int b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x, ch = tid & 31;
     const int i0 = blockIdx.x * EF_SUB;
-    if (tid < HP_NFILT) benv[tid] = (0.5 - 0.5 * cospi(2.0 * (double)tid / 51.0)) / 25.5;   // np.hanning(52) / sum
+    const double* __restrict__ benv = ws.benv;           // uniform index -> scalar loads: the taps cost no LDS read (the loop was bound by LDS issue)
     const int s = ws.shift[(size_t)b * HP_NCH + ch];
     const double* e = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
     // LDS row q <-> shifted-envelope index m = 9*i0 + 26 - 51 + q
@@ -820,6 +821,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(env, double, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(ssp, double, (size_t)B * 2 * 16 * HP_NCH);
+    TAKE(benv, double, 64);
     TAKE(shift, int, (size_t)B * HP_NCH);
     TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
     TAKE(act, int, (size_t)B * nsub);
