@@ -44,6 +44,7 @@ struct HaspiWs {
     double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
     double* ssp;     // [B][2][16][32] control-bank sum-of-squares partials per chunk (chunk-parallel banks)
     double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
+    double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
     double* lp;      // [B][2][nsub][32]
     int* act;        // [B][nsub]     indices of the active sub-sampled frames
@@ -585,6 +586,11 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
     if (ch < HP_NCH) ws.shift[(size_t)b * HP_NCH + ch] = (int)((mx - mn) - (gd - mn));
     if (b == 0 && ch < HP_NFILT) ws.benv[ch] = (0.5 - 0.5 * cospi(2.0 * (double)ch / 51.0)) / 25.5;   // np.hanning(52) / sum, for haspi_envfilt_kernel
+    if (b == 0) {                                        // modulation-filter taps (np.hanning(nfir + 1) / sum), for haspi_mod_kernel
+        const int nfirs[10] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
+        for (int k = 0; k < 10; ++k)
+            for (int i = ch; i <= nfirs[k]; i += 64) ws.bkt[k * 616 + i] = (0.5 - 0.5 * cospi(2.0 * (double)i / (double)nfirs[k])) / (0.5 * (double)nfirs[k]);
+    }
 }
 
 // ---- h9b: ebm_EnvFilt (pyhaspi2.py:378-414): Hann(52)/sum FIR, "same" alignment (nhalf = 26), every 9th sample.
@@ -709,7 +715,6 @@ __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38,
 #define MF_POS(e) ((((e) & 3) * MF_L4) + ((e) >> 2))
 
 __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
-    __shared__ double bk[HP_MAXFIR + 1];
     __shared__ double sxc[4 * MF_L4], sxs[4 * MF_L4], syc[4 * MF_L4], sys_[4 * MF_L4];
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     if (ws.info[2 * b + 1]) return;
     const int nfir = c_modnfir[k], nh = nfir / 2;
     // np.hanning(nfir+1) / sum ; sum of a symmetric Hann window of M points = (M-1)/2
-    for (int i = tid; i <= nfir; i += 256) bk[i] = (0.5 - 0.5 * cospi(2.0 * (double)i / (double)nfir)) / (0.5 * (double)nfir);
+    const double* __restrict__ bk = ws.bkt + k * 616;    // uniform index in the tap loop -> scalar loads
     const double* xc = ws.cep + (((size_t)b * 2 + 0) * HP_NBASIS + basis) * ws.nsub;
     const double* yc = ws.cep + (((size_t)b * 2 + 1) * HP_NBASIS + basis) * ws.nsub;
     const double cf = c_modcf[k];
@@ -822,6 +827,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(ssp, double, (size_t)B * 2 * 16 * HP_NCH);
     TAKE(benv, double, 64);
+    TAKE(bkt, double, 10 * 616);
     TAKE(shift, int, (size_t)B * HP_NCH);
     TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
     TAKE(act, int, (size_t)B * nsub);
