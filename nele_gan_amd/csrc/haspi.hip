@@ -715,7 +715,7 @@ __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38,
 #define MF_POS(e) ((((e) & 3) * MF_L4) + ((e) >> 2))
 
 __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
-    __shared__ double sxc[4 * MF_L4], sxs[4 * MF_L4], syc[4 * MF_L4], sys_[4 * MF_L4];
+    __shared__ __attribute__((aligned(32))) double4 sq[4 * MF_L4];   // (x cos, x sin, y cos, y sin) of one sequence element: two 16-byte reads per tap instead of four 8-byte ones
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[2 * b];
@@ -742,8 +742,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
                 c = SQ2 * cos(ang);
                 s = SQ2 * sin(ang);
             }
-            const int se = MF_POS(e);
-            sxc[se] = vx * c; sxs[se] = vx * s; syc[se] = vy * c; sys_[se] = vy * s;
+            sq[MF_POS(e)] = make_double4(vx * c, vx * s, vy * c, vy * s);
         }
         __syncthreads();
         // thread -> outputs t = t0 + 4 tid + q, q = 0..3:  u[t] = sum_i b[i] z[t + nh - i]  (LDS index 4 tid + q + nfir - i)
@@ -754,7 +753,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
             // window registers hold z[e0 - i + q] for q = 0..3
             double wxc[4], wxs[4], wyc[4], wys[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int se = MF_POS(e0 + q); wxc[q] = sxc[se]; wxs[q] = sxs[se]; wyc[q] = syc[se]; wys[q] = sys_[se]; }
+            for (int q = 0; q < 4; ++q) { const double4 v4 = sq[MF_POS(e0 + q)]; wxc[q] = v4.x; wxs[q] = v4.y; wyc[q] = v4.z; wys[q] = v4.w; }
 #pragma unroll 4                                               // the register window then rotates by renaming instead of 24 moves per tap
             for (int i = 0; i <= nfir; ++i) {
                 const double w = bk[i];
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
 #pragma unroll
                 for (int q = 3; q > 0; --q) { wxc[q] = wxc[q - 1]; wxs[q] = wxs[q - 1]; wyc[q] = wyc[q - 1]; wys[q] = wys[q - 1]; }
                 const int en = e0 - i - 1;
-                if (en >= 0) { const int se = MF_POS(en); wxc[0] = sxc[se]; wxs[0] = sxs[se]; wyc[0] = syc[se]; wys[0] = sys_[se]; }
+                if (en >= 0) { const double4 v4 = sq[MF_POS(en)]; wxc[0] = v4.x; wxs[0] = v4.y; wyc[0] = v4.z; wys[0] = v4.w; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
