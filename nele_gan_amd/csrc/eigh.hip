@@ -804,8 +804,10 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
             const int iend = min(n, i + 8);
             for (; i < iend; ++i) {
                 const double2 de = sde[i];
-                double p2 = (de.x - x) * p1 - de.y * p0;
-                if (p2 == 0.0) p2 = -copysign(pivmin, p1);
+                // an exact zero needs no repair here: the recurrence continues with p3 = -e^2 p1 and its sign bit counts as positive, which can
+                // only misplace the count AT a point that is exactly an eigenvalue of a leading block - the interval still closes around
+                // the eigenvalue (the compare + two selects were a fifth of the instructions of this issue-bound loop)
+                const double p2 = (de.x - x) * p1 - de.y * p0;
                 cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);   // sign change (no zeros, no NaNs here)
                 p0 = p1;
                 p1 = p2;

@@ -212,3 +212,23 @@ def test_haspi_chunk_parallel_filters_equal_the_serial_ones(tmp_path):
         res.append(np.load(out))
     assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
+
+
+def test_eigensolver_on_matrices_that_put_exact_zeros_into_the_sturm_recurrence(mt):
+    """Diagonal, repeated and block-diagonal matrices: the Sturm sequence hits exact zeros (an evaluation point equal to an eigenvalue
+    of a leading block); the bisection kernel does not repair them on its critical chain and must still converge."""
+    n = 64
+    A = np.zeros((4, n, n))
+    A[0] = np.diag(np.arange(1, n + 1, dtype=float))
+    A[1] = np.eye(n); A[1][3, 3] = 2.0
+    A[2] = np.diag(np.arange(1, n + 1, dtype=float)); A[2][:8, :8] += 0.5
+    rs = np.random.RandomState(1)
+    G = rs.randn(n, n)
+    A[3] = np.kron(np.eye(2), (G @ G.T)[:32, :32])
+    lam, U = mt.eigh_batched(torch.from_numpy(A).cuda())
+    lam, U = lam.cpu().numpy(), U.cpu().numpy()
+    for b in range(4):
+        ref = np.linalg.eigvalsh(A[b])
+        V = U[b].T
+        np.testing.assert_allclose(lam[b], ref, rtol=0, atol=1e-13 * ref.max())
+        assert np.abs(A[b] @ V - V * lam[b][None, :]).max() < 1e-11 * ref.max()
