@@ -800,21 +800,31 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
         if (p1 == 0.0) p1 = -pivmin;
         int cnt = (p1 < 0.0) ? 1 : 0;
         int i = 1;
-        while (i < n) {
-            const int iend = min(n, i + 8);
-            for (; i < iend; ++i) {
-                const double2 de = sde[i];
+        // blocks of eight steps with a fixed trip count: the eight LDS reads are issued together ahead of the dependent chain (a
+        // variable-trip inner loop left one LDS latency exposed per step - most of this kernel's time)
+        for (; i + 8 <= n; i += 8) {
+            double2 de[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) de[u] = sde[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
                 // an exact zero needs no repair here: the recurrence continues with p3 = -e^2 p1 and its sign bit counts as positive, which can
-                // only misplace the count AT a point that is exactly an eigenvalue of a leading block - the interval still closes around
-                // the eigenvalue (the compare + two selects were a fifth of the instructions of this issue-bound loop)
-                const double p2 = (de.x - x) * p1 - de.y * p0;
-                cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);   // sign change (no zeros, no NaNs here)
+                // only misplace the count AT a point that is exactly an eigenvalue of a leading block - the interval still closes around it
+                const double p2 = (de[u].x - x) * p1 - de[u].y * p0;
+                cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);   // sign change (no NaNs here)
                 p0 = p1;
                 p1 = p2;
             }
             const double ap = fabs(p1);                    // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
             if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
             else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
+        }
+        for (; i < n; ++i) {
+            const double2 de = sde[i];
+            const double p2 = (de.x - x) * p1 - de.y * p0;
+            cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);
+            p0 = p1;
+            p1 = p2;
         }
         const unsigned long long bal = __ballot(cnt <= j);
         const int m = __popc((unsigned)((bal >> (lane & (64 - NL))) & ((1ull << NL) - 1ull)));   // points of this group with count <= j
