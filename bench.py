@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
 
 
 def cpu_baseline(metrics, length, n_utt, seed_start=9000):
@@ -144,7 +145,8 @@ def main():
     for _ in range(a.warmup):
         tr.canonical_step(cw, nw)
     tag = 'D.conv5.fwd'           # D's 5th conv forward: every launch of the timed region (one in the G-step, one in the D-step per step)
-    ops.PROFILE = {'gstep.' + tag: [], tag: []}
+    wtag = 'D.conv5.wgrad'        # the memory-side companion figure: D's 5th conv weight gradient (events on its own stream; includes its partial reduction)
+    ops.PROFILE = {'gstep.' + tag: [], tag: [], wtag: []}
     stage_ev = []
     barrier()
     t0 = time.perf_counter()
@@ -167,6 +169,7 @@ def main():
         dt = float(t.item())
     prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
     prof = prof_g + prof_d
+    prof_w = ops.PROFILE[wtag]
     # the same launch on an otherwise idle GPU (after the timed region): inside the step the kernel shares the CUs with the metric
     # stream (SIIB's clean-signal part, incl. the all-CU tridiagonalisation, runs beside the G-step), which inflates its duration
     iso_tag = 'iso.D.conv5.fwd'
@@ -218,6 +221,19 @@ def main():
                          'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
+        if prof_w:
+            w_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof_w) / len(prof_w)
+            w_bytes = prof_w[0][2]
+            w_traffic = None
+            try:
+                if a.precision == 'bf16' and a.batch == 32 and a.length == 64000:
+                    w_traffic = [v['hbm_bytes_corrected'] for k, v in tj['kernels'].items() if k.startswith('conv_wgrad_tile16_kernel<4,7>')][0]
+            except Exception:
+                w_traffic = None
+            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
+                                   'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': w_traffic, 'launch_ms': w_ms,
+                                   'algorithmic_bytes': w_bytes, 'launches_timed': len(prof_w)}
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}

@@ -678,7 +678,8 @@ class _DiscriminatorBase(nn.Module):
                     ctx = torch.cuda.stream(wst)
                     ctx.__enter__()
                     wst.wait_event(ev)
-                ops.conv_wgrad(a_in, bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0))
+                ops.conv_wgrad(a_in, bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0),
+                               tag='D.conv%d.wgrad' % (l + 1))
                 call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
                 m.bias.grad.add_(tmpb)

@@ -146,10 +146,18 @@ def wgrad_workspace_floats(B, N, g):
     return int(_lib.lib.nele_conv_wgrad_workspace_floats(M, N, g.Ktot, None))
 
 
-def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True, bf16=False):
+def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True, bf16=False, tag=None):
     M = B * g.Hout * g.Wout
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('nele_conv_wgrad_bf16' if bf16 else 'nele_conv_wgrad', ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db),
          int(accumulate), stream())
+    if prof:
+        e1.record()
+        # algorithmic bytes: the input and the output gradient read once (float32), the weight gradient written once
+        PROFILE[tag].append((e0, e1, 4.0 * (B * g.arr[0] * g.arr[1] * g.arr[2] + M * N + N * g.Ktot)))
 
 
 def weight_prep(Wt, sigma, N, Cvalid, C, KH, KW, Wf, Wb):
