@@ -1323,7 +1323,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     __shared__ float bred[16][64];
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kh = blockIdx.x, grp = blockIdx.y;
+    // grid: 1-D, KH * G workgroups.  Workgroup w runs on XCD w % 8 (round-robin dispatch), and the KH kernel-row workgroups of a group
+    // read the same input / dOut tiles at about the same time: they are given ids of one XCD so that its L2 serves the repeats
+    // (with the natural (kh, group) order the KH readers of a tile sat on different XCDs and every read went to HBM: 1.55 GB per launch
+    // for 160 MB of operands)
+    int kh, grp;
+    if ((p.G & 7) == 0) {
+        const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+        kh = slot % p.KH;
+        grp = (slot / p.KH) * 8 + xcd;
+    } else {
+        kh = blockIdx.x % p.KH;
+        grp = blockIdx.x / p.KH;
+    }
     const int wcols = WT_TW + p.KW - 1, RS = wcols * g.C;
     __bf16* halo = wt_lds;
     __bf16* dt = wt_lds + WT_TH * RS + 64;
@@ -1884,7 +1896,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         if (G > t.ntiles) G = t.ntiles;
         t.G = G; t.g = p.g;
         t.bpart = db ? workspace + (size_t)G * N * p.g.Ktot : nullptr;
-        const dim3 grid(KH, G);
+        const dim3 grid(KH * G);
         const int ktw = (nkt + 3) / 4;
         static bool wattr = false;
         if (!wattr) {
