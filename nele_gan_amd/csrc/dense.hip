@@ -495,7 +495,10 @@ struct Tile16Args {
     int KH, KW, steps_per_seg, SB;
     ConvGeom g;
     long long* dbg;        // optional per-phase clock totals of workgroup 0 (benchmark harness only)
+    int ntiles;            // tile columns x tile rows x utterances
 };
+__device__ __forceinline__ int g_wout(const Tile16Args& p) { return p.g.Wout; }
+__device__ __forceinline__ int g_hout(const Tile16Args& p) { return p.g.Hout; }
 #define TILE16_TW 64
 #define TILE16_SBMAX 9
 
@@ -507,7 +510,17 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
 #endif
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int wo0 = blockIdx.x * TILE16_TW, ho0 = blockIdx.y * TH, b = blockIdx.z;
+    // 1-D grid, XCD-aware: workgroup w runs on XCD w % 8; each XCD takes a contiguous run of tiles (tile columns fastest, then tile
+    // rows, then utterances), so the tiles that share halo rows / columns are neighbours in one L2 instead of strangers in eight
+    int wo0, ho0, b;
+    {
+        const int ntw = (g_wout(p) + TILE16_TW - 1) / TILE16_TW, nth = (g_hout(p) + TH - 1) / TH;
+        const int per = (int)((gridDim.x + 7) >> 3);
+        const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (tile >= p.ntiles) return;
+        const int tw_i = tile % ntw, rem = tile / ntw;
+        wo0 = tw_i * TILE16_TW; ho0 = (rem % nth) * TH; b = rem / nth;
+    }
     const int wcols = TILE16_TW + p.KW - 1;            // halo columns
     const int RS = wcols * g.C;                        // halo row stride (elements)
     const int nrows = TH + p.KH - 1;
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
 #ifdef T16_PROF
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tq0 = clock64(), tq1;
     const long long tw0 = wall_clock64(), tc0 = tq0;
-    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) p.dbg[8] = tw0 - t16_wstart;
+    if (p.dbg && tid == 0 && blockIdx.x == 8) p.dbg[8] = tw0 - t16_wstart;
 #define T16_T(j) do { tq1 = clock64(); tacc[j] += tq1 - tq0; tq0 = tq1; } while (0)
 #else
 #define T16_T(j)
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
     if (valid == (1u << TH) - 1u) mainloop(std::true_type{});
     else mainloop(std::false_type{});
 #ifdef T16_PROF
-    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0)
+    if (p.dbg && tid == 0 && blockIdx.x == 8)
     { for (int j = 0; j < 6; ++j) p.dbg[j] = tacc[j]; p.dbg[6] = wall_clock64() - tw0; p.dbg[7] = clock64() - tc0; }
 #endif
 
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
         }
     }
 #ifdef T16_PROF
-    if (p.dbg && tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) p.dbg[9] = wall_clock64() - t16_wstart;
+    if (p.dbg && tid == 0 && blockIdx.x == 8) p.dbg[9] = wall_clock64() - t16_wstart;
 #endif
 }
 
@@ -1798,7 +1811,8 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
 #undef TILE16_ATTR
             tattr = true;
         }
-        const dim3 grid((p.g.Wout + TILE16_TW - 1) / TILE16_TW, (p.g.Hout + th - 1) / th, B_);
+        t.ntiles = ((p.g.Wout + TILE16_TW - 1) / TILE16_TW) * ((p.g.Hout + th - 1) / th) * B_;
+        const dim3 grid((unsigned)((t.ntiles + 7) / 8 * 8));      // a multiple of 8: every XCD gets the same number of ids
 #define TILE16_LAUNCH(TN_, TH_) hipLaunchKernelGGL((conv_tile16_kernel<TN_, TH_>), grid, dim3(256), lds, s, t)
         if (th == 8) {
             switch (p.NT) { case 1: TILE16_LAUNCH(1, 8); break; case 2: TILE16_LAUNCH(2, 8); break; case 3: TILE16_LAUNCH(3, 8); break; default: TILE16_LAUNCH(4, 8); break; }
