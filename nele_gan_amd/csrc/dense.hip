@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
     __shared__ int nrun_s;
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * SPAN16_BM;
+    // XCD-aware ids (workgroup w runs on XCD w % 8): each XCD takes a contiguous run of position tiles, so the KH input rows that
+    // consecutive tiles share are re-read from one L2 (scattered over the eight XCDs every tile fetched its rows from HBM: 11 x the input)
+    const int mt = (int)(blockIdx.x & 7) * (int)((gridDim.x + 7) >> 3) + (int)(blockIdx.x >> 3);
+    const int m0 = mt * SPAN16_BM;
+    if (m0 >= p.M) return;
     const int mcount = min(SPAN16_BM, p.M - m0);
     const int halo = (p.KW - 1) * g.C;
 
@@ -1825,7 +1829,7 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
     }
     const int maxrun = (SPAN16_BM + p.g.Wout - 1) / p.g.Wout + 1;
     const size_t lds = ((size_t)SPAN16_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C + 64) * 2;
-    const int gx = (M + SPAN16_BM - 1) / SPAN16_BM;
+    const int gx = ((M + SPAN16_BM - 1) / SPAN16_BM + 7) / 8 * 8;     // a multiple of 8: the same number of ids per XCD
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
