@@ -44,6 +44,7 @@ struct SiibWs {
     double* part;    // [B][420][NTL][3]
     double* px;      // [B][7][NTL][16][256] projections of the clean signal in accumulator order (split mode: phase 3 -> phase 4)
     int NT, NA, NTL;
+    int Bn;          // utterances in this call
 };
 
 __device__ __forceinline__ double hann400(int n) { return 0.5 - 0.5 * cospi((double)n / 200.0); }
@@ -532,8 +533,13 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // rows >= 420 are clamped (they only reach outputs that are never stored).
 __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
     __shared__ __attribute__((aligned(16))) double As[2][16][SG_LD], Bs[2][16][SG_LD];
-    const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (bj > bi) return;
+    // 1-D grid, XCD-aware (workgroup id w runs on XCD w % 8): all tiles of an utterance get ids of one XCD, so that its L2 serves the row
+    // tiles of Xs that they share (with the natural 3-D grid the 28 tiles of an utterance sat on all eight XCDs: 4.7 x the operand bytes
+    // from HBM, and the kernel ran at HBM speed)
+    const int xw = (int)blockIdx.x, slot = xw >> 3;
+    const int b = (slot / 49) * 8 + (xw & 7), tile = slot % 49, bi = tile / 7, bj = tile % 7;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (b >= ws.Bn || bj > bi) return;
     const int ti = bi * 64, tj = bj * 64;
     const int na = ws.info[4 * b + 2];
     const int ncols = na - SB_K + 1;
@@ -596,13 +602,17 @@ __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
 template <int MODE>
 __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     __shared__ __attribute__((aligned(32))) double Us[2][16][SG_LD], Xt[2][16][SG_LD], Yt[2][16][SG_LD];
-    const int b = blockIdx.z, ti = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // 1-D grid, XCD-aware like siib_cov_kernel: the 7 x NTL tiles of an utterance share U and the column tiles of Xs in one L2
+    const int xw = (int)blockIdx.x, slot = xw >> 3, per_b = 7 * ws.NTL;
+    const int b = (slot / per_b) * 8 + (xw & 7), tl = slot % per_b, by = tl % 7, bx = tl / 7;   // the 7 row tiles of a column tile are adjacent
+    const int ti = by * 64, t0 = bx * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    if (b >= ws.Bn) return;
     if (t0 >= ws.info[4 * b + 2] - SB_K + 1) {      // tile beyond n_cols: all zero padding
         if (tid < 192) {
             const int q = tid / 64, r = tid - q * 64;
             const bool mine = (MODE == 0) || (MODE == 1 && q == 0) || (MODE == 2 && q != 0);
-            if (mine && ti + r < SB_D) ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + blockIdx.x) * 3 + q] = 0.0;
+            if (mine && ti + r < SB_D) ws.part[(((size_t)b * SB_D + ti + r) * ws.NTL + bx) * 3 + q] = 0.0;
         }
         return;
     }
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
             }
         }
     }
-    double* pxs = ws.px + ((((size_t)b * 7 + blockIdx.y) * ws.NTL + blockIdx.x) * 16) * 256 + tid;
+    double* pxs = ws.px + ((((size_t)b * 7 + by) * ws.NTL + bx) * 16) * 256 + tid;
     if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
         sxx = row16_sum_dpp(sxx); syy = row16_sum_dpp(syy); sxy = row16_sum_dpp(sxy);
         const int gi = ti + 16 * w + lk + 4 * q;
         if (li == 0 && gi < SB_D) {
-            double* dst = ws.part + (((size_t)b * SB_D + gi) * ws.NTL + blockIdx.x) * 3;
+            double* dst = ws.part + (((size_t)b * SB_D + gi) * ws.NTL + bx) * 3;
             if (MODE != 2) dst[0] = sxx;
             if (MODE != 1) { dst[1] = syy; dst[2] = sxy; }
         }
@@ -735,7 +745,7 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(part, double, (size_t)B * SB_D * NTL * 3);
     TAKE(px, double, (size_t)B * 7 * NTL * 16 * 256);
 #undef TAKE
-    if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; }
+    if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; w->Bn = B; }
     return o;
 }
 
@@ -785,20 +795,20 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);
-        if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(7, 7, B), dim3(256), 0, s, ws);
+        if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
     if (eig) {
         int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
         if (st) return st;
         if (phase == 3) {                                   // clean-signal half of the projections, beside whatever the caller overlaps
-            hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+            hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
             NELE_CHECK_LAUNCH("nele_metric_siib(clean projections)");
         }
     }
     if (fin) {
-        if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
-        else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(ws.NTL, 7, B), dim3(256), 0, s, ws);
+        if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+        else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
         hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
         NELE_CHECK_LAUNCH("nele_metric_siib(back)");
