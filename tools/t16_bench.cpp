@@ -17,8 +17,9 @@ int main(int argc, char** argv) {
     t.KH = KH; t.KW = KW; t.steps_per_seg = sps; t.g = g; t.SB = tile16_sb(g); t.dbg = dbg;
     const size_t lds = tile16_lds(g, N, KH, KW, 8);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const dim3 grid((g.Wout + 63) / 64, (g.Hout + 7) / 8, B);
-    printf("grid %d x %d x %d, lds %zu, SB %d sps %d\n", grid.x, grid.y, grid.z, lds, t.SB, sps);
+    t.ntiles = ((g.Wout + 63) / 64) * ((g.Hout + 7) / 8) * B;
+    const dim3 grid((unsigned)((t.ntiles + 7) / 8 * 8));          // 1-D, XCD-aware ids (see conv_tile16_kernel)
+    printf("grid %d (tiles %d), lds %zu, SB %d sps %d\n", grid.x, t.ntiles, lds, t.SB, sps);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
     for (int it = 0; it < 6; ++it) {
