@@ -499,7 +499,8 @@ struct Tile16Args {
     int KH, KW, steps_per_seg, SB;
     ConvGeom g;
     long long* dbg;        // optional per-phase clock totals of workgroup 0 (benchmark harness only)
-    int ntiles;            // tile columns x tile rows x utterances
+    int ntiles;            // tile columns x tile rows x utterances (conv1d strip kernel: N chunks per strip)
+    int SBH;               // conv1d strip kernel: utterances x rows
 };
 __device__ __forceinline__ int g_wout(const Tile16Args& p) { return p.g.Wout; }
 __device__ __forceinline__ int g_hout(const Tile16Args& p) { return p.g.Hout; }
@@ -770,7 +771,17 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 halo[];    // [RS] + 64 slack, then the weight chunk [SB][TN][64][8]
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int wo0 = blockIdx.x * C1D_TW, nb = blockIdx.y, bz = blockIdx.z;
+    // 1-D grid, XCD-aware: the N-chunk workgroups of one input strip (they stage the same strip) get ids of one XCD
+    int wo0, nb, bz;
+    {
+        const int nchN = p.ntiles;                        // N chunks per strip (host)
+        const int gx = (g.Wout + C1D_TW - 1) / C1D_TW;
+        const int w = (int)blockIdx.x, slot = w >> 3;
+        const int strip = (slot / nchN) * 8 + (w & 7);
+        nb = slot % nchN;
+        if (strip >= gx * p.SBH) return;
+        wo0 = (strip % gx) * C1D_TW; bz = strip / gx;
+    }
     const int b = bz / g.Hout, ho = bz - b * g.Hout;
     const int wcols = C1D_TW + p.KW - 1;
     const int RS = wcols * g.C;
@@ -1790,7 +1801,9 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
                 cattr = true;
             }
             const int nchunksN = (N > 64) ? N / 64 : 1, TNsel = (N >= 64) ? 4 : p.NT;
-            const dim3 grid((p.g.Wout + C1D_TW - 1) / C1D_TW, nchunksN, BH);
+            t.ntiles = nchunksN; t.SBH = BH;
+            const int nstrips = ((p.g.Wout + C1D_TW - 1) / C1D_TW) * BH;
+            const dim3 grid((unsigned)(nchunksN * 8 * ((nstrips + 7) / 8)));
             switch (TNsel) {
                 case 1: hipLaunchKernelGGL((conv1d_tile16_kernel<1>), grid, dim3(256), clds, s, t); break;
                 case 2: hipLaunchKernelGGL((conv1d_tile16_kernel<2>), grid, dim3(256), clds, s, t); break;
