@@ -232,3 +232,16 @@ def test_eigensolver_on_matrices_that_put_exact_zeros_into_the_sturm_recurrence(
         V = U[b].T
         np.testing.assert_allclose(lam[b], ref, rtol=0, atol=1e-13 * ref.max())
         assert np.abs(A[b] @ V - V * lam[b][None, :]).max() < 1e-11 * ref.max()
+
+
+def test_siib_is_batch_invariant_across_cluster_launches(mt):
+    """72 utterances = two launches of the 4-workgroup tridiagonalisation (64 + 8) and one tail launch: every utterance's score must equal
+    the score it gets in a small batch (no cross-talk between matrices, hand-over state per matrix)."""
+    from nele_gan_amd import synth
+    c, v = synth.batch(72, 40000, start=200)
+    y = c + v
+    raw, _ = mt.batch_siib(c, y)
+    raw = raw.cpu().numpy()
+    assert np.isfinite(raw).all()
+    sub, _ = mt.batch_siib(c[62:68], y[62:68])
+    assert np.array_equal(raw[62:68], sub.cpu().numpy())
