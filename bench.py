@@ -6,10 +6,16 @@
 
 One "step" = one canonical GAN_epoch step over one batch of synthetic utterances already
 resident in HBM: features(clean, noise) -> G-step (G fwd+bwd through D, Adam-G) -> generate (G eval,
-gain, iSTFT, PCM_16) -> true metrics (SIIB + ESTOI, logistic maps) -> D-step (D fwd+bwd, Adam-D).
-Workload = BASELINE.json configs[1]: batch 32 synthetic 4 s @ 16 kHz utterances per GPU, SIIB+ESTOI
-targets.  Multi-GPU: utterances shard across ranks (weak scaling: 32 per GPU), one flat RCCL
-all-reduce of the G and of the D gradients per step.  Prints ONE JSON line on rank 0.
+gain, iSTFT, PCM_16) -> true metrics (SIIB + HASPI + ESTOI, logistic maps) -> D-step (D fwd+bwd, Adam-D).
+Workload at N = 1 = BASELINE.json configs[2] (the largest single-GPU configuration): batch 256 synthetic
+4 s @ 16 kHz utterances, SIIB+HASPI+ESTOI multi-metric targets, bf16 MFMA operands.  The same JSON line
+carries two companions measured after the timed region: "configs1" (BASELINE configs[1]: batch 32,
+SIIB+ESTOI) and "nonperiodic" (the headline workload at L = 63 900, which is not a multiple of SIIB's
+200-sample hop, so SIIB's frame-periodic shortcut does not apply).
+Multi-GPU: utterances shard across ranks.  Default = weak scaling (--batch per GPU); with
+--global-batch G the G utterances are split over the ranks (strong scaling; `--gpus 8 --global-batch 1024`
+is BASELINE configs[3]).  One flat RCCL all-reduce of the G and of the D gradients per step.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,25 +33,31 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
 
 
 def cpu_baseline(metrics, length, n_utt, seed_start=9000):
-    """The oracle's canonical step (CPU port of the reference path) on a bounded sample."""
-    import numpy as np
+    """The oracle's canonical step (CPU port of the reference path) on a bounded sample, parallelised the way the reference is
+    (SURVEY 8d): features by 8 loader workers (dataloader.py:91), metrics fanned out over min(32, cores) joblib processes
+    (audio_util.py:146), G / D at batch 1 on torch-CPU with a bounded intra-op thread count."""
+    import joblib
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.model import Discriminator, Generator_Conv1D_cLN
-    from oracle.step import CpuStep
+    from oracle.step import CpuStep, _noop
+    ncpu = os.cpu_count() or 1
+    n_metric = min(32, ncpu)
+    n_feat = min(8, ncpu)
+    n_torch = min(16, ncpu)
+    torch.set_num_threads(n_torch)
     torch.manual_seed(666)
     G, D = Generator_Conv1D_cLN(), Discriminator(nout=len(metrics))
     step = CpuStep(G.state_dict(), D.state_dict(), metrics=metrics)
     c, v = synth.batch(n_utt, length, start=seed_start)
+    joblib.Parallel(n_jobs=n_metric)(joblib.delayed(_noop)(i) for i in range(4 * n_metric))     # worker start-up is not part of the sample
     t0 = time.perf_counter()
-    # the reference is batch 1: one utterance per optimiser step
-    for i in range(n_utt):
-        step.canonical_step(c[i:i + 1], v[i:i + 1])
+    step.epoch_slice(c, v, feature_workers=n_feat, metric_workers=n_metric)
     dt = time.perf_counter() - t0
-    return {'value': n_utt / dt, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d synthetic %.1f s utterances, canonical step at batch 1 (reference semantics), %s; %.1f s wall; host %d logical cores; '
-                      'stage seconds %s' % (n_utt, length / 16000.0, '+'.join(metrics), dt, os.cpu_count(),
-                                            {k: round(t, 2) for k, t in step.times.items()})}
+    return {'value': n_utt / dt, 'unit': 'utterances/s', 'cores': max(n_metric, n_torch), 'kind': 'port',
+            'sample': '%d synthetic %.1f s utterances, %s: features on %d worker processes, G-step and D-step at batch 1 (reference semantics) with %d torch '
+                      'threads, metrics on %d joblib processes; %.1f s wall; host %d logical cores; stage seconds %s'
+                      % (n_utt, length / 16000.0, '+'.join(metrics), n_feat, n_torch, n_metric, dt, ncpu, {k: round(t, 2) for k, t in step.times.items()})}
 
 
 def inference_rate(tr, batch, K, rank):
@@ -67,6 +79,29 @@ def inference_rate(tr, batch, K, rank):
     tr.G.train()
     return {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_batch': dt * 1e3, 'utterance_seconds': 8.0, 'batch': batch,
             'realtime_factor': batch * 8.0 / dt}
+
+
+def companion(a, metric_str, batch, length, steps):
+    """The canonical step of another workload on this GPU (fresh trainer, 2 warm-up steps, `steps` timed steps)."""
+    import torch
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    tr = GanTrainer(metric_str)
+    tr.D.precision = tr.G.precision = a.precision
+    c, v = synth.batch(batch, length, start=20000)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    for _ in range(2):
+        tr.canonical_step(cw, nw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lg, ld, tgt = tr.canonical_step(cw, nw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(tgt).all()) and bool(torch.isfinite(ld))
+    tr.check_status()
+    return {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_step': dt * 1e3, 'batch': batch, 'samples_per_utterance': length,
+            'metrics': metric_str, 'steps': steps}
 
 
 def epoch_equivalent(tr, cw, nw, K, utts):
@@ -103,10 +138,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--batch', type=int, default=256, help='utterances per GPU (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=0, metavar='G',
+                    help='total utterances, split over the ranks (strong scaling; overrides --batch)')
     ap.add_argument('--length', type=int, default=64000)
-    ap.add_argument('--metrics', default='siib&estoi')
-    ap.add_argument('--cpu-utts', type=int, default=4, help='utterances in the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--metrics', default='siib&haspi&estoi')
+    ap.add_argument('--companions', type=int, default=1, help='also run the configs[1] and non-periodic-length companions (N = 1 only; 0 = skip)')
+    ap.add_argument('--cpu-utts', type=int, default=32, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
     ap.add_argument('--inference', type=int, default=0, metavar='K',
                     help='also time K batches of the inference path (BASELINE configs[4]: 8 s utterances, features -> G -> resynthesis -> RMS 0.03 -> PCM_16); reported as "inference"')
@@ -128,13 +166,22 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
 
+    from nele_gan_amd import dist as ndist
     from nele_gan_amd import ops, synth
     from nele_gan_amd.train_nele import GanTrainer, parse_metrics
     metrics = parse_metrics(a.metrics)
     tr = GanTrainer(a.metrics, device='cuda:%d' % local)
     tr.D.precision = a.precision
     tr.G.precision = a.precision
-    c, v = synth.batch(a.batch, a.length, start=rank * a.batch)
+    scaling = 'weak'
+    if a.global_batch > 0:
+        assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs (equal shards: one plain mean all-reduce)"
+        lo, hi = ndist.shard_range(a.global_batch, rank, world)      # contiguous utterance shard of this rank
+        a.batch = hi - lo
+        scaling = 'strong'
+    else:
+        lo = rank * a.batch
+    c, v = synth.batch(a.batch, a.length, start=lo)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 
     def barrier():
@@ -160,9 +207,15 @@ def main():
             ev[4].record(); tr.d_step(tr.d_inputs(enh, f['noise_band'], f['clean_band']), tgt)
             ev[5].record(); stage_ev.append(ev)
         else:
-            tr.canonical_step(cw, nw)
+            last = tr.canonical_step(cw, nw)
     barrier()
     dt = time.perf_counter() - t0
+    if not a.breakdown:
+        # the timed steps must have produced numbers: finite losses / targets / weights and no optimiser step masked on the device
+        lg_, ld_, tgt_ = last
+        assert bool(torch.isfinite(lg_)) and bool(torch.isfinite(ld_)) and bool(torch.isfinite(tgt_).all()), "non-finite loss / targets in the timed region"
+        assert bool(torch.isfinite(tr.G.flat_parameters().flat).all()) and bool(torch.isfinite(tr.D.flat_parameters().flat).all()), "non-finite weights"
+        status = tr.check_status(raise_on_error=True)
     if world > 1:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,9 +259,9 @@ def main():
             'unit': 'utterances/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': a.precision, 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[2]' if 'haspi' in a.metrics.lower() else 'BASELINE configs[1]') + ': batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
+            'config': {'workload': (('BASELINE configs[3]' if world > 1 else 'BASELINE configs[2]') if 'haspi' in a.metrics.lower() else 'BASELINE configs[1]') + ': batch=%d/GPU synthetic %.0f s@16 kHz RMS 0.03 utterances, %s targets, '
                                    'canonical GAN_epoch step (features, G-step, generate, metrics, D-step)' % (a.batch, a.length / 16000.0, '+'.join(metrics).upper()),
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma',
@@ -239,9 +292,16 @@ def main():
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}
             sys.stderr.write('stage ms: %s\n' % json.dumps({k: round(x, 3) for k, x in br.items()}))
         if a.inference > 0:
-            out['inference'] = inference_rate(tr, a.batch, a.inference, rank)
-        if a.epoch_equivalent > 0:
-            out['epoch_equivalent'] = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)
+            out['inference'] = inference_rate(tr, min(a.batch, 128), a.inference, rank)
+        if world == 1 and a.companions:
+            out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12)
+            out['nonperiodic'] = companion(a, a.metrics, a.batch, 63900, 4)
+    ee = None
+    if a.epoch_equivalent > 0:           # every rank takes part (g_step / d_step all-reduce when world > 1)
+        ee = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)
+    if rank == 0:
+        if ee is not None:
+            out['epoch_equivalent'] = ee
         if world == 1 and a.cpu_utts > 0:
             out['cpu_baseline'] = cpu_baseline(metrics, a.length, a.cpu_utts)
         print(json.dumps(out))

@@ -37,8 +37,14 @@ int nele_stft_band(const float* wav, int B, int L, float power, void* spec, floa
  * band [B][T][64] f32 = compute_band_E(sqrt(psd))**power (may be NULL). */
 int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream);
 
+/* audio_util.py:30-50 compute_band_E by itself: magnitude spectrogram mag [N][257] f32 -> band [N][64] f32 (no power law). */
+int nele_compute_band_E(const float* mag, int N, float* band, void* stream);
+
+/* audio_util.py:93-110 interp_band_gain by itself: bandE [N][64] f32 -> g [N][257] f64 (bins 0, 1 = 1e-4, bin 256 = 1e-2). */
+int nele_interp_band_gain(const float* bandE, int N, double* g, void* stream);
+
 /* audio_util.py:93-110 interp_band_gain, :76-90 Resyn, :458-461 SP_to_wav, :60-65 ISTFT.
- * alpha2 [B][T][64] f32 (energy gains), spec [B][T][257] complex64 -> wav [B][256*(T-1)] f32. */
+ * alpha2 [B][T][64] f32 (energy gains; NULL = plain ISTFT, no gain), spec [B][T][257] complex64 -> wav [B][256*(T-1)] f32. */
 int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream);
 
 /* inference.py:109 (enh / rms(enh) * target_rms, skipped when target_rms <= 0) and the PCM_16
@@ -163,6 +169,11 @@ int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* 
 /* torch.optim.Adam (train_nele.py:89-91) on flat buffers; step counts from 1. */
 int nele_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    int step, void* stream);
+/* The same update, skipped as a whole when any element of g is not finite (the reference raises from pysiib / pyhaspi2.py:357-358
+ * before such a target ever reaches the optimiser; here the step is masked on the device and counted).
+ * guard: device int[2], zeroed once by the caller = {last step with a non-finite gradient, number of skipped steps}. */
+int nele_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                           int step, int* guard, void* stream);
 
 /* ---- batched objective metrics (csrc/estoi.hip, csrc/siib.hip, csrc/haspi.hip) --------------------
  * Replace audio_util.py:120-203 read_batch_{STOI,SIIB,HASPI} (32 joblib processes over wav files) and

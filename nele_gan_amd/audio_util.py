@@ -98,6 +98,50 @@ def STFT(x, nfft=512, nw=512, nm=256):
     return spec[0].transpose(0, 1)
 
 
+def ISTFT(X, nw=512, nm=256):
+    """audio_util.py:60-65: X [257, T] complex64 -> wav [256*(T-1)] (librosa.istft, hop 256, window 512)."""
+    spec = _dev(X).to(torch.complex64).transpose(0, 1).contiguous().unsqueeze(0)
+    T = spec.shape[1]
+    wav = torch.empty((1, HOP * (T - 1)), dtype=torch.float32, device=spec.device)
+    call('nele_gain_istft', None, ptr(spec), 1, T, ptr(wav), stream())
+    return wav[0]
+
+
+def compute_band_E(X):
+    """audio_util.py:30-50: X magnitude spectrogram [T, 257] -> [T, 64] float32 band energies (device tensor)."""
+    X = _dev(X).float()
+    if X.dim() != 2 or X.shape[1] != N_BINS:
+        raise ValueError("compute_band_E: X must be [T, 257]")
+    out = torch.empty((X.shape[0], NB_BANDS), dtype=torch.float32, device=X.device)
+    call('nele_compute_band_E', ptr(X), X.shape[0], ptr(out), stream())
+    return out
+
+
+def interp_band_gain(bandE):
+    """audio_util.py:93-110: bandE [64] (or [T, 64]) -> g [257] (or [T, 257]) float64."""
+    b = _dev(bandE).float()
+    single = b.dim() == 1
+    b = b.reshape(-1, NB_BANDS).contiguous()
+    g = torch.empty((b.shape[0], N_BINS), dtype=torch.float64, device=b.device)
+    call('nele_interp_band_gain', ptr(b), b.shape[0], ptr(g), stream())
+    return g[0] if single else g
+
+
+def Resyn(X, alpha):
+    """audio_util.py:76-90: X [257, T] complex spectrogram, alpha [T, 64] energy gains -> wav [256*(T-1)]."""
+    spec = _dev(X).to(torch.complex64).transpose(0, 1).contiguous().unsqueeze(0)
+    return gain_istft(_dev(alpha).unsqueeze(0), spec)[0]
+
+
+def clip(x):
+    """audio_util.py:67-74: divide by (1.05, 1.10, ...) until max < 1 and min >= -1 (device tensor in, device tensor out)."""
+    from . import eval_metrics
+    x = _dev(x)
+    single = x.dim() == 1
+    out = eval_metrics.norm_clip(x.reshape(1, -1) if single else x)
+    return out[0] if single else out
+
+
 def NoisePSD(MIXED, nfft=512):
     """audio_util.py:113-117: MIXED [257, T] complex64 -> estimated noise PSD [257, T] f32."""
     spec = _dev(MIXED).transpose(0, 1).contiguous().unsqueeze(0)

@@ -251,6 +251,37 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Guarded update: a non-finite gradient (NaN / inf metric target, poisoned eigen-decomposition, overflow) must not reach the
+// parameters or the Adam moments - one such step would make every later step NaN.  grad_nonfinite_kernel marks guard[0] = step when
+// any element of g is not finite (atomicMax: the stored value is the same whichever thread wins); adam_guarded_kernel does nothing
+// when guard[0] == step and counts the skipped step in guard[1].  No host synchronisation: the host reads guard[1] when it wants to.
+__global__ void grad_nonfinite_kernel(const float* __restrict__ g, size_t n, int* guard, int step) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(g[i]);
+        bad |= ((u & 0x7f800000u) == 0x7f800000u);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(&guard[0], step);
+}
+
+__global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt, int* guard, int step) {
+    if (guard[0] == step) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard[1], 1);
+        return;
+    }
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // ptrs_host: HOST array of 3*layers device pointers {W, u, v} per layer; dims_host: HOST array of 2*layers ints {N, K};
 // sigma: device [layers].
@@ -332,5 +363,19 @@ extern "C" int nele_adam_step(float* p, const float* g, float* m, float* v, long
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long long)2048, (n + 255) / 256)), dim3(256), 0, as_stream(stream), p, g, m, v,
                        (size_t)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
     NELE_CHECK_LAUNCH("nele_adam_step");
+    return NELE_OK;
+}
+
+// guard: device int[2], zero-initialised by the caller once: {last step with a non-finite gradient, number of skipped steps}.
+extern "C" int nele_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                      int step, int* guard, void* stream) {
+    NELE_CHECK_ARG(p && g && m && v && guard && n > 0 && step >= 1, "nele_adam_step_guarded: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const dim3 grid((unsigned)min((long long)2048, (n + 255) / 256));
+    hipLaunchKernelGGL(grad_nonfinite_kernel, grid, dim3(256), 0, as_stream(stream), g, (size_t)n, guard, step);
+    hipLaunchKernelGGL(adam_guarded_kernel, grid, dim3(256), 0, as_stream(stream), p, g, m, v, (size_t)n, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), guard, step);
+    NELE_CHECK_LAUNCH("nele_adam_step_guarded");
     return NELE_OK;
 }

@@ -298,13 +298,13 @@ __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict
                                                          int T, float* __restrict__ wav) {
     __shared__ Fft512Lds s;
     const int b = blockIdx.y, fa = blockIdx.x, fb = fa + 1;
-    const float* a2a = alpha2 + ((size_t)b * T + fa) * NELE_NBANDS;
+    const float* a2a = alpha2 ? alpha2 + ((size_t)b * T + fa) * NELE_NBANDS : nullptr;   // NULL: plain ISTFT (audio_util.py:60-65)
     const float* a2b = a2a + NELE_NBANDS;
     const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
     const float2* Xb = Xa + NELE_NBINS;
     fft512_init_twiddles(s);
     for (int k = threadIdx.x; k < NELE_NBINS; k += 256) {
-        const double ga = band_gain_sqrt(a2a, k), gb = band_gain_sqrt(a2b, k);
+        const double ga = a2a ? band_gain_sqrt(a2a, k) : 1.0, gb = a2a ? band_gain_sqrt(a2b, k) : 1.0;
         const float2 xa = Xa[k], xb = Xb[k];
         double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
         double br = gb * (double)xb.x, bi = gb * (double)xb.y;
@@ -389,8 +389,56 @@ extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, floa
     return NELE_OK;
 }
 
+// compute_band_E (audio_util.py:30-50) on a magnitude spectrogram: X [N][257] f32 -> OUT [N][64] f32 (no power law).
+// One wave per frame: |X|^2 in float32 staged in LDS, then band_energy() in the reference's accumulation order.
+__global__ __launch_bounds__(256) void band_energy_kernel(const float* __restrict__ X, int N, float* __restrict__ out) {
+    __shared__ float tmp[4][NELE_NBINS + 3];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.x * 4 + w;
+    if (f < N)
+        for (int k = lane; k < NELE_NBINS; k += 64) {
+            const float m = X[(size_t)f * NELE_NBINS + k];
+            tmp[w][k] = m * m;
+        }
+    __syncthreads();
+    if (f < N) out[(size_t)f * NELE_NBANDS + lane] = band_energy(tmp[w], lane);
+}
+
+// interp_band_gain (audio_util.py:93-110): bandE [N][64] f32 -> g [N][257] f64 (the reference's np.ones(257) is float64; the
+// interpolation itself runs on the float32 band values, as numpy does with float32 scalars and python-float weights under NEP 50).
+__global__ void interp_gain_kernel(const float* __restrict__ bandE, int N, double* __restrict__ g) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * NELE_NBINS) return;
+    const int f = (int)(i / NELE_NBINS), k = (int)(i % NELE_NBINS);
+    double v;
+    if (k <= 1) v = 1e-4;
+    else if (k == NELE_NBINS - 1) v = 1e-2;
+    else {
+        int b = 0;
+        while (c_gmt[b + 1] <= k) ++b;
+        const int size = c_gmt[b + 1] - c_gmt[b], jj = k - c_gmt[b];
+        const double frac = (double)jj / (double)size;
+        v = (double)((float)(1.0 - frac) * bandE[(size_t)f * NELE_NBANDS + b] + (float)frac * bandE[(size_t)f * NELE_NBANDS + b + 1]);
+    }
+    g[i] = v;
+}
+
+extern "C" int nele_compute_band_E(const float* mag, int N, float* band, void* stream) {
+    NELE_CHECK_ARG(mag && band && N > 0, "nele_compute_band_E: bad arguments");
+    hipLaunchKernelGGL(band_energy_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), mag, N, band);
+    NELE_CHECK_LAUNCH("nele_compute_band_E");
+    return NELE_OK;
+}
+
+extern "C" int nele_interp_band_gain(const float* bandE, int N, double* g, void* stream) {
+    NELE_CHECK_ARG(bandE && g && N > 0, "nele_interp_band_gain: bad arguments");
+    const size_t n = (size_t)N * NELE_NBINS;
+    hipLaunchKernelGGL(interp_gain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), bandE, N, g);
+    NELE_CHECK_LAUNCH("nele_interp_band_gain");
+    return NELE_OK;
+}
+
 extern "C" int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream) {
-    NELE_CHECK_ARG(alpha2 && spec && wav && B > 0, "nele_gain_istft: bad arguments");
+    NELE_CHECK_ARG(spec && wav && B > 0, "nele_gain_istft: bad arguments");
     NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
     hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav);
     NELE_CHECK_LAUNCH("nele_gain_istft");

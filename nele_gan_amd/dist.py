@@ -40,6 +40,31 @@ def allreduce_mean_(flat):
     return flat
 
 
+def allreduce_weighted_mean_(flat, weight):
+    """In-place item-weighted mean over ranks: flat holds this rank's mean gradient over ``weight`` items (0 = none; the buffer is then
+    all zeros).  One all-reduce for the bucket and one for the scalar count; ranks with nothing to add still take part."""
+    if world_size() > 1:
+        cnt = torch.tensor([float(weight)], dtype=torch.float32, device=flat.device)
+        flat.mul_(float(weight))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        flat.div_(torch.clamp(cnt, min=1.0))
+    return flat
+
+
+def allreduce_max_int(value, device='cpu'):
+    """max over ranks of a host integer (e.g. the number of optimiser steps each rank's shard needs)."""
+    if world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def backend_is_nccl():
+    return is_dist() and dist.get_backend() == 'nccl'
+
+
 def broadcast_module_(module, src=0):
     """Make every replica identical to rank src: parameters and buffers (spectral-norm u, v)."""
     if world_size() > 1:

@@ -123,9 +123,19 @@ def _empty(shape, dev):
 _G_LAYERS = [(128, 256, 5), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 64, 5)]
 
 
+def _check_generation(ctx, name):
+    """The activation buffers are cached per (B, T): a second forward of the same shape overwrites what the first graph's backward
+    pass needs.  Each forward bumps the buffer set's generation; a backward whose generation is stale raises instead of silently
+    differentiating the wrong activations."""
+    if ctx.module._bufs[ctx.key].gen != ctx.gen:
+        raise RuntimeError("%s: backward() after another forward pass of the same (batch, frames) shape - the cached activations of "
+                           "this graph have been overwritten (run backward before the next forward of that shape)" % name)
+
+
 class _GBuffers:
     def __init__(self, B, T, dev):
         self.B, self.T = B, T
+        self.gen = 0
         self.inp = []      # time-padded inputs of each conv [B][T+K-1][Cin]
         self.Y = []        # raw conv outputs [B][T][Cout]
         self.mean, self.rstd = [], []
@@ -164,6 +174,7 @@ class _GFn(torch.autograd.Function):
     def forward(ctx, x, y, anchor, module):
         ctx.module = module
         ctx.key = module._forward_impl(x, y)
+        ctx.gen = module._bufs[ctx.key].gen
         mask = module._last_mask
         module._last_mask = None             # the output must not stay reachable from ctx except through save_for_backward:
         ctx.save_for_backward(mask)          # output -> grad_fn -> ctx -> output is a cycle the collector cannot free (2 MB per G-step)
@@ -172,6 +183,7 @@ class _GFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmask):
         (mask,) = ctx.saved_tensors
+        _check_generation(ctx, 'Generator_Conv1D_cLN')
         ctx.module._backward_impl(dmask.contiguous(), ctx.key, mask)
         return None, None, None, None
 
@@ -285,6 +297,7 @@ class Generator_Conv1D_cLN(nn.Module):
         self._flat.ensure(dev)
         B, T, _ = x.shape
         key, bf = self._get_bufs(B, T, dev)
+        bf.gen += 1
         wf, wb = self._prep_weights(dev)
         b16 = self.precision == 'bf16'
         call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
@@ -366,6 +379,7 @@ _D_CONVS = [(8, 1), (16, 3), (32, 5), (48, 7), (64, 9)]   # (Cout, k) ; Cin of l
 class _DBuffers:
     def __init__(self, B, T, dev, cin0):
         self.B, self.T = B, T
+        self.gen = 0
         H, W, C = 64, T, 4
         self.dims = [(H, W, C)]
         self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
@@ -418,6 +432,7 @@ class _DFn(torch.autograd.Function):
     def forward(ctx, din, anchor, module):
         ctx.module = module
         ctx.key = module._forward_impl(din)
+        ctx.gen = module._bufs[ctx.key].gen
         ctx.need_din = din.requires_grad
         score = module._last_score
         module._last_score = None
@@ -427,6 +442,7 @@ class _DFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dscore):
         (score,) = ctx.saved_tensors
+        _check_generation(ctx, 'Discriminator')
         ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, score)
         return ddin, None, None
 
@@ -519,8 +535,8 @@ class _DiscriminatorBase(nn.Module):
         ev.record(torch.cuda.current_stream())
         self._prepared = (key, self.training, ev)
 
-    def _prepare_inline(self, key, bf, w):
-        n_iter = 1 if self.training else 0
+    def _prepare_inline(self, key, bf, w, power_iter=True):
+        n_iter = 1 if (self.training and power_iter) else 0
         # spectral norm: power iteration (train mode) + sigma for all 8 layers in one launch (model.py:105-116)
         mods = self._sn_modules()
         pp = (c_void_p * (3 * len(mods)))()
@@ -583,10 +599,15 @@ class _DiscriminatorBase(nn.Module):
         key, bf = self._get_bufs(B, T, dev)
         w = self._weights(dev)
         prep, self._prepared = self._prepared, None
-        if prep is not None and prep[0] == key and prep[1] == self.training:
+        if prep is not None and prep[1] == self.training:
             torch.cuda.current_stream().wait_event(prep[2])
+            if prep[0] != key:
+                # prepared for another shape: u, v have already advanced once for this forward pass (the reference advances them once per
+                # training forward, model.py:105-116) - only the shape-dependent weight layouts are redone
+                self._prepare_inline(key, bf, w, power_iter=False)
         else:
             self._prepare_inline(key, bf, w)
+        bf.gen += 1
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):

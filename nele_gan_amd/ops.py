@@ -44,6 +44,7 @@ _SIGS = {
                          c_int, _P, _P, _P, _P, _P, _P],
     'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     'nele_adam_step': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P],
+    'nele_adam_step_guarded': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P, _P],
 }
 for _n, _a in _SIGS.items():
     declare(_n, _a)
@@ -164,8 +165,11 @@ def weight_prep(Wt, sigma, N, Cvalid, C, KH, KW, Wf, Wb):
     call('nele_weight_prep', ptr(Wt), ptr(sigma), N, Cvalid, C, KH, KW, ptr(Wf), ptr(Wb), stream())
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
-    call('nele_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream())
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, guard=None):
+    if guard is not None:
+        call('nele_adam_step_guarded', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, ptr(guard), stream())
+    else:
+        call('nele_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream())
 
 
 def energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True, want_alpha2=False):

@@ -14,12 +14,14 @@ class Adam:
         self.step_count = 0
         self.m = None
         self.v = None
+        self.guard = None        # device int[2]: {last step whose gradient was not finite, number of skipped steps}
 
     def _state(self):
         fp = self.module.flat_parameters()
         if self.m is None or self.m.device != fp.flat.device or self.m.numel() != fp.flat.numel():
             self.m = torch.zeros_like(fp.flat)
             self.v = torch.zeros_like(fp.flat)
+            self.guard = torch.zeros(2, dtype=torch.int32, device=fp.flat.device)
         return fp
 
     def zero_grad(self):
@@ -28,7 +30,11 @@ class Adam:
     def step(self):
         fp = self._state()
         self.step_count += 1
-        ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.guard)
+
+    def skipped_steps(self):
+        """Optimiser steps masked on the device because the gradient was not finite (synchronises the host)."""
+        return 0 if self.guard is None else int(self.guard[1].item())
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.m, 'exp_avg_sq': self.v, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps}

@@ -67,15 +67,26 @@ class GanTrainer:
         self._side = None
         self._side2 = None
         self._fside = None
+        self._last_enh = None                        # enhanced batch of the last canonical_step (parity tests read it)
+        # metric status, accumulated on the device without a host synchronisation and read by check_status():
+        # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
+        #  HASPI below threshold (pyhaspi2.py:357-358 raises)] - one accumulator per stream that folds into it
+        self._status = {}
         self.world = ndist.world_size()
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
                 ndist.broadcast_module_(m, 0)
 
     # ---------------------------------------------------------------- data-parallel glue
-    def _allreduce_grads(self, module):
+    def _allreduce_grads(self, module, weight=None):
+        """One flat all-reduce of the module's gradient bucket.  weight=None: mean over ranks (equal shards).  weight=n: this rank's
+        gradient is the mean over its n items (0 = empty step); the result is the mean over all items of all ranks."""
         if self.world > 1:
-            ndist.allreduce_mean_(module.flat_parameters().grad)
+            g = module.flat_parameters().grad
+            if weight is None:
+                ndist.allreduce_mean_(g)
+            else:
+                ndist.allreduce_weighted_mean_(g, float(weight))
 
     # ---------------------------------------------------------------- features (dataloader.py:30-42)
     def features(self, clean_wav, noise_wav):
@@ -117,10 +128,7 @@ class GanTrainer:
         self.D.profile_prefix = ''
         loss = self.MSELoss(score, torch.ones_like(score))
         if self.D_Qua is not None:
-            din_q = torch.zeros_like(din)
-            din_q[..., 0] = din[..., 0]
-            din_q[..., 1] = din[..., 2]
-            score_q = self.D_Qua.forward_packed(din_q)
+            score_q = self.D_Qua.forward_packed(self.quality_inputs(din))
             loss = loss + weight_qua * self.MSELoss(score_q, torch.ones_like(score_q))
         loss.backward()
         self._allreduce_grads(self.G)
@@ -141,7 +149,47 @@ class GanTrainer:
         self.G.train()
         return enh_wav
 
+    # ---------------------------------------------------------------- metric status (intel.py / pysiib / pyhaspi2.py raise; here: count)
+    def _note_status(self, which, siib_info=None, haspi_info=None):
+        """Fold a metric call's per-utterance status into the device-side counters of accumulator ``which`` on the current stream."""
+        acc = self._status.get(which)
+        if acc is None:
+            acc = self._status[which] = torch.zeros(3, dtype=torch.int64, device=self.device)
+        if siib_info is not None:
+            st = siib_info[:, 3]
+            acc[0:2] += torch.stack((((st & 24) != 0).sum(), ((st & 7) != 0).sum()))
+        if haspi_info is not None:
+            acc[2:3] += (haspi_info[:, 1] != 0).sum()
+
+    def check_status(self, raise_on_error=True):
+        """Synchronising read of everything the step masked or counted on the device: metric scores the reference would have raised on
+        (SIIB with too few active frames, HASPI below threshold), truncated SIIB scores (replication / frame caps), and optimiser steps
+        skipped because their gradient was not finite (a NaN target or a poisoned eigen-decomposition must not reach the weights).
+        Call once per epoch (run_epoch does)."""
+        tot = torch.zeros(3, dtype=torch.int64)
+        for acc in self._status.values():
+            tot += acc.cpu()
+        st = {'siib_undefined': int(tot[0]), 'siib_clamped': int(tot[1]), 'haspi_below_threshold': int(tot[2]),
+              'skipped_g_steps': self.optimizer_g.skipped_steps(), 'skipped_d_steps': self.optimizer_d.skipped_steps(),
+              'skipped_dqua_steps': self.optimizer_dqua.skipped_steps() if self.optimizer_dqua is not None else 0}
+        if raise_on_error and any(st[k] for k in ('siib_undefined', 'haspi_below_threshold', 'skipped_g_steps', 'skipped_d_steps',
+                                                  'skipped_dqua_steps')):
+            raise RuntimeError("NELE-GAN step status: %s (undefined metric targets; the reference raises from pysiib / "
+                               "pyhaspi2.py:357-358 on such utterances; the affected optimiser steps were skipped)" % st)
+        return st
+
     # ---------------------------------------------------------------- true metric targets (train_nele.py:318-340)
+    def _metric(self, m, x, y, which):
+        if m == 'siib':
+            raw, mapped, info = mt.batch_siib(x, y, return_info=True)
+            self._note_status(which, siib_info=info)
+        elif m == 'haspi':
+            raw, mapped, info = mt.batch_haspi(x, y, return_info=True)
+            self._note_status(which, haspi_info=info)
+        else:
+            raw, mapped = mt.batch_estoi(x, y)
+        return raw, mapped
+
     @torch.no_grad()
     def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True):
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
@@ -149,7 +197,7 @@ class GanTrainer:
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
         cols = []
         for m in self.metrics:
-            raw, mapped = getattr(mt, _METRIC_FN[m])(x, y)
+            raw, mapped = self._metric(m, x, y, 'main')
             cols.append(mapped if norm else raw)
         return torch.stack(cols, dim=1)
 
@@ -159,18 +207,39 @@ class GanTrainer:
         _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False)
         return ops.d_pack(enh_band, noise_band, clean_band)
 
-    def d_step(self, din, target):
-        self.optimizer_d.zero_grad()
-        score = self.D.forward_packed(din)
-        return self._d_finish(score, target)
+    @staticmethod
+    def quality_inputs(din):
+        """[enhanced, clean] of the packed D input (dataloader.py:83: the D_Qua item drops the noise channel)."""
+        din_q = torch.zeros_like(din)
+        din_q[..., 0] = din[..., 0]
+        din_q[..., 1] = din[..., 2]
+        return din_q
 
-    def _d_finish(self, score, target):
-        loss = self.MSELoss(score, target)
-        loss.backward()
-        self._allreduce_grads(self.D)
+    def d_step(self, din, target, target_qua=None, weight=None):
+        """One optimiser step of D on (din, target) - and of D_Qua on ([enh, clean], target_qua) when the quality discriminator is
+        enabled and quality targets are given (train_nele.py:356-365).  ``weight``: number of items this rank contributes (d_epoch
+        under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives."""
+        self.optimizer_d.zero_grad()
+        score = self.D.forward_packed(din) if din is not None else None
+        loss = self._d_finish(score, target, weight)
+        if self.D_Qua is not None and (target_qua is not None or (din is None and weight is not None)):
+            self.optimizer_dqua.zero_grad()
+            if din is not None:
+                loss_qua = self.MSELoss(self.D_Qua.forward_packed(self.quality_inputs(din)), target_qua)
+                loss_qua.backward()
+            self._allreduce_grads(self.D_Qua, weight)
+            self.optimizer_dqua.step()
+        return loss
+
+    def _d_finish(self, score, target, weight=None):
+        loss = None
+        if score is not None:
+            loss = self.MSELoss(score, target)
+            loss.backward()
+        self._allreduce_grads(self.D, weight)
         self.optimizer_d.step()
         self.step_d += 1
-        return loss.detach()
+        return loss.detach() if loss is not None else None
 
     # ---------------------------------------------------------------- one canonical step (SURVEY 8d)
     def canonical_step(self, clean_wav, noise_wav, feats=None):
@@ -210,6 +279,7 @@ class GanTrainer:
             self.D.prepare(B_, T_, self.device)
         enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
         assert enh.shape[1] == L
+        self._last_enh = enh
         ready = torch.cuda.Event()
         ready.record(main)
         if self._side2 is None:
@@ -223,11 +293,14 @@ class GanTrainer:
             y_ready.record(side)
             if split is not None:
                 cols['siib'] = split.degraded_part(y)[1]
+        haspi_info = None
         with torch.cuda.stream(side2):                     # the cheaper metrics beside SIIB's degraded-signal part
             side2.wait_event(start)
             side2.wait_event(y_ready)
             for m in self.metrics:
-                if m != 'siib':
+                if m == 'haspi':
+                    _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True)
+                elif m != 'siib':
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
             others = torch.cuda.Event()
             others.record(side2)
@@ -238,6 +311,8 @@ class GanTrainer:
             tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
             done = torch.cuda.Event()
             done.record(side)
+            # status accounting after the event the main stream waits for: off the critical path
+            self._note_status('side', siib_info=split.info if split is not None else None, haspi_info=haspi_info)
         for t in (x, y):
             t.record_stream(side2)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
@@ -253,19 +328,120 @@ class GanTrainer:
         return lg, ld, tgt
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
+    @staticmethod
+    def _length_buckets(lst, batch):
+        """Shuffled sample list -> batches of at most ``batch`` items with the same frame count T (the reference trains D at batch 1
+        on utterances of any length, train_nele.py:349-367; a batched launch needs one T, so items are grouped by T in shuffled
+        order and every group is cut into batches)."""
+        groups = {}
+        for it in lst:
+            groups.setdefault(int(it[0].shape[1]), []).append(it)
+        out = []
+        for T in sorted(groups):
+            g = groups[T]
+            out += [g[k:k + batch] for k in range(0, len(g), batch)]
+        return out
+
+    def _d_pass(self, lst, batch):
+        random.shuffle(lst)
+        chunks = self._length_buckets(lst, batch)
+        n_steps = len(chunks)
+        if self.world > 1:
+            # ranks hold different shards (and length mixes): every rank must join the same number of all-reduces
+            n_steps = ndist.allreduce_max_int(n_steps, self.device)
+        for k in range(n_steps):
+            if k < len(chunks):
+                ch = chunks[k]
+                tq = torch.stack([c[2] for c in ch]) if (self.D_Qua is not None and len(ch[0]) > 2 and ch[0][2] is not None) else None
+                self.d_step(torch.stack([c[0] for c in ch]), torch.stack([c[1] for c in ch]), tq,
+                            weight=len(ch) if self.world > 1 else None)
+            else:
+                self.d_step(None, None, None, weight=0)
+        return n_steps
+
     def d_epoch(self, samples, batch=32):
-        """samples: list of (din [64,T,4], target [n]) tensors of this epoch (generated + pre-enhanced 'DRC' examples)."""
-        def run(lst):
-            random.shuffle(lst)
-            for i in range(0, len(lst), batch):
-                chunk = lst[i:i + batch]
-                self.d_step(torch.stack([c[0] for c in chunk]), torch.stack([c[1] for c in chunk]))
+        """samples: list of (din [64,T,4], target [n]) or (din, target, target_qua [2]) tensors of this epoch (generated +
+        pre-enhanced 'DRC' examples), this rank's shard.  Three passes as train_nele.py:342-426."""
         cur = list(samples)
-        run(cur)                                                        # pass A
-        random.shuffle(self.history)
-        run(self.history[0:len(self.history) // 30] + cur)              # pass B: replay 1/30 of the history
-        self.history = self.history + cur
-        run(cur)                                                        # pass C
+        self._d_pass(cur, batch)                                        # pass A (:349-367)
+        n_hist = len(self.history)
+        if self.world > 1:
+            # the same replay positions on every rank (drawn on rank 0, broadcast): shards have equal history lengths up to the
+            # remainder, so positions are drawn below the shortest one
+            n_hist = -ndist.allreduce_max_int(-n_hist, self.device)
+            idx = ndist.replay_indices(n_hist, 30, seed=self.step_d, device=self.device if ndist.backend_is_nccl() else 'cpu')
+            replay = [self.history[i] for i in idx]
+        else:
+            random.shuffle(self.history)                                # :373-376
+            replay = self.history[0:n_hist // 30]
+        self._d_pass(replay + cur, batch)                               # pass B: 1/30 of the history + current (:380-398)
+        self.history = self.history + cur                               # :403
+        self._d_pass(cur, batch)                                        # pass C (:406-424)
+
+    # ---------------------------------------------------------------- one GAN epoch (train_nele.py:110-429)
+    def run_epoch(self, gan_epoch, train_batches, valid_batches=(), chkpt_path=None, sample_dir=None, log_path=None, d_batch=32,
+                  check=True):
+        """One iteration of ``for gan_epoch in np.arange(1, GAN_epoch+1)`` (train_nele.py:110) in the reference's order.
+
+        train_batches / valid_batches: sequences of dicts {'clean': wav [B,L], 'noise': wav [B,L], optional 'names': [B] wave names,
+        optional 'drc': pre-enhanced wav [B,L] (the MultiEnh example of the same utterance, train_nele.py:333-340), optional
+        'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua)}.
+          1. G-steps over the training batches - from epoch 2 on (:122-156; epoch 1 fits D to the untrained generator first)
+          2. validation: enhance, raw (unmapped) metrics, learning-curve line (:159-225)
+          3. checkpoint (:272-277)
+          4. generate the D training samples of the same training utterances (:279-316)
+          5. true metric targets of the generated and of the pre-enhanced examples (:318-340)
+          6. D (and D_Qua) training: three passes with 1/30 history replay (:342-426)
+        Returns a dict of what happened (losses, validation means, counts)."""
+        out = {'gan_epoch': int(gan_epoch), 'g_steps': 0, 'g_loss': None, 'valid': None, 'samples': 0}
+        feats = [None] * len(train_batches)
+        if gan_epoch >= 2:                                              # :122
+            tot = None
+            for i, b in enumerate(train_batches):
+                feats[i] = self.features(b['clean'], b['noise'])
+                lg = self.g_step(feats[i]['clean_band'], feats[i]['noise_band'])
+                tot = lg if tot is None else tot + lg
+                out['g_steps'] += 1
+            out['g_loss'] = tot / max(1, out['g_steps']) if tot is not None else None
+        raw = []
+        for b in valid_batches:                                         # :159-222
+            f = self.features(b['clean'], b['noise'])
+            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False))
+        if raw:
+            r = torch.cat(raw, dim=0).double().mean(dim=0).cpu().numpy()
+            col = {m: float(r[i]) for i, m in enumerate(self.metrics)}
+            out['valid'] = col
+            line = self.validation_log_line(col.get('siib', 0.0), col.get('haspi', 0.0), col.get('estoi', 0.0), gan_epoch)
+            if log_path is not None and ndist.rank() == 0:
+                with open(log_path, 'a') as fh:                         # :224-225
+                    fh.write(line)
+        if chkpt_path is not None and ndist.rank() == 0:
+            self.save_checkpoint(chkpt_path)                            # :272-277
+        samples = []
+        for i, b in enumerate(train_batches):                           # :279-340
+            f = feats[i] if feats[i] is not None else self.features(b['clean'], b['noise'])
+            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+            if sample_dir is not None and 'names' in b:
+                self.write_samples(enh, b['names'], sample_dir, gan_epoch)
+            tgt = self.true_metrics(b['clean'], enh, b['noise'])
+            din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
+            qua = b.get('qua')
+            samples += [(din[k], tgt[k], qua[k] if qua is not None else None) for k in range(din.shape[0])]
+            if b.get('drc') is not None:
+                Lr = enh.shape[1]
+                drc = b['drc'][:, :Lr].contiguous()
+                tgt_d = self.true_metrics(b['clean'], drc, b['noise'])
+                din_d = self.d_inputs(drc, f['noise_band'], f['clean_band'])
+                qd = b.get('drc_qua')
+                samples += [(din_d[k], tgt_d[k], qd[k] if qd is not None else None) for k in range(din_d.shape[0])]
+        out['samples'] = len(samples)
+        d0 = self.step_d
+        self.d_epoch(samples, batch=d_batch)                            # :342-426
+        out['d_steps'] = self.step_d - d0
+        if check:
+            out['status'] = self.check_status()
+        return out
 
     # ---------------------------------------------------------------- file hand-off (train_nele.py:303-340, 224-225)
     def write_samples(self, enh_wav, wave_names, directory, gan_epoch):

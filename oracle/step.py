@@ -41,6 +41,19 @@ def metric_targets(clean, enh, noise, metrics, norm=True):
     return np.asarray(out, dtype=np.float32)
 
 
+def _one_metric(clean, enh, noise, metric, norm=True):
+    return float(metric_targets(clean, enh, noise, (metric,), norm)[0])
+
+
+def _one_feature(c, v):
+    b, m, p = F.sp_and_phase_speech(c, P_POWER)
+    return b, m, p, F.sp_and_phase_noise(v, P_POWER)[0]
+
+
+def _noop(i):
+    return i
+
+
 class CpuStep:
     """State (weights, Adam moments) + one canonical step over a batch."""
 
@@ -58,14 +71,15 @@ class CpuStep:
     def _t(self, key, t0):
         self.times[key] = self.times.get(key, 0.0) + time.perf_counter() - t0
 
-    def features(self, clean, noise):
+    def features(self, clean, noise, workers=1):
+        """workers > 1: one process per utterance, as the reference's DataLoader(num_workers=8) (dataloader.py:91)."""
         t0 = time.perf_counter()
-        cb, cm, cp = [], [], []
-        nb = []
-        for c, v in zip(clean, noise):
-            b, m, p = F.sp_and_phase_speech(c, P_POWER)
-            cb.append(b); cm.append(m); cp.append(p)
-            nb.append(F.sp_and_phase_noise(v, P_POWER)[0])
+        if workers > 1:
+            from joblib import Parallel, delayed
+            res = Parallel(n_jobs=workers)(delayed(_one_feature)(c, v) for c, v in zip(clean, noise))
+        else:
+            res = [_one_feature(c, v) for c, v in zip(clean, noise)]
+        cb, cm, cp, nb = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res], [r[3] for r in res]
         self._t('features', t0)
         return np.stack(cb), cm, cp, np.stack(nb)
 
@@ -87,7 +101,7 @@ class CpuStep:
         loss.backward()
         self.opt_g.step()
         self._t('g_step', t0)
-        return float(loss)
+        return float(loss.detach())
 
     def generate(self, cb, nb, cm, cp, pcm16=True):
         t0 = time.perf_counter()
@@ -104,11 +118,32 @@ class CpuStep:
         self._t('generate', t0)
         return out
 
-    def targets(self, clean, enh, noise):
+    def targets(self, clean, enh, noise, workers=1):
+        """workers > 1: the reference's joblib fan-out, one job per (utterance, metric) (audio_util.py:146, 174, 202)."""
         t0 = time.perf_counter()
-        t = np.stack([metric_targets(c, e, v, self.metrics) for c, e, v in zip(clean, enh, noise)])
+        if workers > 1:
+            from joblib import Parallel, delayed
+            jobs = [(i, m) for m in self.metrics for i in range(len(clean))]
+            vals = Parallel(n_jobs=workers)(delayed(_one_metric)(clean[i], enh[i], noise[i], m) for i, m in jobs)
+            t = np.zeros((len(clean), len(self.metrics)), dtype=np.float32)
+            for (i, m), x in zip(jobs, vals):
+                t[i, self.metrics.index(m)] = x
+        else:
+            t = np.stack([metric_targets(c, e, v, self.metrics) for c, e, v in zip(clean, enh, noise)])
         self._t('metrics', t0)
         return t
+
+    def epoch_slice(self, clean, noise, feature_workers=8, metric_workers=32):
+        """The reference's work for these utterances in its own order and batching (train_nele.py:119-156, 279-367): features by the
+        loader workers, one G-step per utterance (batch 1), generate, metric fan-out over processes, one D-step per utterance."""
+        cb, cm, cp, nb = self.features(clean, noise, workers=feature_workers)
+        for i in range(len(clean)):
+            self.g_step(cb[i:i + 1], nb[i:i + 1])
+        enh = self.generate(cb, nb, cm, cp)
+        tgt = self.targets(clean, enh, noise, workers=metric_workers)
+        for i in range(len(clean)):
+            self.d_step(enh[i:i + 1], nb[i:i + 1], cb[i:i + 1], tgt[i:i + 1])
+        return tgt
 
     def d_step(self, enh, nb, cb, tgt):
         t0 = time.perf_counter()
@@ -120,7 +155,7 @@ class CpuStep:
         loss.backward()
         self.opt_d.step()
         self._t('d_step', t0)
-        return float(loss)
+        return float(loss.detach())
 
     def canonical_step(self, clean, noise):
         cb, cm, cp, nb = self.features(clean, noise)

@@ -1,0 +1,213 @@
+"""CPU: the epoch driver's ORDER (train_nele.py:110-429) with stubbed stages, the length bucketing of the D passes, and the
+data-parallel D epoch on ragged shards (gloo, world size 2): every rank joins the same number of all-reduces and the replicas
+stay identical.  No GPU and no HIP kernels are involved: the stages are replaced by recorders / a tiny torch-CPU discriminator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _bare_trainer():
+    from nele_gan_amd.train_nele import GanTrainer
+    tr = GanTrainer.__new__(GanTrainer)
+    tr.metrics = ['siib', 'estoi']
+    tr.device = torch.device('cpu')
+    tr.D_Qua = None
+    tr.optimizer_dqua = None
+    tr.history = []
+    tr.step_d = 0
+    tr.step_g = 0
+    tr.world = 1
+    tr.pcm16 = True
+    tr._status = {}
+    return tr
+
+
+def _recording_trainer(log):
+    tr = _bare_trainer()
+    T = 30
+
+    def features(c, n):
+        log.append('features')
+        return {'clean_band': torch.zeros(c.shape[0], T, 64), 'noise_band': torch.zeros(c.shape[0], T, 64), 'clean_spec': None}
+
+    def g_step(cb, nb):
+        log.append('g_step')
+        return torch.tensor(0.5)
+
+    def generate(cb, nb, spec, rms_target=0.0):
+        log.append('generate')
+        return torch.zeros(cb.shape[0], 256 * (T - 1))
+
+    def true_metrics(c, e, n, norm=True):
+        log.append('metrics' if norm else 'metrics_raw')
+        return torch.full((c.shape[0], 2), 0.25)
+
+    def d_inputs(e, nb, cb):
+        log.append('d_inputs')
+        return torch.zeros(e.shape[0], 64, T, 4)
+
+    def d_epoch(samples, batch=32):
+        log.append('d_epoch:%d' % len(samples))
+
+    def save_checkpoint(path):
+        log.append('checkpoint')
+
+    tr.features, tr.g_step, tr.generate, tr.true_metrics = features, g_step, generate, true_metrics
+    tr.d_inputs, tr.d_epoch, tr.save_checkpoint = d_inputs, d_epoch, save_checkpoint
+    tr.check_status = lambda raise_on_error=True: {}
+    return tr
+
+
+def _batches(n, B=2, L=256 * 29, drc=False):
+    out = []
+    for _ in range(n):
+        b = {'clean': torch.zeros(B, L), 'noise': torch.zeros(B, L)}
+        if drc:
+            b['drc'] = torch.zeros(B, L)
+        out.append(b)
+    return out
+
+
+def test_epoch_one_has_no_generator_step_and_the_reference_order(tmp_path):
+    """train_nele.py:122: `if gan_epoch >= 2` guards the G-steps; then validation (:159), checkpoint (:272), sample generation
+    (:279), true targets of the generated and of the pre-enhanced examples (:318-340), the three D passes (:342)."""
+    log = []
+    tr = _recording_trainer(log)
+    out = tr.run_epoch(1, _batches(2, drc=True), valid_batches=_batches(1), chkpt_path=str(tmp_path / 'c.pt'), log_path=str(tmp_path / 'log.txt'))
+    assert 'g_step' not in log and out['g_steps'] == 0 and out['g_loss'] is None
+    assert log == ['features', 'generate', 'metrics_raw',                       # validation
+                   'checkpoint',
+                   'features', 'generate', 'metrics', 'd_inputs', 'metrics', 'd_inputs',   # batch 0: generated + DRC example
+                   'features', 'generate', 'metrics', 'd_inputs', 'metrics', 'd_inputs',   # batch 1
+                   'd_epoch:8']
+    assert out['samples'] == 8
+    line = open(tmp_path / 'log.txt').read()
+    assert line == 'SIIB is 0.250, HASPI is 0.000, ESTOI is 0.250, PESQ is 0.000, VISQOL is 0.000, EPOCH:1 \n'   # train_nele.py:224
+
+
+def test_epoch_two_runs_generator_steps_first_and_reuses_their_features():
+    log = []
+    tr = _recording_trainer(log)
+    out = tr.run_epoch(2, _batches(3))
+    assert log[:6] == ['features', 'g_step'] * 3 and out['g_steps'] == 3 and float(out['g_loss']) == 0.5
+    rest = log[6:]
+    assert rest == ['generate', 'metrics', 'd_inputs'] * 3 + ['d_epoch:6']       # no second feature pass for the same utterances
+    assert 'checkpoint' not in log                                                # no path given
+
+
+def test_length_buckets_group_by_frame_count_in_shuffled_order():
+    from nele_gan_amd.train_nele import GanTrainer
+    items = [(torch.zeros(64, T, 4), torch.tensor([float(i)])) for i, T in enumerate([30, 40, 30, 30, 40, 50, 30])]
+    chunks = GanTrainer._length_buckets(items, 2)
+    assert [[int(c[1]) for c in ch] for ch in chunks] == [[0, 2], [3, 6], [1, 4], [5]]
+    assert all(len({int(c[0].shape[1]) for c in ch}) == 1 for ch in chunks)
+
+
+# ------------------------------------------------------------------------------------------ data-parallel D epoch on ragged shards
+class _Flat:
+    def __init__(self, n):
+        self.flat = torch.zeros(n)
+        self.grad = torch.zeros(n)
+
+
+class _TinyD(torch.nn.Module):
+    """Stands for the discriminator: score = sigmoid(mean over (64, T, 4) * w + b); same flat-buffer surface as the real module."""
+
+    def __init__(self):
+        super().__init__()
+        self._f = _Flat(2)
+        self._f.flat[:] = torch.tensor([0.3, -0.1])
+
+    def flat_parameters(self):
+        return self._f
+
+    def forward_packed(self, din):
+        self._w = self._f.flat.detach().clone().requires_grad_(True)
+        return torch.sigmoid(din.mean(dim=(1, 2, 3)).unsqueeze(1) * self._w[0] + self._w[1])
+
+    def collect(self):
+        if getattr(self, '_w', None) is not None and self._w.grad is not None:
+            self._f.grad += self._w.grad
+            self._w = None
+
+
+class _Sgd:
+    def __init__(self, mod, lr=0.5):
+        self.mod, self.lr, self.steps = mod, lr, 0
+
+    def zero_grad(self):
+        self.mod.flat_parameters().grad.zero_()
+
+    def step(self):
+        f = self.mod.flat_parameters()
+        f.flat -= self.lr * f.grad
+        self.steps += 1
+
+    def skipped_steps(self):
+        return 0
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import random
+    from nele_gan_amd import dist as nd
+    tr = _bare_trainer()
+    tr.world = world
+    tr.D = _TinyD()
+    tr.optimizer_d = _Sgd(tr.D)
+    tr.MSELoss = torch.nn.MSELoss()
+    orig_allreduce = tr._allreduce_grads
+
+    def allreduce(module, weight=None):                 # the tiny module accumulates its autograd result into the flat bucket first
+        module.collect()
+        orig_allreduce(module, weight)
+    tr._allreduce_grads = allreduce
+    random.seed(100 + rank)                             # different shuffles per rank, as with different shards
+    rs = np.random.RandomState(7)
+    # 11 items of 3 different lengths, sharded 6 / 5: ragged chunk counts per rank
+    Ts = [30, 30, 40, 50, 30, 40, 30, 30, 50, 50, 40]
+    items = [(torch.from_numpy(rs.rand(64, T, 4).astype(np.float32)), torch.tensor([float(rs.rand())])) for T in Ts]
+    lo, hi = nd.shard_range(len(items))
+    tr.history = [items[i] for i in range(lo, hi)] * 8   # 48 / 40 items of history: replay positions < 40 // 30 ... drawn on rank 0
+    tr.d_epoch(items[lo:hi], batch=2)
+    res = {'w': tr.D.flat_parameters().flat.numpy().copy(), 'steps': tr.optimizer_d.steps, 'step_d': tr.step_d,
+                 'hist': len(tr.history)}
+    # one explicit weighted step: rank 0 contributes 3 items, rank 1 one item -> the global mean over 4 items
+    g = torch.tensor([float(rank + 1), 2.0 * (rank + 1)])
+    nd.allreduce_weighted_mean_(g, 3 if rank == 0 else 1)
+    res['wmean'] = g.numpy().copy()
+    e = torch.zeros(2)
+    nd.allreduce_weighted_mean_(e, 0)                     # nobody contributes: stays zero, no division by zero
+    res['empty'] = e.numpy().copy()
+    res['max'] = nd.allreduce_max_int(3 + rank)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_data_parallel_d_epoch_on_ragged_shards_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0['steps'] == r1['steps'] and r0['step_d'] == r1['step_d']            # same number of optimiser steps / all-reduces
+    np.testing.assert_array_equal(r0['w'], r1['w'])                               # replicas identical after the epoch
+    assert not np.array_equal(r0['w'], np.array([0.3, -0.1], dtype=np.float32))   # and they did move
+    np.testing.assert_allclose(r0['wmean'], [(3 * 1 + 1 * 2) / 4.0, (3 * 2 + 1 * 4) / 4.0])
+    np.testing.assert_array_equal(r0['wmean'], r1['wmean'])
+    np.testing.assert_array_equal(r0['empty'], [0.0, 0.0])
+    assert r0['max'] == 4 and r1['max'] == 4
