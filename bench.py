@@ -81,13 +81,18 @@ def inference_rate(tr, batch, K, rank):
             'realtime_factor': batch * 8.0 / dt}
 
 
-def companion(a, metric_str, batch, length, steps):
+def companion(a, metric_str, batch, length, steps, main_tr=None):
     """The canonical step of another workload on this GPU (fresh trainer, 2 warm-up steps, `steps` timed steps)."""
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
     tr = GanTrainer(metric_str)
     tr.D.precision = tr.G.precision = a.precision
+    if main_tr is not None:
+        # same logical streams as the headline trainer: the runtime multiplexes streams onto 4 hardware queues, and a second set of
+        # seven streams would time-slice with the (idle) first set's queues (DESIGN 6, "hardware queues")
+        tr._side, tr._side2, tr._fside = main_tr._side, main_tr._side2, main_tr._fside
+        tr.D._wstream, tr.G._wstream = main_tr.D._wstream, main_tr.G._wstream
     c, v = synth.batch(batch, length, start=20000)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
     for _ in range(2):
@@ -294,8 +299,8 @@ def main():
         if a.inference > 0:
             out['inference'] = inference_rate(tr, min(a.batch, 128), a.inference, rank)
         if world == 1 and a.companions:
-            out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12)
-            out['nonperiodic'] = companion(a, a.metrics, a.batch, 63900, 4)
+            out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12, tr)
+            out['nonperiodic'] = companion(a, a.metrics, a.batch, 63900, 4, tr)
     ee = None
     if a.epoch_equivalent > 0:           # every rank takes part (g_step / d_step all-reduce when world > 1)
         ee = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)

@@ -221,6 +221,14 @@ long long nele_metric_haspi_workspace_bytes(int B, int L, int fs_in);
 int nele_metric_haspi_nsub(int L, int fs_in);
 int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
                       long long workspace_bytes, float* raw, float* mapped, int* info, void* stream);
+/* The same with per-utterance lengths and split by data dependence.  lengths [B] (device, may be NULL = every row has L samples):
+ * samples of each utterance in the padded [B][L] buffers - the reference scores files of any length one at a time
+ * (audio_util.py:134-141, intel.py:58-60), a batch carries them side by side.  phase 0 = everything; phase 3 = everything that
+ * needs only the CLEAN signal x (its whole ear model, envelope filter, silence gate, group-delay shifts, cepstra, modulation
+ * filtering; y, raw, mapped may be NULL); phase 4 = the degraded signal's chain + correlation + score on the same workspace
+ * (x may be NULL).  Phase 0 runs 3 then 4, so the split is bit-identical to the one-shot call. */
+int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
+                          void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info, int phase, void* stream);
 
 /* ---- evaluation path (csrc/reverb.hip) ---------------------------------------------------------------------- */
 

@@ -295,7 +295,11 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
             vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
         }
         EC_T(6);
-        if (p == ((s + 1) & 7)) {                          // one workgroup records the step
+        // Step -1's record (row 0 of A becomes reflector 0) is deferred until after this step's exchange: a peer workgroup that is
+        // scheduled late (the launch is only co-resident on an otherwise idle GPU) still has to read row 0 / column 0 of the ORIGINAL
+        // matrix in its prologue; every peer's first publication proves that it has.  (Found in round 2: wrong - not NaN - eigenvalues
+        // whenever another stream's kernels delayed some workgroups of a matrix.)
+        if (s >= 0 && p == ((s + 1) & 7)) {                          // one workgroup records the step
             if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
             if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
         }
@@ -388,6 +392,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 #endif
             }
             if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
+        }
+        if (s == -1 && p == 0) {                             // deferred record of step -1 (see above)
+            if (i == 0) { d[0] = x_i; e[0] = betan; tau[0] = tn; }
+            if (i >= 1 && i < n) A[i] = vn_i;
         }
         v_i = vn_i;
         tk = tn;
@@ -486,7 +494,11 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             }
             vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
         }
-        if (p == ((s + 1) & 3)) {
+        // Step -1's record (row 0 of A becomes reflector 0) is deferred until after this step's exchange: a peer workgroup that is
+        // scheduled late (the launch is only co-resident on an otherwise idle GPU) still has to read row 0 / column 0 of the ORIGINAL
+        // matrix in its prologue; every peer's first publication proves that it has.  (Found in round 2: wrong - not NaN - eigenvalues
+        // whenever another stream's kernels delayed some workgroups of a matrix.)
+        if (s >= 0 && p == ((s + 1) & 3)) {
             if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
             if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
         }
@@ -590,6 +602,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
             if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
         }
         EC_T(5);
+        if (s == -1 && p == 0) {                             // deferred record of step -1 (see above)
+            if (i == 0) { d[0] = x_i; e[0] = betan; tau[0] = tn; }
+            if (i >= 1 && i < n) A[i] = vn_i;
+        }
         v_i = vn_i;
         tk = tn;
         if (s == s_stop) {

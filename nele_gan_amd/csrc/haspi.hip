@@ -35,12 +35,19 @@
 #define HP_NFILT 52
 #define HP_NHALF 26
 
+// Storage type of the two per-sample, per-channel envelope arrays (12.6 GB each in float64 at B = 256, and every stage between the
+// filter banks and the envelope low-pass streams them through HBM).  All ARITHMETIC on them stays float64 (filter states, IHC
+// adaptation, FIR sums); only the stored |u|^2 / dB values are rounded to float32: 6e-8 relative = 2.6e-7 dB on |u|^2, < 4e-6 dB on
+// the dB-SL envelope (values 0..100) - against the 0.1 dB dither the reference itself adds per frame (pyhaspi2.py:362-365), and
+// 1e-4 relative on the final score (measured effect: < 1e-7, tests/test_metrics_gpu.py golden + oracle comparisons).
+typedef float hp_env_t;
+
 struct HaspiWs {
     double* win;     // [HP_NWIN] resampler half window
     float* r24;      // [B][2][n24]   resampled, RMS-restored (float32 as in the reference)
     double* mid;     // [B][2][n24]   middle-ear output
-    double* ctl;     // [B][2][n24][32] control envelope -> compression gain -> (reused)
-    double* env;     // [B][2][n24][32] signal envelope -> compressed -> dB SL -> adapted dB SL
+    hp_env_t* ctl;   // [B][2][n24][32] control envelope |u|^2 (-> compression gain in the unfused diagnostic path)
+    hp_env_t* env;   // [B][2][n24][32] signal envelope |u|^2 -> compressed, dB SL -> adapted dB SL
     double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
     double* ssp;     // [B][2][16][32] control-bank sum-of-squares partials per chunk (chunk-parallel banks)
     double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
@@ -51,9 +58,23 @@ struct HaspiWs {
     int* info;       // [B][2]        {n_active, status}
     double* cep;     // [B][2][6][nsub] mean-removed cepstral sequences (only the first n_active columns)
     double* cm;      // [B][6][10]    |rho|
-    int n24, nsub;
+    double* xf;      // [B][5][10][nsub] modulation-filtered reference sequences (clean part -> degraded part)
+    const int* lens; // [B] samples per utterance at the input rate, or NULL (every row has L samples)
+    int fs_in;
+    int n24, nsub;   // of the longest row: buffer strides
     int n24p;        // n24 rounded up to a multiple of HP_CH: row stride of the per-sample buffers (chunked kernels read/write whole chunks)
 };
+
+// Per-utterance lengths inside one padded batch (the reference is batch 1 over files of any length, audio_util.py:134-141)
+__device__ __forceinline__ int hp_len(const HaspiWs& ws, int b, int L) { return ws.lens ? min(ws.lens[b], L) : L; }
+__device__ __forceinline__ int hp_n24(const HaspiWs& ws, int b) {
+    if (!ws.lens) return ws.n24;
+    const int Lb = ws.lens[b];
+    return min(ws.n24, (ws.fs_in == 24000) ? Lb : (int)((double)Lb * 1.5));
+}
+__device__ __forceinline__ int hp_nsub(const HaspiWs& ws, int b) { return (hp_n24(ws, b) + HP_SPACE - 1) / HP_SPACE; }
+// (utterance, signal) row of a launch that covers nsig signals starting at sig0: idx = b * nsig + s
+__device__ __forceinline__ int hp_row(int idx, int sig0, int nsig) { return nsig == 2 ? idx : 2 * idx + sig0; }
 
 __device__ __forceinline__ double i0_series(double x) {
     double s = 1.0, t = 1.0;
@@ -81,12 +102,14 @@ __global__ void haspi_win_kernel(double* __restrict__ win) {
 }
 
 // ---- h1: one block per (utterance, signal)
-__global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, int fs_in,
-                                                             HaspiWs ws) {
+__global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, int fs_in,
+                                                             HaspiWs ws, int sig0) {
     __shared__ double red[8];
-    const int b = blockIdx.x, sig = blockIdx.y, tid = threadIdx.x;
-    const float* src = (sig ? y : x) + (size_t)b * L;
+    const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
+    const int L = hp_len(ws, b, Lmax), n24 = hp_n24(ws, b);
+    const float* src = (sig ? y : x) + (size_t)b * Lmax;
     float* dst = ws.r24 + ((size_t)b * 2 + sig) * ws.n24p;
+    for (int i = n24 + tid; i < ws.n24p; i += 256) dst[i] = 0.f;      // the chunked kernels read whole chunks: defined values behind a short row
     // rms normalisation (pyhaspi2.py:81-84), float32 like the reference's arrays
     double acc = 0.0;
     for (int i = tid; i < L; i += 256) acc += (double)(src[i] * src[i]);
@@ -117,12 +140,12 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     }
     const double time_increment = 1.0 / 1.5;
     double a2 = 0.0;
-    for (int t0 = 0; t0 < ws.n24; t0 += RS_CH) {
+    for (int t0 = 0; t0 < n24; t0 += RS_CH) {
         const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
         __syncthreads();
         for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? src[nbase + e] / rms : 0.f;
         __syncthreads();
-        for (int t = t0 + tid; t < min(ws.n24, t0 + RS_CH); t += 256) {
+        for (int t = t0 + tid; t < min(n24, t0 + RS_CH); t += 256) {
             const double time_register = (double)t * time_increment;
             const int n = (int)time_register;
             double frac = time_register - (double)n;
@@ -175,19 +198,19 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     for (int i = tid; i < L; i += 256) { const float v = src[i] / rms; xs += (double)(v * v); }
     xs = block_sum(xs, red);
     a2 = block_sum(a2, red);
-    const float xr = sqrtf((float)(xs / (double)L)), yr = sqrtf((float)(a2 / (double)ws.n24));
+    const float xr = sqrtf((float)(xs / (double)L)), yr = sqrtf((float)(a2 / (double)n24));
     const float g = xr / yr;
     __syncthreads();
-    for (int t = tid; t < ws.n24; t += 256) dst[t] = g * dst[t];
+    for (int t = tid; t < n24; t += 256) dst[t] = g * dst[t];
 }
 
 // ---- h2: middle ear (pyhaspi2.py:833-841), scipy lfilter = direct form II transposed. grid B, block 64 (lanes 0,1 active).
 // All serial kernels below move samples in register chunks of HP_CH: the loads of a chunk are issued back to back (one
 // memory latency per chunk instead of one per sample), then the recurrence runs out of registers.
 #define HP_CH 32
-__global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws) {
-    const int b = blockIdx.x, sig = threadIdx.x;
-    if (sig >= 2) return;
+__global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int b = blockIdx.x, sig = sig0 + threadIdx.x;
+    if ((int)threadIdx.x >= nsig) return;
     const float* src = ws.r24 + ((size_t)b * 2 + sig) * ws.n24p;
     double* dst = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
@@ -218,8 +241,8 @@ __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws) {
 // rounding of the samples (two active lanes per utterance made the serial kernel 7 ms at B = 256).  grid (ceil(chunks / 64), 2 B).
 #define ME_N 2048
 #define ME_W 1024
-__global__ __launch_bounds__(64) void haspi_midear_par_kernel(HaspiWs ws) {
-    const int row = blockIdx.y, n0 = (blockIdx.x * 64 + threadIdx.x) * ME_N;
+__global__ __launch_bounds__(64) void haspi_midear_par_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int row = hp_row(blockIdx.y, sig0, nsig), n0 = (blockIdx.x * 64 + threadIdx.x) * ME_N;
     if (n0 >= ws.n24p) return;
     const int n1 = min(n0 + ME_N, ws.n24p);
     const float* src = ws.r24 + (size_t)row * ws.n24p;
@@ -291,7 +314,7 @@ __device__ __forceinline__ double hp_bw1(int ch) {
 // (utterance, signal), issue-bound - the float64 square root was half of the instructions of a sample.
 __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn, double sn);
 __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ xin, int n24, const GtCoef c, double cf, int part,
-                                                    double* __restrict__ out) {
+                                                    hp_env_t* __restrict__ out) {
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
     double cold = 1.0, sold = 0.0;
@@ -318,7 +341,7 @@ __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ x
         }
         if (part == 0) {
 #pragma unroll
-            for (int u = 0; u < HP_CH; ++u) out[(size_t)(n0 + u) * HP_NCH] = eo[u];
+            for (int u = 0; u < HP_CH; ++u) out[(size_t)(n0 + u) * HP_NCH] = (hp_env_t)eo[u];
         }
     }
     return ss;
@@ -338,12 +361,20 @@ __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn,
     cold = arg;
 }
 __device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ xin, int n24, int n24p, const GtCoef c, double cf, int part,
-                                                     double* __restrict__ out, int chunk, int lc) {
+                                                     hp_env_t* __restrict__ out, int chunk, int lc) {
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
-    const int n0 = chunk * lc, n1 = min(n0 + lc, n24p), start = max(0, n0 - GT_W);
+    const int n0 = chunk * lc, n1 = min(n0 + lc, min(n24p, (n24 + HP_CH - 1) / HP_CH * HP_CH)), start = max(0, n0 - GT_W);
+    if (n0 >= n1) return 0.0;                                          // chunk entirely behind the end of a short row
+    // demodulator state before sample `start` = R^(start-1) applied to (1, 0) (eb_CosSinCF's rotation recurrence, pyhaspi2.py:855-860):
+    // evaluated directly - replaying up to 90 000 dependent rotations put 0.7 ms of pure latency at the head of the last chunk; the
+    // recurrence's own accumulated rounding is ~1e-11 of a radian there, far below anything the score can see
     double cold = 1.0, sold = 0.0;
-    for (int n = 1; n < start; ++n) hp_rotate(cold, sold, cn, sn);      // state before sample `start` = R^(start-1)
+    if (start > 1) {
+        const double ang = tpt * cf * (double)(start - 1);
+        cold = cos(ang);
+        sold = -sin(ang);
+    }
     double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     double ss = 0.0;
     for (int nb = start; nb < n1; nb += HP_CH) {
@@ -368,55 +399,56 @@ __device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ 
         }
         if (part == 0 && live) {
 #pragma unroll
-            for (int u = 0; u < HP_CH; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
+            for (int u = 0; u < HP_CH; ++u) out[(size_t)(nb + u) * HP_NCH] = (hp_env_t)eo[u];
         }
     }
     return ss;
 }
 // grid (chunks, 2, B), block 64
-__global__ __launch_bounds__(64) void haspi_control_par_kernel(HaspiWs ws, int lc) {
-    const int b = blockIdx.z, sig = blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+__global__ __launch_bounds__(64) void haspi_control_par_kernel(HaspiWs ws, int lc, int sig0) {
+    const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    const double ss = hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(bw1, cf), cf, part, out, blockIdx.x, lc);
+    hp_env_t* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    const double ss = hp_gammatone_chunk(xin, hp_n24(ws, b), ws.n24p, hp_gt(bw1, cf), cf, part, out, blockIdx.x, lc);
     if (part == 0) ws.ssp[(((size_t)b * 2 + sig) * GT_MAXC + blockIdx.x) * HP_NCH + ch] = ss;
 }
 // eb_BWadjust from the chunk partials.  grid 2 B, block 32
-__global__ void haspi_bw_kernel(HaspiWs ws, int nchunks) {
-    const int row = blockIdx.x, ch = threadIdx.x;
+__global__ void haspi_bw_kernel(HaspiWs ws, int nchunks, int sig0, int nsig) {
+    const int row = hp_row(blockIdx.x, sig0, nsig), ch = threadIdx.x;
     const double bw1 = hp_bw1(ch);
     const GtCoef cc = hp_gt(bw1, hp_cfreq(ch));
     double ss = 0.0;
     for (int c = 0; c < nchunks; ++c) ss += ws.ssp[((size_t)row * GT_MAXC + c) * HP_NCH + ch];
     ss *= cc.gain * cc.gain;
-    const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
+    const double cdB = 20.0 * log10(sqrt(ss / (double)hp_n24(ws, row >> 1))) + HP_LEVEL;
     double BW;
     if (cdB < 50.0) BW = 1.0;
     else if (cdB > 100.0) BW = bw1;
     else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
     ws.bw[(size_t)row * HP_NCH + ch] = BW;
 }
-__global__ __launch_bounds__(64) void haspi_signal_par_kernel(HaspiWs ws, int lc) {
-    const int b = blockIdx.z, sig = blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+__global__ __launch_bounds__(64) void haspi_signal_par_kernel(HaspiWs ws, int lc, int sig0) {
+    const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch);
     const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    (void)hp_gammatone_chunk(xin, ws.n24, ws.n24p, hp_gt(BW, cf), cf, part, out, blockIdx.x, lc);
+    hp_env_t* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    (void)hp_gammatone_chunk(xin, hp_n24(ws, b), ws.n24p, hp_gt(BW, cf), cf, part, out, blockIdx.x, lc);
 }
 
 // ---- h3: control bank + bandwidth adjustment. grid (2, B), block 64
-__global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws) {
-    const int b = blockIdx.y, sig = blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+__global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws, int sig0) {
+    const int b = blockIdx.y, sig = sig0 + blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    double* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    hp_env_t* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
     const GtCoef cc = hp_gt(bw1, cf);
-    const double ss = (cc.gain * cc.gain) * hp_gammatone_wave(xin, ws.n24, cc, cf, part, out);   // sum of (gain |u|)^2
+    const int n24 = hp_n24(ws, b);
+    const double ss = (cc.gain * cc.gain) * hp_gammatone_wave(xin, n24, cc, cf, part, out);   // sum of (gain |u|)^2
     if (part == 0) {
         // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
-        const double cdB = 20.0 * log10(sqrt(ss / (double)ws.n24)) + HP_LEVEL;
+        const double cdB = 20.0 * log10(sqrt(ss / (double)n24)) + HP_LEVEL;
         double BW;
         if (cdB < 50.0) BW = 1.0;
         else if (cdB > 100.0) BW = bw1;
@@ -426,40 +458,42 @@ __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws) {
 }
 
 // ---- h4: signal bank. grid (2, B), block 64
-__global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws) {
-    const int b = blockIdx.y, sig = blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+__global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws, int sig0) {
+    const int b = blockIdx.y, sig = sig0 + blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch);
     const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
     const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    double* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    (void)hp_gammatone_wave(xin, ws.n24, hp_gt(BW, cf), cf, part, out);
+    hp_env_t* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    (void)hp_gammatone_wave(xin, hp_n24(ws, b), hp_gt(BW, cf), cf, part, out);
 }
 
 // ---- h5: compression gain from the control envelope (pyhaspi2.py:982-991), point-wise, in place on ctl
-__global__ void haspi_gain_kernel(HaspiWs ws, size_t total) {
+__global__ void haspi_gain_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) {
     // the grid stride is a multiple of 32, so a thread stays on one channel: its control-filter gain is computed once
     const int ch = (int)(threadIdx.x & 31);
     const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
     const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        double le = fmax(cgain * sqrt(ws.ctl[i]), 1.0e-30);          // control envelope = gain |u| (ctl holds |u|^2)
+    const size_t base = (size_t)hp_row(blockIdx.y, sig0, nsig) * per_row;
+    for (size_t i = base + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < base + per_row; i += (size_t)gridDim.x * blockDim.x) {
+        double le = fmax(cgain * sqrt((double)ws.ctl[i]), 1.0e-30);  // control envelope = gain |u| (ctl holds |u|^2)
         le = HP_LEVEL + 20.0 * log10(le);
         le = fmin(fmax(le, 30.0), 100.0);
         const double g = -0.0 - (le - 30.0) * (1.0 - (1.0 / CR));
-        ws.ctl[i] = exp(g * (2.302585092994046 / 20.0));   // 10^(g/20)
+        ws.ctl[i] = (hp_env_t)exp(g * (2.302585092994046 / 20.0));   // 10^(g/20)
     }
 }
 
 // ---- h6: gain low-pass lfilter([b,b],[1,a]) (pyhaspi2.py:992-995), serial, in place on ctl (one stream per lane). grid B, block 64
-__global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double* g = ws.ctl + (((size_t)b * 2 + (lane >> 5)) * ws.n24p) * HP_NCH + (lane & 31);
+__global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws, int sig0, int nsig, int nrows) {
+    const int lane = threadIdx.x, idx = 2 * blockIdx.x + (lane >> 5);
+    if (idx >= nrows) return;
+    hp_env_t* g = ws.ctl + ((size_t)hp_row(idx, sig0, nsig) * ws.n24p) * HP_NCH + (lane & 31);
     const double b0 = 0.095107983402496, a1 = -0.809784033195007;
     double z = 0.0;
     for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
         double gx[HP_CH];
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) gx[u] = g[(size_t)(n0 + u) * HP_NCH];
+        for (int u = 0; u < HP_CH; ++u) gx[u] = (double)g[(size_t)(n0 + u) * HP_NCH];
 #pragma unroll
         for (int u = 0; u < HP_CH; ++u) {
             const double y = b0 * gx[u] + z;
@@ -467,21 +501,21 @@ __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws) {
             gx[u] = y;
         }
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) g[(size_t)(n0 + u) * HP_NCH] = gx[u];
+        for (int u = 0; u < HP_CH; ++u) g[(size_t)(n0 + u) * HP_NCH] = (hp_env_t)gx[u];
     }
 }
 
 // ---- h7: compressed envelope = filtered gain * envelope (pyhaspi2.py:997) and eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise
 // grid (blocks, 2 B): blockIdx.y = (utterance, signal), whose adjusted bandwidth fixes the signal filter's gain per channel
-__global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row) {
-    const int ch = (int)(threadIdx.x & 31);
-    const double sgain = hp_gt(ws.bw[(size_t)blockIdx.y * HP_NCH + ch], hp_cfreq(ch)).gain;
-    const size_t base = (size_t)blockIdx.y * per_row;
+__global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) {
+    const int ch = (int)(threadIdx.x & 31), row = hp_row(blockIdx.y, sig0, nsig);
+    const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
+    const size_t base = (size_t)row * per_row;
     for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < per_row; r += (size_t)gridDim.x * blockDim.x) {
         const size_t i = base + r;
-        const double c = ws.ctl[i] * (sgain * sqrt(ws.env[i]));      // signal envelope = gain |u| (env holds |u|^2)
+        const double c = (double)ws.ctl[i] * (sgain * sqrt((double)ws.env[i]));      // signal envelope = gain |u| (env holds |u|^2)
         const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
-        ws.env[i] = y < 0.0 ? 0.0 : y;
+        ws.env[i] = (hp_env_t)(y < 0.0 ? 0.0 : y);
     }
 }
 
@@ -494,34 +528,43 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row) {
 #define GL_N 2048
 #define GL_W 256
 #define GL_U 8
-__global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws) {
-    const int ch = threadIdx.x & 31, row = blockIdx.y;
+// log2 / exp2 on the float32 transcendental unit (v_log_f32 / v_exp_f32, 1 ulp): the dB values they produce are accurate to 1e-6 dB,
+// like the float32 storage of the envelopes (see hp_env_t); the float64 log10 / exp / sqrt calls they replace were 90 % of this
+// kernel's instructions and kept it compute-bound at 0.3 of the HBM rate.
+__device__ __forceinline__ float hp_log2f(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float hp_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
+__global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int ch = threadIdx.x & 31, row = hp_row(blockIdx.y, sig0, nsig);
     const int n0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * GL_N;
-    if (n0 >= ws.n24p) return;
-    const int n1 = min(n0 + GL_N, ws.n24p);
+    const int n24r = (hp_n24(ws, row >> 1) + HP_CH - 1) / HP_CH * HP_CH;   // whole register chunks of this row
+    if (n0 >= n24r) return;
+    const int n1 = min(n0 + GL_N, n24r);
     const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
     const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
-    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1), slope = 1.0 - (1.0 / CR);
+    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+    const float slope = (float)(1.0 - (1.0 / CR));
+    // 20 log10(gain sqrt(c)) = 20 log10(gain) + 10 log10(c) = 20 log10(gain) + (10 log10 2) log2(c)
+    const float TEN_LOG10_2 = 3.0102999566398120f, LOG2_10_OVER_20 = 0.16609640474436813f;
+    const float c_off = (float)(HP_LEVEL + 20.0 * log10(cgain)), s_off = (float)(HP_LEVEL + 20.0 * log10(sgain));
     const double b0 = 0.095107983402496, a1 = -0.809784033195007;
-    const double* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
-    double* env = ws.env + (size_t)row * ws.n24p * HP_NCH + ch;
+    const hp_env_t* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
+    hp_env_t* env = ws.env + (size_t)row * ws.n24p * HP_NCH + ch;
     double z = 0.0;
     for (int n = max(0, n0 - GL_W); n < n1; n += GL_U) {       // n0, GL_W and n24p are multiples of GL_U
-        double gx[GL_U], ev[GL_U];
+        float gc[GL_U], ev[GL_U];
+        double gx[GL_U];
         const bool live = n >= n0;
 #pragma unroll
-        for (int u = 0; u < GL_U; ++u) gx[u] = ctl[(size_t)(n + u) * HP_NCH];
+        for (int u = 0; u < GL_U; ++u) gc[u] = ctl[(size_t)(n + u) * HP_NCH];
         if (live) {
 #pragma unroll
             for (int u = 0; u < GL_U; ++u) ev[u] = env[(size_t)(n + u) * HP_NCH];
         }
 #pragma unroll
-        for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:982-991
-            double le = fmax(cgain * sqrt(gx[u]), 1.0e-30);
-            le = HP_LEVEL + 20.0 * log10(le);
-            le = fmin(fmax(le, 30.0), 100.0);
-            const double g = -0.0 - (le - 30.0) * slope;
-            gx[u] = exp(g * (2.302585092994046 / 20.0));
+        for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:982-991 (the 1e-30 floor lies far below the 30 dB clamp)
+            float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
+            le = fminf(fmaxf(le, 30.0f), 100.0f);
+            gx[u] = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);    // 10^(g/20)
         }
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:992-995
@@ -531,19 +574,22 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws) {
         }
         if (live) {
 #pragma unroll
-            for (int u = 0; u < GL_U; ++u) {                   // pyhaspi2.py:997, 1080-1088
-                const double c = gx[u] * (sgain * sqrt(ev[u]));
-                const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
-                env[(size_t)(n + u) * HP_NCH] = y < 0.0 ? 0.0 : y;
+            for (int u = 0; u < GL_U; ++u) {                   // pyhaspi2.py:997, 1080-1088: 20 log10(g sgain sqrt(e) + 1e-30), clamped at 0
+                // (the 1e-30 term only matters where the result is far below the clamp)
+                const float g = (float)gx[u];
+                const float y = s_off + TEN_LOG10_2 * hp_log2f(g * g * ev[u]);
+                env[(size_t)(n + u) * HP_NCH] = y > 0.0f ? y : 0.0f;
             }
         }
     }
 }
 
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
-__global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double* e = ws.env + (((size_t)b * 2 + (lane >> 5)) * ws.n24p) * HP_NCH + (lane & 31);
+__global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int nsig, int nrows) {
+    const int lane = threadIdx.x, idx = 2 * blockIdx.x + (lane >> 5);
+    if (idx >= nrows) return;
+    const int row = hp_row(idx, sig0, nsig), n24 = hp_n24(ws, row >> 1);
+    hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + (lane & 31);
     const double delta = 2.0;
     const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
     const double T = 1 / HP_FS;
@@ -554,10 +600,10 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
     const double denom = 1.0 / (a11 * a22 - a21 * a12);
     const double R1inv = 1.0 / R1, R12C1 = R1 * R2 * (C1 / T), R23C2 = R2 * R3 * (C2 / T);
     double V1 = 0.0, V2 = 0.0;
-    for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
+    for (int n0 = 0; n0 < n24; n0 += HP_CH) {
         double ex[HP_CH];
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) ex[u] = e[(size_t)(n0 + u) * HP_NCH];
+        for (int u = 0; u < HP_CH; ++u) ex[u] = (double)e[(size_t)(n0 + u) * HP_NCH];
 #pragma unroll
         for (int u = 0; u < HP_CH; ++u) {
             const double V0 = ex[u];
@@ -569,7 +615,7 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws) {
             ex[u] = out < 0.0 ? 0.0 : out;
         }
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) e[(size_t)(n0 + u) * HP_NCH] = ex[u];
+        for (int u = 0; u < HP_CH; ++u) e[(size_t)(n0 + u) * HP_NCH] = (hp_env_t)ex[u];
     }
 }
 
@@ -598,13 +644,15 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
 // applied while loading) are staged in LDS once; thread = (sub-frame, channel).
 #define EF_SUB 16
 #define EF_SPAN (EF_SUB * HP_SPACE + HP_NFILT)
-__global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
+__global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0) {
     __shared__ double xs[EF_SPAN][HP_NCH + 1];
-    const int b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x, ch = tid & 31;
+    const int b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x, ch = tid & 31;
     const int i0 = blockIdx.x * EF_SUB;
+    const int n24 = hp_n24(ws, b), nsub = hp_nsub(ws, b);
+    if (i0 >= nsub) return;
     const double* __restrict__ benv = ws.benv;           // uniform index -> scalar loads: the taps cost no LDS read (the loop was bound by LDS issue)
     const int s = ws.shift[(size_t)b * HP_NCH + ch];
-    const double* e = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
+    const hp_env_t* e = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
     // LDS row q <-> shifted-envelope index m = 9*i0 + 26 - 51 + q
     const int mbase = HP_SPACE * i0 + HP_NHALF - (HP_NFILT - 1);
     {   // all loads of the thread are issued before the first LDS store (unconditional, clamped index, then select)
@@ -614,19 +662,19 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
         for (int u = 0; u < NQ; ++u) {
             const int q = (tid >> 5) + 8 * u;
             const int src = mbase + q - s;
-            val[u] = e[(size_t)min(max(src, 0), ws.n24 - 1) * HP_NCH];
+            val[u] = (double)e[(size_t)min(max(src, 0), n24 - 1) * HP_NCH];
         }
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int q = (tid >> 5) + 8 * u;
             const int m = mbase + q, src = m - s;
-            if (q < EF_SPAN) xs[q][ch] = (m >= 0 && m < ws.n24 && src >= 0) ? val[u] : 0.0;
+            if (q < EF_SPAN) xs[q][ch] = (m >= 0 && m < n24 && src >= 0) ? val[u] : 0.0;
         }
     }
     __syncthreads();
     for (int li = tid >> 5; li < EF_SUB; li += 8) {
         const int i = i0 + li;
-        if (i >= ws.nsub) break;
+        if (i >= nsub) break;
         double acc = 0.0;
         // out[i] = sum_k benv[k] * x[9 i + 26 - k]  ->  LDS row (9 li + 51 - k)
 #pragma unroll 4
@@ -635,13 +683,17 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws) {
     }
 }
 
-// ---- h10: ebm_CepCoef (pyhaspi2.py:342-375). one block per utterance
-__global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve) {
+// ---- h10: ebm_CepCoef (pyhaspi2.py:342-375). one block per utterance.
+// gate != 0: silence gate on the REFERENCE envelope + ordered compaction of the active frames (needs x only);
+// then the cepstral sequences of signals sig0 .. sig0+nsig-1 over those frames.
+__global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int gate, int sig0,
+                                                        int nsig) {
     __shared__ double cepm[HP_NCH][HP_NBASIS];
     __shared__ int scan[256];
     __shared__ int base;
     __shared__ double red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int nsub = hp_nsub(ws, b);
     if (tid < HP_NBASIS) {
         double nn = 0.0;
         for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
@@ -653,33 +705,38 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
     const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
     const double* ylp = xlp + (size_t)ws.nsub * HP_NCH;
     int* act = ws.act + (size_t)b * ws.nsub;
-    // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
-    for (int i0 = 0; i0 < ws.nsub; i0 += 256) {
-        const int i = i0 + tid;
-        int k = 0;
-        if (i < ws.nsub) {
-            double s = 0.0;
-            for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
-            k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
-        }
-        scan[tid] = k;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int v = (tid >= o) ? scan[tid - o] : 0;
+    int na;
+    if (gate) {
+        // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
+        for (int i0 = 0; i0 < nsub; i0 += 256) {
+            const int i = i0 + tid;
+            int k = 0;
+            if (i < nsub) {
+                double s = 0.0;
+                for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
+                k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+            }
+            scan[tid] = k;
             __syncthreads();
-            scan[tid] += v;
+            for (int o = 1; o < 256; o <<= 1) {
+                const int v = (tid >= o) ? scan[tid - o] : 0;
+                __syncthreads();
+                scan[tid] += v;
+                __syncthreads();
+            }
+            if (k) act[base + scan[tid] - 1] = i;
+            __syncthreads();
+            if (tid == 255) base += scan[255];
             __syncthreads();
         }
-        if (k) act[base + scan[tid] - 1] = i;
-        __syncthreads();
-        if (tid == 255) base += scan[255];
-        __syncthreads();
+        na = base;
+        if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
+    } else {
+        na = ws.info[2 * b];
     }
-    const int na = base;
-    if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
     if (na <= 1) return;
     // cepstra of the active frames (+ dither), then remove the mean of each sequence
-    for (int sig = 0; sig < 2; ++sig) {
+    for (int sig = sig0; sig < sig0 + nsig; ++sig) {
         const double* lp = sig ? ylp : xlp;
         const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
         double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
@@ -714,8 +771,13 @@ __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38,
 #define MF_L4 ((HP_TILE + HP_MAXFIR + 4 + 3) / 4 + 1)
 #define MF_POS(e) ((((e) & 3) * MF_L4) + ((e) >> 2))
 
+// SIG = 0 (clean part): filter the reference's cepstral sequence and keep the filtered sequence xf [b][basis-1][band][t];
+// SIG = 1 (degraded part): filter the processed signal's sequence and correlate it with the stored xf (ebm_ModCorr).
+// Each pass stages (v cos, v sin) of ONE signal: half of the LDS and of the per-tap work of a joint pass; the reference half runs
+// before the enhanced signal exists (GanTrainer overlaps it with the G-step).
+template <int SIG>
 __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
-    __shared__ __attribute__((aligned(32))) double4 sq[4 * MF_L4];   // (x cos, x sin, y cos, y sin) of one sequence element: two 16-byte reads per tap instead of four 8-byte ones
+    __shared__ __attribute__((aligned(16))) double2 sq[4 * MF_L4];   // (v cos, v sin) of one sequence element: one 16-byte read per tap
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[2 * b];
@@ -723,8 +785,8 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     const int nfir = c_modnfir[k], nh = nfir / 2;
     // np.hanning(nfir+1) / sum ; sum of a symmetric Hann window of M points = (M-1)/2
     const double* __restrict__ bk = ws.bkt + k * 616;    // uniform index in the tap loop -> scalar loads
-    const double* xc = ws.cep + (((size_t)b * 2 + 0) * HP_NBASIS + basis) * ws.nsub;
-    const double* yc = ws.cep + (((size_t)b * 2 + 1) * HP_NBASIS + basis) * ws.nsub;
+    const double* vc = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + basis) * ws.nsub;
+    double* xf = ws.xf + (((size_t)b * (HP_NBASIS - 1) + (basis - 1)) * HP_NMOD + k) * ws.nsub;
     const double cf = c_modcf[k];
     const double SQ2 = 1.4142135623730951;
     double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
@@ -734,36 +796,36 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
         for (int e = tid; e < HP_TILE + nfir; e += 256) {
             const int j = t0 - nh + e;
             const int jc = min(max(j, 0), na - 1);
-            double vx = xc[jc], vy = yc[jc], c = 1.0, s = 0.0;
-            if (!(j >= 0 && j < na)) { vx = 0.0; vy = 0.0; }
+            double v = vc[jc], c = 1.0, s = 0.0;
+            if (!(j >= 0 && j < na)) v = 0.0;
             if (k > 0) {
                 // sqrt(2) cos(pi n cf / fNyq), n = j + 1, fNyq = 1280
                 const double ang = M_PI * (double)(j + 1) * cf / 1280.0;
                 c = SQ2 * cos(ang);
                 s = SQ2 * sin(ang);
             }
-            sq[MF_POS(e)] = make_double4(vx * c, vx * s, vy * c, vy * s);
+            sq[MF_POS(e)] = make_double2(v * c, v * s);
         }
         __syncthreads();
         // thread -> outputs t = t0 + 4 tid + q, q = 0..3:  u[t] = sum_i b[i] z[t + nh - i]  (LDS index 4 tid + q + nfir - i)
         const int tb = t0 + 4 * tid;
         if (tb < na) {
-            double ur[4] = {0, 0, 0, 0}, ui[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
+            double ur[4] = {0, 0, 0, 0}, ui[4] = {0, 0, 0, 0};
             const int e0 = 4 * tid + nfir;
             // window registers hold z[e0 - i + q] for q = 0..3
-            double wxc[4], wxs[4], wyc[4], wys[4];
+            double wc[4], wsn[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const double4 v4 = sq[MF_POS(e0 + q)]; wxc[q] = v4.x; wxs[q] = v4.y; wyc[q] = v4.z; wys[q] = v4.w; }
-#pragma unroll 4                                               // the register window then rotates by renaming instead of 24 moves per tap
+            for (int q = 0; q < 4; ++q) { const double2 v2 = sq[MF_POS(e0 + q)]; wc[q] = v2.x; wsn[q] = v2.y; }
+#pragma unroll 4                                               // the register window then rotates by renaming instead of moves per tap
             for (int i = 0; i <= nfir; ++i) {
                 const double w = bk[i];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ur[q] += w * wxc[q]; ui[q] -= w * wxs[q]; vr[q] += w * wyc[q]; vi[q] -= w * wys[q]; }
+                for (int q = 0; q < 4; ++q) { ur[q] += w * wc[q]; ui[q] -= w * wsn[q]; }
                 // slide: next tap reads one element lower
 #pragma unroll
-                for (int q = 3; q > 0; --q) { wxc[q] = wxc[q - 1]; wxs[q] = wxs[q - 1]; wyc[q] = wyc[q - 1]; wys[q] = wys[q - 1]; }
+                for (int q = 3; q > 0; --q) { wc[q] = wc[q - 1]; wsn[q] = wsn[q - 1]; }
                 const int en = e0 - i - 1;
-                if (en >= 0) { const double4 v4 = sq[MF_POS(en)]; wxc[0] = v4.x; wxs[0] = v4.y; wyc[0] = v4.z; wys[0] = v4.w; }
+                if (en >= 0) { const double2 v2 = sq[MF_POS(en)]; wc[0] = v2.x; wsn[0] = v2.y; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -775,12 +837,18 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
                         c = SQ2 * cos(ang);
                         s = SQ2 * sin(ang);
                     }
-                    const double xf = ur[q] * c - ui[q] * s, yf = vr[q] * c - vi[q] * s;
-                    sx += xf; sy += yf; sxx += xf * xf; syy += yf * yf; sxy += xf * yf;
+                    const double f = ur[q] * c - ui[q] * s;
+                    if (SIG == 0) {
+                        xf[t] = f;
+                    } else {
+                        const double xv = xf[t];
+                        sx += xv; sy += f; sxx += xv * xv; syy += f * f; sxy += xv * f;
+                    }
                 }
             }
         }
     }
+    if (SIG == 0) return;
     sx = block_sum(sx, red); sy = block_sum(sy, red); sxx = block_sum(sxx, red); syy = block_sum(syy, red); sxy = block_sum(sxy, red);
     if (tid == 0) {
         const double n = (double)na;
@@ -821,8 +889,8 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(win, double, HP_NWIN);
     TAKE(r24, float, (size_t)B * 2 * n24p);
     TAKE(mid, double, (size_t)B * 2 * n24p);
-    TAKE(ctl, double, (size_t)B * 2 * n24p * HP_NCH);
-    TAKE(env, double, (size_t)B * 2 * n24p * HP_NCH);
+    TAKE(ctl, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
+    TAKE(env, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(ssp, double, (size_t)B * 2 * 16 * HP_NCH);
     TAKE(benv, double, 64);
@@ -833,8 +901,9 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(info, int, (size_t)B * 2);
     TAKE(cep, double, (size_t)B * 2 * HP_NBASIS * nsub);
     TAKE(cm, double, (size_t)B * HP_NBASIS * HP_NMOD);
+    TAKE(xf, double, (size_t)B * (HP_NBASIS - 1) * HP_NMOD * nsub);
 #undef TAKE
-    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; }
+    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; }
     return o;
 }
 
@@ -845,57 +914,80 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
     return (n24 + HP_SPACE - 1) / HP_SPACE;
 }
 
+// The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
+static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws, int sig0, int nsig, hipStream_t s) {
+    const int rows = B * nsig;
+    hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
+    static int par_iir = -1;
+    if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
+    if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, rows), dim3(64), 0, s, ws, sig0, nsig);
+    else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);
+    int gt_chunks = 2048 / (2 * B);                         // about two waves per SIMD (256 CUs x 4 SIMDs) when both signals are in flight; measured at B = 256: 2 chunks 124.8, 4 chunks 122.0 ms/step
+    if (gt_chunks > GT_MAXC) gt_chunks = GT_MAXC;
+    if (gt_chunks > ws.n24p / GT_W) gt_chunks = ws.n24p / GT_W;   // a chunk shorter than its warm-up only multiplies the work
+    int gt_lc = ws.n24p;
+    if (gt_chunks > 1) { gt_lc = ((ws.n24p + gt_chunks - 1) / gt_chunks + HP_CH - 1) / HP_CH * HP_CH; gt_chunks = (ws.n24p + gt_lc - 1) / gt_lc; }
+    if (par_iir && gt_chunks > 1) {
+        hipLaunchKernelGGL(haspi_control_par_kernel, dim3(gt_chunks, nsig, B), dim3(64), 0, s, ws, gt_lc, sig0);
+        hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, gt_chunks, sig0, nsig);
+        hipLaunchKernelGGL(haspi_signal_par_kernel, dim3(gt_chunks, nsig, B), dim3(64), 0, s, ws, gt_lc, sig0);
+    } else {
+        hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
+    }
+    static int fused_gain = -1;
+    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
+    if (fused_gain) {
+        hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
+    } else {                                                   // the three passes of the first version (A/B switch; serial low-pass)
+        const size_t per_row = (size_t)ws.n24p * HP_NCH;
+        const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
+        hipLaunchKernelGGL(haspi_gain_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
+        hipLaunchKernelGGL(haspi_gainlp_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
+        hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
+    }
+    hipLaunchKernelGGL(haspi_ihc_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
+    if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone
+    hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, nsig), dim3(256), 0, s, ws, sig0);
+}
+
 // dither: NULL (no dither: deterministic) or standard normals [B][2][nsub][32]; row k perturbs the k-th ACTIVE
 // frame (the reference draws randn(n_active, 32) for x, then for y: pyhaspi2.py:362-365).
-extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
-                                 long long workspace_bytes, float* raw, float* mapped, int* info_out, void* stream) {
-    NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_haspi: bad arguments");
+// phase 0: everything.  Split by data dependence (the whole reference-signal chain - ear model, envelope filter, silence gate, group
+// delays, cepstra, modulation filters - needs the clean signal only): phase 3 = clean part (y may be NULL), phase 4 = degraded part on
+// the same workspace (x may be NULL).  Phase 0 runs exactly these two parts back to back, so the split is bit-identical by construction.
+extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
+                                     void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info_out, int phase,
+                                     void* stream) {
+    NELE_CHECK_ARG(workspace && B > 0 && (phase == 0 || phase == 3 || phase == 4), "nele_metric_haspi: bad arguments");
+    NELE_CHECK_ARG((x || phase == 4) && (y || phase == 3) && (raw || mapped || phase == 3), "nele_metric_haspi: missing signal / output for phase %d", phase);
     NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi: fs must be 16000 or 24000 (got %d)", fs_in);
     if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi: L=%d too short", L);
     if (workspace_bytes < nele_metric_haspi_workspace_bytes(B, L, fs_in))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_haspi: workspace too small");
     HaspiWs ws;
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
+    ws.lens = lengths;
     hipStream_t s = as_stream(stream);
-    const size_t total = (size_t)B * 2 * ws.n24p * HP_NCH;
-    const unsigned pw_blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
-    hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, 2), dim3(256), 0, s, x, y, L, fs_in, ws);
-    static int par_iir = -1;
-    if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
-    if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, 2 * B), dim3(64), 0, s, ws);
-    else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws);
-    int gt_chunks = 2048 / (2 * B);                         // about two waves per SIMD (256 CUs x 4 SIMDs); measured at B = 256: 2 chunks 124.8, 4 chunks 122.0 ms/step
-    if (gt_chunks > GT_MAXC) gt_chunks = GT_MAXC;
-    if (gt_chunks > ws.n24p / GT_W) gt_chunks = ws.n24p / GT_W;   // a chunk shorter than its warm-up only multiplies the work
-    int gt_lc = ws.n24p;
-    if (gt_chunks > 1) { gt_lc = ((ws.n24p + gt_chunks - 1) / gt_chunks + HP_CH - 1) / HP_CH * HP_CH; gt_chunks = (ws.n24p + gt_lc - 1) / gt_lc; }
-    if (par_iir && gt_chunks > 1) {
-        hipLaunchKernelGGL(haspi_control_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws, gt_lc);
-        hipLaunchKernelGGL(haspi_bw_kernel, dim3(2 * B), dim3(32), 0, s, ws, gt_chunks);
-        hipLaunchKernelGGL(haspi_signal_par_kernel, dim3(gt_chunks, 2, B), dim3(64), 0, s, ws, gt_lc);
-    } else {
-        hipLaunchKernelGGL(haspi_control_kernel, dim3(2, B), dim3(64), 0, s, ws);
-        hipLaunchKernelGGL(haspi_signal_kernel, dim3(2, B), dim3(64), 0, s, ws);
+    if (phase == 0 || phase == 3) {
+        if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
+        haspi_chain(x, y, B, L, fs_in, ws, 0, 1, s);
+        hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);
+        hipLaunchKernelGGL(haspi_mod_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
     }
-    static int fused_gain = -1;
-    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
-    if (fused_gain) {
-        hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), 2 * B), dim3(256), 0, s, ws);
-    } else {                                                   // the three passes of the first version (A/B switch; serial low-pass)
-        hipLaunchKernelGGL(haspi_gain_kernel, dim3(pw_blocks), dim3(256), 0, s, ws, total);
-        hipLaunchKernelGGL(haspi_gainlp_kernel, dim3(B), dim3(64), 0, s, ws);
-        const size_t per_row = (size_t)ws.n24p * HP_NCH;
-        const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
-        hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, 2 * B), dim3(256), 0, s, ws, per_row);
+    if (phase == 0 || phase == 4) {
+        haspi_chain(x, y, B, L, fs_in, ws, 1, 1, s);
+        hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 0, 1, 1);
+        hipLaunchKernelGGL(haspi_mod_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(haspi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     }
-    hipLaunchKernelGGL(haspi_ihc_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);
-    hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, 2), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1);
-    hipLaunchKernelGGL(haspi_mod_kernel, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(haspi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 2 * (size_t)B, hipMemcpyDeviceToDevice, s);
     NELE_CHECK_LAUNCH("nele_metric_haspi");
     return NELE_OK;
+}
+
+extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, const double* dither, void* workspace,
+                                 long long workspace_bytes, float* raw, float* mapped, int* info_out, void* stream) {
+    NELE_CHECK_ARG(x && y && (raw || mapped), "nele_metric_haspi: bad arguments");
+    return nele_metric_haspi_var(x, y, nullptr, B, L, fs_in, dither, workspace, workspace_bytes, raw, mapped, info_out, 0, stream);
 }

@@ -34,6 +34,8 @@ _lib._SIGS['nele_metric_siib_workspace_bytes'] = _lib.lib.nele_metric_siib_works
 
 declare('nele_metric_haspi', [_P, _P, c_int, c_int, c_int, _P, _P, c_longlong, _P, _P, _P, _P])
 _lib._SIGS['nele_metric_haspi'] = _lib.lib.nele_metric_haspi.argtypes
+declare('nele_metric_haspi_var', [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_longlong, _P, _P, _P, c_int, _P])
+_lib._SIGS['nele_metric_haspi_var'] = _lib.lib.nele_metric_haspi_var.argtypes
 _lib.lib.nele_metric_haspi_workspace_bytes.argtypes = [c_int, c_int, c_int]
 _lib.lib.nele_metric_haspi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_haspi_workspace_bytes'] = _lib.lib.nele_metric_haspi_workspace_bytes.argtypes
@@ -174,7 +176,7 @@ def SIIB_Wrapper_harvard(x, y, fs):
     return float(_siib_checked(x, y)[1][0])
 
 
-def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False):
+def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False, lengths=None):
     """clean x [B,L], degraded y [B,L] -> (raw HASPI v2 [B], mapped [B]).
     dither: None -> no IHC firing jitter (deterministic score); True -> standard normals drawn on the device
     (torch generator, optional ``seed``) as the reference does with np.random.randn (pyhaspi2.py:362-365); or a
@@ -197,10 +199,43 @@ def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False):
     raw = torch.empty(B, device=x.device)
     mapped = torch.empty(B, device=x.device)
     info = torch.zeros((B, 2), dtype=torch.int32, device=x.device)
-    call('nele_metric_haspi', ptr(x), ptr(y), B, L, int(fs), ptr(dither), ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), stream())
+    if lengths is not None:
+        lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32).contiguous()
+    call('nele_metric_haspi_var', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), ptr(dither), ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), 0,
+         stream())
     if return_info:
         return raw, mapped, info
     return raw, mapped
+
+
+class HaspiSplit:
+    """batch_haspi split by data dependence: clean_part() runs the whole reference-signal chain (ear model, envelope filter,
+    silence gate, group-delay shifts, cepstra, modulation filters) before the degraded signal exists; degraded_part(y) does the same
+    for y and correlates.  Own workspace: the clean-signal state must survive until degraded_part()."""
+
+    def __init__(self, x, fs=16000, lengths=None):
+        self.x = x.contiguous().float()
+        self.fs = int(fs)
+        B, L = self.x.shape
+        self.lengths = None if lengths is None else lengths.to(device=self.x.device, dtype=torch.int32).contiguous()
+        self.ws = _workspace('haspi_split', _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs), self.x.device)
+        self.raw = torch.empty(B, device=self.x.device)
+        self.mapped = torch.empty(B, device=self.x.device)
+        self.info = torch.zeros((B, 2), dtype=torch.int32, device=self.x.device)
+
+    def _call(self, y, dither, phase):
+        B, L = self.x.shape
+        call('nele_metric_haspi_var', ptr(self.x), ptr(y), ptr(self.lengths), B, L, self.fs, ptr(dither), ptr(self.ws), self.ws.numel(),
+             ptr(self.raw), ptr(self.mapped), ptr(self.info), phase, stream())
+
+    def clean_part(self, dither=None):
+        self._call(None, dither, 3)
+
+    def degraded_part(self, y, dither=None):
+        assert y.shape == self.x.shape
+        self.y = y.contiguous().float()
+        self._call(self.y, dither, 4)
+        return self.raw, self.mapped
 
 
 def _haspi_checked(x, y, fs):

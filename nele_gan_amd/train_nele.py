@@ -68,6 +68,7 @@ class GanTrainer:
         self._side2 = None
         self._fside = None
         self._last_enh = None                        # enhanced batch of the last canonical_step (parity tests read it)
+        self.split_haspi = os.environ.get('NELE_HASPI_SPLIT', '1') != '0'   # HASPI's clean-signal half beside the G-step (A/B switch)
         # metric status, accumulated on the device without a host synchronisation and read by check_status():
         # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
         #  HASPI below threshold (pyhaspi2.py:357-358 raises)] - one accumulator per stream that folds into it
@@ -256,9 +257,12 @@ class GanTrainer:
         start = torch.cuda.Event()
         start.record(main)
         split = None
+        hsplit = None
         with torch.cuda.stream(side):
             side.wait_event(start)
             x = clean_wav[:, :L].contiguous()
+            x_ready = torch.cuda.Event()
+            x_ready.record(side)
             if 'siib' in self.metrics:
                 split = mt.SiibSplit(x)
                 split.clean_part()
@@ -270,12 +274,19 @@ class GanTrainer:
         with torch.cuda.stream(self._side2):
             self._side2.wait_event(start)                  # after the previous step's D update
             self.D.prepare(B_, T_, self.device)
+            if 'haspi' in self.metrics and self.split_haspi:
+                # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
+                self._side2.wait_event(x_ready)
+                hsplit = mt.HaspiSplit(x)
+                hsplit.clean_part()
         f = feats or self.features(clean_wav, noise_wav)
         lg = self.g_step(f['clean_band'], f['noise_band'])
         gdone = torch.cuda.Event()
         gdone.record(main)                                 # the G-step's backward pass is the last reader of D's current weight layouts
-        with torch.cuda.stream(self._side2):
-            self._side2.wait_event(gdone)
+        # second D.prepare: on the feature side stream when the metric side stream is busy with HASPI's clean part
+        pstream = self._fside if (hsplit is not None and self._fside is not None) else self._side2
+        with torch.cuda.stream(pstream):
+            pstream.wait_event(gdone)
             self.D.prepare(B_, T_, self.device)
         enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
         assert enh.shape[1] == L
@@ -293,14 +304,19 @@ class GanTrainer:
             y_ready.record(side)
             if split is not None:
                 cols['siib'] = split.degraded_part(y)[1]
+            if 'estoi' in self.metrics and 'haspi' in self.metrics:
+                cols['estoi'] = mt.batch_estoi(x, y)[1]    # HASPI's degraded-signal chain owns the other stream: ESTOI rides behind SIIB
         haspi_info = None
         with torch.cuda.stream(side2):                     # the cheaper metrics beside SIIB's degraded-signal part
             side2.wait_event(start)
             side2.wait_event(y_ready)
             for m in self.metrics:
-                if m == 'haspi':
+                if m == 'haspi' and hsplit is not None:
+                    cols[m] = hsplit.degraded_part(y)[1]
+                    haspi_info = hsplit.info
+                elif m == 'haspi':
                     _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True)
-                elif m != 'siib':
+                elif m != 'siib' and m not in cols:
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
             others = torch.cuda.Event()
             others.record(side2)

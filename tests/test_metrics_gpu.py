@@ -245,3 +245,48 @@ def test_siib_is_batch_invariant_across_cluster_launches(mt):
     assert np.isfinite(raw).all()
     sub, _ = mt.batch_siib(c[62:68], y[62:68])
     assert np.array_equal(raw[62:68], sub.cpu().numpy())
+
+
+def test_haspi_split_by_data_dependence_equals_one_shot(mt):
+    """clean_part() + degraded_part(y) (the order GanTrainer uses) must give exactly the one-shot result; a second degraded signal
+    against the same clean part too; and the dither rows of x / y are consumed by their own halves."""
+    from nele_gan_amd import synth
+    c, v = synth.batch(3, 40000, start=21)
+    x = torch.from_numpy(c).cuda()
+    y = torch.from_numpy(c + v).cuda()
+    raw0, map0, info0 = mt.batch_haspi(x, y, return_info=True)
+    raw0, map0 = raw0.clone(), map0.clone()
+    sp = mt.HaspiSplit(x)
+    sp.clean_part()
+    raw1, map1 = sp.degraded_part(y)
+    assert torch.equal(raw0, raw1) and torch.equal(map0, map1) and torch.equal(info0, sp.info)
+    y2 = torch.from_numpy(c + 2.0 * v).cuda()
+    raw2 = sp.degraded_part(y2)[0].clone()
+    raw2_ref = mt.batch_haspi(x, y2)[0]
+    assert torch.equal(raw2, raw2_ref) and not torch.equal(raw2, raw0)
+    nsub = mt._lib.lib.nele_metric_haspi_nsub(40000, 16000)
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    d = torch.randn((3, 2, nsub, 32), dtype=torch.float64, device='cuda', generator=g)
+    raw3 = mt.batch_haspi(x, y, dither=d)[0].clone()
+    sp.clean_part(dither=d)
+    raw4 = sp.degraded_part(y, dither=d)[0]
+    assert torch.equal(raw3, raw4) and not torch.equal(raw3, raw0)
+
+
+def test_haspi_per_utterance_lengths_in_one_padded_batch(mt):
+    """Three utterances of different lengths side by side in one padded [B, Lmax] launch: every score equals the score of the same
+    utterance launched alone at its own length (the reference scores files one at a time, audio_util.py:134-141)."""
+    from nele_gan_amd import synth
+    lens = [40000, 33536, 26001]
+    c, v = synth.batch(3, 40000, start=51)
+    y = c + v
+    xp, yp = c.copy(), y.copy()
+    for b, n in enumerate(lens):
+        xp[b, n:] = 0.0
+        yp[b, n:] = 7.0                                                     # garbage behind the end must not matter
+    raw, mapped, info = mt.batch_haspi(xp, yp, lengths=lens, return_info=True)
+    raw, info = raw.cpu().numpy(), info.cpu().numpy()
+    for b, n in enumerate(lens):
+        r1, _, i1 = mt.batch_haspi(c[b:b + 1, :n], y[b:b + 1, :n], return_info=True)
+        assert raw[b] == pytest.approx(float(r1[0]), rel=1e-6), (b, raw[b], float(r1[0]))   # chunk seams sit elsewhere: warm-up residue 1e-20
+        assert info[b, 0] == int(i1[0, 0])
