@@ -49,7 +49,14 @@ struct HaspiWs {
     hp_env_t* ctl;   // [B][2][n24][32] control envelope |u|^2 (-> compression gain in the unfused diagnostic path)
     hp_env_t* env;   // [B][2][n24][32] signal envelope |u|^2 -> compressed, dB SL -> adapted dB SL
     double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
-    double* ssp;     // [B][2][16][32] control-bank sum-of-squares partials per chunk (chunk-parallel banks)
+    double* ssp;     // [B][2][nchunk][32] control-bank sum-of-squares partials per scan chunk
+    double* est;     // [B][2][nchunk][4][64] filter-bank state at the END of each scan chunk, started from a zero state (pass 1)
+    double* pmat;    // [1 + B*2][32][16] 4x4 state-transition matrices M^lc per channel: entry 0 control bank, 1 + row signal bank
+    double* ihe;     // [B][2][nchunk_g][2][32] IHC adaptation state at the end of each gain-pass chunk from a zero state
+    double* pihc;    // [4] IHC state transition over GL_N samples
+    double* rsp;     // [B][2][RS_MAXC] resampler: sum of squares of each chunk of outputs
+    float* rinfo;    // [B][2][4] {rms of the input, rms of the normalised input, restore gain xRMS / yRMS, -}
+    int nchunk, lc;  // scan chunks per row (of the longest row) and their length
     double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
     double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
@@ -58,7 +65,9 @@ struct HaspiWs {
     int* info;       // [B][2]        {n_active, status}
     double* cep;     // [B][2][6][nsub] mean-removed cepstral sequences (only the first n_active columns)
     double* cm;      // [B][6][10]    |rho|
-    double* xf;      // [B][5][10][nsub] modulation-filtered reference sequences (clean part -> degraded part)
+    double* xf;      // modulation-filtered reference sequences (clean part -> degraded part): [B][nsub][64] (lane = (basis-1)*10 + band)
+                     // from the sliding kernel, [B][5][10][nsub] from the direct one
+    double* cpart;   // [B][MS_MAXC][64][5] correlation sums per chunk of outputs
     const int* lens; // [B] samples per utterance at the input rate, or NULL (every row has L samples)
     int fs_in;
     int n24, nsub;   // of the longest row: buffer strides
@@ -101,32 +110,56 @@ __global__ void haspi_win_kernel(double* __restrict__ win) {
     win[i] = kais * rolloff * sinc;
 }
 
-// ---- h1: one block per (utterance, signal)
-__global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, int fs_in,
-                                                             HaspiWs ws, int sig0) {
+// ---- h1: rms normalisation + resampy kaiser_best 16 -> 24 kHz + RMS restore, three launches:
+//   haspi_rms_kernel           one block per (utterance, signal): rms of the input, rms of the normalised input (float32, as the reference)
+//   haspi_resample_kernel      one block per chunk of RS_CH outputs: the resampler proper + that chunk's output sum of squares
+//   haspi_resample_gain_kernel per row: g = xRMS / yRMS from the chunk partials in chunk order; applied by the middle-ear kernels
+// (one block per row walking all 125 chunks took 3.7 ms at B = 256: a latency-bound serial loop on 256 of the 1024 SIMDs)
+#define RS_CH 768
+#define RS_MAXC 512                 // chunks of RS_CH outputs per row at most: n24 <= 393 216 (16 s)
+__global__ __launch_bounds__(256) void haspi_rms_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, int fs_in, HaspiWs ws,
+                                                        int sig0) {
     __shared__ double red[8];
-    const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x, row = 2 * b + sig;
     const int L = hp_len(ws, b, Lmax), n24 = hp_n24(ws, b);
     const float* src = (sig ? y : x) + (size_t)b * Lmax;
-    float* dst = ws.r24 + ((size_t)b * 2 + sig) * ws.n24p;
+    float* dst = ws.r24 + (size_t)row * ws.n24p;
     for (int i = n24 + tid; i < ws.n24p; i += 256) dst[i] = 0.f;      // the chunked kernels read whole chunks: defined values behind a short row
     // rms normalisation (pyhaspi2.py:81-84), float32 like the reference's arrays
     double acc = 0.0;
     for (int i = tid; i < L; i += 256) acc += (double)(src[i] * src[i]);
     acc = block_sum(acc, red);
     const float rms = sqrtf((float)acc / (float)L);
+    float* ri = ws.rinfo + (size_t)row * 4;
     if (fs_in == 24000) {
         for (int i = tid; i < L; i += 256) dst[i] = src[i] / rms;
+        if (tid == 0) { ri[0] = rms; ri[1] = 1.f; ri[2] = 1.f; }
         return;
     }
-    // resampy resample_f (ratio 1.5: scale = 1, index_step = num_table).  For this ratio the fractional position takes three
-    // values, so the interpolated-window taps start at table offsets 0, 170, 341 (left wing) and 512, 341, 170 (right wing):
-    // those four tap columns (value and forward difference) are staged in LDS once, the normalised input of each chunk of
-    // outputs is staged in LDS, and the per-tap work is two LDS reads and the reference's float32-rounded accumulate.  Same
-    // arithmetic as indexing the 32769-entry window in memory (offsets outside the four columns fall back to it).
-    constexpr int RS_CH = 768, RS_IN = RS_CH * 2 / 3 + 2 * 66 + 4;
+    double xs = 0.0;                                                   // xRMS of the normalised input (pyhaspi2.py:816)
+    for (int i = tid; i < L; i += 256) { const float v = src[i] / rms; xs += (double)(v * v); }
+    xs = block_sum(xs, red);
+    if (tid == 0) { ri[0] = rms; ri[1] = sqrtf((float)(xs / (double)L)); }
+}
+
+// resampy resample_f (ratio 1.5: scale = 1, index_step = num_table).  For this ratio the fractional position takes three
+// values, so the interpolated-window taps start at table offsets 0, 170, 341 (left wing) and 512, 341, 170 (right wing):
+// those four tap columns (value and forward difference) are staged in LDS, the normalised input of the chunk is staged in LDS, and
+// the per-tap work is two LDS reads and the reference's float32-rounded accumulate.  Same arithmetic as indexing the 32769-entry
+// window in memory (offsets outside the four columns fall back to it).  grid (chunks, nsig, B), block 256.
+__global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, HaspiWs ws,
+                                                             int sig0) {
+    __shared__ double red[8];
+    constexpr int RS_IN = RS_CH * 2 / 3 + 2 * 66 + 4;
     __shared__ double wv[4][66], wd[4][66];
     __shared__ float xsn[RS_IN];
+    const int b = blockIdx.z, sig = sig0 + blockIdx.y, tid = threadIdx.x, row = 2 * b + sig;
+    const int L = hp_len(ws, b, Lmax), n24 = hp_n24(ws, b);
+    const int t0 = blockIdx.x * RS_CH;
+    if (t0 >= n24) return;
+    const float* src = (sig ? y : x) + (size_t)b * Lmax;
+    float* dst = ws.r24 + (size_t)row * ws.n24p;
+    const float rms = ws.rinfo[(size_t)row * 4];
     for (int e = tid; e < 4 * 66; e += 256) {
         const int slot = e / 66, i = e - slot * 66;
         const int off = (slot == 0) ? 0 : (slot == 1) ? 170 : (slot == 2) ? 341 : 512;
@@ -140,68 +173,69 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     }
     const double time_increment = 1.0 / 1.5;
     double a2 = 0.0;
-    for (int t0 = 0; t0 < n24; t0 += RS_CH) {
-        const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
-        __syncthreads();
-        for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? src[nbase + e] / rms : 0.f;
-        __syncthreads();
-        for (int t = t0 + tid; t < min(n24, t0 + RS_CH); t += 256) {
-            const double time_register = (double)t * time_increment;
-            const int n = (int)time_register;
-            double frac = time_register - (double)n;
-            double index_frac = frac * HP_NTAB;
-            int offset = (int)index_frac;
-            double eta = index_frac - offset;
-            int i_max = (HP_NWIN - offset) / HP_NTAB;
-            if (n + 1 < i_max) i_max = n + 1;
-            float yv = 0.f;
-            int slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
-            if (slot >= 0 && n - (i_max - 1) >= nbase) {
-                for (int i = 0; i < i_max; ++i) {
-                    const double w = wv[slot][i] + eta * wd[slot][i];
-                    yv = (float)((double)yv + w * (double)xsn[n - i - nbase]);
-                }
-            } else {
-                for (int i = 0; i < i_max; ++i) {
-                    const int idx = offset + i * HP_NTAB;
-                    const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
-                    const double w = ws.win[idx] + eta * d;
-                    yv = (float)((double)yv + w * (double)(src[n - i] / rms));
-                }
-            }
-            frac = 1.0 - frac;
-            index_frac = frac * HP_NTAB;
-            offset = (int)index_frac;
-            eta = index_frac - offset;
-            int k_max = (HP_NWIN - offset) / HP_NTAB;
-            if (L - n - 1 < k_max) k_max = L - n - 1;
-            slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
-            if (slot >= 0 && n + k_max - nbase < RS_IN) {
-                for (int k = 0; k < k_max; ++k) {
-                    const double w = wv[slot][k] + eta * wd[slot][k];
-                    yv = (float)((double)yv + w * (double)xsn[n + k + 1 - nbase]);
-                }
-            } else {
-                for (int k = 0; k < k_max; ++k) {
-                    const int idx = offset + k * HP_NTAB;
-                    const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
-                    const double w = ws.win[idx] + eta * d;
-                    yv = (float)((double)yv + w * (double)(src[n + k + 1] / rms));
-                }
-            }
-            dst[t] = yv;
-            a2 += (double)(yv * yv);
-        }
-    }
-    // y = (xRMS / yRMS) * y  (pyhaspi2.py:816-818); xRMS of the normalised input
-    double xs = 0.0;
-    for (int i = tid; i < L; i += 256) { const float v = src[i] / rms; xs += (double)(v * v); }
-    xs = block_sum(xs, red);
-    a2 = block_sum(a2, red);
-    const float xr = sqrtf((float)(xs / (double)L)), yr = sqrtf((float)(a2 / (double)n24));
-    const float g = xr / yr;
+    const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
+    for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? src[nbase + e] / rms : 0.f;
     __syncthreads();
-    for (int t = tid; t < n24; t += 256) dst[t] = g * dst[t];
+    for (int t = t0 + tid; t < min(n24, t0 + RS_CH); t += 256) {
+        const double time_register = (double)t * time_increment;
+        const int n = (int)time_register;
+        double frac = time_register - (double)n;
+        double index_frac = frac * HP_NTAB;
+        int offset = (int)index_frac;
+        double eta = index_frac - offset;
+        int i_max = (HP_NWIN - offset) / HP_NTAB;
+        if (n + 1 < i_max) i_max = n + 1;
+        float yv = 0.f;
+        int slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
+        if (slot >= 0 && n - (i_max - 1) >= nbase) {
+            for (int i = 0; i < i_max; ++i) {
+                const double w = wv[slot][i] + eta * wd[slot][i];
+                yv = (float)((double)yv + w * (double)xsn[n - i - nbase]);
+            }
+        } else {
+            for (int i = 0; i < i_max; ++i) {
+                const int idx = offset + i * HP_NTAB;
+                const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+                const double w = ws.win[idx] + eta * d;
+                yv = (float)((double)yv + w * (double)(src[n - i] / rms));
+            }
+        }
+        frac = 1.0 - frac;
+        index_frac = frac * HP_NTAB;
+        offset = (int)index_frac;
+        eta = index_frac - offset;
+        int k_max = (HP_NWIN - offset) / HP_NTAB;
+        if (L - n - 1 < k_max) k_max = L - n - 1;
+        slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
+        if (slot >= 0 && n + k_max - nbase < RS_IN) {
+            for (int k = 0; k < k_max; ++k) {
+                const double w = wv[slot][k] + eta * wd[slot][k];
+                yv = (float)((double)yv + w * (double)xsn[n + k + 1 - nbase]);
+            }
+        } else {
+            for (int k = 0; k < k_max; ++k) {
+                const int idx = offset + k * HP_NTAB;
+                const double d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - ws.win[idx] : 0.0;
+                const double w = ws.win[idx] + eta * d;
+                yv = (float)((double)yv + w * (double)(src[n + k + 1] / rms));
+            }
+        }
+        dst[t] = yv;
+        a2 += (double)(yv * yv);
+    }
+    a2 = block_sum(a2, red);
+    if (tid == 0) ws.rsp[(size_t)row * RS_MAXC + blockIdx.x] = a2;
+}
+
+// y = (xRMS / yRMS) * y (pyhaspi2.py:816-818).  grid rows, block 64: the chunk partials are added in chunk order by one lane.
+__global__ void haspi_resample_gain_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int row = hp_row(blockIdx.x, sig0, nsig);
+    if (threadIdx.x != 0) return;
+    const int n24 = hp_n24(ws, row >> 1);
+    double a2 = 0.0;
+    for (int c = 0; c * RS_CH < n24; ++c) a2 += ws.rsp[(size_t)row * RS_MAXC + c];
+    float* ri = ws.rinfo + (size_t)row * 4;
+    ri[2] = ri[1] / sqrtf((float)(a2 / (double)n24));
 }
 
 // ---- h2: middle ear (pyhaspi2.py:833-841), scipy lfilter = direct form II transposed. grid B, block 64 (lanes 0,1 active).
@@ -215,11 +249,12 @@ __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws, int sig0, 
     double* dst = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
     const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
     const double c0 = 0.937260390269893, c1 = -1.874520780539785, c2 = 0.937260390269893, d1 = -1.870580640735279, d2 = 0.878460920344291;
+    const float g = ws.rinfo[((size_t)b * 2 + sig) * 4 + 2];          // y = (xRMS / yRMS) * y, float32 like the reference's arrays
     double z = 0.0, w0 = 0.0, w1 = 0.0;
     for (int n0 = 0; n0 < ws.n24; n0 += HP_CH) {
         float xin[HP_CH];
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) xin[u] = src[n0 + u];        // buffers are padded to whole chunks: no per-element guards
+        for (int u = 0; u < HP_CH; ++u) xin[u] = g * src[n0 + u];    // buffers are padded to whole chunks: no per-element guards
         double yo[HP_CH];
 #pragma unroll
         for (int u = 0; u < HP_CH; ++u) {
@@ -249,13 +284,14 @@ __global__ __launch_bounds__(64) void haspi_midear_par_kernel(HaspiWs ws, int si
     double* dst = ws.mid + (size_t)row * ws.n24p;
     const double b0 = 0.434173751206302, b1 = 0.434173751206302, a1 = -0.131652497587396;
     const double c0 = 0.937260390269893, c1 = -1.874520780539785, c2 = 0.937260390269893, d1 = -1.870580640735279, d2 = 0.878460920344291;
+    const float g = ws.rinfo[(size_t)row * 4 + 2];                    // y = (xRMS / yRMS) * y, float32 like the reference's arrays
     double z = 0.0, w0 = 0.0, w1 = 0.0;
     for (int n = max(0, n0 - ME_W); n < n1; n += HP_CH) {
         float xin[HP_CH];
 #pragma unroll
         for (int u = 0; u < HP_CH / 4; ++u) {
             const float4 v = *reinterpret_cast<const float4*>(src + n + 4 * u);
-            xin[4 * u] = v.x; xin[4 * u + 1] = v.y; xin[4 * u + 2] = v.z; xin[4 * u + 3] = v.w;
+            xin[4 * u] = g * v.x; xin[4 * u + 1] = g * v.y; xin[4 * u + 2] = g * v.z; xin[4 * u + 3] = g * v.w;
         }
         double yo[HP_CH];
 #pragma unroll
@@ -347,44 +383,89 @@ __device__ __forceinline__ double hp_gammatone_wave(const double* __restrict__ x
     return ss;
 }
 
-// The same banks parallel over chunks of lc samples (chosen by the host: about two waves per SIMD).  Each wave (utterance, signal, chunk) (i) replays the demodulator's rotation
-// recurrence from sample 0 up to its start - three operations per sample, the identical sequence, so cos / sin carry the same
-// accumulated rounding as in the serial kernel - and (ii) runs the filters from a zero state GT_W = 8192 samples before its chunk: the
-// slowest channel (80 Hz, BW = 1) has the quadruple pole a = 0.99115, whose response n^3 a^n / 6 is 2e-21 at n = 8192, 1e-27 of the
-// filter's gain.  The serial kernels keep one wave on 2 B of the 1024 SIMDs.
-// ss partials go to ws.ssp [row][chunk][32] and are added in chunk order by haspi_bw_kernel.
-#define GT_W 8192
-#define GT_MAXC 16
+// The same banks as an EXACT parallel scan over chunks of lc samples (a few thousand waves instead of one per (utterance, signal)).
+// The filter is linear: r[n+1] = M r[n] + q xr[n] with the 4 DF2T states r.  Pass 1 runs every chunk from a ZERO state and keeps
+// only the end state e_c; the true state at the start of chunk c is R_c = sum_j M^(lc (c-1-j)) e_j, evaluated by Horner's rule with the
+// per-channel matrix P = M^lc (haspi_pmat_kernel: the homogeneous recurrence itself, iterated lc times on the four unit vectors -
+// no matrix powers, M is a Jordan block and squaring it cancels catastrophically); pass 2 reruns the chunk from R_c and writes the
+// envelope.  Same arithmetic per sample as the serial kernel; the only difference is the rounding of R_c (1e-16 relative).
+// The demodulator state at a chunk start (eb_CosSinCF's rotation recurrence, pyhaspi2.py:855-860) is evaluated directly: the
+// recurrence's own accumulated rounding is ~1e-11 of a radian after 96 000 samples, far below anything the score can see.
+// (Round 1 ran the chunks from a zero state 8192 samples early instead: 4 chunks at most before the warm-up dominated.)
+#define GS_RC 16                   // samples per register chunk
+#define GS_LC 1536                 // default scan-chunk length
+#define GS_MAXC 160                // scan chunks per row at most (the host lengthens the chunks of longer signals)
 __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn, double sn) {
     const double arg = fma(sold, sn, cold * cn);
     sold = fma(sold, cn, -(cold * sn));
     cold = arg;
 }
-__device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ xin, int n24, int n24p, const GtCoef c, double cf, int part,
-                                                     hp_env_t* __restrict__ out, int chunk, int lc) {
+// P = M^lc per channel.  grid (1 + rows) for the signal bank (blockIdx.x = 1 + launch row) / 1 for the control bank, block 128:
+// thread = (unit vector k, channel).
+__global__ __launch_bounds__(128) void haspi_pmat_kernel(HaspiWs ws, int lc, int signal, int sig0, int nsig) {
+    const int ch = threadIdx.x & 31, k = threadIdx.x >> 5;
+    const int row = signal ? hp_row(blockIdx.x, sig0, nsig) : 0;
+    const double BW = signal ? ws.bw[(size_t)row * HP_NCH + ch] : hp_bw1(ch);
+    const GtCoef c = hp_gt(BW, hp_cfreq(ch));
+    double r0 = (k == 0), r1 = (k == 1), r2 = (k == 2), r3 = (k == 3);
+    for (int n = 0; n < lc; ++n) {                       // the serial kernel's update with xr = 0
+        const double yr = r0;
+        r0 = c.a1 * yr + r1;
+        r1 = c.a2 * yr + r2;
+        r2 = c.a3 * yr + r3;
+        r3 = c.a4 * yr;
+    }
+    double* P = ws.pmat + ((size_t)(signal ? 1 + row : 0) * HP_NCH + ch) * 16;
+    P[0 * 4 + k] = r0; P[1 * 4 + k] = r1; P[2 * 4 + k] = r2; P[3 * 4 + k] = r3;     // column k of M^lc
+}
+
+// grid (chunks, nsig, B), block 64: lane = part * 32 + channel as in the serial kernel.
+template <bool SIGNAL, bool PASS2>
+__global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig0) {
+    const int chunk = blockIdx.x, b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+    const int row = 2 * b + sig, lc = ws.lc;
+    const int n24 = hp_n24(ws, b);
+    const int n0 = chunk * lc, n1 = min(n0 + lc, (n24 + GS_RC - 1) / GS_RC * GS_RC);
+    if (n0 >= n1) return;                                  // chunk behind the end of a short row: nothing reads its state
+    const double cf = hp_cfreq(ch);
+    const GtCoef c = hp_gt(SIGNAL ? ws.bw[(size_t)row * HP_NCH + ch] : hp_bw1(ch), cf);
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
-    const int n0 = chunk * lc, n1 = min(n0 + lc, min(n24p, (n24 + HP_CH - 1) / HP_CH * HP_CH)), start = max(0, n0 - GT_W);
-    if (n0 >= n1) return 0.0;                                          // chunk entirely behind the end of a short row
-    // demodulator state before sample `start` = R^(start-1) applied to (1, 0) (eb_CosSinCF's rotation recurrence, pyhaspi2.py:855-860):
-    // evaluated directly - replaying up to 90 000 dependent rotations put 0.7 ms of pure latency at the head of the last chunk; the
-    // recurrence's own accumulated rounding is ~1e-11 of a radian there, far below anything the score can see
-    double cold = 1.0, sold = 0.0;
-    if (start > 1) {
-        const double ang = tpt * cf * (double)(start - 1);
+    double* est = ws.est + (size_t)row * ws.nchunk * 256 + lane;             // [chunk][4][64]
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if (PASS2 && chunk > 0) {
+        const double* P = ws.pmat + ((size_t)(SIGNAL ? 1 + row : 0) * HP_NCH + ch) * 16;
+        double Pm[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Pm[q] = P[q];
+        for (int j = 0; j < chunk; ++j) {                  // R_(j+1) = P R_j + e_j
+            const double e0 = est[(size_t)j * 256], e1 = est[(size_t)j * 256 + 64], e2 = est[(size_t)j * 256 + 128], e3 = est[(size_t)j * 256 + 192];
+            const double t0 = ((Pm[0] * r0 + Pm[1] * r1) + (Pm[2] * r2 + Pm[3] * r3)) + e0;
+            const double t1 = ((Pm[4] * r0 + Pm[5] * r1) + (Pm[6] * r2 + Pm[7] * r3)) + e1;
+            const double t2 = ((Pm[8] * r0 + Pm[9] * r1) + (Pm[10] * r2 + Pm[11] * r3)) + e2;
+            const double t3 = ((Pm[12] * r0 + Pm[13] * r1) + (Pm[14] * r2 + Pm[15] * r3)) + e3;
+            r0 = t0; r1 = t1; r2 = t2; r3 = t3;
+        }
+    }
+    double cold = 1.0, sold = 0.0;                         // demodulator state before sample n0: R^(n0 - 1) (1, 0)
+    if (n0 > 1) {
+        const double ang = tpt * cf * (double)(n0 - 1);
         cold = cos(ang);
         sold = -sin(ang);
     }
-    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    const double* xin = ws.mid + (size_t)row * ws.n24p;
+    hp_env_t* out = (SIGNAL ? ws.env : ws.ctl) + ((size_t)row * ws.n24p) * HP_NCH + ch;
     double ss = 0.0;
-    for (int nb = start; nb < n1; nb += HP_CH) {
-        double xc[HP_CH];
+    for (int nb = n0; nb < n1; nb += GS_RC) {
+        double xc[GS_RC];
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) xc[u] = xin[nb + u];
-        double eo[HP_CH];
-        const bool live = nb >= n0;
+        for (int u = 0; u < GS_RC / 2; ++u) {
+            const double2 v = *reinterpret_cast<const double2*>(xin + nb + 2 * u);
+            xc[2 * u] = v.x; xc[2 * u + 1] = v.y;
+        }
+        float eo[GS_RC];
 #pragma unroll
-        for (int u = 0; u < HP_CH; ++u) {
+        for (int u = 0; u < GS_RC; ++u) {
             if (nb + u > 0) hp_rotate(cold, sold, cn, sn);
             const double xr = xc[u] * (part ? sold : cold);
             const double yr = xr + r0;
@@ -392,49 +473,40 @@ __device__ __forceinline__ double hp_gammatone_chunk(const double* __restrict__ 
             r1 = c.a5 * xr + c.a2 * yr + r2;
             r2 = c.a3 * yr + r3;
             r3 = c.a4 * yr;
-            const double yo = lane_xor32(yr);
-            const double e2 = yr * yr + yo * yo;
-            eo[u] = e2;
-            ss += (live && nb + u < n24) ? e2 : 0.0;
+            if (PASS2) {
+                const double yo = lane_xor32(yr);
+                const double e2 = yr * yr + yo * yo;
+                eo[u] = (float)e2;
+                if (!SIGNAL) ss += (nb + u < n24) ? e2 : 0.0;
+            }
         }
-        if (part == 0 && live) {
+        if (PASS2 && part == 0) {
 #pragma unroll
-            for (int u = 0; u < HP_CH; ++u) out[(size_t)(nb + u) * HP_NCH] = (hp_env_t)eo[u];
+            for (int u = 0; u < GS_RC; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
         }
     }
-    return ss;
+    if (!PASS2) {
+        est[(size_t)chunk * 256] = r0; est[(size_t)chunk * 256 + 64] = r1; est[(size_t)chunk * 256 + 128] = r2; est[(size_t)chunk * 256 + 192] = r3;
+    } else if (!SIGNAL && part == 0) {
+        ws.ssp[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
+    }
 }
-// grid (chunks, 2, B), block 64
-__global__ __launch_bounds__(64) void haspi_control_par_kernel(HaspiWs ws, int lc, int sig0) {
-    const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
-    const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
-    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    hp_env_t* out = ws.ctl + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    const double ss = hp_gammatone_chunk(xin, hp_n24(ws, b), ws.n24p, hp_gt(bw1, cf), cf, part, out, blockIdx.x, lc);
-    if (part == 0) ws.ssp[(((size_t)b * 2 + sig) * GT_MAXC + blockIdx.x) * HP_NCH + ch] = ss;
-}
-// eb_BWadjust from the chunk partials.  grid 2 B, block 32
-__global__ void haspi_bw_kernel(HaspiWs ws, int nchunks, int sig0, int nsig) {
+// eb_BWadjust from the chunk partials (added in chunk order).  grid rows, block 32
+__global__ void haspi_bw_kernel(HaspiWs ws, int sig0, int nsig) {
     const int row = hp_row(blockIdx.x, sig0, nsig), ch = threadIdx.x;
     const double bw1 = hp_bw1(ch);
     const GtCoef cc = hp_gt(bw1, hp_cfreq(ch));
+    const int n24 = hp_n24(ws, row >> 1);
+    const int nch = (n24 + ws.lc - 1) / ws.lc;
     double ss = 0.0;
-    for (int c = 0; c < nchunks; ++c) ss += ws.ssp[((size_t)row * GT_MAXC + c) * HP_NCH + ch];
+    for (int c = 0; c < nch; ++c) ss += ws.ssp[((size_t)row * ws.nchunk + c) * HP_NCH + ch];
     ss *= cc.gain * cc.gain;
-    const double cdB = 20.0 * log10(sqrt(ss / (double)hp_n24(ws, row >> 1))) + HP_LEVEL;
+    const double cdB = 20.0 * log10(sqrt(ss / (double)n24)) + HP_LEVEL;
     double BW;
     if (cdB < 50.0) BW = 1.0;
     else if (cdB > 100.0) BW = bw1;
     else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
     ws.bw[(size_t)row * HP_NCH + ch] = BW;
-}
-__global__ __launch_bounds__(64) void haspi_signal_par_kernel(HaspiWs ws, int lc, int sig0) {
-    const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
-    const double cf = hp_cfreq(ch);
-    const double BW = ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch];
-    const double* xin = ws.mid + ((size_t)b * 2 + sig) * ws.n24p;
-    hp_env_t* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
-    (void)hp_gammatone_chunk(xin, hp_n24(ws, b), ws.n24p, hp_gt(BW, cf), cf, part, out, blockIdx.x, lc);
 }
 
 // ---- h3: control bank + bandwidth adjustment. grid (2, B), block 64
@@ -525,6 +597,27 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) 
 // state - the neglected history is below 0.81^256 = 4e-24 of the signal, far under the float64 rounding of the values themselves -
 // which makes the recursion parallel over chunks.  Thread = (chunk of 2048 samples, channel); block = 8 chunks x 32 channels;
 // grid (ceil(n24p / 16384), 2 B).  ctl (|u|^2 of the control bank) is only read, env (|u|^2 of the signal bank) is rewritten in place.
+struct IhcC { double R2, R12C1, R23C2, a11, a12, a21, a22, denom, R1inv; };
+__device__ __forceinline__ IhcC hp_ihc_consts() {
+    const double delta = 2.0;
+    const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
+    const double T = 1 / HP_FS;
+    const double R1 = 1 / delta, R2 = 0.5 * (1 - R1), R3 = R2;
+    const double C1 = tau1 * (R1 + R2) / (R1 * R2);
+    const double C2 = tau2 / ((R1 + R2) * R3);
+    IhcC k;
+    k.a11 = R1 + R2 + R1 * R2 * (C1 / T); k.a12 = -R1; k.a21 = -R3; k.a22 = R2 + R3 + R2 * R3 * (C2 / T);
+    k.denom = 1.0 / (k.a11 * k.a22 - k.a21 * k.a12);
+    k.R1inv = 1.0 / R1; k.R12C1 = R1 * R2 * (C1 / T); k.R23C2 = R2 * R3 * (C2 / T); k.R2 = R2;
+    return k;
+}
+__device__ __forceinline__ void hp_ihc_step(const IhcC& k, double V0, double& V1, double& V2) {
+    const double b1 = V0 * k.R2 + k.R12C1 * V1;
+    const double b2 = k.R23C2 * V2;
+    V1 = k.denom * (k.a22 * b1 - k.a12 * b2);
+    V2 = k.denom * (-k.a21 * b1 + k.a11 * b2);
+}
+
 #define GL_N 2048
 #define GL_W 256
 #define GL_U 8
@@ -550,6 +643,8 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
     const hp_env_t* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
     hp_env_t* env = ws.env + (size_t)row * ws.n24p * HP_NCH + ch;
     double z = 0.0;
+    const IhcC ik = hp_ihc_consts();
+    double V1 = 0.0, V2 = 0.0;                                 // IHC adaptation pass 1: this chunk from a zero state
     for (int n = max(0, n0 - GL_W); n < n1; n += GL_U) {       // n0, GL_W and n24p are multiples of GL_U
         float gc[GL_U], ev[GL_U];
         double gx[GL_U];
@@ -577,10 +672,55 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
             for (int u = 0; u < GL_U; ++u) {                   // pyhaspi2.py:997, 1080-1088: 20 log10(g sgain sqrt(e) + 1e-30), clamped at 0
                 // (the 1e-30 term only matters where the result is far below the clamp)
                 const float g = (float)gx[u];
-                const float y = s_off + TEN_LOG10_2 * hp_log2f(g * g * ev[u]);
-                env[(size_t)(n + u) * HP_NCH] = y > 0.0f ? y : 0.0f;
+                float y = s_off + TEN_LOG10_2 * hp_log2f(g * g * ev[u]);
+                y = y > 0.0f ? y : 0.0f;
+                env[(size_t)(n + u) * HP_NCH] = y;
+                hp_ihc_step(ik, (double)y, V1, V2);            // on the stored (float32) value: pass 2 reads exactly that
             }
         }
+    }
+    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
+    double* ihe = ws.ihe + ((size_t)row * ncg + (n0 / GL_N)) * 64 + ch;
+    ihe[0] = V1; ihe[32] = V2;
+}
+
+// eb_IHCadapt (pyhaspi2.py:1028-1078): a LINEAR two-state recurrence driven by the dB-SL envelope; the max(., 0) on the output does
+// not feed back (pyhaspi2.py:1072), so the state is a linear scan like the filter banks': pass 1 (inside the gain pass, which walks
+// every chunk of GL_N samples in order anyway) runs the recurrence from a zero state and keeps the end state, pass 2
+// (haspi_ihc_scan_kernel) starts every chunk from the Horner-combined true state.  P over GL_N samples comes from iterating the
+// homogeneous recurrence itself (haspi_shift_kernel).
+// IHC pass 2.  Thread = (chunk of GL_N samples, channel); block = 8 chunks x 32 channels; grid (ceil(chunks / 8), rows).  In place on env.
+__global__ __launch_bounds__(256) void haspi_ihc_scan_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int ch = threadIdx.x & 31, row = hp_row(blockIdx.y, sig0, nsig);
+    const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5), n0 = chunk * GL_N;
+    const int n24 = hp_n24(ws, row >> 1);
+    const int n24r = (n24 + GL_U - 1) / GL_U * GL_U;
+    if (n0 >= n24r) return;
+    const int n1 = min(n0 + GL_N, n24r);
+    const IhcC k = hp_ihc_consts();
+    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
+    const double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;             // [chunk][2][32]
+    const double p00 = ws.pihc[0], p01 = ws.pihc[1], p10 = ws.pihc[2], p11 = ws.pihc[3];
+    double V1 = 0.0, V2 = 0.0;
+    for (int j = 0; j < chunk; ++j) {
+        const double e1 = ihe[(size_t)j * 64], e2 = ihe[(size_t)j * 64 + 32];
+        const double t1 = (p00 * V1 + p01 * V2) + e1, t2 = (p10 * V1 + p11 * V2) + e2;
+        V1 = t1; V2 = t2;
+    }
+    hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
+    for (int n = n0; n < n1; n += GL_U) {
+        float ex[GL_U];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) ex[u] = e[(size_t)(n + u) * HP_NCH];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {
+            const double V0 = (double)ex[u];
+            hp_ihc_step(k, V0, V1, V2);
+            const double out = (V0 - V1) * k.R1inv;
+            ex[u] = (float)(out < 0.0 ? 0.0 : out);
+        }
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) e[(size_t)(n + u) * HP_NCH] = ex[u];
     }
 }
 
@@ -590,15 +730,7 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int
     if (idx >= nrows) return;
     const int row = hp_row(idx, sig0, nsig), n24 = hp_n24(ws, row >> 1);
     hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + (lane & 31);
-    const double delta = 2.0;
-    const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
-    const double T = 1 / HP_FS;
-    const double R1 = 1 / delta, R2 = 0.5 * (1 - R1), R3 = R2;
-    const double C1 = tau1 * (R1 + R2) / (R1 * R2);
-    const double C2 = tau2 / ((R1 + R2) * R3);
-    const double a11 = R1 + R2 + R1 * R2 * (C1 / T), a12 = -R1, a21 = -R3, a22 = R2 + R3 + R2 * R3 * (C2 / T);
-    const double denom = 1.0 / (a11 * a22 - a21 * a12);
-    const double R1inv = 1.0 / R1, R12C1 = R1 * R2 * (C1 / T), R23C2 = R2 * R3 * (C2 / T);
+    const IhcC k = hp_ihc_consts();
     double V1 = 0.0, V2 = 0.0;
     for (int n0 = 0; n0 < n24; n0 += HP_CH) {
         double ex[HP_CH];
@@ -607,11 +739,8 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int
 #pragma unroll
         for (int u = 0; u < HP_CH; ++u) {
             const double V0 = ex[u];
-            const double b1 = V0 * R2 + R12C1 * V1;
-            const double b2 = R23C2 * V2;
-            V1 = denom * (a22 * b1 - a12 * b2);
-            V2 = denom * (-a21 * b1 + a11 * b2);
-            const double out = (V0 - V1) * R1inv;
+            hp_ihc_step(k, V0, V1, V2);
+            const double out = (V0 - V1) * k.R1inv;
             ex[u] = out < 0.0 ? 0.0 : out;
         }
 #pragma unroll
@@ -631,6 +760,12 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
     double mn = (ch < HP_NCH) ? gd : 1e300, mx = (ch < HP_NCH) ? gd : -1e300;
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
     if (ch < HP_NCH) ws.shift[(size_t)b * HP_NCH + ch] = (int)((mx - mn) - (gd - mn));
+    if (b == 0 && ch < 2) {                              // IHC state transition over one gain-pass chunk: column ch of the 2x2 matrix
+        const IhcC k = hp_ihc_consts();
+        double V1 = (ch == 0), V2 = (ch == 1);
+        for (int n = 0; n < GL_N; ++n) hp_ihc_step(k, 0.0, V1, V2);
+        ws.pihc[ch] = V1; ws.pihc[2 + ch] = V2;
+    }
     if (b == 0 && ch < HP_NFILT) ws.benv[ch] = (0.5 - 0.5 * cospi(2.0 * (double)ch / 51.0)) / 25.5;   // np.hanning(52) / sum, for haspi_envfilt_kernel
     if (b == 0) {                                        // modulation-filter taps (np.hanning(nfir + 1) / sum), for haspi_mod_kernel
         const int nfirs[10] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
@@ -764,6 +899,7 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
 // ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
 __constant__ double c_modcf[HP_NMOD] = {2, 6, 10, 16, 25, 40, 64, 100, 160, 256};
 __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
+#define MS_MAXC 64            // chunks of MS_TC outputs per utterance at most (nsub <= 131 072)
 #define HP_TILE 1024          // outputs per tile: 256 threads x 4 consecutive outputs (sliding register window over the taps)
 #define HP_MAXFIR 614
 // LDS position of sequence element e: a thread reads elements 4 tid + c, so the four residues mod 4 live in four sub-arrays and a
@@ -776,7 +912,7 @@ __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38,
 // Each pass stages (v cos, v sin) of ONE signal: half of the LDS and of the per-tap work of a joint pass; the reference half runs
 // before the enhanced signal exists (GanTrainer overlaps it with the G-step).
 template <int SIG>
-__global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
+__global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
     __shared__ __attribute__((aligned(16))) double2 sq[4 * MF_L4];   // (v cos, v sin) of one sequence element: one 16-byte read per tap
     __shared__ double red[8];
     const int k = blockIdx.x, basis = blockIdx.y + 1, b = blockIdx.z, tid = threadIdx.x;
@@ -859,6 +995,93 @@ __global__ __launch_bounds__(256) void haspi_mod_kernel(HaspiWs ws) {
     }
 }
 
+// ---- h11, sliding form (the default).  The modulation filters are Hann windows, b[i] = (0.5 - 0.5 cos(2 pi i / L)) / (L / 2),
+// i = 0..L (L = nfir; both end taps are zero), so the FIR is a combination of three sliding sums over exactly one period L:
+//     S_m[tau] = sum_{i=0}^{L-1} e^{j m phi i} z[tau - i]      (m = 0, +1, -1; phi = 2 pi / L)
+//     S_m[tau] = e^{j m phi} S_m[tau - 1] + z[tau] - z[tau - L]            (e^{j m phi L} = 1)
+//     u[t]     = (2 / L) (0.5 S_0 - 0.25 S_+1 - 0.25 S_-1)[t + nh]
+// i.e. ~40 float64 operations per output instead of 2 (nfir + 1) multiply-adds (nfir up to 614): the direct form above was 14 ms of
+// every B = 256 step.  The rotations have modulus one, so rounding accumulates linearly: < 1e-12 relative over a chunk (A/B-tested
+// against the direct kernel, NELE_HASPI_MOD_DIRECT=1).  One wave per (utterance, chunk of MS_TC outputs): lane = basis * 10 + band
+// (50 of 64 lanes), every chunk warms its sums up over the L samples before it (recurrence without the subtraction).  A lane owns
+// one (basis, band) pair, so the correlation sums of ebm_ModCorr stay in its registers; chunk partials are combined in chunk order.
+// SIG = 0 stores the filtered reference sequence xf [b][t][64]; SIG = 1 filters the processed signal and correlates it with xf.
+#define MS_TC 2048
+template <int SIG>
+__global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
+    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int na = ws.info[2 * b];
+    if (ws.info[2 * b + 1]) return;
+    const int t0 = chunk * MS_TC, t1 = min(t0 + MS_TC, na);
+    if (t0 >= na) return;
+    const bool act = lane < (HP_NBASIS - 1) * HP_NMOD;
+    const int basis = act ? 1 + lane / HP_NMOD : 1, k = act ? lane % HP_NMOD : 0;
+    const int L = c_modnfir[k], nh = L / 2;
+    const double theta = (k > 0) ? M_PI * c_modcf[k] / 1280.0 : 0.0;     // pi cf / fNyq
+    const double phi = 2.0 * M_PI / (double)L;
+    const double rc = cos(phi), rs = sin(phi);                           // e^{+j phi}; S_-1 uses the conjugate
+    const double ec = cos(theta), es = -sin(theta);                       // e^{-j theta}: demodulator step
+    const double k1c = cos(theta * (double)L), k1s = sin(theta * (double)L);     // e^{+j theta L}: phase of the sample leaving the window
+    const double k2c = cos(theta * (double)nh), k2s = -sin(theta * (double)nh);  // e^{-j theta nh}: output phase = conj(E) K2
+    const double scale = ((k > 0) ? 2.0 : 1.0) * (2.0 / (double)L);      // sqrt(2) of the demodulator and of the remodulator
+    const double* v = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + basis) * ws.nsub;
+    double* xf = ws.xf + ((size_t)b * ws.nsub) * 64 + lane;
+    // common output index tt = t0 - LMAX + step; this lane's newest input is tau = tt + nh
+    constexpr int LMAX = HP_MAXFIR;
+    double Er, Ei;                                                        // E = e^{-j theta (tau + 1)} at tau = t0 - LMAX + nh - 1 (one step before the loop)
+    {
+        const double a0 = theta * (double)(t0 - LMAX + nh);
+        Er = cos(a0); Ei = -sin(a0);
+    }
+    double s0r = 0, s0i = 0, spr = 0, spi = 0, smr = 0, smi = 0;
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int tt = t0 - LMAX; tt < t1; ++tt) {
+        const int tau = tt + nh;
+        { const double nr = Er * ec - Ei * es; Ei = Er * es + Ei * ec; Er = nr; }       // E <- E e^{-j theta}
+        if (tt < t0 - L) continue;                                        // before this lane's warm-up window
+        const bool live = tt >= t0;
+        const double vn = (tau >= 0 && tau < na) ? v[min(max(tau, 0), na - 1)] : 0.0;
+        const int to = tau - L;
+        const double vo = (live && to >= 0 && to < na) ? v[min(max(to, 0), na - 1)] : 0.0;
+        const double eor = Er * k1c - Ei * k1s, eoi = Er * k1s + Ei * k1c;             // phase of z[tau - L]
+        const double dr = vn * Er - vo * eor, di = vn * Ei - vo * eoi;                 // z[tau] - z[tau - L]
+        s0r += dr; s0i += di;
+        { const double nr = (rc * spr - rs * spi) + dr; spi = (rc * spi + rs * spr) + di; spr = nr; }
+        { const double nr = (rc * smr + rs * smi) + dr; smi = (rc * smi - rs * smr) + di; smr = nr; }
+        if (live) {
+            const double ur = 0.5 * s0r - 0.25 * (spr + smr), ui = 0.5 * s0i - 0.25 * (spi + smi);
+            const double oc = Er * k2c + Ei * k2s, os = Er * k2s - Ei * k2c;            // conj(E) K2 = e^{+j theta (t + 1)}
+            const double f = scale * (ur * oc - ui * os);
+            if (SIG == 0) {
+                xf[(size_t)tt * 64] = f;
+            } else {
+                const double xv = xf[(size_t)tt * 64];
+                sx += xv; sy += f; sxx += xv * xv; syy += f * f; sxy += xv * f;
+            }
+        }
+    }
+    if (SIG == 1 && act) {
+        double* cp = ws.cpart + (((size_t)b * MS_MAXC + chunk) * 64 + lane) * 5;
+        cp[0] = sx; cp[1] = sy; cp[2] = sxx; cp[3] = syy; cp[4] = sxy;
+    }
+}
+// chunk partials -> |rho| per (basis, band).  grid B, block 64
+__global__ void haspi_modcorr_kernel(HaspiWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (ws.info[2 * b + 1] || lane >= (HP_NBASIS - 1) * HP_NMOD) return;
+    const int na = ws.info[2 * b];
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int c = 0; c * MS_TC < na; ++c) {
+        const double* cp = ws.cpart + (((size_t)b * MS_MAXC + c) * 64 + lane) * 5;
+        sx += cp[0]; sy += cp[1]; sxx += cp[2]; syy += cp[3]; sxy += cp[4];
+    }
+    const double n = (double)na;
+    const double xsum = sxx - sx * sx / n, ysum = syy - sy * sy / n, xy = sxy - sx * sy / n;
+    double cm = 0.0;
+    if (!(xsum < 1.0e-30 || ysum < 1.0e-30)) cm = fabs(xy) / sqrt(xsum * ysum);
+    ws.cm[((size_t)b * HP_NBASIS + 1 + lane / HP_NMOD) * HP_NMOD + lane % HP_NMOD] = cm;
+}
+
 __global__ void haspi_final_kernel(HaspiWs ws, float* __restrict__ raw, float* __restrict__ mapped, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -892,7 +1115,16 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(ctl, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(env, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
-    TAKE(ssp, double, (size_t)B * 2 * 16 * HP_NCH);
+    int lc = GS_LC;
+    while ((n24p + lc - 1) / lc > GS_MAXC) lc += GS_LC;
+    const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + GL_N - 1) / GL_N;
+    TAKE(ssp, double, (size_t)B * 2 * nchunk * HP_NCH);
+    TAKE(est, double, (size_t)B * 2 * nchunk * 256);
+    TAKE(pmat, double, (size_t)(1 + B * 2) * HP_NCH * 16);
+    TAKE(ihe, double, (size_t)B * 2 * ncg * 64);
+    TAKE(pihc, double, 4);
+    TAKE(rsp, double, (size_t)B * 2 * RS_MAXC);
+    TAKE(rinfo, float, (size_t)B * 2 * 4);
     TAKE(benv, double, 64);
     TAKE(bkt, double, 10 * 616);
     TAKE(shift, int, (size_t)B * HP_NCH);
@@ -901,9 +1133,10 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(info, int, (size_t)B * 2);
     TAKE(cep, double, (size_t)B * 2 * HP_NBASIS * nsub);
     TAKE(cm, double, (size_t)B * HP_NBASIS * HP_NMOD);
-    TAKE(xf, double, (size_t)B * (HP_NBASIS - 1) * HP_NMOD * nsub);
+    TAKE(xf, double, (size_t)B * 64 * nsub);
+    TAKE(cpart, double, (size_t)B * MS_MAXC * 64 * 5);
 #undef TAKE
-    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; }
+    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; }
     return o;
 }
 
@@ -917,37 +1150,45 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
 // The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
 static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws, int sig0, int nsig, hipStream_t s) {
     const int rows = B * nsig;
-    hipLaunchKernelGGL(haspi_resample_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
-    static int par_iir = -1;
+    static int par_iir = -1;                               // NELE_HASPI_PAR_IIR=0: the serial recurrence kernels (A/B diagnostic)
     if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
+    static int fused_gain = -1;
+    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
+    hipLaunchKernelGGL(haspi_rms_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
+    if (fs_in != 24000) {
+        hipLaunchKernelGGL(haspi_resample_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
+        hipLaunchKernelGGL(haspi_resample_gain_kernel, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
+    }
     if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, rows), dim3(64), 0, s, ws, sig0, nsig);
     else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);
-    int gt_chunks = 2048 / (2 * B);                         // about two waves per SIMD (256 CUs x 4 SIMDs) when both signals are in flight; measured at B = 256: 2 chunks 124.8, 4 chunks 122.0 ms/step
-    if (gt_chunks > GT_MAXC) gt_chunks = GT_MAXC;
-    if (gt_chunks > ws.n24p / GT_W) gt_chunks = ws.n24p / GT_W;   // a chunk shorter than its warm-up only multiplies the work
-    int gt_lc = ws.n24p;
-    if (gt_chunks > 1) { gt_lc = ((ws.n24p + gt_chunks - 1) / gt_chunks + HP_CH - 1) / HP_CH * HP_CH; gt_chunks = (ws.n24p + gt_lc - 1) / gt_lc; }
-    if (par_iir && gt_chunks > 1) {
-        hipLaunchKernelGGL(haspi_control_par_kernel, dim3(gt_chunks, nsig, B), dim3(64), 0, s, ws, gt_lc, sig0);
-        hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, gt_chunks, sig0, nsig);
-        hipLaunchKernelGGL(haspi_signal_par_kernel, dim3(gt_chunks, nsig, B), dim3(64), 0, s, ws, gt_lc, sig0);
+    if (par_iir) {
+        if (sig0 == 0) hipLaunchKernelGGL(haspi_pmat_kernel, dim3(1), dim3(128), 0, s, ws, ws.lc, 0, 0, 1);   // control bank: per channel only
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, true>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
+        hipLaunchKernelGGL(haspi_pmat_kernel, dim3(rows), dim3(128), 0, s, ws, ws.lc, 1, sig0, nsig);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
     }
-    static int fused_gain = -1;
-    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
-    if (fused_gain) {
+    if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone (+ constant tables)
+    if (fused_gain && par_iir) {
         hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
-    } else {                                                   // the three passes of the first version (A/B switch; serial low-pass)
-        const size_t per_row = (size_t)ws.n24p * HP_NCH;
-        const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
-        hipLaunchKernelGGL(haspi_gain_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
-        hipLaunchKernelGGL(haspi_gainlp_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
-        hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
+        hipLaunchKernelGGL(haspi_ihc_scan_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
+    } else {                                                   // the serial passes of the first version (A/B switch)
+        if (fused_gain) {
+            hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
+        } else {
+            const size_t per_row = (size_t)ws.n24p * HP_NCH;
+            const unsigned bx = (unsigned)((per_row + 255) / 256 < 256 ? (per_row + 255) / 256 : 256);
+            hipLaunchKernelGGL(haspi_gain_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
+            hipLaunchKernelGGL(haspi_gainlp_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
+            hipLaunchKernelGGL(haspi_sl_kernel, dim3(bx, rows), dim3(256), 0, s, ws, per_row, sig0, nsig);
+        }
+        hipLaunchKernelGGL(haspi_ihc_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
     }
-    hipLaunchKernelGGL(haspi_ihc_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
-    if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone
     hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, nsig), dim3(256), 0, s, ws, sig0);
 }
 
@@ -969,16 +1210,24 @@ extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* 
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
     ws.lens = lengths;
     hipStream_t s = as_stream(stream);
+    static int mod_direct = -1;                            // NELE_HASPI_MOD_DIRECT=1: direct-form modulation FIR (A/B diagnostic)
+    if (mod_direct < 0) { const char* e_ = getenv("NELE_HASPI_MOD_DIRECT"); mod_direct = (e_ && e_[0] == '1'); }
+    NELE_CHECK_ARG((ws.nsub + MS_TC - 1) / MS_TC <= MS_MAXC, "nele_metric_haspi: signal too long (%d sub-sampled frames)", ws.nsub);
     if (phase == 0 || phase == 3) {
         if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
         haspi_chain(x, y, B, L, fs_in, ws, 0, 1, s);
         hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);
-        hipLaunchKernelGGL(haspi_mod_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        else hipLaunchKernelGGL(haspi_mod_slide_kernel<0>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
     }
     if (phase == 0 || phase == 4) {
         haspi_chain(x, y, B, L, fs_in, ws, 1, 1, s);
         hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 0, 1, 1);
-        hipLaunchKernelGGL(haspi_mod_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        else {
+            hipLaunchKernelGGL(haspi_mod_slide_kernel<1>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
+            hipLaunchKernelGGL(haspi_modcorr_kernel, dim3(B), dim3(64), 0, s, ws);
+        }
         hipLaunchKernelGGL(haspi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     }
     if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 2 * (size_t)B, hipMemcpyDeviceToDevice, s);

@@ -194,7 +194,7 @@ _HASPI_AB_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 from nele_gan_amd import metrics as mt, synth
-c, v = synth.batch(4, 40000, start=33)
+c, v = synth.batch(4, 64000, start=33)
 raw, mapped = mt.batch_haspi(c, c + v, dither=None)
 np.save(sys.argv[2], raw.double().cpu().numpy())
 '''
@@ -208,6 +208,20 @@ def test_haspi_chunk_parallel_filters_equal_the_serial_ones(tmp_path):
     res = []
     for env in ({}, {'NELE_HASPI_PAR_IIR': '0', 'NELE_HASPI_FUSED_GAIN': '0'}):
         out = str(tmp_path / ('haspi_%d.npy' % len(res)))
+        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **env), timeout=240)
+        res.append(np.load(out))
+    assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
+    np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
+
+
+def test_haspi_sliding_modulation_filters_equal_the_direct_fir(tmp_path):
+    """The modulation filter bank runs as three sliding sums per Hann window (O(1) per output); A/B against the direct-form FIR
+    kernel of the same library (NELE_HASPI_MOD_DIRECT=1, read once per process)."""
+    import subprocess
+    import sys
+    res = []
+    for env in ({}, {'NELE_HASPI_MOD_DIRECT': '1'}):
+        out = str(tmp_path / ('haspi_mod_%d.npy' % len(res)))
         subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **env), timeout=240)
         res.append(np.load(out))
     assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
