@@ -724,6 +724,89 @@ __global__ __launch_bounds__(256) void haspi_ihc_scan_kernel(HaspiWs ws, int sig
     }
 }
 
+// IHC pass 2 FUSED with ebm_EnvFilt (pyhaspi2.py:378-414: Hann(52)/sum FIR at "same" alignment, every 9th sample, after the
+// group-delay shift).  The adapted envelope never goes back to memory: a thread (chunk of GL_N samples, channel) runs the IHC
+// recurrence and feeds its output - rounded to float32 exactly as the stored envelope of the unfused path was - into the FIR in
+// SLIDING form: np.hanning(52)[k] = 0.5 - 0.5 cos(2 pi k / 51) has zero end taps, so the window is one period L = 51 of
+//     S_m[n] = e^{j m phi} S_m[n - 1] + o[n] - o[n - 51],      y[n] = (0.5 S_0 - 0.5 Re S_1)[n] / 25.5,
+// 6 operations per sample instead of 52 / 9 multiply-adds + tap look-ups; o[n - 51] comes from a 64-deep float32 ring in LDS.
+// The group-delay shift s of the channel only relabels the lane's own time axis: output i is emitted when its window ends,
+// n = 9 i + 26 - s, and samples with n + s >= n24 count as zero.  A chunk needs o[n] from 51 samples before its start: the IHC
+// recurrence is invertible (its inverse grows by 1.02 per step), so the thread steps its Horner-combined state 51 samples BACK and
+// reruns them forward.  Every output is written by exactly one thread (the one whose chunk holds its window end): no atomics.
+// The separate envelope-filter kernel below gathered 4 bytes per lane from 32 different rows (the shifts differ per channel): 64
+// cache lines per load instruction, 4.2 ms per call at B = 256.
+// grid (ceil(chunks / 4), rows), block 128 = 4 chunks x 32 channels.
+#define IF_L 51
+__global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0, int nsig) {
+    __shared__ float ring[64][128];
+    const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig), b = row >> 1;
+    const int chunk = blockIdx.x * 4 + (tid >> 5), n0 = chunk * GL_N;
+    const int n24 = hp_n24(ws, b), nsub = hp_nsub(ws, b);
+    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
+    const int last = (n24 - 1) / GL_N;                       // chunk that holds the row's last sample
+#pragma unroll
+    for (int q = 0; q < 64; ++q) ring[q][tid] = 0.f;          // own column only: no barrier needed
+    if (chunk > last) return;
+    const int sh = ws.shift[(size_t)b * HP_NCH + ch];
+    // this chunk emits the outputs whose window ends in [n0, n1); the last chunk also those that end behind the row's end
+    const int n1 = (chunk == last) ? n24 + 9 + 26 : n0 + GL_N;
+    const IhcC k = hp_ihc_consts();
+    const double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;
+    const double p00 = ws.pihc[0], p01 = ws.pihc[1], p10 = ws.pihc[2], p11 = ws.pihc[3];
+    double V1 = 0.0, V2 = 0.0;
+    for (int j = 0; j < chunk; ++j) {
+        const double e1 = ihe[(size_t)j * 64], e2 = ihe[(size_t)j * 64 + 32];
+        const double t1 = (p00 * V1 + p01 * V2) + e1, t2 = (p10 * V1 + p11 * V2) + e2;
+        V1 = t1; V2 = t2;
+    }
+    const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
+    int nstart = n0;
+    if (chunk > 0) {                                         // state at n0 -> state at n0 - 51 (inverse of hp_ihc_step)
+        nstart = n0 - IF_L;
+        for (int n = n0 - 1; n >= nstart; --n) {
+            const double V0 = (double)e[(size_t)n * HP_NCH];
+            const double b1 = k.a11 * V1 + k.a12 * V2, b2 = k.a21 * V1 + k.a22 * V2;
+            V1 = (b1 - V0 * k.R2) / k.R12C1;
+            V2 = b2 / k.R23C2;
+        }
+    }
+    double* lp = ws.lp + ((size_t)row * ws.nsub) * HP_NCH + ch;
+    if (chunk == 0) {                                        // outputs whose whole window lies before the lane's first sample
+        for (int i = 0; i < nsub && 9 * i + 26 - sh < 0; ++i) lp[(size_t)i * HP_NCH] = 0.0;
+    }
+    const double phi = 2.0 * M_PI / (double)IF_L, rc = cos(phi), rs = sin(phi);
+    double s0 = 0.0, s1r = 0.0, s1i = 0.0;
+    int ph = (nstart + sh - 26) % 9;                         // (n + s - 26) mod 9; an output is due when it is 0
+    if (ph < 0) ph += 9;
+    for (int nb = nstart; nb < n1; nb += GL_U) {
+        float ex[GL_U];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) ex[u] = e[(size_t)min(nb + u, n24 - 1) * HP_NCH];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) {
+            const int n = nb + u;
+            float o = 0.f;
+            if (n + sh < n24) {                              // (n < n24 follows; beyond it the shifted envelope is zero)
+                const double V0 = (double)ex[u];
+                hp_ihc_step(k, V0, V1, V2);
+                const double out = (V0 - V1) * k.R1inv;
+                o = (float)(out < 0.0 ? 0.0 : out);
+            }
+            const float old = ring[(n - IF_L) & 63][tid];
+            ring[n & 63][tid] = o;
+            const double dx = (double)o - (double)old;
+            s0 += dx;
+            { const double nr = (rc * s1r - rs * s1i) + dx; s1i = rc * s1i + rs * s1r; s1r = nr; }
+            if (ph == 0 && n >= n0 && n < n1) {
+                const int i = (n + sh - 26) / 9;
+                if (i >= 0 && i < nsub) lp[(size_t)i * HP_NCH] = (0.5 * s0 - 0.5 * s1r) * (1.0 / 25.5);
+            }
+            ph = (ph == 8) ? 0 : ph + 1;
+        }
+    }
+}
+
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
 __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int nsig, int nrows) {
     const int lane = threadIdx.x, idx = 2 * blockIdx.x + (lane >> 5);
@@ -1176,7 +1259,8 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone (+ constant tables)
     if (fused_gain && par_iir) {
         hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
-        hipLaunchKernelGGL(haspi_ihc_scan_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
+        hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * GL_N - 1) / (4 * GL_N), rows), dim3(128), 0, s, ws, sig0, nsig);
+        return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
         if (fused_gain) {
             hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
