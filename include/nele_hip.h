@@ -31,11 +31,17 @@ int nele_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
  * audio_util.py:30-50 compute_band_E, audio_util.py:422-437 Sp_and_phase_Speech.
  * wav [B][L] f32 -> spec [B][T][257] complex64 (may be NULL), band [B][T][64] f32 = bandE**power (may be NULL). */
 int nele_stft_band(const float* wav, int B, int L, float power, void* spec, float* band, void* stream);
+/* Per-utterance lengths.  The reference works on one file of any length at a time (dataloader.py:30-42, audio_util.py:134-141); a
+ * batch carries utterances of different lengths side by side in padded [B][L] buffers.  lengths [B] (device int32, may be NULL) =
+ * samples of each row; frames [B] = STFT frames of each row, 1 + lengths / 256.  Everything behind a row's own end is written as
+ * zeros and never read.  The same convention holds for every *_var entry point below. */
+int nele_stft_band_var(const float* wav, const int* lengths, int B, int L, float power, void* spec, float* band, void* stream);
 
 /* noise_est/imcra.py:521-577 imcra_est.estimate + :363-484 imcra.update; audio_util.py:113-117 NoisePSD,
  * :439-456 Sp_and_phase_Noise.  spec [B][T][257] complex64 -> psd [B][T][257] f32 (may be NULL),
  * band [B][T][64] f32 = compute_band_E(sqrt(psd))**power (may be NULL). */
 int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream);
+int nele_imcra_band_var(const void* spec, const int* frames, int B, int T, float power, float* psd, float* band, void* stream);
 
 /* audio_util.py:30-50 compute_band_E by itself: magnitude spectrogram mag [N][257] f32 -> band [N][64] f32 (no power law). */
 int nele_compute_band_E(const float* mag, int N, float* band, void* stream);
@@ -46,10 +52,12 @@ int nele_interp_band_gain(const float* bandE, int N, double* g, void* stream);
 /* audio_util.py:93-110 interp_band_gain, :76-90 Resyn, :458-461 SP_to_wav, :60-65 ISTFT.
  * alpha2 [B][T][64] f32 (energy gains; NULL = plain ISTFT, no gain), spec [B][T][257] complex64 -> wav [B][256*(T-1)] f32. */
 int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream);
+int nele_gain_istft_var(const float* alpha2, const void* spec, const int* frames, int B, int T, float* wav, void* stream);
 
 /* inference.py:109 (enh / rms(enh) * target_rms, skipped when target_rms <= 0) and the PCM_16
  * write/read round trip of train_nele.py:313 + dataloader.py:58 (pcm16 != 0).  In place on wav [B][N]. */
 int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream);
+int nele_wav_post_var(float* wav, const int* frames, int B, int N, float target_rms, int pcm16, void* stream);   /* row b has 256 (frames[b] - 1) samples */
 
 /* ---- dense layers: convolution as implicit GEMM on the f32 matrix cores (csrc/dense.hip) ------- */
 
@@ -164,6 +172,14 @@ int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_hos
 int nele_gap_mlp_bwd(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
                      const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, int OH, int OW, int oh0,
                      int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream);
+/* The same for a padded batch of utterances of different lengths: wvalid [B] (device int32, may be NULL) = valid output columns of
+ * each utterance in the last conv layer's output (frames - 20); the pooling mean and its gradient run over those columns only, as
+ * the batch-1 reference pools every utterance over its own extent (model.py:123). */
+int nele_gap_mlp_fwd_var(const float* act, int B, int P, int Wout, const int* wvalid, const float* const* mlp_host, int nout, float slope,
+                         float* pooled, float* h1, float* h2, float* score, double* scratch, void* stream);
+int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                         const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                         int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream);
 int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream);
 
 /* torch.optim.Adam (train_nele.py:89-91) on flat buffers; step counts from 1. */
@@ -187,6 +203,8 @@ int nele_adam_step_guarded(float* p, const float* g, float* m, float* v, long lo
 long long nele_metric_estoi_workspace_bytes(int B, int L);
 int nele_metric_estoi(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                       float* mapped, void* stream);
+int nele_metric_estoi_var(const float* x, const float* y, const int* lengths, int B, int L, void* workspace, long long workspace_bytes,
+                          float* raw, float* mapped, void* stream);
 
 /* intel.py:57-100 SIIB_Wrapper[_raw]_harvard: VAD (intel.py:37-50), replication rule (intel.py:93-97) and
  * pysiib.SIIB(x, y, 16000, gauss=True) (algorithm restated, oracle/siib.py).  info [B][4] (may be NULL) =
@@ -203,6 +221,9 @@ int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspa
  * phase 4 = the rest (y spectra / masking / stacking, projections, score).  Phase 3 can run before y exists. */
 int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                            float* mapped, int* info, int phase, void* stream);
+/* Same with per-utterance lengths (the frame-periodic shortcut for L % 200 == 0 is not taken then; results are identical). */
+int nele_metric_siib_var(const float* x, const float* y, const int* lengths, int B, int L, void* workspace, long long workspace_bytes,
+                         float* raw, float* mapped, int* info, int phase, void* stream);
 
 /* Batched symmetric eigen-decomposition, float64, n <= 512 (np.linalg.eigh in pysiib's KLT): A [B][n][n] symmetric
  * (destroyed) -> lam [B][n] ascending, U [B][n][n] with ROW j = eigenvector j.  Householder tridiagonalisation,

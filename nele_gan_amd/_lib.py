@@ -42,6 +42,10 @@ _SIGS = {
     'nele_imcra_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft': [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     'nele_wav_post': [c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'nele_stft_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'nele_imcra_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'nele_gain_istft_var': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    'nele_wav_post_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'nele_compute_band_E': [c_void_p, c_int, c_void_p, c_void_p],
     'nele_interp_band_gain': [c_void_p, c_int, c_void_p, c_void_p],
 }

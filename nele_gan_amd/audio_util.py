@@ -38,10 +38,23 @@ def n_frames(L):
     return 1 + L // HOP
 
 
+def _i32(t, device):
+    """lengths / frame counts -> contiguous device int32 tensor (or None)."""
+    if t is None:
+        return None
+    return torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()
+
+
+def frames_of(lengths):
+    """STFT frames of utterances with ``lengths`` samples: T = 1 + L // 256 (device int32 in, device int32 out)."""
+    return None if lengths is None else (1 + torch.div(lengths, HOP, rounding_mode='floor')).to(torch.int32)
+
+
 # ------------------------------------------------------------------ batched device API
-def stft_band(wav, power=1.0 / 6, want_spec=True, want_band=True):
+def stft_band(wav, power=1.0 / 6, want_spec=True, want_band=True, lengths=None):
     """wav [B,L] f32 (device) -> (spec [B,T,257] complex64 | None, band [B,T,64] f32 | None).
-    band = compute_band_E(|STFT|) ** power (audio_util.py:426-433)."""
+    band = compute_band_E(|STFT|) ** power (audio_util.py:426-433).  lengths [B]: samples of each utterance inside the padded
+    batch (frames behind a row's own end come out as zeros)."""
     wav = _dev(wav).float()
     if wav.dim() != 2:
         raise ValueError("stft_band: wav must be [B, L]")
@@ -49,11 +62,11 @@ def stft_band(wav, power=1.0 / 6, want_spec=True, want_band=True):
     T = n_frames(L)
     spec = torch.empty((B, T, N_BINS), dtype=torch.complex64, device=wav.device) if want_spec else None
     band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=wav.device) if want_band else None
-    call('nele_stft_band', ptr(wav), B, L, float(power), ptr(spec), ptr(band), stream())
+    call('nele_stft_band_var', ptr(wav), ptr(_i32(lengths, wav.device)), B, L, float(power), ptr(spec), ptr(band), stream())
     return spec, band
 
 
-def imcra_band(spec, power=1.0 / 6, want_psd=False):
+def imcra_band(spec, power=1.0 / 6, want_psd=False, frames=None):
     """spec [B,T,257] complex64 -> (psd [B,T,257] f32 | None, band [B,T,64] f32) with
     band = compute_band_E(sqrt(NoisePSD(spec))) ** power (audio_util.py:445-451)."""
     if spec.dtype != torch.complex64 or spec.dim() != 3 or spec.shape[2] != N_BINS:
@@ -63,11 +76,11 @@ def imcra_band(spec, power=1.0 / 6, want_psd=False):
     # the PSD buffer is always handed over: with it the kernel computes the band feature from the PSD after the serial scan instead of inside it
     psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=spec.device)
     band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=spec.device)
-    call('nele_imcra_band', ptr(spec), B, T, float(power), ptr(psd), ptr(band), stream())
+    call('nele_imcra_band_var', ptr(spec), ptr(_i32(frames, spec.device)), B, T, float(power), ptr(psd), ptr(band), stream())
     return psd, band
 
 
-def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False):
+def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False, frames=None):
     """alpha2 [B,T,64] f32 (energy gains), spec [B,T,257] complex64 -> wav [B, 256*(T-1)] f32.
     Resyn (audio_util.py:76-90) + optional enh/rms(enh)*target (inference.py:109) + optional
     PCM_16 write/read round trip (train_nele.py:313, dataloader.py:58)."""
@@ -77,9 +90,10 @@ def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False):
     if alpha2.shape != (B, T, NB_BANDS):
         raise ValueError("gain_istft: alpha2 must be [B, T, 64] matching spec")
     wav = torch.empty((B, HOP * (T - 1)), dtype=torch.float32, device=spec.device)
-    call('nele_gain_istft', ptr(alpha2), ptr(spec), B, T, ptr(wav), stream())
+    frames = _i32(frames, spec.device)
+    call('nele_gain_istft_var', ptr(alpha2), ptr(spec), ptr(frames), B, T, ptr(wav), stream())
     if rms_target > 0 or pcm16:
-        call('nele_wav_post', ptr(wav), B, wav.shape[1], float(rms_target), int(bool(pcm16)), stream())
+        call('nele_wav_post_var', ptr(wav), ptr(frames), B, wav.shape[1], float(rms_target), int(bool(pcm16)), stream())
     return wav
 
 

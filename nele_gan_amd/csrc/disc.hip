@@ -106,13 +106,18 @@ struct MlpW {
 
 // Pooling partial sums: grid (GAP_CHUNKS, B), block 256: act [B][P][64] -> part [B][GAP_CHUNKS][64] (float64)
 #define GAP_CHUNKS 32
-__global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ act, int P, double* __restrict__ part) {
+// wvalid (may be NULL): valid output width of each utterance inside a padded batch (T_b - 20 for the last conv layer); columns at or
+// behind it come from zero padding and take no part in the pooling (the reference pools each utterance over its own extent).
+__global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ act, int P, double* __restrict__ part, int Wout,
+                                                          const int* __restrict__ wvalid) {
     __shared__ double sp[4][64];
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
     const int per = (P + GAP_CHUNKS - 1) / GAP_CHUNKS, p0 = ch * per, p1 = min(P, p0 + per);
     const float* a = act + (size_t)b * P * 64;
+    const int wv = wvalid ? min(wvalid[b], Wout) : Wout;
     double s = 0.0;
-    for (int pos = p0 + g; pos < p1; pos += 4) s += (double)a[(size_t)pos * 64 + c];
+    for (int pos = p0 + g; pos < p1; pos += 4)
+        if (pos % Wout < wv) s += (double)a[(size_t)pos * 64 + c];
     sp[g][c] = s;
     __syncthreads();
     if (tid < 64) part[((size_t)b * GAP_CHUNKS + ch) * 64 + tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
@@ -121,9 +126,10 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restric
 // One block per utterance: finish the pooling from the partial sums, then the 3-layer head.
 __global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const double* __restrict__ part, int P, MlpW w, int nout, float slope,
                                                           float* __restrict__ pooled, float* __restrict__ h1, float* __restrict__ h2,
-                                                          float* __restrict__ score) {
+                                                          float* __restrict__ score, int Wout, const int* __restrict__ wvalid) {
     __shared__ float sp[64], sh1[64], sh2[16];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (wvalid) P = (P / Wout) * min(wvalid[b], Wout);
     if (tid < 64) {
         double s = 0.0;
         for (int ch = 0; ch < GAP_CHUNKS; ++ch) s += part[((size_t)b * GAP_CHUNKS + ch) * 64 + tid];
@@ -205,14 +211,15 @@ __global__ __launch_bounds__(64) void mlp_bwd_kernel(const float* __restrict__ d
 // d act[b][pos][c] = dpooled[b][c] / P * lrelu'(act), written into the zero-bordered gradient buffer
 // [B][OH][OW][64] at offset (oh0, ow0).
 __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, int Hout, int Wout, int OH, int OW,
-                               int oh0, int ow0, float slope, float* __restrict__ gbuf) {
+                               int oh0, int ow0, float slope, float* __restrict__ gbuf, const int* __restrict__ wvalid) {
     const int b = blockIdx.y, P = Hout * Wout;
-    const float invP = 1.f / (float)P;
+    const int wv = wvalid ? min(wvalid[b], Wout) : Wout;
+    const float invP = 1.f / (float)(Hout * wv);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P * 64; i += gridDim.x * blockDim.x) {
         const int pos = i >> 6, c = i & 63;
         const int ho = pos / Wout, wo = pos - ho * Wout;
         const float a = act[(size_t)b * P * 64 + i];
-        const float d = dpooled[(size_t)b * 64 + c] * invP * (a > 0.f ? 1.f : slope);
+        const float d = (wo < wv) ? dpooled[(size_t)b * 64 + c] * invP * (a > 0.f ? 1.f : slope) : 0.f;
         gbuf[(((size_t)b * OH + ho + oh0) * OW + wo + ow0) * 64 + c] = d;
     }
 }
@@ -317,21 +324,35 @@ extern "C" int nele_sn_grad(const float* dW, const float* W, const float* u, con
 
 // mlp: 9 device pointers {w1,b1,sigma1,w2,b2,sigma2,w3,b3,sigma3}
 // scratch: float64 [B][32][64] pooling partial sums
-extern "C" int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled, float* h1,
-                                float* h2, float* score, double* scratch, void* stream) {
+extern "C" int nele_gap_mlp_fwd_var(const float* act, int B, int P, int Wout, const int* wvalid, const float* const* mlp_host, int nout, float slope,
+                                    float* pooled, float* h1, float* h2, float* score, double* scratch, void* stream) {
     NELE_CHECK_ARG(act && mlp_host && pooled && h1 && h2 && score && scratch && B > 0 && P > 0 && nout >= 1 && nout <= 4,
                    "nele_gap_mlp_fwd: bad arguments");
+    NELE_CHECK_ARG(Wout > 0 && P % Wout == 0, "nele_gap_mlp_fwd: P=%d is not a multiple of the output width %d", P, Wout);
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
-    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, as_stream(stream), act, P, scratch);
-    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), scratch, P, w, nout, slope, pooled, h1, h2, score);
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, as_stream(stream), act, P, scratch, Wout, wvalid);
+    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), scratch, P, w, nout, slope, pooled, h1, h2, score, Wout, wvalid);
     NELE_CHECK_LAUNCH("nele_gap_mlp_fwd");
     return NELE_OK;
 }
+extern "C" int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled, float* h1,
+                                float* h2, float* score, double* scratch, void* stream) {
+    return nele_gap_mlp_fwd_var(act, B, P, P, nullptr, mlp_host, nout, slope, pooled, h1, h2, score, scratch, stream);
+}
 
+extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                                    const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                                    int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream);
 extern "C" int nele_gap_mlp_bwd(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
                                 const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, int OH, int OW, int oh0,
                                 int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream) {
+    return nele_gap_mlp_bwd_var(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, nullptr, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled,
+                                gbuf, stream);
+}
+extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                                    const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                                    int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream) {
     NELE_CHECK_ARG(dscore && score && h1 && h2 && mlp_host && dz3 && dz2 && dz1 && dpooled && B > 0, "nele_gap_mlp_bwd: bad arguments");
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
@@ -342,7 +363,7 @@ extern "C" int nele_gap_mlp_bwd(const float* dscore, const float* score, const f
         NELE_CHECK_ARG(act, "nele_gap_mlp_bwd: act required for the pooling gradient");
         const int P = Hout * Wout;
         hipLaunchKernelGGL(gap_bwd_kernel, dim3(min(512, (P * 64 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout, OH, OW, oh0,
-                           ow0, slope, gbuf);
+                           ow0, slope, gbuf, wvalid);
         NELE_CHECK_LAUNCH("nele_gap_mlp_bwd(gap)");
     }
     return NELE_OK;

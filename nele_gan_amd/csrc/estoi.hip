@@ -31,8 +31,20 @@ struct EstoiWs {
     int* nkept;      // [B]
     double* tob;     // [B][2][ES_NB][F]
     double* dseg;    // [B][F]
-    int n10, F;
+    int n10, F;      // of the longest row: buffer strides
+    const int* lens; // [B] samples per utterance inside the padded [B][L] buffers, or NULL
+    int L;
 };
+// per-utterance sizes (the reference scores files of any length one at a time: intel.py:122-134, audio_util.py:134-141)
+__device__ __forceinline__ int es_len(const EstoiWs& ws, int b) { return ws.lens ? min(ws.lens[b], ws.L) : ws.L; }
+__device__ __forceinline__ int es_n10(const EstoiWs& ws, int b) {
+    const long long n = (long long)es_len(ws, b) * 5;
+    return (int)(n / 8 + (n % 8 ? 1 : 0));
+}
+__device__ __forceinline__ int es_frames(const EstoiWs& ws, int b) {
+    const int n10 = es_n10(ws, b);
+    return (n10 >= ES_NFRAME) ? (n10 - ES_NFRAME) / ES_HOP + 1 : 0;
+}
 
 __device__ __forceinline__ double hann_sym256(int j) { return 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / 257.0); }
 
@@ -77,8 +89,9 @@ __global__ __launch_bounds__(256) void estoi_resample_kernel(const float* __rest
     __syncthreads();
     const int b = blockIdx.y, sig = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ws.n10) return;
+    if (i >= es_n10(ws, b)) return;
     const float* src = (sig == 0 ? x : y) + (size_t)b * L;
+    L = es_len(ws, b);
     // out[i] = sum_n src[n] * h[8 i + 290 - 5 n]
     const int c = 8 * i + ES_HALF;
     int n_lo = (c - 2 * ES_HALF + 4) / 5;  // ceil((c-580)/5) for c-580 >= 0
@@ -98,8 +111,9 @@ __global__ __launch_bounds__(256) void estoi_vad_kernel(EstoiWs ws) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* x = ws.xr + (size_t)b * 2 * ws.n10;
     double* en = ws.en + (size_t)b * ws.F;
+    const int Fb = es_frames(ws, b);
     double mx = -1e300;
-    for (int f = wave; f < ws.F; f += 4) {
+    for (int f = wave; f < Fb; f += 4) {
         double s = 0.0;
         for (int j = lane; j < ES_NFRAME; j += 64) {
             const double v = hann_sym256(j) * x[(size_t)f * ES_HOP + j];
@@ -114,9 +128,9 @@ __global__ __launch_bounds__(256) void estoi_vad_kernel(EstoiWs ws) {
     // ordered compaction of frames with (max - 40 - en) < 0
     if (tid == 0) base = 0;
     __syncthreads();
-    for (int f0 = 0; f0 < ws.F; f0 += 256) {
+    for (int f0 = 0; f0 < Fb; f0 += 256) {
         const int f = f0 + tid;
-        const int k = (f < ws.F && (mx - 40.0 - en[f]) < 0.0) ? 1 : 0;
+        const int k = (f < Fb && (mx - 40.0 - en[f]) < 0.0) ? 1 : 0;
         scan[tid] = k;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -276,8 +290,8 @@ extern "C" long long nele_metric_estoi_workspace_bytes(int B, int L) {
     return (long long)t;
 }
 
-extern "C" int nele_metric_estoi(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
-                                 float* mapped, void* stream) {
+extern "C" int nele_metric_estoi_var(const float* x, const float* y, const int* lengths, int B, int L, void* workspace, long long workspace_bytes,
+                                     float* raw, float* mapped, void* stream) {
     NELE_CHECK_ARG(x && y && workspace && (raw || mapped) && B > 0, "nele_metric_estoi: bad arguments");
     int n10, F;
     estoi_dims(L, &n10, &F);
@@ -287,7 +301,7 @@ extern "C" int nele_metric_estoi(const float* x, const float* y, int B, int L, v
     char* p = (char*)workspace;
     double* h = (double*)p; p += align256(sizeof(double) * (2 * ES_HALF + 1));
     EstoiWs ws;
-    ws.n10 = n10; ws.F = F;
+    ws.n10 = n10; ws.F = F; ws.lens = lengths; ws.L = L;
     ws.xr = (double*)p; p += align256(sizeof(double) * (size_t)B * 2 * n10);
     ws.en = (double*)p; p += align256(sizeof(double) * (size_t)B * F);
     ws.keep = (int*)p; p += align256(sizeof(int) * (size_t)B * F);
@@ -303,4 +317,9 @@ extern "C" int nele_metric_estoi(const float* x, const float* y, int B, int L, v
     hipLaunchKernelGGL(estoi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     NELE_CHECK_LAUNCH("nele_metric_estoi");
     return NELE_OK;
+}
+
+extern "C" int nele_metric_estoi(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                                 float* mapped, void* stream) {
+    return nele_metric_estoi_var(x, y, nullptr, B, L, workspace, workspace_bytes, raw, mapped, stream);
 }

@@ -55,13 +55,22 @@ __device__ __forceinline__ double hann512(int n) { return 0.5 - 0.5 * cospi((dou
 
 // ------------------------------------------------------------------------------------------ STFT
 // grid (ceil(T/2), B), block 256.  Frames 2p and 2p+1 share one complex FFT.
+// lens (may be NULL): samples of each utterance inside the padded [B][L] buffer (the reference handles files of any length one at a
+// time, dataloader.py:30-42); frames at or behind a short row's own count T_b = 1 + L_b / 256 are written as zeros.
 __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict__ wav, int L, int T, float power,
-                                                        float2* __restrict__ spec, float* __restrict__ band) {
+                                                        float2* __restrict__ spec, float* __restrict__ band, const int* __restrict__ lens) {
     __shared__ Fft512Lds s;
     __shared__ float tmp[2][NELE_NBINS + 3];
     const int b = blockIdx.y, t0 = 2 * blockIdx.x, t1 = t0 + 1;
-    const bool has1 = t1 < T;
     const float* x = wav + (size_t)b * L;
+    int Tb = T;
+    if (lens) { L = min(lens[b], L); Tb = 1 + L / NELE_HOP; }
+    for (int t = max(t0, Tb); t <= t1 && t < T; ++t) {     // frames behind the end of a short row
+        if (spec) for (int k = threadIdx.x; k < NELE_NBINS; k += 256) spec[((size_t)b * T + t) * NELE_NBINS + k] = make_float2(0.f, 0.f);
+        if (band && threadIdx.x < NELE_NBANDS) band[((size_t)b * T + t) * NELE_NBANDS + threadIdx.x] = 0.f;
+    }
+    if (t0 >= Tb) return;
+    const bool has1 = t1 < Tb;
     fft512_init_twiddles(s);
     for (int n = threadIdx.x; n < NELE_NFFT; n += 256) {
         int o0 = NELE_HOP * t0 + n - NELE_HOP;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
     __syncthreads();
     if (band && threadIdx.x < 2 * NELE_NBANDS) {
         const int f = threadIdx.x >> 6, i = threadIdx.x & 63, t = t0 + f;
-        if (t < T) {
+        if (t < Tb) {
             const float e = band_energy(tmp[f], i);
             band[((size_t)b * T + t) * NELE_NBANDS + i] = pow_f32(e, power);
         }
@@ -124,7 +133,8 @@ __device__ __forceinline__ double fsmooth3(const double* v, int k, double w0, do
 // barriers per frame instead of four and no 64-band reduction on the wave that paces it.
 template <bool BAND_IN_LOOP>
 __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2* __restrict__ spec, int T, float power,
-                                                                   float* __restrict__ psd, float* __restrict__ band) {
+                                                                   float* __restrict__ psd, float* __restrict__ band,
+                                                                   const int* __restrict__ tlens) {
     __shared__ ImcraLds s;
     const int b = blockIdx.x, k = threadIdx.x;
     const bool act = k < NELE_NBINS;
@@ -143,11 +153,16 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
     // the spectrum of frame l+1 is loaded while frame l is processed: the recursion is serial over frames and would otherwise pay
     // a full global-load latency per frame
     float2 ynext = act ? Y[k] : make_float2(0.f, 0.f);
-    for (int l = 0; l < T; ++l) {
+    const int Tb = tlens ? min(tlens[blockIdx.x], T) : T;   // frames of this utterance inside the padded batch
+    for (int l = Tb; l < T; ++l) {                          // behind the end of a short row: zeros
+        if (act && psd) psd[((size_t)b * T + l) * NELE_NBINS + k] = 0.f;
+        if (BAND_IN_LOOP && band && k < NELE_NBANDS) band[((size_t)b * T + l) * NELE_NBANDS + k] = 0.f;
+    }
+    for (int l = 0; l < Tb; ++l) {
         float Y2f = 0.f, outv = 0.f;
         double xi = 0.0, I = 0.0;
         const float2 y = ynext;
-        if (act && l + 1 < T) ynext = Y[(size_t)(l + 1) * NELE_NBINS + k];
+        if (act && l + 1 < Tb) ynext = Y[(size_t)(l + 1) * NELE_NBINS + k];
         if (act) {
             const float h = np_cabsf(y.x, y.y);                                   // np.abs(complex64)
             Y2f = h * h;                                                          // **2 on a float32 array
@@ -295,9 +310,13 @@ __device__ __forceinline__ double band_gain_sqrt(const float* __restrict__ a2, i
 }
 
 __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
-                                                         int T, float* __restrict__ wav) {
+                                                         int T, float* __restrict__ wav, const int* __restrict__ tlens) {
     __shared__ Fft512Lds s;
     const int b = blockIdx.y, fa = blockIdx.x, fb = fa + 1;
+    if (tlens && fb >= min(tlens[b], T)) {                  // behind the end of a short row (its signal has 256 (T_b - 1) samples): zeros
+        wav[(size_t)b * (NELE_HOP * (T - 1)) + (size_t)NELE_HOP * fa + threadIdx.x] = 0.f;
+        return;
+    }
     const float* a2a = alpha2 ? alpha2 + ((size_t)b * T + fa) * NELE_NBANDS : nullptr;   // NULL: plain ISTFT (audio_util.py:60-65)
     const float* a2b = a2a + NELE_NBANDS;
     const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
@@ -329,9 +348,10 @@ __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict
 
 // One block per utterance: optional enh / rms(enh) * target (inference.py:109) and optional PCM_16
 // round trip (libsndfile float->short with 0x7FFF scaling + lrintf, read back / 32768: PARITY UNPINNED).
-__global__ __launch_bounds__(256) void wav_post_kernel(float* __restrict__ wav, int N, float target_rms, int pcm16) {
+__global__ __launch_bounds__(256) void wav_post_kernel(float* __restrict__ wav, int N, float target_rms, int pcm16, const int* __restrict__ tlens) {
     __shared__ double red[8];
     float* x = wav + (size_t)blockIdx.x * N;
+    if (tlens) N = min(N, NELE_HOP * (tlens[blockIdx.x] - 1));   // samples of this utterance; the zeros behind them stay zeros
     float scale = 1.f;
     if (target_rms > 0.f) {
         double acc = 0.0;
@@ -359,34 +379,40 @@ __global__ __launch_bounds__(256) void wav_post_kernel(float* __restrict__ wav, 
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-extern "C" int nele_stft_band(const float* wav, int B, int L, float power, void* spec, float* band, void* stream) {
+extern "C" int nele_stft_band_var(const float* wav, const int* lengths, int B, int L, float power, void* spec, float* band, void* stream) {
     NELE_CHECK_ARG(wav && B > 0, "nele_stft_band: null wav or B <= 0");
     NELE_CHECK_ARG(L > NELE_HOP, "nele_stft_band: L=%d must exceed 256 (reflect padding)", L);
     NELE_CHECK_ARG(spec || band, "nele_stft_band: no output requested");
     const int T = 1 + L / NELE_HOP;
     dim3 grid((T + 1) / 2, B);
-    hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band);
+    hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
     NELE_CHECK_LAUNCH("nele_stft_band");
     return NELE_OK;
 }
+extern "C" int nele_stft_band(const float* wav, int B, int L, float power, void* spec, float* band, void* stream) {
+    return nele_stft_band_var(wav, nullptr, B, L, power, spec, band, stream);
+}
 
-extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream) {
+extern "C" int nele_imcra_band_var(const void* spec, const int* frames, int B, int T, float power, float* psd, float* band, void* stream) {
     NELE_CHECK_ARG(spec && B > 0 && T > 0, "nele_imcra_band: bad arguments");
     NELE_CHECK_ARG(psd || band, "nele_imcra_band: no output requested");
     if (psd && band) {      // noise PSD kept: the band feature is computed from it afterwards, off the serial loop
-        hipLaunchKernelGGL(imcra_band_kernel<false>, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power, psd, band);
+        hipLaunchKernelGGL(imcra_band_kernel<false>, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power, psd, band, frames);
         hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
         NELE_CHECK_LAUNCH("nele_imcra_band");
         return NELE_OK;
     }
     hipLaunchKernelGGL(imcra_band_kernel<true>, dim3(B), dim3(IMCRA_THREADS), 0, as_stream(stream), (const float2*)spec, T, power,
-                       psd, band);
+                       psd, band, frames);
     if (band) {
         const size_t nb = (size_t)B * T * NELE_NBANDS;
         hipLaunchKernelGGL(band_pow_kernel, dim3((unsigned)((nb + 255) / 256 < 2048 ? (nb + 255) / 256 : 2048)), dim3(256), 0, as_stream(stream), band, nb, power);
     }
     NELE_CHECK_LAUNCH("nele_imcra_band");
     return NELE_OK;
+}
+extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream) {
+    return nele_imcra_band_var(spec, nullptr, B, T, power, psd, band, stream);
 }
 
 // compute_band_E (audio_util.py:30-50) on a magnitude spectrogram: X [N][257] f32 -> OUT [N][64] f32 (no power law).
@@ -437,12 +463,15 @@ extern "C" int nele_interp_band_gain(const float* bandE, int N, double* g, void*
     return NELE_OK;
 }
 
-extern "C" int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream) {
+extern "C" int nele_gain_istft_var(const float* alpha2, const void* spec, const int* frames, int B, int T, float* wav, void* stream) {
     NELE_CHECK_ARG(spec && wav && B > 0, "nele_gain_istft: bad arguments");
     NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
-    hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav);
+    hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);
     NELE_CHECK_LAUNCH("nele_gain_istft");
     return NELE_OK;
+}
+extern "C" int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* wav, void* stream) {
+    return nele_gain_istft_var(alpha2, spec, nullptr, B, T, wav, stream);
 }
 
 // PCM_16 round trip alone (no level normalisation: nothing per utterance to reduce): plain element-wise pass over the whole batch
@@ -454,7 +483,11 @@ __global__ void wav_quant_kernel(float* __restrict__ wav, size_t n) {
     }
 }
 
+extern "C" int nele_wav_post_var(float* wav, const int* frames, int B, int N, float target_rms, int pcm16, void* stream);
 extern "C" int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream) {
+    return nele_wav_post_var(wav, nullptr, B, N, target_rms, pcm16, stream);
+}
+extern "C" int nele_wav_post_var(float* wav, const int* frames, int B, int N, float target_rms, int pcm16, void* stream) {
     NELE_CHECK_ARG(wav && B > 0 && N > 0, "nele_wav_post: bad arguments");
     if (target_rms <= 0.f && !pcm16) return NELE_OK;
     if (target_rms <= 0.f) {
@@ -463,7 +496,7 @@ extern "C" int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm
         NELE_CHECK_LAUNCH("nele_wav_post");
         return NELE_OK;
     }
-    hipLaunchKernelGGL(wav_post_kernel, dim3(B), dim3(256), 0, as_stream(stream), wav, N, target_rms, pcm16);
+    hipLaunchKernelGGL(wav_post_kernel, dim3(B), dim3(256), 0, as_stream(stream), wav, N, target_rms, pcm16, frames);
     NELE_CHECK_LAUNCH("nele_wav_post");
     return NELE_OK;
 }

@@ -45,7 +45,10 @@ struct SiibWs {
     double* px;      // [B][7][NTL][16][256] projections of the clean signal in accumulator order (split mode: phase 3 -> phase 4)
     int NT, NA, NTL;
     int Bn;          // utterances in this call
+    const int* lens; // [B] samples per utterance inside the padded [B][L] buffers, or NULL (every row has L samples)
 };
+// per-utterance length (the reference scores files of any length one at a time: intel.py:58-60, audio_util.py:134-141)
+__device__ __forceinline__ int sb_len(const SiibWs& ws, int b, int L) { return ws.lens ? min(ws.lens[b], L) : L; }
 
 __device__ __forceinline__ double hann400(int n) { return 0.5 - 0.5 * cospi((double)n / 200.0); }
 
@@ -131,15 +134,16 @@ __device__ double kth_largest(const double* __restrict__ v, int n, int r, double
 __global__ __launch_bounds__(256) void siib_db_kernel(const float* __restrict__ x, int L, SiibWs ws, int tiled, int Pf) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    long long total = L;
-    int nf = nframes_of(L);
+    const int Lb = sb_len(ws, b, L);
+    long long total = Lb;
+    int nf = nframes_of(Lb);
     if (tiled) {
         f += nf;                                           // first frame the base pass did not produce
-        total = (long long)ws.info[4 * b] * L;
+        total = (long long)ws.info[4 * b] * Lb;
         nf = min(ws.info[4 * b + 1], Pf);
     }
     if (f >= nf || f >= ws.NT) return;
-    const double e = frame_db(x + (size_t)b * L, L, total, f, lane);
+    const double e = frame_db(x + (size_t)b * L, Lb, total, f, lane);
     if (lane == 0) ws.xdb[(size_t)b * ws.NT + f] = e;
 }
 
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(256) void siib_m_kernel(int L, SiibWs ws) {
     __shared__ double red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     const double* xdb = ws.xdb + (size_t)b * ws.NT;
+    L = sb_len(ws, b, L);
     const int n1 = nframes_of(L);
     const int ind = round_half_even_pos((double)n1 * 0.999) - 1;
     const double thr = kth_largest(xdb, n1, n1 - 1 - ind, red, nullptr) - 40.0;
@@ -237,6 +242,8 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
     const int* info = ws.info + 4 * b;
     const int na = ws.nprim[b];                        // frames of the first period only: siib_spread_kernel copies the repeats
     if (k0 >= na) return;
+    const int Lrow = L;                                 // row stride of the padded buffers
+    L = sb_len(ws, b, L);
     const long long total = (long long)info[0] * L;
     const int fs = tid / 20, lane20 = tid - fs * 20;   // frame slot, n2 (stage 1) / k1 (stage 2)
     __shared__ double tcs[SB_WLEN], tsn[SB_WLEN];     // W400 twiddles (LDS copy of ws.tab: 31 dependent-latency reads per thread otherwise)
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
     }
     const bool act = fs < SP_F && k0 + fs < na;
     for (int sig = sig0; sig <= sig1; ++sig) {
-        const float* sb = (sig ? y : x) + (size_t)b * L;
+        const float* sb = (sig ? y : x) + (size_t)b * Lrow;
         __syncthreads();
         for (int e = tid; e < SP_F * SB_WLEN; e += 128) {
             const int f_ = e / SB_WLEN, j = e - f_ * SB_WLEN;
@@ -757,8 +764,8 @@ extern "C" long long nele_metric_siib_workspace_bytes(int B, int L) { return (lo
 // eigen-decomposition; y is not read and may be null), 4 = the rest (y spectra / masking / stacking, projections, score) on the
 // same workspace: the Karhunen-Loeve basis of SIIB is that of the clean signal, so phase 3 can run before the degraded signal
 // exists (GanTrainer runs it beside the G-step).
-extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
-                                      float* mapped, int* info_out, int phase, void* stream) {
+extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* lengths, int B, int L, void* workspace, long long workspace_bytes,
+                                    float* raw, float* mapped, int* info_out, int phase, void* stream) {
     NELE_CHECK_ARG(x && workspace && (raw || mapped) && B > 0, "nele_metric_siib: bad arguments");
     NELE_CHECK_ARG(phase >= 0 && phase <= 4, "nele_metric_siib: phase must be 0..4");
     NELE_CHECK_ARG(y || phase == 3, "nele_metric_siib: degraded signal missing");
@@ -768,11 +775,14 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     SiibWs ws;
     const size_t used = siib_layout(B, L, &ws, (char*)workspace);
     (void)used;
+    ws.lens = lengths;
     hipStream_t s = as_stream(stream);
     int g = L, r = SB_SHIFT;
     while (r) { const int t = g % r; g = r; r = t; }
     static const bool dedup = [] { const char* e = getenv("NELE_SIIB_DEDUP"); return !(e && e[0] == '0'); }();
-    const int Pf = dedup ? L / g : 0x7fffffff;               // frame period of the tiled signal (NELE_SIIB_DEDUP=0: A/B switch, every frame computed)
+    // frame period of the tiled signal (NELE_SIIB_DEDUP=0: A/B switch, every frame computed; per-utterance lengths: every row has its
+    // own period, the shortcut is not taken)
+    const int Pf = (dedup && !lengths) ? L / g : 0x7fffffff;
     const int n1 = (int)(((long long)L - SB_WLEN + SB_SHIFT - 1) / SB_SHIFT);   // frames of the un-tiled signal (L > 400 checked above)
     const bool vad = (phase == 0 || phase == 1 || phase == 3);
     const bool sx = vad, sy = (phase == 0 || phase == 1 || phase == 4);
@@ -784,7 +794,8 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
         hipLaunchKernelGGL(siib_m_kernel, dim3(B), dim3(256), 0, s, L, ws);
         {
             const int last = Pf < ws.NT ? Pf : ws.NT;            // tiled frames the base pass and the period do not give
-            if (last > n1) hipLaunchKernelGGL(siib_db_kernel, dim3((last - n1 + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1, Pf);
+            const int first = lengths ? 0 : n1;                  // shorter rows have fewer base frames: the grid starts at each row's own count
+            if (last > first) hipLaunchKernelGGL(siib_db_kernel, dim3((last - first + 3) / 4, B), dim3(256), 0, s, x, L, ws, 1, Pf);
         }
         hipLaunchKernelGGL(siib_compact_kernel, dim3(B), dim3(256), 0, s, ws, Pf);
     }
@@ -816,7 +827,12 @@ extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int
     return NELE_OK;
 }
 
+extern "C" int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
+                                      float* mapped, int* info_out, int phase, void* stream) {
+    return nele_metric_siib_var(x, y, nullptr, B, L, workspace, workspace_bytes, raw, mapped, info_out, phase, stream);
+}
+
 extern "C" int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                                 float* mapped, int* info_out, void* stream) {
-    return nele_metric_siib_phase(x, y, B, L, workspace, workspace_bytes, raw, mapped, info_out, 0, stream);
+    return nele_metric_siib_var(x, y, nullptr, B, L, workspace, workspace_bytes, raw, mapped, info_out, 0, stream);
 }

@@ -5,8 +5,8 @@ wav (``train_nele.py:198,313``, ``inference.py:115``) under ``name@epoch.wav``, 
 (clean, noise, enhanced) triple back per file (``audio_util.py:120-203``, ``267-321``), and the D-step consumes
 ``"s0,s1,s2,s3,s4,path"`` strings (``audio_util.py:367-389``, ``dataloader.py:54-84``).  This module reads and
 writes those formats so that folders and lists produced by either implementation are interchangeable, and it
-feeds the batched GPU kernels from them: files are decoded on the host, grouped by length, and each group is
-one batched launch (the reference: one joblib process per file, ``audio_util.py:146``).
+feeds the batched GPU kernels from them: files are decoded on the host, padded side by side with their per-file lengths,
+and each metric is one batched launch (the reference: one joblib process per file, ``audio_util.py:146``).
 
 No third-party audio library: RIFF/WAVE PCM is parsed here (libsndfile / librosa are not in the image).
 PCM_16 semantics follow libsndfile: write ``rint(x * 0x7FFF)`` (round half to even), read ``s / 0x8000``
@@ -159,26 +159,33 @@ def _triple(clean_root, noise_root, enhanced_file, drc):
     return clean[:n], enh[:n] + noise[:n]
 
 
+def pad_batch(signals):
+    """list of float32 [L_i] -> (padded [n, Lmax] float32 with zeros behind every row's end, lengths int32 [n])."""
+    lens = np.asarray([len(a) for a in signals], dtype=np.int32)
+    out = np.zeros((len(signals), int(lens.max())), dtype=np.float32)
+    for i, a in enumerate(signals):
+        out[i, :len(a)] = a
+    return out, lens
+
+
 def _read_batch(kind, clean_root, noise_root, enhanced_list, norm, drc=False, max_batch=256):
+    """Files of ANY lengths go side by side into one padded batch with per-utterance lengths: one kernel launch per metric and
+    ``max_batch`` files (the reference: one joblib process per file, audio_util.py:146)."""
     import torch
     from . import metrics as mt
     fn = {'estoi': mt.batch_estoi, 'siib': mt.batch_siib, 'haspi': mt.batch_haspi}[kind]
     pairs = [_triple(clean_root, noise_root, en, drc) for en in enhanced_list]
-    groups = {}
-    for i, (x, _) in enumerate(pairs):
-        groups.setdefault(len(x), []).append(i)
     out = [None] * len(pairs)
-    for _, idx in sorted(groups.items()):
-        for k in range(0, len(idx), max_batch):
-            sel = idx[k:k + max_batch]
-            x = torch.from_numpy(np.stack([pairs[i][0] for i in sel])).cuda()
-            y = torch.from_numpy(np.stack([pairs[i][1] for i in sel])).cuda()
-            raw, mapped = fn(x, y)[:2]
-            vals = (mapped if norm else raw).double().cpu().numpy()
-            for i, v in zip(sel, vals):
-                if not np.isfinite(v):
-                    raise ValueError('%s: metric undefined for %s (the reference raises here)' % (kind, enhanced_list[i]))
-                out[i] = float(v)
+    for k in range(0, len(pairs), max_batch):
+        sel = list(range(k, min(k + max_batch, len(pairs))))
+        xp, lens = pad_batch([pairs[i][0] for i in sel])
+        yp, _ = pad_batch([pairs[i][1] for i in sel])
+        raw, mapped = fn(torch.from_numpy(xp).cuda(), torch.from_numpy(yp).cuda(), lengths=torch.from_numpy(lens))[:2]
+        vals = (mapped if norm else raw).double().cpu().numpy()
+        for i, v in zip(sel, vals):
+            if not np.isfinite(v):
+                raise ValueError('%s: metric undefined for %s (the reference raises here)' % (kind, enhanced_list[i]))
+            out[i] = float(v)
     return out
 
 

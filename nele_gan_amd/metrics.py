@@ -20,6 +20,10 @@ from ._lib import c_int, c_longlong, c_void_p, call, declare, ptr, stream
 _P = c_void_p
 declare('nele_metric_estoi', [_P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P])
 _lib._SIGS['nele_metric_estoi'] = _lib.lib.nele_metric_estoi.argtypes
+declare('nele_metric_estoi_var', [_P, _P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P])
+_lib._SIGS['nele_metric_estoi_var'] = _lib.lib.nele_metric_estoi_var.argtypes
+declare('nele_metric_siib_var', [_P, _P, _P, c_int, c_int, _P, c_longlong, _P, _P, _P, c_int, _P])
+_lib._SIGS['nele_metric_siib_var'] = _lib.lib.nele_metric_siib_var.argtypes
 _lib.lib.nele_metric_estoi_workspace_bytes.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_estoi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_estoi_workspace_bytes'] = _lib.lib.nele_metric_estoi_workspace_bytes.argtypes
@@ -87,15 +91,20 @@ def _pair(x, y):
     return x[:, :L].contiguous(), y[:, :L].contiguous(), single
 
 
-def batch_estoi(x, y):
-    """clean x [B,L], degraded y [B,L] (16 kHz) -> (raw [B], mapped [B]) float32 device tensors."""
+def _lens(lengths, device):
+    return None if lengths is None else torch.as_tensor(lengths).to(device=device, dtype=torch.int32).contiguous()
+
+
+def batch_estoi(x, y, lengths=None):
+    """clean x [B,L], degraded y [B,L] (16 kHz) -> (raw [B], mapped [B]) float32 device tensors.
+    lengths [B]: samples of each utterance inside the padded batch (one launch for files of different lengths)."""
     x, y, _ = _pair(x, y)
     B, L = x.shape
     nb = _lib.lib.nele_metric_estoi_workspace_bytes(B, L)
     ws = _workspace('estoi', nb, x.device)
     raw = torch.empty(B, device=x.device)
     mapped = torch.empty(B, device=x.device)
-    call('nele_metric_estoi', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), stream())
+    call('nele_metric_estoi_var', ptr(x), ptr(y), ptr(_lens(lengths, x.device)), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), stream())
     return raw, mapped
 
 
@@ -105,7 +114,8 @@ class SiibSplit:
     dependence - SIIB's Karhunen-Loeve basis comes from the clean signal alone, so VAD, the clean spectra, the covariance and its
     eigen-decomposition can run before the degraded signal exists."""
 
-    def __init__(self, x, y=None):
+    def __init__(self, x, y=None, lengths=None):
+        self.lengths = None
         if y is None:
             self.x = x.contiguous().float()
             self.y = None
@@ -117,11 +127,12 @@ class SiibSplit:
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
+        self.lengths = _lens(lengths, self.x.device)
 
     def _call(self, phase):
         B, L = self.x.shape
-        call('nele_metric_siib_phase', ptr(self.x), ptr(self.y), B, L, ptr(self.ws), self.ws.numel(), ptr(self.raw), ptr(self.mapped),
-             ptr(self.info), phase, stream())
+        call('nele_metric_siib_var', ptr(self.x), ptr(self.y), ptr(self.lengths), B, L, ptr(self.ws), self.ws.numel(), ptr(self.raw),
+             ptr(self.mapped), ptr(self.info), phase, stream())
 
     def front(self):
         self._call(1)
@@ -140,7 +151,7 @@ class SiibSplit:
         return self.raw, self.mapped
 
 
-def batch_siib(x, y, return_info=False):
+def batch_siib(x, y, return_info=False, lengths=None):
     """clean x [B,L], degraded y [B,L] (16 kHz) -> (raw [B] bits/s, mapped [B]); the replication rule of
     intel.py:93-97 is applied per utterance on the device.  info [B,4] = (M, tiled frames, active frames, status)."""
     x, y, _ = _pair(x, y)
@@ -150,7 +161,8 @@ def batch_siib(x, y, return_info=False):
     raw = torch.empty(B, device=x.device)
     mapped = torch.empty(B, device=x.device)
     info = torch.zeros((B, 4), dtype=torch.int32, device=x.device)
-    call('nele_metric_siib', ptr(x), ptr(y), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), stream())
+    call('nele_metric_siib_var', ptr(x), ptr(y), ptr(_lens(lengths, x.device)), B, L, ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), 0,
+         stream())
     if return_info:
         return raw, mapped, info
     return raw, mapped

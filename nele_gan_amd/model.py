@@ -380,6 +380,7 @@ class _DBuffers:
     def __init__(self, B, T, dev, cin0):
         self.B, self.T = B, T
         self.gen = 0
+        self.wvalid = None
         H, W, C = 64, T, 4
         self.dims = [(H, W, C)]
         self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
@@ -429,9 +430,10 @@ class _DBuffers:
 
 class _DFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, din, anchor, module):
+    def forward(ctx, din, anchor, module, frames=None):
         ctx.module = module
-        ctx.key = module._forward_impl(din)
+        ctx.key = module._forward_impl(din, frames)
+        ctx.wvalid = module._bufs[ctx.key].wvalid
         ctx.gen = module._bufs[ctx.key].gen
         ctx.need_din = din.requires_grad
         score = module._last_score
@@ -443,8 +445,8 @@ class _DFn(torch.autograd.Function):
     def backward(ctx, dscore):
         (score,) = ctx.saved_tensors
         _check_generation(ctx, 'Discriminator')
-        ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, score)
-        return ddin, None, None
+        ddin = ctx.module._backward_impl(dscore.contiguous(), ctx.key, ctx.need_din, score, ctx.wvalid)
+        return ddin, None, None, None
 
 
 class _NchwToPacked(torch.autograd.Function):
@@ -589,7 +591,7 @@ class _DiscriminatorBase(nn.Module):
                     ops.weight_prep_frag(w['wb'][l], cpad, k * k * cout, w['wbf'][l])
                 cin = cpad = cout
 
-    def _forward_impl(self, din):
+    def _forward_impl(self, din, frames=None):
         if not din.is_cuda:
             raise RuntimeError("nele_gan_amd: the discriminator runs on the GPU only (no CPU fallback)")
         dev = din.device
@@ -619,16 +621,19 @@ class _DiscriminatorBase(nn.Module):
                 ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
         score = _empty((B, self._nout), dev)
-        call('nele_gap_mlp_fwd', ptr(a), B, bf.P, self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score),
-             ptr(bf.scratch64), stream())
+        # padded batch of utterances of different lengths: the pooling runs over each utterance's own valid output columns (frames - 20)
+        bf.wvalid = None if frames is None else (frames.to(device=dev, dtype=torch.int32) - 20).contiguous()
+        call('nele_gap_mlp_fwd_var', ptr(a), B, bf.P, bf.dims[-1][1], ptr(bf.wvalid), self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1),
+             ptr(bf.h2), ptr(score), ptr(bf.scratch64), stream())
         self._last_score = score
         return key
 
-    def forward_packed(self, din):
-        """din: channels-last [B,64,T,4] (ops.d_pack / energy-norm output)."""
+    def forward_packed(self, din, frames=None):
+        """din: channels-last [B,64,T,4] (ops.d_pack / energy-norm output).  frames [B] (optional): STFT frames of each utterance
+        inside a padded batch (every utterance needs >= 21, like T)."""
         if torch.is_grad_enabled() and (din.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _DFn.apply(din, self._anchor.get(din.device), self)
-        self._forward_impl(din)
+            return _DFn.apply(din, self._anchor.get(din.device), self, frames)
+        self._forward_impl(din, frames)
         score, self._last_score = self._last_score, None
         return score
 
@@ -638,7 +643,7 @@ class _DiscriminatorBase(nn.Module):
             raise ValueError("%s.forward: x must be [B, %d, 64, T]" % (type(self).__name__, self._cin))
         return self.forward_packed(_NchwToPacked.apply(x))
 
-    def _backward_impl(self, dscore, key, need_din, score):
+    def _backward_impl(self, dscore, key, need_din, score, wvalid=None):
         bf = self._bufs[key]
         B = bf.B
         w = self._w
@@ -646,8 +651,8 @@ class _DiscriminatorBase(nn.Module):
         wgrad = self.weight_grad_enabled
         Ho, Wo, _ = bf.dims[-1]
         p5 = bf.pad[-1]
-        call('nele_gap_mlp_bwd', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]), self._mlp_ptrs(w), nout,
-             SLOPE, B, Ho, Wo, Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1), ptr(bf.dpooled), ptr(bf.gbuf[-1]),
+        call('nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]), self._mlp_ptrs(w), nout,
+             SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1), ptr(bf.dpooled), ptr(bf.gbuf[-1]),
              stream())
         ddin = None
         # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
@@ -762,8 +767,9 @@ def energy_norm_pack(mask, clean_band, noise_band, p_power=1.0 / 6, inv_p=6.0):
     return _EnergyNormPack.apply(mask.contiguous(), clean_band.contiguous(), noise_band.contiguous(), float(p_power), float(inv_p))
 
 
-def normed_alpha2(mask, clean_band, inv_p=6.0):
-    """mask * beta_2 (train_nele.py:303-307; inference.py:99-104), no autograd."""
+def normed_alpha2(mask, clean_band, inv_p=6.0, frames=None):
+    """mask * beta_2 (train_nele.py:303-307; inference.py:99-104), no autograd.  frames [B]: STFT frames of each utterance inside a
+    padded batch (the energy sums of beta_2 run over those frames only)."""
     _, _, _, alpha2 = ops.energy_norm_fwd(clean_band.contiguous(), mask.contiguous(), None, 1.0 / inv_p, float(inv_p), want_din=False,
-                                          want_alpha2=True)
+                                          want_alpha2=True, frames=frames)
     return alpha2

@@ -42,6 +42,9 @@ _SIGS = {
     'nele_gap_mlp_fwd': [_P, c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P, _P],
     'nele_gap_mlp_bwd': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, _P, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_fwd_var': [_P, c_int, c_int, c_int, _P, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_bwd_var': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                             c_int, _P, _P, _P, _P, _P, _P],
     'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     'nele_adam_step': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P],
     'nele_adam_step_guarded': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P, _P],
@@ -172,7 +175,10 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, guard=None):
         call('nele_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream())
 
 
-def energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True, want_alpha2=False):
+def energy_norm_fwd(clean, mask, noise, p, inv_p, want_din=True, want_alpha2=False, frames=None):
+    """frames [B] is accepted for symmetry with the other padded-batch entry points and needs no kernel support: the band features of
+    frames behind an utterance's end are exactly zero (nele_stft_band_var / nele_imcra_band_var), so they add nothing to beta_2's sums,
+    their D input is zero and their mask gradient is zero."""
     B, T, _ = clean.shape
     dev = clean.device
     beta2 = torch.empty(B, device=dev)

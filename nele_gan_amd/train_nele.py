@@ -90,32 +90,36 @@ class GanTrainer:
                 ndist.allreduce_weighted_mean_(g, float(weight))
 
     # ---------------------------------------------------------------- features (dataloader.py:30-42)
-    def features(self, clean_wav, noise_wav):
-        """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64).
+    def features(self, clean_wav, noise_wav, lengths=None):
+        """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64, frames).
+        lengths [B] (optional): samples of each utterance inside the padded batch - the reference handles one file of any length at a
+        time (dataloader.py:30-42); 'frames' = 1 + lengths // 256 travels with the features to the stages that need it.
         The noise branch (STFT -> IMCRA, a 1.1 ms scan that is serial over frames and fills 1/8 of the GPU) heads the step's critical
         path, so it is issued first; the clean STFT + band energies run beside it on their own stream."""
         main = torch.cuda.current_stream()
         if self._fside is None:
             self._fside = ops.side_stream(self.device)
         fs_ = self._fside
+        lengths = au._i32(lengths, self.device)
+        frames = au.frames_of(lengths)
         ev0 = torch.cuda.Event()
         ev0.record(main)
         with torch.cuda.stream(fs_):
             fs_.wait_event(ev0)
-            clean_spec, clean_band = au.stft_band(clean_wav, p_power)
+            clean_spec, clean_band = au.stft_band(clean_wav, p_power, lengths=lengths)
             evc = torch.cuda.Event()
             evc.record(fs_)
-        noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False)
-        _, noise_band = au.imcra_band(noise_spec, p_power)
+        noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False, lengths=lengths)
+        _, noise_band = au.imcra_band(noise_spec, p_power, frames=frames)
         main.wait_event(evc)
         clean_spec.record_stream(main)
         clean_band.record_stream(main)
         if clean_wav.is_cuda:
             clean_wav.record_stream(fs_)
-        return {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec}
+        return {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec, 'frames': frames, 'lengths': lengths}
 
     # ---------------------------------------------------------------- G-step (train_nele.py:122-156)
-    def g_step(self, clean_band, noise_band):
+    def g_step(self, clean_band, noise_band, frames=None):
         B = clean_band.shape[0]
         self.D.weight_grad_enabled = False           # D / D_Qua gradients of this step are never applied (train_nele.py:153-155)
         if self.D_Qua is not None:
@@ -125,11 +129,11 @@ class GanTrainer:
         din, _ = M.energy_norm_pack(mask, clean_band, noise_band, p_power, inv_p)
         self._last_din = din                         # bench.py re-launches D's forward on it for the isolated roofline figure
         self.D.profile_prefix = 'gstep.'             # bench.py times these launches
-        score = self.D.forward_packed(din)
+        score = self.D.forward_packed(din, frames)
         self.D.profile_prefix = ''
         loss = self.MSELoss(score, torch.ones_like(score))
         if self.D_Qua is not None:
-            score_q = self.D_Qua.forward_packed(self.quality_inputs(din))
+            score_q = self.D_Qua.forward_packed(self.quality_inputs(din), frames)
             loss = loss + weight_qua * self.MSELoss(score_q, torch.ones_like(score_q))
         loss.backward()
         self._allreduce_grads(self.G)
@@ -142,11 +146,11 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- sample generation (train_nele.py:279-316)
     @torch.no_grad()
-    def generate(self, clean_band, noise_band, clean_spec, rms_target=0.0):
+    def generate(self, clean_band, noise_band, clean_spec, rms_target=0.0, frames=None):
         self.G.eval()
         mask = self.G(clean_band, noise_band)
-        alpha2 = M.normed_alpha2(mask, clean_band, inv_p)
-        enh_wav = au.gain_istft(alpha2, clean_spec, rms_target=rms_target, pcm16=self.pcm16)
+        alpha2 = M.normed_alpha2(mask, clean_band, inv_p, frames=frames)
+        enh_wav = au.gain_istft(alpha2, clean_spec, rms_target=rms_target, pcm16=self.pcm16, frames=frames)
         self.G.train()
         return enh_wav
 
@@ -180,32 +184,40 @@ class GanTrainer:
         return st
 
     # ---------------------------------------------------------------- true metric targets (train_nele.py:318-340)
-    def _metric(self, m, x, y, which):
+    def _metric(self, m, x, y, which, lengths=None):
         if m == 'siib':
-            raw, mapped, info = mt.batch_siib(x, y, return_info=True)
+            raw, mapped, info = mt.batch_siib(x, y, return_info=True, lengths=lengths)
             self._note_status(which, siib_info=info)
         elif m == 'haspi':
-            raw, mapped, info = mt.batch_haspi(x, y, return_info=True)
+            raw, mapped, info = mt.batch_haspi(x, y, return_info=True, lengths=lengths)
             self._note_status(which, haspi_info=info)
         else:
-            raw, mapped = mt.batch_estoi(x, y)
+            raw, mapped = mt.batch_estoi(x, y, lengths=lengths)
         return raw, mapped
 
+    @staticmethod
+    def enhanced_lengths(lengths):
+        """Samples of the resynthesised signal of an utterance with ``lengths`` samples: 256 * (L // 256) (audio_util.py:60-65), which is
+        also what the metrics see (min of the clean and the enhanced length, audio_util.py:134-141)."""
+        return None if lengths is None else (torch.div(lengths, 256, rounding_mode='floor') * 256).to(torch.int32)
+
     @torch.no_grad()
-    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True):
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None):
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
         x = clean_wav[:, :L].contiguous()
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
+        lengths = self.enhanced_lengths(au._i32(lengths, self.device))
         cols = []
         for m in self.metrics:
-            raw, mapped = self._metric(m, x, y, 'main')
+            raw, mapped = self._metric(m, x, y, 'main', lengths)
             cols.append(mapped if norm else raw)
         return torch.stack(cols, dim=1)
 
     # ---------------------------------------------------------------- D-step (train_nele.py:349-367)
-    def d_inputs(self, enh_wav, noise_band, clean_band):
-        """dataloader.py:54-84: features of the enhanced wav, stacked (enhanced, noise, clean)."""
-        _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False)
+    def d_inputs(self, enh_wav, noise_band, clean_band, lengths=None):
+        """dataloader.py:54-84: features of the enhanced wav, stacked (enhanced, noise, clean).  lengths: of the ORIGINAL utterances
+        (the enhanced ones hold 256 * (L // 256) samples and have the same frame count)."""
+        _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False, lengths=self.enhanced_lengths(au._i32(lengths, self.device)))
         return ops.d_pack(enh_band, noise_band, clean_band)
 
     @staticmethod
@@ -216,17 +228,17 @@ class GanTrainer:
         din_q[..., 1] = din[..., 2]
         return din_q
 
-    def d_step(self, din, target, target_qua=None, weight=None):
+    def d_step(self, din, target, target_qua=None, weight=None, frames=None):
         """One optimiser step of D on (din, target) - and of D_Qua on ([enh, clean], target_qua) when the quality discriminator is
         enabled and quality targets are given (train_nele.py:356-365).  ``weight``: number of items this rank contributes (d_epoch
         under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives."""
         self.optimizer_d.zero_grad()
-        score = self.D.forward_packed(din) if din is not None else None
+        score = self.D.forward_packed(din, frames) if din is not None else None
         loss = self._d_finish(score, target, weight)
         if self.D_Qua is not None and (target_qua is not None or (din is None and weight is not None)):
             self.optimizer_dqua.zero_grad()
             if din is not None:
-                loss_qua = self.MSELoss(self.D_Qua.forward_packed(self.quality_inputs(din)), target_qua)
+                loss_qua = self.MSELoss(self.D_Qua.forward_packed(self.quality_inputs(din), frames), target_qua)
                 loss_qua.backward()
             self._allreduce_grads(self.D_Qua, weight)
             self.optimizer_dqua.step()
@@ -243,8 +255,9 @@ class GanTrainer:
         return loss.detach() if loss is not None else None
 
     # ---------------------------------------------------------------- one canonical step
-    def canonical_step(self, clean_wav, noise_wav, feats=None):
-        """features -> G-step -> generate -> true metrics -> D-step on the same batch."""
+    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None):
+        """features -> G-step -> generate -> true metrics -> D-step on the same batch.  lengths [B] (optional): samples of each
+        utterance inside the padded batch (every utterance needs >= 21 frames, i.e. 5120 samples, for D)."""
         # The metric kernels run on a side stream.  (1) Everything SIIB derives from the CLEAN signal alone - VAD, clean spectra,
         # the covariance and its eigen-decomposition (the KLT basis) - is enqueued first and runs beside features / G-step /
         # generate.  (2) Once the enhanced signal exists the remaining metric work follows on the side stream while the main
@@ -254,6 +267,8 @@ class GanTrainer:
             self._side = ops.side_stream(self.device)
         side = self._side
         L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
+        lengths = au._i32(lengths, self.device)
+        mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
         start = torch.cuda.Event()
         start.record(main)
         split = None
@@ -264,7 +279,7 @@ class GanTrainer:
             x_ready = torch.cuda.Event()
             x_ready.record(side)
             if 'siib' in self.metrics:
-                split = mt.SiibSplit(x)
+                split = mt.SiibSplit(x, lengths=mlens)
                 split.clean_part()
         if self._side2 is None:
             self._side2 = ops.side_stream(self.device)
@@ -277,10 +292,11 @@ class GanTrainer:
             if 'haspi' in self.metrics and self.split_haspi:
                 # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
                 self._side2.wait_event(x_ready)
-                hsplit = mt.HaspiSplit(x)
+                hsplit = mt.HaspiSplit(x, lengths=mlens)
                 hsplit.clean_part()
-        f = feats or self.features(clean_wav, noise_wav)
-        lg = self.g_step(f['clean_band'], f['noise_band'])
+        f = feats or self.features(clean_wav, noise_wav, lengths)
+        frames = f.get('frames')
+        lg = self.g_step(f['clean_band'], f['noise_band'], frames)
         gdone = torch.cuda.Event()
         gdone.record(main)                                 # the G-step's backward pass is the last reader of D's current weight layouts
         # second D.prepare: on the feature side stream when the metric side stream is busy with HASPI's clean part
@@ -288,7 +304,7 @@ class GanTrainer:
         with torch.cuda.stream(pstream):
             pstream.wait_event(gdone)
             self.D.prepare(B_, T_, self.device)
-        enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+        enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=frames)
         assert enh.shape[1] == L
         self._last_enh = enh
         ready = torch.cuda.Event()
@@ -305,7 +321,7 @@ class GanTrainer:
             if split is not None:
                 cols['siib'] = split.degraded_part(y)[1]
             if 'estoi' in self.metrics and 'haspi' in self.metrics:
-                cols['estoi'] = mt.batch_estoi(x, y)[1]    # HASPI's degraded-signal chain owns the other stream: ESTOI rides behind SIIB
+                cols['estoi'] = mt.batch_estoi(x, y, lengths=mlens)[1]    # HASPI's degraded-signal chain owns the other stream: ESTOI rides behind SIIB
         haspi_info = None
         with torch.cuda.stream(side2):                     # the cheaper metrics beside SIIB's degraded-signal part
             side2.wait_event(start)
@@ -315,9 +331,9 @@ class GanTrainer:
                     cols[m] = hsplit.degraded_part(y)[1]
                     haspi_info = hsplit.info
                 elif m == 'haspi':
-                    _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True)
+                    _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True, lengths=mlens)
                 elif m != 'siib' and m not in cols:
-                    cols[m] = getattr(mt, _METRIC_FN[m])(x, y)[1]
+                    cols[m] = getattr(mt, _METRIC_FN[m])(x, y, lengths=mlens)[1]
             others = torch.cuda.Event()
             others.record(side2)
         with torch.cuda.stream(side):
@@ -331,9 +347,9 @@ class GanTrainer:
             self._note_status('side', siib_info=split.info if split is not None else None, haspi_info=haspi_info)
         for t in (x, y):
             t.record_stream(side2)
-        din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
+        din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lengths)
         self.optimizer_d.zero_grad()
-        score = self.D.forward_packed(din)
+        score = self.D.forward_packed(din, frames)
         for t in (tgt, x, y):
             t.record_stream(main)
         enh.record_stream(side)

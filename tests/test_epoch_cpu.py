@@ -126,7 +126,7 @@ class _TinyD(torch.nn.Module):
     def flat_parameters(self):
         return self._f
 
-    def forward_packed(self, din):
+    def forward_packed(self, din, frames=None):
         self._w = self._f.flat.detach().clone().requires_grad_(True)
         return torch.sigmoid(din.mean(dim=(1, 2, 3)).unsqueeze(1) * self._w[0] + self._w[1])
 
