@@ -199,6 +199,10 @@ def main():
     tag = 'D.conv5.fwd'           # D's 5th conv forward: every launch of the timed region (one in the G-step, one in the D-step per step)
     wtag = 'D.conv5.wgrad'        # the memory-side companion figure: D's 5th conv weight gradient (events on its own stream; includes its partial reduction)
     ops.PROFILE = {'gstep.' + tag: [], tag: [], wtag: []}
+    from nele_gan_amd import _lib
+    htag = 'haspi_gain_lp_sl_kernel'   # the HBM-side figure: HASPI's fused compression-gain pass, timed by the library's HIP-event hook
+    if 'haspi' in metrics:
+        _lib.profile_begin(htag)
     stage_ev = []
     barrier()
     t0 = time.perf_counter()
@@ -225,6 +229,7 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    hbm_ms = _lib.profile_collect() if 'haspi' in metrics else []
     prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
     prof = prof_g + prof_d
     prof_w = ops.PROFILE[wtag]
@@ -245,14 +250,17 @@ def main():
     ops.PROFILE = None
     if rank == 0:
         T = 1 + a.length // 256
-        traffic = None      # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01/traffic.json), B = 32 bf16 only
+        # HBM bytes per launch (PMC FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950-corrected) and MFMA-busy figures of the
+        # SAME command on this tree: profiles/r02/traffic.json (tools/prof_r02.sh + tools/make_traffic_json.py); counters cannot be
+        # read from inside the process, so the line carries them only for the workload the committed passes were taken on
+        pmc = {}
         try:
-            import json as _json
-            tj = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'traffic.json')))
-            if a.precision == 'bf16' and a.batch == 32 and a.length == 64000:
-                traffic = [v['hbm_bytes_corrected'] for k, v in tj['kernels'].items() if k.startswith('conv_tile16_kernel<4,8>')][0]
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'traffic.json')))
+            if tj.get('workload') == {'batch': a.batch, 'length': a.length, 'metrics': a.metrics, 'precision': a.precision}:
+                pmc = tj['kernels']
         except Exception:
-            traffic = None
+            pmc = {}
+        traffic = pmc.get('conv_tile16_kernel<4, 8>', {}).get('hbm_bytes_corrected')
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
         iso_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in iso) / max(1, len(iso))
@@ -273,25 +281,32 @@ def main():
                          'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
                              'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'launch_ms': kernel_ms,
+                         'traffic': traffic, 'mfma_busy_frac': pmc.get('conv_tile16_kernel<4, 8>', {}).get('mfma_busy_frac'), 'launch_ms': kernel_ms,
                          'launch_ms_gstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_g) / max(1, len(prof_g)),   # beside the half-GPU tridiagonalisation
                          'launch_ms_dstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_d) / max(1, len(prof_d)),
                          'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops},
         }
         if prof_w:
+            # D.conv5 weight gradient: dW[64][3888] = dY^T im2col(X), an MFMA-bound GEMM (arithmetic intensity ~1000 FLOP/B)
             w_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof_w) / len(prof_w)
-            w_bytes = prof_w[0][2]
-            w_traffic = None
-            try:
-                if a.precision == 'bf16' and a.batch == 32 and a.length == 64000:
-                    w_traffic = [v['hbm_bytes_corrected'] for k, v in tj['kernels'].items() if k.startswith('conv_wgrad_tile16_kernel<4,7>')][0]
-            except Exception:
-                w_traffic = None
-            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
-                                   'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                   'frac': w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': w_traffic, 'launch_ms': w_ms,
-                                   'algorithmic_bytes': w_bytes, 'launches_timed': len(prof_w)}
+            w_flops = flops                                            # same M, N, K as the forward pass
+            out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
+                                     'achieved': w_flops / (w_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                                     'frac': w_flops / (w_ms * 1e-3) / 1e12 / peak,
+                                     'traffic': pmc.get('conv_wgrad_tile16_kernel<4, 7>', {}).get('hbm_bytes_corrected'),
+                                     'algorithmic_bytes': prof_w[0][2], 'launch_ms': w_ms, 'launches_timed': len(prof_w)}
+        if hbm_ms:
+            # HASPI compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step: reads the control and the signal
+            # envelope (float32 |u|^2, [rows][n24][32]) once and rewrites the signal envelope in place: 12 bytes per (sample, channel)
+            n24p = (int(a.length * 1.5) + 31) // 32 * 32
+            h_bytes = float(a.batch) * n24p * 32 * 12
+            h_ms = sum(hbm_ms) / len(hbm_ms)
+            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': htag + ' (pyhaspi2.py:982-997, 1080-1088 fused; %d rows x %d samples x 32 channels)' % (a.batch, n24p),
+                                   'achieved': h_bytes / (h_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': h_bytes / (h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   'traffic': pmc.get(htag, {}).get('hbm_bytes_corrected'), 'launch_ms': h_ms,
+                                   'algorithmic_bytes': h_bytes, 'launches_timed': len(hbm_ms)}
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}

@@ -25,6 +25,12 @@ int nele_version(void);
 const char* nele_last_error_string(void);
 int nele_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 
+/* Measurement hook (no reference counterpart): HIP-event timing of one kernel that is launched from inside a multi-kernel entry
+ * point.  nele_profile_begin(tag) arms it for the launch sites tagged `tag` (e.g. "haspi_gain_lp_sl_kernel"; NULL disarms);
+ * nele_profile_collect waits for the recorded launches and writes their durations in milliseconds (returns how many). */
+int nele_profile_begin(const char* tag);
+int nele_profile_collect(float* ms_out, int max_n);
+
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */
 
 /* audio_util.py:53-58 STFT (librosa 0.7.1: reflect pad 256, periodic Hann 512, hop 256),

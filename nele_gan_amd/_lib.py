@@ -42,6 +42,8 @@ _SIGS = {
     'nele_imcra_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft': [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     'nele_wav_post': [c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'nele_profile_begin': [ctypes.c_char_p],
+    'nele_profile_collect': [c_void_p, c_int],
     'nele_stft_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft_var': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -88,6 +90,18 @@ def ptr(t):
 def stream():
     """The current torch HIP stream as a hipStream_t."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_begin(tag):
+    """Arm the library's HIP-event hook for the launch sites tagged ``tag`` (None disarms)."""
+    lib.nele_profile_begin(tag.encode() if tag else None)
+
+
+def profile_collect(max_n=4096):
+    """-> list of durations (ms) of the tagged launches since profile_begin (synchronises on them)."""
+    buf = (c_float * max_n)()
+    n = lib.nele_profile_collect(buf, max_n)
+    return [float(buf[i]) for i in range(n)]
 
 
 def device_info():

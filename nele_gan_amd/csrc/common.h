@@ -38,6 +38,17 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// csrc/capi.hip: HIP-event pair around one tagged launch when nele_profile_begin(tag) armed it (bench.py's roofline figures)
+bool nele_prof_match(const char* tag);
+void nele_prof_mark(hipStream_t s);
+#define NELE_PROF(tag, stream, launch)                      \
+    do {                                                    \
+        const bool prof_ = nele_prof_match(tag);            \
+        if (prof_) nele_prof_mark(stream);                  \
+        launch;                                             \
+        if (prof_) nele_prof_mark(stream);                  \
+    } while (0)
+
 // ---- wave64 reductions (fixed-order butterflies: deterministic) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

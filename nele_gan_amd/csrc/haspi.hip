@@ -1258,7 +1258,8 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     }
     if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone (+ constant tables)
     if (fused_gain && par_iir) {
-        hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
+        NELE_PROF("haspi_gain_lp_sl_kernel", s,
+                  hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
         hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * GL_N - 1) / (4 * GL_N), rows), dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)

@@ -361,32 +361,38 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
     @staticmethod
-    def _length_buckets(lst, batch):
-        """Shuffled sample list -> batches of at most ``batch`` items with the same frame count T (the reference trains D at batch 1
-        on utterances of any length, train_nele.py:349-367; a batched launch needs one T, so items are grouped by T in shuffled
-        order and every group is cut into batches)."""
-        groups = {}
-        for it in lst:
-            groups.setdefault(int(it[0].shape[1]), []).append(it)
+    def _padded_chunks(lst, batch, round_to=8):
+        """Shuffled sample list -> batches of at most ``batch`` items in list order.  The reference trains D at batch 1 on utterances
+        of any length (train_nele.py:349-367); here the items of a batch are zero-padded along the frame axis to the batch's longest
+        (rounded up to a multiple of ``round_to`` so that few distinct buffer shapes occur) and carry their own frame counts, which
+        D's pooling honours (nele_gap_mlp_fwd_var).  -> list of (din [b,64,T,4], target [b,n], target_qua [b,2] | None, frames [b])."""
         out = []
-        for T in sorted(groups):
-            g = groups[T]
-            out += [g[k:k + batch] for k in range(0, len(g), batch)]
+        for k in range(0, len(lst), batch):
+            ch = lst[k:k + batch]
+            Ts = [int(c[0].shape[1]) for c in ch]
+            Tm = (max(Ts) + round_to - 1) // round_to * round_to
+            if all(t == Ts[0] for t in Ts):
+                din, frames = torch.stack([c[0] for c in ch]), None
+            else:
+                din = ch[0][0].new_zeros((len(ch), 64, Tm, 4))
+                for r, c in enumerate(ch):
+                    din[r, :, :Ts[r]] = c[0]
+                frames = torch.tensor(Ts, dtype=torch.int32, device=din.device)
+            tq = torch.stack([c[2] for c in ch]) if (len(ch[0]) > 2 and ch[0][2] is not None) else None
+            out.append((din, torch.stack([c[1] for c in ch]), tq, frames))
         return out
 
     def _d_pass(self, lst, batch):
         random.shuffle(lst)
-        chunks = self._length_buckets(lst, batch)
+        chunks = self._padded_chunks(lst, batch)
         n_steps = len(chunks)
         if self.world > 1:
-            # ranks hold different shards (and length mixes): every rank must join the same number of all-reduces
+            # ranks hold different shards: every rank must join the same number of all-reduces
             n_steps = ndist.allreduce_max_int(n_steps, self.device)
         for k in range(n_steps):
             if k < len(chunks):
-                ch = chunks[k]
-                tq = torch.stack([c[2] for c in ch]) if (self.D_Qua is not None and len(ch[0]) > 2 and ch[0][2] is not None) else None
-                self.d_step(torch.stack([c[0] for c in ch]), torch.stack([c[1] for c in ch]), tq,
-                            weight=len(ch) if self.world > 1 else None)
+                din, tgt, tq, frames = chunks[k]
+                self.d_step(din, tgt, tq if self.D_Qua is not None else None, weight=din.shape[0] if self.world > 1 else None, frames=frames)
             else:
                 self.d_step(None, None, None, weight=0)
         return n_steps

@@ -100,12 +100,16 @@ def test_epoch_two_runs_generator_steps_first_and_reuses_their_features():
     assert 'checkpoint' not in log                                                # no path given
 
 
-def test_length_buckets_group_by_frame_count_in_shuffled_order():
+def test_padded_chunks_keep_list_order_and_carry_frame_counts():
     from nele_gan_amd.train_nele import GanTrainer
-    items = [(torch.zeros(64, T, 4), torch.tensor([float(i)])) for i, T in enumerate([30, 40, 30, 30, 40, 50, 30])]
-    chunks = GanTrainer._length_buckets(items, 2)
-    assert [[int(c[1]) for c in ch] for ch in chunks] == [[0, 2], [3, 6], [1, 4], [5]]
-    assert all(len({int(c[0].shape[1]) for c in ch}) == 1 for ch in chunks)
+    items = [(torch.full((64, T, 4), float(i)), torch.tensor([float(i)])) for i, T in enumerate([30, 40, 30, 30, 41, 50, 30])]
+    chunks = GanTrainer._padded_chunks(items, 2)
+    assert [[int(v) for v in ch[1][:, 0]] for ch in chunks] == [[0, 1], [2, 3], [4, 5], [6]]
+    din, tgt, tq, frames = chunks[0]
+    assert din.shape == (2, 64, 40, 4) and frames.tolist() == [30, 40] and tq is None
+    assert float(din[0, :, 30:].abs().sum()) == 0.0 and float(din[0, :, :30].min()) == 0.0 and float(din[1].min()) == 1.0
+    assert chunks[1][3] is None and chunks[1][0].shape == (2, 64, 30, 4)          # equal lengths: plain stack, no frame counts
+    assert chunks[2][0].shape == (2, 64, 56, 4) and chunks[2][3].tolist() == [41, 50]   # padded to a multiple of 8
 
 
 # ------------------------------------------------------------------------------------------ data-parallel D epoch on ragged shards

@@ -89,7 +89,7 @@ def test_d_epoch_three_passes_and_history_replay():
     item = lambda i: (din[i % 2].clone(), torch.tensor([0.25 + 0.01 * i], device='cuda'))
     seen = []
     orig = tr.d_step
-    tr.d_step = lambda d, t, *a, **k: (seen.append(d.shape[0]), orig(d, t, *a, **k))[1]
+    tr.d_step = lambda d, t, *a, **k: (seen.append(d.shape[0]), orig(d, t, *a, **k))[1]   # equal lengths here: plain batches
     tr.history = [item(i) for i in range(60)]                       # 60 // 30 = 2 replayed items
     cur = [item(100 + i) for i in range(5)]
     w0 = tr.D.layers[4].weight_orig.detach().clone()

@@ -1,0 +1,50 @@
+"""Summarise the PMC passes of tools/prof_r02.sh into profiles/r02/traffic.json (read by bench.py for roofline.traffic).
+
+  FETCH_SIZE / WRITE_SIZE (KB, separate passes) -> HBM bytes per launch, gfx950-corrected as MI355X_MICROARCH.md prescribes:
+  FETCH_SIZE counts 16-byte-per-lane loads at half their bytes (x 2), WRITE_SIZE is exact.
+  SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) / (1024 SIMDs x duration x 2.4 GHz) -> MFMA-busy fraction.
+usage: python tools/make_traffic_json.py gpurun_out/r02_prof batch length metrics precision
+"""
+import csv, glob, json, sys
+from collections import defaultdict
+
+root = sys.argv[1]
+work = {'batch': int(sys.argv[2]), 'length': int(sys.argv[3]), 'metrics': sys.argv[4], 'precision': sys.argv[5]}
+WANT = ('conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7>',
+        'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_bank_scan_kernel<true, true>', 'haspi_bank_scan_kernel<false, true>',
+        'haspi_mod_slide_kernel<1>', 'stft_band_kernel', 'gain_istft_kernel', 'siib_proj_kernel<2>', 'siib_cov_kernel',
+        'eigh_tridiag_cluster4_kernel', 'conv1d_tile16_kernel<4>', 'adam_guarded_kernel')
+
+
+def key(name):
+    for w in WANT:
+        if w in name:
+            return w
+    return None
+
+
+acc = defaultdict(lambda: defaultdict(list))
+for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ'):
+    for f in glob.glob('%s/%s/*/*_counter_collection.csv' % (root, d)):
+        for r in csv.DictReader(open(f)):
+            k = key(r['Kernel_Name'])
+            if k:
+                acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+                if d == 'pmc_SQ' and r['Counter_Name'] == 'SQ_WAVE_CYCLES':
+                    acc[k]['_dur_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+out = {'note': __doc__.strip().split('\n\n')[0] + ' Averages per launch over all launches of the kernel in `bench.py --steps 3 --warmup 1 --cpu-utts 0 --companions 0`.',
+       'workload': work, 'kernels': {}}
+for k, c in acc.items():
+    avg = {n: sum(v) / len(v) for n, v in c.items()}
+    e = {'launches': len(c.get('FETCH_SIZE', c.get('SQ_WAVE_CYCLES', [])))}
+    if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
+        e.update({'FETCH_SIZE_KB': avg['FETCH_SIZE'], 'WRITE_SIZE_KB': avg['WRITE_SIZE'],
+                  'hbm_bytes_corrected': int(avg['FETCH_SIZE'] * 1024 * 2 + avg['WRITE_SIZE'] * 1024)})
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in avg and avg.get('_dur_ns'):
+        e.update({'SQ_VALU_MFMA_BUSY_CYCLES': avg['SQ_VALU_MFMA_BUSY_CYCLES'], 'SQ_INSTS_VALU_MFMA_MOPS_BF16': avg.get('SQ_INSTS_VALU_MFMA_MOPS_BF16'),
+                  'SQ_BUSY_CU_CYCLES': avg.get('SQ_BUSY_CU_CYCLES'), 'SQ_WAVE_CYCLES': avg.get('SQ_WAVE_CYCLES'), 'pmc_pass_duration_us': avg['_dur_ns'] / 1e3,
+                  'mfma_busy_frac': avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * avg['_dur_ns'] * 2.4)})
+    out['kernels'][k] = e
+json.dump(out, open('profiles/r02/traffic.json', 'w'), indent=1)
+for k, e in sorted(out['kernels'].items()):
+    print('%-40s %s' % (k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in e.items() if a in ('hbm_bytes_corrected', 'mfma_busy_frac', 'pmc_pass_duration_us', 'launches')}))
