@@ -419,10 +419,52 @@ __global__ __launch_bounds__(128) void haspi_pmat_kernel(HaspiWs ws, int lc, int
     P[0 * 4 + k] = r0; P[1 * 4 + k] = r1; P[2 * 4 + k] = r2; P[3 * 4 + k] = r3;     // column k of M^lc
 }
 
-// grid (chunks, nsig, B), block 64: lane = part * 32 + channel as in the serial kernel.
+// End states of pass 1 -> start states of pass 2, in place: R_0 = 0, R_(j+1) = P R_j + e_j.  grid rows, block 64 (lane = part * 32 +
+// channel); the end states of a group of chunks are loaded together ahead of the (serial) Horner steps.
+template <bool SIGNAL>
+__global__ __launch_bounds__(64) void haspi_bank_prefix_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int row = hp_row(blockIdx.x, sig0, nsig), lane = threadIdx.x, ch = lane & 31;
+    const int n24 = hp_n24(ws, row >> 1);
+    const int nch = ((n24 + GS_RC - 1) / GS_RC * GS_RC + ws.lc - 1) / ws.lc;          // chunks pass 1 produced for this row
+    const double* P = ws.pmat + ((size_t)(SIGNAL ? 1 + row : 0) * HP_NCH + ch) * 16;
+    double Pm[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Pm[q] = P[q];
+    double* est = ws.est + (size_t)row * ws.nchunk * 256 + lane;
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    constexpr int G = 8;
+    for (int j0 = 0; j0 < nch; j0 += G) {
+        double e[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int j = min(j0 + g, nch - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[g][q] = est[(size_t)j * 256 + 64 * q];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (j0 + g < nch) {
+                double* o = est + (size_t)(j0 + g) * 256;
+                o[0] = r0; o[64] = r1; o[128] = r2; o[192] = r3;
+                const double t0 = ((Pm[0] * r0 + Pm[1] * r1) + (Pm[2] * r2 + Pm[3] * r3)) + e[g][0];
+                const double t1 = ((Pm[4] * r0 + Pm[5] * r1) + (Pm[6] * r2 + Pm[7] * r3)) + e[g][1];
+                const double t2 = ((Pm[8] * r0 + Pm[9] * r1) + (Pm[10] * r2 + Pm[11] * r3)) + e[g][2];
+                const double t3 = ((Pm[12] * r0 + Pm[13] * r1) + (Pm[14] * r2 + Pm[15] * r3)) + e[g][3];
+                r0 = t0; r1 = t1; r2 = t2; r3 = t3;
+            }
+        }
+    }
+}
+
+// grid (ceil(chunks / 2), nsig, B), block 64: lane = (chunk parity) * 32 + channel.  A lane runs BOTH demodulated branches (x cos and
+// x sin) of its channel: the rotation recurrence is computed once per channel instead of once per branch, and the envelope
+// |u|^2 = yr^2 + yi^2 needs no cross-lane exchange (the serial kernel's lane = branch * 32 + channel layout spent half of its issue
+// slots on selects, register moves and v_permlane32_swap: every VALU instruction of a wave64 costs 4 cycles on the 16-wide SIMDs,
+// whatever its width).  Same arithmetic per branch as the serial kernel.
 template <bool SIGNAL, bool PASS2>
 __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig0) {
-    const int chunk = blockIdx.x, b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
+    const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, ch = lane & 31;
+    const int chunk = 2 * blockIdx.x + (lane >> 5);
     const int row = 2 * b + sig, lc = ws.lc;
     const int n24 = hp_n24(ws, b);
     const int n0 = chunk * lc, n1 = min(n0 + lc, (n24 + GS_RC - 1) / GS_RC * GS_RC);
@@ -431,24 +473,16 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
     const GtCoef c = hp_gt(SIGNAL ? ws.bw[(size_t)row * HP_NCH + ch] : hp_bw1(ch), cf);
     const double tpt = 2.0 * M_PI / HP_FS;
     const double cn = cos(tpt * cf), sn = sin(tpt * cf);
-    double* est = ws.est + (size_t)row * ws.nchunk * 256 + lane;             // [chunk][4][64]
-    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    if (PASS2 && chunk > 0) {
-        const double* P = ws.pmat + ((size_t)(SIGNAL ? 1 + row : 0) * HP_NCH + ch) * 16;
-        double Pm[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Pm[q] = P[q];
-        for (int j = 0; j < chunk; ++j) {                  // R_(j+1) = P R_j + e_j
-            const double e0 = est[(size_t)j * 256], e1 = est[(size_t)j * 256 + 64], e2 = est[(size_t)j * 256 + 128], e3 = est[(size_t)j * 256 + 192];
-            const double t0 = ((Pm[0] * r0 + Pm[1] * r1) + (Pm[2] * r2 + Pm[3] * r3)) + e0;
-            const double t1 = ((Pm[4] * r0 + Pm[5] * r1) + (Pm[6] * r2 + Pm[7] * r3)) + e1;
-            const double t2 = ((Pm[8] * r0 + Pm[9] * r1) + (Pm[10] * r2 + Pm[11] * r3)) + e2;
-            const double t3 = ((Pm[12] * r0 + Pm[13] * r1) + (Pm[14] * r2 + Pm[15] * r3)) + e3;
-            r0 = t0; r1 = t1; r2 = t2; r3 = t3;
-        }
+    double* est = ws.est + ((size_t)row * ws.nchunk + chunk) * 256 + ch;       // [4][branch * 32 + channel]
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    if (PASS2) {                                          // true state at the chunk start (haspi_bank_prefix_kernel)
+        r0 = est[0]; r1 = est[64]; r2 = est[128]; r3 = est[192];
+        i0 = est[32]; i1 = est[96]; i2 = est[160]; i3 = est[224];
     }
-    double cold = 1.0, sold = 0.0;                         // demodulator state before sample n0: R^(n0 - 1) (1, 0)
-    if (n0 > 1) {
+    // demodulator state one step BEFORE sample n0, so that the rotation below is unconditional: R^(n0 - 1) (1, 0); for n0 = 0 that
+    // is R^(-1) (1, 0) = (cos, +sin), which the first rotation turns into (1, 0) to rounding
+    double cold, sold;
+    {
         const double ang = tpt * cf * (double)(n0 - 1);
         cold = cos(ang);
         sold = -sin(ang);
@@ -466,28 +500,32 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
         float eo[GS_RC];
 #pragma unroll
         for (int u = 0; u < GS_RC; ++u) {
-            if (nb + u > 0) hp_rotate(cold, sold, cn, sn);
-            const double xr = xc[u] * (part ? sold : cold);
-            const double yr = xr + r0;
+            hp_rotate(cold, sold, cn, sn);
+            const double xr = xc[u] * cold, xi = xc[u] * sold;
+            const double yr = xr + r0, yi = xi + i0;
             r0 = c.a1 * xr + c.a1 * yr + r1;
             r1 = c.a5 * xr + c.a2 * yr + r2;
             r2 = c.a3 * yr + r3;
             r3 = c.a4 * yr;
+            i0 = c.a1 * xi + c.a1 * yi + i1;
+            i1 = c.a5 * xi + c.a2 * yi + i2;
+            i2 = c.a3 * yi + i3;
+            i3 = c.a4 * yi;
             if (PASS2) {
-                const double yo = lane_xor32(yr);
-                const double e2 = yr * yr + yo * yo;
+                const double e2 = yr * yr + yi * yi;
                 eo[u] = (float)e2;
                 if (!SIGNAL) ss += (nb + u < n24) ? e2 : 0.0;
             }
         }
-        if (PASS2 && part == 0) {
+        if (PASS2) {
 #pragma unroll
             for (int u = 0; u < GS_RC; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
         }
     }
     if (!PASS2) {
-        est[(size_t)chunk * 256] = r0; est[(size_t)chunk * 256 + 64] = r1; est[(size_t)chunk * 256 + 128] = r2; est[(size_t)chunk * 256 + 192] = r3;
-    } else if (!SIGNAL && part == 0) {
+        est[0] = r0; est[64] = r1; est[128] = r2; est[192] = r3;
+        est[32] = i0; est[96] = i1; est[160] = i2; est[224] = i3;
+    } else if (!SIGNAL) {
         ws.ssp[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
     }
 }
@@ -689,38 +727,27 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
 // every chunk of GL_N samples in order anyway) runs the recurrence from a zero state and keeps the end state, pass 2
 // (haspi_ihc_scan_kernel) starts every chunk from the Horner-combined true state.  P over GL_N samples comes from iterating the
 // homogeneous recurrence itself (haspi_shift_kernel).
-// IHC pass 2.  Thread = (chunk of GL_N samples, channel); block = 8 chunks x 32 channels; grid (ceil(chunks / 8), rows).  In place on env.
-__global__ __launch_bounds__(256) void haspi_ihc_scan_kernel(HaspiWs ws, int sig0, int nsig) {
-    const int ch = threadIdx.x & 31, row = hp_row(blockIdx.y, sig0, nsig);
-    const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5), n0 = chunk * GL_N;
-    const int n24 = hp_n24(ws, row >> 1);
-    const int n24r = (n24 + GL_U - 1) / GL_U * GL_U;
-    if (n0 >= n24r) return;
-    const int n1 = min(n0 + GL_N, n24r);
-    const IhcC k = hp_ihc_consts();
-    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
-    const double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;             // [chunk][2][32]
+// IHC end states of pass 1 (inside the gain pass) -> start states of pass 2, in place.  grid rows, block 32 (channel).
+__global__ __launch_bounds__(32) void haspi_ihc_prefix_kernel(HaspiWs ws, int sig0, int nsig) {
+    const int row = hp_row(blockIdx.x, sig0, nsig), ch = threadIdx.x;
+    const int n24 = hp_n24(ws, row >> 1), ncg = (ws.n24p + GL_N - 1) / GL_N;
+    const int nch = ((n24 + HP_CH - 1) / HP_CH * HP_CH + GL_N - 1) / GL_N;            // chunks the gain pass produced for this row
+    double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;
     const double p00 = ws.pihc[0], p01 = ws.pihc[1], p10 = ws.pihc[2], p11 = ws.pihc[3];
     double V1 = 0.0, V2 = 0.0;
-    for (int j = 0; j < chunk; ++j) {
-        const double e1 = ihe[(size_t)j * 64], e2 = ihe[(size_t)j * 64 + 32];
-        const double t1 = (p00 * V1 + p01 * V2) + e1, t2 = (p10 * V1 + p11 * V2) + e2;
-        V1 = t1; V2 = t2;
-    }
-    hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
-    for (int n = n0; n < n1; n += GL_U) {
-        float ex[GL_U];
+    constexpr int G = 8;
+    for (int j0 = 0; j0 < nch; j0 += G) {
+        double e1[G], e2[G];
 #pragma unroll
-        for (int u = 0; u < GL_U; ++u) ex[u] = e[(size_t)(n + u) * HP_NCH];
+        for (int g = 0; g < G; ++g) { const int j = min(j0 + g, nch - 1); e1[g] = ihe[(size_t)j * 64]; e2[g] = ihe[(size_t)j * 64 + 32]; }
 #pragma unroll
-        for (int u = 0; u < GL_U; ++u) {
-            const double V0 = (double)ex[u];
-            hp_ihc_step(k, V0, V1, V2);
-            const double out = (V0 - V1) * k.R1inv;
-            ex[u] = (float)(out < 0.0 ? 0.0 : out);
+        for (int g = 0; g < G; ++g) {
+            if (j0 + g < nch) {
+                ihe[(size_t)(j0 + g) * 64] = V1; ihe[(size_t)(j0 + g) * 64 + 32] = V2;
+                const double t1 = (p00 * V1 + p01 * V2) + e1[g], t2 = (p10 * V1 + p11 * V2) + e2[g];
+                V1 = t1; V2 = t2;
+            }
         }
-#pragma unroll
-        for (int u = 0; u < GL_U; ++u) e[(size_t)(n + u) * HP_NCH] = ex[u];
     }
 }
 
@@ -752,23 +779,22 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
     // this chunk emits the outputs whose window ends in [n0, n1); the last chunk also those that end behind the row's end
     const int n1 = (chunk == last) ? n24 + 9 + 26 : n0 + GL_N;
     const IhcC k = hp_ihc_consts();
-    const double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;
-    const double p00 = ws.pihc[0], p01 = ws.pihc[1], p10 = ws.pihc[2], p11 = ws.pihc[3];
-    double V1 = 0.0, V2 = 0.0;
-    for (int j = 0; j < chunk; ++j) {
-        const double e1 = ihe[(size_t)j * 64], e2 = ihe[(size_t)j * 64 + 32];
-        const double t1 = (p00 * V1 + p01 * V2) + e1, t2 = (p10 * V1 + p11 * V2) + e2;
-        V1 = t1; V2 = t2;
-    }
+    const double* ihe = ws.ihe + ((size_t)row * ncg + chunk) * 64 + ch;
+    double V1 = ihe[0], V2 = ihe[32];                        // true state at the chunk start (haspi_ihc_prefix_kernel)
     const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
     int nstart = n0;
     if (chunk > 0) {                                         // state at n0 -> state at n0 - 51 (inverse of hp_ihc_step)
         nstart = n0 - IF_L;
-        for (int n = n0 - 1; n >= nstart; --n) {
-            const double V0 = (double)e[(size_t)n * HP_NCH];
+        float hb[IF_L];                                      // all 51 loads first, then the (serial) backward steps
+#pragma unroll
+        for (int q = 0; q < IF_L; ++q) hb[q] = e[(size_t)(n0 - 1 - q) * HP_NCH];
+        const double iR12 = 1.0 / k.R12C1, iR23 = 1.0 / k.R23C2;
+#pragma unroll
+        for (int q = 0; q < IF_L; ++q) {
+            const double V0 = (double)hb[q];
             const double b1 = k.a11 * V1 + k.a12 * V2, b2 = k.a21 * V1 + k.a22 * V2;
-            V1 = (b1 - V0 * k.R2) / k.R12C1;
-            V2 = b2 / k.R23C2;
+            V1 = (b1 - V0 * k.R2) * iR12;
+            V2 = b2 * iR23;
         }
     }
     double* lp = ws.lp + ((size_t)row * ws.nsub) * HP_NCH + ch;
@@ -779,10 +805,15 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
     double s0 = 0.0, s1r = 0.0, s1i = 0.0;
     int ph = (nstart + sh - 26) % 9;                         // (n + s - 26) mod 9; an output is due when it is 0
     if (ph < 0) ph += 9;
+    float nx[GL_U];                                          // the next group's samples are in flight while this group is processed
+#pragma unroll
+    for (int u = 0; u < GL_U; ++u) nx[u] = e[(size_t)min(nstart + u, n24 - 1) * HP_NCH];
     for (int nb = nstart; nb < n1; nb += GL_U) {
         float ex[GL_U];
 #pragma unroll
-        for (int u = 0; u < GL_U; ++u) ex[u] = e[(size_t)min(nb + u, n24 - 1) * HP_NCH];
+        for (int u = 0; u < GL_U; ++u) ex[u] = nx[u];
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) nx[u] = e[(size_t)min(nb + GL_U + u, n24 - 1) * HP_NCH];
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) {
             const int n = nb + u;
@@ -982,7 +1013,7 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
 // ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
 __constant__ double c_modcf[HP_NMOD] = {2, 6, 10, 16, 25, 40, 64, 100, 160, 256};
 __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38, 24};
-#define MS_MAXC 64            // chunks of MS_TC outputs per utterance at most (nsub <= 131 072)
+#define MS_MAXC 128           // chunks of MS_TC outputs per utterance at most (nsub <= 131 072)
 #define HP_TILE 1024          // outputs per tile: 256 threads x 4 consecutive outputs (sliding register window over the taps)
 #define HP_MAXFIR 614
 // LDS position of sequence element e: a thread reads elements 4 tid + c, so the four residues mod 4 live in four sub-arrays and a
@@ -1089,7 +1120,7 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
 // (50 of 64 lanes), every chunk warms its sums up over the L samples before it (recurrence without the subtraction).  A lane owns
 // one (basis, band) pair, so the correlation sums of ebm_ModCorr stay in its registers; chunk partials are combined in chunk order.
 // SIG = 0 stores the filtered reference sequence xf [b][t][64]; SIG = 1 filters the processed signal and correlates it with xf.
-#define MS_TC 2048
+#define MS_TC 1024
 template <int SIG>
 __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
     const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
@@ -1118,27 +1149,38 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
     }
     double s0r = 0, s0i = 0, spr = 0, spi = 0, smr = 0, smi = 0;
     double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-    for (int tt = t0 - LMAX; tt < t1; ++tt) {
-        const int tau = tt + nh;
-        { const double nr = Er * ec - Ei * es; Ei = Er * es + Ei * ec; Er = nr; }       // E <- E e^{-j theta}
-        if (tt < t0 - L) continue;                                        // before this lane's warm-up window
-        const bool live = tt >= t0;
-        const double vn = (tau >= 0 && tau < na) ? v[min(max(tau, 0), na - 1)] : 0.0;
-        const int to = tau - L;
-        const double vo = (live && to >= 0 && to < na) ? v[min(max(to, 0), na - 1)] : 0.0;
-        const double eor = Er * k1c - Ei * k1s, eoi = Er * k1s + Ei * k1c;             // phase of z[tau - L]
-        const double dr = vn * Er - vo * eor, di = vn * Ei - vo * eoi;                 // z[tau] - z[tau - L]
-        s0r += dr; s0i += di;
-        { const double nr = (rc * spr - rs * spi) + dr; spi = (rc * spi + rs * spr) + di; spr = nr; }
-        { const double nr = (rc * smr + rs * smi) + dr; smi = (rc * smi - rs * smr) + di; smr = nr; }
-        if (live) {
+    // steps in groups of MS_U: the group's loads (two sequence elements and, for SIG = 1, the stored reference output per step) are
+    // issued together ahead of the dependent recurrences - one memory latency per group instead of one per step
+    constexpr int MS_U = 8;
+    for (int tb = t0 - LMAX; tb < t1; tb += MS_U) {
+        double vnv[MS_U], vov[MS_U], xvv[MS_U];
+#pragma unroll
+        for (int u = 0; u < MS_U; ++u) {
+            const int tt = tb + u, tau = tt + nh, to = tau - L;
+            vnv[u] = v[min(max(tau, 0), na - 1)];
+            vov[u] = v[min(max(to, 0), na - 1)];
+            if (SIG == 1) xvv[u] = xf[(size_t)min(max(tt, 0), na - 1) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < MS_U; ++u) {
+            const int tt = tb + u, tau = tt + nh, to = tau - L;
+            { const double nr = Er * ec - Ei * es; Ei = Er * es + Ei * ec; Er = nr; }   // E <- E e^{-j theta}
+            const bool live = tt >= t0 && tt < t1;
+            // before this lane's warm-up window (tt < t0 - L) nothing enters the sums; during it (tt < t0) nothing leaves them
+            const double vn = (tt >= t0 - L && tau >= 0 && tau < na) ? vnv[u] : 0.0;
+            const double vo = (tt >= t0 && to >= 0 && to < na) ? vov[u] : 0.0;
+            const double eor = Er * k1c - Ei * k1s, eoi = Er * k1s + Ei * k1c;         // phase of z[tau - L]
+            const double dr = vn * Er - vo * eor, di = vn * Ei - vo * eoi;             // z[tau] - z[tau - L]
+            s0r += dr; s0i += di;
+            { const double nr = (rc * spr - rs * spi) + dr; spi = (rc * spi + rs * spr) + di; spr = nr; }
+            { const double nr = (rc * smr + rs * smi) + dr; smi = (rc * smi - rs * smr) + di; smr = nr; }
             const double ur = 0.5 * s0r - 0.25 * (spr + smr), ui = 0.5 * s0i - 0.25 * (spi + smi);
             const double oc = Er * k2c + Ei * k2s, os = Er * k2s - Ei * k2c;            // conj(E) K2 = e^{+j theta (t + 1)}
             const double f = scale * (ur * oc - ui * os);
             if (SIG == 0) {
-                xf[(size_t)tt * 64] = f;
-            } else {
-                const double xv = xf[(size_t)tt * 64];
+                if (live) xf[(size_t)tt * 64] = f;
+            } else if (live) {
+                const double xv = xvv[u];
                 sx += xv; sy += f; sxx += xv * xv; syy += f * f; sxy += xv * f;
             }
         }
@@ -1246,12 +1288,14 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);
     if (par_iir) {
         if (sig0 == 0) hipLaunchKernelGGL(haspi_pmat_kernel, dim3(1), dim3(128), 0, s, ws, ws.lc, 0, 0, 1);   // control bank: per channel only
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, true>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL(haspi_bank_prefix_kernel<false>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL(haspi_pmat_kernel, dim3(rows), dim3(128), 0, s, ws, ws.lc, 1, sig0, nsig);
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3(ws.nchunk, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
+        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
@@ -1260,6 +1304,7 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     if (fused_gain && par_iir) {
         NELE_PROF("haspi_gain_lp_sl_kernel", s,
                   hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
+        hipLaunchKernelGGL(haspi_ihc_prefix_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * GL_N - 1) / (4 * GL_N), rows), dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
