@@ -803,17 +803,28 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
     }
     const double phi = 2.0 * M_PI / (double)IF_L, rc = cos(phi), rs = sin(phi);
     double s0 = 0.0, s1r = 0.0, s1i = 0.0;
-    int ph = (nstart + sh - 26) % 9;                         // (n + s - 26) mod 9; an output is due when it is 0
-    if (ph < 0) ph += 9;
+    // n + s - 26 = 9 icur + ph with 0 <= ph < 9 (floor division): output icur is due at the sample where ph == 0
+    int icur, ph;
+    {
+        const int t = nstart + sh - 26;
+        icur = (t >= 0) ? t / 9 : -((-t + 8) / 9);
+        ph = t - 9 * icur;
+    }
     float nx[GL_U];                                          // the next group's samples are in flight while this group is processed
 #pragma unroll
     for (int u = 0; u < GL_U; ++u) nx[u] = e[(size_t)min(nstart + u, n24 - 1) * HP_NCH];
     for (int nb = nstart; nb < n1; nb += GL_U) {
-        float ex[GL_U];
+        float ex[GL_U], olds[GL_U], news[GL_U];
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) ex[u] = nx[u];
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) nx[u] = e[(size_t)min(nb + GL_U + u, n24 - 1) * HP_NCH];
+        // the samples leaving the window during this group (slots n - 51 .. n - 44) are all older than anything the group writes: one
+        // LDS round trip per group instead of one per sample on the serial chain
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) olds[u] = ring[(nb + u - IF_L) & 63][tid];
+        double yv = 0.0;
+        int yi = -1;                                         // at most one output falls into 8 consecutive samples (they are 9 apart)
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) {
             const int n = nb + u;
@@ -824,17 +835,20 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
                 const double out = (V0 - V1) * k.R1inv;
                 o = (float)(out < 0.0 ? 0.0 : out);
             }
-            const float old = ring[(n - IF_L) & 63][tid];
-            ring[n & 63][tid] = o;
-            const double dx = (double)o - (double)old;
+            news[u] = o;
+            const double dx = (double)o - (double)olds[u];
             s0 += dx;
             { const double nr = (rc * s1r - rs * s1i) + dx; s1i = rc * s1i + rs * s1r; s1r = nr; }
-            if (ph == 0 && n >= n0 && n < n1) {
-                const int i = (n + sh - 26) / 9;
-                if (i >= 0 && i < nsub) lp[(size_t)i * HP_NCH] = (0.5 * s0 - 0.5 * s1r) * (1.0 / 25.5);
-            }
-            ph = (ph == 8) ? 0 : ph + 1;
+            const bool due = (ph == 0) && n >= n0 && n < n1;
+            yv = due ? (0.5 * s0 - 0.5 * s1r) * (1.0 / 25.5) : yv;
+            yi = due ? icur : yi;
+            const bool wrap = ph == 8;
+            ph = wrap ? 0 : ph + 1;
+            icur += wrap ? 1 : 0;
         }
+#pragma unroll
+        for (int u = 0; u < GL_U; ++u) ring[(nb + u) & 63][tid] = news[u];
+        if (yi >= 0 && yi < nsub) lp[(size_t)yi * HP_NCH] = yv;
     }
 }
 
