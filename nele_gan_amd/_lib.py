@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnele_hip.so')
+LIB_PATH = os.environ.get('NELE_LIB') or os.path.join(_HERE, 'libnele_hip.so')     # NELE_LIB: another build of the same ABI (A/B measurements)
 
 c_int = ctypes.c_int
 c_float = ctypes.c_float

@@ -1749,10 +1749,23 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
     }
     return 0;
 }
+// Tile height: the candidate that wastes the fewest output rows (ceil(Hout / TH) * TH - Hout; a taller tile also needs fewer LDS reads
+// per MFMA: TH + TN fragment reads per TH * TN MFMAs) among those whose halo fits LDS.  D.conv5 (Hout = 44): 11 instead of 8 (48 rows
+// computed); D.conv4 (52): 13; the 58-row gradients: 10.
 static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
-    if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
-    if (tile16_lds(g, N, KH, KW, 4)) return 4;
-    return 0;
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("NELE_CONV_TALL"); tall = !(e && e[0] == '0'); }
+    const int cand[5] = {13, 11, 10, 8, 4};
+    int best = 0, bestrows = 1 << 30;
+    for (int q = 0; q < 5; ++q) {
+        const int th = cand[q];
+        if (!tall && th > 8) continue;
+        if (th > 4 && g.Hout < 8) continue;
+        if (!tile16_lds(g, N, KH, KW, th)) continue;
+        const int rows = (g.Hout + th - 1) / th * th;
+        if (rows < bestrows) { bestrows = rows; best = th; }
+    }
+    return best;
 }
 static int span16_supported(int M, int N, const ConvGeom& g, int KH, int KW) {
     if (N > 64 || g.C % 8 || g.Wout < 64 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
@@ -1825,17 +1838,24 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
 #define TILE16_ATTR(TN_, TH_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<TN_, TH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
             TILE16_ATTR(1, 8); TILE16_ATTR(2, 8); TILE16_ATTR(3, 8); TILE16_ATTR(4, 8);
             TILE16_ATTR(1, 4); TILE16_ATTR(2, 4); TILE16_ATTR(3, 4); TILE16_ATTR(4, 4);
+            TILE16_ATTR(1, 10); TILE16_ATTR(2, 10); TILE16_ATTR(3, 10); TILE16_ATTR(4, 10);
+            TILE16_ATTR(1, 11); TILE16_ATTR(2, 11); TILE16_ATTR(3, 11); TILE16_ATTR(4, 11);
+            TILE16_ATTR(1, 13); TILE16_ATTR(2, 13); TILE16_ATTR(3, 13); TILE16_ATTR(4, 13);
 #undef TILE16_ATTR
             tattr = true;
         }
         t.ntiles = ((p.g.Wout + TILE16_TW - 1) / TILE16_TW) * ((p.g.Hout + th - 1) / th) * B_;
         const dim3 grid((unsigned)((t.ntiles + 7) / 8 * 8));      // a multiple of 8: every XCD gets the same number of ids
 #define TILE16_LAUNCH(TN_, TH_) hipLaunchKernelGGL((conv_tile16_kernel<TN_, TH_>), grid, dim3(256), lds, s, t)
-        if (th == 8) {
-            switch (p.NT) { case 1: TILE16_LAUNCH(1, 8); break; case 2: TILE16_LAUNCH(2, 8); break; case 3: TILE16_LAUNCH(3, 8); break; default: TILE16_LAUNCH(4, 8); break; }
-        } else {
-            switch (p.NT) { case 1: TILE16_LAUNCH(1, 4); break; case 2: TILE16_LAUNCH(2, 4); break; case 3: TILE16_LAUNCH(3, 4); break; default: TILE16_LAUNCH(4, 4); break; }
+#define TILE16_PICK(TH_) switch (p.NT) { case 1: TILE16_LAUNCH(1, TH_); break; case 2: TILE16_LAUNCH(2, TH_); break; case 3: TILE16_LAUNCH(3, TH_); break; default: TILE16_LAUNCH(4, TH_); break; }
+        switch (th) {
+            case 13: TILE16_PICK(13); break;
+            case 11: TILE16_PICK(11); break;
+            case 10: TILE16_PICK(10); break;
+            case 8: TILE16_PICK(8); break;
+            default: TILE16_PICK(4); break;
         }
+#undef TILE16_PICK
 #undef TILE16_LAUNCH
         NELE_CHECK_LAUNCH("nele_conv_span_bf16(tile)");
         return NELE_OK;

@@ -114,7 +114,7 @@ class SiibSplit:
     dependence - SIIB's Karhunen-Loeve basis comes from the clean signal alone, so VAD, the clean spectra, the covariance and its
     eigen-decomposition can run before the degraded signal exists."""
 
-    def __init__(self, x, y=None, lengths=None):
+    def __init__(self, x, y=None, lengths=None, owner=None):
         self.lengths = None
         if y is None:
             self.x = x.contiguous().float()
@@ -123,7 +123,8 @@ class SiibSplit:
             self.x, self.y, _ = _pair(x, y)
         B, L = self.x.shape
         # own workspace: the clean-signal state must survive until degraded_part(), whatever else calls batch_siib() meanwhile
-        self.ws = _workspace('siib_split', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
+        # (``owner``: one workspace per owner, e.g. per trainer, when split objects of several owners are alive at the same time)
+        self.ws = _workspace('siib_split' if owner is None else 'siib_split:%s' % owner, _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
@@ -225,12 +226,13 @@ class HaspiSplit:
     silence gate, group-delay shifts, cepstra, modulation filters) before the degraded signal exists; degraded_part(y) does the same
     for y and correlates.  Own workspace: the clean-signal state must survive until degraded_part()."""
 
-    def __init__(self, x, fs=16000, lengths=None):
+    def __init__(self, x, fs=16000, lengths=None, owner=None):
         self.x = x.contiguous().float()
         self.fs = int(fs)
         B, L = self.x.shape
         self.lengths = None if lengths is None else lengths.to(device=self.x.device, dtype=torch.int32).contiguous()
-        self.ws = _workspace('haspi_split', _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs), self.x.device)
+        self.ws = _workspace('haspi_split' if owner is None else 'haspi_split:%s' % owner, _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs),
+                             self.x.device)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 2), dtype=torch.int32, device=self.x.device)

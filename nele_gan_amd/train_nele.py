@@ -68,6 +68,7 @@ class GanTrainer:
         self._side2 = None
         self._fside = None
         self._last_enh = None                        # enhanced batch of the last canonical_step (parity tests read it)
+        self.prefetched = None                       # input-only work of the next batch (canonical_step(next_batch=...))
         self.split_haspi = os.environ.get('NELE_HASPI_SPLIT', '1') != '0'   # HASPI's clean-signal half beside the G-step (A/B switch)
         # metric status, accumulated on the device without a host synchronisation and read by check_status():
         # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
@@ -255,45 +256,97 @@ class GanTrainer:
         return loss.detach() if loss is not None else None
 
     # ---------------------------------------------------------------- one canonical step
-    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None):
+    def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features):
+        """Everything of a step that needs only its INPUTS, enqueued on the side streams behind event ``after``: the clean-signal
+        halves of SIIB (VAD .. eigen-decomposition .. clean projections) and HASPI (the whole reference-signal chain) and, with
+        ``with_features``, the features of both waveforms.  -> dict."""
+        if self._side is None:
+            self._side = ops.side_stream(self.device)
+        if self._side2 is None:
+            self._side2 = ops.side_stream(self.device)
+        side, side2 = self._side, self._side2
+        L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
+        lengths = au._i32(lengths, self.device)
+        mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
+        w = {'clean': clean_wav, 'noise': noise_wav, 'lengths': lengths, 'mlens': mlens, 'split': None, 'hsplit': None, 'feats': None}
+        with torch.cuda.stream(side):
+            side.wait_event(after)
+            w['x'] = clean_wav[:, :L].contiguous()
+            x_ready = torch.cuda.Event()
+            x_ready.record(side)
+            if 'siib' in self.metrics:
+                w['split'] = mt.SiibSplit(w['x'], lengths=mlens, owner=id(self))
+                w['split'].clean_part()
+        if 'haspi' in self.metrics and self.split_haspi:
+            # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
+            with torch.cuda.stream(side2):
+                side2.wait_event(after)
+                side2.wait_event(x_ready)
+                w['hsplit'] = mt.HaspiSplit(w['x'], lengths=mlens, owner=id(self))
+                w['hsplit'].clean_part()
+        if with_features:
+            if self._fside is None:
+                self._fside = ops.side_stream(self.device)
+            fs_ = self._fside
+            with torch.cuda.stream(fs_):
+                fs_.wait_event(after)
+                frames = au.frames_of(lengths)
+                clean_spec, clean_band = au.stft_band(clean_wav, p_power, lengths=lengths)
+                noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False, lengths=lengths)
+                _, noise_band = au.imcra_band(noise_spec, p_power, frames=frames)
+                w['feats'] = {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec, 'frames': frames, 'lengths': lengths}
+                w['feats_ready'] = torch.cuda.Event()
+                w['feats_ready'].record(fs_)
+        return w
+
+    def prefetch(self, clean_wav, noise_wav, lengths=None, after=None):
+        """The input-only work of the NEXT batch, as the reference's DataLoader workers prepare the features of upcoming items
+        while the current one trains (dataloader.py:86-92, 8 workers).  canonical_step(..., next_batch=...) calls this at the point where
+        the current step's targets are done, so that the work fills the D backward pass (the one phase of a step in which the side
+        streams are idle); pass the returned object as ``pre`` to the next canonical_step.  Results are bit-identical to computing
+        the same things inside the step (tests/test_step_parity_gpu.py)."""
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream())
+        return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True)
+
+    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None):
         """features -> G-step -> generate -> true metrics -> D-step on the same batch.  lengths [B] (optional): samples of each
-        utterance inside the padded batch (every utterance needs >= 21 frames, i.e. 5120 samples, for D)."""
+        utterance inside the padded batch (every utterance needs >= 21 frames, i.e. 5120 samples, for D).
+        pre: what prefetch() returned for THIS batch (its input-only work is then already in flight or done);
+        next_batch: (clean, noise[, lengths]) of the following step - its input-only work is enqueued behind this step's targets and the
+        result left in ``self.prefetched``."""
         # The metric kernels run on a side stream.  (1) Everything SIIB derives from the CLEAN signal alone - VAD, clean spectra,
         # the covariance and its eigen-decomposition (the KLT basis) - is enqueued first and runs beside features / G-step /
         # generate.  (2) Once the enhanced signal exists the remaining metric work follows on the side stream while the main
         # stream runs D's forward pass, which does not need the targets; the loss waits for them.
         main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = ops.side_stream(self.device)
-        side = self._side
         L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
-        lengths = au._i32(lengths, self.device)
-        mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
         start = torch.cuda.Event()
         start.record(main)
-        split = None
-        hsplit = None
-        with torch.cuda.stream(side):
-            side.wait_event(start)
-            x = clean_wav[:, :L].contiguous()
-            x_ready = torch.cuda.Event()
-            x_ready.record(side)
-            if 'siib' in self.metrics:
-                split = mt.SiibSplit(x, lengths=mlens)
-                split.clean_part()
+        B_, T_ = clean_wav.shape[0], 1 + clean_wav.shape[1] // 256
+        if self._fside is None:
+            self._fside = ops.side_stream(self.device)
         if self._side2 is None:
             self._side2 = ops.side_stream(self.device)
-        B_, T_ = clean_wav.shape[0], 1 + clean_wav.shape[1] // 256
         # D's spectral-norm iteration and weight layouts depend on its parameters only: they run on a side stream ahead of each of D's two
-        # forward passes (beside the generator's forward pass / beside generate) instead of at the head of those passes
-        with torch.cuda.stream(self._side2):
-            self._side2.wait_event(start)                  # after the previous step's D update
+        # forward passes (beside the generator's forward pass / beside generate) instead of at the head of those passes.  With a
+        # prefetched batch the metric side stream already carries HASPI's clean half: the feature stream (idle then) takes it.
+        p1 = self._fside if pre is not None else self._side2
+        with torch.cuda.stream(p1):
+            p1.wait_event(start)                           # after the previous step's D update
             self.D.prepare(B_, T_, self.device)
-            if 'haspi' in self.metrics and self.split_haspi:
-                # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
-                self._side2.wait_event(x_ready)
-                hsplit = mt.HaspiSplit(x, lengths=mlens)
-                hsplit.clean_part()
+        if pre is None:
+            pre = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False)
+        else:
+            assert pre['clean'] is clean_wav and pre['noise'] is noise_wav, "canonical_step: `pre` belongs to another batch"
+        side = self._side
+        lengths, mlens, x, split, hsplit = pre['lengths'], pre['mlens'], pre['x'], pre['split'], pre['hsplit']
+        if feats is None and pre['feats'] is not None:
+            feats = pre['feats']
+            main.wait_event(pre['feats_ready'])
+            for t in (feats['clean_band'], feats['noise_band'], feats['clean_spec']):
+                t.record_stream(main)
         f = feats or self.features(clean_wav, noise_wav, lengths)
         frames = f.get('frames')
         lg = self.g_step(f['clean_band'], f['noise_band'], frames)
@@ -355,6 +408,9 @@ class GanTrainer:
         enh.record_stream(side)
         clean_wav.record_stream(side)
         noise_wav.record_stream(side)
+        self.prefetched = None
+        if next_batch is not None:                          # the next batch's input-only work fills the D backward pass
+            self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done)
         main.wait_event(done)
         ld = self._d_finish(score, tgt)
         return lg, ld, tgt

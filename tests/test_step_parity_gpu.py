@@ -64,6 +64,29 @@ def test_multistream_step_is_bit_identical_to_the_staged_sequence(precision):
     assert all(x == 0 for x in a.check_status().values())
 
 
+def test_prefetched_pipeline_is_bit_identical_to_plain_steps():
+    """canonical_step(pre=..., next_batch=...) moves the input-only work of batch k + 1 (features, SIIB / HASPI clean halves) behind the
+    targets of batch k.  Three steps over two alternating batches must reproduce the plain step-by-step sequence bit for bit."""
+    from nele_gan_amd import synth
+    batches = []
+    for st in (40, 140):
+        c, v = synth.batch(3, 24000, start=st)
+        batches.append((torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()))
+    a = _trainer('siib&haspi&estoi', 'bf16')
+    b = _trainer('siib&haspi&estoi', 'bf16')
+    pre = a.prefetch(*batches[0])
+    for k in range(3):
+        cur, nxt = batches[k % 2], batches[(k + 1) % 2]
+        ra = a.canonical_step(cur[0], cur[1], pre=pre, next_batch=nxt)
+        pre = a.prefetched
+        rb = b.canonical_step(cur[0], cur[1])
+        torch.cuda.synchronize()
+        assert torch.equal(ra[2], rb[2]) and float(ra[0]) == float(rb[0]) and float(ra[1]) == float(rb[1]), k
+        assert torch.equal(a._last_enh, b._last_enh)
+        assert torch.equal(a.G.flat_parameters().flat, b.G.flat_parameters().flat) and torch.equal(a.D.flat_parameters().flat, b.D.flat_parameters().flat)
+    assert all(x == 0 for x in a.check_status().values())
+
+
 # tolerances of the bf16 operand mode against the float32 ORACLE (8-bit mantissa operands, float32 accumulation; DESIGN 4.1)
 BF16 = dict(score_abs=4e-3, loss_rel=3e-2, mask_rel=8e-2, grad_l2=0.12, grad_cos=0.99, enh_rel_l2=5e-2)
 
