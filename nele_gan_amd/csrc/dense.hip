@@ -1749,17 +1749,24 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
     }
     return 0;
 }
-// Tile height: the candidate that wastes the fewest output rows (ceil(Hout / TH) * TH - Hout; a taller tile also needs fewer LDS reads
-// per MFMA: TH + TN fragment reads per TH * TN MFMAs) among those whose halo fits LDS.  D.conv5 (Hout = 44): 11 instead of 8 (48 rows
-// computed); D.conv4 (52): 13; the 58-row gradients: 10.
+// Tile height.  Default: 8 rows where the halo fits, else 4 (round 1).  NELE_CONV_TALL=1 picks among {13, 11, 10, 8, 4} the candidate that
+// wastes the fewest output rows (D.conv5, Hout = 44: 11; D.conv4, 52: 13; the 58-row gradients: 10) - a taller tile also needs fewer LDS
+// reads per MFMA (TH + TN fragment reads per TH * TN MFMAs).  Measured at B = 256 (A/B inside one run, tools/ab.sh): D.conv5 forward alone
+// 1.70 -> 1.62 ms (0.305 -> 0.32 of the bf16 peak), but the whole step 75.6 -> 76.9 ms: the taller tile's 160 KB of LDS leaves no room for
+// the metric streams' workgroups beside it, and at B = 256 the step is bound by the sum of all kernels, not by the convolutions.  (The
+// converse also holds: 4-row tiles make the kernel 17 % slower alone and the step 0.5 ms faster.)  Hence opt-in.
 static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
     static int tall = -1;
-    if (tall < 0) { const char* e = getenv("NELE_CONV_TALL"); tall = !(e && e[0] == '0'); }
+    if (tall < 0) { const char* e = getenv("NELE_CONV_TALL"); tall = (e && e[0] == '1'); }
+    if (!tall) {
+        if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
+        if (tile16_lds(g, N, KH, KW, 4)) return 4;
+        return 0;
+    }
     const int cand[5] = {13, 11, 10, 8, 4};
     int best = 0, bestrows = 1 << 30;
     for (int q = 0; q < 5; ++q) {
         const int th = cand[q];
-        if (!tall && th > 8) continue;
         if (th > 4 && g.Hout < 8) continue;
         if (!tile16_lds(g, N, KH, KW, th)) continue;
         const int rows = (g.Hout + th - 1) / th * th;

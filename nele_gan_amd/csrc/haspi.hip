@@ -61,7 +61,11 @@ struct HaspiWs {
     double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
     double* lp;      // [B][2][nsub][32]
-    int* act;        // [B][nsub]     indices of the active sub-sampled frames
+    int* grank;      // [B][nsub]     rank of an active frame inside its block of CP_F frames, or -1 (silence gate)
+    int* gcnt;       // [B][ngb]      active frames per block -> exclusive offsets
+    double* cpsum;   // [B][2][ngb][6] block partial sums of the cepstral sequences
+    double* cmean;   // [B][2][6]     sequence means (subtracted by the modulation filters on load)
+    int ngb;         // blocks of CP_F sub-sampled frames per row
     int* info;       // [B][2]        {n_active, status}
     double* cep;     // [B][2][6][nsub] mean-removed cepstral sequences (only the first n_active columns)
     double* cm;      // [B][6][10]    |rho|
@@ -946,82 +950,89 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0
     }
 }
 
-// ---- h10: ebm_CepCoef (pyhaspi2.py:342-375). one block per utterance.
-// gate != 0: silence gate on the REFERENCE envelope + ordered compaction of the active frames (needs x only);
-// then the cepstral sequences of signals sig0 .. sig0+nsig-1 over those frames.
-__global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int gate, int sig0,
-                                                        int nsig) {
-    __shared__ double cepm[HP_NCH][HP_NBASIS];
-    __shared__ int scan[256];
-    __shared__ int base;
-    __shared__ double red[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// ---- h10: ebm_CepCoef (pyhaspi2.py:342-375), parallel over sub-sampled frames (one block per utterance walking 10 667 frames - 32
+// float64 pow() each for the silence gate - took 0.75 ms alone and 4.8 ms beside the convolutions):
+//   haspi_gate_kernel      silence gate on the REFERENCE envelope, 256 frames per block: flag + rank inside the block + block count
+//   haspi_gate_scan_kernel block offsets (ordered compaction), n_active, status
+//   haspi_cepstra_kernel   cepstral coefficients of the active frames (+ dither) at their compacted position, block partial sums
+//   haspi_cepmean_kernel   sequence means from the partials in block order; the consumers (modulation filters) subtract them on load
+#define CP_F 256
+__global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
+    __shared__ int scan[CP_F];
+    const int b = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * CP_F + tid;
     const int nsub = hp_nsub(ws, b);
+    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
+    int k = 0;
+    if (i < nsub) {                                        // 20 log10(mean_k 10^(x/20)) > 2.5
+        double s = 0.0;
+        for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
+        k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+    }
+    scan[tid] = k;
+    __syncthreads();
+    for (int o = 1; o < CP_F; o <<= 1) {
+        const int v = (tid >= o) ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    if (i < ws.nsub) ws.grank[(size_t)b * ws.nsub + i] = k ? scan[tid] - 1 : -1;
+    if (tid == CP_F - 1) ws.gcnt[(size_t)b * ws.ngb + blockIdx.x] = scan[CP_F - 1];
+}
+// grid B, block 64 (one lane works: at most a few dozen blocks)
+__global__ void haspi_gate_scan_kernel(HaspiWs ws) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int nb = (hp_nsub(ws, b) + CP_F - 1) / CP_F;
+    int* cnt = ws.gcnt + (size_t)b * ws.ngb;
+    int tot = 0;
+    for (int q = 0; q < nb; ++q) { const int c = cnt[q]; cnt[q] = tot; tot += c; }      // counts -> exclusive offsets
+    ws.info[2 * b] = tot;
+    ws.info[2 * b + 1] = (tot <= 1) ? 1 : 0;
+}
+// grid (blocks of CP_F frames, B, nsig), block CP_F
+__global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int sig0) {
+    __shared__ double cepm[HP_NCH][HP_NBASIS];
+    __shared__ double red[8];
+    const int b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x, i = blockIdx.x * CP_F + tid;
+    if (ws.info[2 * b + 1] || blockIdx.x * CP_F >= hp_nsub(ws, b)) return;
     if (tid < HP_NBASIS) {
         double nn = 0.0;
         for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
         nn = sqrt(nn);
         for (int k = 0; k < HP_NCH; ++k) cepm[k][tid] = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)) / nn;
     }
-    if (tid == 0) base = 0;
     __syncthreads();
-    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
-    const double* ylp = xlp + (size_t)ws.nsub * HP_NCH;
-    int* act = ws.act + (size_t)b * ws.nsub;
-    int na;
-    if (gate) {
-        // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
-        for (int i0 = 0; i0 < nsub; i0 += 256) {
-            const int i = i0 + tid;
-            int k = 0;
-            if (i < nsub) {
-                double s = 0.0;
-                for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
-                k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
-            }
-            scan[tid] = k;
-            __syncthreads();
-            for (int o = 1; o < 256; o <<= 1) {
-                const int v = (tid >= o) ? scan[tid - o] : 0;
-                __syncthreads();
-                scan[tid] += v;
-                __syncthreads();
-            }
-            if (k) act[base + scan[tid] - 1] = i;
-            __syncthreads();
-            if (tid == 255) base += scan[255];
-            __syncthreads();
-        }
-        na = base;
-        if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
-    } else {
-        na = ws.info[2 * b];
-    }
-    if (na <= 1) return;
-    // cepstra of the active frames (+ dither), then remove the mean of each sequence
-    for (int sig = sig0; sig < sig0 + nsig; ++sig) {
-        const double* lp = sig ? ylp : xlp;
-        const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
-        double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
-        double sums[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
-        for (int k = tid; k < na; k += 256) {
-            const int i = act[k];
-            double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
-            for (int c = 0; c < HP_NCH; ++c) {
-                double v = lp[(size_t)i * HP_NCH + c];
-                if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
+    const int rank = (i < ws.nsub) ? ws.grank[(size_t)b * ws.nsub + i] : -1;
+    const double* lp = ws.lp + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH;
+    const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
+    double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
+    double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+    if (rank >= 0) {
+        const int k = ws.gcnt[(size_t)b * ws.ngb + blockIdx.x] + rank;          // compacted position of this frame
+        for (int c = 0; c < HP_NCH; ++c) {
+            double v = lp[(size_t)i * HP_NCH + c];
+            if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
 #pragma unroll
-                for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
-            }
+            for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
+        }
 #pragma unroll
-            for (int q = 0; q < HP_NBASIS; ++q) { cep[(size_t)q * ws.nsub + k] = c6[q]; sums[q] += c6[q]; }
-        }
-        for (int q = 0; q < HP_NBASIS; ++q) {
-            const double mu = block_sum(sums[q], red) / (double)na;
-            for (int k = tid; k < na; k += 256) cep[(size_t)q * ws.nsub + k] -= mu;
-            __syncthreads();
-        }
+        for (int q = 0; q < HP_NBASIS; ++q) cep[(size_t)q * ws.nsub + k] = c6[q];
     }
+#pragma unroll
+    for (int q = 0; q < HP_NBASIS; ++q) {
+        const double t = block_sum(c6[q], red);
+        if (tid == 0) ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + blockIdx.x) * HP_NBASIS + q] = t;
+    }
+}
+// grid (B, nsig), block 64
+__global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
+    const int b = blockIdx.x, sig = sig0 + blockIdx.y, q = threadIdx.x;
+    if (q >= HP_NBASIS || ws.info[2 * b + 1]) return;
+    const int nb = (hp_nsub(ws, b) + CP_F - 1) / CP_F;
+    double t = 0.0;
+    for (int g = 0; g < nb; ++g) t += ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + g) * HP_NBASIS + q];
+    ws.cmean[((size_t)b * 2 + sig) * HP_NBASIS + q] = t / (double)ws.info[2 * b];
 }
 
 // ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
@@ -1050,6 +1061,7 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
     // np.hanning(nfir+1) / sum ; sum of a symmetric Hann window of M points = (M-1)/2
     const double* __restrict__ bk = ws.bkt + k * 616;    // uniform index in the tap loop -> scalar loads
     const double* vc = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + basis) * ws.nsub;
+    const double vmu = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + basis];          // the sequence's mean (ebm_CepCoef removes it)
     double* xf = ws.xf + (((size_t)b * (HP_NBASIS - 1) + (basis - 1)) * HP_NMOD + k) * ws.nsub;
     const double cf = c_modcf[k];
     const double SQ2 = 1.4142135623730951;
@@ -1060,7 +1072,7 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
         for (int e = tid; e < HP_TILE + nfir; e += 256) {
             const int j = t0 - nh + e;
             const int jc = min(max(j, 0), na - 1);
-            double v = vc[jc], c = 1.0, s = 0.0;
+            double v = vc[jc] - vmu, c = 1.0, s = 0.0;
             if (!(j >= 0 && j < na)) v = 0.0;
             if (k > 0) {
                 // sqrt(2) cos(pi n cf / fNyq), n = j + 1, fNyq = 1280
@@ -1153,6 +1165,7 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
     const double k2c = cos(theta * (double)nh), k2s = -sin(theta * (double)nh);  // e^{-j theta nh}: output phase = conj(E) K2
     const double scale = ((k > 0) ? 2.0 : 1.0) * (2.0 / (double)L);      // sqrt(2) of the demodulator and of the remodulator
     const double* v = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + basis) * ws.nsub;
+    const double vmu = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + basis];          // the sequence's mean (ebm_CepCoef removes it)
     double* xf = ws.xf + ((size_t)b * ws.nsub) * 64 + lane;
     // common output index tt = t0 - LMAX + step; this lane's newest input is tau = tt + nh
     constexpr int LMAX = HP_MAXFIR;
@@ -1171,8 +1184,8 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
 #pragma unroll
         for (int u = 0; u < MS_U; ++u) {
             const int tt = tb + u, tau = tt + nh, to = tau - L;
-            vnv[u] = v[min(max(tau, 0), na - 1)];
-            vov[u] = v[min(max(to, 0), na - 1)];
+            vnv[u] = v[min(max(tau, 0), na - 1)] - vmu;
+            vov[u] = v[min(max(to, 0), na - 1)] - vmu;
             if (SIG == 1) xvv[u] = xf[(size_t)min(max(tt, 0), na - 1) * 64];
         }
 #pragma unroll
@@ -1268,14 +1281,18 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bkt, double, 10 * 616);
     TAKE(shift, int, (size_t)B * HP_NCH);
     TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
-    TAKE(act, int, (size_t)B * nsub);
+    const int ngb = (nsub + 255) / 256;
+    TAKE(grank, int, (size_t)B * nsub);
+    TAKE(gcnt, int, (size_t)B * ngb);
+    TAKE(cpsum, double, (size_t)B * 2 * ngb * HP_NBASIS);
+    TAKE(cmean, double, (size_t)B * 2 * HP_NBASIS);
     TAKE(info, int, (size_t)B * 2);
     TAKE(cep, double, (size_t)B * 2 * HP_NBASIS * nsub);
     TAKE(cm, double, (size_t)B * HP_NBASIS * HP_NMOD);
     TAKE(xf, double, (size_t)B * 64 * nsub);
     TAKE(cpart, double, (size_t)B * MS_MAXC * 64 * 5);
 #undef TAKE
-    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; }
+    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; w->ngb = ngb; }
     return o;
 }
 
@@ -1360,13 +1377,17 @@ extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* 
     if (phase == 0 || phase == 3) {
         if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
         haspi_chain(x, y, B, L, fs_in, ws, 0, 1, s);
-        hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);
+        hipLaunchKernelGGL(haspi_gate_kernel, dim3(ws.ngb, B), dim3(CP_F), 0, s, ws);
+        hipLaunchKernelGGL(haspi_gate_scan_kernel, dim3(B), dim3(64), 0, s, ws);
+        hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 0);
+        hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 0);
         if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
         else hipLaunchKernelGGL(haspi_mod_slide_kernel<0>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
     }
     if (phase == 0 || phase == 4) {
         haspi_chain(x, y, B, L, fs_in, ws, 1, 1, s);
-        hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 0, 1, 1);
+        hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 1);
+        hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 1);
         if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
         else {
             hipLaunchKernelGGL(haspi_mod_slide_kernel<1>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);

@@ -14,6 +14,7 @@ on the f32 matrix cores (csrc/dense.hip), cLN scan, spectral-norm power iteratio
 gradient buffer (one bucket per model: what Adam and the RCCL all-reduce operate on).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -58,6 +59,15 @@ class cLN(nn.Module):
         self.bias0 = nn.Parameter(torch.zeros(1, dimension, 1), requires_grad=trainable)
 
 
+def _norm_dev(dev):
+    """torch.device('cuda') != torch.device('cuda:0'): an index-less device would make every cache below look stale (and re-home the
+    flat parameter buffer on every call).  Normalise to the indexed device."""
+    dev = torch.device(dev)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 class FlatParams:
     """All parameters of a module as views into ONE flat buffer (+ one flat gradient buffer)."""
 
@@ -70,6 +80,7 @@ class FlatParams:
         return [p for p in self.module.parameters()]
 
     def valid(self, device):
+        device = _norm_dev(device)
         if self.flat is None or self.flat.device != device:
             return False
         off = 0
@@ -80,6 +91,7 @@ class FlatParams:
         return True
 
     def ensure(self, device):
+        device = _norm_dev(device)
         if self.valid(device):
             return
         ps = self.params()
@@ -87,11 +99,20 @@ class FlatParams:
         flat = torch.empty(n, dtype=torch.float32, device=device)
         grad = torch.zeros(n, dtype=torch.float32, device=device)
         off = 0
+        cur = torch.cuda.current_stream(device) if device.type == 'cuda' else None
         for p in ps:
             k = p.numel()
             flat[off:off + k].copy_(p.data.reshape(-1).to(device))
             if p.grad is not None:
                 grad[off:off + k].copy_(p.grad.reshape(-1).to(device))
+            # The old storages lose their last reference below and go back to the allocator at once; it only knows the stream they were
+            # ALLOCATED on.  If this runs on another stream (D.prepare on a side stream, first step of a fresh trainer) the copies above
+            # may still be pending there when the main stream reuses the blocks: round 2 found D's initial weights silently corrupted
+            # whenever the side stream lagged.  record_stream makes the allocator wait for this stream too.
+            if cur is not None and p.data.is_cuda:
+                p.data.record_stream(cur)
+                if p.grad is not None and p.grad.is_cuda:
+                    p.grad.record_stream(cur)
             p.data = flat[off:off + k].view(p.shape)
             p.grad = grad[off:off + k].view(p.shape)
             off += k
@@ -106,6 +127,7 @@ class _Anchor:
         self.t = None
 
     def get(self, device):
+        device = _norm_dev(device)
         if self.t is None or self.t.device != device:
             self.t = torch.zeros(1, device=device, requires_grad=True)
         return self.t
@@ -224,6 +246,7 @@ class Generator_Conv1D_cLN(nn.Module):
         return self._flat
 
     def _weights(self, dev):
+        dev = _norm_dev(dev)
         if self._wf is None or self._wf[0][0].device != dev:
             wf, wb = [], []
             for (cin, cout, k) in _G_LAYERS:
@@ -269,7 +292,7 @@ class Generator_Conv1D_cLN(nn.Module):
         return wf, wb
 
     def _get_bufs(self, B, T, dev):
-        key = (B, T, str(dev))
+        key = (B, T, str(_norm_dev(dev)))
         if key not in self._bufs:
             self._bufs[key] = _GBuffers(B, T, dev)
         return key, self._bufs[key]
@@ -496,6 +519,7 @@ class _DiscriminatorBase(nn.Module):
         return list(self.layers) + [self.fc1, self.fc2, self.fc3]
 
     def _weights(self, dev):
+        dev = _norm_dev(dev)
         if self._w is None or self._w['sigma'].device != dev:
             w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': [], 'wff16': [], 'wbf16': []}
             cin = 4
@@ -511,7 +535,7 @@ class _DiscriminatorBase(nn.Module):
         return self._w
 
     def _get_bufs(self, B, T, dev):
-        key = (B, T, str(dev))
+        key = (B, T, str(_norm_dev(dev)))
         if key not in self._bufs:
             self._bufs[key] = _DBuffers(B, T, dev, self._cin)
         return key, self._bufs[key]

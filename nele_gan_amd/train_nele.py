@@ -50,7 +50,7 @@ def parse_metrics(target_metric):
 class GanTrainer:
     def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666):
         self.metrics = parse_metrics(target_metric)
-        self.device = torch.device(device)
+        self.device = M._norm_dev(device)            # indexed ('cuda' -> 'cuda:0'): torch.device('cuda') != torch.device('cuda:0')
         torch.manual_seed(seed)                      # same initial weights on every rank
         random.seed(seed)                            # train_nele.py:28
         self.G = M.Generator_Conv1D_cLN().to(self.device)
@@ -59,6 +59,10 @@ class GanTrainer:
         self.optimizer_g = Adam(self.G, lr=lr_g)     # train_nele.py:89-91
         self.optimizer_d = Adam(self.D, lr=lr_d)
         self.optimizer_dqua = Adam(self.D_Qua, lr=lr_d) if use_quality else None
+        # flat parameter / gradient buffers now, on the current stream (not lazily inside D.prepare on a side stream: see FlatParams.ensure)
+        for m in (self.G, self.D, self.D_Qua):
+            if m is not None:
+                m.flat_parameters(self.device)
         self.MSELoss = nn.MSELoss()
         self.pcm16 = pcm16
         self.step_g = 0

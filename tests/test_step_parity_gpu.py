@@ -64,6 +64,40 @@ def test_multistream_step_is_bit_identical_to_the_staged_sequence(precision):
     assert all(x == 0 for x in a.check_status().values())
 
 
+def test_delayed_side_streams_do_not_change_the_step():
+    """Every cross-stream hand-over of canonical_step is ordered by events only.  Holding a side stream back (a 25 ms spin kernel in front
+    of D.prepare / of the clean-feature branch) must not change anything; and the flat parameter buffers must stay where they are
+    (round 2: GanTrainer('cuda') handed an index-less device to D.prepare, torch.device('cuda') != torch.device('cuda:0') made every
+    cache look stale, and D's parameters were re-homed into a fresh flat buffer on the side stream twice per step)."""
+    from nele_gan_amd import audio_util as au
+    from nele_gan_amd import synth
+    c, v = synth.batch(3, 24000, start=40)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    ref = _trainer('siib&estoi', 'bf16')
+    r0 = ref.canonical_step(cw, nw)
+    torch.cuda.synchronize()
+    for which in ('prepare', 'features'):
+        tr = _trainer('siib&estoi', 'bf16')
+        orig_prepare, orig_stft = tr.D.prepare, au.stft_band
+        if which == 'prepare':
+            tr.D.prepare = lambda *a, **k: (torch.cuda._sleep(60_000_000), orig_prepare(*a, **k))[1]
+        else:
+            au.stft_band = lambda *a, **k: ((torch.cuda._sleep(60_000_000) if torch.cuda.current_stream() != torch.cuda.default_stream() else None),
+                                            orig_stft(*a, **k))[1]
+        try:
+            r1 = tr.canonical_step(cw, nw)
+            torch.cuda.synchronize()
+        finally:
+            au.stft_band = orig_stft
+        assert float(r1[0]) == float(r0[0]) and float(r1[1]) == float(r0[1]) and torch.equal(r1[2], r0[2]), which
+        tr.D.prepare = orig_prepare
+        p0 = (tr.D.flat_parameters().flat.data_ptr(), tr.G.flat_parameters().flat.data_ptr(), tr.D._w['sigma'].data_ptr())
+        tr.canonical_step(cw, nw)
+        torch.cuda.synchronize()
+        assert p0 == (tr.D.flat_parameters().flat.data_ptr(), tr.G.flat_parameters().flat.data_ptr(), tr.D._w['sigma'].data_ptr())
+        assert len(tr.D._bufs) == 1 and len(tr.G._bufs) == 1
+
+
 def test_prefetched_pipeline_is_bit_identical_to_plain_steps():
     """canonical_step(pre=..., next_batch=...) moves the input-only work of batch k + 1 (features, SIIB / HASPI clean halves) behind the
     targets of batch k.  Three steps over two alternating batches must reproduce the plain step-by-step sequence bit for bit."""
