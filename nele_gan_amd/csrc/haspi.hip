@@ -61,6 +61,7 @@ struct HaspiWs {
     double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
     double* lp;      // [B][2][nsub][32]
+    int* act;        // [B][nsub]     indices of the active sub-sampled frames (serial cepstrum kernel only)
     int* grank;      // [B][nsub]     rank of an active frame inside its block of CP_F frames, or -1 (silence gate)
     int* gcnt;       // [B][ngb]      active frames per block -> exclusive offsets
     double* cpsum;   // [B][2][ngb][6] block partial sums of the cepstral sequences
@@ -956,17 +957,28 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0
 //   haspi_gate_scan_kernel block offsets (ordered compaction), n_active, status
 //   haspi_cepstra_kernel   cepstral coefficients of the active frames (+ dither) at their compacted position, block partial sums
 //   haspi_cepmean_kernel   sequence means from the partials in block order; the consumers (modulation filters) subtract them on load
-#define CP_F 256
+#define CP_F 128
+// the block's [CP_F frames][32 channels] tile of the low-passed envelope, loaded with coalesced reads (a thread that walks its own
+// 256-byte row touches 64 cache lines per load instruction) and padded against bank conflicts
+__device__ __forceinline__ void hp_stage_lp(const double* __restrict__ lp, int i0, int nsub, double (*tile)[HP_NCH + 1]) {
+    const double* src = lp + (size_t)i0 * HP_NCH;
+    const int nel = min(CP_F, nsub - i0) * HP_NCH;
+    for (int e = threadIdx.x; e < CP_F * HP_NCH; e += CP_F) tile[e >> 5][e & 31] = (e < nel) ? src[e] : 0.0;
+}
 __global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
+    __shared__ double tile[CP_F][HP_NCH + 1];
     __shared__ int scan[CP_F];
-    const int b = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * CP_F + tid;
+    const int b = blockIdx.y, tid = threadIdx.x, i0 = blockIdx.x * CP_F, i = i0 + tid;
     const int nsub = hp_nsub(ws, b);
-    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
     int k = 0;
-    if (i < nsub) {                                        // 20 log10(mean_k 10^(x/20)) > 2.5
-        double s = 0.0;
-        for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
-        k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+    if (i0 < nsub) {
+        hp_stage_lp(ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH, i0, nsub, tile);
+        __syncthreads();
+        if (i < nsub) {                                    // 20 log10(mean_k 10^(x/20)) > 2.5
+            double s = 0.0;
+            for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, tile[tid][c] / 20.0);
+            k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+        }
     }
     scan[tid] = k;
     __syncthreads();
@@ -992,26 +1004,28 @@ __global__ void haspi_gate_scan_kernel(HaspiWs ws) {
 }
 // grid (blocks of CP_F frames, B, nsig), block CP_F
 __global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int sig0) {
+    __shared__ double tile[CP_F][HP_NCH + 1];
     __shared__ double cepm[HP_NCH][HP_NBASIS];
-    __shared__ double red[8];
-    const int b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x, i = blockIdx.x * CP_F + tid;
-    if (ws.info[2 * b + 1] || blockIdx.x * CP_F >= hp_nsub(ws, b)) return;
+    __shared__ double part[CP_F / 64][HP_NBASIS];
+    const int b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x, i0 = blockIdx.x * CP_F, i = i0 + tid;
+    const int nsub = hp_nsub(ws, b);
+    if (ws.info[2 * b + 1] || i0 >= nsub) return;
     if (tid < HP_NBASIS) {
         double nn = 0.0;
         for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
         nn = sqrt(nn);
         for (int k = 0; k < HP_NCH; ++k) cepm[k][tid] = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)) / nn;
     }
+    hp_stage_lp(ws.lp + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH, i0, nsub, tile);
     __syncthreads();
     const int rank = (i < ws.nsub) ? ws.grank[(size_t)b * ws.nsub + i] : -1;
-    const double* lp = ws.lp + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH;
     const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
     double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
     double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
     if (rank >= 0) {
         const int k = ws.gcnt[(size_t)b * ws.ngb + blockIdx.x] + rank;          // compacted position of this frame
         for (int c = 0; c < HP_NCH; ++c) {
-            double v = lp[(size_t)i * HP_NCH + c];
+            double v = tile[tid][c];
             if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
 #pragma unroll
             for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
@@ -1019,10 +1033,17 @@ __global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const d
 #pragma unroll
         for (int q = 0; q < HP_NBASIS; ++q) cep[(size_t)q * ws.nsub + k] = c6[q];
     }
+    // block partial sums of the six sequences (fixed order: wave butterflies, then the waves in order)
 #pragma unroll
     for (int q = 0; q < HP_NBASIS; ++q) {
-        const double t = block_sum(c6[q], red);
-        if (tid == 0) ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + blockIdx.x) * HP_NBASIS + q] = t;
+        const double t = wave_sum(c6[q]);
+        if ((tid & 63) == 0) part[tid >> 6][q] = t;
+    }
+    __syncthreads();
+    if (tid < HP_NBASIS) {
+        double t = 0.0;
+        for (int w = 0; w < CP_F / 64; ++w) t += part[w][tid];
+        ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + blockIdx.x) * HP_NBASIS + tid] = t;
     }
 }
 // grid (B, nsig), block 64
@@ -1033,6 +1054,86 @@ __global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
     double t = 0.0;
     for (int g = 0; g < nb; ++g) t += ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + g) * HP_NBASIS + q];
     ws.cmean[((size_t)b * 2 + sig) * HP_NBASIS + q] = t / (double)ws.info[2 * b];
+}
+
+// ---- h10, one block per utterance (round-2 start; kept behind NELE_HASPI_CEP_SERIAL=1): it takes 0.75 ms alone against 0.15 ms for the
+// parallel kernels above, and 4.8 ms inside a step - but see the note at its launch site.
+// gate != 0: silence gate on the REFERENCE envelope + ordered compaction of the active frames (needs x only);
+// then the cepstral sequences of signals sig0 .. sig0+nsig-1 over those frames.
+__global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int gate, int sig0,
+                                                        int nsig) {
+    __shared__ double cepm[HP_NCH][HP_NBASIS];
+    __shared__ int scan[256];
+    __shared__ int base;
+    __shared__ double red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nsub = hp_nsub(ws, b);
+    if (tid < HP_NBASIS) {
+        double nn = 0.0;
+        for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
+        nn = sqrt(nn);
+        for (int k = 0; k < HP_NCH; ++k) cepm[k][tid] = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)) / nn;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
+    const double* ylp = xlp + (size_t)ws.nsub * HP_NCH;
+    int* act = ws.act + (size_t)b * ws.nsub;
+    int na;
+    if (gate) {
+        // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
+        for (int i0 = 0; i0 < nsub; i0 += 256) {
+            const int i = i0 + tid;
+            int k = 0;
+            if (i < nsub) {
+                double s = 0.0;
+                for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
+                k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
+            }
+            scan[tid] = k;
+            __syncthreads();
+            for (int o = 1; o < 256; o <<= 1) {
+                const int v = (tid >= o) ? scan[tid - o] : 0;
+                __syncthreads();
+                scan[tid] += v;
+                __syncthreads();
+            }
+            if (k) act[base + scan[tid] - 1] = i;
+            __syncthreads();
+            if (tid == 255) base += scan[255];
+            __syncthreads();
+        }
+        na = base;
+        if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
+    } else {
+        na = ws.info[2 * b];
+    }
+    if (na <= 1) return;
+    // cepstra of the active frames (+ dither), then remove the mean of each sequence
+    for (int sig = sig0; sig < sig0 + nsig; ++sig) {
+        const double* lp = sig ? ylp : xlp;
+        const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
+        double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
+        double sums[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+        for (int k = tid; k < na; k += 256) {
+            const int i = act[k];
+            double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < HP_NCH; ++c) {
+                double v = lp[(size_t)i * HP_NCH + c];
+                if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
+#pragma unroll
+                for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
+            }
+#pragma unroll
+            for (int q = 0; q < HP_NBASIS; ++q) { cep[(size_t)q * ws.nsub + k] = c6[q]; sums[q] += c6[q]; }
+        }
+        for (int q = 0; q < HP_NBASIS; ++q) {
+            const double mu = block_sum(sums[q], red) / (double)na;
+            for (int k = tid; k < na; k += 256) cep[(size_t)q * ws.nsub + k] -= mu;
+            if (tid == 0) ws.cmean[((size_t)b * 2 + sig) * HP_NBASIS + q] = 0.0;    // already removed (the consumers subtract cmean)
+            __syncthreads();
+        }
+    }
 }
 
 // ---- h11: ebm_ModFilt + ebm_ModCorr for one (modulation band, basis, utterance). grid (10, 5, B), block 256
@@ -1281,7 +1382,8 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bkt, double, 10 * 616);
     TAKE(shift, int, (size_t)B * HP_NCH);
     TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
-    const int ngb = (nsub + 255) / 256;
+    const int ngb = (nsub + CP_F - 1) / CP_F;
+    TAKE(act, int, (size_t)B * nsub);
     TAKE(grank, int, (size_t)B * nsub);
     TAKE(gcnt, int, (size_t)B * ngb);
     TAKE(cpsum, double, (size_t)B * 2 * ngb * HP_NBASIS);
@@ -1371,23 +1473,38 @@ extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* 
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
     ws.lens = lengths;
     hipStream_t s = as_stream(stream);
+    // Cepstrum stage: one block per utterance (default) or the frame-parallel kernels (NELE_HASPI_CEP_SERIAL=0).  Alone on the GPU the
+    // parallel version takes 0.15 ms against 0.75 ms per call; inside the B = 256 step (A/B in one run, three repetitions each,
+    // tools/ab.sh) the step is 76.0 ms with the serial kernel and 78.2 ms with the parallel one: the GPU is saturated by the step's own
+    // streams, and a side-stream kernel that bursts over every CU (87 M float64 pow() in the silence gate) takes more from the main
+    // chain than its own chain gains.  Splitting HASPI into row groups (a narrower footprint throughout) did not help (78-79 ms).
+    static int cep_serial = -1;
+    if (cep_serial < 0) { const char* e_ = getenv("NELE_HASPI_CEP_SERIAL"); cep_serial = !(e_ && e_[0] == '0'); }
     static int mod_direct = -1;                            // NELE_HASPI_MOD_DIRECT=1: direct-form modulation FIR (A/B diagnostic)
     if (mod_direct < 0) { const char* e_ = getenv("NELE_HASPI_MOD_DIRECT"); mod_direct = (e_ && e_[0] == '1'); }
     NELE_CHECK_ARG((ws.nsub + MS_TC - 1) / MS_TC <= MS_MAXC, "nele_metric_haspi: signal too long (%d sub-sampled frames)", ws.nsub);
     if (phase == 0 || phase == 3) {
         if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
         haspi_chain(x, y, B, L, fs_in, ws, 0, 1, s);
-        hipLaunchKernelGGL(haspi_gate_kernel, dim3(ws.ngb, B), dim3(CP_F), 0, s, ws);
-        hipLaunchKernelGGL(haspi_gate_scan_kernel, dim3(B), dim3(64), 0, s, ws);
-        hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 0);
-        hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 0);
+        if (cep_serial) {
+            hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);
+        } else {
+            hipLaunchKernelGGL(haspi_gate_kernel, dim3(ws.ngb, B), dim3(CP_F), 0, s, ws);
+            hipLaunchKernelGGL(haspi_gate_scan_kernel, dim3(B), dim3(64), 0, s, ws);
+            hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 0);
+            hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 0);
+        }
         if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
         else hipLaunchKernelGGL(haspi_mod_slide_kernel<0>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
     }
     if (phase == 0 || phase == 4) {
         haspi_chain(x, y, B, L, fs_in, ws, 1, 1, s);
-        hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 1);
-        hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 1);
+        if (cep_serial) {
+            hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 0, 1, 1);
+        } else {
+            hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 1);
+            hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 1);
+        }
         if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
         else {
             hipLaunchKernelGGL(haspi_mod_slide_kernel<1>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);

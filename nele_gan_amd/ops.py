@@ -74,7 +74,9 @@ class Geom:
 
 def side_stream(device):
     """A new side stream - or, with NELE_SERIAL=1 (diagnostic: every kernel then runs alone and a rocprofv3 kernel trace shows
-    isolated durations), the current stream itself, which serialises the whole step."""
+    isolated durations), the current stream itself, which serialises the whole step.
+    (CU-masked streams - hipExtStreamCreateWithCUMask, to keep the metric streams off part of the GPU - were tried in rounds 1 and 2: a
+    masked queue's kernels stop overlapping with the other queues altogether: 96-128 ms per B = 256 step against 78.)"""
     if os.environ.get('NELE_SERIAL', '0') == '1':
         return torch.cuda.current_stream(device)
     return torch.cuda.Stream(device=device)
