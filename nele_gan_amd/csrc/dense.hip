@@ -1758,6 +1758,11 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
 static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("NELE_CONV_TALL"); tall = (e && e[0] == '1'); }
+    static int force = -1;                                     // NELE_CONV_TH=4|8: force one tile height where it fits (A/B)
+    if (force < 0) { const char* e = getenv("NELE_CONV_TH"); force = e ? atoi(e) : 0; }
+    if (force == 4 || force == 8 || force == 10 || force == 11 || force == 13) {
+        if ((force == 4 || g.Hout >= 8) && tile16_lds(g, N, KH, KW, force)) return force;
+    }
     if (!tall) {
         if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
         if (tile16_lds(g, N, KH, KW, 4)) return 4;
