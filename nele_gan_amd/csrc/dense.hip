@@ -1749,7 +1749,7 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
     }
     return 0;
 }
-// Tile height.  Default: 8 rows where the halo fits, else 4 (round 1).  NELE_CONV_TALL=1 picks among {13, 11, 10, 8, 4} the candidate that
+// Tile height.  Default: see below.  NELE_CONV_TH=4|8|10|11|13 forces one height where it fits; NELE_CONV_TALL=1 picks among {13, 11, 10, 8, 4} the candidate that
 // wastes the fewest output rows (D.conv5, Hout = 44: 11; D.conv4, 52: 13; the 58-row gradients: 10) - a taller tile also needs fewer LDS
 // reads per MFMA (TH + TN fragment reads per TH * TN MFMAs).  Measured at B = 256 (A/B inside one run, tools/ab.sh): D.conv5 forward alone
 // 1.70 -> 1.62 ms (0.305 -> 0.32 of the bf16 peak), but the whole step 75.6 -> 76.9 ms: the taller tile's 160 KB of LDS leaves no room for
@@ -1764,6 +1764,11 @@ static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
         if ((force == 4 || g.Hout >= 8) && tile16_lds(g, N, KH, KW, force)) return force;
     }
     if (!tall) {
+        // 64 output channels (D.conv5 forward, the 64-wide gradients): 8-row tiles; fewer channels: 4-row tiles.  Measured inside the
+        // B = 256 step (tools/ab.sh, three alternating repetitions): all 8-row 75.5 ms, all 4-row 73.9 ms (but D.conv5 forward alone
+        // 1.96 instead of 1.70 ms), this mix 73.9 ms with D.conv5 at 1.74 ms: the narrow layers (TN <= 3) are bound by their LDS reads
+        // either way, and the smaller halo leaves room for the workgroups of the other streams.
+        if (N < 64 && tile16_lds(g, N, KH, KW, 4)) return 4;
         if (g.Hout >= 8 && tile16_lds(g, N, KH, KW, 8)) return 8;
         if (tile16_lds(g, N, KH, KW, 4)) return 4;
         return 0;
