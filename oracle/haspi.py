@@ -189,6 +189,85 @@ def resample_24k(x, fsampx):
     return (xRMS / yRMS) * y
 
 
+def gammatone_bm(x, BW, coscf, sincf, cf):
+    """pyhaspi2.py:863-915 (one signal): -> (envelope, basilar-membrane motion)."""
+    a, a1, a2, a3, a4, a5, gain = gammatone_coeffs(BW, cf)
+    b = [1, a1, a5]
+    aa = [1, -a1, -a2, -a3, -a4]
+    ureal = lfilter(b, aa, x * coscf)
+    uimag = lfilter(b, aa, x * sincf)
+    return gain * np.sqrt(ureal * ureal + uimag * uimag), gain * (ureal * coscf + uimag * sincf)
+
+
+def compress_gain(control, attnOHC, thrLow, CR, Level1=LEVEL1):
+    """pyhaspi2.py:982-995: the low-passed compression gain both the envelope and the BM motion are multiplied by."""
+    logenv = np.clip(control, a_min=1.0e-30, a_max=None)
+    logenv = Level1 + 20 * np.log10(logenv)
+    logenv = np.clip(logenv, a_min=thrLow, a_max=100.0)
+    gain = -attnOHC - (logenv - thrLow) * (1 - (1 / CR))
+    gain = np.power(10, (gain / 20))
+    return lfilter([0.095107983402496, 0.095107983402496], [1.0, -0.809784033195007], gain)
+
+
+def ave_sl(env, control, attnOHC, thrLow, CR, attnIHC, Level1=LEVEL1):
+    """pyhaspi2.py:1135-1152: average band levels (RMS of the signal / control envelopes, [32]) -> dB SL."""
+    small = 1.0e-30
+    logenv = Level1 + 20 * np.log10(np.clip(control, a_min=small, a_max=None))
+    logenv = np.clip(logenv, a_min=thrLow, a_max=100.0)
+    gain = -attnOHC - (logenv - thrLow) * (1 - (1 / CR))
+    logenv = Level1 + 20 * np.log10(np.clip(env, a_min=small, a_max=None))
+    logenv = np.clip(logenv, a_min=0, a_max=None)
+    return np.clip(logenv + gain - attnIHC, a_min=0.0, a_max=None)
+
+
+def ear_model_bm(x, fx, y, fy, noise_x=None, noise_y=None):
+    """pyhaspi2.py:1155-1248 for HL = 0 (itype 0 and 2 coincide then) with the basilar-membrane outputs:
+    -> (xdB, xBM, ydB, yBM [32, nsamp], xSL, ySL [32], parts).  noise_* [32, nsamp]: the standard-normal draws of eb_BMaddnoise
+    (pyhaspi2.py:1091-1095; the reference draws channel by channel, x before y), None = no noise."""
+    small = 1.0e-30
+    HL = np.zeros(6)
+    cfreq = center_freq()
+    attnOHC, BWmin, lowknee, CR, attnIHC = loss_parameters(HL, cfreq)
+    _, BW1, _, _, _ = loss_parameters(100 * np.ones(6), cfreq)
+    x24 = resample_24k(x, fx)
+    y24 = resample_24k(y, fy)
+    nsamp = len(x24)
+    mid = (middle_ear(x24), middle_ear(y24))
+    dB = np.zeros((2, NCHAN, nsamp))
+    BM = np.zeros((2, NCHAN, nsamp))
+    ave = np.zeros((2, NCHAN))
+    cave = np.zeros((2, NCHAN))
+    BW = np.zeros((2, NCHAN))
+    gn = 10 ** ((-10.0 - LEVEL1) / 20.0)                    # IHCthr = -10 (pyhaspi2.py:1229)
+    noise = (noise_x, noise_y)
+    for n in range(NCHAN):
+        coscf, sincf = cos_sin_cf(nsamp, FSAMP, cfreq[n])
+        control = [gammatone_env(m, BW1[n], coscf, sincf, cfreq[n]) for m in mid]
+        for s in range(2):
+            BW[s, n] = bw_adjust(control[s], BWmin[n], BW1[n])
+            env, bm = gammatone_bm(mid[s], BW[s, n], coscf, sincf, cfreq[n])
+            ave[s, n] = np.sqrt(np.mean(env ** 2))
+            cave[s, n] = np.sqrt(np.mean(control[s] ** 2))
+            g = compress_gain(control[s], attnOHC[n], lowknee[n], CR[n])
+            c, b = g * env, g * bm
+            sl = env_sl2(c, attnIHC[n])
+            b = ((sl + small) / (c + small)) * b            # eb_EnvSL2: the gain that took the envelope to dB SL, on the BM motion
+            out = ihc_adapt(sl)
+            b = ((out + small) / (sl + small)) * b          # eb_IHCadapt: the adaptation gain on the BM motion
+            if noise[s] is not None:
+                b = b + gn * noise[s][n]
+            dB[s, n], BM[s, n] = out, b
+    shifts = group_delay_shifts(BW[0], cfreq)
+    for arr in (dB[0], dB[1], BM[0], BM[1]):                # all four use BWx (pyhaspi2.py:1239-1242)
+        for n in range(NCHAN):
+            sft = int(shifts[n])
+            if sft > 0:
+                arr[n] = np.concatenate((np.zeros(sft), arr[n, :nsamp - sft]))
+    xSL = ave_sl(ave[0], cave[0], attnOHC, lowknee, CR, attnIHC)
+    ySL = ave_sl(ave[1], cave[1], attnOHC, lowknee, CR, attnIHC)
+    return dB[0], BM[0], dB[1], BM[1], xSL, ySL, dict(cfreq=cfreq, BW1=BW1, BWx=BW[0], BWy=BW[1], shifts=shifts)
+
+
 def ear_model(x, fx, y, fy):
     """pyhaspi2.py:1155-1248 for HL = 0, itype = 0: -> (xdB, ydB [32, nsamp], parts)."""
     HL = np.zeros(6)
@@ -365,3 +444,234 @@ def haspi_wrapper(x, y, fs=16000, norm=True, dither_x=None, dither_y=None):
     from .intel import mapping_HASPI_harvard
     s, _ = haspi_v2(x, fs, y, fs, dither_x=dither_x, dither_y=dither_y)
     return float(mapping_HASPI_harvard(s)) if norm else s
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# HASPI (version 1) and HASQI v2: the remaining entry points of pyhaspi2.py.  Same ear model, plus the basilar-
+# membrane outputs; 16 ms raised-cosine segments at 50 % overlap (125 Hz) instead of the 320 Hz envelope filter.
+def _seg_window(segsize, fsamp=FSAMP):
+    nwin = round(segsize * (0.001 * fsamp))
+    if nwin % 2:
+        nwin += 1
+    return nwin, np.hanning(nwin)
+
+
+def n_segments(npts, nwin):
+    return int(1 + np.floor(npts / nwin) + np.floor((npts - nwin / 2) / nwin))
+
+
+def env_smooth(env, segsize=16, fsamp=FSAMP):
+    """pyhaspi2.py:674-703: [32, npts] -> [32, nseg]; half windows at both ends."""
+    nwin, window = _seg_window(segsize, fsamp)
+    nhalf = nwin // 2
+    npts = env.shape[1]
+    nseg = n_segments(npts, nwin)
+    out = np.zeros((env.shape[0], nseg))
+    out[:, 0] = env[:, :nhalf] @ window[nhalf:] / np.sum(window[nhalf:])
+    for n in range(1, nseg - 1):
+        out[:, n] = env[:, n * nhalf:n * nhalf + nwin] @ window / np.sum(window)
+    st = (nseg - 1) * nhalf
+    out[:, nseg - 1] = env[:, st:st + nhalf] @ window[:nhalf] / np.sum(window[nhalf:])
+    return out
+
+
+def _loud_index(xdB_like, thr):
+    """Segments whose band-averaged linear level, back in dB, exceeds thr (pyhaspi2.py:717-721, :422-427, :172-176)."""
+    xsum = 20 * np.log10(np.sum(np.power(10, xdB_like / 20), axis=0) / xdB_like.shape[0])
+    return xsum, np.where(xsum > thr)[0]
+
+
+def melcor(x, y, thr=2.5):
+    """pyhaspi2.py:706-751 with addnoise = 0: -> (mean of |corr| of cepstral coefficients 2-6, all six)."""
+    nbands, nbasis = x.shape[0], 6
+    k = np.arange(nbands)
+    cepm = np.stack([np.cos(nb * np.pi * k / (nbands - 1)) for nb in range(nbasis)], axis=1)
+    cepm = cepm / np.linalg.norm(cepm, axis=0, keepdims=True)
+    _, index = _loud_index(x, thr)
+    if len(index) <= 1:
+        raise Exception('Function eb_melcor: Signal below threshold, outputs set to 0.')
+    xcep = cepm.T @ x[:, index]
+    ycep = cepm.T @ y[:, index]
+    xcep = xcep - xcep.mean(axis=1, keepdims=True)
+    ycep = ycep - ycep.mean(axis=1, keepdims=True)
+    xs, ys = np.sum(xcep ** 2, axis=1), np.sum(ycep ** 2, axis=1)
+    xy = np.zeros(nbasis)
+    ok = (xs >= 1.0e-30) & (ys >= 1.0e-30)
+    xy[ok] = np.abs(np.sum(xcep * ycep, axis=1)[ok] / np.sqrt(xs[ok] * ys[ok]))
+    return float(np.sum(xy[1:]) / (nbasis - 1)), xy
+
+
+def window_corr(window, maxlag):
+    """1 / xcorr(window, window, maxlag): the normalisation tables pyhaspi2.py:563 / :570 keep as literals (MATLAB output)."""
+    n = len(window)
+    full = np.correlate(window, window, 'full')
+    return 1.0 / full[n - 1 - maxlag:n + maxlag]
+
+
+def bm_covary(xBM, yBM, segsize=16, fsamp=FSAMP):
+    """pyhaspi2.py:550-657: per band and segment, max over lags |l| <= 1 ms of the normalised cross-covariance of the windowed,
+    mean-removed BM motion, and the mean-square levels.  -> sigcov, sigMSx, sigMSy [32, nseg]."""
+    small = 1.0e-30
+    maxlag = round(1.0 * (0.001 * fsamp))
+    nwin, window = _seg_window(segsize, fsamp)
+    nhalf = nwin // 2
+    wincorr = window_corr(window, maxlag)
+    halfcorr = window_corr(window[nhalf:], maxlag)
+    winsum2 = 1.0 / np.sum(window ** 2)
+    halfsum2 = 1.0 / np.sum(window[nhalf:] ** 2)
+    nchan, npts = xBM.shape
+    nseg = n_segments(npts, nwin)
+    sigcov = np.zeros((nchan, nseg))
+    sigMSx = np.zeros((nchan, nseg))
+    sigMSy = np.zeros((nchan, nseg))
+    lags = np.arange(-maxlag, maxlag + 1)
+
+    def one(segx, segy, corr, norm2):
+        segx = segx - segx.mean(axis=1, keepdims=True)
+        segy = segy - segy.mean(axis=1, keepdims=True)
+        MSx = np.sum(segx ** 2, axis=1) * norm2
+        MSy = np.sum(segy ** 2, axis=1) * norm2
+        N = segx.shape[1]
+        c = np.zeros((nchan, len(lags)))
+        for i, l in enumerate(lags):                        # np.correlate(segx, segy, 'full')[N - 1 + l] = sum_n segx[n + l] segy[n]
+            if l >= 0:
+                c[:, i] = np.sum(segx[:, l:] * segy[:, :N - l], axis=1)
+            else:
+                c[:, i] = np.sum(segx[:, :N + l] * segy[:, -l:], axis=1)
+        Mxy = np.max(np.abs(c * corr), axis=1)
+        ok = (MSx > small) & (MSy > small)
+        cov = np.zeros(nchan)
+        cov[ok] = Mxy[ok] / np.sqrt(MSx[ok] * MSy[ok])
+        return cov, MSx, MSy
+
+    sigcov[:, 0], sigMSx[:, 0], sigMSy[:, 0] = one(xBM[:, :nhalf] * window[nhalf:], yBM[:, :nhalf] * window[nhalf:], halfcorr, halfsum2)
+    for n in range(1, nseg - 1):
+        st = n * nhalf
+        sigcov[:, n], sigMSx[:, n], sigMSy[:, n] = one(xBM[:, st:st + nwin] * window, yBM[:, st:st + nwin] * window, wincorr, winsum2)
+    st = (nseg - 1) * nhalf
+    sigcov[:, -1], sigMSx[:, -1], sigMSy[:, -1] = one(xBM[:, st:st + nhalf] * window[:nhalf], yBM[:, st:st + nhalf] * window[:nhalf], halfcorr, halfsum2)
+    return np.clip(sigcov, 0, 1), 2.0 * sigMSx, 2.0 * sigMSy
+
+
+SII_CF = [150, 250, 350, 450, 570, 700, 840, 1000, 1170, 1370, 1600, 1850, 2150, 2500, 2900, 3400, 4000, 4800, 5800, 7000, 8500]
+SII_WGT = [.0103, .0261, .0419, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0577, .0460,
+           .0343, .0226, .0110]
+
+
+def three_level_covary(sigcov, sigMSx, thr=2.5):
+    """pyhaspi2.py:416-547: the above-threshold segments are split into thirds of the cumulative 0.5 dB histogram of their
+    loudness; per third, the band-average of the per-band mean covariance.  -> cov3, covSII [low, mid, high]."""
+    from scipy.interpolate import interp1d
+    nbands = sigcov.shape[0]
+    sigRMS = np.sqrt(sigMSx)
+    xsum, index = _loud_index(sigRMS, thr)
+    if len(index) <= 1:
+        raise Exception('Function eb_3LevelCovary: Signal below threshold, outputs set to 0.')
+    cfreq = center_freq(nbands)
+    wfreq = interp1d(np.array([0] + SII_CF + [FSAMP]), np.array([0] + SII_WGT + [0]), kind='cubic')(cfreq)
+    wfreq[0] = wfreq[1] = 0.0
+    wfreq = wfreq / np.sum(wfreq)
+    sigcov, sigRMS, xsum = sigcov[:, index], sigRMS[:, index], xsum[index]
+    bins = np.arange(np.min(xsum), np.max(xsum) + 0.5, 0.5)
+    # np.histogram over the mid-points between bin centres = nearest-centre assignment, open at both ends
+    edges = np.concatenate(([-1e8], (bins + np.concatenate((bins[1:], [1e8]))) / 2))
+    xhist, _ = np.histogram(xsum, edges)
+    xcum = np.cumsum(xhist.astype(np.float64))
+    xcum = xcum / xcum[-1]
+    edge = np.zeros(2)
+    for n in range(len(bins)):
+        if xcum[n] < 0.333:
+            edge[0] = bins[n]
+        if xcum[n] < 0.667:
+            edge[1] = bins[n]
+    groups = (np.where(xsum < edge[0])[0], np.where((xsum >= edge[0]) & (xsum < edge[1]))[0], np.where(xsum >= edge[1])[0])
+    weight = (sigRMS > thr).astype(np.float64)
+    sigcov = weight * sigcov
+    cov3, covSII = np.zeros(3), np.zeros(3)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for g, idx in enumerate(groups):
+            ssum, wsum = sigcov[:, idx].sum(axis=1), weight[:, idx].sum(axis=1)
+            ok = wsum != 0
+            ave = np.zeros(nbands)
+            ave[ok] = ssum[ok] / wsum[ok]
+            cov3[g] = np.float64(np.sum(ave)) / np.float64(np.count_nonzero(ok))
+            covSII[g] = np.float64(np.sum(ave * wfreq * ok)) / np.float64(np.sum(wfreq[ok]))
+    return cov3, covSII
+
+
+def ave_covary2(sigcov, sigMSx, thr=2.5):
+    """pyhaspi2.py:160-220: average covariance over the above-threshold time-frequency cells, plain and with six low-pass
+    band weightings ("synchrony" up to 1.5 ... 4 kHz)."""
+    nchan = sigcov.shape[0]
+    cfreq = center_freq(nchan)
+    p = np.array([1, 3, 5, 5, 5, 5])
+    fcut = 1000 * np.array([1.5, 2.0, 2.5, 3.0, 3.5, 4.0])
+    fsync = np.stack([np.sqrt(fcut[n] ** (2 * p[n]) / (fcut[n] ** (2 * p[n]) + cfreq ** (2 * p[n]))) for n in range(6)])
+    sigRMS = np.sqrt(sigMSx)
+    _, index = _loud_index(sigRMS, thr)
+    if len(index) <= 1:
+        return 0, 0
+    sigcov, sigRMS = sigcov[:, index], sigRMS[:, index]
+    weight = (sigRMS > thr).astype(np.float64)
+    wsum = np.sum(weight)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        syncov = np.array([np.sum(fsync[n][:, None] * weight * sigcov) / np.sum(fsync[n][:, None] * weight) for n in range(6)])
+    return (0 if wsum < 1 else np.sum(weight * sigcov) / wsum), syncov
+
+
+def spect_diff(xSL, ySL):
+    """pyhaspi2.py:222-251: differences of the normalised long-term spectra and of their slopes: (sum |d|, nbands std d, max |d|)."""
+    nbands = len(xSL)
+    x = 10 ** (xSL / 20)
+    y = 10 ** (ySL / 20)
+    x = x / np.sum(x)
+    y = y / np.sum(y)
+
+    def three(d):
+        return np.array([np.sum(np.abs(d)), nbands * np.std(d), np.max(np.abs(d))])
+    return three(x - y), three((x - y) / (x + y)), three((x[1:] - x[:-1]) - (y[1:] - y[:-1]))
+
+
+def _normalised_pair(x, y):
+    L = min(len(x), len(y))
+    x, y = x[:L], y[:L]
+    return x / np.sqrt(np.sum(x ** 2) / L), y / np.sqrt(np.sum(y ** 2) / L)
+
+
+def haspi_v1(x, fx, y, fy, alpha=-1.0, noise_x=None, noise_y=None, return_parts=False):
+    """pyhaspi2.py:109-157 (`haspi`): logistic of cepstral correlation + high-level BM covariance.  -> (Intel, [CepCorr, cov3])."""
+    x, y = _normalised_pair(x, y)
+    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y)
+    xdB, ydB = env_smooth(xenv), env_smooth(yenv)
+    CepCorr, xy = melcor(xdB, ydB)
+    sigcov, sigMSx, sigMSy = bm_covary(xBM, yBM)
+    cov3, covSII = three_level_covary(sigcov, sigMSx)
+    arg = -9.047 + 14.816 * CepCorr + np.sum(np.array([0, 0, 4.616]) * cov3)
+    intel = 1.0 / (1.0 + np.exp(alpha * arg))
+    raw = np.concatenate((np.array([CepCorr]), cov3))
+    if return_parts:
+        parts.update(xdB=xdB, ydB=ydB, xy=xy, sigcov=sigcov, sigMSx=sigMSx, sigMSy=sigMSy, covSII=covSII, xSL=xSL, ySL=ySL)
+        return float(intel), raw, parts
+    return float(intel), raw
+
+
+def hasqi_v2(x, fx, y, fy, noise_x=None, noise_y=None, return_parts=False):
+    """pyhaspi2.py:32-74: -> (Combined, Nonlin, Linear, [CepCorr, BMsync5, Dloud, Dslope])."""
+    x, y = _normalised_pair(x, y)
+    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y)
+    xdB, ydB = env_smooth(xenv), env_smooth(yenv)
+    CepCorr, xy = melcor(xdB, ydB)
+    dloud, dnorm, dslope = spect_diff(xSL, ySL)
+    sigcov, sigMSx, sigMSy = bm_covary(xBM, yBM)
+    avecov, syncov = ave_covary2(sigcov, sigMSx)
+    BMsync5 = syncov[4]
+    Dloud = float(np.clip(1.0 - dloud[1] / 2.5, 0, 1))
+    Dslope = float(np.clip(1.0 - dslope[1], 0, 1))
+    Nonlin = (CepCorr ** 2) * BMsync5
+    Linear = 0.579 * Dloud + 0.421 * Dslope
+    raw = [CepCorr, BMsync5, Dloud, Dslope]
+    if return_parts:
+        parts.update(xdB=xdB, ydB=ydB, xy=xy, sigcov=sigcov, sigMSx=sigMSx, avecov=avecov, syncov=syncov, dloud=dloud, dnorm=dnorm,
+                     dslope=dslope, xSL=xSL, ySL=ySL)
+        return Nonlin * Linear, Nonlin, Linear, raw, parts
+    return Nonlin * Linear, Nonlin, Linear, raw

@@ -282,8 +282,9 @@ def main():
     sys.path.insert(0, a.ref)
     sys.path.insert(0, os.path.join(a.ref, 'pyHASPI'))
     try:
-        from make_golden_haspi import gen_haspi
+        from make_golden_haspi import gen_haspi, gen_haspi_quality
         GENS['haspi'] = gen_haspi
+        GENS['haspi_quality'] = gen_haspi_quality
     except ImportError:
         pass
     for name, fn in GENS.items():

@@ -92,3 +92,68 @@ def gen_haspi(ref):
     print('haspi.npz written: Intel %.6f (oracle %.6f, rel err %.2e), n_sub %d, n_active %d, shifts max %d' %
           (intel, val, err, out['n_sub'], rec['xcep'].shape[0], rec['shifts'].max()))
     assert err < 1e-9, err
+
+
+def golden_bm_noise(seed, n_samples):
+    """The 64 draws of eb_BMaddnoise (pyhaspi2.py:1091-1095) in the reference's order: per channel, x then y."""
+    rs = np.random.RandomState(seed)
+    nx = np.empty((32, n_samples))
+    ny = np.empty((32, n_samples))
+    for n in range(32):
+        nx[n] = rs.randn(n_samples)
+        ny[n] = rs.randn(n_samples)
+    return nx, ny
+
+
+def gen_haspi_quality(ref):
+    """HASPI version 1 (`haspi`) and HASQI v2 of the reference on the same seeded pair: final values and stage outputs."""
+    import pyhaspi2 as P
+    from nele_gan_amd import synth
+    n = 30000
+    x = synth.clean_utterance(77, n).astype(np.float32)
+    v = synth.noise_utterance(77, n, x)
+    y = (x + np.float32(0.3) * v).astype(np.float32)
+    rec = {}
+    names = ('eb_EnvSmooth', 'eb_melcor', 'eb_BMcovary', 'eb_3LevelCovary', 'eb_AveCovary2', 'eb_SpectDiff', 'eb_EarModel')
+    orig = {k: getattr(P, k) for k in names}
+
+    def tap(name):
+        def f(*a, **k):
+            r = orig[name](*a, **k)
+            rec.setdefault(name, []).append(r)
+            return r
+        return f
+    for k in names:
+        setattr(P, k, tap(k))
+    try:
+        np.random.seed(9001)
+        intel, raw1 = P.haspi(x, 24000, y, 24000)
+        np.random.seed(9001)
+        comb, nonlin, lin, raw2 = P.hasqi_v2(x, 24000, y, 24000)
+    finally:
+        for k, f in orig.items():
+            setattr(P, k, f)
+    xdB, ydB = rec['eb_EnvSmooth'][0], rec['eb_EnvSmooth'][1]
+    sigcov, sigMSx, sigMSy = rec['eb_BMcovary'][0]
+    cov3, covSII = rec['eb_3LevelCovary'][0]
+    avecov, syncov = rec['eb_AveCovary2'][0]
+    dloud, dnorm, dslope = rec['eb_SpectDiff'][0]
+    ear = rec['eb_EarModel'][0]
+    out = dict(x=x, y=y, seed=np.int64(9001), intel=np.float64(intel), raw_v1=np.asarray(raw1, dtype=np.float64),
+               hasqi=np.array([comb, nonlin, lin], dtype=np.float64), raw_q=np.asarray(raw2, dtype=np.float64),
+               xdB_s=xdB[:, ::25].copy(), ydB_s=ydB[:, ::25].copy(), xdB_colsum=xdB.sum(axis=0), ydB_colsum=ydB.sum(axis=0),
+               xy=rec['eb_melcor'][0][1], sigcov_s=sigcov[:, ::25].copy(), sigcov_colsum=sigcov.sum(axis=0), sigMSx_colsum=sigMSx.sum(axis=0),
+               sigMSy_colsum=sigMSy.sum(axis=0), cov3=cov3, covSII=covSII, avecov=np.float64(avecov), syncov=np.asarray(syncov),
+               dloud=dloud, dnorm=dnorm, dslope=dslope, xSL=ear[4], ySL=ear[5], nseg=np.int64(xdB.shape[1]))
+    np.savez_compressed(os.path.join(HERE, 'haspi_quality.npz'), **out)
+    from oracle import haspi as H
+    nx, ny = golden_bm_noise(9001, len(x))
+    v1, r1, parts = H.haspi_v1(x, 24000, y, 24000, noise_x=nx, noise_y=ny, return_parts=True)
+    q = H.hasqi_v2(x, 24000, y, 24000, noise_x=nx, noise_y=ny)
+    e1 = abs(v1 - intel) / abs(intel)
+    e2 = abs(q[0] - comb) / abs(comb)
+    print('haspi_quality.npz written: HASPI v1 %.6f (oracle rel err %.2e), HASQI %.6f / %.6f / %.6f (oracle rel err %.2e), nseg %d' %
+          (intel, e1, comb, nonlin, lin, e2, xdB.shape[1]))
+    print('  raw v1', raw1, 'oracle', r1)
+    print('  raw q ', raw2, 'oracle', q[3])
+    assert e1 < 1e-9 and e2 < 1e-9, (e1, e2)

@@ -59,3 +59,54 @@ def test_below_threshold_raises_like_reference():
     z = np.zeros((100, 32))
     with pytest.raises(Exception):
         H.cep_coef(z, z)
+
+
+# ------------------------------------------------------------------ HASPI version 1 and HASQI v2
+Q = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'haspi_quality.npz'))
+
+
+def test_window_normalisation_tables_equal_the_reference_literals():
+    """pyhaspi2.py:563 / :570 keep 1/xcorr(window, window, 24) as MATLAB literals; the oracle (and the kernel) compute them."""
+    w = np.hanning(384)
+    wc, hc = H.window_corr(w, 24), H.window_corr(w[192:], 24)
+    assert wc[24] == pytest.approx(0.00696257615317668, rel=1e-13) and wc[0] == pytest.approx(0.00714486118736300, rel=1e-13)
+    assert hc[24] == pytest.approx(0.0139251523063533, rel=1e-13) and hc[0] == pytest.approx(0.0171564012932667, rel=1e-13)
+    assert np.allclose(wc, wc[::-1], rtol=1e-14) and np.allclose(hc, hc[::-1], rtol=1e-14)
+
+
+def test_haspi_v1_and_hasqi_v2_match_the_reference_with_captured_noise():
+    from make_golden_haspi import golden_bm_noise
+    x, y = Q['x'], Q['y']
+    nx, ny = golden_bm_noise(int(Q['seed']), len(x))
+    intel, raw, p = H.haspi_v1(x, 24000, y, 24000, noise_x=nx, noise_y=ny, return_parts=True)
+    assert p['xdB'].shape[1] == int(Q['nseg'])
+    np.testing.assert_allclose(p['xdB'][:, ::25], Q['xdB_s'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(p['ydB'].sum(axis=0), Q['ydB_colsum'], rtol=1e-10)
+    np.testing.assert_allclose(p['xy'], Q['xy'], rtol=1e-10)
+    np.testing.assert_allclose(p['sigcov'][:, ::25], Q['sigcov_s'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(p['sigcov'].sum(axis=0), Q['sigcov_colsum'], rtol=1e-10)
+    np.testing.assert_allclose(p['sigMSx'].sum(axis=0), Q['sigMSx_colsum'], rtol=1e-10)
+    np.testing.assert_allclose(p['sigMSy'].sum(axis=0), Q['sigMSy_colsum'], rtol=1e-10)
+    np.testing.assert_allclose(raw[1:], Q['cov3'], rtol=1e-10)
+    np.testing.assert_allclose(p['covSII'], Q['covSII'], rtol=1e-10)
+    np.testing.assert_allclose(p['xSL'], Q['xSL'], rtol=1e-11)
+    np.testing.assert_allclose(raw, Q['raw_v1'], rtol=1e-10)
+    assert intel == pytest.approx(float(Q['intel']), rel=1e-10)
+    comb, nonlin, lin, rawq, pq = H.hasqi_v2(x, 24000, y, 24000, noise_x=nx, noise_y=ny, return_parts=True)
+    np.testing.assert_allclose(pq['syncov'], Q['syncov'], rtol=1e-10)
+    assert float(pq['avecov']) == pytest.approx(float(Q['avecov']), rel=1e-10)
+    for k in ('dloud', 'dnorm', 'dslope'):
+        np.testing.assert_allclose(pq[k], Q[k], rtol=1e-9)
+    np.testing.assert_allclose(rawq, Q['raw_q'], rtol=1e-10)
+    np.testing.assert_allclose([comb, nonlin, lin], Q['hasqi'], rtol=1e-10)
+
+
+def test_bm_noise_changes_the_quality_scores_by_less_than_a_thousandth():
+    """The reference adds N(0, 10^((-10 - 65)/20)) to the BM motion (pyhaspi2.py:1091-1095): what a different noise realisation (or
+    none) does to the scores - the tolerance a device-side generator has to meet."""
+    x, y = Q['x'], Q['y']
+    v0, r0 = H.haspi_v1(x, 24000, y, 24000)
+    q0 = H.hasqi_v2(x, 24000, y, 24000)
+    assert v0 == pytest.approx(float(Q['intel']), abs=1e-3)
+    assert q0[0] == pytest.approx(float(Q['hasqi'][0]), abs=1e-3)
+    np.testing.assert_allclose(r0, Q['raw_v1'], atol=2e-3)
