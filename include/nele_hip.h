@@ -257,6 +257,23 @@ int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, c
 int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
                           void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info, int phase, void* stream);
 
+/* pyHASPI/pyhaspi2.py:109-157 haspi(x, fx, y, fy, HL, alpha) (HASPI version 1) and :32-74 hasqi_v2(x, fx, y, fy, HL), HL = 0: same ear
+ * model plus the basilar-membrane motion (pyhaspi2.py:897, :997, :1076, :1087), 16 ms raised-cosine segments (eb_EnvSmooth :674-703),
+ * cepstral correlation (eb_melcor :706-751), segment cross-covariance of the BM motion (eb_BMcovary :550-657), its three-level and
+ * synchrony averages (eb_3LevelCovary :416-547, eb_AveCovary2 :160-220), long-term spectral differences (eb_aveSL :1135-1152,
+ * eb_SpectDiff :222-251).  One launch chain scores both.  x = reference, y = processed, [B][L] float32; lengths [B] or NULL.
+ * noise != 0: eb_BMaddnoise (pyhaspi2.py:1091-1095: N(0, 10^(-75/20)) on every BM sample, numpy's global generator in the reference)
+ * from a counter-based generator seeded with `seed`; 0 = none (deterministic).  alpha: logistic slope of haspi() (default -1).
+ * out [B][12] float64 = {HASPI v1 Intel, CepCorr, cov3 low, mid, high, HASQI Combined, Nonlin, Linear, BMsync5, Dloud, Dslope, avecov};
+ * info [B][4] (may be NULL) = {segments above threshold in eb_melcor, status, segments above threshold in the covariance stages,
+ * histogram bins}; status bit 1: eb_melcor's 'Signal below threshold' (reference raises, pyhaspi2.py:723-724), bit 2: the covariance
+ * stages' (:427-428; eb_AveCovary2 returns (0, 0) and hasqi_v2 fails on it), bit 4: more than 2048 histogram bins; the affected values
+ * are NaN. */
+long long nele_metric_haspi_quality_workspace_bytes(int B, int L, int fs_in);
+int nele_metric_haspi_quality(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise,
+                              unsigned long long seed, double alpha, void* workspace, long long workspace_bytes, double* out, int* info,
+                              void* stream);
+
 /* ---- evaluation path (csrc/reverb.hip) ---------------------------------------------------------------------- */
 
 /* eval_metrics.py:132,137 scipy.signal.lfilter(h, [1], x): room impulse response h [Lh] (float64) applied to x [B][L] (float32),

@@ -74,6 +74,8 @@ struct HaspiWs {
                      // from the sliding kernel, [B][5][10][nsub] from the direct one
     double* cpart;   // [B][MS_MAXC][64][5] correlation sums per chunk of outputs
     const int* lens; // [B] samples per utterance at the input rate, or NULL (every row has L samples)
+    float* cphi;     // quality path only (haspi_quality.h): [B][2][n24p][32] cosine of the carrier phase, BM motion / envelope
+    double* sse;     // quality path only: [B][2][nchunk][32] signal-bank sum-of-squares partials per scan chunk
     int fs_in;
     int n24, nsub;   // of the longest row: buffer strides
     int n24p;        // n24 rounded up to a multiple of HP_CH: row stride of the per-sample buffers (chunked kernels read/write whole chunks)
@@ -466,7 +468,9 @@ __global__ __launch_bounds__(64) void haspi_bank_prefix_kernel(HaspiWs ws, int s
 // |u|^2 = yr^2 + yi^2 needs no cross-lane exchange (the serial kernel's lane = branch * 32 + channel layout spent half of its issue
 // slots on selects, register moves and v_permlane32_swap: every VALU instruction of a wave64 costs 4 cycles on the 16-wide SIMDs,
 // whatever its width).  Same arithmetic per branch as the serial kernel.
-template <bool SIGNAL, bool PASS2>
+// BM (quality path, pass 2 of the signal bank): also the basilar-membrane motion u_r cos + u_i sin (pyhaspi2.py:897) as its ratio to the
+// envelope |u| - the cosine of the carrier phase, which is all the later stages need (see haspi_quality.h) - and the envelope's sum of squares.
+template <bool SIGNAL, bool PASS2, bool BM = false>
 __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig0) {
     const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, ch = lane & 31;
     const int chunk = 2 * blockIdx.x + (lane >> 5);
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
     }
     const double* xin = ws.mid + (size_t)row * ws.n24p;
     hp_env_t* out = (SIGNAL ? ws.env : ws.ctl) + ((size_t)row * ws.n24p) * HP_NCH + ch;
+    float* cph = BM ? ws.cphi + ((size_t)row * ws.n24p) * HP_NCH + ch : nullptr;
     double ss = 0.0;
     for (int nb = n0; nb < n1; nb += GS_RC) {
         double xc[GS_RC];
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
             const double2 v = *reinterpret_cast<const double2*>(xin + nb + 2 * u);
             xc[2 * u] = v.x; xc[2 * u + 1] = v.y;
         }
-        float eo[GS_RC];
+        float eo[GS_RC], co[BM ? GS_RC : 1];
 #pragma unroll
         for (int u = 0; u < GS_RC; ++u) {
             hp_rotate(cold, sold, cn, sn);
@@ -519,12 +524,17 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
             if (PASS2) {
                 const double e2 = yr * yr + yi * yi;
                 eo[u] = (float)e2;
-                if (!SIGNAL) ss += (nb + u < n24) ? e2 : 0.0;
+                if (!SIGNAL || BM) ss += (nb + u < n24) ? e2 : 0.0;
+                if (BM) co[u] = e2 > 0.0 ? (float)((yr * cold + yi * sold) / sqrt(e2)) : 0.f;
             }
         }
         if (PASS2) {
 #pragma unroll
             for (int u = 0; u < GS_RC; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
+            if (BM) {
+#pragma unroll
+                for (int u = 0; u < GS_RC; ++u) cph[(size_t)(nb + u) * HP_NCH] = co[u];
+            }
         }
     }
     if (!PASS2) {
@@ -532,6 +542,8 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
         est[32] = i0; est[96] = i1; est[160] = i2; est[224] = i3;
     } else if (!SIGNAL) {
         ws.ssp[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
+    } else if (BM) {
+        ws.sse[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
     }
 }
 // eb_BWadjust from the chunk partials (added in chunk order).  grid rows, block 32
@@ -1394,7 +1406,8 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(xf, double, (size_t)B * 64 * nsub);
     TAKE(cpart, double, (size_t)B * MS_MAXC * 64 * 5);
 #undef TAKE
-    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; w->ngb = ngb; }
+    if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; w->ngb = ngb;
+             w->cphi = nullptr; w->sse = nullptr; }
     return o;
 }
 
@@ -1406,12 +1419,16 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
 }
 
 // The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
-static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws, int sig0, int nsig, hipStream_t s) {
+static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws, int sig0, int nsig, hipStream_t s,
+                        bool quality = false) {
     const int rows = B * nsig;
     static int par_iir = -1;                               // NELE_HASPI_PAR_IIR=0: the serial recurrence kernels (A/B diagnostic)
     if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
     static int fused_gain = -1;
     if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
+    const int par_iir_saved = par_iir, fused_gain_saved = fused_gain;
+    if (quality) par_iir = fused_gain = 1;                     // the quality path exists for the scan kernels only
+    struct Restore { int& a; int& b; int va, vb; ~Restore() { a = va; b = vb; } } restore_{par_iir, fused_gain, par_iir_saved, fused_gain_saved};
     hipLaunchKernelGGL(haspi_rms_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
     if (fs_in != 24000) {
         hipLaunchKernelGGL(haspi_resample_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
@@ -1428,7 +1445,8 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         hipLaunchKernelGGL(haspi_pmat_kernel, dim3(rows), dim3(128), 0, s, ws, ws.lc, 1, sig0, nsig);
         hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        if (quality) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
@@ -1438,6 +1456,7 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         NELE_PROF("haspi_gain_lp_sl_kernel", s,
                   hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
         hipLaunchKernelGGL(haspi_ihc_prefix_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
+        if (quality) return;                                   // haspi_quality.h goes on from the dB-SL envelope + IHC start states
         hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * GL_N - 1) / (4 * GL_N), rows), dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
@@ -1522,3 +1541,5 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
     NELE_CHECK_ARG(x && y && (raw || mapped), "nele_metric_haspi: bad arguments");
     return nele_metric_haspi_var(x, y, nullptr, B, L, fs_in, dither, workspace, workspace_bytes, raw, mapped, info_out, 0, stream);
 }
+
+#include "haspi_quality.h"

@@ -43,6 +43,11 @@ _lib._SIGS['nele_metric_haspi_var'] = _lib.lib.nele_metric_haspi_var.argtypes
 _lib.lib.nele_metric_haspi_workspace_bytes.argtypes = [c_int, c_int, c_int]
 _lib.lib.nele_metric_haspi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_haspi_workspace_bytes'] = _lib.lib.nele_metric_haspi_workspace_bytes.argtypes
+_lib.lib.nele_metric_haspi_quality_workspace_bytes.argtypes = [c_int, c_int, c_int]
+_lib.lib.nele_metric_haspi_quality_workspace_bytes.restype = c_longlong
+_lib._SIGS['nele_metric_haspi_quality_workspace_bytes'] = _lib.lib.nele_metric_haspi_quality_workspace_bytes.argtypes
+declare('nele_metric_haspi_quality', [_P, _P, _P, c_int, c_int, c_int, c_int, ctypes.c_ulonglong, ctypes.c_double, _P, c_longlong, _P, _P, _P])
+_lib._SIGS['nele_metric_haspi_quality'] = _lib.lib.nele_metric_haspi_quality.argtypes
 _lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_haspi_nsub.restype = c_int
 _lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
@@ -250,6 +255,61 @@ class HaspiSplit:
         self.y = y.contiguous().float()
         self._call(self.y, dither, 4)
         return self.raw, self.mapped
+
+
+QUALITY_FIELDS = ('haspi', 'CepCorr', 'cov3_low', 'cov3_mid', 'cov3_high', 'hasqi', 'Nonlin', 'Linear', 'BMsync5', 'Dloud', 'Dslope', 'avecov')
+
+
+def batch_haspi_quality(x, y, fs=16000, lengths=None, noise=True, seed=None, alpha=-1.0, return_info=False):
+    """reference x [B,L], processed y [B,L] -> float64 [B, 12] (columns QUALITY_FIELDS): HASPI version 1 (pyhaspi2.py:109-157) and
+    HASQI v2 (pyhaspi2.py:32-74) from one launch chain.  noise: the reference's eb_BMaddnoise (device generator, ``seed`` or a fresh
+    one per call); False = none (deterministic, the parity tests)."""
+    x, y, _ = _pair(x, y)
+    B, L = x.shape
+    ws = _workspace('haspi_quality', _lib.lib.nele_metric_haspi_quality_workspace_bytes(B, L, int(fs)), x.device)
+    out = torch.empty((B, len(QUALITY_FIELDS)), dtype=torch.float64, device=x.device)
+    info = torch.zeros((B, 4), dtype=torch.int32, device=x.device)
+    if lengths is not None:
+        lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32).contiguous()
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise else 0
+    call('nele_metric_haspi_quality', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), int(bool(noise)), int(seed), float(alpha), ptr(ws), ws.numel(),
+         ptr(out), ptr(info), stream())
+    return (out, info) if return_info else out
+
+
+def _quality_checked(x, fx, y, fy, alpha=-1.0):
+    if fx != fy:
+        raise ValueError('haspi / hasqi_v2: both signals must have the same sampling rate here (the reference resamples each to 24 kHz)')
+    L = min(len(x), len(y))
+    out, info = batch_haspi_quality(x[:L], y[:L], fx, alpha=alpha, return_info=True)
+    st = int(info[0, 1])
+    if st & 1:
+        raise Exception('Function eb_melcor: Signal below threshold, outputs set to 0.')        # pyhaspi2.py:723-724
+    return out[0].cpu().numpy(), st
+
+
+def haspi(x, fx, y, fy, HL=None, alpha=-1.0):
+    """pyhaspi2.py:109-157 (HASPI version 1), normal hearing: -> (Intel, raw = [CepCorr, cov3 low, mid, high])."""
+    _no_loss(HL)
+    o, st = _quality_checked(x, fx, y, fy, alpha)
+    if st & 2:
+        raise Exception('Function eb_3LevelCovary: Signal below threshold, outputs set to 0.')    # pyhaspi2.py:427-428
+    return float(o[0]), o[1:5].copy()
+
+
+def hasqi_v2(x, fx, y, fy, HL=None):
+    """pyhaspi2.py:32-74, normal hearing: -> (Combined, Nonlin, Linear, raw = [CepCorr, BMsync5, Dloud, Dslope])."""
+    _no_loss(HL)
+    o, st = _quality_checked(x, fx, y, fy)
+    if st & 2:
+        raise TypeError("'int' object is not subscriptable")                                       # eb_AveCovary2's (0, 0) return at pyhaspi2.py:54
+    return float(o[5]), float(o[6]), float(o[7]), [float(o[1]), float(o[8]), float(o[9]), float(o[10])]
+
+
+def _no_loss(HL):
+    if HL is not None and any(float(v) != 0.0 for v in HL):
+        raise NotImplementedError('hearing loss HL != 0 is not built: every call site of the reference passes the default (intel.py:108-120)')
 
 
 def _haspi_checked(x, y, fs):
