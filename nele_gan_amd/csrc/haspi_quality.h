@@ -3,8 +3,8 @@
 // quality one, itype 2, coincide: pyhaspi2.py:1162-1165, :1176).  Included at the end of haspi.hip: the ear model up to the dB-SL
 // envelope is haspi_chain() itself, run with the BM switch; from there
 //   q1  hq_ihc_bm_kernel   IHC adaptation pass 2 (pyhaspi2.py:1028-1078) writing the adapted envelope AND the basilar-membrane motion
-//   q2  hq_smooth_kernel   eb_EnvSmooth (:674-703): 16 ms raised-cosine segments, 50 % overlap, after the group-delay shift
-//   q3  hq_bmcov_kernel    eb_BMcovary (:550-657): windowed, mean-removed BM segments, cross-covariance over |lag| <= 24, mean squares
+//   q2  hq_segment_kernel  eb_EnvSmooth (:674-703): 16 ms raised-cosine segments, 50 % overlap, after the group-delay shift, and
+//   q3                     eb_BMcovary (:550-657): windowed, mean-removed BM segments, cross-covariance over |lag| <= 24, mean squares
 //   q4  hq_loud_kernel     segment loudness (band average of 10^(dB/20), back in dB) for the silence gates of eb_melcor / the covariance stages
 //   q5  hq_final_kernel    eb_melcor (:706-751), eb_3LevelCovary (:416-547), eb_AveCovary2 (:160-220), eb_aveSL (:1135-1152), eb_SpectDiff
 //                          (:222-251) and the two score formulas, one block per utterance
@@ -94,31 +94,6 @@ __device__ __forceinline__ void hq_segment(int seg, int nseg, int& st, int& len,
     else { len = HQ_NWIN; woff = 0; }
 }
 
-// ---- q2: grid (ceil(nseg / 8), 2 B), block 256 = 8 segments x 32 channels
-__global__ __launch_bounds__(256) void hq_smooth_kernel(HaspiWs ws, QualWs q) {
-    __shared__ double w[HQ_NWIN];
-    const int tid = threadIdx.x, ch = tid & 31, row = blockIdx.y, b = row >> 1;
-    for (int k = tid; k < HQ_NWIN; k += 256) w[k] = hq_win(k);
-    __syncthreads();
-    const int n24 = hp_n24(ws, b), nseg = hq_nseg(n24);
-    const int seg = blockIdx.x * 8 + (tid >> 5);
-    if (seg >= nseg) return;
-    int st, len, woff;
-    hq_segment(seg, nseg, st, len, woff);
-    const int sh = ws.shift[(size_t)b * HP_NCH + ch];
-    const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
-    double acc = 0.0;
-    for (int k0 = 0; k0 < len; k0 += 8) {                   // len is a multiple of 8
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int m = st + k0 + u - sh; v[u] = m >= 0 ? e[(size_t)m * HP_NCH] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u] * w[woff + k0 + u];
-    }
-    // sum(np.hanning(384)) = 191.5, of one half 95.75
-    q.sm[((size_t)row * q.nseg + seg) * HP_NCH + ch] = acc / (len == HQ_NWIN ? 191.5 : 95.75);
-}
-
 // 1 / xcorr(w, w, 24) of the full window and of its second half (the literal tables of pyhaspi2.py:563, :570).  grid 1, block 128
 __global__ void hq_corr_kernel(QualWs q) {
     const int t = threadIdx.x, half = t >> 6, i = t & 63;
@@ -132,75 +107,120 @@ __global__ void hq_corr_kernel(QualWs q) {
     q.corr[half * 64 + i] = 1.0 / s;
 }
 
-// ---- q3: grid (nseg, 4, B), block 128: 8 channels per block; thread = (k16 = tid >> 3, c = tid & 7).  The windowed segments of x and y
-// go to LDS, their means are removed there, then thread (lag group lg < 13, c) accumulates the 4 consecutive lags -24 + 4 lg ... with a
-// sliding register window over x: 2 LDS reads per 4 multiply-adds.
+// ---- q2 + q3: one block per (segment, group of 8 channels, utterance): eb_EnvSmooth of both envelopes and eb_BMcovary.
+// grid (nseg, 4, B), block 128: thread = (k16 = tid >> 3, c = tid & 7).
+// The group-delay compensation (pyhaspi2.py:1098-1131, :1239-1242) delays channel ch by shift[ch] samples, up to 433 between the lowest
+// and the highest band: a lane that reads its own shifted column straight from the [sample][32] arrays touches a different cache
+// line than every other lane (the first version did: 50 ms for the smoothing alone at B = 256).  Here the rows [st - max shift, st + len -
+// min shift) of the group's 8 columns are loaded row by row (32 bytes = two float4 lanes per row) into an LDS tile, and the lanes
+// pick their shifted columns from there.  The four arrays (envelope and BM motion of x and y) go through the same tile one after
+// the other.  The windowed, mean-removed BM segments are kept in LDS as float32 (they were float32 in memory), all sums are float64.
+// Lag loop: thread (lag group lg < 13, c) accumulates the 4 consecutive lags -24 + 4 lg ... with a sliding register window over x:
+// 2 LDS reads per 4 multiply-adds.
 #define HQ_XR (HQ_NWIN + 2 * HQ_MAXLAG + 4)
-__global__ __launch_bounds__(128) void hq_bmcov_kernel(HaspiWs ws, QualWs q) {
-    __shared__ double xs[HQ_XR][8];
-    __shared__ double ys[HQ_NWIN][8];
+#define HQ_TROWS 640                 // tile rows: 384 + the largest shift spread inside a group of 8 neighbouring bands that still uses the tile
+__global__ __launch_bounds__(128) void hq_segment_kernel(HaspiWs ws, QualWs q) {
+    __shared__ __attribute__((aligned(16))) float tile[HQ_TROWS][8];
+    __shared__ float xs[HQ_XR][8];
+    __shared__ float ys[HQ_NWIN][8];
+    __shared__ double wtab[HQ_NWIN];
     __shared__ double part[16][8][2];
     __shared__ double mx[16][8];
-    const int tid = threadIdx.x, c = tid & 7, k16 = tid >> 3, b = blockIdx.z, ch = blockIdx.y * 8 + c;
+    const int tid = threadIdx.x, c = tid & 7, k16 = tid >> 3, b = blockIdx.z, ch0 = blockIdx.y * 8, ch = ch0 + c;
     const int n24 = hp_n24(ws, b), nseg = hq_nseg(n24), seg = blockIdx.x;
     if (seg >= nseg) return;
     int st, N, woff;
     hq_segment(seg, nseg, st, N, woff);
+    for (int k = tid; k < N; k += 128) wtab[k] = hq_win(woff + k);
     const int sh = ws.shift[(size_t)b * HP_NCH + ch];
-    const float* bx = ws.cphi + ((size_t)(2 * b) * ws.n24p) * HP_NCH + ch;
-    const float* by = ws.cphi + ((size_t)(2 * b + 1) * ws.n24p) * HP_NCH + ch;
-    for (int r = k16; r < HQ_XR; r += 16) xs[r][c] = 0.0;
-    __syncthreads();
-    double sx = 0.0, sy = 0.0;
-    for (int k = k16; k < N; k += 16) {
-        const int m = st + k - sh;
-        const double w = hq_win(woff + k);
-        const double vx = m >= 0 ? (double)bx[(size_t)m * HP_NCH] * w : 0.0;
-        const double vy = m >= 0 ? (double)by[(size_t)m * HP_NCH] * w : 0.0;
-        xs[k + HQ_MAXLAG][c] = vx;
-        ys[k][c] = vy;
-        sx += vx; sy += vy;
-    }
-    part[k16][c][0] = sx; part[k16][c][1] = sy;
-    __syncthreads();
-    double mxv = 0.0, myv = 0.0;
+    int smin = sh, smax = sh;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { mxv += part[j][c][0]; myv += part[j][c][1]; }
-    mxv /= (double)N; myv /= (double)N;
-    __syncthreads();
-    sx = 0.0; sy = 0.0;
-    for (int k = k16; k < N; k += 16) {
-        const double vx = xs[k + HQ_MAXLAG][c] - mxv, vy = ys[k][c] - myv;
-        xs[k + HQ_MAXLAG][c] = vx;
-        ys[k][c] = vy;
-        sx += vx * vx; sy += vy * vy;
+    for (int o = 1; o < 8; o <<= 1) { smin = min(smin, __shfl_xor(smin, o, 64)); smax = max(smax, __shfl_xor(smax, o, 64)); }
+    const int base = st - smax;                              // first row of the tile (may be negative: zeros, as the reference prepends)
+    const int rows = min(N + smax - smin, HQ_TROWS);
+    const int roff = smax - sh;                              // the lane's segment starts at tile row roff
+    for (int r = k16; r < HQ_XR; r += 16) xs[r][c] = 0.f;
+    double res[2] = {0.0, 0.0};
+    double MSx = 0.0, MSy = 0.0;
+    for (int a = 0; a < 4; ++a) {                            // 0, 1: envelopes of x, y; 2, 3: BM motion of x, y
+        const float* src = ((a < 2) ? (const float*)ws.env : ws.cphi) + ((size_t)(2 * b + (a & 1)) * ws.n24p) * HP_NCH + ch0;
+        __syncthreads();                                     // the previous array's readers are done with the tile
+        for (int r = tid >> 1; r < rows; r += 64) {
+            const int m = base + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m >= 0 && m < n24) v = *reinterpret_cast<const float4*>(src + (size_t)m * HP_NCH + 4 * (tid & 1));
+            *reinterpret_cast<float4*>(&tile[r][4 * (tid & 1)]) = v;
+        }
+        __syncthreads();
+        double s = 0.0;
+        if (a < 2) {
+            for (int k = k16; k < N; k += 16) {
+                const int r = roff + k, m = base + r;
+                const float v = r < HQ_TROWS ? tile[r][c] : ((m >= 0 && m < n24) ? src[(size_t)m * HP_NCH + c] : 0.f);
+                s += (double)v * wtab[k];
+            }
+            part[k16][c][0] = s;
+            __syncthreads();
+            if (k16 == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += part[j][c][0];
+                // sum(np.hanning(384)) = 191.5, of one half 95.75
+                q.sm[((size_t)(2 * b + a) * q.nseg + seg) * HP_NCH + ch] = t / (N == HQ_NWIN ? 191.5 : 95.75);
+            }
+        } else {
+            float* dst = (a == 2) ? &xs[HQ_MAXLAG][0] : &ys[0][0];
+            for (int k = k16; k < N; k += 16) {
+                const int r = roff + k, m = base + r;
+                const float v = r < HQ_TROWS ? tile[r][c] : ((m >= 0 && m < n24) ? src[(size_t)m * HP_NCH + c] : 0.f);
+                s += (double)v * wtab[k];
+            }
+            part[k16][c][0] = s;
+            __syncthreads();
+            double mean = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mean += part[j][c][0];
+            mean /= (double)N;
+            double s2 = 0.0;
+            for (int k = k16; k < N; k += 16) {
+                const int r = roff + k, m = base + r;
+                const float v = r < HQ_TROWS ? tile[r][c] : ((m >= 0 && m < n24) ? src[(size_t)m * HP_NCH + c] : 0.f);
+                const float d = (float)((double)v * wtab[k] - mean);
+                dst[k * 8 + c] = d;
+                s2 += (double)d * (double)d;
+            }
+            part[k16][c][1] = s2;
+            __syncthreads();
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += part[j][c][1];
+            if (a == 2) MSx = t; else MSy = t;
+        }
     }
-    part[k16][c][0] = sx; part[k16][c][1] = sy;
     __syncthreads();
     double best = 0.0;
     if (k16 < 13) {
         const int l0 = -HQ_MAXLAG + 4 * k16;                 // lags l0 .. l0 + 3; x row of (n, l) = n + l + 24
         const double* corr = q.corr + (N == HQ_NWIN ? 0 : 64);
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        double x0 = xs[l0 + HQ_MAXLAG][c], x1 = xs[l0 + HQ_MAXLAG + 1][c], x2 = xs[l0 + HQ_MAXLAG + 2][c];
+        double x0 = (double)xs[l0 + HQ_MAXLAG][c], x1 = (double)xs[l0 + HQ_MAXLAG + 1][c], x2 = (double)xs[l0 + HQ_MAXLAG + 2][c];
+#pragma unroll 4
         for (int n = 0; n < N; ++n) {
-            const double x3 = xs[n + l0 + HQ_MAXLAG + 3][c], y = ys[n][c];
+            const double x3 = (double)xs[n + l0 + HQ_MAXLAG + 3][c], y = (double)ys[n][c];
             a0 += x0 * y; a1 += x1 * y; a2 += x2 * y; a3 += x3 * y;
             x0 = x1; x1 = x2; x2 = x3;
         }
-        const double a[4] = {a0, a1, a2, a3};
+        const double av[4] = {a0, a1, a2, a3};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (l0 + j <= HQ_MAXLAG) best = fmax(best, fabs(a[j] * corr[l0 + j + HQ_MAXLAG]));
+            if (l0 + j <= HQ_MAXLAG) best = fmax(best, fabs(av[j] * corr[l0 + j + HQ_MAXLAG]));
     }
     mx[k16][c] = best;
     __syncthreads();
     if (k16 == 0) {
-        double Mxy = 0.0, MSx = 0.0, MSy = 0.0;
+        double Mxy = 0.0;
 #pragma unroll
         for (int j = 0; j < 13; ++j) Mxy = fmax(Mxy, mx[j][c]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { MSx += part[j][c][0]; MSy += part[j][c][1]; }
         const double norm2 = 1.0 / (N == HQ_NWIN ? 143.625 : 71.8125);     // sum(np.hanning(384)^2) = 3 (N - 1) / 8; the second half holds half of it
         MSx *= norm2; MSy *= norm2;
         double cv = (MSx > 1.0e-30 && MSy > 1.0e-30) ? Mxy / sqrt(MSx * MSy) : 0.0;
@@ -507,8 +527,7 @@ extern "C" int nele_metric_haspi_quality(const float* x, const float* y, const i
     const int rows = 2 * B;
     hipLaunchKernelGGL(hq_ihc_bm_kernel, dim3(((ws.n24p + GL_N - 1) / GL_N + 7) / 8, rows), dim3(256), 0, s, ws, q, 0, 2);
     hipLaunchKernelGGL(hq_corr_kernel, dim3(1), dim3(128), 0, s, q);
-    hipLaunchKernelGGL(hq_smooth_kernel, dim3((q.nseg + 7) / 8, rows), dim3(256), 0, s, ws, q);
-    hipLaunchKernelGGL(hq_bmcov_kernel, dim3(q.nseg, 4, B), dim3(128), 0, s, ws, q);
+    hipLaunchKernelGGL(hq_segment_kernel, dim3(q.nseg, 4, B), dim3(128), 0, s, ws, q);
     hipLaunchKernelGGL(hq_loud_kernel, dim3((q.nseg + 63) / 64, B), dim3(64), 0, s, ws, q);
     hipLaunchKernelGGL(hq_final_kernel, dim3(B), dim3(256), 0, s, ws, q, alpha, out);
     if (info_out) (void)hipMemcpyAsync(info_out, q.qinfo, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
