@@ -19,6 +19,7 @@
 
 #define EG_MAXN 512
 
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
 struct EighWs {
     double* d;      // [B][n]
     double* e;      // [B][n]
@@ -1186,6 +1187,136 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
     }
 }
 
+// ------------------------------------------------------------------------------------------ e4, blocked (compact WY) on the matrix cores
+// The reflector-by-reflector kernel above is bound by LDS instruction issue (2 x BT_Q reads per reflector and wave for 4 x BT_Q FMAs):
+// 3.0 ms for 256 matrices of 420.  Here 16 consecutive reflectors H_klo ... H_khi are applied at once as I - V T V^T (LAPACK dlarft
+// "forward, columnwise": T upper triangular, T_jj = tau_j, T_(0:j, j) = -tau_j T_(0:j, 0:j) V_(:, 0:j)^T v_j):
+//     W = V^T Z (16 x 16 per wave),  W' = -T W,  Z += V W'
+// with v_mfma_f64_16x16x4_f64.  A wave keeps 16 eigenvectors in the MFMA accumulator layout (reg q of lane l = row (l >> 4) + 4 q of the
+// 16-row tile, column l & 15) for the whole kernel: a k-step t of the first product takes rows 4 t + (l >> 4), which IS register t of the
+// tile, and the W / W' tiles feed the next product the same way - no shuffles, one 8-byte LDS read (the V or T operand) per MFMA.
+// eigh_wy_t_kernel: grid (blocks of 16 reflectors, B), block 256: -T per block -> ws.lu (free once the inverse iteration is done).
+#define WY_NB 16
+#define WY_LD 17
+__global__ __launch_bounds__(256) void eigh_wy_t_kernel(const double* __restrict__ Aall, int n, EighWs ws) {
+    __shared__ double V[WY_NB][EG_MAXN + 1];
+    __shared__ double G[WY_NB][WY_LD], T[WY_NB][WY_LD], tau_s[WY_NB];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int khi = n - 2 - WY_NB * c, klo = khi - (WY_NB - 1);          // reflectors klo .. khi (those with k < 0 do not exist: tau = 0)
+    const double* A = Aall + (size_t)b * n * n;
+    for (int idx = tid; idx < WY_NB * n; idx += 256) {
+        const int r = idx / n, i = idx - r * n, k = klo + r;
+        V[r][i] = (k >= 0 && i > k) ? A[(size_t)k * n + i] : 0.0;
+    }
+    if (tid < WY_NB) tau_s[tid] = (klo + tid >= 0) ? ws.tau[(size_t)b * n + klo + tid] : 0.0;
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double g = 0.0;
+        for (int r = max(klo + 1, 0); r < n; ++r) g += V[i][r] * V[j][r];      // rows <= klo are zero in every reflector of the block
+        G[i][j] = g;
+        T[i][j] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < WY_NB; ++j) {                                     // column j from columns 0 .. j-1
+        if (tid < j) {
+            double t = 0.0;
+            for (int m = tid; m < j; ++m) t += T[tid][m] * G[m][j];
+            T[tid][j] = -tau_s[j] * t;
+        } else if (tid == j) {
+            T[j][j] = tau_s[j];
+        }
+        __syncthreads();
+    }
+    double* out = ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN + (size_t)c * 256;
+    out[tid] = -T[tid >> 4][tid & 15];
+}
+
+// grid (ceil(n / 64), B), block 256: wave w holds eigenvectors 64 blockIdx.x + 16 w ... + 15.  One workgroup per CU (the two V buffers
+// take 117 KB of LDS), so a wave may use the whole register file: WY_RT tiles x 4 doubles of Z per lane.
+template <int WY_RT>     // 16-row tiles held per lane: 27 covers n <= 432 (SIIB: 420), 32 covers EG_MAXN
+__global__ __launch_bounds__(256, 1) void eigh_backtransform_wy_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
+    extern __shared__ double wy_sm[];                       // Vs[2][16 WY_RT][WY_LD], Ts[2][16][WY_LD]
+    constexpr int NR = 16 * WY_RT;
+    double* Vs = wy_sm;
+    double* Ts = wy_sm + 2 * NR * WY_LD;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int j = blockIdx.x * 64 + 16 * w + li;            // this lane's eigenvector
+    const double* A = Aall + (size_t)b * n * n;
+    const double* zt = ws.zt + (size_t)b * n * EG_MAXN;
+    const double* Tall = ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN;
+    f64x4_t Z[WY_RT];
+#pragma unroll
+    for (int rt = 0; rt < WY_RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * rt + g + 4 * q;
+            Z[rt][q] = (i < n && j < n) ? zt[(size_t)i * EG_MAXN + j] : 0.0;
+        }
+    const int nblk = (n - 1 + WY_NB - 1) / WY_NB;
+    // staging: thread = (reflector r = tid >> 4, row slot ii = tid & 15), rows ii + 16 u: 128-byte runs of a reflector row
+    double pre[WY_RT], pret = 0.0;
+    const int sr = tid >> 4, sii = tid & 15;
+    auto gload = [&](int c) {
+        const int k = n - 2 - WY_NB * c - (WY_NB - 1) + sr;
+        const double* src = A + (size_t)max(k, 0) * n + sii;
+#pragma unroll
+        for (int u = 0; u < WY_RT; ++u) {
+            const int i = sii + 16 * u;
+            pre[u] = (k >= 0 && i > k && i < n) ? src[16 * u] : 0.0;
+        }
+        pret = Tall[(size_t)c * 256 + tid];
+    };
+    auto lstore = [&](int buf) {
+        double* dst = Vs + ((size_t)buf * NR + sii) * WY_LD + sr;
+#pragma unroll
+        for (int u = 0; u < WY_RT; ++u) dst[16 * u * WY_LD] = pre[u];
+        Ts[(buf * 16 + sr) * WY_LD + sii] = pret;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nblk; ++c) {
+        const int buf = c & 1, klo = n - 2 - WY_NB * c - (WY_NB - 1);
+        if (c + 1 < nblk) gload(c + 1);
+        const int rt0 = max(klo + 1, 0) >> 4;               // rows below 16 rt0 are zero in every reflector of the block
+        const double* vb = Vs + (size_t)buf * NR * WY_LD;
+        // four independent accumulators (one per k-step t): consecutive MFMAs never wait for each other's result
+        f64x4_t Wa[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int rt = 0; rt < WY_RT; ++rt) {
+            if (rt >= rt0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)                  // A = V^T: [reflector li][row 16 rt + 4 t + g]
+                    Wa[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[(16 * rt + 4 * t + g) * WY_LD + li], Z[rt][t], Wa[t], 0, 0, 0);
+            }
+        }
+        const f64x4_t W = (Wa[0] + Wa[1]) + (Wa[2] + Wa[3]);
+        f64x4_t Wn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)                          // A = -T: [row li][column g + 4 t]
+            Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(buf * 16 + li) * WY_LD + g + 4 * t], W[t], Wn, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                        // k-step outermost: consecutive MFMAs update different tiles
+#pragma unroll
+            for (int rt = 0; rt < WY_RT; ++rt) {
+                if (rt >= rt0)                               // A = V: [row 16 rt + li][reflector g + 4 t]
+                    Z[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[(16 * rt + li) * WY_LD + g + 4 * t], Wn[t], Z[rt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nblk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    double* Ub = U + (size_t)b * n * n;
+#pragma unroll
+    for (int rt = 0; rt < WY_RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * rt + g + 4 * q;
+            if (i < n && j < n) Ub[(size_t)j * n + i] = Z[rt][q];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -1279,7 +1410,19 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         attr_done = true;
     }
-    if (n <= 448) hipLaunchKernelGGL(eigh_backtransform_kernel<28>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
+    static int wy_on = -1;                                  // NELE_EIGH_WY=0: the reflector-by-reflector back-transformation (A/B diagnostic)
+    if (wy_on < 0) {
+        const char* e_ = getenv("NELE_EIGH_WY");
+        wy_on = !(e_ && e_[0] == '0');
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_wy_kernel<27>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_wy_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    }
+    if (wy_on) {
+        const int nblk = (n - 1 + WY_NB - 1) / WY_NB;
+        hipLaunchKernelGGL(eigh_wy_t_kernel, dim3(nblk, B), dim3(256), 0, s, A, n, ws);
+        if (n <= 432) hipLaunchKernelGGL(eigh_backtransform_wy_kernel<27>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 432 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
+        else hipLaunchKernelGGL(eigh_backtransform_wy_kernel<32>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 512 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
+    } else if (n <= 448) hipLaunchKernelGGL(eigh_backtransform_kernel<28>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
     else hipLaunchKernelGGL(eigh_backtransform_kernel<32>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
     NELE_CHECK_LAUNCH("nele_eigh_sym_batched");
     return NELE_OK;
