@@ -1204,8 +1204,9 @@ __global__ __launch_bounds__(256) void eigh_wy_t_kernel(const double* __restrict
     const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int khi = n - 2 - WY_NB * c, klo = khi - (WY_NB - 1);          // reflectors klo .. khi (those with k < 0 do not exist: tau = 0)
     const double* A = Aall + (size_t)b * n * n;
-    for (int idx = tid; idx < WY_NB * n; idx += 256) {
-        const int r = idx / n, i = idx - r * n, k = klo + r;
+    const int lo = max(klo + 1, 0), nr = n - lo;                      // rows <= klo are zero in every reflector of the block
+    for (int idx = tid; idx < WY_NB * nr; idx += 256) {
+        const int r = idx / nr, i = lo + idx - r * nr, k = klo + r;
         V[r][i] = (k >= 0 && i > k) ? A[(size_t)k * n + i] : 0.0;
     }
     if (tid < WY_NB) tau_s[tid] = (klo + tid >= 0) ? ws.tau[(size_t)b * n + klo + tid] : 0.0;
@@ -1213,21 +1214,26 @@ __global__ __launch_bounds__(256) void eigh_wy_t_kernel(const double* __restrict
     {
         const int i = tid >> 4, j = tid & 15;
         double g = 0.0;
-        for (int r = max(klo + 1, 0); r < n; ++r) g += V[i][r] * V[j][r];      // rows <= klo are zero in every reflector of the block
+        for (int r = lo; r < n; ++r) g += V[i][r] * V[j][r];
         G[i][j] = g;
         T[i][j] = 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < WY_NB; ++j) {                                     // column j from columns 0 .. j-1
-        if (tid < j) {
-            double t = 0.0;
-            for (int m = tid; m < j; ++m) t += T[tid][m] * G[m][j];
-            T[tid][j] = -tau_s[j] * t;
-        } else if (tid == j) {
-            T[j][j] = tau_s[j];
+    if (tid < 64) {                                                    // one wave, lanes 0..15 = rows of T: no workgroup barriers
+        for (int j = 0; j < WY_NB; ++j) {                              // column j from columns 0 .. j-1
+            if (tid < j) {
+                double t = 0.0;
+                for (int m = tid; m < j; ++m) t += T[tid][m] * G[m][j];
+                T[tid][j] = -tau_s[j] * t;
+            } else if (tid == j) {
+                T[j][j] = tau_s[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        __syncthreads();
     }
+    __syncthreads();
     double* out = ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN + (size_t)c * 256;
     out[tid] = -T[tid >> 4][tid & 15];
 }
@@ -1257,20 +1263,33 @@ __global__ __launch_bounds__(256, 1) void eigh_backtransform_wy_kernel(const dou
     // staging: thread = (reflector r = tid >> 4, row slot ii = tid & 15), rows ii + 16 u: 128-byte runs of a reflector row
     double pre[WY_RT], pret = 0.0;
     const int sr = tid >> 4, sii = tid & 15;
+    constexpr int GT = (WY_RT % 3 == 0) ? 3 : 4;             // tiles per group (see the MFMA loops)
+    int sg0 = 0;                                            // first tile group of the staged block that is ever read
     auto gload = [&](int c) {
-        const int k = n - 2 - WY_NB * c - (WY_NB - 1) + sr;
+        const int klo = n - 2 - WY_NB * c - (WY_NB - 1), k = klo + sr;
         const double* src = A + (size_t)max(k, 0) * n + sii;
+        sg0 = (max(klo + 1, 0) >> 4) / GT;
 #pragma unroll
-        for (int u = 0; u < WY_RT; ++u) {
-            const int i = sii + 16 * u;
-            pre[u] = (k >= 0 && i > k && i < n) ? src[16 * u] : 0.0;
+        for (int gi = 0; gi < WY_RT / GT; ++gi) {
+            if (gi >= sg0) {
+#pragma unroll
+                for (int u = GT * gi; u < GT * gi + GT; ++u) {
+                    const int i = sii + 16 * u;
+                    pre[u] = (k >= 0 && i > k && i < n) ? src[16 * u] : 0.0;
+                }
+            }
         }
         pret = Tall[(size_t)c * 256 + tid];
     };
     auto lstore = [&](int buf) {
         double* dst = Vs + ((size_t)buf * NR + sii) * WY_LD + sr;
 #pragma unroll
-        for (int u = 0; u < WY_RT; ++u) dst[16 * u * WY_LD] = pre[u];
+        for (int gi = 0; gi < WY_RT / GT; ++gi) {
+            if (gi >= sg0) {
+#pragma unroll
+                for (int u = GT * gi; u < GT * gi + GT; ++u) dst[16 * u * WY_LD] = pre[u];
+            }
+        }
         Ts[(buf * 16 + sr) * WY_LD + sii] = pret;
     };
     gload(0);
@@ -1281,27 +1300,46 @@ __global__ __launch_bounds__(256, 1) void eigh_backtransform_wy_kernel(const dou
         if (c + 1 < nblk) gload(c + 1);
         const int rt0 = max(klo + 1, 0) >> 4;               // rows below 16 rt0 are zero in every reflector of the block
         const double* vb = Vs + (size_t)buf * NR * WY_LD;
-        // four independent accumulators (one per k-step t): consecutive MFMAs never wait for each other's result
+        // Tiles are handled in groups of GT: one uniform branch per group (tiles above the block's first row are all zero and skipped),
+        // the group's 4 GT operand reads issued together ahead of its 4 GT MFMAs - a guard and an LDS round trip per MFMA left the matrix
+        // pipe idle most of the time.  Four independent accumulators (one per k-step t) for W.
         f64x4_t Wa[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-        for (int rt = 0; rt < WY_RT; ++rt) {
-            if (rt >= rt0) {
+        for (int gi = 0; gi < WY_RT / GT; ++gi) {
+            if (GT * gi + GT - 1 >= rt0) {
+                double a[GT][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)                  // A = V^T: [reflector li][row 16 rt + 4 t + g]
-                    Wa[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[(16 * rt + 4 * t + g) * WY_LD + li], Z[rt][t], Wa[t], 0, 0, 0);
+                for (int u = 0; u < GT; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[u][t] = vb[(16 * (GT * gi + u) + 4 * t + g) * WY_LD + li];   // A = V^T: [reflector li][row]
+#pragma unroll
+                for (int u = 0; u < GT; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) Wa[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], Z[GT * gi + u][t], Wa[t], 0, 0, 0);
             }
         }
         const f64x4_t W = (Wa[0] + Wa[1]) + (Wa[2] + Wa[3]);
         f64x4_t Wn = {0.0, 0.0, 0.0, 0.0};
+        {
+            double a[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)                          // A = -T: [row li][column g + 4 t]
-            Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(buf * 16 + li) * WY_LD + g + 4 * t], W[t], Wn, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) a[t] = Ts[(buf * 16 + li) * WY_LD + g + 4 * t];                       // A = -T: [row li][column g + 4 t]
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                        // k-step outermost: consecutive MFMAs update different tiles
+            for (int t = 0; t < 4; ++t) Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], W[t], Wn, 0, 0, 0);
+        }
 #pragma unroll
-            for (int rt = 0; rt < WY_RT; ++rt) {
-                if (rt >= rt0)                               // A = V: [row 16 rt + li][reflector g + 4 t]
-                    Z[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[(16 * rt + li) * WY_LD + g + 4 * t], Wn[t], Z[rt], 0, 0, 0);
+        for (int gi = 0; gi < WY_RT / GT; ++gi) {
+            if (GT * gi + GT - 1 >= rt0) {
+                double a[GT][4];
+#pragma unroll
+                for (int u = 0; u < GT; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[u][t] = vb[(16 * (GT * gi + u) + li) * WY_LD + g + 4 * t];   // A = V: [row][reflector g + 4 t]
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < GT; ++u)
+                        Z[GT * gi + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], Wn[t], Z[GT * gi + u], 0, 0, 0);
             }
         }
         if (c + 1 < nblk) lstore(buf ^ 1);
