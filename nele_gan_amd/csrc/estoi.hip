@@ -81,25 +81,40 @@ __global__ void estoi_filter_kernel(double* __restrict__ h) {
     if (t < n) h[t] = 5.0 * v / tot;
 }
 
-// grid (ceil(n10/256), B, 2)
+// grid (ceil(n10/256), B, 2).  out[i] = sum_n src[n] * h[8 i + 290 - 5 n], n ascending (the order is part of the result).
+// The taps an output uses are h[p + 5 m], p = (8 i + 290) mod 5: the filter sits in LDS by PHASE, hp[p][m] = h[p + 5 m], and every lane
+// walks m downwards in step - 5 distinct LDS addresses per read instead of 64 lanes striding 64 bytes through h (16-way bank
+// conflicts: 1.2 ms per call at B = 256).  The input samples a block needs are staged in LDS too.
+#define ES_NPH ((2 * ES_HALF + 1 + 4) / 5)            // taps per phase (117)
+#define ES_XIN ((256 * 8 + 2 * ES_HALF) / 5 + 4)     // input samples under 256 consecutive outputs
 __global__ __launch_bounds__(256) void estoi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const double* __restrict__ h, int L, EstoiWs ws) {
-    __shared__ double sh[2 * ES_HALF + 1];
-    for (int i = threadIdx.x; i < 2 * ES_HALF + 1; i += 256) sh[i] = h[i];
-    __syncthreads();
+    __shared__ double hp[5][ES_NPH + 1];
+    __shared__ float xs[ES_XIN];
     const int b = blockIdx.y, sig = blockIdx.z;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= es_n10(ws, b)) return;
+    const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+    if (i0 >= es_n10(ws, b)) return;
+    for (int k = threadIdx.x; k < 5 * (ES_NPH + 1); k += 256) {
+        const int p = k / (ES_NPH + 1), m = k - p * (ES_NPH + 1), idx = p + 5 * m;
+        hp[p][m] = (idx <= 2 * ES_HALF) ? h[idx] : 0.0;
+    }
     const float* src = (sig == 0 ? x : y) + (size_t)b * L;
     L = es_len(ws, b);
-    // out[i] = sum_n src[n] * h[8 i + 290 - 5 n]
+    // inputs of the block: n from ceil((8 i0 + 290 - 580) / 5) (>= 0) to (8 (i0 + 255) + 290) / 5
+    const int c0 = 8 * i0 + ES_HALF;
+    const int nb0 = (c0 - 2 * ES_HALF < 0) ? 0 : (c0 - 2 * ES_HALF + 4) / 5;
+    for (int k = threadIdx.x; k < ES_XIN; k += 256) xs[k] = (nb0 + k < L) ? src[nb0 + k] : 0.f;
+    __syncthreads();
+    if (i >= es_n10(ws, b)) return;
     const int c = 8 * i + ES_HALF;
     int n_lo = (c - 2 * ES_HALF + 4) / 5;  // ceil((c-580)/5) for c-580 >= 0
     if (c - 2 * ES_HALF < 0) n_lo = 0;
     int n_hi = c / 5;
     if (n_hi > L - 1) n_hi = L - 1;
+    const int p = c % 5;                   // tap index c - 5 n = p + 5 m with m = (c - p) / 5 - n
+    const int mtop = (c - p) / 5;
     double acc = 0.0;
-    for (int n = n_lo; n <= n_hi; ++n) acc += (double)src[n] * sh[c - 5 * n];
+    for (int n = n_lo; n <= n_hi; ++n) acc += (double)xs[n - nb0] * hp[p][mtop - n];
     ws.xr[((size_t)b * 2 + sig) * ws.n10 + i] = acc;
 }
 
