@@ -508,24 +508,38 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
     if (tid < SB_J) rstat[2 * tid + 1] = sum / (double)na;
 }
 
-// grid (420, B, 2), block 256: s5
+// grid (28 bands, B, signals), block 256, dynamic LDS NA doubles: s5.  The 15 stacked rows of a band are shifted copies of ONE row of
+// the masked spectrum: it is read once into LDS (the version with one block per stacked row read every band row 30 times), the 15
+// window means are summed from there in the same thread-strided order as before (bit-identical), and the 15 rows go out.
 __global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws, int sig0) {
+    extern __shared__ double sk_v[];                     // v[t] = masked band value - its row mean
     __shared__ double red[8];
-    const int a = blockIdx.x, b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x;
+    __shared__ double mus[SB_K];
+    const int j = blockIdx.x, b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x;
     const int na = ws.info[4 * b + 2];
     const int ncols = na - SB_K + 1;
-    double* dst = ws.Xs + (((size_t)b * 2 + sig) * SB_D + a) * ws.NA;
+    double* dst0 = ws.Xs + (((size_t)b * 2 + sig) * SB_D + j) * ws.NA;               // row a = k * 28 + j
     if (ncols < 2) {
-        for (int t = tid; t < ws.NA; t += 256) dst[t] = 0.0;
+        for (int k = 0; k < SB_K; ++k)
+            for (int t = tid; t < ws.NA; t += 256) dst0[(size_t)k * SB_J * ws.NA + t] = 0.0;
         return;
     }
-    const int k = a / SB_J, j = a - k * SB_J;
-    const double* src = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k;
+    const double* src = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA;
     const double mr = ws.rowstat[(((size_t)b * 2 + sig) * SB_J + j) * 2 + 1];     // row mean of the masked band (removed here)
-    double s = 0.0;
-    for (int t = tid; t < ncols; t += 256) s += src[t] - mr;
-    const double mu = block_sum(s, red) / (double)ncols;
-    for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? (src[t] - mr) - mu : 0.0;
+    for (int t = tid; t < na; t += 256) sk_v[t] = src[t] - mr;
+    __syncthreads();
+    for (int k = 0; k < SB_K; ++k) {
+        double sm = 0.0;
+        for (int t = tid; t < ncols; t += 256) sm += sk_v[t + k];
+        const double mu = block_sum(sm, red) / (double)ncols;
+        if (tid == 0) mus[k] = mu;
+    }
+    __syncthreads();
+    for (int k = 0; k < SB_K; ++k) {
+        const double mu = mus[k];
+        double* dst = dst0 + (size_t)k * SB_J * ws.NA;
+        for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? sk_v[t + k] - mu : 0.0;
+    }
 }
 
 // ---------------------------------------------------------------- float64 MFMA GEMMs
@@ -805,7 +819,13 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
         hipLaunchKernelGGL(siib_spread_kernel, dim3((ws.NA + 255) / 256, B), dim3(256), 0, s, ws, Pf, sig0, sig1);
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
-        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_D, B, nsig), dim3(256), 0, s, ws, sig0);
+        static bool sk_attr = false;
+        if (!sk_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(siib_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            sk_attr = true;
+        }
+        NELE_CHECK_ARG((size_t)ws.NA * sizeof(double) <= 152 * 1024, "nele_metric_siib: signal too long (%d active frames)", ws.NA);
+        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_J, B, nsig), dim3(256), sizeof(double) * (size_t)ws.NA, s, ws, sig0);
         if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
