@@ -127,7 +127,9 @@ def test_haspi_random_dither_is_small_and_seeded(mt):
     assert abs(float(r1[0]) - float(r0[0])) < 0.02 * abs(float(r0[0]))    # N(0, 0.1 dB) jitter: per-mille level effect
 
 
-@pytest.mark.parametrize('n,B', [(420, 3), (97, 2), (16, 4), (420, 17), (420, 33), (512, 9)])   # 17 / 33: ragged cluster launches
+# 17 / 33: ragged cluster launches; 300 / 227 / 448: other hand-over points of the cluster -> register kernel chain (227 = one cluster step),
+# 448 / 512: the 32-tile variant of the blocked back-transformation
+@pytest.mark.parametrize('n,B', [(420, 3), (97, 2), (16, 4), (420, 17), (420, 33), (512, 9), (300, 5), (227, 3), (226, 2), (448, 2)])
 def test_batched_eigensolver_vs_numpy(mt, n, B):
     rs = np.random.RandomState(n)
     A = np.zeros((B, n, n))
