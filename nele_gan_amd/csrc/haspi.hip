@@ -57,6 +57,8 @@ struct HaspiWs {
     double* rsp;     // [B][2][RS_MAXC] resampler: sum of squares of each chunk of outputs
     float* rinfo;    // [B][2][4] {rms of the input, rms of the normalised input, restore gain xRMS / yRMS, -}
     int nchunk, lc;  // scan chunks per row (of the longest row) and their length
+    int lcg;         // samples per IHC-adaptation chunk: GL_N when the gain pass is its own kernel, lc when it rides in the signal-bank pass
+    int fmul;        // haspi_ihc_fir_kernel walks fmul IHC chunks per thread (its 51-sample back-stepping is per thread)
     double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
     double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
@@ -463,6 +465,35 @@ __global__ __launch_bounds__(64) void haspi_bank_prefix_kernel(HaspiWs ws, int s
     }
 }
 
+#define GL_N 2048
+#define GL_W 256
+#define GL_U 8
+// log2 / exp2 on the float32 transcendental unit (v_log_f32 / v_exp_f32, 1 ulp): the dB values they produce are accurate to 1e-6 dB,
+// like the float32 storage of the envelopes (see hp_env_t); the float64 log10 / exp / sqrt calls they replace were 90 % of this
+// kernel's instructions and kept it compute-bound at 0.3 of the HBM rate.
+__device__ __forceinline__ float hp_log2f(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float hp_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
+struct IhcC { double R2, R12C1, R23C2, a11, a12, a21, a22, denom, R1inv; };
+__device__ __forceinline__ IhcC hp_ihc_consts() {
+    const double delta = 2.0;
+    const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
+    const double T = 1 / HP_FS;
+    const double R1 = 1 / delta, R2 = 0.5 * (1 - R1), R3 = R2;
+    const double C1 = tau1 * (R1 + R2) / (R1 * R2);
+    const double C2 = tau2 / ((R1 + R2) * R3);
+    IhcC k;
+    k.a11 = R1 + R2 + R1 * R2 * (C1 / T); k.a12 = -R1; k.a21 = -R3; k.a22 = R2 + R3 + R2 * R3 * (C2 / T);
+    k.denom = 1.0 / (k.a11 * k.a22 - k.a21 * k.a12);
+    k.R1inv = 1.0 / R1; k.R12C1 = R1 * R2 * (C1 / T); k.R23C2 = R2 * R3 * (C2 / T); k.R2 = R2;
+    return k;
+}
+__device__ __forceinline__ void hp_ihc_step(const IhcC& k, double V0, double& V1, double& V2) {
+    const double b1 = V0 * k.R2 + k.R12C1 * V1;
+    const double b2 = k.R23C2 * V2;
+    V1 = k.denom * (k.a22 * b1 - k.a12 * b2);
+    V2 = k.denom * (-k.a21 * b1 + k.a11 * b2);
+}
+
 // grid (ceil(chunks / 2), nsig, B), block 64: lane = (chunk parity) * 32 + channel.  A lane runs BOTH demodulated branches (x cos and
 // x sin) of its channel: the rotation recurrence is computed once per channel instead of once per branch, and the envelope
 // |u|^2 = yr^2 + yi^2 needs no cross-lane exchange (the serial kernel's lane = branch * 32 + channel layout spent half of its issue
@@ -470,7 +501,11 @@ __global__ __launch_bounds__(64) void haspi_bank_prefix_kernel(HaspiWs ws, int s
 // whatever its width).  Same arithmetic per branch as the serial kernel.
 // BM (quality path, pass 2 of the signal bank): also the basilar-membrane motion u_r cos + u_i sin (pyhaspi2.py:897) as its ratio to the
 // envelope |u| - the cosine of the carrier phase, which is all the later stages need (see haspi_quality.h) - and the envelope's sum of squares.
-template <bool SIGNAL, bool PASS2, bool BM = false>
+// GAIN (pass 2 of the signal bank, training path): the compression gain (pyhaspi2.py:982-997), its low-pass, the dB-SL conversion
+// (:1080-1088) and pass 1 of the IHC adaptation ride along - the same arithmetic as haspi_gain_lp_sl_kernel on the same float32-rounded
+// |u|^2, so the result is bit-identical, but the envelope goes to memory once (as dB SL) instead of |u|^2 out, |u|^2 + control in, dB SL
+// out: 8.7 instead of 16 bytes per (sample, channel) over the two kernels.  The IHC chunks are the scan chunks then (ws.lcg = ws.lc).
+template <bool SIGNAL, bool PASS2, bool BM = false, bool GAIN = false>
 __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig0) {
     const int b = blockIdx.z, sig = sig0 + blockIdx.y, lane = threadIdx.x, ch = lane & 31;
     const int chunk = 2 * blockIdx.x + (lane >> 5);
@@ -500,6 +535,32 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
     hp_env_t* out = (SIGNAL ? ws.env : ws.ctl) + ((size_t)row * ws.n24p) * HP_NCH + ch;
     float* cph = BM ? ws.cphi + ((size_t)row * ws.n24p) * HP_NCH + ch : nullptr;
     double ss = 0.0;
+    // ---- GAIN state (see haspi_gain_lp_sl_kernel for the derivation of the constants)
+    const hp_env_t* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
+    const float TEN_LOG10_2 = 3.0102999566398120f, LOG2_10_OVER_20 = 0.16609640474436813f;
+    float slope = 0.f, c_off = 0.f, s_off = 0.f;
+    double gz = 0.0, V1 = 0.0, V2 = 0.0;
+    const double gb0 = 0.095107983402496, ga1 = -0.809784033195007;
+    const IhcC ik = hp_ihc_consts();
+    if (GAIN) {
+        const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+        slope = (float)(1.0 - (1.0 / CR));
+        c_off = (float)(HP_LEVEL + 20.0 * log10(hp_gt(hp_bw1(ch), cf).gain));
+        s_off = (float)(HP_LEVEL + 20.0 * log10(c.gain));
+        for (int n = max(0, n0 - GL_W); n < n0; n += GL_U) {    // low-pass warm-up on the control envelope alone (0.81^256 = 4e-24)
+            float gc[GL_U];
+#pragma unroll
+            for (int u = 0; u < GL_U; ++u) gc[u] = ctl[(size_t)(n + u) * HP_NCH];
+#pragma unroll
+            for (int u = 0; u < GL_U; ++u) {
+                float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
+                le = fminf(fmaxf(le, 30.0f), 100.0f);
+                const double gx = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);
+                const double y = gb0 * gx + gz;
+                gz = gb0 * gx - ga1 * y;
+            }
+        }
+    }
     for (int nb = n0; nb < n1; nb += GS_RC) {
         double xc[GS_RC];
 #pragma unroll
@@ -528,6 +589,24 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
                 if (BM) co[u] = e2 > 0.0 ? (float)((yr * cold + yi * sold) / sqrt(e2)) : 0.f;
             }
         }
+        if (GAIN) {
+            float gc[GS_RC];
+#pragma unroll
+            for (int u = 0; u < GS_RC; ++u) gc[u] = ctl[(size_t)(nb + u) * HP_NCH];
+#pragma unroll
+            for (int u = 0; u < GS_RC; ++u) {
+                float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
+                le = fminf(fmaxf(le, 30.0f), 100.0f);
+                const double gx = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);
+                const double yl = gb0 * gx + gz;
+                gz = gb0 * gx - ga1 * yl;
+                const float g = (float)yl;
+                float y = s_off + TEN_LOG10_2 * hp_log2f(g * g * eo[u]);
+                y = y > 0.0f ? y : 0.0f;
+                eo[u] = y;
+                hp_ihc_step(ik, (double)y, V1, V2);
+            }
+        }
         if (PASS2) {
 #pragma unroll
             for (int u = 0; u < GS_RC; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
@@ -544,6 +623,11 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
         ws.ssp[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
     } else if (BM) {
         ws.sse[((size_t)row * ws.nchunk + chunk) * HP_NCH + ch] = ss;
+    }
+    if (GAIN) {
+        const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
+        double* ihe = ws.ihe + ((size_t)row * ncg + chunk) * 64 + ch;
+        ihe[0] = V1; ihe[32] = V2;
     }
 }
 // eb_BWadjust from the chunk partials (added in chunk order).  grid rows, block 32
@@ -652,41 +736,13 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) 
 // state - the neglected history is below 0.81^256 = 4e-24 of the signal, far under the float64 rounding of the values themselves -
 // which makes the recursion parallel over chunks.  Thread = (chunk of 2048 samples, channel); block = 8 chunks x 32 channels;
 // grid (ceil(n24p / 16384), 2 B).  ctl (|u|^2 of the control bank) is only read, env (|u|^2 of the signal bank) is rewritten in place.
-struct IhcC { double R2, R12C1, R23C2, a11, a12, a21, a22, denom, R1inv; };
-__device__ __forceinline__ IhcC hp_ihc_consts() {
-    const double delta = 2.0;
-    const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
-    const double T = 1 / HP_FS;
-    const double R1 = 1 / delta, R2 = 0.5 * (1 - R1), R3 = R2;
-    const double C1 = tau1 * (R1 + R2) / (R1 * R2);
-    const double C2 = tau2 / ((R1 + R2) * R3);
-    IhcC k;
-    k.a11 = R1 + R2 + R1 * R2 * (C1 / T); k.a12 = -R1; k.a21 = -R3; k.a22 = R2 + R3 + R2 * R3 * (C2 / T);
-    k.denom = 1.0 / (k.a11 * k.a22 - k.a21 * k.a12);
-    k.R1inv = 1.0 / R1; k.R12C1 = R1 * R2 * (C1 / T); k.R23C2 = R2 * R3 * (C2 / T); k.R2 = R2;
-    return k;
-}
-__device__ __forceinline__ void hp_ihc_step(const IhcC& k, double V0, double& V1, double& V2) {
-    const double b1 = V0 * k.R2 + k.R12C1 * V1;
-    const double b2 = k.R23C2 * V2;
-    V1 = k.denom * (k.a22 * b1 - k.a12 * b2);
-    V2 = k.denom * (-k.a21 * b1 + k.a11 * b2);
-}
 
-#define GL_N 2048
-#define GL_W 256
-#define GL_U 8
-// log2 / exp2 on the float32 transcendental unit (v_log_f32 / v_exp_f32, 1 ulp): the dB values they produce are accurate to 1e-6 dB,
-// like the float32 storage of the envelopes (see hp_env_t); the float64 log10 / exp / sqrt calls they replace were 90 % of this
-// kernel's instructions and kept it compute-bound at 0.3 of the HBM rate.
-__device__ __forceinline__ float hp_log2f(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float hp_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
 __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int sig0, int nsig) {
     const int ch = threadIdx.x & 31, row = hp_row(blockIdx.y, sig0, nsig);
-    const int n0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * GL_N;
+    const int n0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * ws.lcg;
     const int n24r = (hp_n24(ws, row >> 1) + HP_CH - 1) / HP_CH * HP_CH;   // whole register chunks of this row
     if (n0 >= n24r) return;
-    const int n1 = min(n0 + GL_N, n24r);
+    const int n1 = min(n0 + ws.lcg, n24r);
     const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
     const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
     const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
@@ -734,8 +790,8 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
             }
         }
     }
-    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
-    double* ihe = ws.ihe + ((size_t)row * ncg + (n0 / GL_N)) * 64 + ch;
+    const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
+    double* ihe = ws.ihe + ((size_t)row * ncg + (n0 / ws.lcg)) * 64 + ch;
     ihe[0] = V1; ihe[32] = V2;
 }
 
@@ -747,8 +803,8 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
 // IHC end states of pass 1 (inside the gain pass) -> start states of pass 2, in place.  grid rows, block 32 (channel).
 __global__ __launch_bounds__(32) void haspi_ihc_prefix_kernel(HaspiWs ws, int sig0, int nsig) {
     const int row = hp_row(blockIdx.x, sig0, nsig), ch = threadIdx.x;
-    const int n24 = hp_n24(ws, row >> 1), ncg = (ws.n24p + GL_N - 1) / GL_N;
-    const int nch = ((n24 + HP_CH - 1) / HP_CH * HP_CH + GL_N - 1) / GL_N;            // chunks the gain pass produced for this row
+    const int n24 = hp_n24(ws, row >> 1), ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
+    const int nch = ((n24 + HP_CH - 1) / HP_CH * HP_CH + ws.lcg - 1) / ws.lcg;            // chunks the gain pass produced for this row
     double* ihe = ws.ihe + ((size_t)row * ncg) * 64 + ch;
     const double p00 = ws.pihc[0], p01 = ws.pihc[1], p10 = ws.pihc[2], p11 = ws.pihc[3];
     double V1 = 0.0, V2 = 0.0;
@@ -785,18 +841,19 @@ __global__ __launch_bounds__(32) void haspi_ihc_prefix_kernel(HaspiWs ws, int si
 __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0, int nsig) {
     __shared__ float ring[64][128];
     const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig), b = row >> 1;
-    const int chunk = blockIdx.x * 4 + (tid >> 5), n0 = chunk * GL_N;
+    const int lcf = ws.lcg * ws.fmul;                          // samples per thread
+    const int chunk = blockIdx.x * 4 + (tid >> 5), n0 = chunk * lcf;
     const int n24 = hp_n24(ws, b), nsub = hp_nsub(ws, b);
-    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
-    const int last = (n24 - 1) / GL_N;                       // chunk that holds the row's last sample
+    const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
+    const int last = (n24 - 1) / lcf;                       // chunk that holds the row's last sample
 #pragma unroll
     for (int q = 0; q < 64; ++q) ring[q][tid] = 0.f;          // own column only: no barrier needed
     if (chunk > last) return;
     const int sh = ws.shift[(size_t)b * HP_NCH + ch];
     // this chunk emits the outputs whose window ends in [n0, n1); the last chunk also those that end behind the row's end
-    const int n1 = (chunk == last) ? n24 + 9 + 26 : n0 + GL_N;
+    const int n1 = (chunk == last) ? n24 + 9 + 26 : n0 + lcf;
     const IhcC k = hp_ihc_consts();
-    const double* ihe = ws.ihe + ((size_t)row * ncg + chunk) * 64 + ch;
+    const double* ihe = ws.ihe + ((size_t)row * ncg + (size_t)chunk * ws.fmul) * 64 + ch;
     double V1 = ihe[0], V2 = ihe[32];                        // true state at the chunk start (haspi_ihc_prefix_kernel)
     const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
     int nstart = n0;
@@ -908,7 +965,7 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
     if (b == 0 && ch < 2) {                              // IHC state transition over one gain-pass chunk: column ch of the 2x2 matrix
         const IhcC k = hp_ihc_consts();
         double V1 = (ch == 0), V2 = (ch == 1);
-        for (int n = 0; n < GL_N; ++n) hp_ihc_step(k, 0.0, V1, V2);
+        for (int n = 0; n < ws.lcg; ++n) hp_ihc_step(k, 0.0, V1, V2);
         ws.pihc[ch] = V1; ws.pihc[2 + ch] = V2;
     }
     if (b == 0 && ch < HP_NFILT) ws.benv[ch] = (0.5 - 0.5 * cospi(2.0 * (double)ch / 51.0)) / 25.5;   // np.hanning(52) / sum, for haspi_envfilt_kernel
@@ -1382,7 +1439,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     int lc = GS_LC;
     while ((n24p + lc - 1) / lc > GS_MAXC) lc += GS_LC;
-    const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + GL_N - 1) / GL_N;
+    const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + (lc < GL_N ? lc : GL_N) - 1) / (lc < GL_N ? lc : GL_N);
     TAKE(ssp, double, (size_t)B * 2 * nchunk * HP_NCH);
     TAKE(est, double, (size_t)B * 2 * nchunk * 256);
     TAKE(pmat, double, (size_t)(1 + B * 2) * HP_NCH * 16);
@@ -1407,7 +1464,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(cpart, double, (size_t)B * MS_MAXC * 64 * 5);
 #undef TAKE
     if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; w->ngb = ngb;
-             w->cphi = nullptr; w->sse = nullptr; }
+             w->cphi = nullptr; w->sse = nullptr; w->lcg = GL_N; w->fmul = 1; }
     return o;
 }
 
@@ -1419,9 +1476,12 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
 }
 
 // The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
-static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws, int sig0, int nsig, hipStream_t s,
+static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws_in, int sig0, int nsig, hipStream_t s,
                         bool quality = false) {
     const int rows = B * nsig;
+    static int bank_gain = -1;                             // NELE_HASPI_BANK_GAIN=0: the gain pass as its own kernel (A/B diagnostic)
+    if (bank_gain < 0) { const char* e_ = getenv("NELE_HASPI_BANK_GAIN"); bank_gain = !(e_ && e_[0] == '0'); }
+    HaspiWs ws = ws_in;
     static int par_iir = -1;                               // NELE_HASPI_PAR_IIR=0: the serial recurrence kernels (A/B diagnostic)
     if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
     static int fused_gain = -1;
@@ -1429,6 +1489,9 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     const int par_iir_saved = par_iir, fused_gain_saved = fused_gain;
     if (quality) par_iir = fused_gain = 1;                     // the quality path exists for the scan kernels only
     struct Restore { int& a; int& b; int va, vb; ~Restore() { a = va; b = vb; } } restore_{par_iir, fused_gain, par_iir_saved, fused_gain_saved};
+    const bool in_bank = bank_gain && par_iir && fused_gain && !quality;     // gain pass inside pass 2 of the signal bank
+    ws.lcg = in_bank ? ws.lc : GL_N;
+    ws.fmul = 1;
     hipLaunchKernelGGL(haspi_rms_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
     if (fs_in != 24000) {
         hipLaunchKernelGGL(haspi_resample_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
@@ -1446,6 +1509,7 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         if (quality) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else if (in_bank) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
@@ -1453,11 +1517,12 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     }
     if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone (+ constant tables)
     if (fused_gain && par_iir) {
-        NELE_PROF("haspi_gain_lp_sl_kernel", s,
-                  hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
+        if (!in_bank)
+            NELE_PROF("haspi_gain_lp_sl_kernel", s,
+                      hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
         hipLaunchKernelGGL(haspi_ihc_prefix_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         if (quality) return;                                   // haspi_quality.h goes on from the dB-SL envelope + IHC start states
-        hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * GL_N - 1) / (4 * GL_N), rows), dim3(128), 0, s, ws, sig0, nsig);
+        hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * ws.lcg * ws.fmul - 1) / (4 * ws.lcg * ws.fmul), rows), dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
         if (fused_gain) {

@@ -54,11 +54,11 @@ __device__ __forceinline__ float hq_gauss(unsigned long long seed, unsigned long
 // cphi <- BM motion.
 __global__ __launch_bounds__(256) void hq_ihc_bm_kernel(HaspiWs ws, QualWs q, int sig0, int nsig) {
     const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig);
-    const int chunk = blockIdx.x * 8 + (tid >> 5), n0 = chunk * GL_N;
+    const int chunk = blockIdx.x * 8 + (tid >> 5), n0 = chunk * ws.lcg;
     const int n24 = hp_n24(ws, row >> 1);
     if (n0 >= n24) return;
-    const int n1 = min(n0 + GL_N, (n24 + GL_U - 1) / GL_U * GL_U);      // whole groups: the buffers are padded to n24p (multiple of 32)
-    const int ncg = (ws.n24p + GL_N - 1) / GL_N;
+    const int n1 = min(n0 + ws.lcg, (n24 + GL_U - 1) / GL_U * GL_U);      // whole groups: the buffers are padded to n24p (multiple of 32)
+    const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
     const IhcC k = hp_ihc_consts();
     const double* ihe = ws.ihe + ((size_t)row * ncg + chunk) * 64 + ch;
     double V1 = ihe[0], V2 = ihe[32];
