@@ -222,7 +222,7 @@ def main():
     wtag = 'D.conv5.wgrad'        # the memory-side companion figure: D's 5th conv weight gradient (events on its own stream; includes its partial reduction)
     ops.PROFILE = {'gstep.' + tag: [], tag: [], wtag: []}
     from nele_gan_amd import _lib
-    htag = 'haspi_gain_lp_sl_kernel'   # the HBM-side figure: HASPI's fused compression-gain pass, timed by the library's HIP-event hook
+    htag = 'haspi_bank_gain_kernel'    # the HBM-side figure: HASPI's signal filter bank + compression-gain pass, timed by the library's HIP-event hook
     if 'haspi' in metrics:
         _lib.profile_begin(htag)
     stage_ev = []
@@ -319,16 +319,18 @@ def main():
                                      'traffic': pmc.get('conv_wgrad_tile16_kernel<4, 7>', {}).get('hbm_bytes_corrected'),
                                      'algorithmic_bytes': prof_w[0][2], 'launch_ms': w_ms, 'launches_timed': len(prof_w)}
         if hbm_ms:
-            # HASPI compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step: reads the control and the signal
-            # envelope (float32 |u|^2, [rows][n24][32]) once and rewrites the signal envelope in place: 12 bytes per (sample, channel)
+            # HASPI signal filter bank (pass 2) + compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step - the
+            # step's largest single HBM consumer since the gain pass moved into it: reads the middle-ear signal (float64, once per sample)
+            # and the control envelope (float32 |u|^2), writes the dB-SL envelope (float32): 8 bytes per (sample, channel) + 8 per sample.
+            # It is bound by the float64 issue rate of its recurrences, not by HBM: the fraction says how far from the memory roof it runs.
             n24p = (int(a.length * 1.5) + 31) // 32 * 32
-            h_bytes = float(a.batch) * n24p * 32 * 12
+            h_bytes = float(a.batch) * n24p * (32 * 8 + 8)
             h_ms = sum(hbm_ms) / len(hbm_ms)
-            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': htag + ' (pyhaspi2.py:982-997, 1080-1088 fused; %d rows x %d samples x 32 channels)' % (a.batch, n24p),
+            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'haspi_bank_scan_kernel<true,true,false,true> (pyhaspi2.py:863-915, 982-997, 1080-1088 fused; %d rows x %d samples x 32 channels)' % (a.batch, n24p),
                                    'achieved': h_bytes / (h_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': h_bytes / (h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   'traffic': pmc.get(htag, {}).get('hbm_bytes_corrected'), 'launch_ms': h_ms,
-                                   'algorithmic_bytes': h_bytes, 'launches_timed': len(hbm_ms)}
+                                   'traffic': pmc.get('haspi_bank_scan_kernel<true, true, false, true>', {}).get('hbm_bytes_corrected'), 'launch_ms': h_ms,
+                                   'algorithmic_bytes': h_bytes, 'launches_timed': len(hbm_ms), 'limited_by': 'float64 issue rate (recurrences), not HBM'}
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}

@@ -1509,7 +1509,9 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         if (quality) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
-        else if (in_bank) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else if (in_bank)
+            NELE_PROF("haspi_bank_gain_kernel", s,
+                      hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0));
         else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
     } else {
         hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
