@@ -499,8 +499,9 @@ struct Tile16Args {
     int KH, KW, steps_per_seg, SB;
     ConvGeom g;
     long long* dbg;        // optional per-phase clock totals of workgroup 0 (benchmark harness only)
-    int ntiles;            // tile columns x tile rows x utterances (conv1d strip kernel: N chunks per strip)
+    int ntiles;            // tile columns x tile rows x utterances (conv1d strip kernel: N chunks per strip that have their own workgroup)
     int SBH;               // conv1d strip kernel: utterances x rows
+    int ncl;               // conv1d strip kernel: N chunks a workgroup walks itself over its staged strip (1 or N / 64)
 };
 __device__ __forceinline__ int g_wout(const Tile16Args& p) { return p.g.Wout; }
 __device__ __forceinline__ int g_hout(const Tile16Args& p) { return p.g.Hout; }
@@ -766,6 +767,13 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
 // positions, staged once in LDS (bf16) and addressed Toeplitz-style; the weight fragments of the workgroup's 4 n-tiles stream
 // through LDS in chunks of SB k-steps as in conv_tile16_kernel.  grid (ceil(Wout/128), N/64 chunks, B*Hout).
 #define C1D_TW 128
+// Position stride of the strip in LDS.  With C a multiple of 128 the plain stride (2 C bytes) is a multiple of the 256-byte bank cycle: the
+// 16 lanes of an A-fragment read (16 consecutive positions, the same 16 bytes of each) all hit the same banks.  PAD elements per position
+// shift consecutive positions; a k-step (32 consecutive k) never straddles positions when 32 | C, so its offset is tap * CP + channel offset.
+#ifndef C1D_PADE
+#define C1D_PADE 8
+#endif
+#define C1D_PAD(C_) (((C_) % 128 == 0) ? C1D_PADE : 0)
 template <int TN>
 __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 halo[];    // [RS] + 64 slack, then the weight chunk [SB][TN][64][8]
@@ -784,7 +792,9 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     }
     const int b = bz / g.Hout, ho = bz - b * g.Hout;
     const int wcols = C1D_TW + p.KW - 1;
-    const int RS = wcols * g.C;
+    const int CP = g.C + (((g.C & (g.C - 1)) == 0) ? C1D_PAD(g.C) : 0);   // position stride in LDS (see C1D_PAD; padded only for powers of two)
+    const int lgC = (CP == g.C) ? 30 : __ffs(g.C) - 1;
+    const int RS = wcols * CP;
     const int wi0 = wo0 + g.iw0;
     const int vcols = max(0, min(wcols, g.W - wi0));
     const float* src = p.A + (((size_t)b * g.H + ho + g.ih0) * g.W + wi0) * g.C;
@@ -793,7 +803,7 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     const int cfrag = SB * TN * 64;
     {   // stage the input strip (float32 -> bf16), zero beyond the input
         const int nval = vcols * g.C;
-        for (int e = tid * 8; e < RS; e += 2048) {
+        for (int e = tid * 8; e < wcols * g.C; e += 2048) {
             bf16x8 v;
             if (e < nval) {
                 const float4 a = *reinterpret_cast<const float4*>(src + e);
@@ -804,7 +814,8 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
             }
-            *reinterpret_cast<bf16x8*>(halo + e) = v;
+            const int px = (CP == g.C) ? 0 : e / g.C;
+            *reinterpret_cast<bf16x8*>(halo + e + px * (CP - g.C)) = v;
         }
         if (tid < 64) halo[RS + tid] = (__bf16)0.f;
     }
@@ -812,32 +823,42 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     constexpr int NBR = (TILE16_SBMAX * TN + 3) / 4;
     bf16x8 breg[NBR];
     const int nq = (cfrag + 255) >> 8;
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(p.Wfrag) + (size_t)nb * 4 * 64;
-    auto wload = [&](int c) {
+    const bf16x8* wsrc = nullptr;
+    int woff[NBR];                                       // fragment offsets inside a chunk: the same for every chunk
 #pragma unroll
-        for (int q = 0; q < NBR; ++q) {
-            if (q < nq) {
-                const int f = min(tid + 256 * q, cfrag - 1), u = f / (TN * 64), r = f - u * (TN * 64);
-                breg[q] = wsrc[((size_t)(c * SB + u) * p.NT) * 64 + r];
-            }
-        }
+    for (int q = 0; q < NBR; ++q) {
+        const int f = min(tid + 256 * q, cfrag - 1), u = f / (TN * 64), r = f - u * (TN * 64);
+        woff[q] = u * p.NT * 64 + r;
+    }
+    auto wload = [&](int c) {
+        const bf16x8* wc = wsrc + (size_t)c * SB * p.NT * 64;
+#pragma unroll
+        for (int q = 0; q < NBR; ++q)
+            if (q < nq) breg[q] = wc[woff[q]];
     };
     auto wstore = [&]() {
 #pragma unroll
         for (int q = 0; q < NBR; ++q)
             if (q < nq) reinterpret_cast<bf16x8*>(wbuf)[tid + 256 * q] = breg[q];
     };
-    wload(0);
-    wstore();
     // this wave's two position tiles: columns 16 (wave + 4 t)
     int pb[2];
     unsigned valid = 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int c = wave + 4 * t;
-        pb[t] = (16 * c + li) * g.C + 8 * lg;
+        pb[t] = (16 * c + li) * CP + 8 * lg;
         if (wo0 + 16 * c < g.Wout) valid |= 1u << t;
     }
+    // Large batches (every CU has strips of its own): ONE workgroup per strip walks all N / 64 output-channel chunks over the strip it
+    // staged instead of four workgroups staging the same strip (128 + k - 1 input positions x C channels, converted to bf16).  The
+    // epilogue then transposes through its own LDS scratch (behind the weight chunk), not through the strip.
+    const int nb_end = nb + p.ncl;
+    float* epbase = (p.ncl > 1) ? reinterpret_cast<float*>(wbuf + ((cfrag * 8 + 2047) & ~2047)) : reinterpret_cast<float*>(halo);
+    for (; nb < nb_end; ++nb) {
+    wsrc = reinterpret_cast<const bf16x8*>(p.Wfrag) + (size_t)nb * 4 * 64;
+    wload(0);
+    wstore();
     f32x4 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -847,13 +868,19 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf) + lane;
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) wload(c + 1);
-        const __bf16* hk = halo + c * SB * 32;
-        for (int u = 0; u < SB; ++u) {
-            bf16x8 bfr[TN], af[2];
+        const __bf16* hk = halo;
+        const int ug0 = c * SB;                            // k-step ug: elements [32 ug, 32 ug + 32) of the im2col row
+        // fragments double buffered in registers: the ds_reads of step u + 1 are issued before the MFMAs of step u (one wave per SIMD and
+        // one workgroup per CU here: nothing else hides an LDS round trip per k-step)
+        auto ldfrag = [&](int u, bf16x8 (&af)[2], bf16x8 (&bfr)[TN]) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bfr[j] = wl[(u * TN + j) * 64];
+            const int k0 = (ug0 + u) * 32;
+            const int koff = k0 + (k0 >> lgC) * (CP - g.C);     // = tap * CP + channel offset (C is a power of two whenever CP != C)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hk + pb[i] + u * 32);
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hk + pb[i] + koff);
+        };
+        auto mm = [&](const bf16x8 (&af)[2], const bf16x8 (&bfr)[TN]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (valid & (1u << i)) {
@@ -861,7 +888,17 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
             }
+        };
+        bf16x8 a0[2], b0[TN], a1[2], b1[TN];
+        ldfrag(0, a0, b0);
+        int u = 0;
+        for (; u + 1 < SB; u += 2) {
+            ldfrag(u + 1, a1, b1);
+            mm(a0, b0);
+            ldfrag(min(u + 2, SB - 1), a0, b0);
+            mm(a1, b1);
         }
+        if (u < SB) mm(a0, b0);
         if (c + 1 < nchunk) {
             __syncthreads();
             wstore();
@@ -870,7 +907,7 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     }
     // ---- epilogue through LDS (float4 stores along the channels)
     __syncthreads();
-    float* ep = reinterpret_cast<float*>(halo) + wave * (16 * 68);
+    float* ep = epbase + wave * (16 * 68);
     constexpr int NQ = TN * 4;
     const int n0 = nb * 64;
 #pragma unroll
@@ -904,6 +941,8 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
                 *reinterpret_cast<float4*>(p.out + o_off) = v;
             }
         }
+    }
+    if (nb + 1 < nb_end) __syncthreads();                  // the next chunk's first weights replace this chunk's last ones
     }
 }
 
@@ -1737,7 +1776,7 @@ static int tile16_sb(const ConvGeom& g) {
 static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out) {
     if (KH != 1 || N % 4 || g.OC % 4 || g.C % 8 || KW * g.C != g.seglen || g.seglen != g.Ktot || g.seglen % 32) return 0;
     if (N > 64 && N % 64) return 0;
-    const long long RS = (long long)(C1D_TW + KW - 1) * g.C;
+    const long long RS = (long long)(C1D_TW + KW - 1) * (g.C + (((g.C & (g.C - 1)) == 0) ? C1D_PAD(g.C) : 0));
     const int sps = g.seglen / 32, TNsel = (N >= 64) ? 4 : (N + 15) / 16;
     for (int d = TILE16_SBMAX; d >= 1; --d) {
         if (sps % d) continue;
@@ -1831,9 +1870,14 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
                 cattr = true;
             }
             const int nchunksN = (N > 64) ? N / 64 : 1, TNsel = (N >= 64) ? 4 : p.NT;
-            t.ntiles = nchunksN; t.SBH = BH;
             const int nstrips = ((p.g.Wout + C1D_TW - 1) / C1D_TW) * BH;
-            const dim3 grid((unsigned)(nchunksN * 8 * ((nstrips + 7) / 8)));
+            static int walk_on = -1;                       // NELE_CONV1D_WALK=0: one workgroup per (strip, N chunk) at every batch (A/B)
+            if (walk_on < 0) { const char* e = getenv("NELE_CONV1D_WALK"); walk_on = !(e && e[0] == '0'); }
+            const size_t ep_bytes = 4 * 16 * 68 * 4;
+            const bool walk = walk_on && nchunksN > 1 && nstrips >= 256 && clds + 4096 + ep_bytes <= 158 * 1024;
+            t.ntiles = walk ? 1 : nchunksN; t.ncl = walk ? nchunksN : 1; t.SBH = BH;
+            if (walk) clds = ((clds + 2047) & ~(size_t)2047) + 4096 + ep_bytes;
+            const dim3 grid((unsigned)(t.ntiles * 8 * ((nstrips + 7) / 8)));
             switch (TNsel) {
                 case 1: hipLaunchKernelGGL((conv1d_tile16_kernel<1>), grid, dim3(256), clds, s, t); break;
                 case 2: hipLaunchKernelGGL((conv1d_tile16_kernel<2>), grid, dim3(256), clds, s, t); break;
