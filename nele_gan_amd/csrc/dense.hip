@@ -328,6 +328,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define SPAN16_BM 512
 #define SPAN16_MAXRUN 10
+// Position stride of the staged span in LDS.  With C = 64 (D.conv5's data gradient: 64 gradient channels) the plain stride is 128 bytes and
+// the 16 positions of an A-fragment read fall on two alternating bank groups - 69 % of the kernel's LDS cycles were bank conflicts (PMC,
+// rounds 1 and 2).  8 elements of padding per position make consecutive positions 144 bytes apart: 16 lanes x 16 bytes cover all banks
+// once.  A k-step never straddles positions when 32 | C; its offset becomes tap * CP + channel offset.
+#define SPAN16_PAD(C_) ((((C_) & ((C_) - 1)) == 0 && (C_) >= 64) ? 8 : 0)
 
 struct Span16Args {
     const float* A;
@@ -358,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
     const int m0 = mt * SPAN16_BM;
     if (m0 >= p.M) return;
     const int mcount = min(SPAN16_BM, p.M - m0);
-    const int halo = (p.KW - 1) * g.C;
+    const int CP = g.C + SPAN16_PAD(g.C), lgC = (CP == g.C) ? 30 : __ffs(g.C) - 1;
+    const int halo = (p.KW - 1) * g.C, halo_p = (p.KW - 1) * CP;
 
     if (tid == 0) {
         int b, ho, wo;
@@ -369,8 +375,8 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
             run_gbase[r] = (int)((((size_t)b * g.H + ho + g.ih0) * g.W + wo + g.iw0) * g.C);
             run_len[r] = len;
             run_off[r] = off;
-            for (int i = 0; i < len; ++i) posbase[done + i] = off + i * g.C;
-            off += len * g.C + halo;
+            for (int i = 0; i < len; ++i) posbase[done + i] = off + i * CP;
+            off += len * CP + halo_p;
             done += len;
             left -= len;
             wo = 0;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
                             bf16x8 v;
                             v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
                             v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-                            *reinterpret_cast<bf16x8*>(dst + e) = v;
+                            *reinterpret_cast<bf16x8*>(dst + e + (e >> lgC) * (CP - g.C)) = v;
                         }
                     }
                     __syncthreads();
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
                 for (int h = 0; h < 2; ++h) {
                     bf16x8 af[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(span16 + pb[4 * h + i] + s * 32);
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(span16 + pb[4 * h + i] + s * 32 + ((s * 32) >> lgC) * (CP - g.C));
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1827,8 +1833,9 @@ static int span16_supported(int M, int N, const ConvGeom& g, int KH, int KW) {
     if (N > 64 || g.C % 8 || g.Wout < 64 || KH * g.seglen != g.Ktot || KW * g.C != g.seglen) return 0;
     const int maxrun = (SPAN16_BM + g.Wout - 1) / g.Wout + 1;
     if (maxrun > SPAN16_MAXRUN) return 0;
-    const long long el = (long long)SPAN16_BM * g.C + (long long)maxrun * (KW - 1) * g.C + 64;
-    if (el * 2 > 76 * 1024) return 0;
+    const int cp = g.C + SPAN16_PAD(g.C);
+    const long long el = (long long)SPAN16_BM * cp + (long long)maxrun * (KW - 1) * cp + 64;
+    if (el * 2 > 79 * 1024) return 0;
     return 1;
 }
 extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int KH, int KW) {
@@ -1922,7 +1929,8 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
         return NELE_OK;
     }
     const int maxrun = (SPAN16_BM + p.g.Wout - 1) / p.g.Wout + 1;
-    const size_t lds = ((size_t)SPAN16_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C + 64) * 2;
+    const int cp16 = p.g.C + SPAN16_PAD(p.g.C);
+    const size_t lds = ((size_t)SPAN16_BM * cp16 + (size_t)maxrun * (KW - 1) * cp16 + 64) * 2;
     const int gx = ((M + SPAN16_BM - 1) / SPAN16_BM + 7) / 8 * 8;     // a multiple of 8: the same number of ids per XCD
     static bool attr_done = false;
     if (!attr_done) {
