@@ -2014,10 +2014,49 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         t.A = A; t.dOut = dOut; t.part = workspace; t.N = N; t.B = M / (p.g.Hout * p.g.Wout); t.KH = KH; t.KW = KW;
         t.nth = (p.g.Hout + WT_TH - 1) / WT_TH; t.ntw = (p.g.Wout + WT_TW - 1) / WT_TW; t.ntiles = t.B * t.nth * t.ntw;
         if (G > t.ntiles) G = t.ntiles;
+        const int ktw = (nkt + 3) / 4;
+        {   // Workgroups that do not fit the chip at once run as a second, nearly empty round: KH * 64 = 576 workgroups on 512 slots (two
+            // per CU for D.conv5) took 1.64 x as long as KH * 56 = 504 (3.20 -> 1.95 ms at B = 256).  Pick the group count (a multiple
+            // of 8, at most the partial slots of the workspace) that minimises rounds x tiles per workgroup.
+            static int ncu = 0;
+            static int occ_tab[5][3] = {{0}};
+            const int ki = ktw <= 2 ? 0 : (ktw <= 4 ? 1 : 2), ni = NT < 1 ? 1 : (NT > 4 ? 4 : NT);
+            if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+            if (!occ_tab[ni][ki]) {
+                int occ = 0;
+                const void* fn = nullptr;
+#define WT_FN(NT_, K_) reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>)
+#define WT_FNK(K_) (ni == 1 ? WT_FN(1, K_) : ni == 2 ? WT_FN(2, K_) : ni == 3 ? WT_FN(3, K_) : WT_FN(4, K_))
+                fn = ki == 0 ? WT_FNK(2) : (ki == 1 ? WT_FNK(4) : WT_FNK(7));
+#undef WT_FNK
+#undef WT_FN
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, (size_t)wt_lds) != hipSuccess || occ < 1) occ = 1;
+                hipFuncAttributes fa;
+                if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {      // registers: 512 per SIMD lane, one wave of the workgroup per SIMD
+                    const int by_regs = 512 / ((fa.numRegs + 7) & ~7);
+                    if (by_regs >= 1 && by_regs < occ) occ = by_regs;
+                }
+                if (getenv("NELE_DEBUG_WGRAD")) fprintf(stderr, "wgrad tile <%d,%d>: occupancy %d (regs %d, lds %lld + %zu)\n", ni, ki, occ, fa.numRegs, wt_lds, fa.sharedSizeBytes);
+                occ_tab[ni][ki] = occ;
+            }
+            const long long slots = (long long)ncu * occ_tab[ni][ki];
+            static int gauto = -1;                        // NELE_WGRAD_AUTOGROUPS=0: the fixed 64 groups (A/B diagnostic)
+            if (gauto < 0) { const char* e = getenv("NELE_WGRAD_AUTOGROUPS"); gauto = !(e && e[0] == '0'); }
+            if (gauto && G >= 16) {
+                long long best = -1;
+                int bestG = G;
+                for (int cand = G & ~7; cand >= 8; cand -= 8) {    // (any count up to the workspace's partial slots works for this kernel)
+                    const long long rounds = ((long long)KH * cand + slots - 1) / slots, per = (t.ntiles + cand - 1) / cand;
+                    const long long cost = rounds * per;
+                    if (best < 0 || cost < best) { best = cost; bestG = cand; }
+                }
+                G = bestG;
+            }
+        }
         t.G = G; t.g = p.g;
         t.bpart = db ? workspace + (size_t)G * N * p.g.Ktot : nullptr;
         const dim3 grid(KH * G);
-        const int ktw = (nkt + 3) / 4;
         static bool wattr = false;
         if (!wattr) {
 #define WT_ATTR(NT_, K_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
