@@ -114,6 +114,16 @@ int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, co
                         float slope, const int* geom_host, int KH, int KW, long long a_elems, void* stream);
 int nele_conv_wgrad(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                     const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
+/* The pooling gradient of D's last conv layer (autograd of model.py:124-126) stored as bf16: its two consumers - the layer's data and
+ * weight gradients - round their operands to bf16 anyway, and the data gradient re-stages it once per kernel row.  Same layouts and zero
+ * border as the float32 buffer; only for geometries that run on the span kernel / the 2-D weight-gradient tile kernel
+ * (nele_conv_span_bf16_a16_supported; NELE_ERR_UNSUPPORTED otherwise). */
+int nele_conv_span_bf16_a16_supported(int M, int N, const int* geom_host, int KH, int KW);
+int nele_conv_span_bf16_a16(const void* A16, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                            float slope, const int* geom_host, int KH, int KW, long long a_elems, void* stream);
+int nele_conv_wgrad_bf16_d16_supported(int M, int N, const int* geom_host, int KH, int KW);
+int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
+                             const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
 
 /* PyTorch parameter layout [N][Cvalid][KH][KW] (optionally / sigma[0]) -> GEMM layouts:
  * Wf[n][kh][kw][c] (c zero-padded to C) and, if Wb != NULL, the flipped data-gradient layout
@@ -186,6 +196,10 @@ int nele_gap_mlp_fwd_var(const float* act, int B, int P, int Wout, const int* wv
 int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
                          const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
                          int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream);
+/* ... with the pooling gradient written as bf16 (see nele_conv_span_bf16_a16) */
+int nele_gap_mlp_bwd_var16(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                           const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                           int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream);
 int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream);
 
 /* torch.optim.Adam (train_nele.py:89-91) on flat buffers; step counts from 1. */

@@ -345,6 +345,7 @@ struct Span16Args {
     float slope;
     int KH, KW, steps_per_seg;
     ConvGeom g;
+    int a16;               // A is bf16 in memory (same layout): staged as is - half the bytes of the re-staging, no conversion
 };
 
 template <int TN>
@@ -424,6 +425,11 @@ __global__ __launch_bounds__(256, 2) void conv_span16_kernel(Span16Args p) {
                         const int nfl = run_len[r] * g.C + halo;          // multiple of 8
                         const float* src = p.A + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
                         __bf16* dst = span16 + run_off[r];
+                        if (p.a16) {
+                            const __bf16* src16 = reinterpret_cast<const __bf16*>(p.A) + (size_t)run_gbase[r] + (size_t)kh * g.segstride;
+                            for (int e = tid * 8; e < nfl; e += 2048)
+                                *reinterpret_cast<bf16x8*>(dst + e + (e >> lgC) * (CP - g.C)) = *reinterpret_cast<const bf16x8*>(src16 + e);
+                        } else
                         for (int e = tid * 8; e < nfl; e += 2048) {
                             const float4 a = *reinterpret_cast<const float4*>(src + e);
                             const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
@@ -1388,9 +1394,10 @@ struct WgradTileArgs {
     int N, B, KH, KW;
     int nth, ntw, ntiles, G;
     ConvGeom g;
+    int d16;             // dOut is bf16 in memory
 };
 
-template <int NT, int KTW>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj)
+template <int NT, int KTW, bool D16 = false>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj); D16: dOut is bf16 in memory
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wt_lds[];     // halo rows [WT_TH][RS] + 64 slack, then dOut tile [256][WT_NP]
     __shared__ float bred[16][64];
@@ -1448,7 +1455,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
             }
         }
         // ---- dOut tile [256 positions][N] (zero for positions outside the output and n >= N)
-        {
+        if (D16) {                                       // bf16 in memory: staged as is
+            bf16x4 rh[16];
+            const __bf16* d16 = reinterpret_cast<const __bf16*>(p.dOut);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
+                const int ho = min(ho0 + r, g.Hout - 1), wo = min(wo0 + c, g.Wout - 1);
+                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + min(4 * dnq, p.N - 4);
+                rh[it] = *reinterpret_cast<const bf16x4*>(d16 + off);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
+                const bool ok = (ho0 + r < g.Hout) && (wo0 + c < g.Wout) && (4 * dnq < p.N);
+                bf16x4 v = rh[it];
+                if (!ok) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; v[2] = (__bf16)0.f; v[3] = (__bf16)0.f; }
+                *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
+                if (want_bias) { bq[0] += (float)v[0]; bq[1] += (float)v[1]; bq[2] += (float)v[2]; bq[3] += (float)v[3]; }
+            }
+        } else {
             float4 rd[16];
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -1845,8 +1871,27 @@ extern "C" int nele_conv_span_bf16_supported(int M, int N, const int* geom, int 
     if (g.Wout >= 32 && conv1d16_sb(g, N, KH, KW, nullptr)) return 1;
     return span16_supported(M, N, g, KH, KW);
 }
+static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                               float slope, const int* geom, int KH, int KW, long long a_elems, int a16, void* stream);
 extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
                                    float slope, const int* geom, int KH, int KW, long long a_elems, void* stream) {
+    return conv_span_bf16_impl(A, Wfrag, bias, aux, out, M, N, epi, slope, geom, KH, KW, a_elems, 0, stream);
+}
+// The same with the input tensor stored as bf16 (same [B][H][W][C] layout and zero border).  Only geometries that run on the span kernel
+// (NELE_ERR_UNSUPPORTED otherwise): D.conv5's data gradient, whose input - the pooling gradient - is re-staged once per kernel row.
+extern "C" int nele_conv_span_bf16_a16(const void* A16, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                                       float slope, const int* geom, int KH, int KW, long long a_elems, void* stream) {
+    return conv_span_bf16_impl(reinterpret_cast<const float*>(A16), Wfrag, bias, aux, out, M, N, epi, slope, geom, KH, KW, a_elems, 1, stream);
+}
+extern "C" int nele_conv_span_bf16_a16_supported(int M, int N, const int* geom, int KH, int KW) {
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    if (g.Wout >= 32 && tile16_th(g, N, KH, KW)) return 0;
+    if (g.Wout >= 32 && conv1d16_sb(g, N, KH, KW, nullptr)) return 0;
+    return span16_supported(M, N, g, KH, KW);
+}
+static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* bias, const float* aux, float* out, int M, int N, int epi,
+                               float slope, const int* geom, int KH, int KW, long long a_elems, int a16, void* stream) {
     NELE_CHECK_ARG(A && Wfrag && out && geom, "nele_conv_span_bf16: null pointer");
     if (!nele_conv_span_bf16_supported(M, N, geom, KH, KW)) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_span_bf16: geometry not supported");
     NELE_CHECK_ARG(a_elems < 2147483647LL, "nele_conv_span_bf16: input buffer too large for 32-bit offsets");
@@ -1855,6 +1900,9 @@ extern "C" int nele_conv_span_bf16(const float* A, const void* Wfrag, const floa
     p.slope = slope; p.KH = KH; p.KW = KW;
     memcpy(&p.g, geom, sizeof(ConvGeom));
     p.steps_per_seg = (p.g.seglen + 31) / 32;
+    p.a16 = a16;
+    if (a16 && !nele_conv_span_bf16_a16_supported(M, N, geom, KH, KW))
+        return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_span_bf16_a16: this geometry does not run on the span kernel");
     NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_span_bf16: epilogue needs bias");
     NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_span_bf16: epilogue needs aux");
     hipStream_t s = as_stream(stream);
@@ -1977,10 +2025,30 @@ extern "C" int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* wo
                                     const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
     return conv_wgrad_impl(A, dOut, workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 1, stream);
 }
+static bool wgrad_tile_eligible(int M, int N, const ConvGeom& g, int KH, int KW) {
+    static int wt_on = -1;
+    if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
+    const int nkt = (g.seglen + 15) / 16;
+    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * g.C + 64 + 256 * WT_NP) * 2;
+    return wt_on && N <= 64 && g.C % 8 == 0 && KW * g.C == g.seglen && nkt <= 28 && g.Wout >= 32 && wt_lds <= 64 * 1024 &&
+           M % (g.Hout * g.Wout) == 0;
+}
+extern "C" int nele_conv_wgrad_bf16_d16_supported(int M, int N, const int* geom, int KH, int KW) {
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    return wgrad_tile_eligible(M, N, g, KH, KW) ? 1 : 0;
+}
+// ... and the output gradient stored as bf16 (same layout); only for layers that run on the 2-D tile kernel (NELE_ERR_UNSUPPORTED otherwise)
+extern "C" int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
+                                        const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
+    return conv_wgrad_impl(A, reinterpret_cast<const float*>(dOut16), workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 3, stream);
+}
 
 static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                            const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, int bf16, void* stream) {
     NELE_CHECK_ARG(A && dOut && workspace && geom && dW, "nele_conv_wgrad: null pointer");
+    const int d16 = (bf16 >> 1) & 1;                       // dOut stored as bf16
+    bf16 &= 1;
     WgradArgs p;
     memcpy(&p.g, geom, sizeof(ConvGeom));
     int st = check_geom("nele_conv_wgrad", p.g, M, N);
@@ -2008,10 +2076,9 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         if (genv > 0 && genv < G) G = genv;
     }
     bool tiled = false;
-    if (bf16 && wt_on && N <= 64 && p.g.C % 8 == 0 && KW * p.g.C == p.g.seglen && nkt <= 28 && p.g.Wout >= 32 && wt_lds <= 64 * 1024 &&
-        M % (p.g.Hout * p.g.Wout) == 0) {
+    if (bf16 && wgrad_tile_eligible(M, N, p.g, KH, KW)) {
         WgradTileArgs t;
-        t.A = A; t.dOut = dOut; t.part = workspace; t.N = N; t.B = M / (p.g.Hout * p.g.Wout); t.KH = KH; t.KW = KW;
+        t.A = A; t.dOut = dOut; t.part = workspace; t.N = N; t.B = M / (p.g.Hout * p.g.Wout); t.KH = KH; t.KW = KW; t.d16 = d16;
         t.nth = (p.g.Hout + WT_TH - 1) / WT_TH; t.ntw = (p.g.Wout + WT_TW - 1) / WT_TW; t.ntiles = t.B * t.nth * t.ntw;
         if (G > t.ntiles) G = t.ntiles;
         const int ktw = (nkt + 3) / 4;
@@ -2059,13 +2126,15 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         const dim3 grid(KH * G);
         static bool wattr = false;
         if (!wattr) {
-#define WT_ATTR(NT_, K_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+#define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); } while (0)
             WT_ATTR(1, 2); WT_ATTR(2, 2); WT_ATTR(3, 2); WT_ATTR(4, 2); WT_ATTR(1, 4); WT_ATTR(2, 4); WT_ATTR(3, 4); WT_ATTR(4, 4);
             WT_ATTR(1, 7); WT_ATTR(2, 7); WT_ATTR(3, 7); WT_ATTR(4, 7);
 #undef WT_ATTR
             wattr = true;
         }
-#define WT_LAUNCH(NT_, K_) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_>), grid, dim3(256), (size_t)wt_lds, s, t)
+#define WT_LAUNCH(NT_, K_) do { if (d16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true>), grid, dim3(256), (size_t)wt_lds, s, t); \
+                                else hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_>), grid, dim3(256), (size_t)wt_lds, s, t); } while (0)
 #define WT_PICK(K_) switch (NT) { case 1: WT_LAUNCH(1, K_); break; case 2: WT_LAUNCH(2, K_); break; case 3: WT_LAUNCH(3, K_); break; default: WT_LAUNCH(4, K_); break; }
         if (ktw <= 2) { WT_PICK(2) } else if (ktw <= 4) { WT_PICK(4) } else { WT_PICK(7) }
 #undef WT_PICK
@@ -2076,6 +2145,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         p.part = workspace;
         p.bpart = t.bpart;
     }
+    if (!tiled && d16) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_wgrad_bf16_d16: this layer does not run on the tile kernel");
     if (!tiled && KH == 1 && KW == 1 && p.g.C == 4 && p.g.Ktot == 4 && (N == 4 || N == 8) && p.g.OC % 4 == 0 && splits >= 1) {
         // pointwise layer (D conv1): memory-bound row reduction; as many workgroups as there are partial slots, at most 64
         int sp = splits < 64 ? splits : 64;

@@ -210,8 +210,11 @@ __global__ __launch_bounds__(64) void mlp_bwd_kernel(const float* __restrict__ d
 
 // d act[b][pos][c] = dpooled[b][c] / P * lrelu'(act), written into the zero-bordered gradient buffer
 // [B][OH][OW][64] at offset (oh0, ow0).
+// T = float, or __bf16: the consumers (the layer's data- and weight-gradient kernels) round their operands to bf16 anyway, and the data
+// gradient re-stages this buffer once per kernel row - half the bytes and no conversion there (see conv_span16_kernel).
+template <typename T>
 __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, int Hout, int Wout, int OH, int OW,
-                               int oh0, int ow0, float slope, float* __restrict__ gbuf, const int* __restrict__ wvalid) {
+                               int oh0, int ow0, float slope, T* __restrict__ gbuf, const int* __restrict__ wvalid) {
     const int b = blockIdx.y, P = Hout * Wout;
     const int wv = wvalid ? min(wvalid[b], Wout) : Wout;
     const float invP = 1.f / (float)(Hout * wv);
@@ -220,7 +223,7 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* _
         const int ho = pos / Wout, wo = pos - ho * Wout;
         const float a = act[(size_t)b * P * 64 + i];
         const float d = (wo < wv) ? dpooled[(size_t)b * 64 + c] * invP * (a > 0.f ? 1.f : slope) : 0.f;
-        gbuf[(((size_t)b * OH + ho + oh0) * OW + wo + ow0) * 64 + c] = d;
+        gbuf[(((size_t)b * OH + ho + oh0) * OW + wo + ow0) * 64 + c] = (T)d;
     }
 }
 
@@ -350,9 +353,9 @@ extern "C" int nele_gap_mlp_bwd(const float* dscore, const float* score, const f
     return nele_gap_mlp_bwd_var(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, nullptr, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled,
                                 gbuf, stream);
 }
-extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
-                                    const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
-                                    int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream) {
+static int gap_mlp_bwd_impl(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                            const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                            int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf, int gbuf_bf16, void* stream) {
     NELE_CHECK_ARG(dscore && score && h1 && h2 && mlp_host && dz3 && dz2 && dz1 && dpooled && B > 0, "nele_gap_mlp_bwd: bad arguments");
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
@@ -362,11 +365,25 @@ extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, con
     if (gbuf) {
         NELE_CHECK_ARG(act, "nele_gap_mlp_bwd: act required for the pooling gradient");
         const int P = Hout * Wout;
-        hipLaunchKernelGGL(gap_bwd_kernel, dim3(min(512, (P * 64 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout, OH, OW, oh0,
-                           ow0, slope, gbuf, wvalid);
+        if (gbuf_bf16) hipLaunchKernelGGL(gap_bwd_kernel<__bf16>, dim3(min(512, (P * 64 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout,
+                                          OH, OW, oh0, ow0, slope, (__bf16*)gbuf, wvalid);
+        else hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(min(512, (P * 64 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout, OH, OW, oh0,
+                                ow0, slope, (float*)gbuf, wvalid);
         NELE_CHECK_LAUNCH("nele_gap_mlp_bwd(gap)");
     }
     return NELE_OK;
+}
+extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                                    const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                                    int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, float* gbuf, void* stream) {
+    return gap_mlp_bwd_impl(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, wvalid, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled, gbuf, 0,
+                            stream);
+}
+extern "C" int nele_gap_mlp_bwd_var16(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+                                      const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                                      int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream) {
+    return gap_mlp_bwd_impl(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, wvalid, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled, gbuf16,
+                            1, stream);
 }
 
 extern "C" int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream) {

@@ -438,6 +438,10 @@ class _DBuffers:
         self.span_b = [ops.span_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
         self.span16_f = [ops.span16_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
         self.span16_b = [ops.span16_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
+        # bf16 mode: the last layer's output gradient (the pooling gradient) as bfloat16 - its data gradient re-stages it once per kernel
+        # row; allocated on first use (same shape and zero border as gbuf[-1])
+        self.grad16_ok = ops.grad16_supported(B, cins[-1], self.gb[-1], _D_CONVS[-1][0], self.gw[-1])
+        self.gbuf16 = None
         self.P = self.dims[-1][0] * self.dims[-1][1]
         self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
         self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
@@ -675,9 +679,13 @@ class _DiscriminatorBase(nn.Module):
         wgrad = self.weight_grad_enabled
         Ho, Wo, _ = bf.dims[-1]
         p5 = bf.pad[-1]
-        call('nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]), self._mlp_ptrs(w), nout,
-             SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1), ptr(bf.dpooled), ptr(bf.gbuf[-1]),
-             stream())
+        g16 = self.precision == 'bf16' and bf.grad16_ok
+        if g16 and bf.gbuf16 is None:
+            bf.gbuf16 = torch.zeros(bf.gbuf[-1].shape, dtype=torch.bfloat16, device=bf.gbuf[-1].device)
+        glast = bf.gbuf16 if g16 else bf.gbuf[-1]          # the last layer's output gradient, as its two consumers read it
+        call('nele_gap_mlp_bwd_var16' if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
+             self._mlp_ptrs(w), nout, SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1),
+             ptr(bf.dpooled), ptr(glast), stream())
         ddin = None
         # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
         # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on two more streams
@@ -728,7 +736,8 @@ class _DiscriminatorBase(nn.Module):
                     ctx = torch.cuda.stream(wst)
                     ctx.__enter__()
                     wst.wait_event(ev)
-                ops.conv_wgrad(a_in, bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False, bf16=(self.precision == 'bf16' and l > 0),
+                ops.conv_wgrad(a_in, glast if l == len(_D_CONVS) - 1 else bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False,
+                               bf16=(self.precision == 'bf16' and l > 0),
                                tag='D.conv%d.wgrad' % (l + 1))
                 call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
@@ -737,7 +746,8 @@ class _DiscriminatorBase(nn.Module):
                     ctx.__exit__(None, None, None)
             if l > 0:
                 if self.precision == 'bf16' and bf.span16_b[l]:
-                    ops.conv_span_bf16(bf.gbuf[l], w['wbf16'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
+                    ops.conv_span_bf16(glast if l == len(_D_CONVS) - 1 else bf.gbuf[l], w['wbf16'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci,
+                                       EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
                 elif bf.span_b[l]:
                     ops.conv_span(bf.gbuf[l], w['wbf'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
                 else:

@@ -22,6 +22,10 @@ _SIGS = {
     'nele_conv_span': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
     'nele_conv_span_bf16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
     'nele_conv_span_bf16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_conv_span_bf16_a16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_conv_span_bf16_a16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, c_longlong, _P],
+    'nele_conv_wgrad_bf16_d16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_conv_wgrad_bf16_d16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep_frag16': [_P, c_int, c_int, c_int, c_int, _P, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
@@ -45,6 +49,8 @@ _SIGS = {
     'nele_gap_mlp_fwd_var': [_P, c_int, c_int, c_int, _P, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P, _P],
     'nele_gap_mlp_bwd_var': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, _P, c_int, c_int, c_int,
                              c_int, _P, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_bwd_var16': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                               c_int, _P, _P, _P, _P, _P, _P],
     'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     'nele_adam_step': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P],
     'nele_adam_step_guarded': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P, _P],
@@ -127,6 +133,14 @@ def span16_supported(B, N, g):
     return bool(_lib.lib.nele_conv_span_bf16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
 
 
+def grad16_supported(B, N_dgrad, g_dgrad, N_wgrad, g_wgrad):
+    """Can this layer's output gradient live in memory as bfloat16?  (data gradient on the span kernel, weight gradient on the tile kernel)"""
+    if os.environ.get('NELE_GRAD16', '1') == '0':
+        return False
+    return bool(_lib.lib.nele_conv_span_bf16_a16_supported(B * g_dgrad.Hout * g_dgrad.Wout, N_dgrad, g_dgrad.arr, g_dgrad.KH, g_dgrad.KW)) and \
+        bool(_lib.lib.nele_conv_wgrad_bf16_d16_supported(B * g_wgrad.Hout * g_wgrad.Wout, N_wgrad, g_wgrad.arr, g_wgrad.KH, g_wgrad.KW))
+
+
 def frag16_elems(N, seglen, KH):
     return int(_lib.lib.nele_weight_frag16_elems(N, seglen, KH))
 
@@ -136,12 +150,14 @@ def weight_prep_frag16(Wg, N, Ktot, seglen, KH, Wfrag):
 
 
 def conv_span_bf16(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
+    """A float32, or bfloat16 (nele_conv_span_bf16_a16: the span kernel only)."""
     M = B * g.Hout * g.Wout
     prof = PROFILE is not None and tag in PROFILE
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('nele_conv_span_bf16', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE, g.arr, g.KH, g.KW, A.numel(), stream())
+    call('nele_conv_span_bf16_a16' if A.dtype == torch.bfloat16 else 'nele_conv_span_bf16', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE,
+         g.arr, g.KH, g.KW, A.numel(), stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
@@ -158,8 +174,12 @@ def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True, bf16=False
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('nele_conv_wgrad_bf16' if bf16 else 'nele_conv_wgrad', ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db),
-         int(accumulate), stream())
+    fn = 'nele_conv_wgrad_bf16' if bf16 else 'nele_conv_wgrad'
+    if dOut.dtype == torch.bfloat16:
+        if not bf16:
+            raise ValueError('conv_wgrad: a bfloat16 output gradient needs bf16=True')
+        fn = 'nele_conv_wgrad_bf16_d16'
+    call(fn, ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db), int(accumulate), stream())
     if prof:
         e1.record()
         # algorithmic bytes: the input and the output gradient read once (float32), the weight gradient written once
