@@ -316,7 +316,7 @@ def main():
             out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
                                      'achieved': w_flops / (w_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                                      'frac': w_flops / (w_ms * 1e-3) / 1e12 / peak,
-                                     'traffic': pmc.get('conv_wgrad_tile16_kernel<4, 7>', {}).get('hbm_bytes_corrected'),
+                                     'traffic': (pmc.get('conv_wgrad_tile16_kernel<4, 7, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, false>') or pmc.get('conv_wgrad_tile16_kernel<4, 7>') or {}).get('hbm_bytes_corrected'),
                                      'algorithmic_bytes': prof_w[0][2], 'launch_ms': w_ms, 'launches_timed': len(prof_w)}
         if hbm_ms:
             # HASPI signal filter bank (pass 2) + compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step - the
