@@ -279,3 +279,36 @@ def test_bf16_tile_kernels_on_ragged_frame_counts(mods, T):
         assert np.isfinite(b[i]).all()
         assert np.abs(a[i] - b[i]).max() < 5e-2 * np.abs(a[i]).max(), i
         assert (a[i] * b[i]).sum() > 0.9999 * np.linalg.norm(a[i]) * np.linalg.norm(b[i]), i
+
+
+def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, monkeypatch):
+    """bf16 mode stores the last conv layer's output gradient (the pooling gradient) as bfloat16 where the span / tile kernels take it
+    (nele_gap_mlp_bwd_var16 -> nele_conv_span_bf16_a16 + nele_conv_wgrad_bf16_d16).  Both consumers round that operand to bf16 anyway, so
+    everything the data-gradient chain produces - the input gradient and every other layer's weight gradient - must be BIT-identical to the
+    float32-buffer path (NELE_GRAD16=0), conv5's weight gradient too (same bf16 operands, same accumulation order); only conv5's bias
+    gradient sums bf16-rounded instead of float32 values - and since the pooling gradient takes just two values per (utterance, channel),
+    that rounding does not average out: up to 2^-8 relative, inside the documented bf16-mode tolerance (3e-2)."""
+    from nele_gan_amd import ops
+    B, T = 3, 251
+    torch.manual_seed(5)
+    x = torch.rand(B, 3, 64, T, device='cuda') * 2
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('NELE_GRAD16', flag)
+        D = load_recipe(mods.Discriminator(), 33)
+        D.precision = 'bf16'
+        D.eval()
+        xin = x.clone().requires_grad_(True)
+        D(xin).pow(2).sum().backward()
+        bf = next(iter(D._bufs.values()))
+        assert bf.grad16_ok == (flag == '1') and (bf.gbuf16 is not None) == (flag == '1')
+        res[flag] = (xin.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
+    assert ops.grad16_supported.__doc__
+    gin1, g1 = res['1']
+    gin0, g0 = res['0']
+    assert torch.equal(gin1, gin0)
+    for k in g0:
+        if k.endswith('layers.4.bias') or k.endswith('layers.4.conv.bias'):
+            torch.testing.assert_close(g1[k], g0[k], rtol=4e-3, atol=4e-3 * float(g0[k].abs().max()))
+        else:
+            assert torch.equal(g1[k], g0[k]), k
