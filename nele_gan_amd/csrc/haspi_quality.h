@@ -142,15 +142,29 @@ __global__ __launch_bounds__(128) void hq_segment_kernel(HaspiWs ws, QualWs q) {
     for (int r = k16; r < HQ_XR; r += 16) xs[r][c] = 0.f;
     double res[2] = {0.0, 0.0};
     double MSx = 0.0, MSy = 0.0;
-    for (int a = 0; a < 4; ++a) {                            // 0, 1: envelopes of x, y; 2, 3: BM motion of x, y
-        const float* src = ((a < 2) ? (const float*)ws.env : ws.cphi) + ((size_t)(2 * b + (a & 1)) * ws.n24p) * HP_NCH + ch0;
-        __syncthreads();                                     // the previous array's readers are done with the tile
-        for (int r = tid >> 1; r < rows; r += 64) {
-            const int m = base + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m >= 0 && m < n24) v = *reinterpret_cast<const float4*>(src + (size_t)m * HP_NCH + 4 * (tid & 1));
-            *reinterpret_cast<float4*>(&tile[r][4 * (tid & 1)]) = v;
+    // the tile rows of array a + 1 are loaded into registers before array a is processed (one global round trip per array and workgroup was
+    // most of this kernel's time: 12 barriers and 4 exposed load latencies for 61 KB of input)
+    constexpr int HQ_NLD = HQ_TROWS / 64;                    // float4 per thread and array
+    float4 pre[HQ_NLD];
+    auto srcof = [&](int a) { return ((a < 2) ? (const float*)ws.env : ws.cphi) + ((size_t)(2 * b + (a & 1)) * ws.n24p) * HP_NCH + ch0; };
+    auto gload = [&](int a) {
+        const float* src = srcof(a);
+#pragma unroll
+        for (int u = 0; u < HQ_NLD; ++u) {
+            const int r = (tid >> 1) + 64 * u, m = base + r;
+            pre[u] = (r < rows && m >= 0 && m < n24) ? *reinterpret_cast<const float4*>(src + (size_t)m * HP_NCH + 4 * (tid & 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    gload(0);
+    for (int a = 0; a < 4; ++a) {                            // 0, 1: envelopes of x, y; 2, 3: BM motion of x, y
+        const float* src = srcof(a);
+        __syncthreads();                                     // the previous array's readers are done with the tile
+#pragma unroll
+        for (int u = 0; u < HQ_NLD; ++u) {
+            const int r = (tid >> 1) + 64 * u;
+            if (r < rows) *reinterpret_cast<float4*>(&tile[r][4 * (tid & 1)]) = pre[u];
+        }
+        if (a + 1 < 4) gload(a + 1);
         __syncthreads();
         double s = 0.0;
         if (a < 2) {
