@@ -12,9 +12,13 @@ Workload at N = 1 = BASELINE.json configs[2] (the largest single-GPU configurati
 carries two companions measured after the timed region: "configs1" (BASELINE configs[1]: batch 32,
 SIIB+ESTOI) and "nonperiodic" (the headline workload at L = 63 900, which is not a multiple of SIIB's
 200-sample hop, so SIIB's frame-periodic shortcut does not apply).
-Multi-GPU: utterances shard across ranks.  Default = weak scaling (--batch per GPU); with
---global-batch G the G utterances are split over the ranks (strong scaling; `--gpus 8 --global-batch 1024`
-is BASELINE configs[3]).  One flat RCCL all-reduce of the G and of the D gradients per step.
+Multi-GPU: utterances shard across ranks, one flat RCCL all-reduce of the G and of the D gradients
+per step.  `python bench.py --gpus N` with N > 1 and no RANK in the environment starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+(never an exec) before anything touches the GPU, relays its JSON line and exits with its code; under torchrun the
+script is a rank.  Default at N > 1 = BASELINE configs[3]: global batch 1024 split over the ranks (strong scaling,
+north_star's ">= 6x at 8 GPUs"); `--batch B` with N > 1 = B utterances per GPU (weak scaling); `--global-batch G`
+any other total.  `--dry-run` runs the launcher, the sharding and the collectives on CPU (gloo) without kernels.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,6 +34,76 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
+PROFILE_ROUND = 'r03'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
+
+
+def csrc_sha():
+    """sha256 over the kernel sources: PMC counters of another tree's kernels must not be printed next to this tree's timings."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'nele_gan_amd', 'csrc')
+    for n in sorted(os.listdir(d)):
+        if n.endswith(('.hip', '.h')):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as a fresh child process tree and relay its output.  Nothing in this process
+    has touched the GPU (torch is not even imported), and the child is a subprocess, not an exec."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + '\n')
+    if line is not None:
+        print(line)
+    return r.returncode if (r.returncode != 0 or line is not None) else 1
+
+
+def dry_run(a, world, rank):
+    """Launcher + sharding + collectives on CPU (gloo), no kernels: what `--gpus N` does around the step, checkable without GPUs."""
+    import torch
+    import torch.distributed as dist
+    from nele_gan_amd import dist as ndist
+    if world > 1:
+        dist.init_process_group('gloo')
+    lo, hi = ndist.shard_range(a.global_batch, rank, world)
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+    g = torch.full((2093120,), float(rank + 1))            # G's gradient bucket (8.37 MB)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ndist.allreduce_mean_(g)
+        time.sleep(0.001 * (hi - lo) / 64.0)
+    dt = time.perf_counter() - t0
+    shard = torch.tensor([float(hi - lo)])
+    if world > 1:
+        dist.all_reduce(shard)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'utterances/sec per GAN_epoch step (G+D+metric loss)', 'value': a.global_batch * a.steps / dt, 'unit': 'utterances/s',
+                          'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+                          'scaling': a.scaling, 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic', 'dry_run': True,
+                          'config': {'workload': 'DRY RUN (CPU, gloo, no kernels): launcher + sharding + collectives only',
+                                     'global_batch': a.global_batch, 'parallelism': 'dp%d' % world},
+                          'ranks_seen': int(ones.item()), 'shard_sum': int(shard.item()), 'shard_rank0': [lo, hi]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def cpu_baseline(metrics, length, n_utt, seed_start=9000):
@@ -81,13 +155,13 @@ def inference_rate(tr, batch, K, rank):
             'realtime_factor': batch * 8.0 / dt}
 
 
-def companion(a, metric_str, batch, length, steps, main_tr=None):
+def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None):
     """The canonical step of another workload on this GPU (fresh trainer, 2 warm-up steps, `steps` timed steps)."""
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
     tr = GanTrainer(metric_str)
-    tr.D.precision = tr.G.precision = a.precision
+    tr.D.precision = tr.G.precision = precision or a.precision
     if main_tr is not None:
         # same logical streams as the headline trainer: the runtime multiplexes streams onto 4 hardware queues, and a second set of
         # seven streams would time-slice with the (idle) first set's queues (DESIGN 6, "hardware queues")
@@ -115,7 +189,7 @@ def companion(a, metric_str, batch, length, steps, main_tr=None):
     assert bool(torch.isfinite(tgt).all()) and bool(torch.isfinite(ld))
     tr.check_status()
     return {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_step': dt * 1e3, 'batch': batch, 'samples_per_utterance': length,
-            'metrics': metric_str, 'steps': steps}
+            'metrics': metric_str, 'steps': steps, 'dtype': precision or a.precision}
 
 
 def epoch_equivalent(tr, cw, nw, K, utts):
@@ -152,33 +226,57 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='utterances per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=0, help='utterances per GPU (N = 1 default: 256 = BASELINE configs[2]; with N > 1: weak scaling)')
     ap.add_argument('--global-batch', type=int, default=0, metavar='G',
-                    help='total utterances, split over the ranks (strong scaling; overrides --batch)')
+                    help='total utterances, split over the ranks (strong scaling; N > 1 default: 1024 = BASELINE configs[3]; overrides --batch)')
+    ap.add_argument('--dry-run', action='store_true', help='CPU / gloo: launcher, sharding and collectives only, no kernels')
+    ap.add_argument('--no-isolated', action='store_true', help='skip the isolated D.conv5 forward launches after the timed region (profiling runs: '
+                                                                 'the kernel statistics then hold the step\'s own launches only)')
     ap.add_argument('--length', type=int, default=64000)
     ap.add_argument('--metrics', default='siib&haspi&estoi')
     ap.add_argument('--companions', type=int, default=1, help='also run the configs[1] and non-periodic-length companions (N = 1 only; 0 = skip)')
     ap.add_argument('--cpu-utts', type=int, default=32, help='utterances in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--breakdown', action='store_true', help='per-stage timing to stderr')
-    ap.add_argument('--inference', type=int, default=0, metavar='K',
+    ap.add_argument('--inference', type=int, default=-1, metavar='K',
                     help='also time K batches of the inference path (BASELINE configs[4]: 8 s utterances, features -> G -> resynthesis -> RMS 0.03 -> PCM_16); reported as "inference"')
-    ap.add_argument('--epoch-equivalent', type=int, default=0, metavar='K',
+    ap.add_argument('--epoch-equivalent', type=int, default=-1, metavar='K',
                     help='also time K units of the reference epoch mix per batch (SURVEY 8d): 1 G-step, generate, targets of the generated and of the\n'
                          'pre-enhanced (DRC) example, 6 D-steps (2 examples x 3 passes, train_nele.py:342-426); reported as "epoch_equivalent"')
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'],
                     help='MFMA operand type of the discriminator conv forward / data-gradient passes (f32 accumulate; BASELINE configs[1] names bf16)')
     a = ap.parse_args()
-
-    import torch
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))              # before torch is imported: this process never touches a GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    # workload defaults: N = 1 -> configs[2] (256 utterances on the GPU); N > 1 -> configs[3] (1024 utterances over the ranks)
+    a.scaling = 'weak'
+    if a.global_batch == 0 and a.batch == 0:
+        if world > 1:
+            a.global_batch = 1024
+        else:
+            a.batch = 256
+    if a.global_batch > 0:
+        a.scaling = 'strong'
+    companions_default = world == 1 and a.batch == 256 and a.length == 64000 and a.metrics == 'siib&haspi&estoi'
+    if a.inference < 0:
+        a.inference = 10 if (companions_default and a.companions) else 0
+    if a.epoch_equivalent < 0:
+        a.epoch_equivalent = 2 if (companions_default and a.companions) else 0
+    if a.dry_run:
+        if a.global_batch == 0:
+            a.global_batch = a.batch * world
+        return dry_run(a, world, rank)
+
+    import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
 
     from nele_gan_amd import dist as ndist
     from nele_gan_amd import ops, synth
@@ -187,14 +285,18 @@ def main():
     tr = GanTrainer(a.metrics, device='cuda:%d' % local)
     tr.D.precision = a.precision
     tr.G.precision = a.precision
-    scaling = 'weak'
+    scaling = a.scaling
     if a.global_batch > 0:
         assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs (equal shards: one plain mean all-reduce)"
         lo, hi = ndist.shard_range(a.global_batch, rank, world)      # contiguous utterance shard of this rank
         a.batch = hi - lo
-        scaling = 'strong'
     else:
         lo = rank * a.batch
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, device='cuda')
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     c, v = synth.batch(a.batch, a.length, start=lo)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 
@@ -260,26 +362,46 @@ def main():
     iso_tag = 'iso.D.conv5.fwd'
     ops.PROFILE = {iso_tag: []}
     torch.cuda.synchronize()
-    tr.D.eval()
-    tr.D.profile_prefix = 'iso.'
-    with torch.no_grad():
-        for _ in range(6):
-            tr.D.forward_packed(tr._last_din)
-    torch.cuda.synchronize()
-    iso = ops.PROFILE[iso_tag][1:]
-    tr.D.profile_prefix = ''
-    tr.D.train()
+    iso = []
+    if not a.no_isolated:            # profiling runs switch this off: the per-step kernel sums must hold the step's own launches only
+        tr.D.eval()
+        tr.D.profile_prefix = 'iso.'
+        with torch.no_grad():
+            for _ in range(6):
+                tr.D.forward_packed(tr._last_din)
+        torch.cuda.synchronize()
+        iso = ops.PROFILE[iso_tag][1:]
+        tr.D.profile_prefix = ''
+        tr.D.train()
     ops.PROFILE = None
+    # the step's two gradient all-reduces (G 8.37 MB, D 1.37 MB) alone, after the timed region: what a step pays for them at most
+    allreduce_ms = None
+    if world > 1:
+        gg, gd = tr.G.flat_parameters().grad, tr.D.flat_parameters().grad
+        for _ in range(3):
+            ndist.allreduce_mean_(gg); ndist.allreduce_mean_(gd)
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(10):
+            ndist.allreduce_mean_(gg); ndist.allreduce_mean_(gd)
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - ta) / 10 * 1e3
     if rank == 0:
         T = 1 + a.length // 256
         # HBM bytes per launch (PMC FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950-corrected) and MFMA-busy figures of the
         # SAME command on this tree: profiles/r02/traffic.json (tools/prof_r02.sh + tools/make_traffic_json.py); counters cannot be
         # read from inside the process, so the line carries them only for the workload the committed passes were taken on
         pmc = {}
+        pmc_note = 'no committed PMC passes for this workload'
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'traffic.json')))
+            tj = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'traffic.json')))
             if tj.get('workload') == {'batch': a.batch, 'length': a.length, 'metrics': a.metrics, 'precision': a.precision}:
-                pmc = tj['kernels']
+                if tj.get('csrc_sha') == csrc_sha():
+                    pmc = tj['kernels']
+                    pmc_note = 'profiles/%s/traffic.json (csrc %s)' % (PROFILE_ROUND, tj.get('csrc_sha'))
+                else:
+                    pmc_note = 'profiles/%s/traffic.json was taken on other kernel sources (csrc %s, this tree %s): counters dropped' % (
+                        PROFILE_ROUND, tj.get('csrc_sha'), csrc_sha())
         except Exception:
             pmc = {}
         traffic = pmc.get('conv_tile16_kernel<4, 8>', {}).get('hbm_bytes_corrected')
@@ -307,8 +429,12 @@ def main():
                          'launch_ms_gstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_g) / max(1, len(prof_g)),   # beside the half-GPU tridiagonalisation
                          'launch_ms_dstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_d) / max(1, len(prof_d)),
                          'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
-                         'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops},
+                         'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops,
+                         'pmc_source': pmc_note},
+            'ranks_seen': ranks_seen,
         }
+        if allreduce_ms is not None:
+            out['allreduce_ms_per_step'] = allreduce_ms
         if prof_w:
             # D.conv5 weight gradient: dW[64][3888] = dY^T im2col(X), an MFMA-bound GEMM (arithmetic intensity ~1000 FLOP/B)
             w_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof_w) / len(prof_w)
@@ -340,6 +466,8 @@ def main():
         if world == 1 and a.companions:
             out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12, tr)
             out['nonperiodic'] = companion(a, a.metrics, a.batch, 63900, 4, tr)
+            # the parity mode (float32 MFMA operands: what every golden-vector test runs in) on BASELINE configs[1]'s shape
+            out['configs1_f32'] = companion(a, 'siib&estoi', 32, 64000, 8, tr, precision='f32')
     ee = None
     if a.epoch_equivalent > 0:           # every rank takes part (g_step / d_step all-reduce when world > 1)
         ee = epoch_equivalent(tr, cw, nw, a.epoch_equivalent, a.batch * world)

@@ -61,13 +61,22 @@ _lib._SIGS['nele_eigh_workspace_bytes'] = _lib.lib.nele_eigh_workspace_bytes.arg
 _ws_cache = {}
 
 
-def _workspace(kind, nbytes, dev):
+def _workspace(kind, nbytes, dev, cache=None):
+    """Grow-only scratch buffer per (kind, device).  ``cache``: the dict that owns it - the module-global one for the one-shot batch_*
+    calls, or a dict held by the caller (a GanTrainer) for the split objects' multi-GB workspaces, so that they are released with
+    their owner instead of living until the process exits."""
+    cache = _ws_cache if cache is None else cache
     key = (kind, str(dev))
-    t = _ws_cache.get(key)
+    t = cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _ws_cache[key] = t
+        cache[key] = t
     return t
+
+
+def release_workspaces():
+    """Drop the module-global scratch buffers (they are re-created on demand)."""
+    _ws_cache.clear()
 
 
 def eigh_batched(A):
@@ -128,8 +137,8 @@ class SiibSplit:
             self.x, self.y, _ = _pair(x, y)
         B, L = self.x.shape
         # own workspace: the clean-signal state must survive until degraded_part(), whatever else calls batch_siib() meanwhile
-        # (``owner``: one workspace per owner, e.g. per trainer, when split objects of several owners are alive at the same time)
-        self.ws = _workspace('siib_split' if owner is None else 'siib_split:%s' % owner, _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device)
+        # (``owner``: a dict held by the caller, e.g. one per trainer, that owns the workspace - released with the trainer)
+        self.ws = _workspace('siib_split', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device, cache=owner)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
@@ -236,8 +245,7 @@ class HaspiSplit:
         self.fs = int(fs)
         B, L = self.x.shape
         self.lengths = None if lengths is None else lengths.to(device=self.x.device, dtype=torch.int32).contiguous()
-        self.ws = _workspace('haspi_split' if owner is None else 'haspi_split:%s' % owner, _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs),
-                             self.x.device)
+        self.ws = _workspace('haspi_split', _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs), self.x.device, cache=owner)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 2), dtype=torch.int32, device=self.x.device)

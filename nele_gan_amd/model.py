@@ -145,7 +145,25 @@ def _empty(shape, dev):
 _G_LAYERS = [(128, 256, 5), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 64, 5)]
 
 
+MAX_BUFFER_SHAPES = int(os.environ.get('NELE_MAX_BUFFER_SHAPES', '6'))
+
+
+def _lru_get(cache, key, make):
+    """Per-(B, T) activation buffer sets, least-recently-used bounded: a long run over padded batches of many different shapes (D epochs
+    on a real corpus) would otherwise pin one multi-hundred-MB buffer set per shape until the process ends."""
+    bf = cache.pop(key, None)
+    if bf is None:
+        while len(cache) >= MAX_BUFFER_SHAPES:
+            cache.pop(next(iter(cache)))             # dicts keep insertion order: the first key is the least recently used
+        bf = make()
+    cache[key] = bf                                  # (re-)insert as most recent
+    return bf
+
+
 def _check_generation(ctx, name):
+    if ctx.key not in ctx.module._bufs:
+        raise RuntimeError("%s: backward() after %d other (batch, frames) shapes went through the module - the cached activations of "
+                           "this graph have been evicted (raise NELE_MAX_BUFFER_SHAPES)" % (name, MAX_BUFFER_SHAPES))
     """The activation buffers are cached per (B, T): a second forward of the same shape overwrites what the first graph's backward
     pass needs.  Each forward bumps the buffer set's generation; a backward whose generation is stale raises instead of silently
     differentiating the wrong activations."""
@@ -293,9 +311,7 @@ class Generator_Conv1D_cLN(nn.Module):
 
     def _get_bufs(self, B, T, dev):
         key = (B, T, str(_norm_dev(dev)))
-        if key not in self._bufs:
-            self._bufs[key] = _GBuffers(B, T, dev)
-        return key, self._bufs[key]
+        return key, _lru_get(self._bufs, key, lambda: _GBuffers(B, T, dev))
 
     def _gemm(self, A, q, back, bias, aux, out, B, N, epi, g):
         """Conv1d / Linear GEMM of layer q (forward or data-gradient weights): the strip tile kernel in bf16 mode where the
@@ -540,9 +556,7 @@ class _DiscriminatorBase(nn.Module):
 
     def _get_bufs(self, B, T, dev):
         key = (B, T, str(_norm_dev(dev)))
-        if key not in self._bufs:
-            self._bufs[key] = _DBuffers(B, T, dev, self._cin)
-        return key, self._bufs[key]
+        return key, _lru_get(self._bufs, key, lambda: _DBuffers(B, T, dev, self._cin))
 
     def _mlp_ptrs(self, w):
         arr = (c_void_p * 9)()

@@ -28,6 +28,9 @@ class Adam:
         self._state().grad.zero_()
 
     def step(self):
+        """One Adam update.  A step whose gradient is not finite is skipped on the device (parameters and moments untouched); the step
+        number still advances, i.e. the bias correction of later steps counts the skipped one - documented deviation from an optimiser
+        that would have raised / produced NaN weights at that point."""
         fp = self._state()
         self.step_count += 1
         ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.guard)
@@ -37,10 +40,17 @@ class Adam:
         return 0 if self.guard is None else int(self.guard[1].item())
 
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.m, 'exp_avg_sq': self.v, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps}
+        self._state()
+        return {'step': self.step_count, 'exp_avg': self.m, 'exp_avg_sq': self.v, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+                'skipped': self.skipped_steps()}
 
     def load_state_dict(self, sd):
         self._state()
         self.step_count = int(sd['step'])
         self.m.copy_(sd['exp_avg'])
         self.v.copy_(sd['exp_avg_sq'])
+        # guard[0] holds the step NUMBER of the last non-finite gradient: after rewinding step_count a stale value would mask a finite
+        # step of the same number (and let a bad one through).  The skipped-step count survives in the state dict.
+        self.guard.zero_()
+        if 'skipped' in sd:
+            self.guard[1] = int(sd['skipped'])

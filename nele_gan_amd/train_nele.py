@@ -78,6 +78,7 @@ class GanTrainer:
         # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
         #  HASPI below threshold (pyhaspi2.py:357-358 raises)] - one accumulator per stream that folds into it
         self._status = {}
+        self._ws = {}                                # metric workspaces of the split objects (multi-GB at B = 256): owned here, freed with the trainer
         self.world = ndist.world_size()
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
@@ -124,7 +125,16 @@ class GanTrainer:
         return {'clean_band': clean_band, 'noise_band': noise_band, 'clean_spec': clean_spec, 'frames': frames, 'lengths': lengths}
 
     # ---------------------------------------------------------------- G-step (train_nele.py:122-156)
-    def g_step(self, clean_band, noise_band, frames=None):
+    def g_step(self, clean_band, noise_band, frames=None, weight=None):
+        """One optimiser step of G (train_nele.py:130-155).  ``weight``: number of utterances this rank contributes (run_epoch under data
+        parallelism: ranks may hold different batch sizes / batch counts; None = plain mean over ranks); ``clean_band=None`` = an empty
+        step that only joins the collective (this rank has run out of batches)."""
+        if clean_band is None:
+            self.optimizer_g.zero_grad()
+            self._allreduce_grads(self.G, 0 if weight is None else weight)
+            self.optimizer_g.step()
+            self.step_g += 1
+            return None
         B = clean_band.shape[0]
         self.D.weight_grad_enabled = False           # D / D_Qua gradients of this step are never applied (train_nele.py:153-155)
         if self.D_Qua is not None:
@@ -141,7 +151,7 @@ class GanTrainer:
             score_q = self.D_Qua.forward_packed(self.quality_inputs(din), frames)
             loss = loss + weight_qua * self.MSELoss(score_q, torch.ones_like(score_q))
         loss.backward()
-        self._allreduce_grads(self.G)
+        self._allreduce_grads(self.G, weight)
         self.optimizer_g.step()
         self.step_g += 1
         self.D.weight_grad_enabled = True
@@ -176,6 +186,10 @@ class GanTrainer:
         (SIIB with too few active frames, HASPI below threshold), truncated SIIB scores (replication / frame caps), and optimiser steps
         skipped because their gradient was not finite (a NaN target or a poisoned eigen-decomposition must not reach the weights).
         Call once per epoch (run_epoch does)."""
+        cur = torch.cuda.current_stream() if self.device.type == 'cuda' else None
+        for st_ in (self._side, self._side2):        # the 'side' accumulator is updated on a side stream BEHIND the event the main stream waits on
+            if cur is not None and st_ is not None:
+                cur.wait_stream(st_)
         tot = torch.zeros(3, dtype=torch.int64)
         for acc in self._status.values():
             tot += acc.cpu()
@@ -207,11 +221,18 @@ class GanTrainer:
         return None if lengths is None else (torch.div(lengths, 256, rounding_mode='floor') * 256).to(torch.int32)
 
     @torch.no_grad()
-    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None):
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True):
+        """[B, n_metrics] targets of (clean, enhanced + noise) (audio_util.py:120-203).  lengths [B]: samples of each utterance inside the
+        padded batch; resynth=True: ``enh_wav`` came out of ``generate`` (each row holds 256 * (L // 256) samples); False: ``lengths``
+        already are min(clean, enhanced) per utterance (the pre-enhanced 'DRC' examples, audio_util.py:267-321)."""
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
         x = clean_wav[:, :L].contiguous()
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
-        lengths = self.enhanced_lengths(au._i32(lengths, self.device))
+        lengths = au._i32(lengths, self.device)
+        if resynth:
+            lengths = self.enhanced_lengths(lengths)
+        elif lengths is not None:
+            lengths = torch.clamp(lengths, max=L)
         cols = []
         for m in self.metrics:
             raw, mapped = self._metric(m, x, y, 'main', lengths)
@@ -219,10 +240,18 @@ class GanTrainer:
         return torch.stack(cols, dim=1)
 
     # ---------------------------------------------------------------- D-step (train_nele.py:349-367)
-    def d_inputs(self, enh_wav, noise_band, clean_band, lengths=None):
+    def d_inputs(self, enh_wav, noise_band, clean_band, lengths=None, resynth=True):
         """dataloader.py:54-84: features of the enhanced wav, stacked (enhanced, noise, clean).  lengths: of the ORIGINAL utterances
-        (the enhanced ones hold 256 * (L // 256) samples and have the same frame count)."""
-        _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False, lengths=self.enhanced_lengths(au._i32(lengths, self.device)))
+        (resynth=True: the enhanced ones hold 256 * (L // 256) samples and have the same frame count; False: ``lengths`` are the
+        enhanced files' own, e.g. the pre-enhanced 'DRC' examples)."""
+        lengths = au._i32(lengths, self.device)
+        _, enh_band = au.stft_band(enh_wav, p_power, want_spec=False, lengths=self.enhanced_lengths(lengths) if resynth else lengths)
+        T = clean_band.shape[1]
+        if enh_band.shape[1] != T:                   # a pre-enhanced file padded / cut to another frame count than the clean batch
+            eb = enh_band.new_zeros((enh_band.shape[0], T, 64))
+            n = min(T, enh_band.shape[1])
+            eb[:, :n] = enh_band[:, :n]
+            enh_band = eb
         return ops.d_pack(enh_band, noise_band, clean_band)
 
     @staticmethod
@@ -233,18 +262,31 @@ class GanTrainer:
         din_q[..., 1] = din[..., 2]
         return din_q
 
-    def d_step(self, din, target, target_qua=None, weight=None, frames=None):
+    def d_step(self, din, target, target_qua=None, weight=None, frames=None, has_qua=None):
         """One optimiser step of D on (din, target) - and of D_Qua on ([enh, clean], target_qua) when the quality discriminator is
         enabled and quality targets are given (train_nele.py:356-365).  ``weight``: number of items this rank contributes (d_epoch
-        under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives."""
+        under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives.
+        ``has_qua``: whether THIS optimiser step includes D_Qua - under data parallelism it must be the same on every rank (the D_Qua
+        all-reduce is a collective), so d_epoch decides it once per pass for all ranks; None = decide from ``target_qua`` (single rank)."""
+        if has_qua is None:
+            has_qua = self.D_Qua is not None and target_qua is not None
+        if has_qua and self.D_Qua is None:
+            raise ValueError("d_step: quality targets given but the trainer has no D_Qua (use_quality=False)")
+        if has_qua and din is not None and target_qua is None:
+            raise ValueError("d_step: this step trains D_Qua (has_qua) but the batch carries no quality targets")
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din, frames) if din is not None else None
-        loss = self._d_finish(score, target, weight)
-        if self.D_Qua is not None and (target_qua is not None or (din is None and weight is not None)):
+        score_qua = None
+        if has_qua:
             self.optimizer_dqua.zero_grad()
-            if din is not None:
-                loss_qua = self.MSELoss(self.D_Qua.forward_packed(self.quality_inputs(din), frames), target_qua)
+            if din is not None:                      # both forward passes first, as the reference (train_nele.py:356-357)
+                score_qua = self.D_Qua.forward_packed(self.quality_inputs(din), frames)
+        loss = self._d_finish(score, target, weight)
+        if has_qua:
+            if score_qua is not None:
+                loss_qua = self.MSELoss(score_qua, target_qua)
                 loss_qua.backward()
+                self.last_loss_qua = loss_qua.detach()
             self._allreduce_grads(self.D_Qua, weight)
             self.optimizer_dqua.step()
         return loss
@@ -279,14 +321,14 @@ class GanTrainer:
             x_ready = torch.cuda.Event()
             x_ready.record(side)
             if 'siib' in self.metrics:
-                w['split'] = mt.SiibSplit(w['x'], lengths=mlens, owner=id(self))
+                w['split'] = mt.SiibSplit(w['x'], lengths=mlens, owner=self._ws)
                 w['split'].clean_part()
         if 'haspi' in self.metrics and self.split_haspi:
             # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
             with torch.cuda.stream(side2):
                 side2.wait_event(after)
                 side2.wait_event(x_ready)
-                w['hsplit'] = mt.HaspiSplit(w['x'], lengths=mlens, owner=id(self))
+                w['hsplit'] = mt.HaspiSplit(w['x'], lengths=mlens, owner=self._ws)
                 w['hsplit'].clean_part()
         if with_features:
             if self._fside is None:
@@ -438,7 +480,10 @@ class GanTrainer:
                 for r, c in enumerate(ch):
                     din[r, :, :Ts[r]] = c[0]
                 frames = torch.tensor(Ts, dtype=torch.int32, device=din.device)
-            tq = torch.stack([c[2] for c in ch]) if (len(ch[0]) > 2 and ch[0][2] is not None) else None
+            hq = [len(c) > 2 and c[2] is not None for c in ch]
+            if any(hq) != all(hq):
+                raise ValueError("d_epoch: quality targets must be given for every sample of a pass or for none")
+            tq = torch.stack([c[2] for c in ch]) if hq[0] else None
             out.append((din, torch.stack([c[1] for c in ch]), tq, frames))
         return out
 
@@ -446,15 +491,26 @@ class GanTrainer:
         random.shuffle(lst)
         chunks = self._padded_chunks(lst, batch)
         n_steps = len(chunks)
+        # D_Qua is stepped in this pass iff the samples carry quality targets: one decision per pass, the same on every rank (a rank
+        # whose shard is shorter joins the D_Qua collectives with empty steps; mixed presence is an error)
+        hq = [c[2] is not None for c in chunks]
+        if any(hq) != all(hq):
+            raise ValueError("d_epoch: quality targets must be given for every sample of a pass or for none")
+        has_qua = int(self.D_Qua is not None and bool(hq) and hq[0])
         if self.world > 1:
             # ranks hold different shards: every rank must join the same number of all-reduces
             n_steps = ndist.allreduce_max_int(n_steps, self.device)
+            g_has = ndist.allreduce_max_int(has_qua, self.device)
+            if chunks and g_has != has_qua:
+                raise ValueError("d_epoch: some ranks carry quality targets and others do not")
+            has_qua = g_has
         for k in range(n_steps):
             if k < len(chunks):
                 din, tgt, tq, frames = chunks[k]
-                self.d_step(din, tgt, tq if self.D_Qua is not None else None, weight=din.shape[0] if self.world > 1 else None, frames=frames)
+                self.d_step(din, tgt, tq if has_qua else None, weight=din.shape[0] if self.world > 1 else None, frames=frames,
+                            has_qua=bool(has_qua))
             else:
-                self.d_step(None, None, None, weight=0)
+                self.d_step(None, None, None, weight=0, has_qua=bool(has_qua))
         return n_steps
 
     def d_epoch(self, samples, batch=32):
@@ -483,7 +539,11 @@ class GanTrainer:
 
         train_batches / valid_batches: sequences of dicts {'clean': wav [B,L], 'noise': wav [B,L], optional 'names': [B] wave names,
         optional 'drc': pre-enhanced wav [B,L] (the MultiEnh example of the same utterance, train_nele.py:333-340), optional
-        'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua)}.
+        'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua),
+        optional 'lengths': [B] samples of each utterance inside the zero-padded batch (files of different lengths side by side, as
+        the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths')}.
+        Under data parallelism every rank passes its own shard of batches; ranks may hold different batch counts and sizes (empty
+        G-steps / D-steps join the collectives, gradients are item-weighted means, the validation means run over all ranks).
           1. G-steps over the training batches - from epoch 2 on (:122-156; epoch 1 fits D to the untrained generator first)
           2. validation: enhance, raw (unmapped) metrics, learning-curve line (:159-225)
           3. checkpoint (:272-277)
@@ -493,46 +553,75 @@ class GanTrainer:
         Returns a dict of what happened (losses, validation means, counts)."""
         out = {'gan_epoch': int(gan_epoch), 'g_steps': 0, 'g_loss': None, 'valid': None, 'samples': 0}
         feats = [None] * len(train_batches)
+        dp = self.world > 1
+
+        def fts(b):
+            return self.features(b['clean'], b['noise'], b.get('lengths'))
+
         if gan_epoch >= 2:                                              # :122
             tot = None
-            for i, b in enumerate(train_batches):
-                feats[i] = self.features(b['clean'], b['noise'])
-                lg = self.g_step(feats[i]['clean_band'], feats[i]['noise_band'])
-                tot = lg if tot is None else tot + lg
+            n_g = len(train_batches)
+            if dp:                                                      # ranks may hold different batch counts: same number of all-reduces
+                n_g = ndist.allreduce_max_int(n_g, self.device)
+            for i in range(n_g):
+                if i < len(train_batches):
+                    b = train_batches[i]
+                    f = feats[i] = fts(b)
+                    lg = self.g_step(f['clean_band'], f['noise_band'], f.get('frames'), weight=b['clean'].shape[0] if dp else None)
+                    tot = lg if tot is None else tot + lg
+                else:
+                    self.g_step(None, None, weight=0)
                 out['g_steps'] += 1
-            out['g_loss'] = tot / max(1, out['g_steps']) if tot is not None else None
+            out['g_loss'] = tot / max(1, len(train_batches)) if tot is not None else None
         raw = []
         for b in valid_batches:                                         # :159-222
-            f = self.features(b['clean'], b['noise'])
-            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
-            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False))
-        if raw:
-            r = torch.cat(raw, dim=0).double().mean(dim=0).cpu().numpy()
-            col = {m: float(r[i]) for i, m in enumerate(self.metrics)}
-            out['valid'] = col
-            line = self.validation_log_line(col.get('siib', 0.0), col.get('haspi', 0.0), col.get('estoi', 0.0), gan_epoch)
-            if log_path is not None and ndist.rank() == 0:
-                with open(log_path, 'a') as fh:                         # :224-225
-                    fh.write(line)
+            f = fts(b)
+            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f.get('frames'))
+            if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
+                self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch, lengths=b.get('lengths'))
+            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths')))
+        if raw or (dp and valid_batches is not None):
+            n_m = len(self.metrics)
+            acc = torch.zeros(n_m + 1, dtype=torch.float64, device=self.device)
+            if raw:
+                r = torch.cat(raw, dim=0).double()
+                acc[:n_m] = r.sum(dim=0)
+                acc[n_m] = r.shape[0]
+            if dp:                                                      # the learning curve is the mean over ALL validation utterances
+                import torch.distributed as tdist
+                tdist.all_reduce(acc)
+            if float(acc[n_m]) > 0:
+                r = (acc[:n_m] / acc[n_m]).cpu().numpy()
+                col = {m: float(r[i]) for i, m in enumerate(self.metrics)}
+                out['valid'] = col
+                line = self.validation_log_line(col.get('siib', 0.0), col.get('haspi', 0.0), col.get('estoi', 0.0), gan_epoch)
+                if log_path is not None and ndist.rank() == 0:
+                    with open(log_path, 'a') as fh:                     # :224-225
+                        fh.write(line)
         if chkpt_path is not None and ndist.rank() == 0:
             self.save_checkpoint(chkpt_path)                            # :272-277
         samples = []
+        out['sample_files'] = []
         for i, b in enumerate(train_batches):                           # :279-340
-            f = feats[i] if feats[i] is not None else self.features(b['clean'], b['noise'])
-            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+            f = feats[i] if feats[i] is not None else fts(b)
+            lens, frames = b.get('lengths'), f.get('frames')
+            enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=frames)
             if sample_dir is not None and 'names' in b:
-                self.write_samples(enh, b['names'], sample_dir, gan_epoch)
-            tgt = self.true_metrics(b['clean'], enh, b['noise'])
-            din = self.d_inputs(enh, f['noise_band'], f['clean_band'])
+                out['sample_files'] += self.write_samples(enh, b['names'], sample_dir + '/For_discriminator_training', gan_epoch, lengths=lens)
+            tgt = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens)
+            din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
             qua = b.get('qua')
-            samples += [(din[k], tgt[k], qua[k] if qua is not None else None) for k in range(din.shape[0])]
+            samples += self._items(din, tgt, qua, frames)
             if b.get('drc') is not None:
-                Lr = enh.shape[1]
-                drc = b['drc'][:, :Lr].contiguous()
-                tgt_d = self.true_metrics(b['clean'], drc, b['noise'])
-                din_d = self.d_inputs(drc, f['noise_band'], f['clean_band'])
-                qd = b.get('drc_qua')
-                samples += [(din_d[k], tgt_d[k], qd[k] if qd is not None else None) for k in range(din_d.shape[0])]
+                # the pre-enhanced ('DRC') example of the same utterance (:333-340; audio_util.py:267-321): its own file, its own length
+                dl = b.get('drc_lengths', lens)
+                ml = None
+                if dl is not None or lens is not None:
+                    full = lambda t, w: torch.full((w.shape[0],), w.shape[1], dtype=torch.int32, device=self.device) if t is None else au._i32(t, self.device)
+                    ml = torch.minimum(full(dl, b['drc']), full(lens, b['clean']))       # audio_util.py:134-137
+                tgt_d = self.true_metrics(b['clean'], b['drc'], b['noise'], lengths=ml, resynth=False)
+                din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
+                samples += self._items(din_d, tgt_d, b.get('drc_qua'), frames)
         out['samples'] = len(samples)
         d0 = self.step_d
         self.d_epoch(samples, batch=d_batch)                            # :342-426
@@ -541,17 +630,26 @@ class GanTrainer:
             out['status'] = self.check_status()
         return out
 
+    @staticmethod
+    def _items(din, tgt, qua, frames):
+        """A batch's D training items: (din [64, T_k, 4] cut to the utterance's own frames, target [n], quality target [2] | None)."""
+        fr = None if frames is None else [int(v) for v in frames.tolist()]
+        return [(din[k] if fr is None else din[k, :, :fr[k]].contiguous(), tgt[k], qua[k] if qua is not None else None)
+                for k in range(din.shape[0])]
+
     # ---------------------------------------------------------------- file hand-off (train_nele.py:303-340, 224-225)
-    def write_samples(self, enh_wav, wave_names, directory, gan_epoch):
+    def write_samples(self, enh_wav, wave_names, directory, gan_epoch, lengths=None):
         """Enhanced batch -> '<directory>/<name>@<epoch>.wav' PCM_16 files, as the reference stores its generated D samples
-        (train_nele.py:309-313).  ``enh_wav`` is what ``generate`` returned (already PCM_16-quantised when ``self.pcm16``)."""
+        (train_nele.py:309-313).  ``enh_wav`` is what ``generate`` returned (already PCM_16-quantised when ``self.pcm16``);
+        lengths [B]: samples of the ORIGINAL utterances of a padded batch (file k then holds 256 * (lengths[k] // 256) samples)."""
         from . import dataio
         dataio.creatdir(directory)
         host = enh_wav.detach().cpu().numpy()
+        lens = None if lengths is None else [256 * (int(v) // 256) for v in torch.as_tensor(lengths).tolist()]
         out = []
-        for w, name in zip(host, wave_names):
+        for k, (w, name) in enumerate(zip(host, wave_names)):
             path = dataio.enhanced_name(directory, name, gan_epoch)
-            dataio.write_wav_pcm16(path, w, fs, quantised=self.pcm16)
+            dataio.write_wav_pcm16(path, w if lens is None else w[:lens[k]], fs, quantised=self.pcm16)
             out.append(path)
         return out
 

@@ -57,15 +57,25 @@ def _noop(i):
 class CpuStep:
     """State (weights, Adam moments) + one canonical step over a batch."""
 
-    def __init__(self, g_state, d_state, metrics=('siib', 'estoi'), lr_g=5e-4, lr_d=2.5e-4):
+    def __init__(self, g_state, d_state, metrics=('siib', 'estoi'), lr_g=5e-4, lr_d=2.5e-4, dq_state=None, weight_qua=0.5):
+        """dq_state: state_dict of Discriminator_Quality - the G-step then carries the 0.5 * MSE(D_Qua) term (train_nele.py:150-152)
+        and d_step trains D_Qua on [enhanced, clean] against quality targets with its own Adam (train_nele.py:362-365)."""
         self.metrics = tuple(metrics)
+        self.weight_qua = weight_qua
+        self.dq = None
+        if dq_state is not None:
+            self.dq = {k: v.detach().clone().float() for k, v in dq_state.items()}
+            for k, v in self.dq.items():
+                if not (k.endswith('_u') or k.endswith('_v')):
+                    v.requires_grad_(True)
+            self.opt_dq = torch.optim.Adam([v for v in self.dq.values() if v.requires_grad], lr=lr_d)
         self.g = {k: v.detach().clone().float().requires_grad_(True) for k, v in g_state.items()}
-        self.d = {k: v.detach().clone().float() for k, v in d_state.items()}
+        self.d = {k: v.detach().clone().float() for k, v in (d_state or {}).items()}      # d_state=None: inference only (enhance)
         for k, v in self.d.items():
             if not (k.endswith('_u') or k.endswith('_v')):
                 v.requires_grad_(True)
         self.opt_g = torch.optim.Adam(list(self.g.values()), lr=lr_g)
-        self.opt_d = torch.optim.Adam([v for v in self.d.values() if v.requires_grad], lr=lr_d)
+        self.opt_d = torch.optim.Adam([v for v in self.d.values() if v.requires_grad], lr=lr_d) if self.d else None
         self.times = {}
 
     def _t(self, key, t0):
@@ -89,13 +99,24 @@ class CpuStep:
             self.d[k] = v.detach()
         return s
 
+    def _dq_forward(self, x2):
+        s, nb = nets.discriminator_forward(self.dq, x2, train=True)
+        for k, v in nb.items():
+            self.dq[k] = v.detach()
+        return s
+
     def g_step(self, cb, nb):
         t0 = time.perf_counter()
         cbt, nbt = torch.from_numpy(cb), torch.from_numpy(nb)
         mask = nets.generator_forward(self.g, cbt, nbt)
         enh, _ = nets.energy_norm(mask, cbt, P_POWER, INV_P)
-        score = self._d_forward(nets.d_inputs(enh, nbt, cbt))
+        x = nets.d_inputs(enh, nbt, cbt)
+        score = self._d_forward(x)
         loss = torch.nn.functional.mse_loss(score, torch.ones_like(score))
+        if self.dq is not None:                                    # train_nele.py:146-152: d_inputs_qua = cat(enh, ref)
+            score_q = self._dq_forward(x[:, [0, 2]])
+            loss = loss + self.weight_qua * torch.nn.functional.mse_loss(score_q, torch.ones_like(score_q))
+            self.opt_dq.zero_grad()
         self.opt_g.zero_grad()
         self.opt_d.zero_grad()
         loss.backward()
@@ -116,6 +137,22 @@ class CpuStep:
             w = F.sp_to_wav(alpha2[b], cm[b], cp[b])
             out.append(pcm16_roundtrip(w) if pcm16 else w)
         self._t('generate', t0)
+        return out
+
+    def enhance(self, clean, noise, rms_target=0.030, pcm16=True):
+        """inference.py:79-115 per utterance: features -> G (eval) -> mask * beta_2 -> SP_to_wav -> enh / rms(enh) * 0.03 -> PCM_16.
+        -> list of float32 arrays of 256 * (len // 256) samples."""
+        out = []
+        with torch.no_grad():
+            for c, v in zip(clean, noise):
+                cb, cm, cp, nb = _one_feature(c, v)
+                cbt = torch.from_numpy(cb[None])
+                mask = nets.generator_forward(self.g, cbt, torch.from_numpy(nb[None]))
+                cpow = torch.pow(cbt, INV_P)
+                beta2 = cpow.sum() / (mask * cpow).sum()
+                w = F.sp_to_wav((mask * beta2)[0].numpy(), cm, cp)
+                w = (w / np.sqrt(np.mean(w ** 2)) * rms_target).astype(np.float32)          # inference.py:109, audio_util.py:463-464
+                out.append(pcm16_roundtrip(w) if pcm16 else w)
         return out
 
     def targets(self, clean, enh, noise, workers=1):
@@ -145,15 +182,24 @@ class CpuStep:
             self.d_step(enh[i:i + 1], nb[i:i + 1], cb[i:i + 1], tgt[i:i + 1])
         return tgt
 
-    def d_step(self, enh, nb, cb, tgt):
+    def d_step(self, enh, nb, cb, tgt, tgt_qua=None):
+        """train_nele.py:349-367; with ``tgt_qua`` [B,2] (and a D_Qua state) also the D_Qua step -> (loss, loss_qua)."""
         t0 = time.perf_counter()
         eb = np.stack([F.sp_and_phase_speech(e, P_POWER)[0] for e in enh])
         x = nets.d_inputs(torch.from_numpy(eb), torch.from_numpy(nb), torch.from_numpy(cb))
         score = self._d_forward(x)
+        score_q = self._dq_forward(x[:, [0, 2]]) if tgt_qua is not None else None      # dataloader.py:83
         loss = torch.nn.functional.mse_loss(score, torch.from_numpy(tgt))
         self.opt_d.zero_grad()
         loss.backward()
         self.opt_d.step()
+        if score_q is not None:
+            loss_q = torch.nn.functional.mse_loss(score_q, torch.from_numpy(np.asarray(tgt_qua, dtype=np.float32)))
+            self.opt_dq.zero_grad()
+            loss_q.backward()
+            self.opt_dq.step()
+            self._t('d_step', t0)
+            return float(loss.detach()), float(loss_q.detach())
         self._t('d_step', t0)
         return float(loss.detach())
 

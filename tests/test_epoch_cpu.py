@@ -31,23 +31,23 @@ def _recording_trainer(log):
     tr = _bare_trainer()
     T = 30
 
-    def features(c, n):
+    def features(c, n, lengths=None):
         log.append('features')
         return {'clean_band': torch.zeros(c.shape[0], T, 64), 'noise_band': torch.zeros(c.shape[0], T, 64), 'clean_spec': None}
 
-    def g_step(cb, nb):
+    def g_step(cb, nb, frames=None, weight=None):
         log.append('g_step')
         return torch.tensor(0.5)
 
-    def generate(cb, nb, spec, rms_target=0.0):
+    def generate(cb, nb, spec, rms_target=0.0, frames=None):
         log.append('generate')
         return torch.zeros(cb.shape[0], 256 * (T - 1))
 
-    def true_metrics(c, e, n, norm=True):
+    def true_metrics(c, e, n, norm=True, lengths=None, resynth=True):
         log.append('metrics' if norm else 'metrics_raw')
         return torch.full((c.shape[0], 2), 0.25)
 
-    def d_inputs(e, nb, cb):
+    def d_inputs(e, nb, cb, lengths=None, resynth=True):
         log.append('d_inputs')
         return torch.zeros(e.shape[0], 64, T, 4)
 
@@ -215,3 +215,71 @@ def test_data_parallel_d_epoch_on_ragged_shards_world2():
     np.testing.assert_array_equal(r0['wmean'], r1['wmean'])
     np.testing.assert_array_equal(r0['empty'], [0.0, 0.0])
     assert r0['max'] == 4 and r1['max'] == 4
+
+
+# ------------------------------------------------------------------------------------------ data-parallel epoch: D_Qua + ragged G-step loop
+def _dp_epoch_worker(rank, world, port, out):
+    """run_epoch on two ranks that hold DIFFERENT numbers of training batches (3 / 1), with the quality discriminator enabled: the
+    G-step loop and every D pass must issue the same collectives on both ranks (empty steps on the rank that ran out), D_Qua is
+    stepped on both or on neither, and the validation means run over both shards."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import random
+    from nele_gan_amd.train_nele import GanTrainer
+    tr = _bare_trainer()
+    tr.world = world
+    tr.G, tr.D, tr.D_Qua = _TinyD(), _TinyD(), _TinyD()
+    tr.optimizer_g, tr.optimizer_d, tr.optimizer_dqua = _Sgd(tr.G), _Sgd(tr.D), _Sgd(tr.D_Qua)
+    tr.MSELoss = torch.nn.MSELoss()
+    orig_allreduce = tr._allreduce_grads
+
+    def allreduce(module, weight=None):
+        module.collect()
+        orig_allreduce(module, weight)
+    tr._allreduce_grads = allreduce
+    T = 30
+    tr.features = lambda c, n, lengths=None: {'clean_band': c[:, :T * 64].reshape(-1, T, 64), 'noise_band': n[:, :T * 64].reshape(-1, T, 64),
+                                              'clean_spec': None, 'frames': None}
+    real_g_step = GanTrainer.g_step
+
+    def g_step(cb, nb, frames=None, weight=None):
+        if cb is None:
+            return real_g_step(tr, None, None, weight=weight)          # the product's empty-step path
+        tr.optimizer_g.zero_grad()
+        loss = tr.MSELoss(tr.G.forward_packed(cb.reshape(cb.shape[0], 1, T, 64)), torch.ones(cb.shape[0], 1))
+        loss.backward()
+        tr._allreduce_grads(tr.G, weight)
+        tr.optimizer_g.step()
+        tr.step_g += 1
+        return loss.detach()
+    tr.g_step = g_step
+    tr.generate = lambda cb, nb, spec, rms_target=0.0, frames=None: cb.reshape(cb.shape[0], -1)[:, :256 * (T - 1)].clone()
+    tr.true_metrics = lambda c, e, n, norm=True, lengths=None, resynth=True: torch.full((c.shape[0], 2), 0.2 + 0.1 * rank)
+    tr.d_inputs = lambda e, nb, cb, lengths=None, resynth=True: cb.reshape(cb.shape[0], T, 64, 1).transpose(1, 2).repeat(1, 1, 1, 4).contiguous()
+    tr.check_status = lambda raise_on_error=True: {}
+    random.seed(5 + rank)
+    rs = np.random.RandomState(11 + rank)
+    nb_ = 3 if rank == 0 else 1
+    B = 2 if rank == 0 else 3                                           # different batch sizes too: the mean must be item-weighted
+    mk = lambda: torch.from_numpy(rs.rand(B, 256 * T).astype(np.float32))
+    train = [{'clean': mk(), 'noise': mk(), 'qua': torch.full((B, 2), 0.5), 'drc': mk(), 'drc_qua': torch.full((B, 2), 0.25)} for _ in range(nb_)]
+    valid = [{'clean': mk(), 'noise': mk()}] if rank == 0 else []      # only rank 0 holds validation utterances
+    res = tr.run_epoch(2, train, valid, d_batch=4)
+    out[rank] = {'g': tr.G.flat_parameters().flat.numpy().copy(), 'd': tr.D.flat_parameters().flat.numpy().copy(),
+                 'q': tr.D_Qua.flat_parameters().flat.numpy().copy(), 'gs': tr.optimizer_g.steps, 'ds': tr.optimizer_d.steps,
+                 'qs': tr.optimizer_dqua.steps, 'valid': res['valid'], 'g_steps': res['g_steps']}
+    dist.destroy_process_group()
+
+
+def test_data_parallel_epoch_with_ragged_batch_counts_and_quality_discriminator_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_epoch_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0['gs'] == r1['gs'] == 3 and r0['g_steps'] == r1['g_steps'] == 3     # rank 1 joined two empty G-steps
+    assert r0['ds'] == r1['ds'] and r0['qs'] == r1['qs'] == r0['ds']              # D_Qua stepped with every D step, on both ranks
+    for k in ('g', 'd', 'q'):
+        np.testing.assert_array_equal(r0[k], r1[k])                               # replicas identical
+        assert not np.array_equal(r0[k], np.array([0.3, -0.1], dtype=np.float32))
+    assert r0['valid'] == r1['valid'] and r0['valid']['siib'] == pytest.approx(0.2)   # rank 1 logs the global mean (rank 0's shard only)

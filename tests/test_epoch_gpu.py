@@ -1,0 +1,225 @@
+"""GPU: the parts of the loop surface that round 2 had only exercised with stubs or not at all.
+
+* the quality-discriminator training path (train_nele.py:150-152, 362-365): G-step with the 0.5 * MSE(D_Qua) term and a D-step
+  that also trains D_Qua, against the oracle (oracle/step.py with a D_Qua state);
+* GanTrainer.run_epoch on the real kernels, epochs 1 and 2, over utterances of DIFFERENT lengths (toy Train / Test files + two
+  synthetic ones) carried as padded batches with per-utterance lengths: identical, bit for bit, to the same stages called by hand;
+  samples, D steps, checkpoint keys, the learning-curve line and the name@epoch.wav files as train_nele.py:110-122, 224-225,
+  272-340 prescribe;
+* BASELINE configs[4]'s shape: Enhancer.enhance on 8 s utterances (L = 128 000, 501 frames) against the oracle's inference path.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+HERE = os.path.dirname(__file__)
+TOY = os.path.join(HERE, 'golden', 'toy')
+
+
+def _sd(m):
+    return {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+
+
+def test_quality_discriminator_training_path_matches_the_oracle():
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    from oracle.step import CpuStep
+    B, L = 2, 24000
+    c, v = synth.batch(B, L, start=410)
+    tr = GanTrainer('siib&estoi', use_quality=True)
+    cpu = CpuStep(_sd(tr.G), _sd(tr.D), metrics=('siib', 'estoi'), dq_state=_sd(tr.D_Qua))
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    f = tr.features(cw, nw)
+    cb, cm, cp, nb = cpu.features(c, v)
+    # G-step: MSE(D, 1) + 0.5 * MSE(D_Qua, 1) (train_nele.py:150-152)
+    lg = float(tr.g_step(f['clean_band'], f['noise_band']))
+    lg_ref = cpu.g_step(cb, nb)
+    assert lg == pytest.approx(lg_ref, rel=1e-4)
+    plain = CpuStep(_sd(GanTrainer('siib&estoi').G), _sd(tr.D), metrics=('siib', 'estoi'))   # same seed -> same initial G
+    assert abs(lg_ref - plain.g_step(cb, nb)) > 1e-3                  # the quality term is really in the loss
+    for k, t in tr.G.state_dict().items():
+        np.testing.assert_allclose(t.cpu().numpy(), cpu.g[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+    # neither discriminator moved in the G-step (train_nele.py:153-155) - except their spectral-norm u, v (never in eval mode)
+    for name, mod, ref in (('D', tr.D, cpu.d), ('D_Qua', tr.D_Qua, cpu.dq)):
+        for k, t in mod.state_dict().items():
+            np.testing.assert_allclose(t.cpu().numpy(), ref[k].detach().numpy(), rtol=1e-4, atol=1e-6, err_msg=name + '.' + k)
+    # D-step with quality targets (train_nele.py:349-367)
+    enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'])
+    tgt = tr.true_metrics(cw, enh, nw)
+    tq = np.asarray([[0.31, 0.62], [0.74, 0.18]], dtype=np.float32)    # stand-ins for mapped PESQ / ViSQOL scores (absent metrics)
+    din = tr.d_inputs(enh, f['noise_band'], f['clean_band'])
+    ld = float(tr.d_step(din, tgt, torch.from_numpy(tq).cuda()))
+    lq = float(tr.last_loss_qua)
+    ld_ref, lq_ref = cpu.d_step([e for e in enh.cpu().numpy()], nb, cb, tgt.cpu().numpy(), tq)
+    assert ld == pytest.approx(ld_ref, rel=2e-4) and lq == pytest.approx(lq_ref, rel=2e-4)
+    for name, mod, ref in (('D', tr.D, cpu.d), ('D_Qua', tr.D_Qua, cpu.dq)):
+        for k, t in mod.state_dict().items():
+            np.testing.assert_allclose(t.cpu().numpy(), ref[k].detach().numpy(), rtol=2e-3, atol=2e-5, err_msg=name + '.' + k)
+    st = tr.check_status()
+    assert st['skipped_dqua_steps'] == 0 and tr.optimizer_dqua.step_count == 1
+    # the decision whether D_Qua is stepped is explicit: a batch without quality targets cannot be pushed through a D_Qua step
+    with pytest.raises(ValueError):
+        tr.d_step(din, tgt, None, has_qua=True)
+    tr.d_step(din, tgt, None)                                           # no quality targets -> D only
+    assert tr.optimizer_dqua.step_count == 1 and tr.optimizer_d.step_count == 2
+
+
+def _corpus():
+    """Two training batches and one validation batch of utterances of four different lengths, zero-padded, with lengths and names."""
+    from nele_gan_amd import dataio, synth
+    ld = lambda n: dataio.load(os.path.join(TOY, n))[0]
+    c0, n0, e0 = ld('Train_Clean.wav'), ld('Train_Noise.wav'), ld('Train_MultiEnh.wav')        # 33 536 samples
+    c1, n1 = ld('Test_Clean.wav'), ld('Test_Noise.wav')                                          # 34 048
+    (c2,), (n2,) = synth.batch(1, 40000, start=77)
+    (c3,), (n3,) = synth.batch(1, 29000, start=78)
+    (c4,), (n4,) = synth.batch(1, 36000, start=79)
+
+    def batch(cl, ns, names, drc=None, qua=None, drc_qua=None):
+        cp, lens = dataio.pad_batch(cl)
+        npad, _ = dataio.pad_batch(ns)
+        b = {'clean': torch.from_numpy(cp).cuda(), 'noise': torch.from_numpy(npad).cuda(), 'lengths': torch.from_numpy(lens).cuda(),
+             'names': names}
+        if drc is not None:
+            dp, dl = dataio.pad_batch(drc)
+            b['drc'], b['drc_lengths'] = torch.from_numpy(dp).cuda(), torch.from_numpy(dl).cuda()
+        if qua is not None:
+            b['qua'], b['drc_qua'] = torch.tensor(qua, device='cuda'), torch.tensor(drc_qua, device='cuda')
+        return b
+    # pre-enhanced ('DRC') examples: the toy MultiEnh file and, for the synthetic utterances, a fixed spectral tilt of the clean signal
+    drc2 = np.convolve(c2, [1.0, -0.6], mode='same').astype(np.float32)
+    drc3 = np.convolve(c3, [1.0, -0.6], mode='same').astype(np.float32)[:28950]                   # a little shorter than its clean file (same frame count)
+    train = [batch([c0, c2], [n0, n2], ['Train_Clean.wav', 'syn_a.wav'], drc=[e0, drc2]),
+             batch([c3, c4], [n3, n4], ['syn_b.wav', 'syn_c.wav'], drc=[drc3, c4 * 0.9])]
+    valid = [batch([c1, c3], [n1, n3], ['Test_Clean.wav', 'syn_b.wav'])]
+    return train, valid
+
+
+def _by_hand_epoch(tr, gan_epoch, train, valid):
+    """The stages of run_epoch issued one by one through the trainer's public stage methods (same order as train_nele.py:110-429)."""
+    from nele_gan_amd import audio_util as au
+    feats = []
+    if gan_epoch >= 2:
+        for b in train:
+            f = tr.features(b['clean'], b['noise'], b['lengths'])
+            feats.append(f)
+            tr.g_step(f['clean_band'], f['noise_band'], f['frames'])
+    raw = []
+    for b in valid:
+        f = tr.features(b['clean'], b['noise'], b['lengths'])
+        enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f['frames'])
+        raw.append(tr.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b['lengths']))
+    samples, enhs = [], []
+    for i, b in enumerate(train):
+        f = feats[i] if feats else tr.features(b['clean'], b['noise'], b['lengths'])
+        enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f['frames'])
+        enhs.append(enh)
+        tgt = tr.true_metrics(b['clean'], enh, b['noise'], lengths=b['lengths'])
+        din = tr.d_inputs(enh, f['noise_band'], f['clean_band'], b['lengths'])
+        fr = f['frames'].tolist()
+        samples += [(din[k, :, :fr[k]].contiguous(), tgt[k], None) for k in range(din.shape[0])]
+        ml = torch.minimum(b['drc_lengths'], b['lengths'])
+        tgt_d = tr.true_metrics(b['clean'], b['drc'], b['noise'], lengths=ml, resynth=False)
+        din_d = tr.d_inputs(b['drc'], f['noise_band'], f['clean_band'], b['drc_lengths'], resynth=False)
+        samples += [(din_d[k, :, :fr[k]].contiguous(), tgt_d[k], None) for k in range(din_d.shape[0])]
+    tr.d_epoch(samples, batch=3)
+    return torch.cat(raw), samples, enhs
+
+
+def test_run_epoch_on_the_device_with_utterances_of_different_lengths(tmp_path):
+    from nele_gan_amd import dataio
+    from nele_gan_amd.train_nele import GanTrainer
+    from oracle import step as ostep
+    train, valid = _corpus()
+    a = GanTrainer('siib&haspi&estoi')
+    b = GanTrainer('siib&haspi&estoi')                                # same seed: same weights, same shuffles
+    log = str(tmp_path / 'log.txt')
+    for ep in (1, 2):
+        ck = str(tmp_path / ('chkpt_%d.pt' % ep))
+        random.seed(1000 + ep)                                        # the D passes shuffle with the global generator (train_nele.py:347, 377)
+        out = a.run_epoch(ep, train, valid, chkpt_path=ck, sample_dir=str(tmp_path / 'out'), log_path=log, d_batch=3)
+        random.seed(1000 + ep)
+        raw, samples, enhs = _by_hand_epoch(b, ep, train, valid)
+        # bookkeeping (train_nele.py:122, 342-426): no G-step in epoch 1; 8 samples (4 generated + 4 pre-enhanced);
+        # passes A, B, C over ceil(8/3) = 3 batches each, pass B with len(history) // 30 = 0 replayed items
+        assert out['g_steps'] == (0 if ep == 1 else 2) and out['samples'] == 8 and out['d_steps'] == 9
+        assert len(a.history) == 8 * ep and a.step_d == b.step_d == 9 * ep and a.step_g == b.step_g
+        assert out['status']['skipped_d_steps'] == 0 and out['status']['skipped_g_steps'] == 0
+        # same results as the stages called by hand, bit for bit: weights of G and D after the epoch, validation means
+        for mod_a, mod_b in ((a.G, b.G), (a.D, b.D)):
+            for (k, ta), (_, tb) in zip(mod_a.state_dict().items(), mod_b.state_dict().items()):
+                assert torch.equal(ta, tb), k
+        means = raw.double().mean(dim=0).cpu().numpy()
+        assert [out['valid'][m] for m in ('siib', 'haspi', 'estoi')] == pytest.approx(list(means), rel=1e-12)
+        # the learning-curve line (train_nele.py:224-225)
+        line = open(log).read().splitlines()[-1]
+        assert line == ('SIIB is %.3f, HASPI is %.3f, ESTOI is %.3f, PESQ is %.3f, VISQOL is %.3f, EPOCH:%d ' % (means[0], means[1], means[2], 0, 0, ep))
+        # checkpoint keys (train_nele.py:272-277) load into the reference-shaped modules
+        sd = torch.load(ck, map_location='cpu')
+        assert set(sd.keys()) == {'enhance-model', 'intel-model'}
+        assert set(sd['enhance-model'].keys()) == set(a.G.state_dict().keys())
+        # name@epoch.wav files (train_nele.py:309-313): PCM_16, 256 * (L // 256) samples, equal to the generated batch rows
+        files = out['sample_files']
+        assert [os.path.basename(p) for p in files] == ['Train_Clean@%d.wav' % ep, 'syn_a@%d.wav' % ep, 'syn_b@%d.wav' % ep, 'syn_c@%d.wav' % ep]
+        k = 0
+        for bi, bt in enumerate(train):
+            for r, L in enumerate(bt['lengths'].tolist()):
+                w, sr = dataio.load(files[k])
+                assert sr == 16000 and len(w) == 256 * (L // 256)
+                np.testing.assert_array_equal(w, enhs[bi][r, :len(w)].cpu().numpy())
+                assert float(enhs[bi][r, len(w):].abs().sum()) == 0.0
+                k += 1
+        assert os.path.exists(str(tmp_path / 'out' / ('Test_epoch%d' % ep) / ('Test_Clean@%d.wav' % ep)))
+    # and against the oracle: the targets of the first generated sample and of the toy pre-enhanced example (the only reference-supplied
+    # enhanced file) in the last epoch's list, computed per file at the file's own length
+    c0 = train[0]['clean'][0, :33536].cpu().numpy()
+    n0 = train[0]['noise'][0, :33536].cpu().numpy()
+    e0 = enhs[0][0, :256 * (33536 // 256)].cpu().numpy()
+    ref = ostep.metric_targets(c0, e0, n0, ('siib', 'haspi', 'estoi'))
+    np.testing.assert_allclose(samples[0][1].cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    drc0 = train[0]['drc'][0, :33536].cpu().numpy()
+    ref_d = ostep.metric_targets(c0, drc0, n0, ('siib', 'haspi', 'estoi'))
+    np.testing.assert_allclose(samples[2][1].cpu().numpy(), ref_d, rtol=1e-4, atol=1e-5)
+
+
+def test_run_epoch_with_the_quality_discriminator(tmp_path):
+    """use_quality=True through the epoch driver: quality targets travel with the batches ('qua' / 'drc_qua'), D_Qua takes one
+    optimiser step per D step (train_nele.py:362-365), and the checkpoint carries 'quality-model'."""
+    from nele_gan_amd.train_nele import GanTrainer
+    train, _ = _corpus()
+    for bt in train:
+        bt['qua'] = torch.tensor([[0.4, 0.5], [0.6, 0.3]], device='cuda')
+        bt['drc_qua'] = torch.tensor([[0.7, 0.8], [0.2, 0.9]], device='cuda')
+    tr = GanTrainer('estoi', use_quality=True)
+    w0 = tr.D_Qua.layers[4].weight_orig.detach().clone()
+    ck = str(tmp_path / 'c.pt')
+    out = tr.run_epoch(2, train, (), chkpt_path=ck, d_batch=4)
+    assert out['g_steps'] == 2 and out['d_steps'] == 6 and tr.optimizer_dqua.step_count == 6
+    assert not torch.equal(w0, tr.D_Qua.layers[4].weight_orig.detach())
+    assert 'quality-model' in torch.load(ck, map_location='cpu')
+    # mixed presence of quality targets inside one pass is an error, not a silent skip
+    train[1].pop('qua')
+    with pytest.raises(ValueError):
+        tr.run_epoch(3, train, ())
+
+
+def test_inference_on_eight_second_utterances_matches_the_oracle():
+    """BASELINE configs[4]: 8 s utterances (L = 128 000, T = 501: the IMCRA scan over 501 frames, G, iSTFT, RMS 0.03, PCM_16)."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.inference import Enhancer
+    from oracle.step import CpuStep
+    B, L = 4, 128000
+    c, v = synth.batch(B, L, start=900)
+    torch.manual_seed(3)
+    e = Enhancer()
+    cpu = CpuStep(_sd(e.G), None, metrics=('estoi',))
+    out = e.enhance(torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda(), pcm16=True).cpu().numpy()
+    ref = cpu.enhance(c, v)
+    assert out.shape == (B, 256 * (L // 256))
+    for b in range(B):
+        d = np.abs(out[b] - ref[b])
+        assert d.max() <= 1.5 / 32768 and np.mean(d > 1e-7) < 0.02     # PCM_16: rare one-LSB rounding flips (as test_train_gpu.py:34-36)
+        assert np.sqrt(np.mean(out[b].astype(np.float64) ** 2)) == pytest.approx(0.03, rel=2e-4)

@@ -1,14 +1,18 @@
-"""Summarise the PMC passes of tools/prof_r02.sh into profiles/r02/traffic.json (read by bench.py for roofline.traffic).
+"""Summarise the PMC passes of tools/prof_round.sh into profiles/<round>/traffic.json (read by bench.py for roofline.traffic).
 
   FETCH_SIZE / WRITE_SIZE (KB, separate passes) -> HBM bytes per launch, gfx950-corrected as MI355X_MICROARCH.md prescribes:
   FETCH_SIZE counts 16-byte-per-lane loads at half their bytes (x 2), WRITE_SIZE is exact.
   SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) / (1024 SIMDs x duration x 2.4 GHz) -> MFMA-busy fraction.
-usage: python tools/make_traffic_json.py gpurun_out/r02_prof batch length metrics precision
+usage: python tools/make_traffic_json.py gpurun_out/r03_prof batch length metrics precision [round=r03]
+The file records the sha256 of nele_gan_amd/csrc it was taken on; bench.py drops the counters when the kernel sources have changed since.
 """
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
+ROUND = sys.argv[6] if len(sys.argv) > 6 else 'r03'
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 work = {'batch': int(sys.argv[2]), 'length': int(sys.argv[3]), 'metrics': sys.argv[4], 'precision': sys.argv[5]}
 WANT = ('conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_tile16_kernel<3, 4>', 'conv_tile16_kernel<2, 4>', 'conv_tile16_kernel<1, 4>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7, true>', 'conv_wgrad_tile16_kernel<4, 7, false>', 'conv_wgrad_tile16_kernel<3, 4, false>',
         'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_bank_scan_kernel<true, true, false, true>', 'haspi_bank_scan_kernel<false, true, false, false>',
@@ -33,7 +37,8 @@ for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ'):
                 acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
                 if d == 'pmc_SQ' and r['Counter_Name'] == 'SQ_WAVE_CYCLES':
                     acc[k]['_dur_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
-out = {'note': __doc__.strip().split('\n\n')[0] + ' Averages per launch over all launches of the kernel in `bench.py --steps 3 --warmup 1 --cpu-utts 0 --companions 0`.',
+out = {'note': __doc__.strip().split('\n\n')[0] + ' Averages per launch over all launches of the kernel in `bench.py --steps 3 --warmup 1 --cpu-utts 0 --companions 0 --no-isolated`.',
+       'csrc_sha': bench.csrc_sha(),
        'workload': work, 'kernels': {}}
 for k, c in acc.items():
     avg = {n: sum(v) / len(v) for n, v in c.items()}
@@ -46,6 +51,7 @@ for k, c in acc.items():
                   'SQ_BUSY_CU_CYCLES': avg.get('SQ_BUSY_CU_CYCLES'), 'SQ_WAVE_CYCLES': avg.get('SQ_WAVE_CYCLES'), 'pmc_pass_duration_us': avg['_dur_ns'] / 1e3,
                   'mfma_busy_frac': avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * avg['_dur_ns'] * 2.4)})
     out['kernels'][k] = e
-json.dump(out, open('profiles/r02/traffic.json', 'w'), indent=1)
+os.makedirs('profiles/%s' % ROUND, exist_ok=True)
+json.dump(out, open('profiles/%s/traffic.json' % ROUND, 'w'), indent=1)
 for k, e in sorted(out['kernels'].items()):
     print('%-40s %s' % (k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in e.items() if a in ('hbm_bytes_corrected', 'mfma_busy_frac', 'pmc_pass_duration_us', 'launches')}))
