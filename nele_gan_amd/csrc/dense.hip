@@ -18,19 +18,7 @@
 #include <type_traits>
 #include <cstring>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvGeom {
-    // input buffer [B][H][W][C]; window origin of output (ho,wo) is (ho+ih0, wo+iw0)
-    int H, W, C, ih0, iw0;
-    int Hout, Wout;           // output positions per utterance; M = B*Hout*Wout
-    int seglen, segstride;    // KW*C, W*C
-    int Ktot;                 // KH*KW*C
-    // output buffer [B][OH][OW][OC]; element (ho,wo,n) at (ho+oh0, wo+ow0, n)
-    int OH, OW, OC, oh0, ow0;
-};
-
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_LRELU = 2, EPI_MASK_LRELU_GRAD = 3, EPI_BIAS_EXPTANH = 4 };
+#include "conv_common.h"
 
 struct GemmArgs {
     const float* A;
@@ -324,8 +312,6 @@ __global__ void weight_frag_kernel(const float* __restrict__ Wg, int N, int Ktot
 // span is converted to bf16 while it is staged in LDS; a lane's A fragment is 8 consecutive channels (one ds_read_b128),
 // the weights arrive fragment-major in bf16.  Wave tile 128 x (16*TN), block = 4 waves = 512 output positions.
 // Each kernel row is padded to a multiple of 32 k-values with zero weights (the A side then reads finite neighbouring data).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define SPAN16_BM 512
 #define SPAN16_MAXRUN 10
 // Position stride of the staged span in LDS.  With C = 64 (D.conv5's data gradient: 64 gradient channels) the plain stride is 128 bytes and

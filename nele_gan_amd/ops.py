@@ -27,6 +27,9 @@ _SIGS = {
     'nele_conv_wgrad_bf16_d16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
     'nele_conv_wgrad_bf16_d16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_weight_prep_frag16': [_P, c_int, c_int, c_int, c_int, _P, _P],
+    'nele_conv16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'nele_conv16_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
+    'nele_conv16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
@@ -61,6 +64,9 @@ for _n, _a in _SIGS.items():
 _lib.lib.nele_weight_frag16_elems.argtypes = [c_int, c_int, c_int]
 _lib.lib.nele_weight_frag16_elems.restype = c_longlong
 _lib._SIGS['nele_weight_frag16_elems'] = _lib.lib.nele_weight_frag16_elems.argtypes
+_lib.lib.nele_conv16_wfrag_elems.argtypes = [c_int, c_int, c_int]
+_lib.lib.nele_conv16_wfrag_elems.restype = c_longlong
+_lib._SIGS['nele_conv16_wfrag_elems'] = _lib.lib.nele_conv16_wfrag_elems.argtypes
 _lib.lib.nele_conv_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int)]
 _lib.lib.nele_conv_wgrad_workspace_floats.restype = c_longlong
 _lib._SIGS['nele_conv_wgrad_workspace_floats'] = _lib.lib.nele_conv_wgrad_workspace_floats.argtypes
@@ -158,6 +164,32 @@ def conv_span_bf16(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
         e0.record()
     call('nele_conv_span_bf16_a16' if A.dtype == torch.bfloat16 else 'nele_conv_span_bf16', ptr(A), ptr(Wfrag), ptr(bias), ptr(aux), ptr(out), M, N, epi, SLOPE,
          g.arr, g.KH, g.KW, A.numel(), stream())
+    if prof:
+        e1.record()
+        PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
+
+
+def conv16_supported(B, N, g):
+    """Can this layer run on the bf16-activation tile kernel (csrc/conv16.hip)?"""
+    return bool(_lib.lib.nele_conv16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
+
+
+def conv16_wfrag_elems(N, seglen, KH):
+    return int(_lib.lib.nele_conv16_wfrag_elems(N, seglen, KH))
+
+
+def conv16(A16, Wfrag, bias, aux16, out, B, N, epi, g, tag=None):
+    """Conv2d forward / data gradient on bfloat16 activations: A16 [B][H][W][C] bf16, out bf16 or float32 (by its dtype),
+    aux16 = forward activation (bf16) for the LeakyReLU mask of a data gradient."""
+    M = B * g.Hout * g.Wout
+    if A16.dtype != torch.bfloat16 or (aux16 is not None and aux16.dtype != torch.bfloat16):
+        raise ValueError('conv16: activations must be bfloat16')
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call('nele_conv16', ptr(A16), ptr(Wfrag), ptr(bias), ptr(aux16), ptr(out), int(out.dtype == torch.bfloat16), M, N, epi, SLOPE, g.arr, g.KH, g.KW,
+         stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
