@@ -137,7 +137,41 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
         __syncthreads();
 
         int lu = 0, lr = 0;                            // step within its kernel row / ring slot of that kernel row's first input row, of the NEXT step to load
-        for (int c = 0; c < nchunk; ++c) {
+        const __bf16* wl = wring + lane * 8;
+        auto ldfrag = [&](int uu, bf16x8 (&af)[NP], bf16x8 (&bfr)[TN]) {
+            const int kk8 = lu * 32 + 8 * lg;
+            const int vk = vb + kk8 + (((kk8 >> p.lgC) << p.lgPAD) & p.padmask);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(wl + (uu * TN + j) * 512);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                int rr = lr + prow[k];
+                if (rr >= NR) rr -= NR;
+                af[k] = *reinterpret_cast<const bf16x8*>(lds16 + (rr * RSP + 16 * pcol[k] * CP) + vk);
+            }
+            if (++lu == p.sps) { lu = 0; if (++lr == NR) lr = 0; }
+        };
+        auto mm = [&](const bf16x8 (&af)[NP], const bf16x8 (&bfr)[TN]) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[k], acc[k][j], 0, 0, 0);
+        };
+        // One ds_read (and its address arithmetic) in the shadow of every MPR MFMAs; the fences keep the compiler from sinking the next
+        // step's reads back behind this step's MFMAs, and put the wait for them AFTER the MFMAs were issued.
+        constexpr int MPR = (NP * TN) / (NP + TN) > 0 ? (NP * TN) / (NP + TN) : 1;
+#define C16_INTERLEAVE()                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < NP + TN; ++q_) {                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+    }                                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, NP * TN, 0);                              \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                                   \
+    __builtin_amdgcn_sched_barrier(0)
+        const int nfull = p.nsteps / C16_SB, nrem = p.nsteps - nfull * C16_SB;
+        for (int c = 0; c < nfull; ++c) {
             // DMA behind this chunk's MFMAs: the weights of chunk c + 1 into the slot chunk c - 1 left, and the input row chunk c + 1 needs first
             if (c + 1 < nchunk) {
                 w_dma(c + 1);
@@ -145,59 +179,33 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
                 const int need = min(s_next_last / p.sps + TH - 1, nrows - 1);           // rows <= need must be resident when chunk c + 1 starts
                 if (need > resident) { ++resident; row_dma(resident); }
             }
-            const __bf16* wl = wring + (c & 1) * CH + lane * 8;
-            const int ns = min(C16_SB, p.nsteps - c * C16_SB);
-            // ---- ns k-steps from LDS only; fragments double buffered in registers
-            auto ldfrag = [&](int uu, bf16x8 (&af)[NP], bf16x8 (&bfr)[TN]) {
-                const int kk8 = lu * 32 + 8 * lg;
-                const int vk = vb + kk8 + (((kk8 >> p.lgC) << p.lgPAD) & p.padmask);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(wl + (uu * TN + j) * 512);
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    int rr = lr + prow[k];
-                    if (rr >= NR) rr -= NR;
-                    af[k] = *reinterpret_cast<const bf16x8*>(lds16 + (rr * RSP + 16 * pcol[k] * CP) + vk);
-                }
-                if (++lu == p.sps) { lu = 0; if (++lr == NR) lr = 0; }
-            };
-            auto mm = [&](const bf16x8 (&af)[NP], const bf16x8 (&bfr)[TN]) {
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[k], acc[k][j], 0, 0, 0);
-            };
+            // ---- 4 k-steps from LDS only; fragments double buffered in registers
             bf16x8 a0[NP], b0[TN], a1[NP], b1[TN];
             ldfrag(0, a0, b0);
-#define C16_INTERLEAVE()                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < NP + TN; ++q_) {                              \
-        __builtin_amdgcn_sched_group_barrier(0x008, (NP * TN) / (NP + TN) > 0 ? (NP * TN) / (NP + TN) : 1, 0); \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                \
-    }                                                                                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, NP * TN, 0)
-            if (ns == C16_SB) {
-                ldfrag(1, a1, b1);
-                mm(a0, b0);
-                C16_INTERLEAVE();
-                ldfrag(2, a0, b0);
-                mm(a1, b1);
-                C16_INTERLEAVE();
-                ldfrag(3, a1, b1);
-                mm(a0, b0);
-                C16_INTERLEAVE();
-                mm(a1, b1);
-            } else {
-                for (int uu = 0; uu < ns; ++uu) {
-                    if (uu) ldfrag(uu, a0, b0);
-                    mm(a0, b0);
-                }
-            }
-#undef C16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(1, a1, b1);
+            mm(a0, b0);
+            C16_INTERLEAVE();
+            ldfrag(2, a0, b0);
+            mm(a1, b1);
+            C16_INTERLEAVE();
+            ldfrag(3, a1, b1);
+            mm(a0, b0);
+            C16_INTERLEAVE();
+            mm(a1, b1);
+            wl += (c & 1) ? -CH : CH;
             if (c + 1 < nchunk) {
                 __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): the pieces this wave issued at the top of the chunk have landed
                 __syncthreads();                       // ONE barrier: chunk c + 1 and the new row are visible, chunk c's slot is free
             }
+        }
+#undef C16_INTERLEAVE
+        for (int uu = 0; uu < nrem; ++uu) {            // the last, short chunk (nothing left to prefetch)
+            bf16x8 a0[NP], b0[TN];
+            ldfrag(uu, a0, b0);
+            mm(a0, b0);
         }
 
         // ---- epilogue, in registers: lane (li, lg) holds channels n0 .. n0 + 4 TN - 1 of position li of each of its position tiles
@@ -268,6 +276,40 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             default: run(std::integral_constant<int, 1>{}); break;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ D's first layer (1 x 1, 4 -> 8 channels)
+// out[m][n] = LeakyReLU(bias[n] + sum_c in[m][c] * W[n][c]), exact float32 arithmetic, result stored as bf16: the layer is a stream of
+// 16 bytes in, 16 bytes out per position (model.py:105, 118 first Conv2d); one thread per position.  The fma chain runs over the
+// channels in the order 0, 2, 1, 3 - the order in which conv_gemm_kernel's two v_mfma_f32_16x16x4_f32 per k-step of 8 (even k, then
+// odd k) accumulate them - so the float32 values are the ones the float32-buffer path produces.
+__global__ __launch_bounds__(256) void conv16_pointwise_kernel(const float4* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                               __bf16* __restrict__ out, long long M, float slope) {
+    __shared__ float w[8][4], bs[8];
+    if (threadIdx.x < 32) w[threadIdx.x >> 2][threadIdx.x & 3] = W[threadIdx.x];
+    if (threadIdx.x < 8) bs[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        const float4 a = in[m];
+        bf16x8 h;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            float v = fmaf(a.w, w[n][3], fmaf(a.y, w[n][1], fmaf(a.z, w[n][2], a.x * w[n][0]))) + bs[n];
+            v = v > 0.f ? v : slope * v;
+            h[n] = (__bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(out + 8 * m) = h;
+    }
+}
+
+// in [M][4] float32 (channels-last D input), Wf [8][4] float32 (nele_weight_prep's forward layout, sigma-normalised), out [M][8] bf16
+extern "C" int nele_conv16_pointwise_fwd(const float* in, const float* Wf, const float* bias, void* out16, long long M, int N, float slope, void* stream) {
+    NELE_CHECK_ARG(in && Wf && bias && out16 && M > 0 && N == 8, "nele_conv16_pointwise_fwd: needs 4 -> 8 channels");
+    const long long blocks = (M + 255) / 256;
+    hipLaunchKernelGGL(conv16_pointwise_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(in), Wf, bias, reinterpret_cast<__bf16*>(out16), M, slope);
+    NELE_CHECK_LAUNCH("conv16_pointwise_kernel");
+    return NELE_OK;
 }
 
 // ------------------------------------------------------------------------------------------ weight fragments

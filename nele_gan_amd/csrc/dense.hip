@@ -1383,7 +1383,7 @@ struct WgradTileArgs {
     int d16;             // dOut is bf16 in memory
 };
 
-template <int NT, int KTW, bool D16 = false>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj); D16: dOut is bf16 in memory
+template <int NT, int KTW, bool D16 = false, bool A16 = false>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj); D16 / A16: dOut / the input activation is bf16 in memory
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 wt_lds[];     // halo rows [WT_TH][RS] + 64 slack, then dOut tile [256][WT_NP]
     __shared__ float bred[16][64];
@@ -1422,14 +1422,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
         const int wi0 = wo0 + g.iw0;
         const int vcols = max(0, min(wcols, g.W - wi0));
         __syncthreads();                                 // previous tile fully consumed
-        // ---- input rows ho0 + r + kh (float32 -> bf16), zero outside the input
+        // ---- input rows ho0 + r + kh (float32 -> bf16, or bf16 as stored), zero outside the input
 #pragma unroll
         for (int r = 0; r < WT_TH; ++r) {
             const int hi = ho0 + r + kh + g.ih0;
             const bool rin = hi < g.H;
-            const float* src = p.A + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
             const int nval = rin ? vcols * g.C : 0;
             const int emax = max(vcols * g.C - 8, 0);
+            if (A16) {
+                const __bf16* src16 = reinterpret_cast<const __bf16*>(p.A) + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
+                for (int e = tid * 8; e < RS; e += 2048) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(src16 + min(e, emax));
+                    if (!(e < nval)) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(halo + r * RS + e) = v;
+                }
+                continue;
+            }
+            const float* src = p.A + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
             for (int e = tid * 8; e < RS; e += 2048) {
                 const float* sp = src + min(e, emax);
                 const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
@@ -2030,10 +2042,18 @@ extern "C" int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, floa
     return conv_wgrad_impl(A, reinterpret_cast<const float*>(dOut16), workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 3, stream);
 }
 
+// ... and the input activation stored as bf16 too (model.Discriminator's bf16 mode: every activation and output gradient of layers 2-5 is bf16)
+extern "C" int nele_conv_wgrad_bf16_a16d16(const void* A16, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
+                                           const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
+    return conv_wgrad_impl(reinterpret_cast<const float*>(A16), reinterpret_cast<const float*>(dOut16), workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db,
+                           accumulate, 7, stream);
+}
+
 static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                            const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, int bf16, void* stream) {
     NELE_CHECK_ARG(A && dOut && workspace && geom && dW, "nele_conv_wgrad: null pointer");
     const int d16 = (bf16 >> 1) & 1;                       // dOut stored as bf16
+    const int a16 = (bf16 >> 2) & 1;                       // the input activation stored as bf16 (with d16 only)
     bf16 &= 1;
     WgradArgs p;
     memcpy(&p.g, geom, sizeof(ConvGeom));
@@ -2113,13 +2133,15 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         static bool wattr = false;
         if (!wattr) {
 #define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
-                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); } while (0)
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); } while (0)
             WT_ATTR(1, 2); WT_ATTR(2, 2); WT_ATTR(3, 2); WT_ATTR(4, 2); WT_ATTR(1, 4); WT_ATTR(2, 4); WT_ATTR(3, 4); WT_ATTR(4, 4);
             WT_ATTR(1, 7); WT_ATTR(2, 7); WT_ATTR(3, 7); WT_ATTR(4, 7);
 #undef WT_ATTR
             wattr = true;
         }
-#define WT_LAUNCH(NT_, K_) do { if (d16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true>), grid, dim3(256), (size_t)wt_lds, s, t); \
+#define WT_LAUNCH(NT_, K_) do { if (a16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true, true>), grid, dim3(256), (size_t)wt_lds, s, t); \
+                                else if (d16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true>), grid, dim3(256), (size_t)wt_lds, s, t); \
                                 else hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_>), grid, dim3(256), (size_t)wt_lds, s, t); } while (0)
 #define WT_PICK(K_) switch (NT) { case 1: WT_LAUNCH(1, K_); break; case 2: WT_LAUNCH(2, K_); break; case 3: WT_LAUNCH(3, K_); break; default: WT_LAUNCH(4, K_); break; }
         if (ktw <= 2) { WT_PICK(2) } else if (ktw <= 4) { WT_PICK(4) } else { WT_PICK(7) }
@@ -2132,6 +2154,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         p.bpart = t.bpart;
     }
     if (!tiled && d16) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv_wgrad_bf16_d16: this layer does not run on the tile kernel");
+    if (a16 && !d16) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_conv_wgrad: a bf16 activation needs a bf16 output gradient");
     if (!tiled && KH == 1 && KW == 1 && p.g.C == 4 && p.g.Ktot == 4 && (N == 4 || N == 8) && p.g.OC % 4 == 0 && splits >= 1) {
         // pointwise layer (D conv1): memory-bound row reduction; as many workgroups as there are partial slots, at most 64
         int sp = splits < 64 ? splits : 64;

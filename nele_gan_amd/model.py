@@ -416,25 +416,28 @@ _D_CONVS = [(8, 1), (16, 3), (32, 5), (48, 7), (64, 9)]   # (Cout, k) ; Cin of l
 
 
 class _DBuffers:
-    def __init__(self, B, T, dev, cin0):
+    def __init__(self, B, T, dev, cin0, mode16=False):
+        """mode16 (bf16 operand mode): where every layer's kernels support it (csrc/conv16.hip + the weight-gradient tile kernel) the
+        activations of conv1..conv4 and the output gradients of conv2..conv5 live in memory as bfloat16 - their consumers round them to
+        bf16 anyway.  conv5's activation (pooled in float32) and conv1's output gradient (float32 pointwise kernels) stay float32."""
         self.B, self.T = B, T
         self.gen = 0
         self.wvalid = None
         H, W, C = 64, T, 4
         self.dims = [(H, W, C)]
         self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
+        shapes = []
         for (cout, k) in _D_CONVS:
             Ho, Wo = H - k + 1, W - k + 1
             if Ho < 1 or Wo < 1:
                 raise ValueError("Discriminator: T=%d is too short (needs T >= 21, model.py:105-109)" % T)
-            self.act.append(_empty((B, Ho, Wo, cout), dev))
             self.gf.append(Geom(H, W, C, Ho, Wo, k, k, Ho, Wo, cout))
             p = k - 1
             self.pad.append(p)
-            # zero-bordered gradient buffer of this layer's OUTPUT
-            self.gbuf.append(_zeros((B, Ho + 2 * p, Wo + 2 * p, cout), dev))
+            shapes.append(((B, Ho, Wo, cout), (B, Ho + 2 * p, Wo + 2 * p, cout)))
             self.dims.append((Ho, Wo, cout))
             H, W, C = Ho, Wo, cout
+        self._shapes = shapes
         self.ddin = _empty((B, 64, T, 4), dev)
         for l, (cout, k) in enumerate(_D_CONVS):
             Hi, Wi, Ci = self.dims[l]
@@ -450,13 +453,22 @@ class _DBuffers:
             # weight gradient: A = layer input, dOut = gbuf[l] interior
             self.gw.append(Geom(Hi, Wi, Ci, Ho, Wo, k, k, Ho + 2 * p, Wo + 2 * p, cout, 0, 0, p, p))
         cins = [4] + [c for (c, k) in _D_CONVS[:-1]]
+        nl = len(_D_CONVS)
+        self.c16 = bool(mode16) and all(ops.conv16_supported(B, _D_CONVS[l][0], self.gf[l]) and ops.conv16_supported(B, cins[l], self.gb[l]) and
+                                        ops.wgrad_tile_supported(B, _D_CONVS[l][0], self.gw[l]) for l in range(1, nl))
+        b16 = torch.bfloat16
+        for l, (ashape, gshape) in enumerate(shapes):
+            a16, g16 = self.c16 and l < nl - 1, self.c16 and l >= 1
+            self.act.append(torch.empty(ashape, dtype=b16 if a16 else torch.float32, device=dev))
+            # zero-bordered gradient buffer of this layer's OUTPUT
+            self.gbuf.append(torch.zeros(gshape, dtype=b16 if g16 else torch.float32, device=dev))
         self.span_f = [ops.span_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
         self.span_b = [ops.span_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
         self.span16_f = [ops.span16_supported(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gf)]
         self.span16_b = [ops.span16_supported(B, cin, g) for cin, g in zip(cins, self.gb)]
         # bf16 mode: the last layer's output gradient (the pooling gradient) as bfloat16 - its data gradient re-stages it once per kernel
         # row; allocated on first use (same shape and zero border as gbuf[-1])
-        self.grad16_ok = ops.grad16_supported(B, cins[-1], self.gb[-1], _D_CONVS[-1][0], self.gw[-1])
+        self.grad16_ok = (not self.c16) and ops.grad16_supported(B, cins[-1], self.gb[-1], _D_CONVS[-1][0], self.gw[-1])
         self.gbuf16 = None
         self.P = self.dims[-1][0] * self.dims[-1][1]
         self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
@@ -541,9 +553,12 @@ class _DiscriminatorBase(nn.Module):
     def _weights(self, dev):
         dev = _norm_dev(dev)
         if self._w is None or self._w['sigma'].device != dev:
-            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': [], 'wff16': [], 'wbf16': []}
+            w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': [], 'wff16': [], 'wbf16': [], 'wf16c': [], 'wb16c': []}
             cin = 4
             for (cout, k) in _D_CONVS:
+                # fragment streams of csrc/conv16.hip (bf16 activations in memory): forward [cout][k*k*cin], data gradient [cin][k*k*cout]
+                w['wf16c'].append(torch.zeros(ops.conv16_wfrag_elems(cout, k * cin, k), dtype=torch.bfloat16, device=dev) if k > 1 else None)
+                w['wb16c'].append(torch.zeros(ops.conv16_wfrag_elems(cin, k * cout, k), dtype=torch.bfloat16, device=dev) if k > 1 else None)
                 w['wf'].append(_zeros((cout, k * k * cin), dev))
                 w['wb'].append(_zeros((cin, k * k * cout), dev))
                 w['wff'].append(_zeros((ops.frag_floats(cout, k * k * cin),), dev) if (k * k * cin) % 8 == 0 else None)
@@ -555,8 +570,8 @@ class _DiscriminatorBase(nn.Module):
         return self._w
 
     def _get_bufs(self, B, T, dev):
-        key = (B, T, str(_norm_dev(dev)))
-        return key, _lru_get(self._bufs, key, lambda: _DBuffers(B, T, dev, self._cin))
+        key = (B, T, str(_norm_dev(dev)), self.precision)
+        return key, _lru_get(self._bufs, key, lambda: _DBuffers(B, T, dev, self._cin, mode16=self.precision == 'bf16'))
 
     def _mlp_ptrs(self, w):
         arr = (c_void_p * 9)()
@@ -597,10 +612,17 @@ class _DiscriminatorBase(nn.Module):
             if jk not in w:
                 cin, cpad = self._cin, 4
                 pj, dj, fj, ej = [], [], [], []
+                cj, gj = [], []
                 for l, (cout, k) in enumerate(_D_CONVS):
                     m = self.layers[l]
                     pj += [m.weight_orig.data_ptr(), w['sigma'][l:l + 1].data_ptr(), w['wf'][l].data_ptr(), w['wb'][l].data_ptr()]
                     dj += [cout, cin, cpad, k, k]
+                    if bf.c16:
+                        if l >= 1:
+                            cj += [w['wf'][l].data_ptr(), w['wf16c'][l].data_ptr(), w['wb'][l].data_ptr(), w['wb16c'][l].data_ptr()]
+                            gj += [cout, k * k * cpad, k * cpad, k, cpad, k * k * cout, k * cout, k]
+                        cin = cpad = cout
+                        continue
                     if bf.span16_f[l]:
                         fj += [w['wf'][l].data_ptr(), w['wff16'][l].data_ptr()]
                         ej += [cout, k * k * cpad, k * cpad, k]
@@ -609,11 +631,15 @@ class _DiscriminatorBase(nn.Module):
                         ej += [cpad, k * k * cout, k * cout, k]
                     cin = cpad = cout
                 w[jk] = ((c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5,
-                         (c_void_p * max(1, len(fj)))(*fj), (ctypes.c_int * max(1, len(ej)))(*ej), len(ej) // 4)
-            pja, dja, npj, fja, eja, nfj = w[jk]
+                         (c_void_p * max(1, len(fj)))(*fj), (ctypes.c_int * max(1, len(ej)))(*ej), len(ej) // 4,
+                         (c_void_p * max(1, len(cj)))(*cj), (ctypes.c_int * max(1, len(gj)))(*gj), len(gj) // 4)
+            pja, dja, npj, fja, eja, nfj, cja, gja, ncj = w[jk]
             call('nele_weight_prep_batch', pja, dja, npj, stream())
             if nfj:
                 call('nele_weight_prep_frag16_batch', fja, eja, nfj, stream())
+            if ncj:
+                call('nele_conv16_weight_prep_batch', cja, gja, ncj, stream())
+                return
             # layers the bf16 kernels decline still need the float32 fragment layout
             cin, cpad = self._cin, 4
             for l, (cout, k) in enumerate(_D_CONVS):
@@ -655,7 +681,14 @@ class _DiscriminatorBase(nn.Module):
         a = din.contiguous()
         bf.din = a
         for l, (cout, k) in enumerate(_D_CONVS):
-            if self.precision == 'bf16' and bf.span16_f[l]:
+            if bf.c16:
+                # bf16 activations in memory: conv1 as a float32 pointwise stream, conv2..conv5 on the ring / DMA tile kernel
+                if l == 0:
+                    ops.conv16_pointwise_fwd(a, w['wf'][0], self.layers[0].bias, bf.act[0])
+                else:
+                    ops.conv16(a, w['wf16c'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l],
+                               tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
+            elif self.precision == 'bf16' and bf.span16_f[l]:
                 ops.conv_span_bf16(a, w['wff16'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             elif bf.span_f[l]:
                 ops.conv_span(a, w['wff'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
@@ -693,10 +726,10 @@ class _DiscriminatorBase(nn.Module):
         wgrad = self.weight_grad_enabled
         Ho, Wo, _ = bf.dims[-1]
         p5 = bf.pad[-1]
-        g16 = self.precision == 'bf16' and bf.grad16_ok
-        if g16 and bf.gbuf16 is None:
+        g16 = self.precision == 'bf16' and (bf.grad16_ok or bf.c16)
+        if g16 and not bf.c16 and bf.gbuf16 is None:
             bf.gbuf16 = torch.zeros(bf.gbuf[-1].shape, dtype=torch.bfloat16, device=bf.gbuf[-1].device)
-        glast = bf.gbuf16 if g16 else bf.gbuf[-1]          # the last layer's output gradient, as its two consumers read it
+        glast = bf.gbuf16 if (g16 and not bf.c16) else bf.gbuf[-1]      # the last layer's output gradient, as its two consumers read it
         call('nele_gap_mlp_bwd_var16' if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
              self._mlp_ptrs(w), nout, SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1),
              ptr(bf.dpooled), ptr(glast), stream())
@@ -758,7 +791,9 @@ class _DiscriminatorBase(nn.Module):
                 m.bias.grad.add_(tmpb)
                 if wst is not None:
                     ctx.__exit__(None, None, None)
-            if l > 0:
+            if l > 0 and bf.c16:
+                ops.conv16(bf.gbuf[l], w['wb16c'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
+            elif l > 0:
                 if self.precision == 'bf16' and bf.span16_b[l]:
                     ops.conv_span_bf16(glast if l == len(_D_CONVS) - 1 else bf.gbuf[l], w['wbf16'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci,
                                        EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))

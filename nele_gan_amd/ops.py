@@ -30,6 +30,8 @@ _SIGS = {
     'nele_conv16_supported': [c_int, c_int, ctypes.POINTER(c_int), c_int, c_int],
     'nele_conv16_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
     'nele_conv16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, _P],
+    'nele_conv16_pointwise_fwd': [_P, _P, _P, _P, c_longlong, c_int, c_float, _P],
+    'nele_conv_wgrad_bf16_a16d16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
@@ -174,6 +176,17 @@ def conv16_supported(B, N, g):
     return bool(_lib.lib.nele_conv16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
 
 
+def wgrad_tile_supported(B, N, g):
+    """Does this layer's weight gradient run on the 2-D tile kernel (the one that takes bf16 operands from memory)?"""
+    return bool(_lib.lib.nele_conv_wgrad_bf16_d16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
+
+
+def conv16_pointwise_fwd(din, Wf, bias, out16):
+    """D's first layer (1 x 1, 4 -> 8 channels) on the packed float32 input, bf16 activation out."""
+    M = din.numel() // 4
+    call('nele_conv16_pointwise_fwd', ptr(din), ptr(Wf), ptr(bias), ptr(out16), M, 8, SLOPE, stream())
+
+
 def conv16_wfrag_elems(N, seglen, KH):
     return int(_lib.lib.nele_conv16_wfrag_elems(N, seglen, KH))
 
@@ -210,7 +223,9 @@ def conv_wgrad(A, dOut, ws, B, N, g, Cvalid, dW, db, accumulate=True, bf16=False
     if dOut.dtype == torch.bfloat16:
         if not bf16:
             raise ValueError('conv_wgrad: a bfloat16 output gradient needs bf16=True')
-        fn = 'nele_conv_wgrad_bf16_d16'
+        fn = 'nele_conv_wgrad_bf16_a16d16' if A.dtype == torch.bfloat16 else 'nele_conv_wgrad_bf16_d16'
+    elif A.dtype == torch.bfloat16:
+        raise ValueError('conv_wgrad: a bfloat16 activation needs a bfloat16 output gradient')
     call(fn, ptr(A), ptr(dOut), ptr(ws), ws.numel(), M, N, g.arr, g.KH, g.KW, Cvalid, ptr(dW), ptr(db), int(accumulate), stream())
     if prof:
         e1.record()

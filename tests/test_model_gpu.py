@@ -293,6 +293,7 @@ def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, 
     torch.manual_seed(5)
     x = torch.rand(B, 3, 64, T, device='cuda') * 2
     res = {}
+    monkeypatch.setenv('NELE_CONV16', '0')        # the round-2 kernels (float32 activations in memory): the fallback for geometries conv16 declines
     for flag in ('1', '0'):
         monkeypatch.setenv('NELE_GRAD16', flag)
         D = load_recipe(mods.Discriminator(), 33)
@@ -310,5 +311,40 @@ def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, 
     for k in g0:
         if k.endswith('layers.4.bias') or k.endswith('layers.4.conv.bias'):
             torch.testing.assert_close(g1[k], g0[k], rtol=4e-3, atol=4e-3 * float(g0[k].abs().max()))
+        else:
+            assert torch.equal(g1[k], g0[k]), k
+
+
+def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, monkeypatch):
+    """Round 3: in bf16 mode the activations of conv1..conv4 and the output gradients of conv2..conv5 are STORED as bfloat16
+    (csrc/conv16.hip; nele_conv_wgrad_bf16_a16d16).  Every consumer of those tensors rounded them to bf16 while staging them, so the MFMA
+    operands are the same numbers as with float32 buffers (NELE_CONV16=0: the round-2 kernels), accumulated over k in the same order:
+    scores, input gradient and every weight gradient must be BIT-identical.  Only the bias gradients of conv2..conv5 sum bf16-rounded
+    instead of float32 output gradients (the same documented effect as for conv5 in round 2)."""
+    B, T = 3, 251
+    torch.manual_seed(6)
+    x = torch.rand(B, 3, 64, T, device='cuda') * 2
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('NELE_CONV16', flag)
+        D = load_recipe(mods.Discriminator(), 34)
+        D.precision = 'bf16'
+        D.eval()
+        xin = x.clone().requires_grad_(True)
+        score = D(xin)
+        score.pow(2).sum().backward()
+        bf = next(iter(D._bufs.values()))
+        assert bf.c16 == (flag == '1')
+        assert (bf.act[0].dtype == torch.bfloat16) == (flag == '1') and bf.act[4].dtype == torch.float32 and bf.gbuf[0].dtype == torch.float32
+        res[flag] = (score.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None},
+                     [a.float().clone() for a in bf.act])
+    s1, gin1, g1, a1 = res['1']
+    s0, gin0, g0, a0 = res['0']
+    for l in range(5):                                      # activations: what is stored is the bf16 rounding of what the float32 path stores
+        assert torch.equal(a1[l], a0[l].bfloat16().float() if l < 4 else a0[l]), 'activation of conv%d' % (l + 1)
+    assert torch.equal(s1, s0) and torch.equal(gin1, gin0)
+    for k in g0:
+        if '.bias' in k and k.startswith('layers.') and not k.startswith('layers.0.'):
+            torch.testing.assert_close(g1[k], g0[k], rtol=8e-3, atol=8e-3 * float(g0[k].abs().max()))
         else:
             assert torch.equal(g1[k], g0[k]), k
