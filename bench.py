@@ -404,7 +404,8 @@ def main():
                         PROFILE_ROUND, tj.get('csrc_sha'), csrc_sha())
         except Exception:
             pmc = {}
-        traffic = pmc.get('conv_tile16_kernel<4, 8>', {}).get('hbm_bytes_corrected')
+        ckey = 'conv16_kernel<4, 4, false>'                    # D.conv5 forward: 48 -> 64 channels (TN = 4), 4-row tiles, float32 output
+        traffic = pmc.get(ckey, {}).get('hbm_bytes_corrected')
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
         iso_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in iso) / max(1, len(iso))
@@ -423,9 +424,9 @@ def main():
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma',
                          'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
-                             'conv_tile16_kernel<4,8>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
+                             'conv16_kernel<4,4,false>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'mfma_busy_frac': pmc.get('conv_tile16_kernel<4, 8>', {}).get('mfma_busy_frac'), 'launch_ms': kernel_ms,
+                         'traffic': traffic, 'mfma_busy_frac': pmc.get(ckey, {}).get('mfma_busy_frac'), 'launch_ms': kernel_ms,
                          'launch_ms_gstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_g) / max(1, len(prof_g)),   # beside the half-GPU tridiagonalisation
                          'launch_ms_dstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_d) / max(1, len(prof_d)),
                          'isolated_launch_ms': iso_ms, 'achieved_isolated': (flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0),
@@ -442,7 +443,7 @@ def main():
             out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
                                      'achieved': w_flops / (w_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                                      'frac': w_flops / (w_ms * 1e-3) / 1e12 / peak,
-                                     'traffic': (pmc.get('conv_wgrad_tile16_kernel<4, 7, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, false>') or pmc.get('conv_wgrad_tile16_kernel<4, 7>') or {}).get('hbm_bytes_corrected'),
+                                     'traffic': (pmc.get('conv_wgrad_tile16_kernel<4, 7, true, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, false>') or pmc.get('conv_wgrad_tile16_kernel<4, 7>') or {}).get('hbm_bytes_corrected'),
                                      'algorithmic_bytes': prof_w[0][2], 'launch_ms': w_ms, 'launches_timed': len(prof_w)}
         if hbm_ms:
             # HASPI signal filter bank (pass 2) + compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step - the

@@ -124,6 +124,31 @@ int nele_conv_span_bf16_a16(const void* A16, const void* Wfrag, const float* bia
 int nele_conv_wgrad_bf16_d16_supported(int M, int N, const int* geom_host, int KH, int KW);
 int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
                              const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
+/* ... and with the input activation stored as bfloat16 too (round 3: every activation of D.conv1-4 and every output gradient of
+ * D.conv2-5 lives in memory as bf16 in bf16 mode).  Same kernel, same bf16 operands, same accumulation order as the float32-buffer
+ * forms: the weight gradient is bit-identical, the bias gradient sums the bf16-rounded output gradient. */
+int nele_conv_wgrad_bf16_a16d16(const void* A16, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
+                                const int* geom_host, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream);
+
+/* ---- Conv2d on bfloat16 activations (csrc/conv16.hip): model.py:105-109, 118-122 F.conv2d + LeakyReLU(0.3) and its autograd -------
+ * The discriminator's conv2..conv5, forward and data gradient, bf16 MFMA operands / float32 accumulate, with the operands READ AS
+ * bf16 FROM MEMORY: A16 [B][H][W][C] bf16 channels-last (C a multiple of 8, <= 64), out [B][OH][OW][OC] bf16 (out_bf16 != 0) or
+ * float32, aux16 [B][Hout][Wout][N] bf16 = the forward activation whose sign gates a data gradient (EPI_MASK_LRELU_GRAD).
+ * Wfrag: fragment stream of nele_conv16_weight_prep_batch (nele_conv16_wfrag_elems bf16 elements) made from the float32 GEMM layouts
+ * nele_weight_prep writes (forward [N][KH][KW][C], or the flipped data-gradient layout).  geom_host as for nele_conv_gemm; the data
+ * gradient is the forward kernel over the zero-bordered output-gradient buffer.  One tile = 4 (or 8) output rows x 64 columns x all N
+ * channels; the input halo is a ring of tile-rows + 1 rows in LDS filled by global->LDS DMA, weights stream through a two-slot LDS
+ * ring, two workgroups share a CU.  nele_conv16_supported: 0 = use nele_conv_span_bf16 / nele_conv_gemm_bf16 (KH or KW == 1, C < 8,
+ * N > 64, or NELE_CONV16=0). */
+int nele_conv16_supported(int M, int N, const int* geom_host, int KH, int KW);
+long long nele_conv16_wfrag_elems(int N, int seglen, int KH);
+/* jobs <= 16; ptrs_host[2 j] = Wg float32 [N][Ktot] (device), ptrs_host[2 j + 1] = Wfrag bf16 (device); dims_host[4 j ..] = {N, Ktot, seglen, KH} */
+int nele_conv16_weight_prep_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream);
+int nele_conv16(const void* A16, const void* Wfrag, const float* bias, const void* aux16, void* out, int out_bf16, int M, int N, int epi,
+                float slope, const int* geom_host, int KH, int KW, void* stream);
+/* The discriminator's first layer (1 x 1 Conv2d, 3 (+1 zero) -> 8 channels, model.py:105): in [M][4] float32 (the packed D input),
+ * Wf [8][4] float32 (nele_weight_prep's forward layout), out16 [M][8] bf16 = LeakyReLU(W in + bias), exact float32 arithmetic. */
+int nele_conv16_pointwise_fwd(const float* in, const float* Wf, const float* bias, void* out16, long long M, int N, float slope, void* stream);
 
 /* PyTorch parameter layout [N][Cvalid][KH][KW] (optionally / sigma[0]) -> GEMM layouts:
  * Wf[n][kh][kw][c] (c zero-padded to C) and, if Wb != NULL, the flipped data-gradient layout
@@ -270,6 +295,13 @@ int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, c
  * (x may be NULL).  Phase 0 runs 3 then 4, so the split is bit-identical to the one-shot call. */
 int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
                           void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info, int phase, void* stream);
+/* haspi_v2(x, fx, y, fy, HL) for a hearing-impaired listener (pyhaspi2.py:76-107 with eb_LossParameters :779-807 and the HLx / HL
+ * split of eb_EarModel :1155-1166).  hl6_host: HOST pointer to the audiogram at 250, 500, 1000, 2000, 4000, 6000 Hz in dB HL (NULL =
+ * normal hearing); itype 0 = the reference signal is heard with normal hearing (haspi_v2, haspi), 2 = both signals with the loss
+ * (hasqi_v2); itype 1 (NAL-R) raises NotImplementedError in the reference itself (eb_NALR :830-831): NELE_ERR_UNSUPPORTED. */
+int nele_metric_haspi_var_hl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
+                             const double* hl6_host, int itype, void* workspace, long long workspace_bytes, float* raw, float* mapped,
+                             int* info, int phase, void* stream);
 
 /* pyHASPI/pyhaspi2.py:109-157 haspi(x, fx, y, fy, HL, alpha) (HASPI version 1) and :32-74 hasqi_v2(x, fx, y, fy, HL), HL = 0: same ear
  * model plus the basilar-membrane motion (pyhaspi2.py:897, :997, :1076, :1087), 16 ms raised-cosine segments (eb_EnvSmooth :674-703),
@@ -287,6 +319,11 @@ long long nele_metric_haspi_quality_workspace_bytes(int B, int L, int fs_in);
 int nele_metric_haspi_quality(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise,
                               unsigned long long seed, double alpha, void* workspace, long long workspace_bytes, double* out, int* info,
                               void* stream);
+/* The same for a hearing-impaired listener (hl6_host, itype as for nele_metric_haspi_var_hl): itype 0 = haspi() (columns 0-4 of out are
+ * that call's results), itype 2 = hasqi_v2() (columns 5-11): with a loss the two ear models differ, one call serves one of them. */
+int nele_metric_haspi_quality_hl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise,
+                                 unsigned long long seed, double alpha, const double* hl6_host, int itype, void* workspace,
+                                 long long workspace_bytes, double* out, int* info, void* stream);
 
 /* ---- evaluation path (csrc/reverb.hip) ---------------------------------------------------------------------- */
 

@@ -26,7 +26,9 @@
 #include <type_traits>
 
 #define C16_TW 64        // output columns per tile
+#ifndef C16_SB
 #define C16_SB 4         // k-steps (of 32) per weight chunk
+#endif
 
 struct Conv16Args {
     const __bf16* A;
@@ -95,14 +97,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
         for (int t = 0; t < 3; ++t)
             if (wave + 4 * t < npieces) c16_dma(src + rsrc[t], dst + 512 * (wave + 4 * t));
     };
-    // ---- weight chunks: SB * TN pieces of 1 KB per chunk, wave w moves pieces w, w + 4, ..: TN per wave
+    // ---- weight chunks: SB * TN pieces of 1 KB per chunk, wave w moves pieces w, w + 4, ..
     const int nchunk = (p.nsteps + C16_SB - 1) / C16_SB;
     const __bf16* wsrc = p.Wfrag + 512 * wave + 8 * lane;
     auto w_dma = [&](int c) {
         const __bf16* src = wsrc + (size_t)c * CH;
         __bf16* dst = wring + (c & 1) * CH + 512 * wave;
 #pragma unroll
-        for (int q = 0; q < TN; ++q) c16_dma(src + 2048 * q, dst + 2048 * q);
+        for (int q = 0; q < (C16_SB * TN + 3) / 4; ++q)
+            if ((C16_SB * TN) % 4 == 0 || wave + 4 * q < C16_SB * TN) c16_dma(src + 2048 * q, dst + 2048 * q);
     };
     int resident = min(NR, nrows) - 1;                 // rows 0 .. resident are (being) staged: every ring slot is written here once
     for (int r = 0; r <= resident; ++r) row_dma(r);
@@ -179,22 +182,19 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
                 const int need = min(s_next_last / p.sps + TH - 1, nrows - 1);           // rows <= need must be resident when chunk c + 1 starts
                 if (need > resident) { ++resident; row_dma(resident); }
             }
-            // ---- 4 k-steps from LDS only; fragments double buffered in registers
+            // ---- SB k-steps from LDS only; fragments double buffered in registers
             bf16x8 a0[NP], b0[TN], a1[NP], b1[TN];
             ldfrag(0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
-            ldfrag(1, a1, b1);
-            mm(a0, b0);
-            C16_INTERLEAVE();
-            ldfrag(2, a0, b0);
-            mm(a1, b1);
-            C16_INTERLEAVE();
-            ldfrag(3, a1, b1);
-            mm(a0, b0);
-            C16_INTERLEAVE();
-            mm(a1, b1);
+#pragma unroll
+            for (int uu = 0; uu + 1 < C16_SB; ++uu) {
+                if (uu & 1) { ldfrag(uu + 1, a0, b0); mm(a1, b1); }
+                else { ldfrag(uu + 1, a1, b1); mm(a0, b0); }
+                C16_INTERLEAVE();
+            }
+            if (C16_SB & 1) mm(a0, b0); else mm(a1, b1);
             wl += (c & 1) ? -CH : CH;
             if (c + 1 < nchunk) {
                 __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): the pieces this wave issued at the top of the chunk have landed

@@ -49,6 +49,7 @@ struct HaspiWs {
     hp_env_t* ctl;   // [B][2][n24][32] control envelope |u|^2 (-> compression gain in the unfused diagnostic path)
     hp_env_t* env;   // [B][2][n24][32] signal envelope |u|^2 -> compressed, dB SL -> adapted dB SL
     double* bw;      // [B][2][32]    adjusted bandwidths (x then y)
+    double* loss;    // [2][5][32]    eb_LossParameters per signal (x, y) and channel: attnOHC, BWmin, lowknee, CR, attnIHC (haspi_loss_kernel)
     double* ssp;     // [B][2][nchunk][32] control-bank sum-of-squares partials per scan chunk
     double* est;     // [B][2][nchunk][4][64] filter-bank state at the END of each scan chunk, started from a zero state (pass 1)
     double* pmat;    // [1 + B*2][32][16] 4x4 state-transition matrices M^lc per channel: entry 0 control bank, 1 + row signal bank
@@ -350,6 +351,46 @@ __device__ __forceinline__ double hp_bw1(int ch) {
     return 1.0 + r + 2.0 * r * r * r * r * r * r;
 }
 
+// eb_LossParameters (pyhaspi2.py:779-807) of an audiogram HL[6] at (250, 500, 1000, 2000, 4000, 6000) Hz, per signal and channel.
+// haspi_v2 / haspi (itype 0): the reference signal x is heard with normal hearing (HLx = 0 HL, pyhaspi2.py:1162-1165), the processed
+// signal y with HL; hasqi_v2 (itype 2): both with HL.  HL = 0: attnOHC = attnIHC = 0, BWmin = 1, lowknee = 30, CR = 1.25 + 2.25 ch / 31.
+struct HpHL { double x[6], y[6]; };
+struct HpLoss { double attnOHC, BWmin, lowknee, CR, attnIHC; };
+__device__ __forceinline__ HpLoss hp_loss(const HaspiWs& ws, int sig, int ch) {
+    const double* p = ws.loss + (size_t)sig * 5 * HP_NCH + ch;
+    HpLoss l;
+    l.attnOHC = p[0]; l.BWmin = p[HP_NCH]; l.lowknee = p[2 * HP_NCH]; l.CR = p[3 * HP_NCH]; l.attnIHC = p[4 * HP_NCH];
+    return l;
+}
+__global__ __launch_bounds__(64) void haspi_loss_kernel(HaspiWs ws, HpHL hl) {
+    const int sig = threadIdx.x >> 5, ch = threadIdx.x & 31;
+    const double* HL = sig ? hl.y : hl.x;
+    // np.interp(cfreq, [cfreq[0], 250 .. 6000, cfreq[-1]], [HL[0], HL[0..5], HL[5]]), negative losses clipped to 0
+    const double aud[6] = {250.0, 500.0, 1000.0, 2000.0, 4000.0, 6000.0};
+    const double cf = hp_cfreq(ch);
+    double loss;
+    if (cf <= aud[0]) loss = HL[0];
+    else if (cf >= aud[5]) loss = HL[5];
+    else {
+        int k = 0;
+        while (k < 4 && cf >= aud[k + 1]) ++k;
+        const double slope = (HL[k + 1] - HL[k]) / (aud[k + 1] - aud[k]);
+        loss = slope * (cf - aud[k]) + HL[k];                               // numpy's interp formula
+    }
+    if (loss < 0.0) loss = 0.0;
+    const double CR0 = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+    const double maxOHC = 70.0 * (1.0 - (1.0 / CR0)), thrOHC = 1.25 * maxOHC;
+    double attnOHC, attnIHC;
+    if (loss < thrOHC) { attnOHC = 0.8 * loss; attnIHC = 0.2 * loss; }
+    else { attnOHC = 0.8 * thrOHC; attnIHC = 0.2 * thrOHC + (loss - thrOHC); }
+    const double r = attnOHC / 50.0;
+    const double BW = 1.0 + r + 2.0 * (r * r * r * r * r * r);
+    const double lowknee = attnOHC + 30.0, upamp = 30.0 + 70.0 / CR0;
+    const double CR = (100.0 - lowknee) / (upamp + attnOHC - lowknee);
+    double* p = ws.loss + (size_t)sig * 5 * HP_NCH + ch;
+    p[0] = attnOHC; p[HP_NCH] = BW; p[2 * HP_NCH] = lowknee; p[3 * HP_NCH] = CR; p[4 * HP_NCH] = attnIHC;
+}
+
 // Gammatone envelope: demodulate by the rotation recurrence (eb_CosSinCF), filter real and imaginary parts with
 // lfilter([1,a1,a5],[1,-a1,-a2,-a3,-a4]) (DF2T), envelope = gain*|u|.  One wave per (utterance, signal): lane = part*32 +
 // channel, part 0 filters x*cos, part 1 filters x*sin; the two halves meet through one cross-lane swap per sample.
@@ -542,11 +583,13 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
     double gz = 0.0, V1 = 0.0, V2 = 0.0;
     const double gb0 = 0.095107983402496, ga1 = -0.809784033195007;
     const IhcC ik = hp_ihc_consts();
+    float knee = 30.0f, attn = 0.f;
     if (GAIN) {
-        const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
-        slope = (float)(1.0 - (1.0 / CR));
+        const HpLoss ls = hp_loss(ws, sig, ch);
+        slope = (float)(1.0 - (1.0 / ls.CR));
+        knee = (float)ls.lowknee; attn = (float)ls.attnOHC;
         c_off = (float)(HP_LEVEL + 20.0 * log10(hp_gt(hp_bw1(ch), cf).gain));
-        s_off = (float)(HP_LEVEL + 20.0 * log10(c.gain));
+        s_off = (float)(HP_LEVEL - ls.attnIHC + 20.0 * log10(c.gain));
         for (int n = max(0, n0 - GL_W); n < n0; n += GL_U) {    // low-pass warm-up on the control envelope alone (0.81^256 = 4e-24)
             float gc[GL_U];
 #pragma unroll
@@ -554,8 +597,8 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
 #pragma unroll
             for (int u = 0; u < GL_U; ++u) {
                 float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
-                le = fminf(fmaxf(le, 30.0f), 100.0f);
-                const double gx = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);
+                le = fminf(fmaxf(le, knee), 100.0f);
+                const double gx = (double)hp_exp2f((-attn - (le - knee) * slope) * LOG2_10_OVER_20);
                 const double y = gb0 * gx + gz;
                 gz = gb0 * gx - ga1 * y;
             }
@@ -596,8 +639,8 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
 #pragma unroll
             for (int u = 0; u < GS_RC; ++u) {
                 float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
-                le = fminf(fmaxf(le, 30.0f), 100.0f);
-                const double gx = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);
+                le = fminf(fmaxf(le, knee), 100.0f);
+                const double gx = (double)hp_exp2f((-attn - (le - knee) * slope) * LOG2_10_OVER_20);
                 const double yl = gb0 * gx + gz;
                 gz = gb0 * gx - ga1 * yl;
                 const float g = (float)yl;
@@ -641,10 +684,11 @@ __global__ void haspi_bw_kernel(HaspiWs ws, int sig0, int nsig) {
     for (int c = 0; c < nch; ++c) ss += ws.ssp[((size_t)row * ws.nchunk + c) * HP_NCH + ch];
     ss *= cc.gain * cc.gain;
     const double cdB = 20.0 * log10(sqrt(ss / (double)n24)) + HP_LEVEL;
+    const double bwmin = hp_loss(ws, row & 1, ch).BWmin;                     // eb_BWadjust (pyhaspi2.py:971-980)
     double BW;
-    if (cdB < 50.0) BW = 1.0;
+    if (cdB < 50.0) BW = bwmin;
     else if (cdB > 100.0) BW = bw1;
-    else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
+    else BW = bwmin + ((cdB - 50.0) / 50.0) * (bw1 - bwmin);
     ws.bw[(size_t)row * HP_NCH + ch] = BW;
 }
 
@@ -658,12 +702,13 @@ __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws, int sig0)
     const int n24 = hp_n24(ws, b);
     const double ss = (cc.gain * cc.gain) * hp_gammatone_wave(xin, n24, cc, cf, part, out);   // sum of (gain |u|)^2
     if (part == 0) {
-        // eb_BWadjust (pyhaspi2.py:971-980), BWmin = 1 for normal hearing
+        // eb_BWadjust (pyhaspi2.py:971-980)
         const double cdB = 20.0 * log10(sqrt(ss / (double)n24)) + HP_LEVEL;
+        const double bwmin = hp_loss(ws, sig, ch).BWmin;
         double BW;
-        if (cdB < 50.0) BW = 1.0;
+        if (cdB < 50.0) BW = bwmin;
         else if (cdB > 100.0) BW = bw1;
-        else BW = 1.0 + ((cdB - 50.0) / 50.0) * (bw1 - 1.0);
+        else BW = bwmin + ((cdB - 50.0) / 50.0) * (bw1 - bwmin);
         ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch] = BW;
     }
 }
@@ -683,13 +728,14 @@ __global__ void haspi_gain_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig
     // the grid stride is a multiple of 32, so a thread stays on one channel: its control-filter gain is computed once
     const int ch = (int)(threadIdx.x & 31);
     const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
-    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+    const HpLoss ls = hp_loss(ws, hp_row(blockIdx.y, sig0, nsig) & 1, ch);
+    const double CR = ls.CR;
     const size_t base = (size_t)hp_row(blockIdx.y, sig0, nsig) * per_row;
     for (size_t i = base + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < base + per_row; i += (size_t)gridDim.x * blockDim.x) {
         double le = fmax(cgain * sqrt((double)ws.ctl[i]), 1.0e-30);  // control envelope = gain |u| (ctl holds |u|^2)
         le = HP_LEVEL + 20.0 * log10(le);
-        le = fmin(fmax(le, 30.0), 100.0);
-        const double g = -0.0 - (le - 30.0) * (1.0 - (1.0 / CR));
+        le = fmin(fmax(le, ls.lowknee), 100.0);
+        const double g = -ls.attnOHC - (le - ls.lowknee) * (1.0 - (1.0 / CR));
         ws.ctl[i] = (hp_env_t)exp(g * (2.302585092994046 / 20.0));   // 10^(g/20)
     }
 }
@@ -721,11 +767,12 @@ __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws, int sig0, 
 __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) {
     const int ch = (int)(threadIdx.x & 31), row = hp_row(blockIdx.y, sig0, nsig);
     const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
+    const double attnIHC = hp_loss(ws, row & 1, ch).attnIHC;
     const size_t base = (size_t)row * per_row;
     for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < per_row; r += (size_t)gridDim.x * blockDim.x) {
         const size_t i = base + r;
         const double c = (double)ws.ctl[i] * (sgain * sqrt((double)ws.env[i]));      // signal envelope = gain |u| (env holds |u|^2)
-        const double y = HP_LEVEL + 20.0 * log10(c + 1.0e-30);
+        const double y = HP_LEVEL - attnIHC + 20.0 * log10(c + 1.0e-30);
         ws.env[i] = (hp_env_t)(y < 0.0 ? 0.0 : y);
     }
 }
@@ -745,11 +792,11 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
     const int n1 = min(n0 + ws.lcg, n24r);
     const double cgain = hp_gt(hp_bw1(ch), hp_cfreq(ch)).gain;
     const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
-    const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
-    const float slope = (float)(1.0 - (1.0 / CR));
+    const HpLoss ls = hp_loss(ws, row & 1, ch);
+    const float slope = (float)(1.0 - (1.0 / ls.CR)), knee = (float)ls.lowknee, attn = (float)ls.attnOHC;
     // 20 log10(gain sqrt(c)) = 20 log10(gain) + 10 log10(c) = 20 log10(gain) + (10 log10 2) log2(c)
     const float TEN_LOG10_2 = 3.0102999566398120f, LOG2_10_OVER_20 = 0.16609640474436813f;
-    const float c_off = (float)(HP_LEVEL + 20.0 * log10(cgain)), s_off = (float)(HP_LEVEL + 20.0 * log10(sgain));
+    const float c_off = (float)(HP_LEVEL + 20.0 * log10(cgain)), s_off = (float)(HP_LEVEL - ls.attnIHC + 20.0 * log10(sgain));
     const double b0 = 0.095107983402496, a1 = -0.809784033195007;
     const hp_env_t* ctl = ws.ctl + (size_t)row * ws.n24p * HP_NCH + ch;
     hp_env_t* env = ws.env + (size_t)row * ws.n24p * HP_NCH + ch;
@@ -769,8 +816,8 @@ __global__ __launch_bounds__(256) void haspi_gain_lp_sl_kernel(HaspiWs ws, int s
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:982-991 (the 1e-30 floor lies far below the 30 dB clamp)
             float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
-            le = fminf(fmaxf(le, 30.0f), 100.0f);
-            gx[u] = (double)hp_exp2f(-(le - 30.0f) * slope * LOG2_10_OVER_20);    // 10^(g/20)
+            le = fminf(fmaxf(le, knee), 100.0f);
+            gx[u] = (double)hp_exp2f((-attn - (le - knee) * slope) * LOG2_10_OVER_20);    // 10^(g/20)
         }
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) {                       // pyhaspi2.py:992-995
@@ -1437,6 +1484,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(ctl, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(env, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
+    TAKE(loss, double, 2 * 5 * HP_NCH);
     int lc = GS_LC;
     while ((n24p + lc - 1) / lc > GS_MAXC) lc += GS_LC;
     const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + (lc < GL_N ? lc : GL_N) - 1) / (lc < GL_N ? lc : GL_N);
@@ -1546,10 +1594,42 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
 // phase 0: everything.  Split by data dependence (the whole reference-signal chain - ear model, envelope filter, silence gate, group
 // delays, cepstra, modulation filters - needs the clean signal only): phase 3 = clean part (y may be NULL), phase 4 = degraded part on
 // the same workspace (x may be NULL).  Phase 0 runs exactly these two parts back to back, so the split is bit-identical by construction.
+// hl6 (HOST pointer, 6 doubles or NULL = normal hearing): audiogram of the listener at 250, 500, 1000, 2000, 4000, 6000 Hz in dB HL;
+// itype 0: the reference signal is heard with normal hearing, the processed one with the loss (haspi_v2 / haspi, pyhaspi2.py:76-157);
+// itype 2: both with the loss (hasqi_v2, pyhaspi2.py:32-74).  itype 1 (NAL-R equalisation) raises NotImplementedError in the reference
+// itself (eb_NALR, pyhaspi2.py:830-831) and is refused here.
+static int haspi_hl_table(const double* hl6, int itype, HpHL* out) {
+    if (itype != 0 && itype != 2)
+        return nele_set_error(NELE_ERR_UNSUPPORTED, "HASPI ear model: itype %d (NAL-R) is not implemented by the reference either (eb_NALR raises)", itype);
+    for (int k = 0; k < 6; ++k) {
+        const double v = hl6 ? hl6[k] : 0.0;
+        out->y[k] = v;
+        out->x[k] = itype == 0 ? 0.0 : v;
+    }
+    return NELE_OK;
+}
+
+static int haspi_var_impl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither, const double* hl6, int itype,
+                          void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info_out, int phase, void* stream);
+
 extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
                                      void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info_out, int phase,
                                      void* stream) {
+    return haspi_var_impl(x, y, lengths, B, L, fs_in, dither, nullptr, 0, workspace, workspace_bytes, raw, mapped, info_out, phase, stream);
+}
+
+// haspi_v2(x, fx, y, fy, HL) for a hearing-impaired listener (pyhaspi2.py:76-107, 779-807, 1155-1166)
+extern "C" int nele_metric_haspi_var_hl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
+                                        const double* hl6_host, int itype, void* workspace, long long workspace_bytes, float* raw, float* mapped,
+                                        int* info_out, int phase, void* stream) {
+    return haspi_var_impl(x, y, lengths, B, L, fs_in, dither, hl6_host, itype, workspace, workspace_bytes, raw, mapped, info_out, phase, stream);
+}
+
+static int haspi_var_impl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither, const double* hl6, int itype,
+                          void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info_out, int phase, void* stream) {
     NELE_CHECK_ARG(workspace && B > 0 && (phase == 0 || phase == 3 || phase == 4), "nele_metric_haspi: bad arguments");
+    HpHL hl;
+    { const int st_ = haspi_hl_table(hl6, itype, &hl); if (st_) return st_; }
     NELE_CHECK_ARG((x || phase == 4) && (y || phase == 3) && (raw || mapped || phase == 3), "nele_metric_haspi: missing signal / output for phase %d", phase);
     NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi: fs must be 16000 or 24000 (got %d)", fs_in);
     if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi: L=%d too short", L);
@@ -1559,6 +1639,7 @@ extern "C" int nele_metric_haspi_var(const float* x, const float* y, const int* 
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
     ws.lens = lengths;
     hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(haspi_loss_kernel, dim3(1), dim3(64), 0, s, ws, hl);
     // Cepstrum stage: one block per utterance (default) or the frame-parallel kernels (NELE_HASPI_CEP_SERIAL=0).  Alone on the GPU the
     // parallel version takes 0.15 ms against 0.75 ms per call; inside the B = 256 step (A/B in one run, three repetitions each,
     // tools/ab.sh) the step is 76.0 ms with the serial kernel and 78.2 ms with the parallel one: the GPU is saturated by the step's own

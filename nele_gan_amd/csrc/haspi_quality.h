@@ -444,13 +444,13 @@ __global__ __launch_bounds__(256) void hq_final_kernel(HaspiWs ws, QualWs q, dou
         const double cf = hp_cfreq(ch);
         const double sg_ = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], cf).gain, cg_ = hp_gt(hp_bw1(ch), cf).gain;
         const double ave = sg_ * sqrt(se / (double)n24), cave = cg_ * sqrt(sc / (double)n24);
-        const double CR = 1.25 + 2.25 * (double)ch / (double)(HP_NCH - 1);
+        const HpLoss lo = hp_loss(ws, sig, ch);                          // eb_aveSL (pyhaspi2.py:1135-1152)
         double le = HP_LEVEL + 20.0 * log10(fmax(cave, small));
-        le = fmin(fmax(le, 30.0), 100.0);
-        const double gain = -(le - 30.0) * (1.0 - (1.0 / CR));
+        le = fmin(fmax(le, lo.lowknee), 100.0);
+        const double gain = -lo.attnOHC - (le - lo.lowknee) * (1.0 - (1.0 / lo.CR));
         double ls = HP_LEVEL + 20.0 * log10(fmax(ave, small));
         ls = fmax(ls, 0.0);
-        SL[sig][ch] = fmax(ls + gain, 0.0);
+        SL[sig][ch] = fmax(ls + gain - lo.attnIHC, 0.0);
     }
     __syncthreads();
     if (tid < 64) {
@@ -522,10 +522,29 @@ extern "C" long long nele_metric_haspi_quality_workspace_bytes(int B, int L, int
 // x, y [B][L] float32 (reference, processed); lengths [B] or NULL; noise != 0: eb_BMaddnoise with the counter-based generator seeded
 // by `seed`; alpha: the logistic slope of `haspi` (pyhaspi2.py:109, default -1).  out [B][12] float64 (see hq_final_kernel),
 // info_out [B][4] int or NULL.
+static int haspi_quality_impl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise, unsigned long long seed, double alpha,
+                              const double* hl6, int itype, void* workspace, long long workspace_bytes, double* out, int* info_out, void* stream);
+
 extern "C" int nele_metric_haspi_quality(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise,
                                          unsigned long long seed, double alpha, void* workspace, long long workspace_bytes, double* out,
                                          int* info_out, void* stream) {
+    return haspi_quality_impl(x, y, lengths, B, L, fs_in, noise, seed, alpha, nullptr, 0, workspace, workspace_bytes, out, info_out, stream);
+}
+
+// The same for a hearing-impaired listener: hl6 (HOST pointer, 6 doubles) = audiogram at 250 .. 6000 Hz; itype 0 = `haspi` (reference
+// signal heard with normal hearing: columns 0-4 of `out` are that call's results), itype 2 = `hasqi_v2` (both signals with the loss:
+// columns 5-11).  With a loss the two models differ in the reference's ear model (pyhaspi2.py:1162-1166), so one call serves one of them.
+extern "C" int nele_metric_haspi_quality_hl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise,
+                                            unsigned long long seed, double alpha, const double* hl6_host, int itype, void* workspace,
+                                            long long workspace_bytes, double* out, int* info_out, void* stream) {
+    return haspi_quality_impl(x, y, lengths, B, L, fs_in, noise, seed, alpha, hl6_host, itype, workspace, workspace_bytes, out, info_out, stream);
+}
+
+static int haspi_quality_impl(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, int noise, unsigned long long seed, double alpha,
+                              const double* hl6, int itype, void* workspace, long long workspace_bytes, double* out, int* info_out, void* stream) {
     NELE_CHECK_ARG(x && y && out && workspace && B > 0, "nele_metric_haspi_quality: bad arguments");
+    HpHL hl;
+    { const int st_ = haspi_hl_table(hl6, itype, &hl); if (st_) return st_; }
     NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi_quality: fs must be 16000 or 24000 (got %d)", fs_in);
     if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi_quality: L=%d too short", L);
     if (workspace_bytes < nele_metric_haspi_quality_workspace_bytes(B, L, fs_in))
@@ -536,6 +555,7 @@ extern "C" int nele_metric_haspi_quality(const float* x, const float* y, const i
     ws.lens = lengths;
     q.seed = seed; q.noise = noise;
     hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(haspi_loss_kernel, dim3(1), dim3(64), 0, s, ws, hl);
     if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
     haspi_chain(x, y, B, L, fs_in, ws, 0, 2, s, true);       // ear model of both signals up to the IHC prefix states
     const int rows = 2 * B;

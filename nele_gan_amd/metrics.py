@@ -40,6 +40,8 @@ declare('nele_metric_haspi', [_P, _P, c_int, c_int, c_int, _P, _P, c_longlong, _
 _lib._SIGS['nele_metric_haspi'] = _lib.lib.nele_metric_haspi.argtypes
 declare('nele_metric_haspi_var', [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_longlong, _P, _P, _P, c_int, _P])
 _lib._SIGS['nele_metric_haspi_var'] = _lib.lib.nele_metric_haspi_var.argtypes
+declare('nele_metric_haspi_var_hl', [_P, _P, _P, c_int, c_int, c_int, _P, ctypes.POINTER(ctypes.c_double), c_int, _P, c_longlong, _P, _P, _P, c_int, _P])
+_lib._SIGS['nele_metric_haspi_var_hl'] = _lib.lib.nele_metric_haspi_var_hl.argtypes
 _lib.lib.nele_metric_haspi_workspace_bytes.argtypes = [c_int, c_int, c_int]
 _lib.lib.nele_metric_haspi_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_haspi_workspace_bytes'] = _lib.lib.nele_metric_haspi_workspace_bytes.argtypes
@@ -48,6 +50,9 @@ _lib.lib.nele_metric_haspi_quality_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_metric_haspi_quality_workspace_bytes'] = _lib.lib.nele_metric_haspi_quality_workspace_bytes.argtypes
 declare('nele_metric_haspi_quality', [_P, _P, _P, c_int, c_int, c_int, c_int, ctypes.c_ulonglong, ctypes.c_double, _P, c_longlong, _P, _P, _P])
 _lib._SIGS['nele_metric_haspi_quality'] = _lib.lib.nele_metric_haspi_quality.argtypes
+declare('nele_metric_haspi_quality_hl', [_P, _P, _P, c_int, c_int, c_int, c_int, ctypes.c_ulonglong, ctypes.c_double, ctypes.POINTER(ctypes.c_double), c_int, _P,
+                                         c_longlong, _P, _P, _P])
+_lib._SIGS['nele_metric_haspi_quality_hl'] = _lib.lib.nele_metric_haspi_quality_hl.argtypes
 _lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_haspi_nsub.restype = c_int
 _lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
@@ -203,8 +208,21 @@ def SIIB_Wrapper_harvard(x, y, fs):
     return float(_siib_checked(x, y)[1][0])
 
 
-def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False, lengths=None):
+def _hl6(HL):
+    """Audiogram argument of the reference's pyHASPI functions (HL = np.zeros(6) by default) -> ctypes double[6] or None (normal hearing)."""
+    if HL is None:
+        return None
+    v = [float(t) for t in np.asarray(HL, dtype=np.float64).reshape(-1)]
+    if len(v) != 6:
+        raise ValueError('HL must hold the six audiogram values at 250, 500, 1000, 2000, 4000, 6000 Hz (pyhaspi2.py:780)')
+    if not any(v):
+        return None
+    return (ctypes.c_double * 6)(*v)
+
+
+def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False, lengths=None, HL=None):
     """clean x [B,L], degraded y [B,L] -> (raw HASPI v2 [B], mapped [B]).
+    HL: audiogram of the listener (six values in dB HL, pyhaspi2.py:76, 779-807); None / zeros = normal hearing (what the loop uses).
     dither: None -> no IHC firing jitter (deterministic score); True -> standard normals drawn on the device
     (torch generator, optional ``seed``) as the reference does with np.random.randn (pyhaspi2.py:362-365); or a
     float64 tensor [B,2,nsub,32] whose row k perturbs the k-th active frame (used by the parity tests)."""
@@ -228,8 +246,13 @@ def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False, lengt
     info = torch.zeros((B, 2), dtype=torch.int32, device=x.device)
     if lengths is not None:
         lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32).contiguous()
-    call('nele_metric_haspi_var', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), ptr(dither), ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), 0,
-         stream())
+    hl = _hl6(HL)
+    if hl is None:
+        call('nele_metric_haspi_var', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), ptr(dither), ptr(ws), ws.numel(), ptr(raw), ptr(mapped), ptr(info), 0,
+             stream())
+    else:
+        call('nele_metric_haspi_var_hl', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), ptr(dither), hl, 0, ptr(ws), ws.numel(), ptr(raw), ptr(mapped),
+             ptr(info), 0, stream())
     if return_info:
         return raw, mapped, info
     return raw, mapped
@@ -268,10 +291,12 @@ class HaspiSplit:
 QUALITY_FIELDS = ('haspi', 'CepCorr', 'cov3_low', 'cov3_mid', 'cov3_high', 'hasqi', 'Nonlin', 'Linear', 'BMsync5', 'Dloud', 'Dslope', 'avecov')
 
 
-def batch_haspi_quality(x, y, fs=16000, lengths=None, noise=True, seed=None, alpha=-1.0, return_info=False):
+def batch_haspi_quality(x, y, fs=16000, lengths=None, noise=True, seed=None, alpha=-1.0, return_info=False, HL=None, itype=0):
     """reference x [B,L], processed y [B,L] -> float64 [B, 12] (columns QUALITY_FIELDS): HASPI version 1 (pyhaspi2.py:109-157) and
     HASQI v2 (pyhaspi2.py:32-74) from one launch chain.  noise: the reference's eb_BMaddnoise (device generator, ``seed`` or a fresh
-    one per call); False = none (deterministic, the parity tests)."""
+    one per call); False = none (deterministic, the parity tests).  HL: audiogram (six values in dB HL); with a loss the two models
+    differ in how the reference signal is heard (pyhaspi2.py:1162-1166): itype 0 -> the `haspi` columns are valid, itype 2 -> the
+    `hasqi_v2` columns."""
     x, y, _ = _pair(x, y)
     B, L = x.shape
     ws = _workspace('haspi_quality', _lib.lib.nele_metric_haspi_quality_workspace_bytes(B, L, int(fs)), x.device)
@@ -281,16 +306,21 @@ def batch_haspi_quality(x, y, fs=16000, lengths=None, noise=True, seed=None, alp
         lengths = torch.as_tensor(lengths).to(device=x.device, dtype=torch.int32).contiguous()
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise else 0
-    call('nele_metric_haspi_quality', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), int(bool(noise)), int(seed), float(alpha), ptr(ws), ws.numel(),
-         ptr(out), ptr(info), stream())
+    hl = _hl6(HL)
+    if hl is None:
+        call('nele_metric_haspi_quality', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), int(bool(noise)), int(seed), float(alpha), ptr(ws), ws.numel(),
+             ptr(out), ptr(info), stream())
+    else:
+        call('nele_metric_haspi_quality_hl', ptr(x), ptr(y), ptr(lengths), B, L, int(fs), int(bool(noise)), int(seed), float(alpha), hl, int(itype),
+             ptr(ws), ws.numel(), ptr(out), ptr(info), stream())
     return (out, info) if return_info else out
 
 
-def _quality_checked(x, fx, y, fy, alpha=-1.0):
+def _quality_checked(x, fx, y, fy, alpha=-1.0, HL=None, itype=0):
     if fx != fy:
         raise ValueError('haspi / hasqi_v2: both signals must have the same sampling rate here (the reference resamples each to 24 kHz)')
     L = min(len(x), len(y))
-    out, info = batch_haspi_quality(x[:L], y[:L], fx, alpha=alpha, return_info=True)
+    out, info = batch_haspi_quality(x[:L], y[:L], fx, alpha=alpha, return_info=True, HL=HL, itype=itype)
     st = int(info[0, 1])
     if st & 1:
         raise Exception('Function eb_melcor: Signal below threshold, outputs set to 0.')        # pyhaspi2.py:723-724
@@ -298,26 +328,32 @@ def _quality_checked(x, fx, y, fy, alpha=-1.0):
 
 
 def haspi(x, fx, y, fy, HL=None, alpha=-1.0):
-    """pyhaspi2.py:109-157 (HASPI version 1), normal hearing: -> (Intel, raw = [CepCorr, cov3 low, mid, high])."""
-    _no_loss(HL)
-    o, st = _quality_checked(x, fx, y, fy, alpha)
+    """pyhaspi2.py:109-157 (HASPI version 1): -> (Intel, raw = [CepCorr, cov3 low, mid, high]).  HL: audiogram of the listener."""
+    o, st = _quality_checked(x, fx, y, fy, alpha, HL=HL, itype=0)
     if st & 2:
         raise Exception('Function eb_3LevelCovary: Signal below threshold, outputs set to 0.')    # pyhaspi2.py:427-428
     return float(o[0]), o[1:5].copy()
 
 
 def hasqi_v2(x, fx, y, fy, HL=None):
-    """pyhaspi2.py:32-74, normal hearing: -> (Combined, Nonlin, Linear, raw = [CepCorr, BMsync5, Dloud, Dslope])."""
-    _no_loss(HL)
-    o, st = _quality_checked(x, fx, y, fy)
+    """pyhaspi2.py:32-74: -> (Combined, Nonlin, Linear, raw = [CepCorr, BMsync5, Dloud, Dslope]).  HL: audiogram (both signals are heard
+    with it: eq = 2, pyhaspi2.py:41-43)."""
+    o, st = _quality_checked(x, fx, y, fy, HL=HL, itype=2)
     if st & 2:
         raise TypeError("'int' object is not subscriptable")                                       # eb_AveCovary2's (0, 0) return at pyhaspi2.py:54
     return float(o[5]), float(o[6]), float(o[7]), [float(o[1]), float(o[8]), float(o[9]), float(o[10])]
 
 
-def _no_loss(HL):
-    if HL is not None and any(float(v) != 0.0 for v in HL):
-        raise NotImplementedError('hearing loss HL != 0 is not built: every call site of the reference passes the default (intel.py:108-120)')
+def haspi_v2(x, fx, y, fy, HL=None):
+    """pyhaspi2.py:76-107: -> Intel (the modulation-band correlations `raw` stay on the device).  The reference dithers every call
+    (pyhaspi2.py:362-365): so does this wrapper; batch_haspi(dither=None) is the deterministic form."""
+    if fx != fy:
+        raise ValueError('haspi_v2: both signals must have the same sampling rate here (the reference resamples each to 24 kHz)')
+    L = min(len(x), len(y))
+    raw, mapped, info = batch_haspi(x[:L], y[:L], fx, dither=True, return_info=True, HL=HL)
+    if int(info[0, 1]):
+        raise Exception('Function ebm_CepCoef: Signal below threshold')     # pyhaspi2.py:357-358
+    return float(raw[0])
 
 
 def _haspi_checked(x, y, fs):

@@ -1,5 +1,5 @@
 """Oracle: HASPI v2 as computed by reference ``pyHASPI/pyhaspi2.py:haspi_v2`` (the call tree of
-intel.py:108-114), normal-hearing case HL = 0.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+intel.py:108-114), normal hearing (HL = 0, what the loop uses) and hearing-loss audiograms (HL, itype 0 / 2).  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 PINNED at fs = 24 kHz against tests/golden/haspi.npz (made by importing the reference's pyhaspi2 with
 numba.jit as the identity): centre frequencies, control / signal bandwidths, group-delay shifts,
@@ -220,14 +220,24 @@ def ave_sl(env, control, attnOHC, thrLow, CR, attnIHC, Level1=LEVEL1):
     return np.clip(logenv + gain - attnIHC, a_min=0.0, a_max=None)
 
 
-def ear_model_bm(x, fx, y, fy, noise_x=None, noise_y=None):
-    """pyhaspi2.py:1155-1248 for HL = 0 (itype 0 and 2 coincide then) with the basilar-membrane outputs:
+def _loss_pair(HL, itype):
+    """pyhaspi2.py:1160-1166: the processed signal is heard with the audiogram HL, the reference with HLx = 0 * HL for the
+    intelligibility model (itype 0) and with HL otherwise (hasqi_v2 passes 2).  itype 1 would need eb_NALR, which raises in the
+    reference.  -> (per-signal tuple of attnOHC, BWmin, lowknee, CR, attnIHC)."""
+    if itype == 1:
+        raise NotImplementedError('eb_NALR (pyhaspi2.py:830-831)')
+    HL = np.zeros(6) if HL is None else np.asarray(HL, dtype=np.float64)
+    cfreq = center_freq()
+    return loss_parameters(0 * HL if itype == 0 else HL, cfreq), loss_parameters(HL, cfreq)
+
+
+def ear_model_bm(x, fx, y, fy, noise_x=None, noise_y=None, HL=None, itype=0):
+    """pyhaspi2.py:1155-1248 (for HL = 0 itype 0 and 2 coincide) with the basilar-membrane outputs:
     -> (xdB, xBM, ydB, yBM [32, nsamp], xSL, ySL [32], parts).  noise_* [32, nsamp]: the standard-normal draws of eb_BMaddnoise
     (pyhaspi2.py:1091-1095; the reference draws channel by channel, x before y), None = no noise."""
     small = 1.0e-30
-    HL = np.zeros(6)
     cfreq = center_freq()
-    attnOHC, BWmin, lowknee, CR, attnIHC = loss_parameters(HL, cfreq)
+    lossp = _loss_pair(HL, itype)
     _, BW1, _, _, _ = loss_parameters(100 * np.ones(6), cfreq)
     x24 = resample_24k(x, fx)
     y24 = resample_24k(y, fy)
@@ -244,6 +254,7 @@ def ear_model_bm(x, fx, y, fy, noise_x=None, noise_y=None):
         coscf, sincf = cos_sin_cf(nsamp, FSAMP, cfreq[n])
         control = [gammatone_env(m, BW1[n], coscf, sincf, cfreq[n]) for m in mid]
         for s in range(2):
+            attnOHC, BWmin, lowknee, CR, attnIHC = lossp[s]
             BW[s, n] = bw_adjust(control[s], BWmin[n], BW1[n])
             env, bm = gammatone_bm(mid[s], BW[s, n], coscf, sincf, cfreq[n])
             ave[s, n] = np.sqrt(np.mean(env ** 2))
@@ -263,16 +274,18 @@ def ear_model_bm(x, fx, y, fy, noise_x=None, noise_y=None):
             sft = int(shifts[n])
             if sft > 0:
                 arr[n] = np.concatenate((np.zeros(sft), arr[n, :nsamp - sft]))
-    xSL = ave_sl(ave[0], cave[0], attnOHC, lowknee, CR, attnIHC)
-    ySL = ave_sl(ave[1], cave[1], attnOHC, lowknee, CR, attnIHC)
+    SL = []
+    for s in range(2):
+        attnOHC, BWmin, lowknee, CR, attnIHC = lossp[s]
+        SL.append(ave_sl(ave[s], cave[s], attnOHC, lowknee, CR, attnIHC))
+    xSL, ySL = SL
     return dB[0], BM[0], dB[1], BM[1], xSL, ySL, dict(cfreq=cfreq, BW1=BW1, BWx=BW[0], BWy=BW[1], shifts=shifts)
 
 
-def ear_model(x, fx, y, fy):
-    """pyhaspi2.py:1155-1248 for HL = 0, itype = 0: -> (xdB, ydB [32, nsamp], parts)."""
-    HL = np.zeros(6)
+def ear_model(x, fx, y, fy, HL=None, itype=0):
+    """pyhaspi2.py:1155-1248 (envelope outputs only): -> (xdB, ydB [32, nsamp], parts)."""
     cfreq = center_freq()
-    attnOHC, BWmin, lowknee, CR, attnIHC = loss_parameters(HL, cfreq)
+    (aOx, BWminx, lkx, CRx, aIx), (aOy, BWminy, lky, CRy, aIy) = _loss_pair(HL, itype)
     _, BW1, _, _, _ = loss_parameters(100 * np.ones(6), cfreq)
     x24 = resample_24k(x, fx)
     y24 = resample_24k(y, fy)
@@ -287,14 +300,14 @@ def ear_model(x, fx, y, fy):
         coscf, sincf = cos_sin_cf(nsamp, FSAMP, cfreq[n])
         xcontrol = gammatone_env(xmid, BW1[n], coscf, sincf, cfreq[n])
         ycontrol = gammatone_env(ymid, BW1[n], coscf, sincf, cfreq[n])
-        BWx[n] = bw_adjust(xcontrol, BWmin[n], BW1[n])
-        BWy[n] = bw_adjust(ycontrol, BWmin[n], BW1[n])
+        BWx[n] = bw_adjust(xcontrol, BWminx[n], BW1[n])
+        BWy[n] = bw_adjust(ycontrol, BWminy[n], BW1[n])
         xenv = gammatone_env(xmid, BWx[n], coscf, sincf, cfreq[n])
         yenv = gammatone_env(ymid, BWy[n], coscf, sincf, cfreq[n])
-        xc = env_compress(xenv, xcontrol, attnOHC[n], lowknee[n], CR[n])
-        yc = env_compress(yenv, ycontrol, attnOHC[n], lowknee[n], CR[n])
-        xc = env_sl2(xc, attnIHC[n])
-        yc = env_sl2(yc, attnIHC[n])
+        xc = env_compress(xenv, xcontrol, aOx[n], lkx[n], CRx[n])
+        yc = env_compress(yenv, ycontrol, aOy[n], lky[n], CRy[n])
+        xc = env_sl2(xc, aIx[n])
+        yc = env_sl2(yc, aIy[n])
         xdB[n] = ihc_adapt(xc)
         ydB[n] = ihc_adapt(yc)
     shifts = group_delay_shifts(BWx, cfreq)
@@ -417,7 +430,7 @@ def mod_corr(Xmod, Ymod):
 WEIGHTS = np.array([1.361, 1.521, 1.164, 0.492, 0.436, 0.690, 1.142, 0.816, 1.576, 2.269])
 
 
-def haspi_v2(x, fx, y, fy, dither_x=None, dither_y=None, return_parts=False):
+def haspi_v2(x, fx, y, fy, dither_x=None, dither_y=None, return_parts=False, HL=None):
     """pyhaspi2.py:76-107.  dither_* = None -> no dither (deterministic); else standard-normal arrays
     [n_active, 32] as np.random.randn would have produced inside ebm_CepCoef."""
     L = min(len(x), len(y))
@@ -427,7 +440,7 @@ def haspi_v2(x, fx, y, fy, dither_x=None, dither_y=None, return_parts=False):
     rms_y = np.sqrt(np.sum(y ** 2) / L)
     x = x / rms_x
     y = y / rms_y
-    xdB, ydB, parts = ear_model(x, fx, y, fy)
+    xdB, ydB, parts = ear_model(x, fx, y, fy, HL=HL, itype=0)
     xLP, yLP = env_filt(xdB, ydB)
     xcep, ycep, index = cep_coef(xLP, yLP, dither_x=dither_x, dither_y=dither_y)
     xmod, ymod = mod_filt(xcep, ycep)
@@ -638,10 +651,10 @@ def _normalised_pair(x, y):
     return x / np.sqrt(np.sum(x ** 2) / L), y / np.sqrt(np.sum(y ** 2) / L)
 
 
-def haspi_v1(x, fx, y, fy, alpha=-1.0, noise_x=None, noise_y=None, return_parts=False):
+def haspi_v1(x, fx, y, fy, alpha=-1.0, noise_x=None, noise_y=None, return_parts=False, HL=None):
     """pyhaspi2.py:109-157 (`haspi`): logistic of cepstral correlation + high-level BM covariance.  -> (Intel, [CepCorr, cov3])."""
     x, y = _normalised_pair(x, y)
-    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y)
+    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y, HL=HL, itype=0)
     xdB, ydB = env_smooth(xenv), env_smooth(yenv)
     CepCorr, xy = melcor(xdB, ydB)
     sigcov, sigMSx, sigMSy = bm_covary(xBM, yBM)
@@ -655,10 +668,10 @@ def haspi_v1(x, fx, y, fy, alpha=-1.0, noise_x=None, noise_y=None, return_parts=
     return float(intel), raw
 
 
-def hasqi_v2(x, fx, y, fy, noise_x=None, noise_y=None, return_parts=False):
+def hasqi_v2(x, fx, y, fy, noise_x=None, noise_y=None, return_parts=False, HL=None):
     """pyhaspi2.py:32-74: -> (Combined, Nonlin, Linear, [CepCorr, BMsync5, Dloud, Dslope])."""
     x, y = _normalised_pair(x, y)
-    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y)
+    xenv, xBM, yenv, yBM, xSL, ySL, parts = ear_model_bm(x, fx, y, fy, noise_x, noise_y, HL=HL, itype=2)      # eq = 2 (pyhaspi2.py:41-43)
     xdB, ydB = env_smooth(xenv), env_smooth(yenv)
     CepCorr, xy = melcor(xdB, ydB)
     dloud, dnorm, dslope = spect_diff(xSL, ySL)

@@ -282,9 +282,10 @@ def main():
     sys.path.insert(0, a.ref)
     sys.path.insert(0, os.path.join(a.ref, 'pyHASPI'))
     try:
-        from make_golden_haspi import gen_haspi, gen_haspi_quality
+        from make_golden_haspi import gen_haspi, gen_haspi_hl, gen_haspi_quality
         GENS['haspi'] = gen_haspi
         GENS['haspi_quality'] = gen_haspi_quality
+        GENS['haspi_hl'] = gen_haspi_hl
     except ImportError:
         pass
     for name, fn in GENS.items():

@@ -157,3 +157,74 @@ def gen_haspi_quality(ref):
     print('  raw v1', raw1, 'oracle', r1)
     print('  raw q ', raw2, 'oracle', q[3])
     assert e1 < 1e-9 and e2 < 1e-9, (e1, e2)
+
+
+# Audiograms (dB HL at 250, 500, 1000, 2000, 4000, 6000 Hz) of the hearing-loss goldens: a mild, nearly flat loss and a sloping
+# moderate-to-severe one whose high-frequency channels pass the outer-hair-cell threshold (attnOHC saturates, attnIHC takes the rest).
+HL_MILD = (20.0, 20.0, 25.0, 30.0, 40.0, 45.0)
+HL_SLOPING = (10.0, 15.0, 30.0, 50.0, 70.0, 80.0)
+
+
+def gen_haspi_hl(ref):
+    """The reference's own haspi_v2 / haspi / hasqi_v2 for listeners with a hearing loss (pyhaspi2.py:779-807, 1155-1166): final values,
+    the loss parameters and the adjusted bandwidths, on the seeded pair of gen_haspi.  Noise / dither draws are regenerated from the seed
+    by the tests (golden_dither / golden_bm_noise), exactly as for the normal-hearing goldens."""
+    import pyhaspi2 as P
+    from nele_gan_amd import synth
+    n = 30000
+    x = synth.clean_utterance(77, n).astype(np.float32)
+    v = synth.noise_utterance(77, n, x)
+    y = (x + np.float32(0.3) * v).astype(np.float32)
+    out = dict(x=x, y=y, seed=np.int64(4321))
+    real_randn = np.random.randn
+    orig_bw = P.eb_BWadjust
+    for tag, HL in (('mild', HL_MILD), ('sloping', HL_SLOPING)):
+        HLa = np.asarray(HL, dtype=np.float64)
+        cf = P.eb_CenterFreq(32)
+        lp = P.eb_LossParameters(HLa, cf)
+        out['%s_HL' % tag] = HLa
+        out['%s_loss' % tag] = np.stack([np.asarray(a, dtype=np.float64) for a in lp])          # attnOHC, BW, lowknee, CR, attnIHC
+        bw, draws = [], []
+
+        def BWadjust(*a, **k):
+            r = orig_bw(*a, **k)
+            bw.append(r)
+            return r
+
+        def randn(*shape):
+            a = real_randn(*shape)
+            if len(shape) == 2:
+                draws.append(a.copy())
+            return a
+        P.eb_BWadjust = BWadjust
+        np.random.randn = randn
+        try:
+            np.random.seed(4321)
+            intel, raw = P.haspi_v2(x, 24000, y, 24000, HLa)
+            out['%s_v2_intel' % tag], out['%s_v2_aveCM' % tag] = np.float64(intel), np.asarray(raw)
+            out['%s_v2_BWx' % tag], out['%s_v2_BWy' % tag] = np.array(bw[0::2]), np.array(bw[1::2])
+            out['%s_v2_n_active' % tag] = np.int64(draws[0].shape[0])
+            np.random.seed(4321)
+            i1, r1 = P.haspi(x, 24000, y, 24000, HLa)
+            out['%s_v1' % tag] = np.concatenate(([i1], np.asarray(r1)))                         # Intel, CepCorr, cov3 low / mid / high
+            np.random.seed(4321)
+            comb, nonlin, lin, rq = P.hasqi_v2(x, 24000, y, 24000, HLa)
+            out['%s_hasqi' % tag] = np.asarray([comb, nonlin, lin] + list(rq), dtype=np.float64)   # Combined, Nonlin, Linear, CepCorr, BMsync5, Dloud, Dslope
+        finally:
+            np.random.randn = real_randn
+            P.eb_BWadjust = orig_bw
+        print('haspi_hl %s: haspi_v2 %.6f, haspi %.6f, hasqi_v2 %.6f' % (tag, intel, i1, comb))
+    np.savez_compressed(os.path.join(HERE, 'haspi_hl.npz'), **out)
+    # ---- check the oracle against it right away
+    from oracle import haspi as H
+    for tag, HL in (('mild', HL_MILD), ('sloping', HL_SLOPING)):
+        dx, dy = golden_dither(4321, n, int(out['%s_v2_n_active' % tag]))
+        val, _ = H.haspi_v2(x, 24000, y, 24000, dither_x=dx, dither_y=dy, HL=HL)
+        nx, ny = golden_bm_noise(4321, n)
+        v1, r1 = H.haspi_v1(x, 24000, y, 24000, noise_x=nx, noise_y=ny, HL=HL)
+        q = H.hasqi_v2(x, 24000, y, 24000, noise_x=nx, noise_y=ny, HL=HL)
+        e0 = abs(val - out['%s_v2_intel' % tag]) / abs(out['%s_v2_intel' % tag])
+        e1 = abs(v1 - out['%s_v1' % tag][0])
+        e2 = abs(q[0] - out['%s_hasqi' % tag][0])
+        print('  oracle %s: haspi_v2 rel err %.2e, haspi abs err %.2e, hasqi abs err %.2e' % (tag, e0, e1, e2))
+        assert e0 < 1e-9 and e1 < 1e-9 and e2 < 1e-9, (e0, e1, e2)

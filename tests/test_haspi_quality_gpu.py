@@ -89,5 +89,49 @@ def test_reference_shaped_entry_points():
     assert comb == pytest.approx(float(Q['hasqi'][0]), abs=1e-3)
     same = mt.hasqi_v2(x, 24000, x, 24000)
     assert same[0] == pytest.approx(1.0, abs=2e-3)                       # a signal against itself: perfect quality
-    with pytest.raises(NotImplementedError):
-        mt.haspi(x, 24000, y, 24000, HL=[10, 10, 20, 30, 40, 50])
+
+
+def test_hearing_loss_audiograms_match_the_reference_and_the_oracle():
+    """pyhaspi2.py:779-807 (eb_LossParameters) + the HLx / HL split of eb_EarModel (:1155-1166): haspi_v2 with the reference's own
+    dither draws against the reference (1e-4), haspi / hasqi_v2 against the noise-free oracle (tight) and the reference's noisy run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from make_golden_haspi import HL_MILD, HL_SLOPING, golden_dither
+    from nele_gan_amd import metrics as mt
+    from oracle import haspi as H
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'haspi_hl.npz'))
+    x, y, n = G['x'], G['y'], len(G['x'])
+    normal = float(mt.batch_haspi(x, y, 24000)[0][0])
+    for tag, HL in (('mild', HL_MILD), ('sloping', HL_SLOPING)):
+        # haspi_v2: the dither rows are inputs (row k perturbs the k-th active frame)
+        na = int(G[tag + '_v2_n_active'])
+        dx, dy = golden_dither(int(G['seed']), n, na)
+        nsub = (n + 8) // 9
+        d = np.zeros((1, 2, nsub, 32))
+        d[0, 0, :na], d[0, 1, :na] = dx, dy
+        raw, mapped, info = mt.batch_haspi(x, y, 24000, dither=torch.from_numpy(d).cuda(), return_info=True, HL=HL)
+        assert int(info[0, 0]) == na and int(info[0, 1]) == 0
+        assert float(raw[0]) == pytest.approx(float(G[tag + '_v2_intel']), rel=1e-4)
+        assert abs(float(raw[0]) - normal) > 0.05                        # the loss really changes the score
+        # haspi (itype 0) and hasqi_v2 (itype 2)
+        o0 = mt.batch_haspi_quality(x, y, 24000, noise=False, HL=HL, itype=0).cpu().numpy()[0]
+        o2 = mt.batch_haspi_quality(x, y, 24000, noise=False, HL=HL, itype=2).cpu().numpy()[0]
+        v1, r1 = H.haspi_v1(x, 24000, y, 24000, HL=HL)
+        q = H.hasqi_v2(x, 24000, y, 24000, HL=HL)
+        np.testing.assert_allclose(o0[0:5], np.concatenate(([v1], r1)), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(o2[5:11], [q[0], q[1], q[2], q[3][1], q[3][2], q[3][3]], rtol=2e-5, atol=2e-6)
+        # Against the reference's own (noisy) run the device generator's eb_BMaddnoise has to be ON: with a severe loss the attenuated BM
+        # motion of the high bands sits near the -10 dB SL threshold noise, which then is part of the model, not a perturbation (sloping
+        # audiogram: haspi 0.670 without noise, 0.7035 +- 0.0005 with it over noise seeds; oracle, tools-free check in the test history)
+        n0 = mt.batch_haspi_quality(x, y, 24000, noise=True, seed=5, HL=HL, itype=0).cpu().numpy()[0]
+        n2 = mt.batch_haspi_quality(x, y, 24000, noise=True, seed=5, HL=HL, itype=2).cpu().numpy()[0]
+        assert abs(n0[0] - float(G[tag + '_v1'][0])) < 3e-3 and abs(n2[5] - float(G[tag + '_hasqi'][0])) < 1e-3
+        assert abs(o0[5] - o2[5]) > 1e-3                                 # with a loss the two ear models differ: one call serves one model
+    # reference-shaped wrappers take the audiogram; NAL-R (itype 1) is refused as in the reference (eb_NALR raises)
+    intel, raw4 = mt.haspi(x, 24000, y, 24000, HL=HL_SLOPING)
+    assert intel == pytest.approx(float(G['sloping_v1'][0]), abs=3e-3)
+    comb = mt.hasqi_v2(x, 24000, y, 24000, HL=np.asarray(HL_MILD))[0]
+    assert comb == pytest.approx(float(G['mild_hasqi'][0]), abs=1e-3)
+    assert mt.haspi_v2(x, 24000, y, 24000, HL=HL_MILD) == pytest.approx(float(G['mild_v2_intel']), rel=2e-3)     # fresh dither draws
+    with pytest.raises(Exception):
+        mt.batch_haspi_quality(x, y, 24000, HL=HL_MILD, itype=1)

@@ -110,3 +110,30 @@ def test_bm_noise_changes_the_quality_scores_by_less_than_a_thousandth():
     assert v0 == pytest.approx(float(Q['intel']), abs=1e-3)
     assert q0[0] == pytest.approx(float(Q['hasqi'][0]), abs=1e-3)
     np.testing.assert_allclose(r0, Q['raw_v1'], atol=2e-3)
+
+
+def test_hearing_loss_oracle_matches_the_reference(golden_dir):
+    """eb_LossParameters and the HLx / HL split of eb_EarModel (pyhaspi2.py:779-807, 1155-1166): haspi_v2, haspi and hasqi_v2 of the
+    reference itself for a mild and a sloping audiogram (tests/golden/haspi_hl.npz, make_golden_haspi.gen_haspi_hl)."""
+    import os
+    from make_golden_haspi import HL_MILD, HL_SLOPING, golden_bm_noise, golden_dither
+    G = np.load(os.path.join(golden_dir, 'haspi_hl.npz'))
+    x, y, n = G['x'], G['y'], len(G['x'])
+    for tag, HL in (('mild', HL_MILD), ('sloping', HL_SLOPING)):
+        np.testing.assert_array_equal(G[tag + '_HL'], HL)
+        lp = H.loss_parameters(np.asarray(HL, dtype=np.float64), H.center_freq())
+        np.testing.assert_allclose(np.stack(lp), G[tag + '_loss'], rtol=1e-14)
+        dx, dy = golden_dither(int(G['seed']), n, int(G[tag + '_v2_n_active']))
+        val, parts = H.haspi_v2(x, 24000, y, 24000, dither_x=dx, dither_y=dy, return_parts=True, HL=HL)
+        assert val == pytest.approx(float(G[tag + '_v2_intel']), rel=1e-10)
+        np.testing.assert_allclose(parts['aveCM'], G[tag + '_v2_aveCM'], rtol=1e-9)
+        np.testing.assert_allclose(parts['BWx'], G[tag + '_v2_BWx'], rtol=1e-12)      # the reference signal: normal hearing (BWmin = 1)
+        np.testing.assert_allclose(parts['BWy'], G[tag + '_v2_BWy'], rtol=1e-12)      # the processed signal: BWmin of the loss
+        assert np.all(parts['BWy'] >= parts['BWx'] - 1e-12) and np.any(parts['BWy'] > parts['BWx'] + 1e-3)
+        nx, ny = golden_bm_noise(int(G['seed']), n)
+        v1, r1 = H.haspi_v1(x, 24000, y, 24000, noise_x=nx, noise_y=ny, HL=HL)
+        np.testing.assert_allclose(np.concatenate(([v1], r1)), G[tag + '_v1'], rtol=1e-10)
+        q = H.hasqi_v2(x, 24000, y, 24000, noise_x=nx, noise_y=ny, HL=HL)
+        np.testing.assert_allclose([q[0], q[1], q[2]] + list(q[3]), G[tag + '_hasqi'], rtol=1e-10)
+    with pytest.raises(NotImplementedError):
+        H.ear_model(x, 24000, y, 24000, HL=HL_MILD, itype=1)             # NAL-R: eb_NALR raises in the reference too

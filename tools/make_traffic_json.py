@@ -14,7 +14,8 @@ ROUND = sys.argv[6] if len(sys.argv) > 6 else 'r03'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 work = {'batch': int(sys.argv[2]), 'length': int(sys.argv[3]), 'metrics': sys.argv[4], 'precision': sys.argv[5]}
-WANT = ('conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_tile16_kernel<3, 4>', 'conv_tile16_kernel<2, 4>', 'conv_tile16_kernel<1, 4>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7, true>', 'conv_wgrad_tile16_kernel<4, 7, false>', 'conv_wgrad_tile16_kernel<3, 4, false>',
+WANT = ('conv16_kernel<4, 4, false>', 'conv16_kernel<4, 4, true>', 'conv16_kernel<3, 4, true>', 'conv16_kernel<2, 4, true>', 'conv16_kernel<2, 8, true>', 'conv16_kernel<1, 8, true>', 'conv16_kernel<1, 8, false>', 'conv16_kernel<1, 4, true>',
+        'conv_wgrad_tile16_kernel<4, 7, true, true>', 'conv_wgrad_tile16_kernel<3, 4, true, true>', 'conv_wgrad_tile16_kernel<2, 2, true, true>', 'conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_tile16_kernel<3, 4>', 'conv_tile16_kernel<2, 4>', 'conv_tile16_kernel<1, 4>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7, true>', 'conv_wgrad_tile16_kernel<4, 7, false>', 'conv_wgrad_tile16_kernel<3, 4, false>',
         'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_bank_scan_kernel<true, true, false, true>', 'haspi_bank_scan_kernel<false, true, false, false>',
         'eigh_backtransform_wy_kernel', 'eigh_tridiag_mid_kernel', 'siib_stack_kernel',
         'haspi_mod_slide_kernel<1>', 'stft_band_kernel', 'gain_istft_kernel', 'siib_proj_kernel<2>', 'siib_cov_kernel',
