@@ -43,6 +43,11 @@ struct SiibWs {
     double* lam;     // [B][420]
     double* part;    // [B][420][NTL][3]
     double* px;      // [B][7][NTL][16][256] projections of the clean signal in accumulator order (split mode: phase 3 -> phase 4)
+    double* lagp;    // [B][3][nseg][29][784] lag-product partials: pair 0 = (x, x), 1 = (y, y), 2 = (x, y)                     (lag path)
+    double* mu;      // [B][2][15][28] window means of the stacked rows                                                         (lag path)
+    double* S2;      // [B][2][420][420] unscaled second-moment matrices of the stacked frames: Syy, sym(Sxy)                   (lag path)
+    double* qpart;   // [B][420][14] partial quadratic forms u_k^T S u_k per column tile: 7 tiles of Syy, 7 of sym(Sxy)          (lag path)
+    int nseg;        // frame segments the lag products are split into (more workgroups at small batches)
     int NT, NA, NTL;
     int Bn;          // utterances in this call
     const int* lens; // [B] samples per utterance inside the padded [B][L] buffers, or NULL (every row has L samples)
@@ -702,6 +707,263 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     }
 }
 
+
+// ---------------------------------------------------------------- second moments of the stacked frames from LAG PRODUCTS (round 3)
+// The 420-dimensional stacked frame is 15 consecutive 28-band frames (oracle/siib.py stack), so every entry of Xs Xs^T, Ys Ys^T and
+// Xs Ys^T is a lag product of two band rows,
+//     S_ab[(k1, j1), (k2, j2)] = sum_{t < ncols} a_j1[t + k1] b_j2[t + k2] - ncols mu^a_{k1 j1} mu^b_{k2 j2}
+//                              = L_ab(j1, j2, k2 - k1) - (at most 14 head and 14 tail products) - ncols mu mu',
+//     L_ab(j1, j2, D) = sum_s a_j1[s] b_j2[s + D]            (all s for which both indices are frames),
+// with a, b the masked, row-mean-removed log band energies: 28 x 28 x 29 lag products of length n instead of 420 x 420 inner products -
+// 8 x fewer multiply-adds for the covariance.  And the per-component sums the score needs (oracle/siib.py: vx, vy, cxy of the
+// KLT-projected frames) are quadratic forms of the same matrices, sum_t (u_k^T xs_t)(u_k^T ys_t) = u_k^T (Xs Ys^T) u_k: two 420^3
+// products (siib_quad_kernel) replace the two 420 x 420 x n projections, 4.5 x fewer flops, and the 3 GB of stacked frames are never
+// written.  vx_k = (ncols - 1) lambda_k comes from the eigenvalue.  Same mathematics, different summation order: scores agree with
+// the projection path to 1e-9 relative (tests/test_metrics_gpu.py), both are kept (NELE_SIIB_LAG=0: projections).
+#define SL_ND 29                   // lags -14 .. 14
+#define SL_CH 58                   // frames per LDS chunk (a multiple of SL_ND: the rotating register window keeps its phase)
+// window means of the stacked rows: mu[k][j] = mean_t v_j[t + k], t < ncols.  grid (B, signals), block 256
+__global__ __launch_bounds__(256) void siib_mu_kernel(SiibWs ws, int sig0) {
+    __shared__ double red[8];
+    __shared__ double tot[SB_J];
+    const int b = blockIdx.x, sig = sig0 + blockIdx.y, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2], ncols = na - SB_K + 1;
+    double* mu = ws.mu + ((size_t)b * 2 + sig) * SB_D;
+    if (ncols < 2) { for (int a = tid; a < SB_D; a += 256) mu[a] = 0.0; return; }
+    const double* XL = ws.XL + ((size_t)b * 2 + sig) * SB_J * ws.NA;
+    const double* rs = ws.rowstat + ((size_t)b * 2 + sig) * SB_J * 2;
+    for (int j = 0; j < SB_J; ++j) {
+        const double mr = rs[2 * j + 1];
+        double sm = 0.0;
+        for (int t = tid; t < na; t += 256) sm += XL[(size_t)j * ws.NA + t] - mr;
+        const double T = block_sum(sm, red);
+        if (tid == 0) tot[j] = T;
+    }
+    __syncthreads();
+    for (int a = tid; a < SB_D; a += 256) {
+        const int k = a / SB_J, j = a - k * SB_J;
+        const double mr = rs[2 * j + 1];
+        const double* row = XL + (size_t)j * ws.NA;
+        double edge = 0.0;
+        for (int q = 0; q < k; ++q) edge += row[q] - mr;                          // frames before the window
+        for (int q = k + ncols; q < na; ++q) edge += row[q] - mr;                 // frames behind it
+        mu[a] = (tot[j] - edge) / (double)ncols;
+    }
+}
+
+// L_ab partials.  grid (4, nseg, B), block 256: thread p = 256 blockIdx.x + tid < 784 owns the band pair (j1, j2) = (p / 28, p % 28)
+// and ND consecutive lags D0 .. D0 + ND - 1: b_j2[s + D0 .. s + D0 + ND - 1] lives in a ROTATING register window (slot = frame index
+// mod ND; the step loop is unrolled ND times so that every slot index is a compile-time constant), so a frame costs ND multiply-adds,
+// one new window element and one a value from LDS ([frame][band] tiles: a wave's read is one 224-byte run).  Frames outside [0, na)
+// are staged as zeros: the full-lag sums need no bounds in the loop.  The symmetric matrices (Sxx, Syy) only need the lags 0 .. 14
+// (the other half is the mirror image); the cross term needs all 29.
+template <int SIGA, int SIGB, int D0, int ND>
+__global__ __launch_bounds__(256) void siib_lag_kernel(SiibWs ws, int pair) {
+    constexpr int CH = (SL_CH / ND) * ND;                    // frames per LDS chunk: whole window periods
+    __shared__ double sa[CH][SB_J], sb[CH + ND - 1][SB_J];
+    const int b = blockIdx.z, seg = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+    const int na = ws.info[4 * b + 2];
+    const int j1 = min(p, SB_J * SB_J - 1) / SB_J, j2 = min(p, SB_J * SB_J - 1) % SB_J;
+    const int per = ((na + ws.nseg - 1) / ws.nseg + CH - 1) / CH * CH;                   // frames per segment: whole chunks
+    const int s0 = seg * per, s1 = min(na, s0 + per);
+    const double* A = ws.XL + ((size_t)b * 2 + SIGA) * SB_J * ws.NA;
+    const double* Bm = ws.XL + ((size_t)b * 2 + SIGB) * SB_J * ws.NA;
+    const double* ra = ws.rowstat + ((size_t)b * 2 + SIGA) * SB_J * 2;
+    const double* rb = ws.rowstat + ((size_t)b * 2 + SIGB) * SB_J * 2;
+    double acc[ND], w[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { acc[d] = 0.0; w[d] = 0.0; }
+    for (int c0 = s0; c0 < s1; c0 += CH) {
+        __syncthreads();
+        // stage a[c0 .. c0 + CH) and b[c0 + D0 .. c0 + CH + D0 + ND - 1): thread -> (frame, band), coalesced along frames per band row
+        for (int e = tid; e < CH * SB_J; e += 256) {
+            const int j = e / CH, r = e - j * CH, sidx = c0 + r;
+            sa[r][j] = (sidx < na) ? A[(size_t)j * ws.NA + sidx] - ra[2 * j + 1] : 0.0;
+        }
+        for (int e = tid; e < (CH + ND - 1) * SB_J; e += 256) {
+            const int j = e / (CH + ND - 1), r = e - j * (CH + ND - 1), sidx = c0 + D0 + r;
+            sb[r][j] = (sidx >= 0 && sidx < na) ? Bm[(size_t)j * ws.NA + sidx] - rb[2 * j + 1] : 0.0;
+        }
+        __syncthreads();
+        if (c0 == s0) {                                     // window = b[s0 + D0 .. s0 + D0 + ND - 2] in slots 0 .. ND - 2
+#pragma unroll
+            for (int q = 0; q < ND - 1; ++q) w[q] = sb[q][j2];
+        }
+#pragma unroll 1
+        for (int r0 = 0; r0 < CH; r0 += ND) {
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const double a = sa[r0 + u][j1];
+                w[(u + ND - 1) % ND] = sb[r0 + u + ND - 1][j2];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) acc[d] = fma(a, w[(u + d) % ND], acc[d]);
+            }
+        }
+    }
+    if (p < SB_J * SB_J) {                                   // slot D + 14 of the 29 lag slots
+        double* out = ws.lagp + ((((size_t)b * 3 + pair) * ws.nseg + seg) * SL_ND + (D0 + 14)) * (SB_J * SB_J) + p;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) out[(size_t)d * (SB_J * SB_J)] = acc[d];
+    }
+}
+
+// Matrices from the lag products.  MODE 0: C = Sxx / (ncols - 1) (the covariance the eigensolver takes);  MODE 1: S2[0] = Syy,
+// S2[1] = (Sxy + Sxy^T) / 2, unscaled.  grid (15, B), block 256: block D = lag k2 - k1 >= 0; a thread owns the band pair (j1, j2) and
+// walks down the diagonal k1 = 0 .. 14 - D with the running sum  P(k1 + 1) = P(k1) - a[k1] b[k2] + a[k1 + ncols] b[k2 + ncols],
+// P(0) = L(D) - (the 14 - D products behind the window); the first and last 29 frames of every band row it touches sit in LDS.
+// Each value is written to (a1, a2) and (a2, a1): the matrices are exactly symmetric.
+template <int MODE>
+__global__ __launch_bounds__(256) void siib_assemble_kernel(SiibWs ws) {
+    __shared__ double eh[2][SB_J][SL_ND], et[2][SB_J][SL_ND], mus[2][SB_D];
+    const int b = blockIdx.y, D = blockIdx.x, tid = threadIdx.x;
+    const int na = ws.info[4 * b + 2], ncols = na - SB_K + 1;
+    double* C = ws.C + (size_t)b * SB_D * SB_D;
+    double* S = MODE ? ws.S2 + (size_t)b * 2 * SB_D * SB_D : nullptr;
+    if (ncols < 2) {                                         // not enough active frames (status bit set by the front end): zeros
+        for (int e = D * 256 + tid; e < SB_D * SB_D; e += 15 * 256) {
+            if (MODE == 0) C[e] = 0.0; else { S[e] = 0.0; S[(size_t)SB_D * SB_D + e] = 0.0; }
+        }
+        return;
+    }
+    for (int e = tid; e < 2 * SB_J * SL_ND; e += 256) {
+        const int sig = e / (SB_J * SL_ND), r = e - sig * (SB_J * SL_ND), j = r / SL_ND, q = r - j * SL_ND;
+        const double* row = ws.XL + (((size_t)b * 2 + sig) * SB_J + j) * ws.NA;
+        const double mr = ws.rowstat[(((size_t)b * 2 + sig) * SB_J + j) * 2 + 1];
+        eh[sig][j][q] = (q < na) ? row[q] - mr : 0.0;                             // frames 0 .. 28
+        et[sig][j][q] = (na - SL_ND + q >= 0) ? row[na - SL_ND + q] - mr : 0.0;   // frames na - 29 .. na - 1
+    }
+    for (int e = tid; e < 2 * SB_D; e += 256) mus[e / SB_D][e % SB_D] = ws.mu[(size_t)b * 2 * SB_D + e];
+    __syncthreads();
+    const double nc = (double)ncols, scale = 1.0 / (double)(ncols - 1);
+    auto lag = [&](int pair, int ja, int jb, int dd) {       // L_pair(ja, jb, dd), partials added in segment order
+        const double* lp = ws.lagp + (((size_t)b * 3 + pair) * ws.nseg * SL_ND + (dd + 14)) * (SB_J * SB_J) + ja * SB_J + jb;
+        double v = 0.0;
+        for (int sg = 0; sg < ws.nseg; ++sg) v += lp[(size_t)sg * SL_ND * (SB_J * SB_J)];
+        return v;
+    };
+    for (int p = tid; p < SB_J * SB_J; p += 256) {
+        const int j1 = p / SB_J, j2 = p - j1 * SB_J;
+        if (D == 0 && j2 > j1) continue;
+        // walk(sa, ja, sb, jb): sum_t a_ja[t + k1] b_jb[t + k1 + D] for k1 = 0 .. 14 - D
+        const int sA = MODE ? 1 : 0;
+        double P = lag(MODE ? 1 : 0, j1, j2, D);             // (x, x) or (y, y)
+        for (int i = 0; i < 14 - D; ++i) P -= et[sA][j1][15 + i] * et[sA][j2][15 + i + D];
+        double P1 = 0.0, Q = 0.0;
+        if (MODE) {
+            P1 = lag(2, j1, j2, D);                          // sum_t x_j1[t + k1] y_j2[t + k2]
+            Q = lag(2, j2, j1, -D);                          // sum_t x_j2[t + k2] y_j1[t + k1]
+            for (int i = 0; i < 14 - D; ++i) {
+                P1 -= et[0][j1][15 + i] * et[1][j2][15 + i + D];
+                Q -= et[0][j2][15 + D + i] * et[1][j1][15 + i];
+            }
+        }
+        for (int k1 = 0; k1 + D < SB_K; ++k1) {
+            const int k2 = k1 + D, a1 = k1 * SB_J + j1, a2 = k2 * SB_J + j2;
+            const size_t o12 = (size_t)a1 * SB_D + a2, o21 = (size_t)a2 * SB_D + a1;
+            if (MODE == 0) {
+                const double v = (P - nc * mus[0][a1] * mus[0][a2]) * scale;
+                C[o12] = v; C[o21] = v;
+            } else {
+                const double vy = P - nc * mus[1][a1] * mus[1][a2];
+                const double vxy = 0.5 * ((P1 - nc * mus[0][a1] * mus[1][a2]) + (Q - nc * mus[0][a2] * mus[1][a1]));
+                S[o12] = vy; S[o21] = vy;
+                S[(size_t)SB_D * SB_D + o12] = vxy; S[(size_t)SB_D * SB_D + o21] = vxy;
+            }
+            if (k2 + 1 >= SB_K) break;
+            // the window moves one frame: frames k1 / k2 leave, frames k1 + ncols = na - 14 + k1 / k2 + ncols enter
+            P += et[sA][j1][15 + k1] * et[sA][j2][15 + k2] - eh[sA][j1][k1] * eh[sA][j2][k2];
+            if (MODE) {
+                P1 += et[0][j1][15 + k1] * et[1][j2][15 + k2] - eh[0][j1][k1] * eh[1][j2][k2];
+                Q += et[0][j2][15 + k2] * et[1][j1][15 + k1] - eh[0][j2][k2] * eh[1][j1][k1];
+            }
+        }
+    }
+}
+
+// Quadratic forms q_k = u_k^T S u_k for S = Syy and sym(Sxy): P = U S on the f64 matrix cores exactly as siib_proj_kernel computes
+// U X (U rows = eigenvectors), then the row-wise sums of P[k][j] U[k][j] over the tile's 64 columns.  1-D XCD-aware grid:
+// 14 column tiles (7 of Syy, 7 of sym(Sxy)) x 7 row tiles per utterance.
+__global__ __launch_bounds__(256) void siib_quad_kernel(SiibWs ws) {
+    __shared__ __attribute__((aligned(32))) double Us[2][16][SG_LD], Mt[2][16][SG_LD];
+    const int xw = (int)blockIdx.x, slot = xw >> 3, per_b = 7 * 14;
+    const int b = (slot / per_b) * 8 + (xw & 7), tl = slot % per_b, by = tl % 7, bx = tl / 7;
+    if (b >= ws.Bn) return;
+    const int which = bx / 7, ti = by * 64, t0 = (bx % 7) * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const double* U = ws.U + (size_t)b * SB_D * SB_D;
+    const double* M = ws.S2 + ((size_t)b * 2 + which) * SB_D * SB_D;
+    const int ur = tid >> 2, uq = (tid & 3) * 4;                 // U tile: 64 rows x 16 k
+    const double* pu = U + (size_t)min(ti + ur, SB_D - 1) * SB_D + uq;
+    const int xc = tid >> 4, xq = (tid & 15) * 4;                // M tile: 16 k x 64 columns
+    const bool cin = t0 + xq < SB_D;                             // 420 = 4 * 105: column quads are all-in or all-out
+    const double* pm = M + (size_t)xc * SB_D + (cin ? t0 + xq : 0);
+    f64x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const double4 z4 = make_double4(0.0, 0.0, 0.0, 0.0);
+    auto gload = [&](int k0, double4& ru, double4& rm) {
+        ru = (k0 + uq < SB_D) ? *reinterpret_cast<const double4*>(pu + k0) : z4;
+        rm = (cin && k0 + xc < SB_D) ? *reinterpret_cast<const double4*>(pm + (size_t)k0 * SB_D) : z4;
+    };
+    double4 ru, rm;
+    gload(0, ru, rm);
+    for (int k0 = 0, it = 0; k0 < SB_D; k0 += 16, ++it) {
+        const int buf = it & 1;
+        Us[buf][uq][ur] = ru.x; Us[buf][uq + 1][ur] = ru.y; Us[buf][uq + 2][ur] = ru.z; Us[buf][uq + 3][ur] = ru.w;
+        *reinterpret_cast<double4*>(&Mt[buf][xc][xq]) = rm;
+        __syncthreads();
+        if (k0 + 16 < SB_D) gload(k0 + 16, ru, rm);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = 4 * kk + lk;
+            const double a = Us[buf][k][16 * w + li];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Mt[buf][k][16 * j + li], acc[j], 0, 0, 0);
+        }
+    }
+    // acc[j][q] = P[row ti + 16 w + lk + 4 q][column t0 + 16 j + li]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gi = ti + 16 * w + lk + 4 * q;
+        double sm = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = t0 + 16 * j + li;
+            sm += (gi < SB_D && c < SB_D) ? acc[j][q] * U[(size_t)gi * SB_D + c] : 0.0;
+        }
+        sm = row16_sum_dpp(sm);
+        if (li == 0 && gi < SB_D) ws.qpart[((size_t)b * SB_D + gi) * 14 + bx] = sm;
+    }
+}
+
+// score from the eigenvalues and the quadratic forms (lag path); same decisions as siib_final_kernel
+__global__ __launch_bounds__(512) void siib_final_lag_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int* info = ws.info + 4 * b;
+    const double* lam = ws.lam + (size_t)b * SB_D;
+    const int ncols = info[2] - SB_K + 1;
+    double lmax = -1e300;
+    if (j < SB_D) lmax = lam[j];
+    lmax = block_max(lmax, red);
+    double I = 0.0;
+    if (j < SB_D && lam[j] > 1e-10 * lmax) {
+        const double* q = ws.qpart + ((size_t)b * SB_D + j) * 14;
+        double vy = 0.0, cxy = 0.0;
+        for (int t = 0; t < 7; ++t) { vy += q[t]; cxy += q[7 + t]; }
+        const double vx = lam[j] * (double)(ncols - 1);
+        const double rho = cxy / sqrt(vx * vy);
+        I = -0.5 * log2(1.0 - 0.5625 * rho * rho);
+    }
+    const double tot = block_sum(I, red);
+    if (j == 0) {
+        double v = fmax(0.0, 80.0 / 15.0 * tot);
+        if (info[3] & (8 | 16)) v = nan("");
+        if (raw) raw[b] = (float)v;
+        if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.06 * (v - 32.0))));
+    }
+}
+
 // s9: one block (512 threads >= 420) per utterance
 __global__ __launch_bounds__(512) void siib_final_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped) {
     __shared__ double red[8];
@@ -744,6 +1006,12 @@ static void siib_dims(int L, int* NT, int* NA, int* NTL) {
     *NTL = na / 64;
 }
 
+// NELE_SIIB_LAG=0: covariance and projections from the stacked frames (the round-2 kernels; A/B switch)
+static bool siib_lag_path() {
+    static const bool on = [] { const char* e = getenv("NELE_SIIB_LAG"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     int NT, NA, NTL;
     siib_dims(L, &NT, &NA, &NTL);
@@ -758,15 +1026,26 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(info, int, (size_t)B * 4);
     TAKE(nprim, int, (size_t)B);
     TAKE(XL, double, (size_t)B * 2 * SB_J * NA);
-    TAKE(Xs, double, (size_t)B * 2 * SB_D * NA);
     TAKE(C, double, (size_t)B * SB_D * SB_D);
     TAKE(lam, double, (size_t)B * SB_D);
     TAKE(U, double, (size_t)B * SB_D * SB_D);
     TAKE(eigws, char, (size_t)nele_eigh_workspace_bytes(B, SB_D));
     TAKE(part, double, (size_t)B * SB_D * NTL * 3);
-    TAKE(px, double, (size_t)B * 7 * NTL * 16 * 256);
+    const int nseg = B >= 128 ? 1 : (B >= 48 ? 2 : 4);
+    if (siib_lag_path()) {
+        // the lag path needs neither the stacked frames nor the kept clean projections: Xs / px shrink to nothing
+        TAKE(lagp, double, (size_t)B * 3 * nseg * SL_ND * SB_J * SB_J);
+        TAKE(mu, double, (size_t)B * 2 * SB_D);
+        TAKE(S2, double, (size_t)B * 2 * SB_D * SB_D);
+        TAKE(qpart, double, (size_t)B * SB_D * 14);
+        if (w) { w->Xs = nullptr; w->px = nullptr; }
+    } else {
+        TAKE(Xs, double, (size_t)B * 2 * SB_D * NA);
+        TAKE(px, double, (size_t)B * 7 * NTL * 16 * 256);
+        if (w) { w->lagp = nullptr; w->mu = nullptr; w->S2 = nullptr; w->qpart = nullptr; }
+    }
 #undef TAKE
-    if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; w->Bn = B; }
+    if (w) { w->NT = NT; w->NA = NA; w->NTL = NTL; w->Bn = B; w->nseg = nseg; }
     return o;
 }
 
@@ -824,20 +1103,39 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(siib_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             sk_attr = true;
         }
-        NELE_CHECK_ARG((size_t)ws.NA * sizeof(double) <= 152 * 1024, "nele_metric_siib: signal too long (%d active frames)", ws.NA);
-        hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_J, B, nsig), dim3(256), sizeof(double) * (size_t)ws.NA, s, ws, sig0);
-        if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+        if (siib_lag_path()) {
+            hipLaunchKernelGGL(siib_mu_kernel, dim3(B, nsig), dim3(256), 0, s, ws, sig0);
+            const dim3 lg(4, ws.nseg, B);
+            if (sx) {
+                hipLaunchKernelGGL((siib_lag_kernel<0, 0, 0, 15>), lg, dim3(256), 0, s, ws, 0);
+                hipLaunchKernelGGL(siib_assemble_kernel<0>, dim3(15, B), dim3(256), 0, s, ws);
+            }
+            if (sy) {
+                hipLaunchKernelGGL((siib_lag_kernel<1, 1, 0, 15>), lg, dim3(256), 0, s, ws, 1);
+                hipLaunchKernelGGL((siib_lag_kernel<0, 1, -14, 29>), lg, dim3(256), 0, s, ws, 2);
+                hipLaunchKernelGGL(siib_assemble_kernel<1>, dim3(15, B), dim3(256), 0, s, ws);
+            }
+        } else {
+            NELE_CHECK_ARG((size_t)ws.NA * sizeof(double) <= 152 * 1024, "nele_metric_siib: signal too long (%d active frames)", ws.NA);
+            hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_J, B, nsig), dim3(256), sizeof(double) * (size_t)ws.NA, s, ws, sig0);
+            if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+        }
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
     if (eig) {
         int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
         if (st) return st;
-        if (phase == 3) {                                   // clean-signal half of the projections, beside whatever the caller overlaps
+        if (phase == 3 && !siib_lag_path()) {               // clean-signal half of the projections, beside whatever the caller overlaps
             hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
             NELE_CHECK_LAUNCH("nele_metric_siib(clean projections)");
         }
     }
-    if (fin) {
+    if (fin && siib_lag_path()) {
+        hipLaunchKernelGGL(siib_quad_kernel, dim3(7 * 14 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(siib_final_lag_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
+        if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
+        NELE_CHECK_LAUNCH("nele_metric_siib(back, lag path)");
+    } else if (fin) {
         if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
         else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
         hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
