@@ -192,6 +192,35 @@ def test_siib_period_shortcut_is_bit_identical_to_computing_every_frame(tmp_path
     assert res[0].tobytes() == res[1].tobytes()
 
 
+_LAG_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for L, B in ((64000, 3), (63871, 3), (33536, 2), (18000, 2)):
+    c, v = synth.batch(B, L, start=70)
+    raw, _, info = mt.batch_siib(c, 0.8 * c + v, return_info=True)
+    out += [raw.double().cpu().numpy(), info.cpu().numpy().astype(np.float64).ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_siib_lag_products_equal_the_stacked_frame_gemms(tmp_path):
+    """Round 3: covariance and the per-component sums come from lag products of the 28 band rows (the stacked frame is 15 consecutive
+    frames: every entry of Xs Xs^T / Ys Ys^T / Xs Ys^T is a lag product) and quadratic forms u^T S u instead of 420 x 420 x n GEMMs
+    over the stacked frames.  Same mathematics in another summation order: A/B against the round-2 kernels of the same library
+    (NELE_SIIB_LAG=0, read once per process), frame-periodic and aperiodic lengths, a short file with a large replication factor."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('siib_lag_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _LAG_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_SIIB_LAG=flag), timeout=240)
+        res.append(np.load(out))
+    assert np.all(np.isfinite(res[0])) and res[0].shape == res[1].shape
+    np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
+
+
 _HASPI_AB_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
