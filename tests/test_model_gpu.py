@@ -348,3 +348,33 @@ def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, 
             torch.testing.assert_close(g1[k], g0[k], rtol=8e-3, atol=8e-3 * float(g0[k].abs().max()))
         else:
             assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize('B,T', [(1, 21), (2, 37), (1, 52), (2, 53), (3, 85), (2, 149)])
+def test_bf16_activation_kernels_at_edge_frame_counts(mods, B, T):
+    """conv16 tiles are 4 (or 8) rows x 64 columns: 52 frames is the shortest utterance whose every layer runs on the bf16-in-memory kernels
+    (the weight-gradient tile kernel wants >= 32 output columns: conv5's output is 44 x (T - 20)); 53 / 85 / 149 leave partial column tiles
+    of every width class and partial row tiles in every layer.  Shorter utterances (T = 21 is the shortest D accepts) fall back, as a whole,
+    to the float32-buffer kernels.  Against the float32 mode with the tolerances of bf16 operands (scores 2e-3; weight gradients 4e-2 and the
+    input gradient - five layers of bf16 products deep - 1e-1 of the largest entry; measured 6e-2 at the BASELINE frame count on either
+    bf16 path); bit-identity with the float32-buffer bf16 path holds where that path rounds every operand too (test above)."""
+    torch.manual_seed(100 + T)
+    x = torch.rand(B, 3, 64, T, device='cuda') * 2
+    res = {}
+    for prec in ('f32', 'bf16'):
+        D = load_recipe(mods.Discriminator(), 35)
+        D.precision = prec
+        D.train()
+        xin = x.clone().requires_grad_(True)
+        score = D(xin)
+        score.pow(2).sum().backward()
+        if prec == 'bf16':
+            assert next(iter(D._bufs.values())).c16 == (T >= 52)
+        res[prec] = (score.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
+    assert float((res['bf16'][0] - res['f32'][0]).abs().max()) <= 2e-3
+    def close(a, b, tol, what):
+        assert bool(torch.isfinite(a).all()), what
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-12, what
+    close(res['bf16'][1], res['f32'][1], 1e-1, 'input gradient')
+    for k, g0 in res['f32'][2].items():
+        close(res['bf16'][2][k], g0, 4e-2, k)
