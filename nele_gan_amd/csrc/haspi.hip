@@ -673,6 +673,107 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
         ihe[0] = V1; ihe[32] = V2;
     }
 }
+
+// Pass 1 with the chunk's HEAD skipped (round 3).  The end state of a chunk run from a zero state depends on its last W samples only: the
+// bank's impulse response decays like n^3 a^n, a = exp(-BW 2 pi / 24000 ERB 1.019), so everything further back than
+//     W(a):  n^3 a^n < 1e-22 of the response's peak
+// is below the float64 rounding of the state (the same argument as for the middle-ear and gain low-pass warm-ups, 1e-20 there).  W is 60
+// samples at 8 kHz and 5000 at 80 Hz: with the lane = channel layout of haspi_bank_scan_kernel a wave takes as long as its slowest
+// channel, so this kernel turns the mapping around - a WAVE owns one channel and its 64 lanes own 64 chunks of one row: every lane runs
+// the same W steps, ending at its own chunk end (samples before a short chunk's start enter as zeros).  Average work: 0.48 of a chunk for
+// the control bank, 0.55-0.69 for the signal bank (lc = 1536).
+// Input: the 64 lanes read 64 different chunks, and every channel reads the whole signal.  One wave per channel with its own loads ran at
+// the L2 -> L1 rate (32 x the signal per launch: 0.8 ms whatever W), so a workgroup is 8 channels (neighbours: similar W) and stages 16
+// samples of each of the 64 chunks ONCE for all of them: 512 threads x 16 bytes = 8 lines of 128 bytes per load instruction, double
+// buffered in LDS, one barrier per 16 samples; a wave joins the walk when the distance to the chunk end drops to its own W.
+// Same arithmetic per sample as pass 1 of the scan kernel; end states differ from a full-chunk run by < 1e-20 relative.
+// grid 8 * 4 * ceil(nchunk / 64) * ceil(rows / 8) (1-D, see below), block 512 = 8 channels.  full != 0: W = lc for every channel (diagnostic).
+template <bool SIGNAL>
+__global__ __launch_bounds__(512) void haspi_bank_tail_kernel(HaspiWs ws, int sig0, int nsig, int full, int nrows) {
+    __shared__ double stage[2][64][GS_RC + 1];
+    __shared__ int wred[8];
+    // 1-D grid.  Workgroup ids go round-robin over the 8 XCDs; with (channel group, row) in the natural order every XCD would receive
+    // ONE channel group - and the XCDs with the low channels (full-length walks) would finish long after the others.  Here the id is
+    // decoded as (xcd = id & 7, slot = id >> 3): channel group = slot & 3, so every XCD walks through all four groups.
+    const int id = (int)blockIdx.x, slot = id >> 3, cgrp = slot & 3, rest = slot >> 2;
+    const int ncg = (ws.nchunk + 63) / 64;
+    const int ridx = (rest / ncg) * 8 + (id & 7);
+    if (ridx >= nrows) return;                               // (whole workgroup: no barrier is skipped by a part of it)
+    const int row = hp_row(ridx, sig0, nsig), b = row >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ch = 8 * cgrp + wv;
+    const int c0 = 64 * (rest % ncg), chunk = c0 + lane, lc = ws.lc;
+    const int n24 = hp_n24(ws, b), nend = (n24 + GS_RC - 1) / GS_RC * GS_RC;
+    const int n0 = chunk * lc, n1 = min(n0 + lc, nend);
+    const bool live = n0 < n1;                              // chunks behind the end of a short row: nothing reads their state
+    const double cf = hp_cfreq(ch);
+    const double BW = SIGNAL ? ws.bw[(size_t)row * HP_NCH + ch] : hp_bw1(ch);
+    const GtCoef c = hp_gt(BW, cf);
+    const double tpt = 2.0 * M_PI / HP_FS;
+    // decay length: smallest multiple of 16 with 3 ln n + n ln a < ln(1e-22) + (peak of 3 ln n + n ln a)
+    int W;
+    {
+        const double la = BW * tpt * (24.7 + cf / 9.26449) * 1.019;        // -ln a
+        const double npk = fmax(3.0 / la, 1.0);                               // the envelope n^3 a^n peaks at n = 3 / (-ln a)
+        const double peak = 3.0 * log(npk) - la * npk;
+        double nn = 60.0 / la;
+        for (int it = 0; it < 6; ++it) nn = (50.66 - peak + 3.0 * log(nn)) / la;   // 50.66 = -ln 1e-22
+        W = ((int)nn + 1 + GS_RC) / GS_RC * GS_RC;
+        W = min(W, lc);
+        if (full == 1) W = lc;
+        if (full == 2) W = GS_RC;                            // (diagnostic: prologue cost)
+    }
+    if (lane == 0) wred[wv] = W;
+    __syncthreads();
+    int Wmax = wred[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) Wmax = max(Wmax, wred[q]);
+    const double cn = cos(tpt * cf), sn = sin(tpt * cf);
+    double cold, sold;                                      // demodulator one step before this lane's first sample n1 - W
+    {
+        const double ang = tpt * cf * (double)(n1 - W - 1);
+        cold = cos(ang);
+        sold = -sin(ang);
+    }
+    const double* xin = ws.mid + (size_t)row * ws.n24p;
+    // staging: thread -> (chunk cc = tid >> 3, samples 2 (tid & 7) .. + 1) of a group; sample index = cn1 - Wmax + t + 2 part
+    const int cc = tid >> 3, part = tid & 7;
+    const int cn0 = (c0 + cc) * lc, cn1 = min(cn0 + lc, nend);
+    const double* psrc = xin + (cn1 - Wmax + 2 * part);
+    const int pfirst = (cn0 < cn1) ? cn0 - (cn1 - Wmax + 2 * part) : 0x7fffffff;       // the sample lies inside its chunk  <=>  t >= pfirst
+    double2 pv = (0 >= pfirst) ? *reinterpret_cast<const double2*>(psrc) : make_double2(0.0, 0.0);
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    const int tjoin = Wmax - W;                             // this wave's first group
+    for (int t = 0, it = 0; t < Wmax; t += GS_RC, ++it) {
+        double (*st)[GS_RC + 1] = stage[it & 1];
+        st[cc][2 * part] = pv.x; st[cc][2 * part + 1] = pv.y;
+        __syncthreads();                                    // group t is complete; the other buffer (group t - 16) is free again after it
+        if (t + GS_RC < Wmax) pv = (t + GS_RC >= pfirst) ? *reinterpret_cast<const double2*>(psrc + t + GS_RC) : make_double2(0.0, 0.0);
+        if (t >= tjoin) {
+            double xc[GS_RC];
+#pragma unroll
+            for (int u = 0; u < GS_RC; ++u) xc[u] = st[lane][u];
+#pragma unroll
+            for (int u = 0; u < GS_RC; ++u) {
+                hp_rotate(cold, sold, cn, sn);
+                const double xr = xc[u] * cold, xi = xc[u] * sold;
+                const double yr = xr + r0, yi = xi + i0;
+                r0 = c.a1 * xr + c.a1 * yr + r1;
+                r1 = c.a5 * xr + c.a2 * yr + r2;
+                r2 = c.a3 * yr + r3;
+                r3 = c.a4 * yr;
+                i0 = c.a1 * xi + c.a1 * yi + i1;
+                i1 = c.a5 * xi + c.a2 * yi + i2;
+                i2 = c.a3 * yi + i3;
+                i3 = c.a4 * yi;
+            }
+        }
+    }
+    if (live) {
+        double* est = ws.est + ((size_t)row * ws.nchunk + chunk) * 256 + ch;       // [4][branch * 32 + channel]
+        est[0] = r0; est[64] = r1; est[128] = r2; est[192] = r3;
+        est[32] = i0; est[96] = i1; est[160] = i2; est[224] = i3;
+    }
+}
 // eb_BWadjust from the chunk partials (added in chunk order).  grid rows, block 32
 __global__ void haspi_bw_kernel(HaspiWs ws, int sig0, int nsig) {
     const int row = hp_row(blockIdx.x, sig0, nsig), ch = threadIdx.x;
@@ -1486,6 +1587,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(loss, double, 2 * 5 * HP_NCH);
     int lc = GS_LC;
+    { static int lcenv = -1; if (lcenv < 0) { const char* e_ = getenv("NELE_HASPI_LC"); lcenv = e_ ? atoi(e_) : 0; } if (lcenv >= GS_LC) lc = lcenv / GS_LC * GS_LC; }
     while ((n24p + lc - 1) / lc > GS_MAXC) lc += GS_LC;
     const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + (lc < GL_N ? lc : GL_N) - 1) / (lc < GL_N ? lc : GL_N);
     TAKE(ssp, double, (size_t)B * 2 * nchunk * HP_NCH);
@@ -1549,12 +1651,16 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);
     if (par_iir) {
         if (sig0 == 0) hipLaunchKernelGGL(haspi_pmat_kernel, dim3(1), dim3(128), 0, s, ws, ws.lc, 0, 0, 1);   // control bank: per channel only
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        static int tail1 = -1;                             // NELE_HASPI_TAIL1=0: pass 1 over whole chunks (A/B diagnostic)
+        if (tail1 < 0) { const char* e_ = getenv("NELE_HASPI_TAIL1"); tail1 = e_ ? atoi(e_) : 1; }
+        if (tail1) hipLaunchKernelGGL(haspi_bank_tail_kernel<false>, dim3(8 * 4 * ((ws.nchunk + 63) / 64) * ((rows + 7) / 8)), dim3(512), 0, s, ws, sig0, nsig, tail1 >= 2 ? tail1 - 1 : 0, rows);
+        else hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<false>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL((haspi_bank_scan_kernel<false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL(haspi_pmat_kernel, dim3(rows), dim3(128), 0, s, ws, ws.lc, 1, sig0, nsig);
-        hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        if (tail1) hipLaunchKernelGGL(haspi_bank_tail_kernel<true>, dim3(8 * 4 * ((ws.nchunk + 63) / 64) * ((rows + 7) / 8)), dim3(512), 0, s, ws, sig0, nsig, tail1 >= 2 ? tail1 - 1 : 0, rows);
+        else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         if (quality) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         else if (in_bank)

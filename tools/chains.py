@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) if False else sys.path.insert(0, '.')
 from nele_gan_amd import synth, metrics as mt
 from nele_gan_amd.train_nele import GanTrainer
 import os
