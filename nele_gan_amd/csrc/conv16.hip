@@ -16,7 +16,8 @@
 //   * operands are swapped (weights = MFMA A, positions = MFMA B) and the output channels are permuted inside the weight fragments so
 //     that a lane ends up with 4 * TN CONSECUTIVE channels of one position: the epilogue is bias / LeakyReLU / mask in registers and
 //     16-byte stores straight from the accumulators - no LDS round trip;
-//   * positions sit in LDS with a padded stride CP >= C chosen so that the 16-byte fragment reads are bank-conflict free.
+//   * positions sit in LDS at stride C with their 16-byte units XOR-swizzled by the position index where C is 32 or 64 (a power-of-two
+//     stride would put the 16 lanes of a fragment read on 2 or 4 bank groups): conflict-free 16-byte fragment reads without padding.
 // Layout contract: A [B][H][W][C] bf16, out [B][OH][OW][OC] bf16 or float32, aux (forward activation for the LeakyReLU mask of a
 // data gradient) [B][Hout][Wout][N] bf16; C, N multiples of 8 / 4.  The data gradient is the same kernel over the zero-bordered
 // gradient buffer with flipped weights, exactly as before.
@@ -39,8 +40,8 @@ struct Conv16Args {
     int N, epi;
     float slope;
     int KH, KW, sps, nsteps;   // k-steps per kernel row (seglen rounded up to 32), KH * sps
-    int CP, RSP, NR;           // position stride / row stride in LDS (elements), ring rows
-    int lgC, lgPAD, padmask;   // padded position stride: element kk of a window sits at kk + ((kk >> lgC) << lgPAD) (padmask = 0: no padding)
+    int RSP, NR;               // row stride in LDS (elements), ring rows
+    int lgC, swz_sh, swz_mask; // unit u of position q sits at unit u ^ ((q >> swz_sh) & swz_mask) (C = 1 << lgC when swz_mask != 0)
     int ntiles, TH;
     ConvGeom g;
 };
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
         const int tw_i = tile % ntw, rem = tile / ntw;
         wo0 = tw_i * C16_TW; ho0 = (rem % nth) * TH; b = rem / nth;
     }
-    const int C = g.C, CP = p.CP, RSP = p.RSP, NR = p.NR;
+    const int C = g.C, RSP = p.RSP, NR = p.NR;
     const int wcols = C16_TW + p.KW - 1;
     const int nrows = TH + p.KH - 1;                   // input rows this tile touches
     const int hi0 = ho0 + g.ih0, wi0 = wo0 + g.iw0;
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
     constexpr int CH = C16_SB * TN * 512;              // elements per weight chunk
 
     // ---- input rows: global -> LDS by DMA, 1 KB pieces; piece k of a row image covers LDS elements [512 k, 512 k + 512) of the slot,
-    // lane l supplies the 8 elements at o = 512 k + 8 l: position o / CP, channel group o % CP (groups >= C are position padding, and
-    // o >= wcols * CP is the slot's tail: both re-read a valid element - they only ever meet zero weights).  Columns / rows outside the
+    // lane l supplies the 8 elements at o = 512 k + 8 l: position o / C, unit (o % C) / 8 - which holds the position's unit
+    // u ^ swizzle(position); o >= wcols * C is the slot's tail (re-reads a valid element: it only ever meets zero weights).  Columns / rows outside the
     // input re-read the last valid column / row: they only feed outputs outside the output (never stored) and k-padding.
     // Wave w moves pieces w, w + 4, w + 8 (RSP <= 12 pieces).
     const int npieces = RSP >> 9;
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int o = 512 * (wave + 4 * t) + 8 * lane;
-        const int pos = min(o / CP, vcols - 1), within = o - (o / CP) * CP;
-        rsrc[t] = pos * C + (within < C ? within : 0);
+        const int q = o / C, un = ((o - q * C) >> 3) ^ ((q >> p.swz_sh) & p.swz_mask);
+        rsrc[t] = min(q, vcols - 1) * C + 8 * un;
     }
     auto row_dma = [&](int r) {
         const __bf16* src = abase + (size_t)min(r, vrows - 1) * g.W * C;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
     const int nr = min(TH, g.Hout - ho0), ncol = min(4, (g.Wout - wo0 + 15) >> 4), total = nr * ncol;
     const int NPr = (total + 3) >> 2;
     const int n0 = 4 * TN * lg;
-    const int vb = li * CP;                            // lane part of a fragment address (elements)
+    const int vb = li * C;                             // lane part of a fragment address (elements)
 
     auto run = [&](auto np_tag) {
         constexpr int NP = decltype(np_tag)::value;
@@ -143,14 +144,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
         const __bf16* wl = wring + lane * 8;
         auto ldfrag = [&](int uu, bf16x8 (&af)[NP], bf16x8 (&bfr)[TN]) {
             const int kk8 = lu * 32 + 8 * lg;
-            const int vk = vb + kk8 + (((kk8 >> p.lgC) << p.lgPAD) & p.padmask);
+            const int vk = (vb + kk8) ^ ((((li + (kk8 >> p.lgC)) >> p.swz_sh) & p.swz_mask) << 3);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(wl + (uu * TN + j) * 512);
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 int rr = lr + prow[k];
                 if (rr >= NR) rr -= NR;
-                af[k] = *reinterpret_cast<const bf16x8*>(lds16 + (rr * RSP + 16 * pcol[k] * CP) + vk);
+                af[k] = *reinterpret_cast<const bf16x8*>(lds16 + (rr * RSP + 16 * pcol[k] * C) + vk);
             }
             if (++lu == p.sps) { lu = 0; if (++lr == NR) lr = 0; }
         };
@@ -340,9 +341,7 @@ __global__ void conv16_frag_kernel(C16FragJobs J) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static int c16_pad(int C) { return C == 32 ? 16 : C == 64 ? 16 : 0; }     // conflict-free 16-byte fragment reads (ds_read_b128 lane groups)
-
-struct C16Plan { int TN, TH, NR, CP, RSP, PAD, lgC, lgPAD, sps; size_t lds; };
+struct C16Plan { int TN, TH, NR, RSP, lgC, swz_sh, swz_mask, sps; size_t lds; };
 static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
     if (N < 4 || N > 64 || (N & 3) || g.C < 8 || g.C > 64 || (g.C & 7) || KH < 2 || KW < 2 || KW > 9 || KH > 9) return false;
     if (g.seglen != KW * g.C || g.Ktot != KH * KW * g.C) return false;
@@ -355,24 +354,18 @@ static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
     const int th_env = getenv("NELE_CONV16_TH") ? atoi(getenv("NELE_CONV16_TH")) : 0;
     int th = (nsteps * q.TN <= 64 && q.TN <= 2) ? 8 : 4;      // (TN >= 3 with 8 rows does not fit 256 registers)
     if (th_env == 4 || (th_env == 8 && q.TN <= 2)) th = th_env;
-    const int pads[3] = {c16_pad(g.C), 8, 0};
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        q.TH = th;
-        q.PAD = pads[attempt];
-        if (q.PAD && (g.C & (g.C - 1))) continue;
-        q.lgC = 0;
-        while ((1 << q.lgC) < g.C) ++q.lgC;
-        if (!q.PAD) q.lgC = 0;
-        q.lgPAD = q.PAD == 16 ? 4 : 3;
-        q.CP = g.C + q.PAD;
-        q.RSP = ((C16_TW + KW - 1) * q.CP + 511) & ~511;     // whole 1 KB DMA pieces per ring slot
-        const int full = q.TH + KH - 1;
-        const int ring = q.sps >= 2 * C16_SB - 1 ? q.TH + 1 : q.sps >= C16_SB ? q.TH + 2 : full;
-        q.NR = ring < full ? ring : full;
-        q.lds = ((size_t)q.NR * q.RSP + 64 + 2 * C16_SB * q.TN * 512) * 2;
-        if (q.RSP > 12 * 512) continue;                        // a wave moves at most 3 pieces of a row
-        if (q.lds <= 80 * 1024 || attempt == 2 || q.PAD == 0) break;
-    }
+    q.TH = th;
+    // 16-byte fragment reads of 16 consecutive positions: conflict-free at stride 16, 32 and 96 bytes (C = 8, 16, 48); at 64 / 128 bytes
+    // the units of a position are XOR-swizzled by the position index (checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md)
+    q.lgC = 0; q.swz_sh = 0; q.swz_mask = 0;
+    if (g.C == 64) { q.lgC = 6; q.swz_mask = 7; }
+    else if (g.C == 32) { q.lgC = 5; q.swz_sh = 1; q.swz_mask = 3; }
+    q.RSP = ((C16_TW + KW - 1) * g.C + 511) & ~511;          // whole 1 KB DMA pieces per ring slot
+    if (q.RSP > 12 * 512) return false;                       // a wave moves at most 3 pieces of a row
+    const int full = q.TH + KH - 1;
+    const int ring = q.sps >= 2 * C16_SB - 1 ? q.TH + 1 : q.sps >= C16_SB ? q.TH + 2 : full;
+    q.NR = ring < full ? ring : full;
+    q.lds = ((size_t)q.NR * q.RSP + 64 + 2 * C16_SB * q.TN * 512) * 2;
     if (q.lds > 160 * 1024) return false;
     *pl = q;
     return true;
@@ -436,7 +429,7 @@ extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias
     Conv16Args a;
     a.A = (const __bf16*)A16; a.Wfrag = (const __bf16*)Wfrag; a.bias = bias; a.aux = (const __bf16*)aux16; a.out = out;
     a.N = N; a.epi = epi; a.slope = slope; a.KH = KH; a.KW = KW; a.sps = pl.sps; a.nsteps = KH * pl.sps;
-    a.CP = pl.CP; a.RSP = pl.RSP; a.NR = pl.NR; a.lgC = pl.lgC; a.lgPAD = pl.lgPAD; a.padmask = pl.PAD ? -1 : 0; a.TH = pl.TH; a.g = g;
+    a.RSP = pl.RSP; a.NR = pl.NR; a.lgC = pl.lgC; a.swz_sh = pl.swz_sh; a.swz_mask = pl.swz_mask; a.TH = pl.TH; a.g = g;
     a.ntiles = ((g.Wout + C16_TW - 1) / C16_TW) * ((g.Hout + pl.TH - 1) / pl.TH) * B;
     const dim3 grid((unsigned)((a.ntiles + 7) / 8 * 8));
     hipStream_t s = as_stream(stream);

@@ -22,6 +22,7 @@
 //       normalised cross-correlation of reference and processed sequences
 //   h12 average over bases 2-6, weighted sum, logistic map
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 #define HP_NCH 32
@@ -450,6 +451,15 @@ __device__ __forceinline__ void hp_rotate(double& cold, double& sold, double cn,
     sold = fma(sold, cn, -(cold * sn));
     cold = arg;
 }
+// One sample of a branch of the 4th-order gammatone section, y = x + r0 computed by the caller: the serial kernel's state update
+// (r0 = a1 x + a1 y + r1, r1 = a5 x + a2 y + r2, r2 = a3 y + r3, r3 = a4 y; pyhaspi2.py:905-912 through scipy's lfilter) with the two
+// three-term sums as multiply-add chains - 6 operations instead of 8, results equal to rounding (1e-16 relative per step).
+__device__ __forceinline__ void hp_gt_step(const GtCoef& c, double x, double y, double& r0, double& r1, double& r2, double& r3) {
+    r0 = fma(c.a1, x + y, r1);
+    r1 = fma(c.a5, x, fma(c.a2, y, r2));
+    r2 = fma(c.a3, y, r3);
+    r3 = c.a4 * y;
+}
 // P = M^lc per channel.  grid (1 + rows) for the signal bank (blockIdx.x = 1 + launch row) / 1 for the control bank, block 128:
 // thread = (unit vector k, channel).
 __global__ __launch_bounds__(128) void haspi_pmat_kernel(HaspiWs ws, int lc, int signal, int sig0, int nsig) {
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(64) void haspi_bank_prefix_kernel(HaspiWs ws, int s
 // kernel's instructions and kept it compute-bound at 0.3 of the HBM rate.
 __device__ __forceinline__ float hp_log2f(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float hp_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
-struct IhcC { double R2, R12C1, R23C2, a11, a12, a21, a22, denom, R1inv; };
+struct IhcC { double R2, R12C1, R23C2, a11, a12, a21, a22, denom, R1inv, c10, c11, c12, c20, c21, c22; };
 __device__ __forceinline__ IhcC hp_ihc_consts() {
     const double delta = 2.0;
     const double tau1 = 0.001 * 2, tau2 = 0.001 * 60;
@@ -526,13 +536,16 @@ __device__ __forceinline__ IhcC hp_ihc_consts() {
     k.a11 = R1 + R2 + R1 * R2 * (C1 / T); k.a12 = -R1; k.a21 = -R3; k.a22 = R2 + R3 + R2 * R3 * (C2 / T);
     k.denom = 1.0 / (k.a11 * k.a22 - k.a21 * k.a12);
     k.R1inv = 1.0 / R1; k.R12C1 = R1 * R2 * (C1 / T); k.R23C2 = R2 * R3 * (C2 / T); k.R2 = R2;
+    // the step of pyhaspi2.py:1061-1070 (b1 = R2 V0 + R12C1 V1, b2 = R23C2 V2, V = denom * adj(A) b) with its constants multiplied out:
+    // V1' = c10 V0 + c11 V1 + c12 V2, V2' = c20 V0 + c21 V1 + c22 V2 - six operations on the serial chain instead of nine
+    k.c10 = k.denom * k.a22 * k.R2;  k.c11 = k.denom * k.a22 * k.R12C1;  k.c12 = -k.denom * k.a12 * k.R23C2;
+    k.c20 = -k.denom * k.a21 * k.R2; k.c21 = -k.denom * k.a21 * k.R12C1; k.c22 = k.denom * k.a11 * k.R23C2;
     return k;
 }
 __device__ __forceinline__ void hp_ihc_step(const IhcC& k, double V0, double& V1, double& V2) {
-    const double b1 = V0 * k.R2 + k.R12C1 * V1;
-    const double b2 = k.R23C2 * V2;
-    V1 = k.denom * (k.a22 * b1 - k.a12 * b2);
-    V2 = k.denom * (-k.a21 * b1 + k.a11 * b2);
+    const double t1 = fma(k.c12, V2, fma(k.c11, V1, V0 * k.c10));
+    const double t2 = fma(k.c22, V2, fma(k.c21, V1, V0 * k.c20));
+    V1 = t1; V2 = t2;
 }
 
 // grid (ceil(chunks / 2), nsig, B), block 64: lane = (chunk parity) * 32 + channel.  A lane runs BOTH demodulated branches (x cos and
@@ -606,36 +619,37 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
     }
     for (int nb = n0; nb < n1; nb += GS_RC) {
         double xc[GS_RC];
+        const hp_env_t* ctl_nb = ctl + (size_t)nb * HP_NCH;              // one 64-bit address per group, immediates per sample
+        hp_env_t* out_nb = out + (size_t)nb * HP_NCH;
+        float* cph_nb = BM ? cph + (size_t)nb * HP_NCH : nullptr;
 #pragma unroll
         for (int u = 0; u < GS_RC / 2; ++u) {
             const double2 v = *reinterpret_cast<const double2*>(xin + nb + 2 * u);
             xc[2 * u] = v.x; xc[2 * u + 1] = v.y;
         }
         float eo[GS_RC], co[BM ? GS_RC : 1];
+        auto bank = [&](auto tail_tag) {                    // TAIL: the group that holds the row's end (only its samples < n24 count in ss)
+            constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-        for (int u = 0; u < GS_RC; ++u) {
-            hp_rotate(cold, sold, cn, sn);
-            const double xr = xc[u] * cold, xi = xc[u] * sold;
-            const double yr = xr + r0, yi = xi + i0;
-            r0 = c.a1 * xr + c.a1 * yr + r1;
-            r1 = c.a5 * xr + c.a2 * yr + r2;
-            r2 = c.a3 * yr + r3;
-            r3 = c.a4 * yr;
-            i0 = c.a1 * xi + c.a1 * yi + i1;
-            i1 = c.a5 * xi + c.a2 * yi + i2;
-            i2 = c.a3 * yi + i3;
-            i3 = c.a4 * yi;
-            if (PASS2) {
-                const double e2 = yr * yr + yi * yi;
-                eo[u] = (float)e2;
-                if (!SIGNAL || BM) ss += (nb + u < n24) ? e2 : 0.0;
-                if (BM) co[u] = e2 > 0.0 ? (float)((yr * cold + yi * sold) / sqrt(e2)) : 0.f;
+            for (int u = 0; u < GS_RC; ++u) {
+                hp_rotate(cold, sold, cn, sn);
+                const double xr = xc[u] * cold, xi = xc[u] * sold;
+                const double yr = xr + r0, yi = xi + i0;
+                hp_gt_step(c, xr, yr, r0, r1, r2, r3);
+                hp_gt_step(c, xi, yi, i0, i1, i2, i3);
+                if (PASS2) {
+                    const double e2 = yr * yr + yi * yi;
+                    eo[u] = (float)e2;
+                    if (!SIGNAL || BM) ss += (!TAIL || nb + u < n24) ? e2 : 0.0;
+                    if (BM) co[u] = e2 > 0.0 ? (float)((yr * cold + yi * sold) / sqrt(e2)) : 0.f;
+                }
             }
-        }
+        };
+        if (PASS2 && (!SIGNAL || BM) && nb + GS_RC > n24) bank(std::true_type{}); else bank(std::false_type{});
         if (GAIN) {
             float gc[GS_RC];
 #pragma unroll
-            for (int u = 0; u < GS_RC; ++u) gc[u] = ctl[(size_t)(nb + u) * HP_NCH];
+            for (int u = 0; u < GS_RC; ++u) gc[u] = ctl_nb[u * HP_NCH];
 #pragma unroll
             for (int u = 0; u < GS_RC; ++u) {
                 float le = c_off + TEN_LOG10_2 * hp_log2f(gc[u]);
@@ -652,10 +666,10 @@ __global__ __launch_bounds__(64) void haspi_bank_scan_kernel(HaspiWs ws, int sig
         }
         if (PASS2) {
 #pragma unroll
-            for (int u = 0; u < GS_RC; ++u) out[(size_t)(nb + u) * HP_NCH] = eo[u];
+            for (int u = 0; u < GS_RC; ++u) out_nb[u * HP_NCH] = eo[u];
             if (BM) {
 #pragma unroll
-                for (int u = 0; u < GS_RC; ++u) cph[(size_t)(nb + u) * HP_NCH] = co[u];
+                for (int u = 0; u < GS_RC; ++u) cph_nb[u * HP_NCH] = co[u];
             }
         }
     }
@@ -757,14 +771,8 @@ __global__ __launch_bounds__(512) void haspi_bank_tail_kernel(HaspiWs ws, int si
                 hp_rotate(cold, sold, cn, sn);
                 const double xr = xc[u] * cold, xi = xc[u] * sold;
                 const double yr = xr + r0, yi = xi + i0;
-                r0 = c.a1 * xr + c.a1 * yr + r1;
-                r1 = c.a5 * xr + c.a2 * yr + r2;
-                r2 = c.a3 * yr + r3;
-                r3 = c.a4 * yr;
-                i0 = c.a1 * xi + c.a1 * yi + i1;
-                i1 = c.a5 * xi + c.a2 * yi + i2;
-                i2 = c.a3 * yi + i3;
-                i3 = c.a4 * yi;
+                hp_gt_step(c, xr, yr, r0, r1, r2, r3);
+                hp_gt_step(c, xi, yi, i0, i1, i2, i3);
             }
         }
     }
@@ -1071,6 +1079,104 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
 #pragma unroll
         for (int u = 0; u < GL_U; ++u) ring[(nb + u) & 63][tid] = news[u];
         if (yi >= 0 && yi < nsub) lp[(size_t)yi * HP_NCH] = yv;
+    }
+}
+
+// The same pass in groups of NINE samples.  Outputs are 9 samples apart, so with groups that start on multiples of 9 a lane's output
+// always falls on the SAME sample u_lane = (26 - shift) mod 9 of a group: the phase counters, bounds tests and output selects of the
+// kernel above (62 instructions per sample, issue-bound) shrink to one compare-select of s0 - Re s1 per sample (27 per sample; groups
+// that reach n + shift >= n24 take a predicated copy of the body).  The time axis stays common to the wave - per-lane axes aligned to
+// each channel's own phase were measured: one cache line per LANE and load, bound by the L1 tag rate.  The window's trailing edge
+// o[n - 51] lies 5 groups + 6 samples back: the ring in LDS is 7 group slots with wave-uniform slot numbers, every LDS address is a
+// per-group base plus an immediate.  Warm-up: the first group starts 51 .. 59 samples before the chunk (the IHC state is stepped back
+// that far), with the ring zeroed - by the chunk's first output the window is complete.
+#define IF_G 9
+#define IF_SLOTS 7
+__global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig0, int nsig) {
+    __shared__ float ring[IF_SLOTS * IF_G][128];
+    const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig), b = row >> 1;
+    const int lcf = ws.lcg * ws.fmul;                          // samples per thread
+    const int chunk = blockIdx.x * 4 + (tid >> 5), n0 = chunk * lcf;
+    const int n24 = hp_n24(ws, b), nsub = hp_nsub(ws, b);
+    const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
+    const int last = (n24 - 1) / lcf;                          // chunk that holds the row's last sample
+#pragma unroll
+    for (int q = 0; q < IF_SLOTS * IF_G; ++q) ring[q][tid] = 0.f;      // own column only: no barrier needed
+    if (chunk > last) return;
+    const int sh = ws.shift[(size_t)b * HP_NCH + ch];
+    // this chunk emits the outputs whose window ends in [n0, n1); the last chunk also those that end behind the row's end
+    const int n1 = (chunk == last) ? n24 + 9 + 26 : n0 + lcf;
+    const IhcC k = hp_ihc_consts();
+    const double* ihe = ws.ihe + ((size_t)row * ncg + (size_t)chunk * ws.fmul) * 64 + ch;
+    double V1 = ihe[0], V2 = ihe[32];                          // true state at the chunk start (haspi_ihc_prefix_kernel)
+    const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
+    // output i is due at n = 9 i + 26 - sh = 9 g + ul in group g: i = g + di
+    const int ul = (((26 - sh) % 9) + 9) % 9, di = (ul + sh - 26) / 9;          // (exact division)
+    int nG = (chunk > 0) ? (n0 - IF_L) / 9 * 9 : 0;            // first group: 51 .. 59 samples before the chunk
+    if (chunk > 0) {                                           // state at n0 -> state at nG (inverse of hp_ihc_step; it grows by 1.02 per step)
+        const int cnt = n0 - nG;
+        float hb[IF_L + IF_G - 1];                             // all loads first, then the (serial) backward steps
+#pragma unroll
+        for (int q = 0; q < IF_L + IF_G - 1; ++q) hb[q] = e[(size_t)(n0 - 1 - q) * HP_NCH];
+        const double idet = 1.0 / (k.c11 * k.c22 - k.c12 * k.c21);
+#pragma unroll
+        for (int q = 0; q < IF_L + IF_G - 1; ++q) {
+            const double V0 = (double)hb[q];
+            const double w1 = V1 - k.c10 * V0, w2 = V2 - k.c20 * V0;
+            const double o1 = (k.c22 * w1 - k.c12 * w2) * idet, o2 = (k.c11 * w2 - k.c21 * w1) * idet;
+            V1 = q < cnt ? o1 : V1;
+            V2 = q < cnt ? o2 : V2;
+        }
+    }
+    double* lp = ws.lp + ((size_t)row * ws.nsub) * HP_NCH + ch;
+    if (chunk == 0) {                                          // outputs whose whole window lies before the lane's first sample
+        for (int j = 0; j < nsub && 9 * j + 26 - sh < 0; ++j) lp[(size_t)j * HP_NCH] = 0.0;
+    }
+    const double phi = 2.0 * M_PI / (double)IF_L, rc = cos(phi), rs = sin(phi);
+    double s0 = 0.0, s1r = 0.0, s1i = 0.0;
+    const hp_env_t* ep = e + (size_t)nG * HP_NCH;              // (the prefetch runs a few rows past the row's end: still inside the workspace,
+                                                               //  and what it reads there is replaced before use)
+    float nx[IF_G];                                            // the next group's samples are in flight while this group is processed
+#pragma unroll
+    for (int u = 0; u < IF_G; ++u) nx[u] = ep[u * HP_NCH];
+    int slot = 0;                                              // wave-uniform
+    float* rcol = &ring[0][tid];
+    int i = nG / 9 + di;
+    while (nG < n1) {
+        float ex[IF_G], olds[IF_G], news[IF_G];
+#pragma unroll
+        for (int u = 0; u < IF_G; ++u) ex[u] = nx[u];
+#pragma unroll
+        for (int u = 0; u < IF_G; ++u) nx[u] = ep[(IF_G + u) * HP_NCH];
+        const int sa = slot + 1 >= IF_SLOTS ? slot + 1 - IF_SLOTS : slot + 1, sb = slot + 2 >= IF_SLOTS ? slot + 2 - IF_SLOTS : slot + 2;
+        const float* ra = rcol + sa * (IF_G * 128);
+        const float* rb = rcol + sb * (IF_G * 128);
+#pragma unroll
+        for (int u = 0; u < IF_G; ++u) olds[u] = (u < 6) ? ra[(u + 3) * 128] : rb[(u - 6) * 128];
+        double z = 0.0;
+        auto body = [&](auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+            for (int u = 0; u < IF_G; ++u) {
+                const double V0 = (double)ex[u];
+                hp_ihc_step(k, V0, V1, V2);
+                float o = (float)fmax((V0 - V1) * k.R1inv, 0.0);
+                if (EDGE) o = (nG + u + sh < n24) ? o : 0.f;     // beyond the row's end the shifted envelope is zero
+                news[u] = o;
+                const double dx = (double)o - (double)olds[u];
+                s0 += dx;
+                { const double nr = fma(-rs, s1i, fma(rc, s1r, dx)); s1i = fma(rc, s1i, rs * s1r); s1r = nr; }
+                z = (u == ul) ? s0 - s1r : z;
+            }
+        };
+        if (nG + (IF_G - 1) + sh >= n24) body(std::true_type{}); else body(std::false_type{});
+        float* wr = rcol + slot * (IF_G * 128);
+#pragma unroll
+        for (int u = 0; u < IF_G; ++u) wr[u * 128] = news[u];
+        const int nE = nG + ul;
+        if (nE >= n0 && nE < n1 && i >= 0 && i < nsub) lp[(size_t)i * HP_NCH] = (0.5 * z) * (1.0 / 25.5);
+        nG += IF_G; ep += IF_G * HP_NCH; ++i;
+        slot = slot + 1 >= IF_SLOTS ? 0 : slot + 1;
     }
 }
 
@@ -1678,7 +1784,11 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
                       hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
         hipLaunchKernelGGL(haspi_ihc_prefix_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         if (quality) return;                                   // haspi_quality.h goes on from the dB-SL envelope + IHC start states
-        hipLaunchKernelGGL(haspi_ihc_fir_kernel, dim3((ws.n24p + 4 * ws.lcg * ws.fmul - 1) / (4 * ws.lcg * ws.fmul), rows), dim3(128), 0, s, ws, sig0, nsig);
+        static int fir9 = -1;                                  // NELE_HASPI_FIR9=0: the 8-sample-group kernel with per-sample phase counters (A/B diagnostic)
+        if (fir9 < 0) { const char* e_ = getenv("NELE_HASPI_FIR9"); fir9 = !(e_ && e_[0] == '0'); }
+        const dim3 fgrid((ws.n24p + 4 * ws.lcg * ws.fmul - 1) / (4 * ws.lcg * ws.fmul), rows);
+        if (fir9) hipLaunchKernelGGL(haspi_ihc_fir9_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
+        else hipLaunchKernelGGL(haspi_ihc_fir_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
         if (fused_gain) {
