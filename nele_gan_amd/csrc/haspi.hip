@@ -64,8 +64,9 @@ struct HaspiWs {
     double* benv;    // [52] envelope low-pass taps (np.hanning(52) / sum), written by haspi_shift_kernel
     double* bkt;     // [10][616] modulation-filter taps per band, written by haspi_shift_kernel
     int* shift;      // [B][32]
-    double* lp;      // [B][2][nsub][32]
-    int* act;        // [B][nsub]     indices of the active sub-sampled frames (serial cepstrum kernel only)
+    double* lp;      // [B][2][nlp][32]  low-passed, sub-sampled envelope: row = frame i (lp_raw = 0), or row = group g of haspi_ihc_fir9_kernel
+                     //                  with frame i of channel c in row i - di(c) (lp_raw = 1; rows g < 0 are zeros) - read it through hp_lp_at
+    int* act;        // [B][nsub]     compacted position of a frame among the active ones, or -1 (serial cepstrum kernel only)
     int* grank;      // [B][nsub]     rank of an active frame inside its block of CP_F frames, or -1 (silence gate)
     int* gcnt;       // [B][ngb]      active frames per block -> exclusive offsets
     double* cpsum;   // [B][2][ngb][6] block partial sums of the cepstral sequences
@@ -82,6 +83,7 @@ struct HaspiWs {
     double* sse;     // quality path only: [B][2][nchunk][32] signal-bank sum-of-squares partials per scan chunk
     int fs_in;
     int n24, nsub;   // of the longest row: buffer strides
+    int nlp, lp_raw; // rows per (utterance, signal) block of lp (nsub + 4); layout of lp (see there)
     int n24p;        // n24 rounded up to a multiple of HP_CH: row stride of the per-sample buffers (chunked kernels read/write whole chunks)
 };
 
@@ -95,6 +97,22 @@ __device__ __forceinline__ int hp_n24(const HaspiWs& ws, int b) {
 __device__ __forceinline__ int hp_nsub(const HaspiWs& ws, int b) { return (hp_n24(ws, b) + HP_SPACE - 1) / HP_SPACE; }
 // (utterance, signal) row of a launch that covers nsig signals starting at sig0: idx = b * nsig + s
 __device__ __forceinline__ int hp_row(int idx, int sig0, int nsig) { return nsig == 2 ? idx : 2 * idx + sig0; }
+
+// Frame offset of channel ch in the group-space layout of lp: haspi_ihc_fir9_kernel emits frame i of a channel with group-delay shift sh
+// on sample ul = (26 - sh) mod 9 of group g = i - di, di = (ul + sh - 26) / 9 (exact), and stores GROUPS as rows - all 32 channels of a
+// row at once, full cache lines - instead of scattering 8-byte values over the rows i = g + di(ch) (measured: 3.4 x write
+// amplification, and the stores, not the arithmetic, set the kernel's time).
+__device__ __forceinline__ int hp_lp_di(const HaspiWs& ws, int b, int ch) {
+    if (!ws.lp_raw) return 0;
+    const int sh = ws.shift[(size_t)b * HP_NCH + ch];
+    const int ul = (((26 - sh) % 9) + 9) % 9;
+    return (ul + sh - 26) / 9;
+}
+// lp of frame i (< nsub), channel ch; lpb = block of one (utterance, signal), di = hp_lp_di of the channel
+__device__ __forceinline__ double hp_lp_at(const double* __restrict__ lpb, int i, int ch, int di) {
+    const int g = i - di;
+    return g >= 0 ? lpb[(size_t)g * HP_NCH + ch] : 0.0;
+}
 
 __device__ __forceinline__ double i0_series(double x) {
     double s = 1.0, t = 1.0;
@@ -1027,7 +1045,7 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
             V2 = b2 * iR23;
         }
     }
-    double* lp = ws.lp + ((size_t)row * ws.nsub) * HP_NCH + ch;
+    double* lp = ws.lp + ((size_t)row * ws.nlp) * HP_NCH + ch;
     if (chunk == 0) {                                        // outputs whose whole window lies before the lane's first sample
         for (int i = 0; i < nsub && 9 * i + 26 - sh < 0; ++i) lp[(size_t)i * HP_NCH] = 0.0;
     }
@@ -1084,24 +1102,25 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
 
 // The same pass in groups of NINE samples.  Outputs are 9 samples apart, so with groups that start on multiples of 9 a lane's output
 // always falls on the SAME sample u_lane = (26 - shift) mod 9 of a group: the phase counters, bounds tests and output selects of the
-// kernel above (62 instructions per sample, issue-bound) shrink to one compare-select of s0 - Re s1 per sample (27 per sample; groups
-// that reach n + shift >= n24 take a predicated copy of the body).  The time axis stays common to the wave - per-lane axes aligned to
-// each channel's own phase were measured: one cache line per LANE and load, bound by the L1 tag rate.  The window's trailing edge
-// o[n - 51] lies 5 groups + 6 samples back: the ring in LDS is 7 group slots with wave-uniform slot numbers, every LDS address is a
-// per-group base plus an immediate.  Warm-up: the first group starts 51 .. 59 samples before the chunk (the IHC state is stepped back
-// that far), with the ring zeroed - by the chunk's first output the window is complete.
+// kernel above (62 instructions per sample, issue-bound) shrink to one compare-select of s0 - Re s1 per sample (groups that reach
+// n + shift >= n24 take a predicated copy of the body).  The time axis stays common to the wave - per-lane axes aligned to each
+// channel's own phase were measured: one cache line per LANE and load, bound by the L1 tag rate.
+// The window's trailing edge o[n - 51] lies 5 groups + 6 samples back, so the delay line is 6 groups = 54 values updated in place
+// (sample u of a group reads position u + 3 of the oldest group, or u - 6 of the next one, before position u is overwritten) - and with
+// the loop unrolled over those 6 groups every position is a compile-time index: the delay line lives in 54 REGISTERS.  (In LDS, 252
+// bytes per thread, it capped the kernel at 2.5 waves per SIMD - 1.6 on average with the last round of workgroups - and the waves
+// spent half their time waiting: 1.43 ms per call at B = 256 against 0.63 ms of instruction issue.)
+// Warm-up: the first group starts 51 .. 59 samples before the chunk (the IHC state is stepped back that far) with a zero delay line -
+// by the chunk's first output the window is complete.
 #define IF_G 9
-#define IF_SLOTS 7
+#define IF_SLOTS 6
 __global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig0, int nsig) {
-    __shared__ float ring[IF_SLOTS * IF_G][128];
     const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig), b = row >> 1;
     const int lcf = ws.lcg * ws.fmul;                          // samples per thread
     const int chunk = blockIdx.x * 4 + (tid >> 5), n0 = chunk * lcf;
     const int n24 = hp_n24(ws, b), nsub = hp_nsub(ws, b);
     const int ncg = (ws.n24p + ws.lcg - 1) / ws.lcg;
     const int last = (n24 - 1) / lcf;                          // chunk that holds the row's last sample
-#pragma unroll
-    for (int q = 0; q < IF_SLOTS * IF_G; ++q) ring[q][tid] = 0.f;      // own column only: no barrier needed
     if (chunk > last) return;
     const int sh = ws.shift[(size_t)b * HP_NCH + ch];
     // this chunk emits the outputs whose window ends in [n0, n1); the last chunk also those that end behind the row's end
@@ -1110,8 +1129,8 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig
     const double* ihe = ws.ihe + ((size_t)row * ncg + (size_t)chunk * ws.fmul) * 64 + ch;
     double V1 = ihe[0], V2 = ihe[32];                          // true state at the chunk start (haspi_ihc_prefix_kernel)
     const hp_env_t* e = ws.env + ((size_t)row * ws.n24p) * HP_NCH + ch;
-    // output i is due at n = 9 i + 26 - sh = 9 g + ul in group g: i = g + di
-    const int ul = (((26 - sh) % 9) + 9) % 9, di = (ul + sh - 26) / 9;          // (exact division)
+    // output i is due at n = 9 i + 26 - sh = 9 g + ul in group g: i = g + di (hp_lp_di)
+    const int ul = (((26 - sh) % 9) + 9) % 9;
     int nG = (chunk > 0) ? (n0 - IF_L) / 9 * 9 : 0;            // first group: 51 .. 59 samples before the chunk
     if (chunk > 0) {                                           // state at n0 -> state at nG (inverse of hp_ihc_step; it grows by 1.02 per step)
         const int cnt = n0 - nG;
@@ -1128,10 +1147,9 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig
             V2 = q < cnt ? o2 : V2;
         }
     }
-    double* lp = ws.lp + ((size_t)row * ws.nsub) * HP_NCH + ch;
-    if (chunk == 0) {                                          // outputs whose whole window lies before the lane's first sample
-        for (int j = 0; j < nsub && 9 * j + 26 - sh < 0; ++j) lp[(size_t)j * HP_NCH] = 0.0;
-    }
+    // group-space rows (ws.lp_raw, see hp_lp_di): row g holds every channel's output of group g - the consumers read frame i of channel c
+    // from row i - di(c) and take rows g < 0 (windows that end before the lane's first sample) as zeros
+    double* lp = ws.lp + ((size_t)row * ws.nlp) * HP_NCH + ch;
     const double phi = 2.0 * M_PI / (double)IF_L, rc = cos(phi), rs = sin(phi);
     double s0 = 0.0, s1r = 0.0, s1i = 0.0;
     const hp_env_t* ep = e + (size_t)nG * HP_NCH;              // (the prefetch runs a few rows past the row's end: still inside the workspace,
@@ -1139,45 +1157,42 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig
     float nx[IF_G];                                            // the next group's samples are in flight while this group is processed
 #pragma unroll
     for (int u = 0; u < IF_G; ++u) nx[u] = ep[u * HP_NCH];
-    int slot = 0;                                              // wave-uniform
-    float* rcol = &ring[0][tid];
-    int i = nG / 9 + di;
-    while (nG < n1) {
-        float ex[IF_G], olds[IF_G], news[IF_G];
+    float dl[IF_SLOTS * IF_G];                                 // the delay line: every index below is a compile-time constant
+#pragma unroll
+    for (int q = 0; q < IF_SLOTS * IF_G; ++q) dl[q] = 0.f;
+    int i = nG / 9;                                            // group = row of lp
+    auto group = [&](auto slot_tag, auto edge_tag) {
+        constexpr int S = decltype(slot_tag)::value, S1 = (S + 1) % IF_SLOTS;
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        float ex[IF_G];
 #pragma unroll
         for (int u = 0; u < IF_G; ++u) ex[u] = nx[u];
 #pragma unroll
         for (int u = 0; u < IF_G; ++u) nx[u] = ep[(IF_G + u) * HP_NCH];
-        const int sa = slot + 1 >= IF_SLOTS ? slot + 1 - IF_SLOTS : slot + 1, sb = slot + 2 >= IF_SLOTS ? slot + 2 - IF_SLOTS : slot + 2;
-        const float* ra = rcol + sa * (IF_G * 128);
-        const float* rb = rcol + sb * (IF_G * 128);
-#pragma unroll
-        for (int u = 0; u < IF_G; ++u) olds[u] = (u < 6) ? ra[(u + 3) * 128] : rb[(u - 6) * 128];
         double z = 0.0;
-        auto body = [&](auto edge_tag) {
-            constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
-            for (int u = 0; u < IF_G; ++u) {
-                const double V0 = (double)ex[u];
-                hp_ihc_step(k, V0, V1, V2);
-                float o = (float)fmax((V0 - V1) * k.R1inv, 0.0);
-                if (EDGE) o = (nG + u + sh < n24) ? o : 0.f;     // beyond the row's end the shifted envelope is zero
-                news[u] = o;
-                const double dx = (double)o - (double)olds[u];
-                s0 += dx;
-                { const double nr = fma(-rs, s1i, fma(rc, s1r, dx)); s1i = fma(rc, s1i, rs * s1r); s1r = nr; }
-                z = (u == ul) ? s0 - s1r : z;
-            }
-        };
-        if (nG + (IF_G - 1) + sh >= n24) body(std::true_type{}); else body(std::false_type{});
-        float* wr = rcol + slot * (IF_G * 128);
-#pragma unroll
-        for (int u = 0; u < IF_G; ++u) wr[u * 128] = news[u];
+        for (int u = 0; u < IF_G; ++u) {
+            const double V0 = (double)ex[u];
+            hp_ihc_step(k, V0, V1, V2);
+            float o = (float)fmax((V0 - V1) * k.R1inv, 0.0);
+            if (EDGE) o = (nG + u + sh < n24) ? o : 0.f;       // beyond the row's end the shifted envelope is zero
+            const float old = (u < 6) ? dl[S * IF_G + u + 3] : dl[S1 * IF_G + u - 6];     // o[n - 51]
+            dl[S * IF_G + u] = o;
+            const double dx = (double)o - (double)old;
+            s0 += dx;
+            { const double nr = fma(-rs, s1i, fma(rc, s1r, dx)); s1i = fma(rc, s1i, rs * s1r); s1r = nr; }
+            z = (u == ul) ? s0 - s1r : z;
+        }
         const int nE = nG + ul;
-        if (nE >= n0 && nE < n1 && i >= 0 && i < nsub) lp[(size_t)i * HP_NCH] = (0.5 * z) * (1.0 / 25.5);
+        if (nE >= n0 && nE < n1 && i < ws.nlp) lp[(size_t)i * HP_NCH] = (0.5 * z) * (1.0 / 25.5);
         nG += IF_G; ep += IF_G * HP_NCH; ++i;
-        slot = slot + 1 >= IF_SLOTS ? 0 : slot + 1;
-    }
+    };
+#define IF_GROUP(S)                                                                                              \
+    if (nG >= n1) break;                                                                                         \
+    if (nG + (IF_G - 1) + sh >= n24) group(std::integral_constant<int, S>{}, std::true_type{});                  \
+    else group(std::integral_constant<int, S>{}, std::false_type{});
+    for (;;) { IF_GROUP(0) IF_GROUP(1) IF_GROUP(2) IF_GROUP(3) IF_GROUP(4) IF_GROUP(5) }
+#undef IF_GROUP
 }
 
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
@@ -1270,7 +1285,7 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0
         // out[i] = sum_k benv[k] * x[9 i + 26 - k]  ->  LDS row (9 li + 51 - k)
 #pragma unroll 4
         for (int k = 0; k < HP_NFILT; ++k) acc += benv[k] * xs[HP_SPACE * li + (HP_NFILT - 1) - k][ch];
-        ws.lp[(((size_t)b * 2 + sig) * ws.nsub + i) * HP_NCH + ch] = acc;
+        ws.lp[(((size_t)b * 2 + sig) * ws.nlp + i) * HP_NCH + ch] = acc;
     }
 }
 
@@ -1283,10 +1298,10 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0
 #define CP_F 128
 // the block's [CP_F frames][32 channels] tile of the low-passed envelope, loaded with coalesced reads (a thread that walks its own
 // 256-byte row touches 64 cache lines per load instruction) and padded against bank conflicts
-__device__ __forceinline__ void hp_stage_lp(const double* __restrict__ lp, int i0, int nsub, double (*tile)[HP_NCH + 1]) {
-    const double* src = lp + (size_t)i0 * HP_NCH;
-    const int nel = min(CP_F, nsub - i0) * HP_NCH;
-    for (int e = threadIdx.x; e < CP_F * HP_NCH; e += CP_F) tile[e >> 5][e & 31] = (e < nel) ? src[e] : 0.0;
+__device__ __forceinline__ void hp_stage_lp(const HaspiWs& ws, int b, const double* __restrict__ lp, int i0, int nsub, double (*tile)[HP_NCH + 1]) {
+    const int nfr = min(CP_F, nsub - i0);
+    const int di = hp_lp_di(ws, b, threadIdx.x & 31);      // (CP_F is a multiple of 32: a thread keeps its channel)
+    for (int e = threadIdx.x; e < CP_F * HP_NCH; e += CP_F) tile[e >> 5][e & 31] = ((e >> 5) < nfr) ? hp_lp_at(lp, i0 + (e >> 5), e & 31, di) : 0.0;
 }
 __global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
     __shared__ double tile[CP_F][HP_NCH + 1];
@@ -1295,11 +1310,11 @@ __global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
     const int nsub = hp_nsub(ws, b);
     int k = 0;
     if (i0 < nsub) {
-        hp_stage_lp(ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH, i0, nsub, tile);
+        hp_stage_lp(ws, b, ws.lp + ((size_t)b * 2) * ws.nlp * HP_NCH, i0, nsub, tile);
         __syncthreads();
         if (i < nsub) {                                    // 20 log10(mean_k 10^(x/20)) > 2.5
             double s = 0.0;
-            for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, tile[tid][c] / 20.0);
+            for (int c = 0; c < HP_NCH; ++c) s += exp10(tile[tid][c] / 20.0);      // (10^x: half the instructions of the general pow)
             k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
         }
     }
@@ -1339,7 +1354,7 @@ __global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const d
         nn = sqrt(nn);
         for (int k = 0; k < HP_NCH; ++k) cepm[k][tid] = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)) / nn;
     }
-    hp_stage_lp(ws.lp + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH, i0, nsub, tile);
+    hp_stage_lp(ws, b, ws.lp + (((size_t)b * 2 + sig) * ws.nlp) * HP_NCH, i0, nsub, tile);
     __syncthreads();
     const int rank = (i < ws.nsub) ? ws.grank[(size_t)b * ws.nsub + i] : -1;
     const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
@@ -1383,14 +1398,20 @@ __global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
 // parallel kernels above, and 4.8 ms inside a step - but see the note at its launch site.
 // gate != 0: silence gate on the REFERENCE envelope + ordered compaction of the active frames (needs x only);
 // then the cepstral sequences of signals sig0 .. sig0+nsig-1 over those frames.
+// Frames walk through LDS in tiles of 256 frames x 16 channels (two halves per tile): in the group-space layout of lp a frame's channels
+// sit in up to ~40 different rows, and a thread that walked "its" frame through global memory alone touched a new cache line on nearly
+// every channel (1.1 ms per call at B = 256 against 0.84 in frame-space rows; staged: the 16 lanes of a frame read neighbouring rows).
 __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int gate, int sig0,
                                                         int nsig) {
     __shared__ double cepm[HP_NCH][HP_NBASIS];
+    __shared__ double tile[256][17];
     __shared__ int scan[256];
     __shared__ int base;
+    __shared__ int dis[HP_NCH];
     __shared__ double red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nsub = hp_nsub(ws, b);
+    if (tid >= 64 && tid < 64 + HP_NCH) dis[tid - 64] = hp_lp_di(ws, b, tid - 64);
     if (tid < HP_NBASIS) {
         double nn = 0.0;
         for (int k = 0; k < HP_NCH; ++k) { const double v = cos((double)tid * M_PI * (double)k / (double)(HP_NCH - 1)); nn += v * v; }
@@ -1399,32 +1420,51 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
     }
     if (tid == 0) base = 0;
     __syncthreads();
-    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nsub * HP_NCH;
-    const double* ylp = xlp + (size_t)ws.nsub * HP_NCH;
-    int* act = ws.act + (size_t)b * ws.nsub;
+    const double* xlp = ws.lp + ((size_t)b * 2) * ws.nlp * HP_NCH;
+    const double* ylp = xlp + (size_t)ws.nlp * HP_NCH;
+    int* act = ws.act + (size_t)b * ws.nsub;             // compacted position of frame i among the active frames, or -1
+    // Half-tiles: channels 16 h .. 16 h + 15 of frames i0 .. i0 + 255, numbered t = 2 (i0 / 256) + h.  A thread fetches 16 elements of a
+    // half-tile (all loads in flight together) into registers while the block works on the previous one.
+    const int cth = tid & 15, fth = tid >> 4;                    // element j of a thread: frame fth + 16 j, channel cth of the half
+    double pf[16];
+    auto fetch = [&](const double* lpb, int t) {
+        const int i0 = (t >> 1) * 256, c = 16 * (t & 1) + cth, d = dis[c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pf[j] = (i0 + fth + 16 * j < nsub) ? hp_lp_at(lpb, i0 + fth + 16 * j, c, d) : 0.0;
+    };
+    auto put = [&]() {                                          // registers -> tile (barriers on both sides)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[fth + 16 * j][cth] = pf[j];
+        __syncthreads();
+    };
+    const int ntile2 = 2 * ((nsub + 255) / 256);
     int na;
     if (gate) {
         // silence gate on the reference: 20 log10(mean_k 10^(x/20)) > 2.5
-        for (int i0 = 0; i0 < nsub; i0 += 256) {
-            const int i = i0 + tid;
-            int k = 0;
-            if (i < nsub) {
-                double s = 0.0;
-                for (int c = 0; c < HP_NCH; ++c) s += pow(10.0, xlp[(size_t)i * HP_NCH + c] / 20.0);
-                k = (20.0 * log10(s / (double)HP_NCH) > 2.5) ? 1 : 0;
-            }
-            scan[tid] = k;
-            __syncthreads();
-            for (int o = 1; o < 256; o <<= 1) {
-                const int v = (tid >= o) ? scan[tid - o] : 0;
+        fetch(xlp, 0);
+        double sm = 0.0;
+        for (int t = 0; t < ntile2; ++t) {
+            const int i = (t >> 1) * 256 + tid;
+            put();
+            if (t + 1 < ntile2) fetch(xlp, t + 1);
+            if (i < nsub) for (int c = 0; c < 16; ++c) sm += exp10(tile[tid][c] / 20.0);     // (10^x: half the instructions of the general pow)
+            if (t & 1) {
+                const int k = (i < nsub && 20.0 * log10(sm / (double)HP_NCH) > 2.5) ? 1 : 0;
+                sm = 0.0;
+                scan[tid] = k;
                 __syncthreads();
-                scan[tid] += v;
+                for (int o = 1; o < 256; o <<= 1) {
+                    const int v = (tid >= o) ? scan[tid - o] : 0;
+                    __syncthreads();
+                    scan[tid] += v;
+                    __syncthreads();
+                }
+                if (i < nsub) act[i] = k ? base + scan[tid] - 1 : -1;
+                __syncthreads();
+                if (tid == 255) base += scan[255];
                 __syncthreads();
             }
-            if (k) act[base + scan[tid] - 1] = i;
-            __syncthreads();
-            if (tid == 255) base += scan[255];
-            __syncthreads();
         }
         na = base;
         if (tid == 0) { ws.info[2 * b] = na; ws.info[2 * b + 1] = (na <= 1) ? 1 : 0; }
@@ -1438,20 +1478,33 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
         const double* dz = dither ? dither + (((size_t)b * 2 + sig) * ws.nsub) * HP_NCH : nullptr;
         double* cep = ws.cep + (((size_t)b * 2 + sig) * HP_NBASIS) * ws.nsub;
         double sums[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
-        for (int k = tid; k < na; k += 256) {
-            const int i = act[k];
-            double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
-            for (int c = 0; c < HP_NCH; ++c) {
-                double v = lp[(size_t)i * HP_NCH + c];
-                if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + c];
+        double c6[HP_NBASIS] = {0, 0, 0, 0, 0, 0};
+        fetch(lp, 0);
+        for (int t = 0; t < ntile2; ++t) {
+            const int i = (t >> 1) * 256 + tid, h = t & 1;
+            const int k = (i < nsub) ? act[i] : -1;
+            put();
+            if (t + 1 < ntile2) fetch(lp, t + 1);
+            if (k >= 0) {
+                for (int c = 0; c < 16; ++c) {
+                    double v = tile[tid][c];
+                    if (dz) v += thr_nerve * dz[(size_t)k * HP_NCH + 16 * h + c];
 #pragma unroll
-                for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[c][q];
+                    for (int q = 0; q < HP_NBASIS; ++q) c6[q] += v * cepm[16 * h + c][q];
+                }
             }
+            if (h) {
+                if (k >= 0) {
 #pragma unroll
-            for (int q = 0; q < HP_NBASIS; ++q) { cep[(size_t)q * ws.nsub + k] = c6[q]; sums[q] += c6[q]; }
+                    for (int q = 0; q < HP_NBASIS; ++q) { cep[(size_t)q * ws.nsub + k] = c6[q]; sums[q] += c6[q]; }
+                }
+#pragma unroll
+                for (int q = 0; q < HP_NBASIS; ++q) c6[q] = 0.0;
+            }
         }
         for (int q = 0; q < HP_NBASIS; ++q) {
             const double mu = block_sum(sums[q], red) / (double)na;
+            __syncthreads();
             for (int k = tid; k < na; k += 256) cep[(size_t)q * ws.nsub + k] -= mu;
             if (tid == 0) ws.cmean[((size_t)b * 2 + sig) * HP_NBASIS + q] = 0.0;    // already removed (the consumers subtract cmean)
             __syncthreads();
@@ -1706,7 +1759,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(benv, double, 64);
     TAKE(bkt, double, 10 * 616);
     TAKE(shift, int, (size_t)B * HP_NCH);
-    TAKE(lp, double, (size_t)B * 2 * nsub * HP_NCH);
+    TAKE(lp, double, (size_t)B * 2 * (nsub + 4) * HP_NCH);
     const int ngb = (nsub + CP_F - 1) / CP_F;
     TAKE(act, int, (size_t)B * nsub);
     TAKE(grank, int, (size_t)B * nsub);
@@ -1720,7 +1773,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(cpart, double, (size_t)B * MS_MAXC * 64 * 5);
 #undef TAKE
     if (w) { w->n24 = n24; w->nsub = nsub; w->n24p = n24p; w->fs_in = fs_in; w->lens = nullptr; w->nchunk = nchunk; w->lc = lc; w->ngb = ngb;
-             w->cphi = nullptr; w->sse = nullptr; w->lcg = GL_N; w->fmul = 1; }
+             w->cphi = nullptr; w->sse = nullptr; w->lcg = GL_N; w->fmul = 1; w->nlp = nsub + 4; w->lp_raw = 0; }
     return o;
 }
 
@@ -1731,20 +1784,32 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
     return (n24 + HP_SPACE - 1) / HP_SPACE;
 }
 
+// A/B switches of the chain, read once
+struct HaspiFlags { int bank_gain, par_iir, fused_gain, fir9; };
+static const HaspiFlags& haspi_flags() {
+    static HaspiFlags f = [] {
+        auto on = [](const char* name) { const char* e_ = getenv(name); return (int)!(e_ && e_[0] == '0'); };
+        HaspiFlags v;
+        v.bank_gain = on("NELE_HASPI_BANK_GAIN");          // =0: the gain pass as its own kernel
+        v.par_iir = on("NELE_HASPI_PAR_IIR");              // =0: the serial recurrence kernels
+        v.fused_gain = on("NELE_HASPI_FUSED_GAIN");
+        v.fir9 = on("NELE_HASPI_FIR9");                    // =0: the 8-sample-group IHC + envelope-filter kernel with per-sample phase counters
+        return v;
+    }();
+    return f;
+}
+// lp in group-space rows (HaspiWs::lp_raw): whenever haspi_ihc_fir9_kernel produces it
+static int haspi_lp_raw() { const HaspiFlags& f = haspi_flags(); return f.par_iir && f.fused_gain && f.fir9; }
+
 // The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
 static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws_in, int sig0, int nsig, hipStream_t s,
                         bool quality = false) {
     const int rows = B * nsig;
-    static int bank_gain = -1;                             // NELE_HASPI_BANK_GAIN=0: the gain pass as its own kernel (A/B diagnostic)
-    if (bank_gain < 0) { const char* e_ = getenv("NELE_HASPI_BANK_GAIN"); bank_gain = !(e_ && e_[0] == '0'); }
     HaspiWs ws = ws_in;
-    static int par_iir = -1;                               // NELE_HASPI_PAR_IIR=0: the serial recurrence kernels (A/B diagnostic)
-    if (par_iir < 0) { const char* e_ = getenv("NELE_HASPI_PAR_IIR"); par_iir = !(e_ && e_[0] == '0'); }
-    static int fused_gain = -1;
-    if (fused_gain < 0) { const char* e_ = getenv("NELE_HASPI_FUSED_GAIN"); fused_gain = !(e_ && e_[0] == '0'); }
-    const int par_iir_saved = par_iir, fused_gain_saved = fused_gain;
+    const HaspiFlags& fl = haspi_flags();
+    const int bank_gain = fl.bank_gain;
+    int par_iir = fl.par_iir, fused_gain = fl.fused_gain;
     if (quality) par_iir = fused_gain = 1;                     // the quality path exists for the scan kernels only
-    struct Restore { int& a; int& b; int va, vb; ~Restore() { a = va; b = vb; } } restore_{par_iir, fused_gain, par_iir_saved, fused_gain_saved};
     const bool in_bank = bank_gain && par_iir && fused_gain && !quality;     // gain pass inside pass 2 of the signal bank
     ws.lcg = in_bank ? ws.lc : GL_N;
     ws.fmul = 1;
@@ -1784,10 +1849,8 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
                       hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig));
         hipLaunchKernelGGL(haspi_ihc_prefix_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         if (quality) return;                                   // haspi_quality.h goes on from the dB-SL envelope + IHC start states
-        static int fir9 = -1;                                  // NELE_HASPI_FIR9=0: the 8-sample-group kernel with per-sample phase counters (A/B diagnostic)
-        if (fir9 < 0) { const char* e_ = getenv("NELE_HASPI_FIR9"); fir9 = !(e_ && e_[0] == '0'); }
         const dim3 fgrid((ws.n24p + 4 * ws.lcg * ws.fmul - 1) / (4 * ws.lcg * ws.fmul), rows);
-        if (fir9) hipLaunchKernelGGL(haspi_ihc_fir9_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
+        if (ws.lp_raw) hipLaunchKernelGGL(haspi_ihc_fir9_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
         else hipLaunchKernelGGL(haspi_ihc_fir_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
         return;                                                // the envelope filter is part of it
     } else {                                                   // the serial passes of the first version (A/B switch)
@@ -1854,6 +1917,7 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
     HaspiWs ws;
     haspi_layout(B, L, fs_in, &ws, (char*)workspace);
     ws.lens = lengths;
+    ws.lp_raw = haspi_lp_raw();
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(haspi_loss_kernel, dim3(1), dim3(64), 0, s, ws, hl);
     // Cepstrum stage: one block per utterance (default) or the frame-parallel kernels (NELE_HASPI_CEP_SERIAL=0).  Alone on the GPU the
