@@ -1617,15 +1617,17 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
 //     S_m[tau] = sum_{i=0}^{L-1} e^{j m phi i} z[tau - i]      (m = 0, +1, -1; phi = 2 pi / L)
 //     S_m[tau] = e^{j m phi} S_m[tau - 1] + z[tau] - z[tau - L]            (e^{j m phi L} = 1)
 //     u[t]     = (2 / L) (0.5 S_0 - 0.25 S_+1 - 0.25 S_-1)[t + nh]
-// i.e. ~40 float64 operations per output instead of 2 (nfir + 1) multiply-adds (nfir up to 614): the direct form above was 14 ms of
-// every B = 256 step.  The rotations have modulus one, so rounding accumulates linearly: < 1e-12 relative over a chunk (A/B-tested
+// i.e. a few dozen float64 operations per output instead of 2 (nfir + 1) multiply-adds (nfir up to 614): the direct form above was 14 ms
+// of every B = 256 step.  (The kernel runs the sums in the demodulator's rotating frame, see the constants below.)  The rotations have modulus one, so rounding accumulates linearly: < 1e-12 relative over a chunk (A/B-tested
 // against the direct kernel, NELE_HASPI_MOD_DIRECT=1).  One wave per (utterance, chunk of MS_TC outputs): lane = basis * 10 + band
 // (50 of 64 lanes), every chunk warms its sums up over the L samples before it (recurrence without the subtraction).  A lane owns
 // one (basis, band) pair, so the correlation sums of ebm_ModCorr stay in its registers; chunk partials are combined in chunk order.
 // SIG = 0 stores the filtered reference sequence xf [b][t][64]; SIG = 1 filters the processed signal and correlates it with xf.
 #define MS_TC 1024
+#define MS_R 640
 template <int SIG>
 __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
+    __shared__ double ring[HP_NBASIS - 1][MS_R + 8];
     const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
     const int na = ws.info[2 * b];
     if (ws.info[2 * b + 1]) return;
@@ -1636,58 +1638,110 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
     const int L = c_modnfir[k], nh = L / 2;
     const double theta = (k > 0) ? M_PI * c_modcf[k] / 1280.0 : 0.0;     // pi cf / fNyq
     const double phi = 2.0 * M_PI / (double)L;
-    const double rc = cos(phi), rs = sin(phi);                           // e^{+j phi}; S_-1 uses the conjugate
-    const double ec = cos(theta), es = -sin(theta);                       // e^{-j theta}: demodulator step
+    // In the frame that rotates with the demodulator, T_m = conj(E) S_m (E = e^{-j theta (tau + 1)} the demodulator phase, |E| = 1), the
+    // three sliding sums of the header become recurrences with CONSTANT complex factors and a real-valued drive,
+    //     T_m[tau] = e^{j (theta + m phi)} T_m[tau - 1] + v[tau] - e^{j theta L} v[tau - L],
+    //     f[t]     = scale Re( e^{-j theta nh} (0.5 T_0 - 0.25 T_+1 - 0.25 T_-1)[t + nh] ):
+    // no demodulator / remodulator phases to carry along (20 float64 operations per step instead of 45).
+    const double rc0 = cos(theta), rs0 = sin(theta);
+    const double rcp = cos(theta + phi), rsp = sin(theta + phi), rcm = cos(theta - phi), rsm = sin(theta - phi);
     const double k1c = cos(theta * (double)L), k1s = sin(theta * (double)L);     // e^{+j theta L}: phase of the sample leaving the window
-    const double k2c = cos(theta * (double)nh), k2s = -sin(theta * (double)nh);  // e^{-j theta nh}: output phase = conj(E) K2
+    const double k2c = cos(theta * (double)nh), k2s = -sin(theta * (double)nh);  // e^{-j theta nh}
     const double scale = ((k > 0) ? 2.0 : 1.0) * (2.0 / (double)L);      // sqrt(2) of the demodulator and of the remodulator
+    const double A0 = scale * 0.5 * k2c, B0 = -scale * 0.5 * k2s, A1 = -scale * 0.25 * k2c, B1 = scale * 0.25 * k2s;
     const double* v = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + basis) * ws.nsub;
     const double vmu = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + basis];          // the sequence's mean (ebm_CepCoef removes it)
     double* xf = ws.xf + ((size_t)b * ws.nsub) * 64 + lane;
     // common output index tt = t0 - LMAX + step; this lane's newest input is tau = tt + nh
     constexpr int LMAX = HP_MAXFIR;
-    double Er, Ei;                                                        // E = e^{-j theta (tau + 1)} at tau = t0 - LMAX + nh - 1 (one step before the loop)
-    {
-        const double a0 = theta * (double)(t0 - LMAX + nh);
-        Er = cos(a0); Ei = -sin(a0);
-    }
     double s0r = 0, s0i = 0, spr = 0, spi = 0, smr = 0, smi = 0;
     double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-    // steps in groups of MS_U: the group's loads (two sequence elements and, for SIG = 1, the stored reference output per step) are
-    // issued together ahead of the dependent recurrences - one memory latency per group instead of one per step
-    constexpr int MS_U = 8;
+    // The five cepstral sequences of the utterance pass through a ring in LDS.  At step tt a lane reads its sequence at tt + nh (entering
+    // the window) and tt + nh - L (leaving it): 80 different streams per wave, and straight from memory every load instruction touched
+    // ~50 cache lines (PMC: 434 M L1 look-ups, 36 % of them misses, 4.7 GB fetched per launch for 0.26 GB of sequences - the kernel ran
+    // at the speed of the L1 / L2 path, 1.8 ms for 0.5 ms of instructions).  The ring holds the common window [tt - 307, tt + 307 + 8]:
+    // MS_R = 640 elements per sequence (+ 8 mirrored at the end, so that a group's 8 consecutive reads need no wrap), filled by 40 lanes
+    // with ONE coalesced load per group of 8 steps, fetched a group ahead; the mean is removed on the way in.
+    constexpr int MS_U = 8, NHM = LMAX / 2;
+    const int base0 = t0 - LMAX - NHM;                                   // sequence index at ring position 0
+    const int sl = lane >> 3, jl = lane & 7;                             // filler lanes: sequence (basis - 1), element of the group
+    const double* vfill = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + 1 + min(sl, HP_NBASIS - 2)) * ws.nsub;
+    const double mufill = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + 1 + min(sl, HP_NBASIS - 2)];
+    {                                                                    // initial fill: offsets 0 .. 2 NHM + MS_U - 1 (the window of the first group)
+        for (int o = lane; o < (HP_NBASIS - 1) * (2 * NHM + MS_U); o += 64) {
+            const int q = o / (2 * NHM + MS_U), off = o - q * (2 * NHM + MS_U);
+            const double* vq = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + 1 + q) * ws.nsub;
+            const double val = vq[min(max(base0 + off, 0), na - 1)] - ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + 1 + q];
+            ring[q][off] = val;
+            if (off < MS_U) ring[q][MS_R + off] = val;
+        }
+    }
+    int fo = 2 * NHM + MS_U;                                             // ring offset (not yet wrapped) of the next group to fill
+    // the elements of the next three groups are in flight / in registers (a lone wave per SIMD has nothing else to cover a memory latency)
+    auto fetch = [&](int ahead) { return (sl < HP_NBASIS - 1) ? vfill[min(max(base0 + fo + MS_U * ahead + jl, 0), na - 1)] - mufill : 0.0; };
+    double fv0 = fetch(0), fv1 = fetch(1), fv2 = fetch(2);
+    double xnx[MS_U];                                                    // SIG = 1: the next group's stored reference outputs
+    if (SIG == 1) {
+#pragma unroll
+        for (int u = 0; u < MS_U; ++u) xnx[u] = xf[(size_t)min(max(t0 - LMAX + u, 0), na - 1) * 64];
+    }
+    // ring positions of this lane's two reads at the first step: (tau - base0) mod MS_R, (tau - L - base0) mod MS_R
+    int pn = (NHM + nh) % MS_R, po = (NHM + nh - L + MS_R) % MS_R;
+    const double* rq = &ring[basis - 1][0];
+    __syncthreads();
     for (int tb = t0 - LMAX; tb < t1; tb += MS_U) {
         double vnv[MS_U], vov[MS_U], xvv[MS_U];
 #pragma unroll
         for (int u = 0; u < MS_U; ++u) {
-            const int tt = tb + u, tau = tt + nh, to = tau - L;
-            vnv[u] = v[min(max(tau, 0), na - 1)] - vmu;
-            vov[u] = v[min(max(to, 0), na - 1)] - vmu;
-            if (SIG == 1) xvv[u] = xf[(size_t)min(max(tt, 0), na - 1) * 64];
+            vnv[u] = rq[pn + u];
+            vov[u] = rq[po + u];
+            if (SIG == 1) xvv[u] = xnx[u];
         }
+        if (SIG == 1) {
 #pragma unroll
-        for (int u = 0; u < MS_U; ++u) {
-            const int tt = tb + u, tau = tt + nh, to = tau - L;
-            { const double nr = Er * ec - Ei * es; Ei = Er * es + Ei * ec; Er = nr; }   // E <- E e^{-j theta}
-            const bool live = tt >= t0 && tt < t1;
-            // before this lane's warm-up window (tt < t0 - L) nothing enters the sums; during it (tt < t0) nothing leaves them
-            const double vn = (tt >= t0 - L && tau >= 0 && tau < na) ? vnv[u] : 0.0;
-            const double vo = (tt >= t0 && to >= 0 && to < na) ? vov[u] : 0.0;
-            const double eor = Er * k1c - Ei * k1s, eoi = Er * k1s + Ei * k1c;         // phase of z[tau - L]
-            const double dr = vn * Er - vo * eor, di = vn * Ei - vo * eoi;             // z[tau] - z[tau - L]
-            s0r += dr; s0i += di;
-            { const double nr = (rc * spr - rs * spi) + dr; spi = (rc * spi + rs * spr) + di; spr = nr; }
-            { const double nr = (rc * smr + rs * smi) + dr; smi = (rc * smi - rs * smr) + di; smr = nr; }
-            const double ur = 0.5 * s0r - 0.25 * (spr + smr), ui = 0.5 * s0i - 0.25 * (spi + smi);
-            const double oc = Er * k2c + Ei * k2s, os = Er * k2s - Ei * k2c;            // conj(E) K2 = e^{+j theta (t + 1)}
-            const double f = scale * (ur * oc - ui * os);
-            if (SIG == 0) {
-                if (live) xf[(size_t)tt * 64] = f;
-            } else if (live) {
-                const double xv = xvv[u];
-                sx += xv; sy += f; sxx += xv * xv; syy += f * f; sxy += xv * f;
-            }
+            for (int u = 0; u < MS_U; ++u) xnx[u] = xf[(size_t)min(max(tb + MS_U + u, 0), na - 1) * 64];
         }
+        pn = pn + MS_U >= MS_R ? pn + MS_U - MS_R : pn + MS_U;
+        po = po + MS_U >= MS_R ? po + MS_U - MS_R : po + MS_U;
+        // Three copies of the group's body: WARM (all 8 steps before t0: nothing leaves the sums, no output), MAIN (all 8 steps inside
+        // the chunk and both window ends inside the sequence for every lane: no tests at all) and the general one - the per-step
+        // validity tests were half of the loop's instructions.
+        auto body = [&](auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;                  // 0 WARM, 1 MAIN, 2 general
+#pragma unroll
+            for (int u = 0; u < MS_U; ++u) {
+                const int tt = tb + u, tau = tt + nh, to = tau - L;
+                // before this lane's warm-up window (tt < t0 - L) nothing enters the sums; during it (tt < t0) nothing leaves them
+                const double vn = (KIND == 1 || (tt >= t0 - L && tau >= 0 && tau < na)) ? vnv[u] : 0.0;
+                const double vo = (KIND == 1) ? vov[u] : (KIND == 0) ? 0.0 : (tt >= t0 && to >= 0 && to < na) ? vov[u] : 0.0;
+                const double wr = fma(-vo, k1c, vn), wi = -vo * k1s;                     // v[tau] - e^{j theta L} v[tau - L]
+                { const double nr = fma(rc0, s0r, fma(-rs0, s0i, wr)); s0i = fma(rc0, s0i, fma(rs0, s0r, wi)); s0r = nr; }
+                { const double nr = fma(rcp, spr, fma(-rsp, spi, wr)); spi = fma(rcp, spi, fma(rsp, spr, wi)); spr = nr; }
+                { const double nr = fma(rcm, smr, fma(-rsm, smi, wr)); smi = fma(rcm, smi, fma(rsm, smr, wi)); smr = nr; }
+                if (KIND == 0) continue;
+                const bool live = KIND == 1 || (tt >= t0 && tt < t1);
+                const double f = fma(A0, s0r, fma(B0, s0i, fma(A1, spr + smr, B1 * (spi + smi))));
+                if (SIG == 0) {
+                    if (live) xf[(size_t)tt * 64] = f;
+                } else if (live) {
+                    const double xv = xvv[u];
+                    sx += xv; sy += f; sxx += xv * xv; syy += f * f; sxy += xv * f;
+                }
+            }
+        };
+        if (tb + MS_U <= t0) body(std::integral_constant<int, 0>{});
+        else if (tb >= t0 && tb + MS_U <= t1 && tb - NHM >= 0 && tb + MS_U + NHM <= na) body(std::integral_constant<int, 1>{});
+        else body(std::integral_constant<int, 2>{});
+        // the next group's 8 new elements per sequence replace the 8 oldest (no lane reads them any more)
+        __syncthreads();
+        if (sl < HP_NBASIS - 1) {
+            const int pos = (fo + jl) % MS_R;
+            ring[sl][pos] = fv0;
+            if (pos < MS_U) ring[sl][MS_R + pos] = fv0;
+        }
+        fo += MS_U;
+        fv0 = fv1; fv1 = fv2; fv2 = fetch(2);
+        __syncthreads();
     }
     if (SIG == 1 && act) {
         double* cp = ws.cpart + (((size_t)b * MS_MAXC + chunk) * 64 + lane) * 5;
