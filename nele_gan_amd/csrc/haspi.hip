@@ -171,17 +171,22 @@ __global__ __launch_bounds__(256) void haspi_rms_kernel(const float* __restrict_
     if (tid == 0) { ri[0] = rms; ri[1] = sqrtf((float)(xs / (double)L)); }
 }
 
-// resampy resample_f (ratio 1.5: scale = 1, index_step = num_table).  For this ratio the fractional position takes three
-// values, so the interpolated-window taps start at table offsets 0, 170, 341 (left wing) and 512, 341, 170 (right wing):
-// those four tap columns (value and forward difference) are staged in LDS, the normalised input of the chunk is staged in LDS, and
-// the per-tap work is two LDS reads and the reference's float32-rounded accumulate.  Same arithmetic as indexing the 32769-entry
-// window in memory (offsets outside the four columns fall back to it).  grid (chunks, nsig, B), block 256.
+// resampy resample_f (ratio 1.5: scale = 1, index_step = num_table).  For this ratio the fractional position of an output takes three
+// values (t mod 3), so there are only 3 x 2 tap columns: interpolated window values w[phase][wing][i] = win[offset + 512 i] + eta delta[...],
+// built once per workgroup in LDS; the normalised input of the chunk is staged in LDS as float64, and a tap is two LDS reads and the
+// reference's float32-rounded accumulate y[t] += w * x (resampy keeps y in the input's dtype: every tap rounds to float32 - kept, it is
+// the reference's arithmetic; the accumulation order is the reference's too: left wing, then right wing).
+// The tap columns use eta of the exact phases 0, 1/3, 2/3; the reference's eta = frac(t / 1.5) * 512 - offset carries the rounding of
+// t / 1.5 (1e-11 at t = 1e5), i.e. a tap weight may differ by 1e-14 relative: one float32 rounding of one output in ~1e3 falls the other
+// way (6e-8 relative on that sample).  Outputs whose taps leave the staged input (none for 16 kHz inputs of any length) and offsets
+// outside the three phases fall back to indexing the 32769-entry window in memory.  grid (chunks, nsig, B), block 256.
 __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, HaspiWs ws,
                                                              int sig0) {
     __shared__ double red[8];
     constexpr int RS_IN = RS_CH * 2 / 3 + 2 * 66 + 4;
-    __shared__ double wv[4][66], wd[4][66];
-    __shared__ float xsn[RS_IN];
+    __shared__ double wt[3][2][66];
+    __shared__ int woff[3][2];
+    __shared__ double xsn[RS_IN];
     const int b = blockIdx.z, sig = sig0 + blockIdx.y, tid = threadIdx.x, row = 2 * b + sig;
     const int L = hp_len(ws, b, Lmax), n24 = hp_n24(ws, b);
     const int t0 = blockIdx.x * RS_CH;
@@ -189,23 +194,30 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     const float* src = (sig ? y : x) + (size_t)b * Lmax;
     float* dst = ws.r24 + (size_t)row * ws.n24p;
     const float rms = ws.rinfo[(size_t)row * 4];
-    for (int e = tid; e < 4 * 66; e += 256) {
-        const int slot = e / 66, i = e - slot * 66;
-        const int off = (slot == 0) ? 0 : (slot == 1) ? 170 : (slot == 2) ? 341 : 512;
-        const int idx = off + i * HP_NTAB;
-        double v = 0.0, d = 0.0;
-        if (idx < HP_NWIN) {
-            v = ws.win[idx];
-            d = (idx + 1 < HP_NWIN) ? ws.win[idx + 1] - v : 0.0;
-        }
-        wv[slot][i] = v; wd[slot][i] = d;
-    }
     const double time_increment = 1.0 / 1.5;
+    for (int e = tid; e < 3 * 2 * 66; e += 256) {
+        const int ph = e / 132, wing = (e - ph * 132) / 66, i = e - ph * 132 - wing * 66;
+        const double tr = (double)ph * time_increment;
+        double frac = tr - (double)(int)tr;
+        if (wing) frac = 1.0 - frac;
+        const double index_frac = frac * HP_NTAB;
+        const int offset = (int)index_frac;
+        const double eta = index_frac - offset;
+        const int idx = offset + i * HP_NTAB;
+        double w = 0.0;
+        if (idx < HP_NWIN) {
+            const double v = ws.win[idx];
+            w = v + eta * ((idx + 1 < HP_NWIN) ? ws.win[idx + 1] - v : 0.0);
+        }
+        wt[ph][wing][i] = w;
+        if (i == 0) woff[ph][wing] = offset;
+    }
     double a2 = 0.0;
     const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
-    for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? src[nbase + e] / rms : 0.f;
+    for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? (double)(src[nbase + e] / rms) : 0.0;
     __syncthreads();
     for (int t = t0 + tid; t < min(n24, t0 + RS_CH); t += 256) {
+        const int ph = t % 3;
         const double time_register = (double)t * time_increment;
         const int n = (int)time_register;
         double frac = time_register - (double)n;
@@ -215,12 +227,11 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
         int i_max = (HP_NWIN - offset) / HP_NTAB;
         if (n + 1 < i_max) i_max = n + 1;
         float yv = 0.f;
-        int slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
-        if (slot >= 0 && n - (i_max - 1) >= nbase) {
-            for (int i = 0; i < i_max; ++i) {
-                const double w = wv[slot][i] + eta * wd[slot][i];
-                yv = (float)((double)yv + w * (double)xsn[n - i - nbase]);
-            }
+        if (offset == woff[ph][0] && n - (i_max - 1) >= nbase) {
+            const double* wl = wt[ph][0];
+            const double* xl = xsn + (n - nbase);
+#pragma unroll 4
+            for (int i = 0; i < i_max; ++i) yv = (float)fma(wl[i], xl[-i], (double)yv);
         } else {
             for (int i = 0; i < i_max; ++i) {
                 const int idx = offset + i * HP_NTAB;
@@ -235,12 +246,11 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
         eta = index_frac - offset;
         int k_max = (HP_NWIN - offset) / HP_NTAB;
         if (L - n - 1 < k_max) k_max = L - n - 1;
-        slot = (offset == 0) ? 0 : (offset == 170) ? 1 : (offset == 341) ? 2 : (offset == 512) ? 3 : -1;
-        if (slot >= 0 && n + k_max - nbase < RS_IN) {
-            for (int k = 0; k < k_max; ++k) {
-                const double w = wv[slot][k] + eta * wd[slot][k];
-                yv = (float)((double)yv + w * (double)xsn[n + k + 1 - nbase]);
-            }
+        if (offset == woff[ph][1] && n + k_max - nbase < RS_IN) {
+            const double* wr = wt[ph][1];
+            const double* xr = xsn + (n + 1 - nbase);
+#pragma unroll 4
+            for (int k = 0; k < k_max; ++k) yv = (float)fma(wr[k], xr[k], (double)yv);
         } else {
             for (int k = 0; k < k_max; ++k) {
                 const int idx = offset + k * HP_NTAB;
