@@ -31,6 +31,17 @@
 #define C16_SB 4         // k-steps (of 32) per weight chunk
 #endif
 
+// -DC16_PROF: per-phase clock sums of thread 0 of every workgroup (s_memtime), read back by nele_conv16_prof_read - a diagnostic build only
+// (tools/variants.sh conv16 prof:"-DC16_PROF"; tools/conv16_check.py prints the table when the library exports the reader).
+#ifdef C16_PROF
+__device__ unsigned long long c16_prof[8];       // 0 total, 1 prologue (to the first barrier), 2 DMA wait at chunk ends, 3 barrier at chunk ends, 4 epilogue, 5 workgroups
+#define C16_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define C16_ACC(slot, t0_, t1_) do { c16_acc[slot] += (t1_) - (t0_); } while (0)
+#else
+#define C16_T(var) do {} while (0)
+#define C16_ACC(slot, t0_, t1_) do {} while (0)
+#endif
+
 struct Conv16Args {
     const __bf16* A;
     const __bf16* Wfrag;    // [KH * sps][TN][64 lanes][8]: lane (m = lane & 15, g = lane >> 4) holds W[channel 4 TN (m >> 2) + 4 j + (m & 3)][32 u + 8 g ..]
@@ -53,6 +64,10 @@ __device__ __forceinline__ void c16_dma(const __bf16* gsrc_lane, __bf16* lds_pie
 
 template <int TN, int TH, bool OUT16>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
+    C16_T(t_start);
+#ifdef C16_PROF
+    unsigned long long c16_acc[5] = {0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) __bf16 lds16[];    // ring [NR][RSP] + 64 slack, then the weight ring [2][SB][TN][64][8]
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -139,8 +154,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             for (int j = 0; j < TN; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();
+        C16_T(t_pro);
+        C16_ACC(1, t_start, t_pro);
 
-        int lu = 0, lr = 0;                            // step within its kernel row / ring slot of that kernel row's first input row, of the NEXT step to load
+        // Of the NEXT step to load: lu = step within its kernel row; per position tile the ring slot rr[k] of its input row and the
+        // (wave-uniform) element offset so[k] of that slot + the tile's columns - advanced once per kernel row behind a real scalar
+        // branch (recomputed per step, or as per-step selects, this scalar arithmetic was 2.3 instructions per MFMA)
+        int lu = 0, rr[NP], so[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { rr[k] = prow[k]; so[k] = prow[k] * RSP + 16 * pcol[k] * C; }
         const __bf16* wl = wring + lane * 8;
         auto ldfrag = [&](int uu, bf16x8 (&af)[NP], bf16x8 (&bfr)[TN]) {
             const int kk8 = lu * 32 + 8 * lg;
@@ -148,12 +170,16 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(wl + (uu * TN + j) * 512);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                int rr = lr + prow[k];
-                if (rr >= NR) rr -= NR;
-                af[k] = *reinterpret_cast<const bf16x8*>(lds16 + (rr * RSP + 16 * pcol[k] * C) + vk);
+            for (int k = 0; k < NP; ++k) af[k] = *reinterpret_cast<const bf16x8*>(lds16 + so[k] + vk);
+            if (__builtin_expect(++lu == p.sps, 0)) {
+                asm volatile("" ::: "memory");             // (keeps the compiler from turning the branch into selects)
+                lu = 0;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    so[k] += RSP;
+                    if (++rr[k] == NR) { rr[k] = 0; so[k] -= NR * RSP; }
+                }
             }
-            if (++lu == p.sps) { lu = 0; if (++lr == NR) lr = 0; }
         };
         auto mm = [&](const bf16x8 (&af)[NP], const bf16x8 (&bfr)[TN]) {
 #pragma unroll
@@ -175,13 +201,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);                                                   \
     __builtin_amdgcn_sched_barrier(0)
         const int nfull = p.nsteps / C16_SB, nrem = p.nsteps - nfull * C16_SB;
+        int nl_row = (2 * C16_SB - 1) / p.sps, nl_rem = (2 * C16_SB - 1) - nl_row * p.sps;   // kernel row of step 2 SB - 1 (last step of chunk 1), kept by addition
         for (int c = 0; c < nfull; ++c) {
             // DMA behind this chunk's MFMAs: the weights of chunk c + 1 into the slot chunk c - 1 left, and the input row chunk c + 1 needs first
             if (c + 1 < nchunk) {
                 w_dma(c + 1);
-                const int s_next_last = min((c + 2) * C16_SB, p.nsteps) - 1;           // last step of chunk c + 1
-                const int need = min(s_next_last / p.sps + TH - 1, nrows - 1);           // rows <= need must be resident when chunk c + 1 starts
+                const int need = min(nl_row + TH - 1, nrows - 1);                        // rows <= need must be resident when chunk c + 1 starts
                 if (need > resident) { ++resident; row_dma(resident); }
+                nl_rem += C16_SB;
+                while (nl_rem >= p.sps) { nl_rem -= p.sps; ++nl_row; }
             }
             // ---- SB k-steps from LDS only; fragments double buffered in registers
             bf16x8 a0[NP], b0[TN], a1[NP], b1[TN];
@@ -198,8 +226,13 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             if (C16_SB & 1) mm(a0, b0); else mm(a1, b1);
             wl += (c & 1) ? -CH : CH;
             if (c + 1 < nchunk) {
+                C16_T(t_w0);
                 __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): the pieces this wave issued at the top of the chunk have landed
+                C16_T(t_w1);
                 __syncthreads();                       // ONE barrier: chunk c + 1 and the new row are visible, chunk c's slot is free
+                C16_T(t_w2);
+                C16_ACC(2, t_w0, t_w1);
+                C16_ACC(3, t_w1, t_w2);
             }
         }
 #undef C16_INTERLEAVE
@@ -209,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             mm(a0, b0);
         }
 
+        C16_T(t_epi);
         // ---- epilogue, in registers: lane (li, lg) holds channels n0 .. n0 + 4 TN - 1 of position li of each of its position tiles
         float bv[4 * TN];
 #pragma unroll
@@ -256,6 +290,12 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
                     if (n0 + 4 * j < p.N) *reinterpret_cast<float4*>(op + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
             }
         }
+        C16_T(t_end);
+        C16_ACC(4, t_epi, t_end);
+        C16_ACC(0, t_start, t_end);
+#ifdef C16_PROF
+        if (threadIdx.x == 0) { for (int q_ = 0; q_ < 5; ++q_) atomicAdd(&c16_prof[q_], c16_acc[q_]); atomicAdd(&c16_prof[5], 1ull); }
+#endif
     };
     // NPr is workgroup-uniform: one scalar branch to the fully unrolled body for that many position tiles per wave
     if (TH == 8) {
@@ -370,6 +410,15 @@ static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
     *pl = q;
     return true;
 }
+
+#ifdef C16_PROF
+extern "C" int nele_conv16_prof_read(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(c16_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(c16_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" int nele_conv16_supported(int M, int N, const int* geom, int KH, int KW) {
     ConvGeom g;

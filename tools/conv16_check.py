@@ -43,6 +43,15 @@ def timeit(fn, flops, name, n=20):
     torch.cuda.synchronize()
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[n // 2]
     print('%-12s median %.3f ms  %.1f TFLOP/s (%.3f of 2500)' % (name, ms, flops / ms / 1e9, flops / ms / 1e9 / 2500))
+    from nele_gan_amd._lib import lib as _l
+    if hasattr(_l, 'nele_conv16_prof_read'):                 # a -DC16_PROF build: phase clocks of wave 0, averaged per workgroup
+        buf = (ctypes.c_ulonglong * 8)()
+        _l.nele_conv16_prof_read(buf, 1)
+        fn(); 
+        _l.nele_conv16_prof_read(buf, 1)
+        wg = max(buf[5], 1)
+        print('             per workgroup (shader clocks): total %.0f  prologue %.0f  DMA wait %.0f  barrier %.0f  epilogue %.0f  (%d workgroups)' % (
+            buf[0] / wg, buf[1] / wg, buf[2] / wg, buf[3] / wg, buf[4] / wg, buf[5]))
 
 
 for l in range(1, 5):
