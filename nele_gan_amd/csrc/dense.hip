@@ -1222,15 +1222,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
 // (per 16-lane group: a 4-row x 16-column block, lane i receives column i): two reads = the 8 consecutive m of a lane's
 // fragment.  32 reduction rows per step.
 #define WG16_MS 32
-#define WG16_LDD (WG_BN + 8)     // bf16 elements per LDS row of the dOut tile
-#define WG16_LDA (WG_BKK + 8)    // ... of the A_view tile
+#define WG16_LDD (WG_BN + 16)    // bf16 elements per LDS row of the dOut tile (80: see tr_frag)
+#define WG16_LDA (WG_BKK + 16)   // ... of the A_view tile (144)
 
+// MFMA operand fragment (16 columns x 32 rows of a row-major [row][column] tile, rows = the reduction index) by the hardware transpose
+// read: two ds_read_b64_tr_b16, each lane addressing 4 contiguous elements of one row.  Which rows a lane group takes only permutes the
+// reduction index - the same permutation for both operands - so the rows are dealt for the LDS banks: a 32-lane half of one read
+// covers EIGHT CONSECUTIVE rows (lanes 16 g .. 16 g + 15: rows 4 (g & 1) + 16 (g >> 1) + 0 .. 3, then + 8 for the second read), which
+// tile the 64 banks exactly when the row stride is 16, 48, 80 or 112 elements modulo 128.  (With rows 8 g + 0 .. 3 per group - 0 .. 3 and
+// 8 .. 11 in one half - no stride is conflict-free: PMC showed 43 % of the LDS cycles of D.conv5's weight gradient as bank conflicts.)
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int col0, int lane) {
-    // rows 8g..8g+7 (g = lane>>4) of columns col0..col0+15: lane 4q+p of a group addresses (row q, cols 4p..4p+3)
     const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
-    const __bf16* a0 = tile + (8 * g + q) * ld + col0 + 4 * pq;
+    const __bf16* a0 = tile + (4 * (g & 1) + 16 * (g >> 1) + q) * ld + col0 + 4 * pq;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * ld));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * ld));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -1370,7 +1375,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(WgradArgs p) {
 // read KH * 1.1 times instead of KH*KW times.  Partials per workgroup group, reduced by wgrad_reduce_kernel.
 #define WT_TH 4
 #define WT_TW 64
-#define WT_NP (64 + 8)       // LDS row stride (bf16) of the dOut tile
+// LDS row stride (bf16) of the dOut tile for NT n-tiles: 16, 48 or 80 - conflict-free for tr_frag, and no wider than the channels need
+// (a 72-element row for every layer kept D.conv3's weight gradient at 2 workgroups per CU)
+#define WT_NP_OF(NT_) ((NT_) <= 1 ? 16 : (NT_) <= 3 ? 48 : 80)
+#define WT_SLACK 512          // elements between the halo image and the dOut tile: Toeplitz over-read of the last row, overrun of the last 1 KB DMA piece
+
+// -DWT_PROF: phase clocks of thread 0 of every workgroup (diagnostic build: tools/variants.sh dense prof:"-DWT_PROF"; tools/d_check.py prints them)
+#ifdef WT_PROF
+__device__ unsigned long long wt_prof[8];        // 0 loads issued, 1 load wait + LDS writes, 2 barrier, 3 MFMA loop, 4 top barrier, 5 tiles
+#define WT_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#ifndef WT_PROF_NT
+#define WT_PROF_NT 4       // which kernel (n tiles) reports
+#endif
+#else
+#define WT_T(var) do {} while (0)
+#endif
 
 struct WgradTileArgs {
     const float* A;
@@ -1385,10 +1404,13 @@ struct WgradTileArgs {
 
 template <int NT, int KTW, bool D16 = false, bool A16 = false>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj); D16 / A16: dOut / the input activation is bf16 in memory
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs p) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 wt_lds[];     // halo rows [WT_TH][RS] + 64 slack, then dOut tile [256][WT_NP]
+    static_assert(!A16 || D16, "a bf16 activation comes with a bf16 output gradient");
+    constexpr int WT_NP = WT_NP_OF(NT);
+    extern __shared__ __attribute__((aligned(16))) __bf16 wt_lds[];     // halo rows [WT_TH][RS] + WT_SLACK, then dOut tile [256][WT_NP]
     __shared__ float bred[16][64];
     const ConvGeom& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the tile tests below are scalar branches
     // grid: 1-D, KH * G workgroups.  Workgroup w runs on XCD w % 8 (round-robin dispatch), and the KH kernel-row workgroups of a group
     // read the same input / dOut tiles at about the same time: they are given ids of one XCD so that its L2 serves the repeats
     // (with the natural (kh, group) order the KH readers of a tile sat on different XCDs and every read went to HBM: 1.55 GB per launch
@@ -1404,43 +1426,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     }
     const int wcols = WT_TW + p.KW - 1, RS = wcols * g.C;
     __bf16* halo = wt_lds;
-    __bf16* dt = wt_lds + WT_TH * RS + 64;
+    __bf16* dt = wt_lds + WT_TH * RS + WT_SLACK;
     const int nkt = (g.seglen + 15) >> 4;               // kk tiles of this kernel row
     f32x4 acc[NT][KTW];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int jj = 0; jj < KTW; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) halo[WT_TH * RS + tid] = (__bf16)0.f;
+    for (int e = tid; e < WT_SLACK; e += 256) halo[WT_TH * RS + e] = (__bf16)0.f;    // (the last DMA piece may run into the slack)
     const int dnq = tid & 15, dp0 = tid >> 4;            // dOut staging: n quad, first position
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_bias = (p.bpart != nullptr) && (kh == 0);
+#ifdef WT_PROF
+    unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     for (int t = grp; t < p.ntiles; t += p.G) {
         const int tw_i = t % p.ntw, rem = t / p.ntw, th_i = rem % p.nth, b = rem / p.nth;
         const int ho0 = th_i * WT_TH, wo0 = tw_i * WT_TW;
         const int wi0 = wo0 + g.iw0;
         const int vcols = max(0, min(wcols, g.W - wi0));
+        WT_T(t_a);
         __syncthreads();                                 // previous tile fully consumed
+        WT_T(t_b);
         // ---- input rows ho0 + r + kh (float32 -> bf16, or bf16 as stored), zero outside the input
+        // bf16 input: the four halo rows go global -> LDS by DMA (1 KB pieces of the contiguous [4][RS] image, wave w moves pieces w, w + 4,
+        // ..; lane l of a piece supplies the 16 bytes at image element 512 k + 8 l), issued ahead of the dOut loads below: ONE memory
+        // latency per tile and no staging registers (a row-by-row load / store loop paid a latency per load: 9.5 k of the 18 k clocks of
+        // a conv5 tile visit).  Rows / columns outside the input re-read the last valid ones: they only meet output positions outside
+        // the output, whose dOut is staged as zero, and reduction columns >= seglen, which are never stored.
+        if (A16) {
+            const int emax = max(vcols * g.C - 8, 0), himax = g.H - 1;
+            const __bf16* src0 = reinterpret_cast<const __bf16*>(p.A) + (((size_t)b * g.H) * g.W + wi0) * g.C;
+            const int npc = (WT_TH * RS + 511) >> 9;
+            for (int k = wave; k < npc; k += 4) {
+                const int ef = min(512 * k + 8 * lane, WT_TH * RS - 8);
+                const int r = (ef >= RS) + (ef >= 2 * RS) + (ef >= 3 * RS), e = ef - r * RS;
+                const int hi = min(ho0 + r + kh + g.ih0, himax);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (size_t)hi * g.W * g.C + min(e, emax)),
+                                                 (__attribute__((address_space(3))) void*)(halo + 512 * k), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < WT_TH; ++r) {
             const int hi = ho0 + r + kh + g.ih0;
             const bool rin = hi < g.H;
             const int nval = rin ? vcols * g.C : 0;
             const int emax = max(vcols * g.C - 8, 0);
-            if (A16) {
-                const __bf16* src16 = reinterpret_cast<const __bf16*>(p.A) + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
-                for (int e = tid * 8; e < RS; e += 2048) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(src16 + min(e, emax));
-                    if (!(e < nval)) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
-                    }
-                    *reinterpret_cast<bf16x8*>(halo + r * RS + e) = v;
-                }
-                continue;
-            }
+            if (A16) continue;
             const float* src = p.A + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
             for (int e = tid * 8; e < RS; e += 2048) {
                 const float* sp = src + min(e, emax);
@@ -1469,7 +1502,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
                 const bool ok = (ho0 + r < g.Hout) && (wo0 + c < g.Wout) && (4 * dnq < p.N);
                 bf16x4 v = rh[it];
                 if (!ok) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; v[2] = (__bf16)0.f; v[3] = (__bf16)0.f; }
-                *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
+                if (4 * dnq < WT_NP) *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
                 if (want_bias) { bq[0] += (float)v[0]; bq[1] += (float)v[1]; bq[2] += (float)v[2]; bq[3] += (float)v[3]; }
             }
         } else {
@@ -1488,30 +1521,73 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
                 const float4 v4 = ok ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
                 bf16x4 v;
                 v[0] = (__bf16)v4.x; v[1] = (__bf16)v4.y; v[2] = (__bf16)v4.z; v[3] = (__bf16)v4.w;
-                *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
+                if (4 * dnq < WT_NP) *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
                 if (want_bias) { bq[0] += v4.x; bq[1] += v4.y; bq[2] += v4.z; bq[3] += v4.w; }
             }
         }
+        WT_T(t_c);
+        if (A16) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();
-        // ---- 8 reduction steps of 32 positions (row r, columns 32 * half ..)
-#pragma unroll 2
-        for (int ks = 0; ks < WT_TH * 2; ++ks) {
-            const int r = ks >> 1, half = ks & 1;
-            bf16x8 af[NT], bfr[KTW];
+        WT_T(t_d);
+        // ---- 8 reduction steps of 32 positions (row r, columns 32 * half ..).  A read-then-multiply loop left the LDS latency of every
+        // step exposed (9 k clocks per tile for 3.6 k of MFMA issue), two full register sets of fragments do not fit beside the 112
+        // accumulators of D.conv5: the dOut fragments and the first PF input fragments of step ks + 1 are read during step ks, the
+        // remaining input fragments at the top of their own step - they arrive behind the first PF x NT MFMAs.
+#ifndef WT_PFB
+#define WT_PFB 2
+#endif
+#ifndef WT_PFA
+#define WT_PFA 1
+#endif
+        constexpr int PF = KTW < WT_PFB ? KTW : WT_PFB;
+        constexpr int PFS = PF > 0 ? PF : 1;
+        auto lda = [&](int ks, bf16x8 (&af)[NT]) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) af[i] = tr_frag(dt + (ks * 32) * WT_NP, WT_NP, 16 * i, lane);
-            const __bf16* hb = halo + r * RS + half * 32 * g.C;
+        };
+        auto ldb = [&](int ks, int jj) {
+            const __bf16* hb = halo + (ks >> 1) * RS + (ks & 1) * 32 * g.C;
+            return tr_frag(hb, g.C, 16 * min(wave + 4 * jj, nkt - 1), lane);
+        };
+        {
+            bf16x8 ac[NT], an[NT], bc[KTW], bn[PFS];
+            lda(0, ac);
 #pragma unroll
-            for (int jj = 0; jj < KTW; ++jj) bfr[jj] = tr_frag(hb, g.C, 16 * min(wave + 4 * jj, nkt - 1), lane);
+            for (int jj = 0; jj < PF; ++jj) bc[jj] = ldb(0, jj);
+#pragma unroll 1
+            for (int ks = 0; ks < WT_TH * 2; ++ks) {
+                if (!WT_PFA && ks > 0) lda(ks, ac);
 #pragma unroll
-            for (int jj = 0; jj < KTW; ++jj) {
-                if (wave + 4 * jj < nkt) {
+                for (int jj = PF; jj < KTW; ++jj) bc[jj] = ldb(ks, jj);
+                if (ks + 1 < WT_TH * 2) {
+                    if (WT_PFA) lda(ks + 1, an);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
+                    for (int jj = 0; jj < PF; ++jj) bn[jj] = ldb(ks + 1, jj);
                 }
+                // (a wave's surplus tile slots, wave + 4 jj >= nkt, recompute the last tile and are not stored: tests here would cut the
+                //  step's MFMAs into seven basic blocks with a wait in front of each)
+#pragma unroll
+                for (int jj = 0; jj < KTW; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[jj], acc[i][jj], 0, 0, 0);
+                if (ks + 1 < WT_TH * 2) {
+                    if (WT_PFA) {
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) ac[i] = an[i];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < PF; ++jj) bc[jj] = bn[jj];
+                }
+                __builtin_amdgcn_sched_barrier(0);           // the reads of later steps stay behind this step's MFMAs (registers)
             }
         }
+#ifdef WT_PROF
+        { WT_T(t_e); pacc[4] += t_b - t_a; pacc[1] += t_c - t_b; pacc[2] += t_d - t_c; pacc[3] += t_e - t_d; pacc[5] += 1; }
+#endif
     }
+#ifdef WT_PROF
+    if (tid == 0 && NT == WT_PROF_NT) for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&wt_prof[q_], pacc[q_]);
+#endif
     // ---- partials: acc[i][jj][reg] = dW[n = 16 i + 4 lg + reg][kk = kh * seglen + 16 (wave + 4 jj) + li]
     const int li = lane & 15, lg = lane >> 4;
     float* part = p.part + (size_t)grp * p.N * g.Ktot;
@@ -2027,8 +2103,8 @@ static bool wgrad_tile_eligible(int M, int N, const ConvGeom& g, int KH, int KW)
     static int wt_on = -1;
     if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
     const int nkt = (g.seglen + 15) / 16;
-    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * g.C + 64 + 256 * WT_NP) * 2;
-    return wt_on && N <= 64 && g.C % 8 == 0 && KW * g.C == g.seglen && nkt <= 28 && g.Wout >= 32 && wt_lds <= 64 * 1024 &&
+    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * g.C + WT_SLACK + 256 * WT_NP_OF((N + 15) / 16)) * 2;
+    return wt_on && N <= 64 && g.C % 8 == 0 && KW * g.C == g.seglen && nkt <= 28 && g.Wout >= 32 && wt_lds <= 76 * 1024 &&
            M % (g.Hout * g.Wout) == 0;
 }
 extern "C" int nele_conv_wgrad_bf16_d16_supported(int M, int N, const int* geom, int KH, int KW) {
@@ -2043,6 +2119,15 @@ extern "C" int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, floa
 }
 
 // ... and the input activation stored as bf16 too (model.Discriminator's bf16 mode: every activation and output gradient of layers 2-5 is bf16)
+#ifdef WT_PROF
+extern "C" int nele_wgrad_tile_prof_read(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(wt_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(wt_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 extern "C" int nele_conv_wgrad_bf16_a16d16(const void* A16, const void* dOut16, float* workspace, long long workspace_floats, int M, int N,
                                            const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
     return conv_wgrad_impl(reinterpret_cast<const float*>(A16), reinterpret_cast<const float*>(dOut16), workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db,
@@ -2072,7 +2157,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     static int wt_on = -1;
     if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
     const int nkt = (p.g.seglen + 15) / 16, NT = (N + 15) / 16;
-    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * p.g.C + 64 + 256 * WT_NP) * 2;
+    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * p.g.C + WT_SLACK + 256 * WT_NP_OF(NT)) * 2;
     const int max_splits = (M + 511) / 512;
     int G = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
     if (G < splits) G = splits;
@@ -2103,7 +2188,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
                 fn = ki == 0 ? WT_FNK(2) : (ki == 1 ? WT_FNK(4) : WT_FNK(7));
 #undef WT_FNK
 #undef WT_FN
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, (size_t)wt_lds) != hipSuccess || occ < 1) occ = 1;
                 hipFuncAttributes fa;
                 if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {      // registers: 512 per SIMD lane, one wave of the workgroup per SIMD
@@ -2132,9 +2217,9 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         const dim3 grid(KH * G);
         static bool wattr = false;
         if (!wattr) {
-#define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
-                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
-                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); } while (0)
+#define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); } while (0)
             WT_ATTR(1, 2); WT_ATTR(2, 2); WT_ATTR(3, 2); WT_ATTR(4, 2); WT_ATTR(1, 4); WT_ATTR(2, 4); WT_ATTR(3, 4); WT_ATTR(4, 4);
             WT_ATTR(1, 7); WT_ATTR(2, 7); WT_ATTR(3, 7); WT_ATTR(4, 7);
 #undef WT_ATTR
