@@ -16,7 +16,8 @@ import bench
 work = {'batch': int(sys.argv[2]), 'length': int(sys.argv[3]), 'metrics': sys.argv[4], 'precision': sys.argv[5]}
 WANT = ('conv16_kernel<4, 4, false>', 'conv16_kernel<4, 4, true>', 'conv16_kernel<3, 4, true>', 'conv16_kernel<2, 4, true>', 'conv16_kernel<2, 8, true>', 'conv16_kernel<1, 8, true>', 'conv16_kernel<1, 8, false>', 'conv16_kernel<1, 4, true>',
         'conv_wgrad_tile16_kernel<4, 7, true, true>', 'conv_wgrad_tile16_kernel<3, 4, true, true>', 'conv_wgrad_tile16_kernel<2, 2, true, true>', 'conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_tile16_kernel<3, 4>', 'conv_tile16_kernel<2, 4>', 'conv_tile16_kernel<1, 4>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7, true>', 'conv_wgrad_tile16_kernel<4, 7, false>', 'conv_wgrad_tile16_kernel<3, 4, false>',
-        'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_bank_scan_kernel<true, true, false, true>', 'haspi_bank_scan_kernel<false, true, false, false>',
+        'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_ihc_fir9_kernel', 'haspi_mod_slide_kernel<0>', 'haspi_cep_kernel', 'haspi_resample_kernel', 'haspi_bank_tail_kernel<true>', 'haspi_bank_tail_kernel<false>',
+        'siib_quad_kernel', 'siib_lag_kernel<0, 1, -14, 29>', 'eigh_invit_kernel', 'eigh_bisect_kernel', 'conv_wgrad_tile16_kernel<1, 2, true, true>', 'haspi_bank_scan_kernel<true, true, false, true>', 'haspi_bank_scan_kernel<false, true, false, false>',
         'eigh_backtransform_wy_kernel', 'eigh_tridiag_mid_kernel', 'siib_stack_kernel',
         'haspi_mod_slide_kernel<1>', 'stft_band_kernel', 'gain_istft_kernel', 'siib_proj_kernel<2>', 'siib_cov_kernel',
         'eigh_tridiag_cluster4_kernel', 'conv1d_tile16_kernel<4>', 'adam_guarded_kernel')
@@ -31,7 +32,7 @@ def key(name):
 
 acc = defaultdict(lambda: defaultdict(list))
 for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ'):
-    for f in sorted(glob.glob('%s/%s/*/*_counter_collection.csv' % (root, d)))[-1:]:       # the newest run directory only
+    for f in sorted(glob.glob('%s/%s/*/*_counter_collection.csv' % (root, d)), key=os.path.getmtime)[-1:]:       # the newest run only (merged gpurun_out directories keep old ones)
         for r in csv.DictReader(open(f)):
             k = key(r['Kernel_Name'])
             if k:
