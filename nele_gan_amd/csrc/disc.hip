@@ -246,15 +246,33 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* _
 __global__ void mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B, int N, int K, float* __restrict__ dW,
                                  float* __restrict__ db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the batch loop in groups of 8 with the loads issued together: one memory latency per group instead of one per item - this
+    //  16-wave kernel took 110 us at B = 256; the sums stay in batch order)
     if (i < N * K) {
         const int n = i / K, k = i - n * K;
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dz[(size_t)b * N + n] * x[(size_t)b * K + k];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            float dv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = dz[(size_t)(b + u) * N + n]; xv[u] = x[(size_t)(b + u) * K + k]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += dv[u] * xv[u];
+        }
+        for (; b < B; ++b) s += dz[(size_t)b * N + n] * x[(size_t)b * K + k];
         dW[i] = s;
     }
     if (i < N) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dz[(size_t)b * N + i];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[u] = dz[(size_t)(b + u) * N + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += dv[u];
+        }
+        for (; b < B; ++b) s += dz[(size_t)b * N + i];
         db[i] = s;
     }
 }
