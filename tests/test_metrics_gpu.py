@@ -259,6 +259,36 @@ def test_haspi_sliding_modulation_filters_equal_the_direct_fir(tmp_path):
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
 
 
+_HASPI_RAGGED_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+c, v = synth.batch(5, 63871, start=21)
+lens = torch.tensor([63871, 20011, 48000, 5120, 33333], dtype=torch.int32)
+raw, mapped = mt.batch_haspi(c, c * 0.8 + v, dither=None, lengths=lens)
+np.save(sys.argv[2], raw.double().cpu().numpy())
+'''
+
+
+@pytest.mark.parametrize('env', [{'NELE_HASPI_FIR9': '0'}, {'NELE_HASPI_CEP_SERIAL': '0'}, {'NELE_HASPI_TAIL1': '0'}, {'NELE_HASPI_MOD_DIRECT': '1'}],
+                         ids=['fir8-frame-rows', 'parallel-cepstra', 'whole-chunk-pass1', 'direct-modulation-fir'])
+def test_haspi_round3_kernels_equal_the_ones_they_replace(tmp_path, env):
+    """Round 3 restructured HASPI's envelope filter (groups of nine samples, outputs stored as whole rows per GROUP and read back
+    through the per-channel frame offset), the cepstrum stage (LDS-staged tiles), pass 1 of the filter banks (chunk heads skipped) and the
+    modulation filters (LDS ring, rotating frame): each against the kernel it replaced (switches are read once per process), on a padded
+    batch of utterances of different lengths - the row ends, the first frames (windows that start before the signal) and the
+    frame-offset addressing all differ per utterance and channel."""
+    import subprocess
+    import sys
+    res = []
+    for e in ({}, env):
+        out = str(tmp_path / ('haspi_r3_%d.npy' % len(res)))
+        subprocess.run([sys.executable, '-c', _HASPI_RAGGED_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **e), timeout=240)
+        res.append(np.load(out))
+    assert res[0].shape == (5,) and np.all(np.isfinite(res[0]))
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-6, atol=0)           # float32 outputs; multiply-add chains differ in the last bits
+
+
 def test_eigensolver_on_matrices_that_put_exact_zeros_into_the_sturm_recurrence(mt):
     """Diagonal, repeated and block-diagonal matrices: the Sturm sequence hits exact zeros (an evaluation point equal to an eigenvalue
     of a leading block); the bisection kernel does not repair them on its critical chain and must still converge."""
