@@ -1574,9 +1574,12 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             if (mid_on < 0) { const char* e_ = getenv("NELE_EIGH_MID"); mid_on = !(e_ && e_[0] == '0'); }
             const int mhand = (tail_on && mid_on) ? EM_M : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
-            static int p4_batch = -1;                      // NELE_EIGH_P4_BATCH: matrices per launch.  64 fill the chip - with spinning workgroups that own their CU; 32 leave half of it to
-                                                           // the other streams of a step (A/B on the B = 256 step: 47.5 / 48.5 / 46.5 ms with 64, 46.9 / 47.1 / 46.1 / 46.3 with 32)
-            if (p4_batch < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_batch = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 32; }
+            // NELE_EIGH_P4_BATCH: matrices per launch (default 64 = the whole chip).  The spinning workgroups own their CU - registers
+            // full, issue slots mostly idle - so 32 per launch (half the chip, twice the launches) leaves room for the step's other
+            // streams: 45.4 / 45.5 / 46.0 against 46.1 / 46.2 / 46.3 ms on the B = 256 step (alternating, one box), while the chain's
+            // own time doubles (8 x 1.37 instead of 4 x 1.42 ms per 256 matrices).  Within the pool's box-to-box spread: default unchanged.
+            static int p4_batch = -1;
+            if (p4_batch < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_batch = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 64; }
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop);
