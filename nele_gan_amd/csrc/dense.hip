@@ -772,8 +772,21 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(Tile16Args p) {
 #define C1D_PADE 8
 #endif
 #define C1D_PAD(C_) (((C_) % 128 == 0) ? C1D_PADE : 0)
+// -DC1_PROF: phase clocks of thread 0 of every workgroup (diagnostic build; tools/g_check.py prints them)
+#ifdef C1_PROF
+__device__ unsigned long long c1_prof[8];        // 0 strip staging, 1 first weights + barrier, 2 MFMA chunks, 3 chunk-end store + barrier, 4 epilogue, 5 workgroups
+#define C1_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define C1_ACC(slot, a_, b_) do { c1_acc[slot] += (b_) - (a_); } while (0)
+#else
+#define C1_T(var) do {} while (0)
+#define C1_ACC(slot, a_, b_) do {} while (0)
+#endif
 template <int TN>
 __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
+    C1_T(t_k0);
+#ifdef C1_PROF
+    unsigned long long c1_acc[5] = {0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) __bf16 halo[];    // [RS] + 64 slack, then the weight chunk [SB][TN][64][8]
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -800,27 +813,48 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     const int SB = p.SB, nchunk = p.steps_per_seg / SB;
     const int cfrag = SB * TN * 64;
     {   // stage the input strip (float32 -> bf16), zero beyond the input
-        const int nval = vcols * g.C;
-        for (int e = tid * 8; e < wcols * g.C; e += 2048) {
-            bf16x8 v;
-            if (e < nval) {
-                const float4 a = *reinterpret_cast<const float4*>(src + e);
-                const float4 c = *reinterpret_cast<const float4*>(src + e + 4);
-                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-                v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-            } else {
+        // groups of six 32-byte pieces per thread with all their loads in flight together: a load - convert - store loop paid a memory
+        // latency per piece (17 pieces for a 256-channel strip: 16 k of the workgroup's 92 k clocks)
+        const int nval = vcols * g.C, ntot = wcols * g.C;
+        constexpr int SG = 6;
+        for (int e0 = tid * 8; e0 < ntot; e0 += 2048 * SG) {
+            float4 ra[SG], rc[SG];
+            const int emax = max(nval - 8, 0);                  // (unconditional loads from clamped addresses: a test around a load makes the compiler wait for it at once)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
+            for (int q = 0; q < SG; ++q) {
+                const int e = min(e0 + 2048 * q, emax);
+                ra[q] = *reinterpret_cast<const float4*>(src + e); rc[q] = *reinterpret_cast<const float4*>(src + e + 4);
             }
-            const int px = (CP == g.C) ? 0 : e / g.C;
-            *reinterpret_cast<bf16x8*>(halo + e + px * (CP - g.C)) = v;
+#pragma unroll
+            for (int q = 0; q < SG; ++q) {
+                const int e = e0 + 2048 * q;
+                if (e >= ntot) continue;
+                bf16x8 v;
+                if (e < nval) {
+                    v[0] = (__bf16)ra[q].x; v[1] = (__bf16)ra[q].y; v[2] = (__bf16)ra[q].z; v[3] = (__bf16)ra[q].w;
+                    v[4] = (__bf16)rc[q].x; v[5] = (__bf16)rc[q].y; v[6] = (__bf16)rc[q].z; v[7] = (__bf16)rc[q].w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = (__bf16)0.f;
+                }
+                const int px = (CP == g.C) ? 0 : e / g.C;
+                *reinterpret_cast<bf16x8*>(halo + e + px * (CP - g.C)) = v;
+            }
         }
         if (tid < 64) halo[RS + tid] = (__bf16)0.f;
     }
     // weight chunk c: steps [c SB, (c+1) SB) x this workgroup's TN n-tiles (stride NT tiles per step in the fragment stream)
+    C1_T(t_k1);
+    C1_ACC(0, t_k0, t_k1);
+    // Weight chunks travel global -> registers -> LDS TWO chunks ahead (two register sets, two LDS slots): with one wave per SIMD and one
+    // workgroup per CU nothing else covers a memory latency, and a chunk's MFMAs (SB x 2 x TN x 16 cycles) are shorter than one - fetched
+    // one chunk ahead through one slot, every chunk ended in a wait for its successor and two barriers (122 us per layer at B = 256 for
+    // 16 us of MFMA issue).  Chunk c + 2 is requested at the top of chunk c, chunk c + 1 is written to the other slot after chunk c's MFMAs,
+    // ONE barrier per chunk.
     constexpr int NBR = (TILE16_SBMAX * TN + 3) / 4;
-    bf16x8 breg[NBR];
+    bf16x8 bregA[NBR], bregB[NBR];
     const int nq = (cfrag + 255) >> 8;
+    const int wsl = (cfrag * 8 + 2047) & ~2047;           // elements per LDS weight slot
     const bf16x8* wsrc = nullptr;
     int woff[NBR];                                       // fragment offsets inside a chunk: the same for every chunk
 #pragma unroll
@@ -828,16 +862,16 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
         const int f = min(tid + 256 * q, cfrag - 1), u = f / (TN * 64), r = f - u * (TN * 64);
         woff[q] = u * p.NT * 64 + r;
     }
-    auto wload = [&](int c) {
+    auto wload = [&](int c, bf16x8 (&breg)[NBR]) {
         const bf16x8* wc = wsrc + (size_t)c * SB * p.NT * 64;
 #pragma unroll
         for (int q = 0; q < NBR; ++q)
             if (q < nq) breg[q] = wc[woff[q]];
     };
-    auto wstore = [&]() {
+    auto wstore = [&](int slot, const bf16x8 (&breg)[NBR]) {
 #pragma unroll
         for (int q = 0; q < NBR; ++q)
-            if (q < nq) reinterpret_cast<bf16x8*>(wbuf)[tid + 256 * q] = breg[q];
+            if (q < nq) reinterpret_cast<bf16x8*>(wbuf + slot * wsl)[tid + 256 * q] = breg[q];
     };
     // this wave's two position tiles: columns 16 (wave + 4 t)
     int pb[2];
@@ -852,20 +886,25 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
     // staged instead of four workgroups staging the same strip (128 + k - 1 input positions x C channels, converted to bf16).  The
     // epilogue then transposes through its own LDS scratch (behind the weight chunk), not through the strip.
     const int nb_end = nb + p.ncl;
-    float* epbase = (p.ncl > 1) ? reinterpret_cast<float*>(wbuf + ((cfrag * 8 + 2047) & ~2047)) : reinterpret_cast<float*>(halo);
-    for (; nb < nb_end; ++nb) {
+    float* epbase = (p.ncl > 1) ? reinterpret_cast<float*>(wbuf + 2 * wsl) : reinterpret_cast<float*>(halo);
     wsrc = reinterpret_cast<const bf16x8*>(p.Wfrag) + (size_t)nb * 4 * 64;
-    wload(0);
-    wstore();
+    wload(0, bregA);                                      // (the first two chunks of every later N chunk are requested under the epilogue before it)
+    if (nchunk > 1) wload(1, bregB);
+    for (; nb < nb_end; ++nb) {
+    C1_T(t_n0);
+    wstore(0, bregA);
     f32x4 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf) + lane;
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nchunk) wload(c + 1);
+    C1_T(t_n1);
+    C1_ACC(1, t_n0, t_n1);
+    auto chunk = [&](int c, bf16x8 (&bcur)[NBR], bf16x8 (&bnext)[NBR]) {   // bcur held chunk c (already in LDS), bnext holds chunk c + 1
+        C1_T(t_c0);
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf + (c & 1) * wsl) + lane;
+        if (c + 2 < nchunk) wload(c + 2, bcur);
         const __bf16* hk = halo;
         const int ug0 = c * SB;                            // k-step ug: elements [32 ug, 32 ug + 32) of the im2col row
         // fragments double buffered in registers: the ds_reads of step u + 1 are issued before the MFMAs of step u (one wave per SIMD and
@@ -897,13 +936,26 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
             mm(a1, b1);
         }
         if (u < SB) mm(a0, b0);
+        C1_T(t_c1);
+        C1_ACC(2, t_c0, t_c1);
         if (c + 1 < nchunk) {
-            __syncthreads();
-            wstore();
+            wstore((c + 1) & 1, bnext);                    // its slot was last read in chunk c - 1, behind that chunk's barrier
             __syncthreads();
         }
+        C1_T(t_c2);
+        C1_ACC(3, t_c1, t_c2);
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, bregA, bregB);
+        if (c + 1 < nchunk) chunk(c + 1, bregB, bregA);
     }
     // ---- epilogue through LDS (float4 stores along the channels)
+    C1_T(t_e0);
+    if (nb + 1 < nb_end) {                                 // every chunk of this N chunk has left the registers: the next one's first two come in now
+        wsrc = reinterpret_cast<const bf16x8*>(p.Wfrag) + (size_t)(nb + 1) * 4 * 64;
+        wload(0, bregA);
+        if (nchunk > 1) wload(1, bregB);
+    }
     __syncthreads();
     float* ep = epbase + wave * (16 * 68);
     constexpr int NQ = TN * 4;
@@ -941,7 +993,12 @@ __global__ __launch_bounds__(256) void conv1d_tile16_kernel(Tile16Args p) {
         }
     }
     if (nb + 1 < nb_end) __syncthreads();                  // the next chunk's first weights replace this chunk's last ones
+    C1_T(t_e1);
+    C1_ACC(4, t_e0, t_e1);
     }
+#ifdef C1_PROF
+    if (tid == 0) { for (int q_ = 0; q_ < 5; ++q_) atomicAdd(&c1_prof[q_], c1_acc[q_]); atomicAdd(&c1_prof[5], 1ull); }
+#endif
 }
 
 // Wg [N][Ktot] f32 -> bf16 fragment-major [KH*sps][NT][64][8], sps = ceil(seglen/32); element (ks = kh*sps + s, j, lane, e) =
@@ -1886,7 +1943,7 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
     const int sps = g.seglen / 32, TNsel = (N >= 64) ? 4 : (N + 15) / 16;
     for (int d = TILE16_SBMAX; d >= 1; --d) {
         if (sps % d) continue;
-        const long long bytes = (RS + 64) * 2 + (((long long)d * TNsel * 1024 + 4095) & ~4095LL);
+        const long long bytes = (RS + 64) * 2 + 2 * (((long long)d * TNsel * 1024 + 4095) & ~4095LL);     // strip + two weight slots
         if (bytes <= 158 * 1024) {
             if (lds_out) *lds_out = (size_t)(bytes < 4 * 16 * 68 * 4 ? 4 * 16 * 68 * 4 : bytes);
             return d;
@@ -2119,6 +2176,15 @@ extern "C" int nele_conv_wgrad_bf16_d16(const float* A, const void* dOut16, floa
 }
 
 // ... and the input activation stored as bf16 too (model.Discriminator's bf16 mode: every activation and output gradient of layers 2-5 is bf16)
+#ifdef C1_PROF
+extern "C" int nele_conv1d_prof_read(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(c1_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(c1_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 #ifdef WT_PROF
 extern "C" int nele_wgrad_tile_prof_read(unsigned long long* out8, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

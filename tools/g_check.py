@@ -22,3 +22,14 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 print('G forward + backward B=%d T=%d (%s): %.2f ms' % (B, T, G.precision, (time.perf_counter() - t0) / 3 * 1e3))
+
+from nele_gan_amd._lib import lib as _l
+if hasattr(_l, 'nele_conv1d_prof_read'):               # a -DC1_PROF build: phase clocks of conv1d_tile16_kernel per workgroup (all layers pooled)
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    _l.nele_conv1d_prof_read(buf, 1)
+    step(); torch.cuda.synchronize()
+    _l.nele_conv1d_prof_read(buf, 1)
+    n = max(buf[5], 1)
+    print('conv1d_tile16_kernel, shader clocks per workgroup: strip staging %.0f  first weights %.0f  MFMA chunks %.0f  chunk-end store + barrier %.0f  epilogues %.0f  (%d workgroups)' % (
+        buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n, buf[4] / n, buf[5]))
