@@ -1457,6 +1457,11 @@ struct WgradTileArgs {
     int nth, ntw, ntiles, G;
     ConvGeom g;
     int d16;             // dOut is bf16 in memory
+    // Sliced problems (layers too wide for one workgroup's accumulators: the generator's 256 -> 256 Conv1d).  A workgroup then owns a
+    // chunk of p.N output channels and a slice of g.C input channels (g describes the SLICE: C, seglen = KW * C); ics is the position
+    // stride of the input buffer (the layer's full channel count), subs_n x subs_c sub-problems share every group's tiles, Kfull = KH * KW * ics
+    // is the row length of the partials.  Unsliced: ics = g.C, subs_n = subs_c = 1, Kfull = g.Ktot.
+    int ics, subs_n, subs_c, Kfull;
 };
 
 template <int NT, int KTW, bool D16 = false, bool A16 = false>      // n tiles (16 each), kk tiles per wave (16 each; tile index = wave + 4 * jj); D16 / A16: dOut / the input activation is bf16 in memory
@@ -1472,15 +1477,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     // read the same input / dOut tiles at about the same time: they are given ids of one XCD so that its L2 serves the repeats
     // (with the natural (kh, group) order the KH readers of a tile sat on different XCDs and every read went to HBM: 1.55 GB per launch
     // for 160 MB of operands)
-    int kh, grp;
-    if ((p.G & 7) == 0) {
-        const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
-        kh = slot % p.KH;
-        grp = (slot / p.KH) * 8 + xcd;
-    } else {
-        kh = blockIdx.x % p.KH;
-        grp = blockIdx.x / p.KH;
+    int kh, grp, sub;
+    {
+        const int inner = p.KH * p.subs_n * p.subs_c;      // the workgroups that read one group's tiles: ids of one XCD
+        int rest;
+        if ((p.G & 7) == 0) {
+            const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+            rest = slot % inner;
+            grp = (slot / inner) * 8 + xcd;
+        } else {
+            rest = blockIdx.x % inner;
+            grp = blockIdx.x / inner;
+        }
+        kh = rest % p.KH;
+        sub = rest / p.KH;
     }
+    const int sn = sub / p.subs_c, sc = sub - sn * p.subs_c;
+    const int n0 = sn * p.N, ic0 = sc * g.C, Nfull = p.N * p.subs_n;
     const int wcols = WT_TW + p.KW - 1, RS = wcols * g.C;
     __bf16* halo = wt_lds;
     __bf16* dt = wt_lds + WT_TH * RS + WT_SLACK;
@@ -1493,7 +1506,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     for (int e = tid; e < WT_SLACK; e += 256) halo[WT_TH * RS + e] = (__bf16)0.f;    // (the last DMA piece may run into the slack)
     const int dnq = tid & 15, dp0 = tid >> 4;            // dOut staging: n quad, first position
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bias = (p.bpart != nullptr) && (kh == 0);
+    const bool want_bias = (p.bpart != nullptr) && (kh == 0) && (sc == 0);
 #ifdef WT_PROF
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -1524,22 +1537,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
                                                  (__attribute__((address_space(3))) void*)(halo + 512 * k), 16, 0, 0);
             }
         }
+        if (!A16) {
+            // float32 input (the generator's layers, D's first layers in float32-buffer mode): pieces of 8 elements of the [4][RS] image,
+            // loads unconditional from clamped addresses and all in flight together, then converted and stored; a piece sits inside one
+            // position's channel slice (C is a multiple of 8), whose address in the buffer is position * ics + ic0
+            int tl = tid;                                  // laundered per tile: the piece addresses are tile-invariant and the compiler would
+            asm volatile("" : "+v"(tl));                   // otherwise keep all of them in registers across the MFMA loop (187 VGPRs for the 32-channel layer)
+            constexpr int HNF = 9, HB = 3;                 // pieces per thread, in batches of HB (registers: 8 floats per piece in flight)
+            const int pmax = max(vcols - 1, 0), himax = g.H - 1;
+            const float* src0 = p.A + (((size_t)b * g.H) * g.W + wi0) * p.ics + ic0;
 #pragma unroll
-        for (int r = 0; r < WT_TH; ++r) {
-            const int hi = ho0 + r + kh + g.ih0;
-            const bool rin = hi < g.H;
-            const int nval = rin ? vcols * g.C : 0;
-            const int emax = max(vcols * g.C - 8, 0);
-            if (A16) continue;
-            const float* src = p.A + (((size_t)b * g.H + (rin ? hi : 0)) * g.W + wi0) * g.C;
-            for (int e = tid * 8; e < RS; e += 2048) {
-                const float* sp = src + min(e, emax);
-                const float4 a = *reinterpret_cast<const float4*>(sp), c = *reinterpret_cast<const float4*>(sp + 4);
-                bf16x8 v;
-                const bool in = e < nval;
-                v[0] = (__bf16)(in ? a.x : 0.f); v[1] = (__bf16)(in ? a.y : 0.f); v[2] = (__bf16)(in ? a.z : 0.f); v[3] = (__bf16)(in ? a.w : 0.f);
-                v[4] = (__bf16)(in ? c.x : 0.f); v[5] = (__bf16)(in ? c.y : 0.f); v[6] = (__bf16)(in ? c.z : 0.f); v[7] = (__bf16)(in ? c.w : 0.f);
-                *reinterpret_cast<bf16x8*>(halo + r * RS + e) = v;
+            for (int it0 = 0; it0 < HNF; it0 += HB) {
+                float4 fa[HB], fc[HB];
+#pragma unroll
+                for (int q = 0; q < HB; ++q) {
+                    const int ef = min(tl * 8 + 2048 * (it0 + q), WT_TH * RS - 8);
+                    const int r = (ef >= RS) + (ef >= 2 * RS) + (ef >= 3 * RS), e = ef - r * RS;
+                    const int pos = e / g.C, within = e - pos * g.C;
+                    const float* sp = src0 + ((size_t)min(ho0 + r + kh + g.ih0, himax) * g.W + min(pos, pmax)) * p.ics + within;
+                    fa[q] = *reinterpret_cast<const float4*>(sp); fc[q] = *reinterpret_cast<const float4*>(sp + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < HB; ++q) {
+                    const int ef = tl * 8 + 2048 * (it0 + q);
+                    if (ef < WT_TH * RS) {
+                        const int r = (ef >= RS) + (ef >= 2 * RS) + (ef >= 3 * RS), e = ef - r * RS;
+                        const bool in = (ho0 + r + kh + g.ih0 < g.H) && (e < vcols * g.C);
+                        bf16x8 v;
+                        v[0] = (__bf16)(in ? fa[q].x : 0.f); v[1] = (__bf16)(in ? fa[q].y : 0.f); v[2] = (__bf16)(in ? fa[q].z : 0.f); v[3] = (__bf16)(in ? fa[q].w : 0.f);
+                        v[4] = (__bf16)(in ? fc[q].x : 0.f); v[5] = (__bf16)(in ? fc[q].y : 0.f); v[6] = (__bf16)(in ? fc[q].z : 0.f); v[7] = (__bf16)(in ? fc[q].w : 0.f);
+                        *reinterpret_cast<bf16x8*>(halo + ef) = v;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);         // (keeps the next batch's loads behind this batch's stores: registers)
             }
         }
         // ---- dOut tile [256 positions][N] (zero for positions outside the output and n >= N)
@@ -1550,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
             for (int it = 0; it < 16; ++it) {
                 const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
                 const int ho = min(ho0 + r, g.Hout - 1), wo = min(wo0 + c, g.Wout - 1);
-                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + min(4 * dnq, p.N - 4);
+                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + n0 + min(4 * dnq, p.N - 4);
                 rh[it] = *reinterpret_cast<const bf16x4*>(d16 + off);
             }
 #pragma unroll
@@ -1563,23 +1593,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
                 if (want_bias) { bq[0] += (float)v[0]; bq[1] += (float)v[1]; bq[2] += (float)v[2]; bq[3] += (float)v[3]; }
             }
         } else {
-            float4 rd[16];
+            int tq = tid;
+            asm volatile("" : "+v"(tq));                   // (see the input rows above)
+            const int dnq = tq & 15, dp0 = tq >> 4;
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
-                const int ho = min(ho0 + r, g.Hout - 1), wo = min(wo0 + c, g.Wout - 1);
-                const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + min(4 * dnq, p.N - 4);
-                rd[it] = *reinterpret_cast<const float4*>(p.dOut + off);
-            }
+            for (int h = 0; h < 2; ++h) {                    // two batches of 8 positions: 32 instead of 64 staging registers
+                float4 rd[8];
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int pos = dp0 + 16 * it, r = pos >> 6, c = pos & 63;
-                const bool ok = (ho0 + r < g.Hout) && (wo0 + c < g.Wout) && (4 * dnq < p.N);
-                const float4 v4 = ok ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-                bf16x4 v;
-                v[0] = (__bf16)v4.x; v[1] = (__bf16)v4.y; v[2] = (__bf16)v4.z; v[3] = (__bf16)v4.w;
-                if (4 * dnq < WT_NP) *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
-                if (want_bias) { bq[0] += v4.x; bq[1] += v4.y; bq[2] += v4.z; bq[3] += v4.w; }
+                for (int q = 0; q < 8; ++q) {
+                    const int pos = dp0 + 16 * (8 * h + q), r = pos >> 6, c = pos & 63;
+                    const int ho = min(ho0 + r, g.Hout - 1), wo = min(wo0 + c, g.Wout - 1);
+                    const size_t off = (((size_t)b * g.OH + ho + g.oh0) * g.OW + wo + g.ow0) * g.OC + n0 + min(4 * dnq, p.N - 4);
+                    rd[q] = *reinterpret_cast<const float4*>(p.dOut + off);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pos = dp0 + 16 * (8 * h + q), r = pos >> 6, c = pos & 63;
+                    const bool ok = (ho0 + r < g.Hout) && (wo0 + c < g.Wout) && (4 * dnq < p.N);
+                    const float4 v4 = ok ? rd[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bf16x4 v;
+                    v[0] = (__bf16)v4.x; v[1] = (__bf16)v4.y; v[2] = (__bf16)v4.z; v[3] = (__bf16)v4.w;
+                    if (4 * dnq < WT_NP) *reinterpret_cast<bf16x4*>(dt + pos * WT_NP + 4 * dnq) = v;
+                    if (want_bias) { bq[0] += v4.x; bq[1] += v4.y; bq[2] += v4.z; bq[3] += v4.w; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         WT_T(t_c);
@@ -1647,7 +1684,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
 #endif
     // ---- partials: acc[i][jj][reg] = dW[n = 16 i + 4 lg + reg][kk = kh * seglen + 16 (wave + 4 jj) + li]
     const int li = lane & 15, lg = lane >> 4;
-    float* part = p.part + (size_t)grp * p.N * g.Ktot;
+    // (sliced problems: local column kk = kw * C + c of the slice is column kw * ics + ic0 + c of the layer's kernel row, rows n0 + n)
+    float* part = p.part + (size_t)grp * Nfull * p.Kfull + (size_t)n0 * p.Kfull + (size_t)kh * p.KW * p.ics + ic0;
+    int kcol[KTW];
+#pragma unroll
+    for (int jj = 0; jj < KTW; ++jj) {
+        const int kk = 16 * (wave + 4 * jj) + li, kw = kk / g.C;
+        kcol[jj] = (wave + 4 * jj < nkt && kk < g.seglen) ? kw * p.ics + (kk - kw * g.C) : -1;
+    }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -1655,10 +1699,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
             const int n = 16 * i + 4 * lg + reg;
             if (n >= p.N) continue;
 #pragma unroll
-            for (int jj = 0; jj < KTW; ++jj) {
-                const int kk = 16 * (wave + 4 * jj) + li;
-                if (wave + 4 * jj < nkt && kk < g.seglen) part[(size_t)n * g.Ktot + kh * g.seglen + kk] = acc[i][jj][reg];
-            }
+            for (int jj = 0; jj < KTW; ++jj)
+                if (kcol[jj] >= 0) part[(size_t)n * p.Kfull + kcol[jj]] = acc[i][jj][reg];
         }
     if (want_bias) {                                      // fold the 16 threads that share an n quad
         __syncthreads();
@@ -1669,7 +1711,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
             float sum = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) sum += bred[q][tid];
-            p.bpart[(size_t)grp * p.N + tid] = sum;
+            p.bpart[(size_t)grp * Nfull + n0 + tid] = sum;
         }
     }
 }
@@ -2222,8 +2264,24 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     // 2-D tile kernel (bf16): one kernel row per workgroup, accumulators in registers over all position tiles
     static int wt_on = -1;
     if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
-    const int nkt = (p.g.seglen + 15) / 16, NT = (N + 15) / 16;
-    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * p.g.C + WT_SLACK + 256 * WT_NP_OF(NT)) * 2;
+    // Layers too wide for one workgroup's accumulators (N > 64 or more than 28 reduction tiles per kernel row: the generator's Conv1d
+    // layers, 256 x 7 x 256) run on the same tile kernel as subs_n x subs_c sub-problems of 64 output x 64 input channels that share
+    // every group's position tiles; a Conv1d batch is viewed as ONE image whose rows are the utterances (KH = 1: rows are independent),
+    // so that a tile is 4 utterances x 64 frames.  The im2col-gathering kernel read the input KW times per 128-column block of the
+    // gradient: 1.44 GB per launch for 130 MB of operands, 240 us per layer at B = 256.
+    ConvGeom gt = p.g;                                     // geometry the tile kernel sees
+    int Nt = N, subs_n = 1, subs_c = 1, Bt = M / (p.g.Hout * p.g.Wout);
+    bool sliced = false;
+    if (bf16 && !d16 && wt_on && !wgrad_tile_eligible(M, N, p.g, KH, KW) && N % 64 == 0 && p.g.C % 64 == 0 && KW * p.g.C == p.g.seglen &&
+        KW * 4 <= 28 && p.g.Wout >= 32 && M % (p.g.Hout * p.g.Wout) == 0) {
+        gt.C = 64; gt.seglen = KW * 64; gt.Ktot = KH * KW * 64;
+        Nt = 64; subs_n = N / 64; subs_c = p.g.C / 64;
+        if (KH == 1 && p.g.H == 1 && p.g.Hout == 1 && p.g.OH == 1 && p.g.ih0 == 0 && p.g.oh0 == 0) { gt.H = Bt; gt.Hout = Bt; gt.OH = Bt; Bt = 1; }
+        sliced = (((long long)WT_TH * (WT_TW + KW - 1) * 64 + WT_SLACK + 256 * WT_NP_OF(4)) * 2 <= 76 * 1024);
+        if (!sliced) { gt = p.g; Nt = N; subs_n = subs_c = 1; Bt = M / (p.g.Hout * p.g.Wout); }
+    }
+    const int nkt = (gt.seglen + 15) / 16, NT = (Nt + 15) / 16;
+    const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * gt.C + WT_SLACK + 256 * WT_NP_OF(NT)) * 2;
     const int max_splits = (M + 511) / 512;
     int G = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
     if (G < splits) G = splits;
@@ -2233,11 +2291,13 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         if (genv > 0 && genv < G) G = genv;
     }
     bool tiled = false;
-    if (bf16 && wgrad_tile_eligible(M, N, p.g, KH, KW)) {
+    if (bf16 && (sliced || wgrad_tile_eligible(M, N, p.g, KH, KW))) {
         WgradTileArgs t;
-        t.A = A; t.dOut = dOut; t.part = workspace; t.N = N; t.B = M / (p.g.Hout * p.g.Wout); t.KH = KH; t.KW = KW; t.d16 = d16;
-        t.nth = (p.g.Hout + WT_TH - 1) / WT_TH; t.ntw = (p.g.Wout + WT_TW - 1) / WT_TW; t.ntiles = t.B * t.nth * t.ntw;
+        t.A = A; t.dOut = dOut; t.part = workspace; t.N = Nt; t.B = Bt; t.KH = KH; t.KW = KW; t.d16 = d16;
+        t.ics = p.g.C; t.subs_n = subs_n; t.subs_c = subs_c; t.Kfull = p.g.Ktot;
+        t.nth = (gt.Hout + WT_TH - 1) / WT_TH; t.ntw = (gt.Wout + WT_TW - 1) / WT_TW; t.ntiles = t.B * t.nth * t.ntw;
         if (G > t.ntiles) G = t.ntiles;
+        const int wg_per_group = KH * subs_n * subs_c;
         const int ktw = (nkt + 3) / 4;
         {   // Workgroups that do not fit the chip at once run as a second, nearly empty round: KH * 64 = 576 workgroups on 512 slots (two
             // per CU for D.conv5) took 1.64 x as long as KH * 56 = 504 (3.20 -> 1.95 ms at B = 256).  Pick the group count (a multiple
@@ -2271,16 +2331,16 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
                 long long best = -1;
                 int bestG = G;
                 for (int cand = G & ~7; cand >= 8; cand -= 8) {    // (any count up to the workspace's partial slots works for this kernel)
-                    const long long rounds = ((long long)KH * cand + slots - 1) / slots, per = (t.ntiles + cand - 1) / cand;
+                    const long long rounds = ((long long)wg_per_group * cand + slots - 1) / slots, per = (t.ntiles + cand - 1) / cand;
                     const long long cost = rounds * per;
                     if (best < 0 || cost < best) { best = cost; bestG = cand; }
                 }
                 G = bestG;
             }
         }
-        t.G = G; t.g = p.g;
+        t.G = G; t.g = gt;
         t.bpart = db ? workspace + (size_t)G * N * p.g.Ktot : nullptr;
-        const dim3 grid(KH * G);
+        const dim3 grid(wg_per_group * G);
         static bool wattr = false;
         if (!wattr) {
 #define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \

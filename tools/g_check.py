@@ -33,3 +33,12 @@ if hasattr(_l, 'nele_conv1d_prof_read'):               # a -DC1_PROF build: phas
     n = max(buf[5], 1)
     print('conv1d_tile16_kernel, shader clocks per workgroup: strip staging %.0f  first weights %.0f  MFMA chunks %.0f  chunk-end store + barrier %.0f  epilogues %.0f  (%d workgroups)' % (
         buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n, buf[4] / n, buf[5]))
+
+if hasattr(_l, 'nele_wgrad_tile_prof_read'):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    _l.nele_wgrad_tile_prof_read(buf, 1)
+    step(); torch.cuda.synchronize()
+    _l.nele_wgrad_tile_prof_read(buf, 1)
+    n = max(buf[5], 1)
+    print('weight-gradient tile kernel, shader clocks per tile visit: top barrier %.0f  loads + LDS writes %.0f  barrier %.0f  MFMA loop %.0f  (%d visits)' % (buf[4] / n, buf[1] / n, buf[2] / n, buf[3] / n, buf[5]))
