@@ -925,6 +925,202 @@ __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restric
     }
 }
 
+// The same with up to EX_E = 32 more rows / columns: the trailing block's FIRST E = m - 224 rows (the ones eliminated first) sit in an LDS
+// strip S[E][256] (full rows: the E x E corner is stored twice, the off-diagonal block once), the other 224 x 224 in registers as above.
+// While the strip is alive (the first E steps) a step also updates it in place - pass A: thread per column, column sums; pass B: thread
+// group per row, the row sums that stand in for the transposed off-diagonal block - and takes the next pivot column from it.  The
+// cluster kernel, whose step costs 7.2 us on FOUR CUs that no other kernel can share (registers full), hands over 32 steps earlier.
+#define EX_E 32
+#define EX_LD 256
+__global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
+    extern __shared__ double em_strip[];                  // S[E][EX_LD]: rows 0 .. E-1 of the trailing block, all its columns
+    __shared__ __attribute__((aligned(16))) double vperm[3][EM_M + 64];   // v, w, v_next of the register block at [(r & 15) * (EM_RI) + (r >> 4)]
+    __shared__ double vL[EX_LD], wL[EX_LD], nL[EX_LD];    // the same vectors over the whole trailing block, natural order (strip passes)
+    __shared__ double accA[2][EX_LD], accB[EX_E];
+    __shared__ double vnat[EM_M], wnat[EM_M];
+    __shared__ double accb[16][EM_M];
+    __shared__ double prow[EM_M];
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+    const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1, m <= EM_M + EX_E
+    const int E = max(m - EM_M, 0);                      // its first E rows / columns live in the LDS strip, the rest in registers
+    double* S = em_strip;
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    const int cl0 = lane & 31, rs = 2 * wvi + (lane >> 5);
+    double a[EM_NC][EM_RI];
+#pragma unroll
+    for (int cj = 0; cj < EM_NC; ++cj)
+#pragma unroll
+        for (int ri = 0; ri < EM_RI; ++ri) {
+            const int r = E + rs + 16 * ri, c = E + cl0 + 32 * cj;
+            a[cj][ri] = (r < m && c < m) ? A[(size_t)(base + r) * n + base + c] : 0.0;
+        }
+    for (int q = tid; q < E * EX_LD; q += 512) {
+        const int er = q / EX_LD, ec = q - er * EX_LD;
+        S[q] = (ec < m) ? A[(size_t)(base + er) * n + base + ec] : 0.0;
+    }
+    const int i = base + tid;                            // vector element owned by this thread (tid < m)
+    const bool own = tid < m;
+    const int rr = tid - E;                              // index inside the register block (0 <= rr < EM_M for its owners)
+    const bool rown = rr >= 0 && rr < EM_M;
+    const int pi = (rr & 15) * EM_RI + (rr >> 4);        // permuted slot of register-block row rr
+    double v_i = 0.0, tk = 0.0, p_i = 0.0, col_i = 0.0;
+    if (s_first >= 0) {
+        const double* st = ws.zt + (size_t)b * n * EG_MAXN;
+        if (own) { v_i = st[i]; p_i = st[EG_MAXN + i]; col_i = st[2 * EG_MAXN + i]; }
+        tk = st[3 * EG_MAXN];
+    } else if (own) col_i = A[i];                        // whole matrix: column 0
+    __syncthreads();
+    for (int s = s_first; s <= n - 2; ++s) {
+        const bool in = own && (i >= s + 1);
+        double w_i = 0.0, wpiv = 0.0;
+        if (s >= 0) {
+            if (own && i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wvi] = pv;
+            lds_barrier();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (own && i == s + 2) s_alpha = x_i;
+            double ss = (own && i >= s + 3) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wvi] = ss;
+            lds_barrier();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
+            }
+            vn_i = (own && i == s + 2) ? 1.0 : ((own && i > s + 2) ? x_i * scn : 0.0);
+        }
+        if (own && i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+        if (own && i >= s + 2) A[(size_t)(s + 1) * n + i] = vn_i;
+        if (s == n - 2) break;
+        if (rown) {
+            vnat[rr] = v_i; wnat[rr] = w_i;
+            vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
+        }
+        if (E > 0 && tid < EX_LD) { vL[tid] = v_i; wL[tid] = w_i; nL[tid] = vn_i; }
+        lds_barrier();
+        // ---- fused pass: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r   (rows >= s + 2; dead rows / columns are updated harmlessly)
+        const int lo = s + 2 - base;                     // first live local index (>= 0)
+        const int lor = max(lo - E, 0);                  // ... inside the register block
+        // ---- strip pass A (rows lo .. E-1 of the strip, all columns): the same update, column sums acc_c += x * vnext_row.
+        // thread = (column c, row parity); the E x E corner is stored in full, so its column sums cover both of its triangles
+        if (lo < E) {
+            const int c = tid & (EX_LD - 1), par = tid >> 8;
+            double accc = 0.0;
+            if (c < m) {
+                const double vc_ = vL[c], wc_ = wL[c];
+                for (int er = lo + par; er < E; er += 2) {
+                    const double x = S[er * EX_LD + c] - (vL[er] * wc_ + wL[er] * vc_);
+                    S[er * EX_LD + c] = x;
+                    accc += x * nL[er];
+                }
+            }
+            accA[par][c] = accc;
+        }
+        // the columns go in groups of two: 2 x 3 x EM_NC more live doubles (v_c, w_c, acc_c of every column) do not fit beside the block
+        {
+            const int ri0 = (lor - rs + 15) >> 4;
+            const double2* pv0 = reinterpret_cast<const double2*>(&vperm[0][rs * EM_RI]);
+            const double2* pv1 = reinterpret_cast<const double2*>(&vperm[1][rs * EM_RI]);
+            const double2* pv2 = reinterpret_cast<const double2*>(&vperm[2][rs * EM_RI]);
+            constexpr int CH = 2, NH = (EM_NC + CH - 1) / CH;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                double acc[CH], vc[CH], wc[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int cj = h * CH + u;
+                    acc[u] = 0.0;
+                    vc[u] = (cj < EM_NC) ? vnat[cl0 + 32 * (cj < EM_NC ? cj : 0)] : 0.0;
+                    wc[u] = (cj < EM_NC) ? wnat[cl0 + 32 * (cj < EM_NC ? cj : 0)] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < EM_RI / 2; ++q) {
+                    if (2 * q + 1 >= ri0) {              // rows rs + 16 (2q), rs + 16 (2q + 1)
+                        const double2 vr = pv0[q], wr = pv1[q], nr = pv2[q];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int cj = h * CH + u;
+                            if (cj < EM_NC) {
+                                double x0 = a[cj][2 * q], x1 = a[cj][2 * q + 1];
+                                x0 -= vr.x * wc[u] + wr.x * vc[u];
+                                x1 -= vr.y * wc[u] + wr.y * vc[u];
+                                a[cj][2 * q] = x0; a[cj][2 * q + 1] = x1;
+                                acc[u] += x0 * nr.x + x1 * nr.y;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (h * CH + u < EM_NC) accb[rs][cl0 + 32 * (h * CH + u)] = acc[u];
+            }
+        }
+        if (lo >= E && rs == (lor & 15)) {               // the lanes that hold pivot row s + 2 of the updated block publish it
+            switch (lor >> 4) {
+#define EM_CASE(k) case k: _Pragma("unroll") for (int cj = 0; cj < EM_NC; ++cj) prow[cl0 + 32 * cj] = a[cj][k]; break;
+                EM_CASE(0) EM_CASE(1) EM_CASE(2) EM_CASE(3) EM_CASE(4) EM_CASE(5) EM_CASE(6) EM_CASE(7) EM_CASE(8) EM_CASE(9) EM_CASE(10) EM_CASE(11)
+                EM_CASE(12) EM_CASE(13)
+#undef EM_CASE
+            }
+        }
+        lds_barrier();
+        // ---- strip pass B: row sums of the updated strip over the register block's columns (the transposed half of the off-diagonal
+        // block, which is not stored): thread = (row er, 16 threads per row), 16-lane reduction
+        if (lo < E) {
+            const int er = tid >> 4, j = tid & 15;
+            double t = 0.0;
+            if (er >= lo && er < E)
+                for (int c = E + j; c < m; c += 16) t += S[er * EX_LD + c] * nL[c];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+            if (j == 0 && er < EX_E) accB[er] = t;
+            lds_barrier();
+        }
+        if (tid < EX_LD) {
+            double t = 0.0;
+            if (rown) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t += accb[q][rr];
+            }
+            if (lo < E) t += (accA[0][tid] + accA[1][tid]) + ((tid < E) ? accB[tid] : 0.0);
+            p_i = t;
+            // pivot row s + 2 of the updated block = the next pivot column: from the strip while it is alive, then from the register block
+            col_i = (tid >= lo && tid < m) ? ((lo < E) ? S[lo * EX_LD + tid] : (rown ? prow[rr] : 0.0)) : 0.0;
+        }
+        v_i = vn_i;
+        tk = tn;
+        // the next iteration's first barrier orders these reads against its LDS writes
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------ e2
 // grid (ceil(n / (256/NL)), B), block 256.  NL lanes -> one eigenvalue (j-th smallest) by (NL+1)-section on the Sturm count: every
 // round the NL lanes evaluate the count at NL interior points of the current interval, so ~17 rounds at NL = 8 (instead of 53
@@ -1572,7 +1768,13 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             }
             static int mid_on = -1;                        // NELE_EIGH_MID=0: hand over to the LDS tail kernel at 128 instead (A/B diagnostic)
             if (mid_on < 0) { const char* e_ = getenv("NELE_EIGH_MID"); mid_on = !(e_ && e_[0] == '0'); }
-            const int mhand = (tail_on && mid_on) ? EM_M : ET_M;
+            static int midx_on = -1;                       // NELE_EIGH_MIDX=0: hand over at 224 (registers only) instead of 256 (registers + LDS strip)
+            if (midx_on < 0) {
+                const char* e_ = getenv("NELE_EIGH_MIDX");
+                midx_on = !(e_ && e_[0] == '0');
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            }
+            const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
             // NELE_EIGH_P4_BATCH: matrices per launch (default 64 = the whole chip).  The spinning workgroups own their CU - registers
             // full, issue slots mostly idle - so 32 per launch (half the chip, twice the launches) leaves room for the step's other
@@ -1586,7 +1788,8 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             }
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);
-                if (mhand == EM_M) hipLaunchKernelGGL(eigh_tridiag_mid_kernel, dim3(B), dim3(512), 0, s, A, n, ws, s_stop + 1);
+                if (mhand == EM_M + EX_E) hipLaunchKernelGGL(eigh_tridiag_midx_kernel, dim3(B), dim3(512), sizeof(double) * EX_E * EX_LD, s, A, n, ws, s_stop + 1);
+                else if (mhand == EM_M) hipLaunchKernelGGL(eigh_tridiag_mid_kernel, dim3(B), dim3(512), 0, s, A, n, ws, s_stop + 1);
                 else hipLaunchKernelGGL(eigh_tridiag_tail_kernel, dim3(B), dim3(512), sizeof(double) * (size_t)mt * mt, s, A, n, ws, s_stop + 1);
             }
         } else {
