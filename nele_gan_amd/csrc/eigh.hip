@@ -929,9 +929,12 @@ __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restric
 // strip S[E][256] (full rows: the E x E corner is stored twice, the off-diagonal block once), the other 224 x 224 in registers as above.
 // While the strip is alive (the first E steps) a step also updates it in place - pass A: thread per column, column sums; pass B: thread
 // group per row, the row sums that stand in for the transposed off-diagonal block - and takes the next pivot column from it.  The
-// cluster kernel, whose step costs 7.2 us on FOUR CUs that no other kernel can share (registers full), hands over 32 steps earlier.
-#define EX_E 32
+// cluster kernel, whose step costs 7.2 us on FOUR CUs that no other kernel can share (registers full), hands over 32 steps earlier
+// (LDS: 64 KB of strip + 52 KB of vectors and partial sums).
+#ifndef EX_E
+#define EX_E 32                       // (48 rows x 272 columns, 102 KB, measured: the step gains nothing more - 44.9 / 44.9 / 45.4 against 44.9 / 45.2 / 45.2 ms)
 #define EX_LD 256
+#endif
 __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
     extern __shared__ double em_strip[];                  // S[E][EX_LD]: rows 0 .. E-1 of the trailing block, all its columns
     __shared__ __attribute__((aligned(16))) double vperm[3][EM_M + 64];   // v, w, v_next of the register block at [(r & 15) * (EM_RI) + (r >> 4)]
@@ -1032,17 +1035,21 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
         // ---- strip pass A (rows lo .. E-1 of the strip, all columns): the same update, column sums acc_c += x * vnext_row.
         // thread = (column c, row parity); the E x E corner is stored in full, so its column sums cover both of its triangles
         if (lo < E) {
-            const int c = tid & (EX_LD - 1), par = tid >> 8;
+            // 512 threads for EX_LD columns x 2 row parities (EX_LD = 256: one thread per column and parity; wider strips: the columns
+            // beyond 512 - EX_LD have one thread for all rows)
+            const int par = tid >= EX_LD ? 1 : 0, c = tid - par * EX_LD;
+            const int stp = (c < 512 - EX_LD) ? 2 : 1;
             double accc = 0.0;
             if (c < m) {
                 const double vc_ = vL[c], wc_ = wL[c];
-                for (int er = lo + par; er < E; er += 2) {
+                for (int er = lo + (stp == 2 ? par : 0); er < E; er += stp) {
                     const double x = S[er * EX_LD + c] - (vL[er] * wc_ + wL[er] * vc_);
                     S[er * EX_LD + c] = x;
                     accc += x * nL[er];
                 }
             }
             accA[par][c] = accc;
+            if (par == 0 && stp == 1) accA[1][c] = 0.0;
         }
         // the columns go in groups of two: 2 x 3 x EM_NC more live doubles (v_c, w_c, acc_c of every column) do not fit beside the block
         {
@@ -1095,12 +1102,14 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
         // ---- strip pass B: row sums of the updated strip over the register block's columns (the transposed half of the off-diagonal
         // block, which is not stored): thread = (row er, 16 threads per row), 16-lane reduction
         if (lo < E) {
-            const int er = tid >> 4, j = tid & 15;
-            double t = 0.0;
-            if (er >= lo && er < E)
-                for (int c = E + j; c < m; c += 16) t += S[er * EX_LD + c] * nL[c];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
-            if (j == 0 && er < EX_E) accB[er] = t;
+            const int j = tid & 15;
+            for (int er = tid >> 4; er < E; er += 32) {      // (uniform trip count per 16-lane group)
+                double t = 0.0;
+                if (er >= lo)
+                    for (int c = E + j; c < m; c += 16) t += S[er * EX_LD + c] * nL[c];
+                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+                if (j == 0) accB[er] = t;
+            }
             lds_barrier();
         }
         if (tid < EX_LD) {
@@ -1772,7 +1781,7 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             if (midx_on < 0) {
                 const char* e_ = getenv("NELE_EIGH_MIDX");
                 midx_on = !(e_ && e_[0] == '0');
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
             }
             const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
