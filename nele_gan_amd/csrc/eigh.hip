@@ -1223,8 +1223,12 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
 // factorisation time so that the back-substitution chain is two FMAs and a multiply (the reference's tiny-pivot perturbation
 // runs on a slow path when that product is not finite or too large).
 // arrays: 0 a, 1 b, 2 c (stored at step+1, next to the iterate element it meets in the forward sweep), 3 d2, 4 x, 5 1/a
-#define IV_F 32     // forward-sweep chunk (steps)
+#ifndef IV_F
+#define IV_F 32     // forward-sweep chunk (steps; 32 or 16: the interchange masks are one word per 32 steps)
+#endif
+#ifndef IV_B
 #define IV_B 16     // backward-sweep chunk (steps)
+#endif
 __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in, int extra) {
     __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
@@ -1331,7 +1335,7 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
                     yk[u] = LUP(4, pr);
                     ck[u] = LUP(2, pr);
                 }
-                m = pinm[(size_t)ci * EG_MAXN + j];
+                m = pinm[(size_t)((IV_F * ci) >> 5) * EG_MAXN + j] >> ((IV_F * ci) & 31);
             };
             auto fstep = [&](int t, double yraw, double c, int bit) {
                 if (t >= 1 && t <= n - 1) {
