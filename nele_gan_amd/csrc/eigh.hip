@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
 // of a chunk hides behind the previous chunk.  Row interchanges are one 32-bit mask per 32 steps; 1/pivot is stored at
 // factorisation time so that the back-substitution chain is two FMAs and a multiply (the reference's tiny-pivot perturbation
 // runs on a slow path when that product is not finite or too large).
-// arrays: 0 a, 1 b, 2 c (stored at step+1, next to the iterate element it meets in the forward sweep), 3 d2, 4 x, 5 1/a
+// arrays: 0 - (the pivots a: no longer stored), 1 b, 2 c (stored at step+1, next to the iterate element it meets in the forward sweep), 3 d2, 4 x, 5 1/a
 #ifndef IV_F
 #define IV_F 32     // forward-sweep chunk (steps; 32 or 16: the interchange masks are one word per 32 steps)
 #endif
@@ -1260,6 +1260,20 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
     if (n > 1) onenrm = fmax(onenrm, fabs(d[n - 1]) + fabs(e[n - 2]));
     for (int i = 1; i < n - 1; ++i) onenrm = fmax(onenrm, fabs(d[i]) + fabs(e[i - 1]) + fabs(e[i]));
     const double dtpcrt = sqrt(0.1 / (double)n);
+    // ---- start vector: deterministic pseudo-random in (-1, 1), never stored.  The first forward elimination rides inside the
+    // factorisation below (its multiplier and interchange of step k are at hand the moment they are computed) on the UNSCALED vector -
+    // the elimination is linear, and dstein's scale factor needs the last pivot - so the first sweep reads nothing and writes only the
+    // eliminated right-hand side: 14 KB less HBM traffic per eigenvector than storing the vector and sweeping over it (82 KB before).
+    const unsigned int rs0 = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
+    auto lcg = [](unsigned int& rs) {
+        rs = rs * 1664525u + 1013904223u;
+        return ((double)(rs >> 8) / 8388608.0) - 1.0;
+    };
+    double asum = 0.0, s2 = 0.0;
+    {
+        unsigned int rs = rs0;
+        for (int i = 0; i < n; ++i) asum += fabs(lcg(rs));
+    }
     // ---- dlagtf: LU of T - xj I with partial pivoting; the recurrence values live in registers, every output element is
     // stored once.  The pivot test |c|/scale2 <= |a|/scale1 is evaluated cross-multiplied (no divisions on the chain).
     double tol = 0.0, alast;
@@ -1268,11 +1282,14 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
         double bcur = (n > 1) ? e[0] : 0.0;             // b[k] as modified by step k-1
         double scale1 = fabs(acur) + fabs(bcur);
         unsigned mask = 0;
+        unsigned int rs = rs0;
+        double yprev = lcg(rs);                         // forward elimination of the (unscaled) start vector
         for (int k = 0; k < n - 1; ++k) {
             const double ak = acur, bk = bcur, ak1 = d[k + 1] - xj, ck = e[k];
             const double bk1 = (k < n - 2) ? e[k + 1] : 0.0;
             const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
             double a_out = ak, b_out = bk, c_out = ck, d2_out = 0.0, a_next = ak1, b_next = bk1, r;
+            bool swapped = false;
             if (ck == 0.0) {
                 scale1 = scale2;
                 r = 1.0 / ak;
@@ -1283,6 +1300,7 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
                 a_next = ak1 - c_out * bk;
             } else {
                 mask |= 1u << ((k + 1) & 31);
+                swapped = true;
                 r = 1.0 / ck;
                 const double mult = ak * r;
                 a_out = ck;
@@ -1292,32 +1310,25 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
                 b_out = ak1;
                 c_out = mult;
             }
-            LUE(0, k) = a_out;
             LUE(1, k) = b_out;
             LUE(2, k + 1) = c_out;
             LUE(3, k) = d2_out;
             LUE(5, k) = r;
+            {                                           // element t = k + 1 of the start vector meets c[t] (see the forward sweep below)
+                const double y = lcg(rs);
+                if (!swapped) { LUE(4, k) = yprev; yprev = y - c_out * yprev; }
+                else { LUE(4, k) = y; yprev = yprev - c_out * y; }
+            }
             tol = fmax(fmax(tol, fabs(a_out)), fmax(fabs(b_out), fabs(d2_out)));
             if (((k + 1) & 31) == 31 || k == n - 2) { pinm[(size_t)((k + 1) >> 5) * EG_MAXN + j] = (int)mask; mask = 0; }
             acur = a_next;
             bcur = b_next;
         }
-        LUE(0, n - 1) = acur;
         LUE(5, n - 1) = 1.0 / acur;
+        LUE(4, n - 1) = yprev;
         alast = fabs(acur);
         tol = fmax(tol, alast) * eps;
         if (tol == 0.0) tol = eps;
-    }
-    // ---- start vector: deterministic pseudo-random in (-1, 1)
-    double asum = 0.0, s2 = 0.0;
-    {
-        unsigned int rs = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
-        for (int i = 0; i < n; ++i) {
-            rs = rs * 1664525u + 1013904223u;
-            const double v = ((double)(rs >> 8) / 8388608.0) - 1.0;
-            LUE(4, i) = v;
-            asum += fabs(v);
-        }
     }
     const int nf = (n + IV_F - 1) / IV_F;             // forward chunks over t = step + 1 in [1, n)
     const int cbtop = (n - 1) / IV_B;                 // backward chunks over k, cb = cbtop .. 0
@@ -1326,7 +1337,8 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
         // scale: ||x||_1 -> n * onenrm * max(eps, |a_n|)   (folded into the loads of the forward sweep)
         const double scl = (double)n * onenrm * fmax(eps, alast) / asum;
         // ---- forward elimination with the recorded row interchanges; element t = step + 1 meets c[t] (= c of step t-1)
-        {
+        // (the first one was done during the factorisation, unscaled: its scale factor is applied by the back substitution)
+        if (its > 0) {
             double yprev = scl * LUE(4, 0);
             auto fload = [&](int ci, double2 (&yk)[IV_F / 2], double2 (&ck)[IV_F / 2], int& m) {
 #pragma unroll
@@ -1366,6 +1378,7 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
             LUE(4, n - 1) = yprev;
         }
         // ---- back substitution, perturbing tiny pivots (job = -1)
+        const double sclb = (its == 0) ? scl : 1.0;
         double y1 = 0.0, y2 = 0.0;   // x[k+1], x[k+2]
         double nrm = 0.0;
         asum = 0.0;
@@ -1383,10 +1396,10 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
             };
             auto bstep = [&](int k, double xv, double rv, double bv, double dv) {
                 if (k <= n - 1) {
-                    double temp = xv - ((k <= n - 2) ? bv : 0.0) * y1 - ((k <= n - 3) ? dv : 0.0) * y2;
+                    double temp = sclb * xv - ((k <= n - 2) ? bv : 0.0) * y1 - ((k <= n - 3) ? dv : 0.0) * y2;
                     double xk = temp * rv;
                     if (!(fabs(xk) <= bignum)) {                   // slow path: the reference's pivot perturbation
-                        double ak = LUE(0, k);
+                        double ak = 1.0 / rv;              // (the pivot itself is not stored: only this slow path wanted it)
                         double pert = copysign(tol, ak);
                         for (int guard = 0; guard < 200; ++guard) {
                             const double absak = fabs(ak);
