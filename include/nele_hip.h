@@ -278,7 +278,8 @@ int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void*
                           void* stream);
 
 /* intel.py:108-114 HASPI_Wrapper[_raw]_harvard -> pyHASPI/pyhaspi2.py:76-107 haspi_v2(x, fs, y, fs), HL = 0.
- * fs_in 16000 (resampled to 24 kHz as librosa.resample / resampy kaiser_best, pyhaspi2.py:815) or 24000.
+ * fs_in: any rate up to 24000 Hz (below it the signals are resampled to 24 kHz as librosa.resample = resampy kaiser_best + fix_length,
+ * pyhaspi2.py:810-821; above it the reference raises NotImplementedError and so does this call).
  * dither: NULL (no IHC firing jitter) or float64 standard normals [B][2][nsub][32], nsub =
  * nele_metric_haspi_nsub(L, fs_in); row k perturbs the k-th ACTIVE sub-sampled frame exactly as the reference's
  * np.random.randn(n_active, 32) draws (pyhaspi2.py:362-365).  info [B][2] (may be NULL) = {active frames,

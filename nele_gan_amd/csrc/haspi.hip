@@ -89,10 +89,13 @@ struct HaspiWs {
 
 // Per-utterance lengths inside one padded batch (the reference is batch 1 over files of any length, audio_util.py:134-141)
 __device__ __forceinline__ int hp_len(const HaspiWs& ws, int b, int L) { return ws.lens ? min(ws.lens[b], L) : L; }
+// Length at 24 kHz of an input of L samples at fs_in < 24 kHz (pyhaspi2.py:815 -> librosa.resample, fix=True): resampy writes
+// int(L * ratio) outputs (hp_nres_of), librosa pads with zeros to ceil(L * ratio) (hp_n24_of); ratio = float(24000) / fs_in.
+__host__ __device__ static inline int hp_n24_of(int L, int fs_in) { return fs_in == 24000 ? L : (int)ceil((double)L * (24000.0 / (double)fs_in)); }
+__host__ __device__ static inline int hp_nres_of(int L, int fs_in) { return fs_in == 24000 ? L : (int)((double)L * (24000.0 / (double)fs_in)); }
 __device__ __forceinline__ int hp_n24(const HaspiWs& ws, int b) {
     if (!ws.lens) return ws.n24;
-    const int Lb = ws.lens[b];
-    return min(ws.n24, (ws.fs_in == 24000) ? Lb : (int)((double)Lb * 1.5));
+    return min(ws.n24, hp_n24_of(ws.lens[b], ws.fs_in));
 }
 __device__ __forceinline__ int hp_nsub(const HaspiWs& ws, int b) { return (hp_n24(ws, b) + HP_SPACE - 1) / HP_SPACE; }
 // (utterance, signal) row of a launch that covers nsig signals starting at sig0: idx = b * nsig + s
@@ -216,7 +219,10 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     const float* src = (sig ? y : x) + (size_t)b * Lmax;
     float* dst = ws.r24 + (size_t)row * ws.n24p;
     const float rms = ws.rinfo[(size_t)row * 4];
-    const double time_increment = 1.0 / 1.5;
+    // resampy: sample_ratio = float(sr_new) / sr_orig, time_increment = 1 / sample_ratio (1 / 1.5 for 16 kHz inputs)
+    const double time_increment = 1.0 / (24000.0 / (double)ws.fs_in);
+    const bool three_phase = ws.fs_in == 16000;       // other rates (pyhaspi2.py:814: anything below 24 kHz) take the general tap loops below
+    const int n_res = hp_nres_of(L, ws.fs_in);        // resampy's output count; librosa pads with zeros up to n24 = ceil(L * ratio)
     for (int e = tid; e < 3 * 2 * 66; e += 256) {
         const int ph = e / 132, wing = (e - ph * 132) / 66, i = e - ph * 132 - wing * 66;
         const double tr = (double)ph * time_increment;
@@ -232,13 +238,14 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
             w = v + eta * ((idx + 1 < HP_NWIN) ? ws.win[idx + 1] - v : 0.0);
         }
         wt[ph][wing][i] = w;
-        if (i == 0) woff[ph][wing] = offset;
+        if (i == 0) woff[ph][wing] = three_phase ? offset : -1;
     }
     double a2 = 0.0;
     const int nbase = max(0, (int)((double)t0 * time_increment) - 66);
     for (int e = tid; e < RS_IN; e += 256) xsn[e] = (nbase + e < L) ? (double)(src[nbase + e] / rms) : 0.0;
     __syncthreads();
     for (int t = t0 + tid; t < min(n24, t0 + RS_CH); t += 256) {
+        if (t >= n_res) { dst[t] = 0.f; continue; }  // librosa.util.fix_length's padding
         const int ph = t % 3;
         const double time_register = (double)t * time_increment;
         const int n = (int)time_register;
@@ -1819,7 +1826,7 @@ __global__ void haspi_final_kernel(HaspiWs ws, float* __restrict__ raw, float* _
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
-    const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
+    const int n24 = hp_n24_of(L, fs_in);
     const int nsub = (n24 + HP_SPACE - 1) / HP_SPACE;
     const int n24p = (n24 + 31) / 32 * 32;
     size_t o = 0;
@@ -1866,7 +1873,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
 extern "C" long long nele_metric_haspi_workspace_bytes(int B, int L, int fs_in) { return (long long)haspi_layout(B, L, fs_in, nullptr, nullptr); }
 
 extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
-    const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
+    const int n24 = hp_n24_of(L, fs_in);
     return (n24 + HP_SPACE - 1) / HP_SPACE;
 }
 
@@ -1996,7 +2003,8 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
     HpHL hl;
     { const int st_ = haspi_hl_table(hl6, itype, &hl); if (st_) return st_; }
     NELE_CHECK_ARG((x || phase == 4) && (y || phase == 3) && (raw || mapped || phase == 3), "nele_metric_haspi: missing signal / output for phase %d", phase);
-    NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi: fs must be 16000 or 24000 (got %d)", fs_in);
+    // pyhaspi2.py:810-821: 24 kHz passes through, lower rates are resampled, higher ones raise NotImplementedError in the reference
+    NELE_CHECK_ARG(fs_in >= 1000 && fs_in <= 24000, "nele_metric_haspi: fs must be in [1000, 24000] Hz (got %d; the reference has no downsampler)", fs_in);
     if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi: L=%d too short", L);
     if (workspace_bytes < nele_metric_haspi_workspace_bytes(B, L, fs_in))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_haspi: workspace too small");

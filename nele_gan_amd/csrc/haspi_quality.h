@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void hq_final_kernel(HaspiWs ws, QualWs q, dou
 
 static size_t quality_layout(int B, int L, int fs_in, HaspiWs* w, QualWs* q, char* base) {
     size_t o = haspi_layout(B, L, fs_in, w, base);
-    const int n24 = (fs_in == 24000) ? L : (int)((double)L * 1.5);
+    const int n24 = hp_n24_of(L, fs_in);
     const int n24p = (n24 + 31) / 32 * 32;
     const int nseg = 1 + n24 / HQ_NWIN + (n24 - HQ_NHALF) / HQ_NWIN;
     int lc = GS_LC;
@@ -545,7 +545,7 @@ static int haspi_quality_impl(const float* x, const float* y, const int* lengths
     NELE_CHECK_ARG(x && y && out && workspace && B > 0, "nele_metric_haspi_quality: bad arguments");
     HpHL hl;
     { const int st_ = haspi_hl_table(hl6, itype, &hl); if (st_) return st_; }
-    NELE_CHECK_ARG(fs_in == 16000 || fs_in == 24000, "nele_metric_haspi_quality: fs must be 16000 or 24000 (got %d)", fs_in);
+    NELE_CHECK_ARG(fs_in >= 1000 && fs_in <= 24000, "nele_metric_haspi_quality: fs must be in [1000, 24000] Hz (got %d; the reference has no downsampler)", fs_in);
     if (L < 2400) return nele_set_error(NELE_ERR_SIGNAL, "nele_metric_haspi_quality: L=%d too short", L);
     if (workspace_bytes < nele_metric_haspi_quality_workspace_bytes(B, L, fs_in))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_haspi_quality: workspace too small");

@@ -174,14 +174,16 @@ def resample_24k(x, fsampx):
     """pyhaspi2.py:810-821."""
     if fsampx == FSAMP:
         return x
-    assert fsampx == 16000
+    if fsampx > FSAMP:
+        raise NotImplementedError                            # pyhaspi2.py:819-820
     x = np.ascontiguousarray(x, dtype=np.float32)           # x / rms_x is float32 in the reference
     ratio = float(FSAMP) / fsampx
-    n_out = int(x.shape[0] * ratio)
+    n_out = int(x.shape[0] * ratio)                          # resampy.resample: int(shape * sample_ratio) outputs ...
+    n_fix = int(np.ceil(x.shape[0] * ratio))                 # ... librosa.resample(fix=True): zero-padded to ceil(n * ratio)
     win, num_table = resample_filter()
     delta = np.zeros_like(win)
     delta[:-1] = np.diff(win)
-    y = np.zeros(n_out, dtype=np.float32)
+    y = np.zeros(n_fix, dtype=np.float32)
     fp = ctypes.POINTER(ctypes.c_float)
     _lib().resample_f32(x.ctypes.data_as(fp), x.shape[0], y.ctypes.data_as(fp), n_out, ratio, _dp(win), _dp(delta), win.shape[0], num_table)
     xRMS = np.sqrt(np.mean(x ** 2))

@@ -117,6 +117,32 @@ def test_haspi_16k_batch_vs_oracle(mt):
     assert raw[2] == pytest.approx(float(np.sum(H.WEIGHTS)), rel=1e-6)
 
 
+@pytest.mark.parametrize('fs,L', [(22050, 33075), (8000, 12000), (16000, 24001), (11025, 16001)])
+def test_haspi_other_sampling_rates_vs_oracle(mt, fs, L):
+    """pyhaspi2.py:810-821: any rate below 24 kHz goes through librosa.resample (the reference's own demo pair is 22.05 kHz);
+    odd lengths exercise librosa's fix_length padding (ceil(L * ratio) samples, the last one zero)."""
+    from nele_gan_amd import synth
+    from oracle import haspi as H
+    c, v = synth.batch(2, L, start=85)
+    y = c + v
+    raw, mapped, info = mt.batch_haspi(c, y, fs=fs, dither=None, return_info=True)
+    raw = raw.cpu().numpy()
+    for b in range(2):
+        ref, parts = H.haspi_v2(c[b], fs, y[b], fs, return_parts=True)
+        assert int(info[b, 0]) == len(parts['index'])                 # active sub-frames: integer-exact
+        assert raw[b] == pytest.approx(ref, rel=1e-4)
+    q = mt.batch_haspi_quality(c, y, fs=fs, noise=False).cpu().numpy()
+    for b in range(2):
+        assert q[b, 0] == pytest.approx(H.haspi_v1(c[b], fs, y[b], fs)[0], rel=1e-4)
+
+
+def test_haspi_above_24k_is_refused_like_the_reference(mt):
+    from nele_gan_amd import synth
+    c, v = synth.batch(1, 44100, start=86)
+    with pytest.raises(Exception):                                     # NotImplementedError at pyhaspi2.py:819-820
+        mt.batch_haspi(c, c + v, fs=44100, dither=None)
+
+
 def test_haspi_random_dither_is_small_and_seeded(mt):
     from nele_gan_amd import synth
     c, v = synth.batch(1, 24000, start=90)
