@@ -295,6 +295,146 @@ __global__ __launch_bounds__(256) void haspi_resample_kernel(const float* __rest
     if (tid == 0) ws.rsp[(size_t)row * RS_MAXC + blockIdx.x] = a2;
 }
 
+// ---- 16 -> 24 kHz, a thread per output TRIPLE (second session of round 3).  haspi_resample_kernel above pays two LDS reads per tap (the
+// tap weight of the lane's phase and the sample) and is bound by exactly that (the LDS pipe of a CU moves one 8-byte read of a wave in 4
+// cycles; the three dependent float64 operations of a tap take 12 on its SIMD, four SIMDs share the pipe).  Here thread q owns outputs
+// 3q, 3q+1, 3q+2: their input positions are 2q, 2q, 2q+1, so phases 0 and 1 meet the SAME sample at every tap step and phase 2 meets the
+// previous step's - one LDS read per step serves three taps - and since every lane runs the same three phases the tap weights are uniform:
+// they come from a 2 x 64 x 4 table in memory by scalar loads (haspi_rs_taps_kernel, built once per call next to the window), no LDS
+// read at all.  Each output's own chain is unchanged - left wing then right wing, every tap rounded to float32 like resampy's float32
+// accumulator - so the samples are bit-identical to the kernel above; taps the reference does not execute at the signal's ends (n - i < 0,
+// n + k + 1 >= L) meet a staged zero, and fma(w, 0, y) = y exactly.  Outputs whose float64 position arithmetic (t / 1.5 as the reference
+// rounds it) does not land on the expected (n, offset) take the general loops.  grid (chunks, nsig, B), block 256, RS_CH = 768 outputs.
+#define RS3_NT 64                       // taps per wing in the table: (HP_NWIN - offset) / HP_NTAB <= 64, zero beyond a phase's own count
+#define HP_NWIN_AL 32776                // window length rounded up to 8 doubles: the tap table follows it in the workspace
+#define RS3_TAB (2 * RS3_NT * 4 + 8)    // [wing][i][phase 0..2, pad] + the six table offsets
+__global__ __launch_bounds__(256) void haspi_rs_taps_kernel(double* __restrict__ win) {
+    double* tab = win + HP_NWIN_AL;
+    const double time_increment = 1.0 / 1.5;
+    for (int e = threadIdx.x; e < 2 * RS3_NT * 4; e += 256) {
+        const int ph = e & 3, i = (e >> 2) % RS3_NT, wing = e / (4 * RS3_NT);
+        double w = 0.0;
+        if (ph < 3) {
+            const double tr = (double)ph * time_increment;
+            double frac = tr - (double)(int)tr;
+            if (wing) frac = 1.0 - frac;
+            const double index_frac = frac * HP_NTAB;
+            const int offset = (int)index_frac;
+            const double eta = index_frac - offset;
+            const int idx = offset + i * HP_NTAB;
+            if (i < (HP_NWIN - offset) / HP_NTAB) {                  // resampy's i_max / k_max of an interior output
+                const double v = win[idx];
+                w = v + eta * ((idx + 1 < HP_NWIN) ? win[idx + 1] - v : 0.0);
+            }
+            if (i == 0) tab[2 * RS3_NT * 4 + ph * 2 + wing] = (double)offset;
+        }
+        tab[e] = w;
+    }
+}
+
+// one output by resampy's loops as they stand (window indexed in memory): irregular positions of the triple kernel
+__device__ __noinline__ float rs_general_output(const float* __restrict__ src, float rms, int L, const double* __restrict__ win, int t, double time_increment) {
+    const double time_register = (double)t * time_increment;
+    const int n = (int)time_register;
+    double frac = time_register - (double)n;
+    double index_frac = frac * HP_NTAB;
+    int offset = (int)index_frac;
+    double eta = index_frac - offset;
+    int i_max = (HP_NWIN - offset) / HP_NTAB;
+    if (n + 1 < i_max) i_max = n + 1;
+    float yv = 0.f;
+    for (int i = 0; i < i_max; ++i) {
+        const int idx = offset + i * HP_NTAB;
+        const double d = (idx + 1 < HP_NWIN) ? win[idx + 1] - win[idx] : 0.0;
+        const double w = win[idx] + eta * d;
+        yv = (float)fma(w, (double)(src[n - i] / rms), (double)yv);
+    }
+    frac = 1.0 - frac;
+    index_frac = frac * HP_NTAB;
+    offset = (int)index_frac;
+    eta = index_frac - offset;
+    int k_max = (HP_NWIN - offset) / HP_NTAB;
+    if (L - n - 1 < k_max) k_max = L - n - 1;
+    for (int k = 0; k < k_max; ++k) {
+        const int idx = offset + k * HP_NTAB;
+        const double d = (idx + 1 < HP_NWIN) ? win[idx + 1] - win[idx] : 0.0;
+        const double w = win[idx] + eta * d;
+        yv = (float)fma(w, (double)(src[n + k + 1] / rms), (double)yv);
+    }
+    return yv;
+}
+
+__global__ __launch_bounds__(256) void haspi_resample3_kernel(const float* __restrict__ x, const float* __restrict__ y, int Lmax, HaspiWs ws,
+                                                              int sig0) {
+    __shared__ double red[8];
+    constexpr int RS_IN = RS_CH * 2 / 3 + 2 * RS3_NT + 8;
+    __shared__ double xsn[RS_IN];
+    const int b = blockIdx.z, sig = sig0 + blockIdx.y, tid = threadIdx.x, row = 2 * b + sig;
+    const int L = hp_len(ws, b, Lmax), n24 = hp_n24(ws, b);
+    const int t0 = blockIdx.x * RS_CH;
+    if (t0 >= n24) return;
+    const int n_res = hp_nres_of(L, 16000);
+    const float* src = (sig ? y : x) + (size_t)b * Lmax;
+    float* dst = ws.r24 + (size_t)row * ws.n24p;
+    const float rms = ws.rinfo[(size_t)row * 4];
+    const double* __restrict__ tab = ws.win + HP_NWIN_AL;            // uniform indices below: scalar loads
+    const double time_increment = 1.0 / 1.5;
+    const int q0 = t0 / 3;
+    const int nbase = 2 * q0 - RS3_NT - 2;                           // first staged input (may lie before the signal: zeros)
+    for (int e = tid; e < RS_IN; e += 256) {
+        const int idx = nbase + e;
+        xsn[e] = (idx >= 0 && idx < L) ? (double)(src[idx] / rms) : 0.0;
+    }
+    __syncthreads();
+    const int q = q0 + tid;
+    bool regular = true;
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        const double time_register = (double)(3 * q + ph) * time_increment;
+        const int n = (int)time_register;
+        const double frac = time_register - (double)n;
+        const int offl = (int)(frac * HP_NTAB), offr = (int)((1.0 - frac) * HP_NTAB);
+        regular = regular && n == 2 * q + (ph == 2) && offl == (int)tab[2 * RS3_NT * 4 + ph * 2] && offr == (int)tab[2 * RS3_NT * 4 + ph * 2 + 1];
+    }
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    if (regular) {
+        const double* xc = xsn + (2 * q - nbase);
+        double xb = xc[1];
+#pragma unroll 8
+        for (int i = 0; i < RS3_NT; ++i) {                           // left wings: x[2q - i] (phases 0, 1), x[2q + 1 - i] (phase 2)
+            const double xa = xc[-i];
+            y0 = (float)fma(tab[4 * i], xa, (double)y0);
+            y1 = (float)fma(tab[4 * i + 1], xa, (double)y1);
+            y2 = (float)fma(tab[4 * i + 2], xb, (double)y2);
+            xb = xa;
+        }
+        const double* __restrict__ tabr = tab + 4 * RS3_NT;
+        double xa = xc[1];
+#pragma unroll 8
+        for (int k = 0; k < RS3_NT; ++k) {                           // right wings: x[2q + 1 + k] (phases 0, 1), x[2q + 2 + k] (phase 2)
+            const double xn = xc[2 + k];
+            y0 = (float)fma(tabr[4 * k], xa, (double)y0);
+            y1 = (float)fma(tabr[4 * k + 1], xa, (double)y1);
+            y2 = (float)fma(tabr[4 * k + 2], xn, (double)y2);
+            xa = xn;
+        }
+    } else {
+        const int t = 3 * q;
+        if (t < n_res) y0 = rs_general_output(src, rms, L, ws.win, t, time_increment);
+        if (t + 1 < n_res) y1 = rs_general_output(src, rms, L, ws.win, t + 1, time_increment);
+        if (t + 2 < n_res) y2 = rs_general_output(src, rms, L, ws.win, t + 2, time_increment);
+    }
+    double a2 = 0.0;
+    {
+        const int t = 3 * q;
+        if (t < n24) { const float v = (t < n_res) ? y0 : 0.f; dst[t] = v; a2 += (double)(v * v); }       // t >= n_res: librosa's fix_length padding
+        if (t + 1 < n24) { const float v = (t + 1 < n_res) ? y1 : 0.f; dst[t + 1] = v; a2 += (double)(v * v); }
+        if (t + 2 < n24) { const float v = (t + 2 < n_res) ? y2 : 0.f; dst[t + 2] = v; a2 += (double)(v * v); }
+    }
+    a2 = block_sum(a2, red);
+    if (tid == 0) ws.rsp[(size_t)row * RS_MAXC + blockIdx.x] = a2;
+}
+
 // y = (xRMS / yRMS) * y (pyhaspi2.py:816-818).  grid rows, block 64: the chunk partials are added in chunk order by one lane.
 __global__ void haspi_resample_gain_kernel(HaspiWs ws, int sig0, int nsig) {
     const int row = hp_row(blockIdx.x, sig0, nsig);
@@ -1831,7 +1971,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     const int n24p = (n24 + 31) / 32 * 32;
     size_t o = 0;
 #define TAKE(field, type, count) do { if (w) w->field = (type*)(base + o); o += al(sizeof(type) * (size_t)(count)); } while (0)
-    TAKE(win, double, HP_NWIN);
+    TAKE(win, double, HP_NWIN_AL + RS3_TAB);           // resampler half window + the 16 kHz tap table
     TAKE(r24, float, (size_t)B * 2 * n24p);
     TAKE(mid, double, (size_t)B * 2 * n24p);
     TAKE(ctl, hp_env_t, (size_t)B * 2 * n24p * HP_NCH);
@@ -1894,6 +2034,12 @@ static const HaspiFlags& haspi_flags() {
 // lp in group-space rows (HaspiWs::lp_raw): whenever haspi_ihc_fir9_kernel produces it
 static int haspi_lp_raw() { const HaspiFlags& f = haspi_flags(); return f.par_iir && f.fused_gain && f.fir9; }
 
+// resampler window + the 16 kHz tap table behind it (kept in the workspace: the split calls' later phases reuse them)
+static void haspi_build_window(const HaspiWs& ws, hipStream_t s) {
+    hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
+    hipLaunchKernelGGL(haspi_rs_taps_kernel, dim3(1), dim3(256), 0, s, ws.win);
+}
+
 // The ear model + envelope chain of signals sig0 .. sig0+nsig-1 (h1 .. h9 of the header comment).
 static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in, const HaspiWs& ws_in, int sig0, int nsig, hipStream_t s,
                         bool quality = false) {
@@ -1908,7 +2054,12 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     ws.fmul = 1;
     hipLaunchKernelGGL(haspi_rms_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
     if (fs_in != 24000) {
-        hipLaunchKernelGGL(haspi_resample_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
+        static int rs3 = -1;                               // NELE_HASPI_RS3=0: the output-per-thread kernel at 16 kHz too (A/B diagnostic)
+        if (rs3 < 0) { const char* e_ = getenv("NELE_HASPI_RS3"); rs3 = !(e_ && e_[0] == '0'); }
+        if (fs_in == 16000 && rs3)
+            hipLaunchKernelGGL(haspi_resample3_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
+        else
+            hipLaunchKernelGGL(haspi_resample_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
         hipLaunchKernelGGL(haspi_resample_gain_kernel, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
     }
     if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, rows), dim3(64), 0, s, ws, sig0, nsig);
@@ -2025,7 +2176,7 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
     if (mod_direct < 0) { const char* e_ = getenv("NELE_HASPI_MOD_DIRECT"); mod_direct = (e_ && e_[0] == '1'); }
     NELE_CHECK_ARG((ws.nsub + MS_TC - 1) / MS_TC <= MS_MAXC, "nele_metric_haspi: signal too long (%d sub-sampled frames)", ws.nsub);
     if (phase == 0 || phase == 3) {
-        if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
+        if (fs_in != 24000) haspi_build_window(ws, s);
         haspi_chain(x, y, B, L, fs_in, ws, 0, 1, s);
         if (cep_serial) {
             hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);

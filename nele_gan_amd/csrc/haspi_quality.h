@@ -556,7 +556,7 @@ static int haspi_quality_impl(const float* x, const float* y, const int* lengths
     q.seed = seed; q.noise = noise;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(haspi_loss_kernel, dim3(1), dim3(64), 0, s, ws, hl);
-    if (fs_in != 24000) hipLaunchKernelGGL(haspi_win_kernel, dim3((HP_NWIN + 255) / 256), dim3(256), 0, s, ws.win);
+    if (fs_in != 24000) haspi_build_window(ws, s);
     haspi_chain(x, y, B, L, fs_in, ws, 0, 2, s, true);       // ear model of both signals up to the IHC prefix states
     const int rows = 2 * B;
     hipLaunchKernelGGL(hq_ihc_bm_kernel, dim3(((ws.n24p + GL_N - 1) / GL_N + 7) / 8, rows), dim3(256), 0, s, ws, q, 0, 2);

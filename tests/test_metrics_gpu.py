@@ -296,8 +296,8 @@ np.save(sys.argv[2], raw.double().cpu().numpy())
 '''
 
 
-@pytest.mark.parametrize('env', [{'NELE_HASPI_FIR9': '0'}, {'NELE_HASPI_CEP_SERIAL': '0'}, {'NELE_HASPI_TAIL1': '0'}, {'NELE_HASPI_MOD_DIRECT': '1'}],
-                         ids=['fir8-frame-rows', 'parallel-cepstra', 'whole-chunk-pass1', 'direct-modulation-fir'])
+@pytest.mark.parametrize('env', [{'NELE_HASPI_FIR9': '0'}, {'NELE_HASPI_CEP_SERIAL': '0'}, {'NELE_HASPI_TAIL1': '0'}, {'NELE_HASPI_MOD_DIRECT': '1'}, {'NELE_HASPI_RS3': '0'}],
+                         ids=['fir8-frame-rows', 'parallel-cepstra', 'whole-chunk-pass1', 'direct-modulation-fir', 'resampler-output-per-thread'])
 def test_haspi_round3_kernels_equal_the_ones_they_replace(tmp_path, env):
     """Round 3 restructured HASPI's envelope filter (groups of nine samples, outputs stored as whole rows per GROUP and read back
     through the per-channel frame offset), the cepstrum stage (LDS-staged tiles), pass 1 of the filter banks (chunk heads skipped) and the
