@@ -1132,12 +1132,16 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
 
 // ------------------------------------------------------------------------------------------ e2
 // grid (ceil(n / (256/NL)), B), block 256.  NL lanes -> one eigenvalue (j-th smallest) by (NL+1)-section on the Sturm count: every
-// round the NL lanes evaluate the count at NL interior points of the current interval, so ~17 rounds at NL = 8 (instead of 53
+// round the NL lanes evaluate the count at NL interior points of the current interval, so ~23 rounds at NL = 4 (instead of 53
 // bisection steps) of the n-step serial recurrence reach 1 ulp.  NL trades the serial depth (rounds) against the total work
 // (NL x rounds sweeps per eigenvalue): the kernel is issue-bound at NL = 16 and latency-bound at NL = 4 for 32 x 420 eigenvalues.
 // Count: division-free three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes = eigenvalues below x).
+// Measured (tools/eigh_nl_ab.sh, kernel time per call, 256 / 32 matrices of order 420): NL = 8 1296 / 250 us, NL = 4 925 / 226 us, NL = 2
+// 801 / 331 us, NL = 1 (plain bisection) 780 / 487 us - since the loads left the dependent chain the kernel is issue-bound at every batch
+// size, and fewer lanes per eigenvalue mean fewer sweeps in total (136, 92, 68, 53 per eigenvalue); below NL = 4 the small batch runs out
+// of waves.  One value for every batch size: the converged midpoint depends on NL, and a matrix's result must not depend on its batch.
 #ifndef EG_NL
-#define EG_NL 8      // lanes per eigenvalue: (EG_NL + 1)-section per round
+#define EG_NL 4      // lanes per eigenvalue: (EG_NL + 1)-section per round
 #endif
 __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
     __shared__ double2 sde[EG_MAXN];          // {d_i, e_{i-1}^2}: one 16-byte broadcast read per recurrence step

@@ -1802,11 +1802,16 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
 // (50 of 64 lanes), every chunk warms its sums up over the L samples before it (recurrence without the subtraction).  A lane owns
 // one (basis, band) pair, so the correlation sums of ebm_ModCorr stay in its registers; chunk partials are combined in chunk order.
 // SIG = 0 stores the filtered reference sequence xf [b][t][64]; SIG = 1 filters the processed signal and correlates it with xf.
+#ifndef MS_TC
 #define MS_TC 1024
+#endif
+#ifndef MS_PAD
+#define MS_PAD 0             // extra LDS (doubles) per workgroup: caps the workgroups per CU (A/B builds)
+#endif
 #define MS_R 640
 template <int SIG>
 __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
-    __shared__ double ring[HP_NBASIS - 1][MS_R + 8];
+    __shared__ double ring[HP_NBASIS - 1][MS_R + 8 + MS_PAD / (HP_NBASIS - 1)];
     const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
     const int na = ws.info[2 * b];
     if (ws.info[2 * b + 1]) return;
@@ -1847,39 +1852,64 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
     const double* vfill = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + 1 + min(sl, HP_NBASIS - 2)) * ws.nsub;
     const double mufill = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + 1 + min(sl, HP_NBASIS - 2)];
     {                                                                    // initial fill: offsets 0 .. 2 NHM + MS_U - 1 (the window of the first group)
-        for (int o = lane; o < (HP_NBASIS - 1) * (2 * NHM + MS_U); o += 64) {
-            const int q = o / (2 * NHM + MS_U), off = o - q * (2 * NHM + MS_U);
+        // all of a sequence's loads are issued before the first value is used: the one-element-per-iteration loop paid a memory latency
+        // per iteration, 49 in a row - a sixth of a wave's whole run time
+        constexpr int W0 = 2 * NHM + MS_U, NR = (W0 + 63) / 64;
+#pragma unroll
+        for (int q = 0; q < HP_NBASIS - 1; ++q) {
             const double* vq = ws.cep + (((size_t)b * 2 + SIG) * HP_NBASIS + 1 + q) * ws.nsub;
-            const double val = vq[min(max(base0 + off, 0), na - 1)] - ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + 1 + q];
-            ring[q][off] = val;
-            if (off < MS_U) ring[q][MS_R + off] = val;
+            const double muq = ws.cmean[((size_t)b * 2 + SIG) * HP_NBASIS + 1 + q];
+            double tmp[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) tmp[r] = vq[min(max(base0 + min(lane + 64 * r, W0 - 1), 0), na - 1)];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int off = lane + 64 * r;
+                if (off < W0) {
+                    const double val = tmp[r] - muq;
+                    ring[q][off] = val;
+                    if (off < MS_U) ring[q][MS_R + off] = val;
+                }
+            }
         }
     }
     int fo = 2 * NHM + MS_U;                                             // ring offset (not yet wrapped) of the next group to fill
     // the elements of the next three groups are in flight / in registers (a lone wave per SIMD has nothing else to cover a memory latency)
-    auto fetch = [&](int ahead) { return (sl < HP_NBASIS - 1) ? vfill[min(max(base0 + fo + MS_U * ahead + jl, 0), na - 1)] - mufill : 0.0; };
-    double fv0 = fetch(0), fv1 = fetch(1), fv2 = fetch(2);
-    double xnx[MS_U];                                                    // SIG = 1: the next group's stored reference outputs
-    if (SIG == 1) {
+    // (the RAW element is fetched; its mean comes off when it enters the ring three groups later - subtracting at fetch time made every
+    //  group wait for the load it had just issued, which was half of this kernel's time)
+    // Four fetch slots, one per group of the four-fold unrolled loop below: a slot is refilled right after it is consumed and is never copied
+    // (rotating three values through register moves made each move wait for a load issued one group earlier).
+    // (every lane loads - lanes 40..63 a duplicate of sequence 4 - so that the loop holds no branch around a memory instruction)
+    auto fetch = [&](int ahead) { return vfill[min(max(base0 + fo + MS_U * ahead + jl, 0), na - 1)]; };
+    double fs0 = fetch(0), fs1 = fetch(1), fs2 = fetch(2), fs3 = fetch(3);
+    // SIG = 1: the stored reference outputs of a group are loaded one group ahead into one of two register sets that swap roles (the loop
+    // below is unrolled by two groups: a set is never copied, so nothing waits for a load before its values are used); the warm-up groups
+    // (tb + MS_U <= t0) use none and load none.
+    double xa[MS_U], xb[MS_U];
+    auto xload = [&](double (&xs)[MS_U], int tbn, bool always) {
+        if (SIG == 1 && (always || (tbn + MS_U > t0 && tbn < t1))) {
 #pragma unroll
-        for (int u = 0; u < MS_U; ++u) xnx[u] = xf[(size_t)min(max(t0 - LMAX + u, 0), na - 1) * 64];
-    }
+            for (int u = 0; u < MS_U; ++u) xs[u] = xf[(size_t)min(max(tbn + u, 0), na - 1) * 64];
+        }
+    };
+    xload(xa, t0 - LMAX, false);
     // ring positions of this lane's two reads at the first step: (tau - base0) mod MS_R, (tau - L - base0) mod MS_R
     int pn = (NHM + nh) % MS_R, po = (NHM + nh - L + MS_R) % MS_R;
     const double* rq = &ring[basis - 1][0];
     __syncthreads();
-    for (int tb = t0 - LMAX; tb < t1; tb += MS_U) {
-        double vnv[MS_U], vov[MS_U], xvv[MS_U];
+    // STEADY: -1 = the group decides its kind itself (chunk edges); 0 / 1 = a WARM / MAIN group inside a run of four such groups - no
+    // branch anywhere in the group, so the compiler can count the memory operations in flight and wait for exactly the four-groups-old
+    // fetch slot (s_waitcnt vmcnt(n)) instead of draining the queue - stores included - at every branch join.
+    auto group = [&](auto steady_tag, int tb, double (&xvv)[MS_U], double (&xnext)[MS_U], double& fslot) {
+        constexpr int STEADY = decltype(steady_tag)::value;
+        double vnv[MS_U], vov[MS_U];
 #pragma unroll
         for (int u = 0; u < MS_U; ++u) {
             vnv[u] = rq[pn + u];
             vov[u] = rq[po + u];
-            if (SIG == 1) xvv[u] = xnx[u];
         }
-        if (SIG == 1) {
-#pragma unroll
-            for (int u = 0; u < MS_U; ++u) xnx[u] = xf[(size_t)min(max(tb + MS_U + u, 0), na - 1) * 64];
-        }
+        if (STEADY == 1) xload(xnext, tb + MS_U, true);
+        else if (STEADY == -1) xload(xnext, tb + MS_U, false);
         pn = pn + MS_U >= MS_R ? pn + MS_U - MS_R : pn + MS_U;
         po = po + MS_U >= MS_R ? po + MS_U - MS_R : po + MS_U;
         // Three copies of the group's body: WARM (all 8 steps before t0: nothing leaves the sums, no output), MAIN (all 8 steps inside
@@ -1908,19 +1938,46 @@ __global__ __launch_bounds__(64) void haspi_mod_slide_kernel(HaspiWs ws) {
                 }
             }
         };
-        if (tb + MS_U <= t0) body(std::integral_constant<int, 0>{});
+        if (STEADY == 0) body(std::integral_constant<int, 0>{});
+        else if (STEADY == 1) body(std::integral_constant<int, 1>{});
+        else if (tb + MS_U <= t0) body(std::integral_constant<int, 0>{});
         else if (tb >= t0 && tb + MS_U <= t1 && tb - NHM >= 0 && tb + MS_U + NHM <= na) body(std::integral_constant<int, 1>{});
         else body(std::integral_constant<int, 2>{});
-        // the next group's 8 new elements per sequence replace the 8 oldest (no lane reads them any more)
-        __syncthreads();
+        // the next group's 8 new elements per sequence replace the 8 oldest (no lane reads them any more).  The workgroup is ONE wave: its
+        // LDS operations execute in issue order, so ordering them is all a barrier has to do here - __syncthreads() also drains the
+        // vector-memory queue (the fence of a workgroup-scope barrier), i.e. waited for every store of the group.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (sl < HP_NBASIS - 1) {
             const int pos = (fo + jl) % MS_R;
-            ring[sl][pos] = fv0;
-            if (pos < MS_U) ring[sl][MS_R + pos] = fv0;
+            const double fin = fslot - mufill;
+            ring[sl][pos] = fin;
+            if (pos < MS_U) ring[sl][MS_R + pos] = fin;
         }
+        fslot = fetch(4);
         fo += MS_U;
-        fv0 = fv1; fv1 = fv2; fv2 = fetch(2);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    const std::integral_constant<int, -1> edge{};
+    const std::integral_constant<int, 0> warm{};
+    const std::integral_constant<int, 1> mainr{};
+    for (int tb = t0 - LMAX; tb < t1;) {
+        if (tb + 5 * MS_U <= t0) {                                       // four warm-up groups, and the group after them is one too (no reference loads)
+            do {
+                group(warm, tb, xa, xb, fs0); group(warm, tb + MS_U, xb, xa, fs1); group(warm, tb + 2 * MS_U, xa, xb, fs2); group(warm, tb + 3 * MS_U, xb, xa, fs3);
+                tb += 4 * MS_U;
+            } while (tb + 5 * MS_U <= t0);
+        } else if (tb >= t0 && tb + 4 * MS_U <= t1 && tb - NHM >= 0 && tb + 4 * MS_U + NHM <= na) {
+            do {
+                group(mainr, tb, xa, xb, fs0); group(mainr, tb + MS_U, xb, xa, fs1); group(mainr, tb + 2 * MS_U, xa, xb, fs2); group(mainr, tb + 3 * MS_U, xb, xa, fs3);
+                tb += 4 * MS_U;
+            } while (tb + 4 * MS_U <= t1 && tb + 4 * MS_U + NHM <= na);
+        } else {
+            group(edge, tb, xa, xb, fs0);
+            if (tb + MS_U < t1) group(edge, tb + MS_U, xb, xa, fs1);
+            if (tb + 2 * MS_U < t1) group(edge, tb + 2 * MS_U, xa, xb, fs2);
+            if (tb + 3 * MS_U < t1) group(edge, tb + 3 * MS_U, xb, xa, fs3);
+            tb += 4 * MS_U;
+        }
     }
     if (SIG == 1 && act) {
         double* cp = ws.cpart + (((size_t)b * MS_MAXC + chunk) * 64 + lane) * 5;
