@@ -1580,6 +1580,10 @@ __global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
 // Frames walk through LDS in tiles of 256 frames x 16 channels (two halves per tile): in the group-space layout of lp a frame's channels
 // sit in up to ~40 different rows, and a thread that walked "its" frame through global memory alone touched a new cache line on nearly
 // every channel (1.1 ms per call at B = 256 against 0.84 in frame-space rows; staged: the 16 lanes of a frame read neighbouring rows).
+// Barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue (the fences of a workgroup-scope barrier on
+// this target: s_waitcnt vmcnt(0)), which makes every load that was issued ahead of it - the next tile's prefetch - wait right there.
+// Use where the threads exchange data through LDS alone; global data that changes hands between threads still needs __syncthreads().
+__device__ __forceinline__ void hp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int gate, int sig0,
                                                         int nsig) {
     __shared__ double cepm[HP_NCH][HP_NBASIS];
@@ -1611,11 +1615,11 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
 #pragma unroll
         for (int j = 0; j < 16; ++j) pf[j] = (i0 + fth + 16 * j < nsub) ? hp_lp_at(lpb, i0 + fth + 16 * j, c, d) : 0.0;
     };
-    auto put = [&]() {                                          // registers -> tile (barriers on both sides)
-        __syncthreads();
+    auto put = [&]() {                                          // registers -> tile (LDS barriers on both sides)
+        hp_lds_barrier();
 #pragma unroll
         for (int j = 0; j < 16; ++j) tile[fth + 16 * j][cth] = pf[j];
-        __syncthreads();
+        hp_lds_barrier();
     };
     const int ntile2 = 2 * ((nsub + 255) / 256);
     int na;
@@ -1632,17 +1636,17 @@ __global__ __launch_bounds__(256) void haspi_cep_kernel(HaspiWs ws, const double
                 const int k = (i < nsub && 20.0 * log10(sm / (double)HP_NCH) > 2.5) ? 1 : 0;
                 sm = 0.0;
                 scan[tid] = k;
-                __syncthreads();
+                hp_lds_barrier();
                 for (int o = 1; o < 256; o <<= 1) {
                     const int v = (tid >= o) ? scan[tid - o] : 0;
-                    __syncthreads();
+                    hp_lds_barrier();
                     scan[tid] += v;
-                    __syncthreads();
+                    hp_lds_barrier();
                 }
-                if (i < nsub) act[i] = k ? base + scan[tid] - 1 : -1;
-                __syncthreads();
+                if (i < nsub) act[i] = k ? base + scan[tid] - 1 : -1;      // read back by the same thread only (the cepstrum loop below)
+                hp_lds_barrier();
                 if (tid == 255) base += scan[255];
-                __syncthreads();
+                hp_lds_barrier();
             }
         }
         na = base;
