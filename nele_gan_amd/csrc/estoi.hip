@@ -118,6 +118,70 @@ __global__ __launch_bounds__(256) void estoi_resample_kernel(const float* __rest
     ws.xr[((size_t)b * 2 + sig) * ws.n10 + i] = acc;
 }
 
+// ---- the same resampler, a thread per group of FIVE consecutive outputs (second session of round 3).  The kernel above pays two LDS reads
+// and a conversion per tap and is bound by the LDS pipe.  Outputs i = 5 g + r (r = 0..4) have the phases p = (8 i + 290) mod 5 = {0, 3, 1, 4, 2}
+// whatever g is, and their newest inputs sit at n = 8 g + 58 + {0, 1, 3, 4, 6}: walking n upwards, step s of output r meets input
+// x[8 g - 58 + s + off_r] and tap h[p_r + 5 (116 - s)].  So (i) the five tap weights of a step are the same for every lane - they come from a
+// [117][8] table in memory by scalar loads, no LDS read - and (ii) the thread's 123 inputs are read once (31 16-byte LDS reads) and
+// converted once, then serve all five outputs from registers: 6 vector instructions per 5 taps instead of 10 + 10 LDS reads.  Per output
+// the sum runs over n ascending with the same multiply-add as above; taps the kernel above does not execute (n < 0, n >= L, tap index
+// > 580) meet a staged zero input or a zero weight, which leaves the sum unchanged: bit-identical outputs.
+// grid (ceil(n10 / 1280), B, 2), block 256.
+#define ES_M 117                          // steps per output: tap indices p + 5 m, m = 116 .. 0
+#define ES_HPAD 584                       // filter length rounded up to 8 doubles: the step table follows it in the workspace
+#define ES_HTAB (ES_M * 8)                // [step][5 outputs of a group + 3 pad]
+__global__ void estoi_taps_kernel(double* __restrict__ h) {
+    double* tab = h + ES_HPAD;
+    for (int e = threadIdx.x; e < ES_HTAB; e += blockDim.x) {
+        const int s_ = e >> 3, r = e & 7;
+        double w = 0.0;
+        if (r < 5) {
+            const int p = (8 * r) % 5, idx = p + 5 * (ES_M - 1 - s_);
+            if (idx <= 2 * ES_HALF) w = h[idx];
+        }
+        tab[e] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void estoi_resample5_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const double* __restrict__ htab, int L, EstoiWs ws) {
+    constexpr int NX = 8 * 255 + 124;
+    __shared__ __attribute__((aligned(16))) float xs[NX + 4];
+    __shared__ double outs[1280];
+    const int b = blockIdx.y, sig = blockIdx.z, tid = threadIdx.x;
+    const int g0 = blockIdx.x * 256, i0 = 5 * g0, n10b = es_n10(ws, b);
+    if (i0 >= n10b) return;
+    const float* src = (sig == 0 ? x : y) + (size_t)b * L;
+    L = es_len(ws, b);
+    const int nbase = 8 * g0 - (ES_M - 1) / 2;             // input index of xs[0]: x[8 g0 - 58] (may lie before the signal: zeros)
+    for (int k = tid; k < NX; k += 256) {
+        const int idx = nbase + k;
+        xs[k] = (idx >= 0 && idx < L) ? src[idx] : 0.f;
+    }
+    __syncthreads();
+    const float4* xq = reinterpret_cast<const float4*>(xs + 8 * tid);
+    float X[124];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+        const float4 v = xq[k];
+        X[4 * k] = v.x; X[4 * k + 1] = v.y; X[4 * k + 2] = v.z; X[4 * k + 3] = v.w;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+#pragma unroll
+    for (int s_ = 0; s_ < ES_M; ++s_) {
+        a0 += (double)X[s_] * htab[8 * s_];
+        a1 += (double)X[s_ + 1] * htab[8 * s_ + 1];
+        a2 += (double)X[s_ + 3] * htab[8 * s_ + 2];
+        a3 += (double)X[s_ + 4] * htab[8 * s_ + 3];
+        a4 += (double)X[s_ + 6] * htab[8 * s_ + 4];
+    }
+    outs[5 * tid] = a0; outs[5 * tid + 1] = a1; outs[5 * tid + 2] = a2; outs[5 * tid + 3] = a3; outs[5 * tid + 4] = a4;
+    __syncthreads();
+    double* dst = ws.xr + ((size_t)b * 2 + sig) * ws.n10 + i0;
+    for (int k = tid; k < 1280; k += 256)
+        if (i0 + k < n10b) dst[k] = outs[k];
+}
+
 // one block per utterance
 __global__ __launch_bounds__(256) void estoi_vad_kernel(EstoiWs ws) {
     __shared__ double red[8];
@@ -295,7 +359,7 @@ static void estoi_dims(int L, int* n10, int* F) {
 extern "C" long long nele_metric_estoi_workspace_bytes(int B, int L) {
     int n10, F;
     estoi_dims(L, &n10, &F);
-    size_t t = align256(sizeof(double) * (2 * ES_HALF + 1));
+    size_t t = align256(sizeof(double) * (ES_HPAD + ES_HTAB));
     t += align256(sizeof(double) * (size_t)B * 2 * n10);
     t += align256(sizeof(double) * (size_t)B * F);
     t += align256(sizeof(int) * (size_t)B * F);
@@ -314,7 +378,7 @@ extern "C" int nele_metric_estoi_var(const float* x, const float* y, const int* 
     if (workspace_bytes < nele_metric_estoi_workspace_bytes(B, L))
         return nele_set_error(NELE_ERR_WORKSPACE, "nele_metric_estoi: workspace too small");
     char* p = (char*)workspace;
-    double* h = (double*)p; p += align256(sizeof(double) * (2 * ES_HALF + 1));
+    double* h = (double*)p; p += align256(sizeof(double) * (ES_HPAD + ES_HTAB));     // filter + the five-output step table
     EstoiWs ws;
     ws.n10 = n10; ws.F = F; ws.lens = lengths; ws.L = L;
     ws.xr = (double*)p; p += align256(sizeof(double) * (size_t)B * 2 * n10);
@@ -325,7 +389,14 @@ extern "C" int nele_metric_estoi_var(const float* x, const float* y, const int* 
     ws.dseg = (double*)p;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(estoi_filter_kernel, dim3(1), dim3(1024), 0, s, h);
-    hipLaunchKernelGGL(estoi_resample_kernel, dim3((n10 + 255) / 256, B, 2), dim3(256), 0, s, x, y, h, L, ws);
+    static int rs5 = -1;                                   // NELE_ESTOI_RS5=0: the output-per-thread resampler (A/B diagnostic)
+    if (rs5 < 0) { const char* e_ = getenv("NELE_ESTOI_RS5"); rs5 = !(e_ && e_[0] == '0'); }
+    if (rs5) {
+        hipLaunchKernelGGL(estoi_taps_kernel, dim3(1), dim3(256), 0, s, h);
+        hipLaunchKernelGGL(estoi_resample5_kernel, dim3((n10 + 1279) / 1280, B, 2), dim3(256), 0, s, x, y, h + ES_HPAD, L, ws);
+    } else {
+        hipLaunchKernelGGL(estoi_resample_kernel, dim3((n10 + 255) / 256, B, 2), dim3(256), 0, s, x, y, h, L, ws);
+    }
     hipLaunchKernelGGL(estoi_vad_kernel, dim3(B), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(estoi_tob_kernel, dim3(F, B), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(estoi_seg_kernel, dim3(F, B), dim3(64), 0, s, ws);

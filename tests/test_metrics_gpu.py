@@ -247,6 +247,37 @@ def test_siib_lag_products_equal_the_stacked_frame_gemms(tmp_path):
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
 
 
+_ESTOI_AB_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for L, B in ((64000, 3), (63871, 2), (20011, 2)):
+    c, v = synth.batch(B, L, start=75)
+    raw, _ = mt.batch_estoi(c, 0.8 * c + v)
+    out.append(raw.double().cpu().numpy())
+c, v = synth.batch(4, 48000, start=76)
+raw, _ = mt.batch_estoi(c, c + v, lengths=torch.tensor([48000, 30001, 9999, 41234], dtype=torch.int32))
+out.append(raw.double().cpu().numpy())
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_estoi_five_output_resampler_is_bit_identical_to_the_output_per_thread_one(tmp_path):
+    """The 16 -> 10 kHz resampler computes five consecutive outputs per thread (inputs read once, tap weights by scalar loads); every
+    output's own sum is unchanged, so the scores must equal those of the kernel it replaces (NELE_ESTOI_RS5=0, read once per process)
+    exactly - whole and ragged batches, lengths that are no multiple of 8 (the last group of five is partial)."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('estoi_rs5_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_ESTOI_RS5=flag), timeout=240)
+        res.append(np.load(out))
+    assert np.all(np.isfinite(res[0])) and res[0].shape == (11,)
+    assert np.array_equal(res[0], res[1])
+
+
 _HASPI_AB_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
