@@ -112,6 +112,81 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
     }
 }
 
+// ---- the same STFT, one WAVE per frame pair with the transform in registers (fft512_wave: two LDS exchanges instead of nine workgroup
+// barriers; same butterflies, same twiddles, same window values: bit-identical spectra and band features, tests/test_features_gpu.py).
+// A workgroup = 4 waves x STW_NP pairs; twiddles and the Hann window are computed once per workgroup.  A lane loads the 8 samples its
+// registers start from straight from memory (n = fftw_n(lane, r): the lanes of a load cover 64 consecutive samples).
+// grid (ceil(ceil(T / 2) / (4 STW_NP)), B), block 256.
+#define STW_NP 2
+__global__ __launch_bounds__(256) void stft_band_wave_kernel(const float* __restrict__ wav, int L, int T, float power,
+                                                             float2* __restrict__ spec, float* __restrict__ band, const int* __restrict__ lens) {
+    __shared__ double2 tw[256];
+    __shared__ double hw[NELE_NFFT];
+    __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
+    __shared__ float tmp[4][2][NELE_NBINS + 3];
+    const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const float* x = wav + (size_t)b * L;
+    int Tb = T;
+    if (lens) { L = min(lens[b], L); Tb = 1 + L / NELE_HOP; }
+    {
+        double sn, cs;
+        sincospi((double)tid / 256.0, &sn, &cs);
+        tw[tid] = make_double2(cs, -sn);
+        hw[tid] = hann512(tid);
+        hw[tid + 256] = hann512(tid + 256);
+    }
+    __syncthreads();
+    double2* xw = xs[wv];
+    for (int it = 0; it < STW_NP; ++it) {
+        const int t0 = 2 * ((blockIdx.x * STW_NP + it) * 4 + wv), t1 = t0 + 1;
+        if (t0 >= T) break;
+        for (int t = max(t0, Tb); t <= t1 && t < T; ++t) {     // frames behind the end of a short row
+            if (spec) for (int k = lane; k < NELE_NBINS; k += 64) spec[((size_t)b * T + t) * NELE_NBINS + k] = make_float2(0.f, 0.f);
+            if (band) band[((size_t)b * T + t) * NELE_NBANDS + lane] = 0.f;
+        }
+        if (t0 >= Tb) continue;
+        const bool has1 = t1 < Tb;
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = fftw_n(lane, r);
+            int o0 = NELE_HOP * t0 + n - NELE_HOP;
+            if (o0 < 0) o0 = -o0;
+            if (o0 >= L) o0 = 2 * (L - 1) - o0;
+            int o1 = o0;
+            if (has1) {
+                o1 = NELE_HOP * t1 + n - NELE_HOP;
+                if (o1 >= L) o1 = 2 * (L - 1) - o1;
+            }
+            const double w = hw[n];
+            const double zr = w * (double)x[o0];
+            const double zi = has1 ? w * (double)x[o1] : 0.0;
+            v[r] = make_double2(zr, zi);
+        }
+        fft512_wave<false>(v, xw, tw, lane);
+        fft512_wave_store(v, xw, lane);
+        for (int k = lane; k < NELE_NBINS; k += 64) {
+            const double2 zk = xw[fftw_slot(k)], zn = xw[fftw_slot((NELE_NFFT - k) & (NELE_NFFT - 1))];
+            const float2 A = make_float2((float)(0.5 * (zk.x + zn.x)), (float)(0.5 * (zk.y - zn.y)));
+            const float2 Bv = make_float2((float)(0.5 * (zk.y + zn.y)), (float)(0.5 * (zn.x - zk.x)));
+            if (spec) {
+                spec[((size_t)b * T + t0) * NELE_NBINS + k] = A;
+                if (has1) spec[((size_t)b * T + t1) * NELE_NBINS + k] = Bv;
+            }
+            const float m0 = np_cabsf(A.x, A.y);
+            const float m1 = np_cabsf(Bv.x, Bv.y);
+            tmp[wv][0][k] = m0 * m0;
+            tmp[wv][1][k] = m1 * m1;
+        }
+        fftw_wave_sync();
+        if (band) {
+            band[((size_t)b * T + t0) * NELE_NBANDS + lane] = pow_f32(band_energy(tmp[wv][0], lane), power);
+            if (has1) band[((size_t)b * T + t1) * NELE_NBANDS + lane] = pow_f32(band_energy(tmp[wv][1], lane), power);
+        }
+        fftw_wave_sync();                                   // tmp / xw are rewritten by the next pair
+    }
+}
+
 // ------------------------------------------------------------------------------------------ IMCRA
 // One block (320 threads, bins 0..256 active) per utterance; serial over frames (true recurrence),
 // neighbour bins exchanged through LDS.  float32 / float64 staging follows numpy (see oracle/features.py).
@@ -346,6 +421,67 @@ __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict
     }
 }
 
+// ---- the same resynthesis, one WAVE per output hop with the inverse transform in registers (fft512_wave<true>): the lane that holds
+// X[64 m + lane] holds both halves it needs (frame fa's second half in v[m + 4].x, frame fb's first half in v[m].y), so nothing is
+// exchanged after the transform.  Bit-identical to gain_istft_kernel.  grid (ceil((T - 1) / (4 STW_NP)), B), block 256.
+__global__ __launch_bounds__(256) void gain_istft_wave_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
+                                                              int T, float* __restrict__ wav, const int* __restrict__ tlens) {
+    __shared__ double2 tw[256];
+    __shared__ double hw[NELE_NFFT];
+    __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
+    const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    {
+        double sn, cs;
+        sincospi((double)tid / 256.0, &sn, &cs);
+        tw[tid] = make_double2(cs, -sn);
+        hw[tid] = hann512(tid);
+        hw[tid + 256] = hann512(tid + 256);
+    }
+    __syncthreads();
+    double2* xw = xs[wv];
+    float* out = wav + (size_t)b * (NELE_HOP * (T - 1));
+    for (int it = 0; it < STW_NP; ++it) {
+        const int fa = (blockIdx.x * STW_NP + it) * 4 + wv, fb = fa + 1;
+        if (fa >= T - 1) break;
+        if (tlens && fb >= min(tlens[b], T)) {              // behind the end of a short row (its signal has 256 (T_b - 1) samples): zeros
+#pragma unroll
+            for (int m = 0; m < 4; ++m) out[(size_t)NELE_HOP * fa + 64 * m + lane] = 0.f;
+            continue;
+        }
+        const float* a2a = alpha2 ? alpha2 + ((size_t)b * T + fa) * NELE_NBANDS : nullptr;   // NULL: plain ISTFT (audio_util.py:60-65)
+        const float* a2b = a2a + NELE_NBANDS;
+        const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
+        const float2* Xb = Xa + NELE_NBINS;
+        for (int k = lane; k < NELE_NBINS; k += 64) {
+            const double ga = a2a ? band_gain_sqrt(a2a, k) : 1.0, gb = a2a ? band_gain_sqrt(a2b, k) : 1.0;
+            const float2 xa = Xa[k], xb = Xb[k];
+            double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
+            double br = gb * (double)xb.x, bi = gb * (double)xb.y;
+            if (k == 0 || k == NELE_NBINS - 1) { ai = 0.0; bi = 0.0; }  // c2r ignores these imaginary parts
+            xw[fftw_slot(fft512_brev(k))] = make_double2(ar - bi, ai + br);
+            if (k >= 1 && k <= 255) xw[fftw_slot(fft512_brev(NELE_NFFT - k))] = make_double2(ar + bi, br - ai);
+        }
+        fftw_wave_sync();
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = xw[9 * lane + r];
+        fft512_wave<true>(v, xw, tw, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int n = 64 * m + lane;
+            const double x1 = v[m + 4].x * (1.0 / 512.0);      // frame fa, second half
+            const double x2 = v[m].y * (1.0 / 512.0);          // frame fb, first half
+            const double wa = hw[n + 256], wb = hw[n];
+            float y = (float)(wa * x1);                        // overlap-add into a float32 buffer
+            y = (float)((double)y + wb * x2);
+            float wss = (float)(wa * wa);                      // window_sumsquare, same float32 staging
+            wss = (float)((double)wss + wb * wb);
+            out[(size_t)NELE_HOP * fa + n] = y / wss;
+        }
+        fftw_wave_sync();                                   // xw is restaged by the next hop
+    }
+}
+
 // One block per utterance: optional enh / rms(enh) * target (inference.py:109) and optional PCM_16
 // round trip (libsndfile float->short with 0x7FFF scaling + lrintf, read back / 32768: PARITY UNPINNED).
 __global__ __launch_bounds__(256) void wav_post_kernel(float* __restrict__ wav, int N, float target_rms, int pcm16, const int* __restrict__ tlens) {
@@ -384,8 +520,15 @@ extern "C" int nele_stft_band_var(const float* wav, const int* lengths, int B, i
     NELE_CHECK_ARG(L > NELE_HOP, "nele_stft_band: L=%d must exceed 256 (reflect padding)", L);
     NELE_CHECK_ARG(spec || band, "nele_stft_band: no output requested");
     const int T = 1 + L / NELE_HOP;
-    dim3 grid((T + 1) / 2, B);
-    hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
+    static int wave_on = -1;                                // NELE_STFT_WAVE=0: the workgroup-per-frame-pair kernels (A/B diagnostic)
+    if (wave_on < 0) { const char* e_ = getenv("NELE_STFT_WAVE"); wave_on = !(e_ && e_[0] == '0'); }
+    if (wave_on) {
+        dim3 grid(((T + 1) / 2 + 4 * STW_NP - 1) / (4 * STW_NP), B);
+        hipLaunchKernelGGL(stft_band_wave_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
+    } else {
+        dim3 grid((T + 1) / 2, B);
+        hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
+    }
     NELE_CHECK_LAUNCH("nele_stft_band");
     return NELE_OK;
 }
@@ -466,7 +609,13 @@ extern "C" int nele_interp_band_gain(const float* bandE, int N, double* g, void*
 extern "C" int nele_gain_istft_var(const float* alpha2, const void* spec, const int* frames, int B, int T, float* wav, void* stream) {
     NELE_CHECK_ARG(spec && wav && B > 0, "nele_gain_istft: bad arguments");
     NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
-    hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);
+    static int wave_on = -1;                                // NELE_STFT_WAVE=0: the workgroup-per-hop kernel (A/B diagnostic)
+    if (wave_on < 0) { const char* e_ = getenv("NELE_STFT_WAVE"); wave_on = !(e_ && e_[0] == '0'); }
+    if (wave_on)
+        hipLaunchKernelGGL(gain_istft_wave_kernel, dim3((T - 1 + 4 * STW_NP - 1) / (4 * STW_NP), B), dim3(256), 0, as_stream(stream), alpha2,
+                           (const float2*)spec, T, wav, frames);
+    else
+        hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);
     NELE_CHECK_LAUNCH("nele_gain_istft");
     return NELE_OK;
 }

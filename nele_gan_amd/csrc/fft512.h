@@ -45,3 +45,85 @@ __device__ __forceinline__ void fft512_run(Fft512Lds& s) {
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same transform, ONE WAVE per 512-point FFT with the data in registers (round 3, third session).  fft512_run() pays a workgroup
+// barrier and five LDS accesses per butterfly stage; here a lane holds 8 complex values and runs three stages at a time in registers,
+// so nine stages cost two LDS exchanges and no workgroup barrier (the wave's LDS accesses execute in order).  Every butterfly is the
+// SAME operation on the SAME operands with the SAME twiddle (tw[pos << (8 - st)]) as in fft512_run(): results are bit-identical in a
+// translation unit compiled without FMA contraction (features.hip).
+//   in : v[r] = element (8 * lane + r) of the bit-reversed-order array, i.e. input sample  n = fftw_n(lane, r)
+//   out: v[m] = X[64 * m + lane]
+// xw: the wave's exchange buffer (FFTW_SLOTS double2; position i lives in slot i + (i >> 3): conflict-free 16-byte accesses in all
+// three access patterns); on return it holds X in natural order at fftw_slot(k) and is ordered for reading by any lane of the wave.
+#define FFTW_SLOTS 576
+__device__ __forceinline__ int fftw_slot(int i) { return i + (i >> 3); }
+__device__ __forceinline__ int fftw_n(int lane, int r) {
+    return (int)(__brev((unsigned)lane) >> 26) + 64 * (((r & 1) << 2) | (r & 2) | ((r >> 2) & 1));
+}
+// orders the LDS accesses of ONE wave: DS instructions of a wave execute in issue order, so the compiler only has to keep them in place
+__device__ __forceinline__ void fftw_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void fftw_bfly(double2& a, double2& b, double2 w) {
+    if (INVERSE) w.y = -w.y;
+    const double tr = w.x * b.x - w.y * b.y;
+    const double ti = w.x * b.y + w.y * b.x;
+    const double2 a0 = a;
+    a = make_double2(a0.x + tr, a0.y + ti);
+    b = make_double2(a0.x - tr, a0.y - ti);
+}
+
+// three consecutive stages on the 8 register values; stage s of the triple pairs (m, m + 2^s); pos0/1/2 = twiddle position of element 0
+template <bool INVERSE, int ST>
+__device__ __forceinline__ void fftw_triple(double2 (&v)[8], const double2* __restrict__ tw, int p) {
+    // stage ST: pos = p
+    {
+        const double2 w = tw[p << (8 - ST)];
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) fftw_bfly<INVERSE>(v[m], v[m + 1], w);
+    }
+    // stage ST + 1: pos = p + 2^ST * (m & 1)
+    {
+        const double2 w0 = tw[p << (7 - ST)], w1 = tw[(p + (1 << ST)) << (7 - ST)];
+#pragma unroll
+        for (int m = 0; m < 8; m += 4) {
+            fftw_bfly<INVERSE>(v[m], v[m + 2], w0);
+            fftw_bfly<INVERSE>(v[m + 1], v[m + 3], w1);
+        }
+    }
+    // stage ST + 2: pos = p + 2^ST * m, m < 4
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fftw_bfly<INVERSE>(v[m], v[m + 4], tw[(p + (m << ST)) << (6 - ST)]);
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* __restrict__ xw, const double2* __restrict__ tw, int lane) {
+    fftw_triple<INVERSE, 0>(v, tw, 0);                       // stages 0-2 inside blocks of 8 positions
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xw[9 * lane + r] = v[r];     // slot(8 lane + r)
+    fftw_wave_sync();
+    const int B = lane >> 3, p = lane & 7;                   // stages 3-5: positions 64 B + 8 m + p
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = xw[72 * B + 9 * m + p];
+    fftw_triple<INVERSE, 3>(v, tw, p);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) xw[72 * B + 9 * m + p] = v[m];
+    fftw_wave_sync();
+    const int s0 = lane + (lane >> 3);                       // stages 6-8: positions 64 m + lane
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = xw[72 * m + s0];
+    fftw_triple<INVERSE, 6>(v, tw, lane);
+}
+
+// X (as left in v by fft512_wave) to the exchange buffer in natural order, readable by every lane of the wave afterwards
+__device__ __forceinline__ void fft512_wave_store(const double2 (&v)[8], double2* __restrict__ xw, int lane) {
+    const int s0 = lane + (lane >> 3);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) xw[72 * m + s0] = v[m];
+    fftw_wave_sync();
+}

@@ -151,3 +151,45 @@ def test_wav_post_rms_and_pcm16(au):
 def test_errors_surface_as_exceptions(au):
     with pytest.raises(ValueError):
         au.stft_band(torch.zeros(1, 100).cuda())
+
+
+_STFT_AB_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import audio_util as au, synth
+out = []
+for L, B in ((257, 2), (1000, 3), (33536, 2), (64000, 5), (63871, 2), (128000, 2)):
+    c, _ = synth.batch(B, L, start=21)
+    x = torch.from_numpy(c).cuda()
+    spec, band = au.stft_band(x)
+    T = spec.shape[1]
+    alpha = torch.from_numpy(np.exp(0.5 * np.random.RandomState(L).randn(B, T, 64)).astype(np.float32)).cuda()
+    out += [torch.view_as_real(spec).cpu().numpy().ravel(), band.cpu().numpy().ravel(), au.gain_istft(alpha, spec).cpu().numpy().ravel(),
+            au.ISTFT(spec[0].transpose(0, 1)).cpu().numpy().ravel() if L == 1000 else np.zeros(0, np.float32)]
+# a padded batch of different lengths (frames behind a short row's end are zeros; the last pair of a row may hold one frame only)
+c, _ = synth.batch(4, 40000, start=22)
+lens = torch.tensor([40000, 25601, 511, 30000], dtype=torch.int32)
+x = torch.from_numpy(c).cuda()
+spec, band = au.stft_band(x, lengths=lens.cuda())
+alpha = torch.ones(4, spec.shape[1], 64, device='cuda')
+out += [torch.view_as_real(spec).cpu().numpy().ravel(), band.cpu().numpy().ravel(),
+        au.gain_istft(alpha, spec, frames=au.frames_of(lens.cuda())).cpu().numpy().ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_wave_per_transform_stft_istft_are_bit_identical_to_the_workgroup_kernels(tmp_path):
+    """STFT / iSTFT run one wave per 512-point transform with the data in registers (fft512_wave: three butterfly stages per LDS
+    exchange); every butterfly is the same float64 operation on the same operands as in the workgroup-per-transform kernels
+    (NELE_STFT_WAVE=0, read once per process), so spectra, band features and resynthesised signals must be equal bit for bit -
+    single frames, odd frame counts, 4 s / 8 s utterances and a padded batch of different lengths."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('stft_wave_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _STFT_AB_CHILD, os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out], check=True,
+                       env=dict(os.environ, NELE_STFT_WAVE=flag), timeout=240)
+        res.append(np.load(out))
+    assert res[0].shape == res[1].shape and np.all(np.isfinite(res[0]))
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
