@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void siib_compact_kernel(SiibWs ws, int Pf) {
     }
 }
 
+// orders the LDS accesses of ONE wave (its DS instructions execute in issue order; the compiler only has to keep them in place)
+__device__ __forceinline__ void sb_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // s3: 400-point spectra of the active frames -> 28 log band energies.  grid (ceil(NA / 6), B), block 128: six frames per workgroup.
 // 400 = 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2).  Both 20-point stages run from REGISTERS with compile-time twiddles: a thread
 // loads its 20 inputs once and produces all its outputs (stage 1: thread = (frame, n2), real input, k1 = 0..10 + conjugate
@@ -350,6 +357,154 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
                     ws.XL[(((size_t)b * 2 + sig) * SB_J + j) * ws.NA + k0 + f_] = log(a + SB_EPS);
                 }
             }
+        }
+    }
+}
+
+// s3, wave-autonomous form (round 3, third session; NELE_SIIB_SPECW=0 = the kernel above).  The kernel above ran at one wave per SIMD
+// (64 KB of LDS per 2-wave workgroup) with four workgroup barriers per signal, a staging loop of dependent global loads and a band stage
+// that waits for 51 filter rows four at a time: 22 us per workgroup for 3.5 us of float64 arithmetic - 3.0 ms per signal at B = 256 on
+// a non-periodic length, the largest kernel of that step.  Here a WAVE owns three frames from the samples to the band energies:
+//  * a lane loads its 20 samples straight into registers (thread = (frame, n2): for each n1 the 20 lanes of a frame read 80 contiguous
+//    bytes) - no staged frame in LDS; window values and the W400 twiddles of the lane's n2 are per-lane constants, loaded once per
+//    workgroup into registers and reused for SPW_NG groups of six frames;
+//  * LDS only carries the stage-1 output (6.4 KB per frame; |X|^2 overlays it once the stage-2 operands are in registers): 38 KB per
+//    workgroup, four workgroups = eight waves per CU;
+//  * the two stages and the band stage are ordered by wave-level fences only (the three frames of a wave never meet another wave's);
+//  * band stage: lane = (band, half of the bins), the filter rows come from L1 / L2 with all loads of an unrolled block in flight,
+//    the two halves meet through a shuffle.
+// Same sums in the same order per output except the band energies' final association (2 partial sums instead of 4): results agree
+// with the kernel above to a few ulps (tests/test_metrics_gpu.py).
+#define SPW_NG 4
+// cos / sin (2 pi t / 20) in constant memory: wave-uniform scalar operands (s_load) of the multiply-adds.  As compile-time literals
+// (the kernel above) the compiler pre-multiplies and keeps hundreds of products live: 502 registers, one wave per SIMD.
+__constant__ double c_dft20c[20] = {1.0, 0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
+                                    -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                    -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410, 0.0,
+                                    0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212};
+__constant__ double c_dft20s[20] = {0.0, 0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212, 1.0,
+                                    0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
+                                    -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                    -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410};
+__global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
+                                                             int sig1) {
+    __shared__ __attribute__((aligned(16))) double2 Aq[SP_F][SB_WLEN];   // stage-1 output [n2][k1]; then |X|^2 in its first 201 doubles
+    const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int* info = ws.info + 4 * b;
+    const int na = ws.nprim[b];                        // frames of the first period only: siib_spread_kernel copies the repeats
+    const int kbase = blockIdx.x * (SP_F * SPW_NG);
+    if (kbase >= na) return;
+    const int Lrow = L;
+    L = sb_len(ws, b, L);
+    const long long total = (long long)info[0] * L;
+    const int fl = lane / 20, l20 = lane - 20 * fl;    // frame of the wave (3 = idle lanes 60..63), n2 (stage 1) / k1 (stage 2)
+    const int fs = min(3 * wv + fl, SP_F - 1);
+    const bool lact = fl < 3;
+    double2* Af = Aq[fs];
+    double* Pf = reinterpret_cast<double*>(Af);
+    const int bj = lane % SB_J, bpart = lane / SB_J;   // band stage: band, half of the bins (lanes 56..63 idle)
+    const int bq0 = bpart * 101, bq1 = bpart == 0 ? 101 : (bpart == 1 ? SB_NBIN : 0);
+    const double* P0 = reinterpret_cast<const double*>(Aq[3 * wv]);
+    const double* P1 = reinterpret_cast<const double*>(Aq[3 * wv + 1]);
+    const double* P2 = reinterpret_cast<const double*>(Aq[3 * wv + 2]);
+    for (int g = 0; g < SPW_NG; ++g) {
+        const int k0 = kbase + SP_F * g;
+        if (k0 >= na) break;
+        const bool act = lact && (k0 + fs < na);
+        int q0 = 0, nv = 0;
+        if (act) {
+            const long long p0 = (long long)SB_SHIFT * ws.list[(size_t)b * ws.NA + k0 + fs];
+            q0 = (int)(p0 % L);
+            const long long left = total - p0;
+            nv = left >= SB_WLEN ? SB_WLEN : (left > 0 ? (int)left : 0);
+        }
+        for (int sig = sig0; sig <= sig1; ++sig) {
+            const float* sb = (sig ? y : x) + (size_t)b * Lrow;
+            const double* tab = ws.tab;                     // laundered per pass: the per-lane table values are re-read from L1 instead of
+            asm volatile("" : "+s"(tab));                   // living in 120 registers across the whole kernel
+            if (act) {      // stage 1: a[k1] = sum_n1 v[n1] W20^(n1 k1), then * W400^(n2 k1); radix 2 first: W20^(10 k1) = (-1)^k1
+                double ve[10], vo[10];
+#pragma unroll
+                for (int n1 = 0; n1 < 10; ++n1) {
+                    const int j0 = 20 * n1 + l20, j1 = j0 + 200;
+                    int qa = q0 + j0, qb = q0 + j1;
+                    if (qa >= L) qa -= L;                   // L >= 400 (checked on the host): one wrap at most
+                    if (qb >= L) qb -= L;
+                    const float sa = (j0 < nv) ? sb[qa] : 0.f, sc = (j1 < nv) ? sb[qb] : 0.f;
+                    const double va = (j0 < nv) ? (double)sa * tab[2 * SB_WLEN + j0] : 0.0;
+                    const double vb = (j1 < nv) ? (double)sc * tab[2 * SB_WLEN + j1] : 0.0;
+                    ve[n1] = va + vb; vo[n1] = va - vb;
+                }
+#pragma unroll
+                for (int k1 = 0; k1 <= 10; ++k1) {
+                    double ar = 0.0, ai = 0.0;
+#pragma unroll
+                    for (int n1 = 0; n1 < 10; ++n1) {
+                        const double vv = (k1 & 1) ? vo[n1] : ve[n1];
+                        ar += vv * c_dft20c[(n1 * k1) % 20];
+                        ai -= vv * c_dft20s[(n1 * k1) % 20];
+                    }
+                    {
+                        const double c2 = tab[l20 * k1], s2 = tab[SB_WLEN + l20 * k1];
+                        Af[l20 * 20 + k1] = make_double2(ar * c2 + ai * s2, ai * c2 - ar * s2);
+                    }
+                    if (k1 >= 1 && k1 <= 9) {              // a[20 - k1] = conj(a[k1])
+                        const int kc = 20 - k1;
+                        const double c2 = tab[l20 * kc], s2 = tab[SB_WLEN + l20 * kc];
+                        Af[l20 * 20 + kc] = make_double2(ar * c2 - ai * s2, -ai * c2 - ar * s2);
+                    }
+                }
+            }
+            sb_wave_sync();
+            // stage 2: X[k1 + 20 k2] = sum_n2 A[n2][k1] W20^(n2 k2), k2 = 0..10 (only bins <= 200 are used); even k2 from the sums
+            // A[n2] + A[n2 + 10], odd k2 from the differences - two passes over the LDS operands, 40 registers of operands each
+            double pw[11];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                if (act) {
+                    double2 h[10];
+#pragma unroll
+                    for (int n2 = 0; n2 < 10; ++n2) {
+                        const double2 u = Af[n2 * 20 + l20], w = Af[(n2 + 10) * 20 + l20];
+                        h[n2] = par ? make_double2(u.x - w.x, u.y - w.y) : make_double2(u.x + w.x, u.y + w.y);
+                    }
+#pragma unroll
+                    for (int k2 = par; k2 <= 10; k2 += 2) {
+                        double xr = 0.0, xi = 0.0;
+#pragma unroll
+                        for (int n2 = 0; n2 < 10; ++n2) {
+                            const double c = c_dft20c[(n2 * k2) % 20], s_ = c_dft20s[(n2 * k2) % 20];
+                            xr += h[n2].x * c + h[n2].y * s_;
+                            xi += h[n2].y * c - h[n2].x * s_;
+                        }
+                        pw[k2] = xr * xr + xi * xi;
+                    }
+                }
+            }
+            sb_wave_sync();                                 // every lane has read its operands: the frame's region is free for |X|^2
+            if (act) {
+#pragma unroll
+                for (int k2 = 0; k2 <= 10; ++k2) {
+                    const int kk = l20 + 20 * k2;
+                    if (kk < SB_NBIN) Pf[kk] = pw[k2];
+                }
+            }
+            sb_wave_sync();
+            // band energies of the wave's three frames: out[f][j] = sum_q |X_f[q]|^2 g2[j][q]
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+#pragma unroll 8
+            for (int q = bq0; q < bq1; ++q) {
+                const double gq = ws.g2t[q * SB_J + bj];
+                e0 += gq * P0[q]; e1 += gq * P1[q]; e2 += gq * P2[q];
+            }
+            e0 += __shfl(e0, lane + SB_J, 64); e1 += __shfl(e1, lane + SB_J, 64); e2 += __shfl(e2, lane + SB_J, 64);
+            if (lane < SB_J) {
+                double* o = ws.XL + (((size_t)b * 2 + sig) * SB_J + bj) * ws.NA + k0 + 3 * wv;
+                if (k0 + 3 * wv < na) o[0] = log(e0 + SB_EPS);
+                if (k0 + 3 * wv + 1 < na) o[1] = log(e1 + SB_EPS);
+                if (k0 + 3 * wv + 2 < na) o[2] = log(e2 + SB_EPS);
+            }
+            sb_wave_sync();                                 // the regions are rewritten by the next signal / group
         }
     }
 }
@@ -1105,7 +1260,11 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
     }
     if (sx || sy) {
         const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
-        hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
+        static const bool specw = [] { const char* e = getenv("NELE_SIIB_SPECW"); return !(e && e[0] == '0'); }();
+        if (specw)
+            hipLaunchKernelGGL(siib_spec_wave_kernel, dim3((ws.NA + SP_F * SPW_NG - 1) / (SP_F * SPW_NG), B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
+        else
+            hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
         hipLaunchKernelGGL(siib_spread_kernel, dim3((ws.NA + 255) / 256, B), dim3(256), 0, s, ws, Pf, sig0, sig1);
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);

@@ -247,6 +247,38 @@ def test_siib_lag_products_equal_the_stacked_frame_gemms(tmp_path):
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
 
 
+_SPECW_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for L, B in ((64000, 3), (63871, 3), (33536, 2), (18000, 2), (4001, 2)):
+    c, v = synth.batch(B, L, start=77)
+    raw, _, info = mt.batch_siib(c, 0.8 * c + v, return_info=True)
+    out += [raw.double().cpu().numpy(), info.cpu().numpy().astype(np.float64).ravel()]
+c, v = synth.batch(4, 48000, start=78)
+raw, _, info = mt.batch_siib(c, c + v, lengths=torch.tensor([48000, 30001, 9999, 41234], dtype=torch.int32), return_info=True)
+out += [raw.double().cpu().numpy(), info.cpu().numpy().astype(np.float64).ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_siib_wave_autonomous_spectrum_kernel_matches_the_workgroup_kernel(tmp_path):
+    """The 400-point spectra + band energies run one wave per three frames (samples straight into registers, radix-2 split of the two
+    20-point stages, wave-level ordering only).  Same transform in another association: scores against the kernel it replaces
+    (NELE_SIIB_SPECW=0, read once per process) - periodic and aperiodic lengths, short files with large replication factors (frames
+    that run over the end of the tiled signal), a padded batch of different lengths; VAD / frame counts must be identical."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('siib_specw_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _SPECW_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_SIIB_SPECW=flag), timeout=240)
+        res.append(np.load(out))
+    assert np.all(np.isfinite(res[0])) and res[0].shape == res[1].shape
+    np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
+
+
 _ESTOI_AB_CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
