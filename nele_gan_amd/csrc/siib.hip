@@ -87,15 +87,20 @@ __global__ void siib_g2_kernel(double* __restrict__ g2, double* __restrict__ tab
 }
 
 // frame f of the tiled signal: samples x[(200 f + j) mod L], j < 400 (zero beyond M*L: intel.py:28-31 pads)
-__device__ __forceinline__ double frame_db(const float* __restrict__ x, int L, long long total, int f, int lane) {
+// win = the hann400 table siib_g2_kernel has written (ws.tab + 800: the same values, a load instead of a float64 cospi per sample)
+__device__ __forceinline__ double frame_db(const float* __restrict__ x, int L, long long total, int f, int lane, const double* __restrict__ win) {
     double s = 0.0;
     const long long p0 = (long long)SB_SHIFT * f;
     int q = (int)(p0 % L);
-    for (int j = lane; j < SB_WLEN; j += 64) {
-        int qq = q + j;
-        while (qq >= L) qq -= L;
-        const double v = (p0 + j < total) ? (double)x[qq] * hann400(j) : 0.0;
-        s += v * v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int j = lane + 64 * i;
+        if (j < SB_WLEN) {
+            int qq = q + j;
+            while (qq >= L) qq -= L;
+            const double v = (p0 + j < total) ? (double)x[qq] * win[j] : 0.0;
+            s += v * v;
+        }
     }
     s = wave_sum(s);
     return 10.0 * log10(s / (double)SB_WLEN + SB_EPS);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void siib_db_kernel(const float* __restrict__ 
         nf = min(ws.info[4 * b + 1], Pf);
     }
     if (f >= nf || f >= ws.NT) return;
-    const double e = frame_db(x + (size_t)b * L, Lb, total, f, lane);
+    const double e = frame_db(x + (size_t)b * L, Lb, total, f, lane, ws.tab + 2 * SB_WLEN);
     if (lane == 0) ws.xdb[(size_t)b * ws.NT + f] = e;
 }
 
@@ -361,35 +366,42 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
     }
 }
 
-// s3, wave-autonomous form (round 3, third session; NELE_SIIB_SPECW=0 = the kernel above).  The kernel above ran at one wave per SIMD
-// (64 KB of LDS per 2-wave workgroup) with four workgroup barriers per signal, a staging loop of dependent global loads and a band stage
-// that waits for 51 filter rows four at a time: 22 us per workgroup for 3.5 us of float64 arithmetic - 3.0 ms per signal at B = 256 on
-// a non-periodic length, the largest kernel of that step.  Here a WAVE owns three frames from the samples to the band energies:
-//  * a lane loads its 20 samples straight into registers (thread = (frame, n2): for each n1 the 20 lanes of a frame read 80 contiguous
-//    bytes) - no staged frame in LDS; window values and the W400 twiddles of the lane's n2 are per-lane constants, loaded once per
-//    workgroup into registers and reused for SPW_NG groups of six frames;
+// s3, wave-autonomous form (round 3, third session; NELE_SIIB_SPECW=0 = the kernel above).  The kernel above runs at one wave per SIMD
+// (502 registers: with the 20-point twiddles as literals the compiler pre-multiplies and keeps hundreds of products live; 64 KB of
+// LDS per 2-wave workgroup) with four workgroup barriers per signal, a staging loop of dependent global loads and a band stage that
+// waits for 51 filter rows four at a time: 22 us per workgroup for 3.5 us of float64 arithmetic - 2.9 ms per signal at B = 256 on a
+// non-periodic length, the largest kernel of that step.  Here a WAVE owns three frames from the samples to the band energies:
+//  * a lane loads its 20 samples straight into registers (thread = (frame, n2): for each n1 the 20 lanes of a frame read 80
+//    contiguous bytes), one (group, signal) pass AHEAD of their use - no staged frame in LDS, no load latency on the chain;
+//  * both 20-point stages split radix-2 first (W20^(10 k) = (-1)^k: even outputs from sums, odd ones from differences; stage 2 in two
+//    passes over its LDS operands, 40 registers of operands each); the four twiddle magnitudes are wave-uniform scalars, their signs /
+//    zeros / ones resolved at compile time from the table index: 850 float64 operations per lane and frame, 256 registers, two waves
+//    per SIMD; window values and the W400 twiddles are re-read from L1 per pass (laundered pointer) instead of living in 120 registers;
 //  * LDS only carries the stage-1 output (6.4 KB per frame; |X|^2 overlays it once the stage-2 operands are in registers): 38 KB per
 //    workgroup, four workgroups = eight waves per CU;
-//  * the two stages and the band stage are ordered by wave-level fences only (the three frames of a wave never meet another wave's);
-//  * band stage: lane = (band, half of the bins), the filter rows come from L1 / L2 with all loads of an unrolled block in flight,
-//    the two halves meet through a shuffle.
-// Same sums in the same order per output except the band energies' final association (2 partial sums instead of 4): results agree
-// with the kernel above to a few ulps (tests/test_metrics_gpu.py).
+//  * the stages are ordered by wave-level fences only (the three frames of a wave never meet another wave's);
+//  * band stage: lane = (band, half of the bins), filter rows from L1 / L2 in blocks of 25 with all loads of a block in flight (the
+//    45 KB table does not fit L1: a block costs an L2 latency), the halves meet through a shuffle.
+// Same transform in another association (radix-2 split, 2 partial band sums instead of 4): scores agree with the kernel above to the
+// last float32 bit or two (tests/test_metrics_gpu.py).  Measured at B = 256, L = 63 871, both signals in one launch: 5.73 -> 2.79 ms
+// (what is left by diagnostic builds: band stage 1.1 ms, sample / table loads 0.5 ms, the transform itself 1.3 ms, instruction-issue
+// bound - every wave64 instruction takes four cycles and only 40 % of them are float64 arithmetic).
 #define SPW_NG 4
-// cos / sin (2 pi t / 20) in constant memory: wave-uniform scalar operands (s_load) of the multiply-adds.  As compile-time literals
-// (the kernel above) the compiler pre-multiplies and keeps hundreds of products live: 502 registers, one wave per SIMD.
+// cos / sin (2 pi t / 20): the kernel reads entries 1 .. 4 (the four magnitudes) as scalars
 __constant__ double c_dft20c[20] = {1.0, 0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
                                     -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
                                     -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410, 0.0,
                                     0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212};
-__constant__ double c_dft20s[20] = {0.0, 0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212, 1.0,
-                                    0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
-                                    -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
-                                    -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410};
 __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
                                                              int sig1) {
     __shared__ __attribute__((aligned(16))) double2 Aq[SP_F][SB_WLEN];   // stage-1 output [n2][k1]; then |X|^2 in its first 201 doubles
     const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // the four magnitudes of cos / sin (2 pi t / 20) as wave-uniform scalars (8 SGPRs for the whole kernel); signs, zeros and ones are
+    // resolved at compile time from the table index, so multiplications by 0 and +-1 disappear and nothing waits for a table load
+    const double M1 = c_dft20c[1], M2 = c_dft20c[2], M3 = c_dft20c[3], M4 = c_dft20c[4];
+#define TWM(m) ((m) == 0 ? 1.0 : (m) == 1 ? M1 : (m) == 2 ? M2 : (m) == 3 ? M3 : (m) == 4 ? M4 : 0.0)
+#define TWC(t) ((t) <= 5 ? TWM(t) : (t) <= 10 ? -TWM(10 - (t)) : (t) <= 15 ? -TWM((t) - 10) : TWM(20 - (t)))
+#define TWS(t) ((t) <= 5 ? TWM(5 - (t)) : (t) <= 10 ? TWM((t) - 5) : (t) <= 15 ? -TWM(15 - (t)) : -TWM((t) - 15))
     const int* info = ws.info + 4 * b;
     const int na = ws.nprim[b];                        // frames of the first period only: siib_spread_kernel copies the repeats
     const int kbase = blockIdx.x * (SP_F * SPW_NG);
@@ -402,24 +414,48 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
     const bool lact = fl < 3;
     double2* Af = Aq[fs];
     double* Pf = reinterpret_cast<double*>(Af);
-    const int bj = lane % SB_J, bpart = lane / SB_J;   // band stage: band, half of the bins (lanes 56..63 idle)
-    const int bq0 = bpart * 101, bq1 = bpart == 0 ? 101 : (bpart == 1 ? SB_NBIN : 0);
-    const double* P0 = reinterpret_cast<const double*>(Aq[3 * wv]);
-    const double* P1 = reinterpret_cast<const double*>(Aq[3 * wv + 1]);
-    const double* P2 = reinterpret_cast<const double*>(Aq[3 * wv + 2]);
-    for (int g = 0; g < SPW_NG; ++g) {
+    const int bj = lane % SB_J, bpart = lane / SB_J;   // band stage: band, half of the bins (lanes 56..63 idle: they shadow part 0)
+    const int bp = bpart < 2 ? bpart : 0;
+    const double* gp = ws.g2t + (bp * 100) * SB_J + bj;
+    const double* P0 = reinterpret_cast<const double*>(Aq[3 * wv]) + bp * 100;
+    const double* P1 = reinterpret_cast<const double*>(Aq[3 * wv + 1]) + bp * 100;
+    const double* P2 = reinterpret_cast<const double*>(Aq[3 * wv + 2]) + bp * 100;
+    // frame bookkeeping of group g for this lane: first sample (mod L) and the samples before the tiled signal ends
+    auto frame_of = [&](int g, int& q0, int& nv) {
+        q0 = 0; nv = 0;
         const int k0 = kbase + SP_F * g;
-        if (k0 >= na) break;
-        const bool act = lact && (k0 + fs < na);
-        int q0 = 0, nv = 0;
-        if (act) {
+        if (g < SPW_NG && lact && k0 + fs < na) {
             const long long p0 = (long long)SB_SHIFT * ws.list[(size_t)b * ws.NA + k0 + fs];
             q0 = (int)(p0 % L);
             const long long left = total - p0;
             nv = left >= SB_WLEN ? SB_WLEN : (left > 0 ? (int)left : 0);
         }
+    };
+    // the lane's 20 raw samples of one (group, signal) pass: 20 independent loads, issued one pass AHEAD of their use
+    auto fetch = [&](const float* __restrict__ sb, int q0, int nv, float (&r)[20]) {
+#pragma unroll
+        for (int n1 = 0; n1 < 20; ++n1) {
+            const int j = 20 * n1 + l20;
+            int q = q0 + j;
+            if (q >= L) q -= L;                             // L >= 400 (checked on the host): one wrap at most
+            r[n1] = (j < nv) ? sb[q] : 0.f;
+        }
+    };
+    const float* xb = x + (size_t)b * Lrow;
+    const float* yb = y + (size_t)b * Lrow;
+    int q0, nv;
+    float cur[20];
+    frame_of(0, q0, nv);
+    fetch(sig0 ? yb : xb, q0, nv, cur);
+    for (int g = 0; g < SPW_NG; ++g) {
+        const int k0 = kbase + SP_F * g;
+        if (k0 >= na) break;
+        const bool act = nv > 0 || (lact && k0 + fs < na);
         for (int sig = sig0; sig <= sig1; ++sig) {
-            const float* sb = (sig ? y : x) + (size_t)b * Lrow;
+            float nxt[20];
+            int q0n = q0, nvn = nv;
+            if (sig == sig1) frame_of(g + 1, q0n, nvn);
+            fetch((sig == sig1 ? sig0 : sig + 1) ? yb : xb, q0n, nvn, nxt);
             const double* tab = ws.tab;                     // laundered per pass: the per-lane table values are re-read from L1 instead of
             asm volatile("" : "+s"(tab));                   // living in 120 registers across the whole kernel
             if (act) {      // stage 1: a[k1] = sum_n1 v[n1] W20^(n1 k1), then * W400^(n2 k1); radix 2 first: W20^(10 k1) = (-1)^k1
@@ -427,12 +463,8 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
 #pragma unroll
                 for (int n1 = 0; n1 < 10; ++n1) {
                     const int j0 = 20 * n1 + l20, j1 = j0 + 200;
-                    int qa = q0 + j0, qb = q0 + j1;
-                    if (qa >= L) qa -= L;                   // L >= 400 (checked on the host): one wrap at most
-                    if (qb >= L) qb -= L;
-                    const float sa = (j0 < nv) ? sb[qa] : 0.f, sc = (j1 < nv) ? sb[qb] : 0.f;
-                    const double va = (j0 < nv) ? (double)sa * tab[2 * SB_WLEN + j0] : 0.0;
-                    const double vb = (j1 < nv) ? (double)sc * tab[2 * SB_WLEN + j1] : 0.0;
+                    const double va = (j0 < nv) ? (double)cur[n1] * tab[2 * SB_WLEN + j0] : 0.0;
+                    const double vb = (j1 < nv) ? (double)cur[n1 + 10] * tab[2 * SB_WLEN + j1] : 0.0;
                     ve[n1] = va + vb; vo[n1] = va - vb;
                 }
 #pragma unroll
@@ -441,8 +473,8 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
 #pragma unroll
                     for (int n1 = 0; n1 < 10; ++n1) {
                         const double vv = (k1 & 1) ? vo[n1] : ve[n1];
-                        ar += vv * c_dft20c[(n1 * k1) % 20];
-                        ai -= vv * c_dft20s[(n1 * k1) % 20];
+                        ar += vv * TWC((n1 * k1) % 20);
+                        ai -= vv * TWS((n1 * k1) % 20);
                     }
                     {
                         const double c2 = tab[l20 * k1], s2 = tab[SB_WLEN + l20 * k1];
@@ -473,7 +505,7 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
                         double xr = 0.0, xi = 0.0;
 #pragma unroll
                         for (int n2 = 0; n2 < 10; ++n2) {
-                            const double c = c_dft20c[(n2 * k2) % 20], s_ = c_dft20s[(n2 * k2) % 20];
+                            const double c = TWC((n2 * k2) % 20), s_ = TWS((n2 * k2) % 20);
                             xr += h[n2].x * c + h[n2].y * s_;
                             xi += h[n2].y * c - h[n2].x * s_;
                         }
@@ -492,11 +524,20 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
             sb_wave_sync();
             // band energies of the wave's three frames: out[f][j] = sum_q |X_f[q]|^2 g2[j][q]
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-#pragma unroll 8
-            for (int q = bq0; q < bq1; ++q) {
-                const double gq = ws.g2t[q * SB_J + bj];
-                e0 += gq * P0[q]; e1 += gq * P1[q]; e2 += gq * P2[q];
+            // bins 100 bp .. 100 bp + 99 in four blocks of 25 filter rows, all loads of a block in flight; bin 200 belongs to half 1
+            const double g200 = ws.g2t[200 * SB_J + bj];
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                double gq[25];
+#pragma unroll
+                for (int u = 0; u < 25; ++u) gq[u] = gp[(25 * c + u) * SB_J];
+#pragma unroll
+                for (int u = 0; u < 25; ++u) {
+                    const int q = 25 * c + u;
+                    e0 += gq[u] * P0[q]; e1 += gq[u] * P1[q]; e2 += gq[u] * P2[q];
+                }
             }
+            if (bpart == 1) { e0 += g200 * P0[100]; e1 += g200 * P1[100]; e2 += g200 * P2[100]; }
             e0 += __shfl(e0, lane + SB_J, 64); e1 += __shfl(e1, lane + SB_J, 64); e2 += __shfl(e2, lane + SB_J, 64);
             if (lane < SB_J) {
                 double* o = ws.XL + (((size_t)b * 2 + sig) * SB_J + bj) * ws.NA + k0 + 3 * wv;
@@ -505,9 +546,15 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
                 if (k0 + 3 * wv + 2 < na) o[2] = log(e2 + SB_EPS);
             }
             sb_wave_sync();                                 // the regions are rewritten by the next signal / group
+#pragma unroll
+            for (int n1 = 0; n1 < 20; ++n1) cur[n1] = nxt[n1];
+            q0 = q0n; nv = nvn;
         }
     }
 }
+#undef TWM
+#undef TWC
+#undef TWS
 
 // s3b: the tiled signal repeats every Pf = L / gcd(L, 200) frames (frame f starts at sample 200 f mod L; every frame lies wholly inside
 // the tiled signal), so the band energies of an active frame f >= Pf are those of frame f mod Pf, which is active too (same samples,
