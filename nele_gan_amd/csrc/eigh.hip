@@ -1806,12 +1806,13 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             }
             const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
-            // NELE_EIGH_P4_BATCH: matrices per launch (default 64 = the whole chip).  The spinning workgroups own their CU - registers
-            // full, issue slots mostly idle - so 32 per launch (half the chip, twice the launches) leaves room for the step's other
-            // streams: 45.4 / 45.5 / 46.0 against 46.1 / 46.2 / 46.3 ms on the B = 256 step (alternating, one box), while the chain's
-            // own time doubles (8 x 1.37 instead of 4 x 1.42 ms per 256 matrices).  Within the pool's box-to-box spread: default unchanged.
+            // NELE_EIGH_P4_BATCH: matrices per launch (default 32 = half of the chip; 64 = all of it).  The spinning workgroups own
+            // their CU - registers full, issue slots mostly idle - so 32 per launch (twice the launches) leaves room for the step's other
+            // streams while the chain's own time doubles (8 x 1.2 instead of 4 x 1.2 ms per 256 matrices).  Measured twice on the
+            // B = 256 step, alternating on one box: 45.4 / 45.5 / 46.0 against 46.1 / 46.2 / 46.3 ms (second session), 42.8 / 42.5
+            // against 43.7 / 43.3 ms (third session; 48 per launch: 42.9 / 42.4) - the default since the second measurement.
             static int p4_batch = -1;
-            if (p4_batch < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_batch = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 64; }
+            if (p4_batch < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_batch = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 32; }
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop);
