@@ -384,6 +384,16 @@ __device__ __forceinline__ double band_gain_sqrt(const float* __restrict__ a2, i
     return sqrt((double)g);
 }
 
+// the same with the band of bin k looked up (gain_istft_wave_kernel fills the table once per workgroup instead of searching per bin and hop)
+__device__ __forceinline__ double band_gain_sqrt_at(const float* __restrict__ a2, int k, int i) {
+    if (k <= 1) return sqrt(1e-4);
+    if (k == NELE_NBINS - 1) return sqrt(1e-2);
+    const int size = c_gmt[i + 1] - c_gmt[i], jj = k - c_gmt[i];
+    const double frac = (double)jj / (double)size;
+    const float g = (float)(1.0 - frac) * a2[i] + (float)frac * a2[i + 1];
+    return sqrt((double)g);
+}
+
 __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
                                                          int T, float* __restrict__ wav, const int* __restrict__ tlens) {
     __shared__ Fft512Lds s;
@@ -429,7 +439,13 @@ __global__ __launch_bounds__(256) void gain_istft_wave_kernel(const float* __res
     __shared__ double2 tw[256];
     __shared__ double hw[NELE_NFFT];
     __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
+    __shared__ unsigned char bidx[NELE_NBINS + 3];        // band of every bin (the search of band_gain_sqrt, once per workgroup)
     const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    for (int k = tid; k < NELE_NBINS; k += 256) {
+        int i = 0;
+        while (i < NELE_NBANDS - 2 && c_gmt[i + 1] <= k) ++i;
+        bidx[k] = (unsigned char)i;
+    }
     {
         double sn, cs;
         sincospi((double)tid / 256.0, &sn, &cs);
@@ -453,7 +469,8 @@ __global__ __launch_bounds__(256) void gain_istft_wave_kernel(const float* __res
         const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
         const float2* Xb = Xa + NELE_NBINS;
         for (int k = lane; k < NELE_NBINS; k += 64) {
-            const double ga = a2a ? band_gain_sqrt(a2a, k) : 1.0, gb = a2a ? band_gain_sqrt(a2b, k) : 1.0;
+            const int bi_ = bidx[k];
+            const double ga = a2a ? band_gain_sqrt_at(a2a, k, bi_) : 1.0, gb = a2a ? band_gain_sqrt_at(a2b, k, bi_) : 1.0;
             const float2 xa = Xa[k], xb = Xb[k];
             double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
             double br = gb * (double)xb.x, bi = gb * (double)xb.y;

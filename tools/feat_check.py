@@ -9,10 +9,12 @@ c, v = synth.batch(min(B, 16), L, start=40)
 reps = (B + len(c) - 1) // len(c)
 x = torch.from_numpy(np.tile(c, (reps, 1))[:B]).cuda(); n = torch.from_numpy(np.tile(v, (reps, 1))[:B]).cuda()
 p_power = 0.3 if not hasattr(au, 'P_POWER') else au.P_POWER
+alpha = torch.ones(B, 1 + L // 256, 64, device='cuda') * 0.7
 def step():
     cs, cb = au.stft_band(x, p_power)
     ns, _ = au.stft_band(n, p_power, want_band=False)
     _, nb = au.imcra_band(ns, p_power)
+    w = au.gain_istft(alpha, cs)
     return cs, cb, nb
 for _ in range(2):
     step()
