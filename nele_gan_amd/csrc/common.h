@@ -20,6 +20,7 @@
 int nele_set_error(int code, const char* fmt, ...);
 
 // csrc/eigh.hip (also part of the public C ABI)
+extern __attribute__((visibility("hidden"))) int nele_eigh_cluster_batch_hint;   // eigh.hip: matrices per cluster launch for the next call (0 = default; a hint only)
 extern "C" long long nele_eigh_workspace_bytes(int B, int n);
 extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
                                      void* stream);

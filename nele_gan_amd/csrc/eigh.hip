@@ -1753,6 +1753,9 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     return o;
 }
 
+// matrices per cluster launch asked for by the caller of the next nele_eigh_sym_batched (0 = no preference; a performance hint only)
+__attribute__((visibility("hidden"))) int nele_eigh_cluster_batch_hint = 0;
+
 extern "C" long long nele_eigh_workspace_bytes(int B, int n) { return (long long)eigh_layout(B, n, nullptr, nullptr); }
 
 // A [B][n][n] symmetric (destroyed: holds the Householder reflectors on exit) -> lam [B][n] ascending,
@@ -1806,13 +1809,18 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             }
             const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
-            // NELE_EIGH_P4_BATCH: matrices per launch (default 32 = half of the chip; 64 = all of it).  The spinning workgroups own
+            // NELE_EIGH_P4_BATCH: matrices per launch (32 = half of the chip inside a training step, 64 = all of it otherwise).  The spinning workgroups own
             // their CU - registers full, issue slots mostly idle - so 32 per launch (twice the launches) leaves room for the step's other
             // streams while the chain's own time doubles (8 x 1.2 instead of 4 x 1.2 ms per 256 matrices).  Measured twice on the
             // B = 256 step, alternating on one box: 45.4 / 45.5 / 46.0 against 46.1 / 46.2 / 46.3 ms (second session), 42.8 / 42.5
             // against 43.7 / 43.3 ms (third session; 48 per launch: 42.9 / 42.4) - the default since the second measurement.
-            static int p4_batch = -1;
-            if (p4_batch < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_batch = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 32; }
+            // The caller says which: SIIB's clean-signal phase inside a training step (nele_metric_siib phase 3, which runs beside the
+            // G-step) asks for 32 through nele_eigh_cluster_batch_hint; a stand-alone call (one-shot SIIB, nele_eigh_sym_batched by
+            // itself) has nothing to share the chip with and takes 64 - one SIIB call at B = 256 is 17 ms that way and 21.5 ms with 32.
+            static int p4_env = -1;
+            if (p4_env < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_env = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 0; }
+            const int hint = nele_eigh_cluster_batch_hint;
+            const int p4_batch = p4_env ? p4_env : (hint >= 8 && hint <= 64 ? hint / 8 * 8 : 64);
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop);

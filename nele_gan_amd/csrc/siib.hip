@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void siib_mu_kernel(SiibWs ws, int sig0) {
 // are staged as zeros: the full-lag sums need no bounds in the loop.  The symmetric matrices (Sxx, Syy) only need the lags 0 .. 14
 // (the other half is the mirror image); the cross term needs all 29.
 template <int SIGA, int SIGB, int D0, int ND>
-__global__ __launch_bounds__(256) void siib_lag_kernel(SiibWs ws, int pair) {
+__global__ __launch_bounds__(256, (ND > 15 ? 2 : 4)) void siib_lag_kernel(SiibWs ws, int pair) {
     constexpr int CH = (SL_CH / ND) * ND;                    // frames per LDS chunk: whole window periods
     __shared__ double sa[CH][SB_J], sb[CH + ND - 1][SB_J];
     const int b = blockIdx.z, seg = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * 256 + tid;
@@ -975,18 +975,57 @@ __global__ __launch_bounds__(256) void siib_lag_kernel(SiibWs ws, int pair) {
     double acc[ND], w[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { acc[d] = 0.0; w[d] = 0.0; }
+    // Staging, software-pipelined (third session of round 3): a chunk's multiply-adds take 3 us, its staging loop - two dependent
+    // global loads per element, 16 rounds - took 10 (PMC: the waves of this kernel waited 55 % of their time at two workgroups per
+    // CU).  The raw values of chunk c + 1 are requested into registers before the multiply-adds of chunk c and stored (minus the row
+    // means, which sit in LDS) after them: one barrier pair per chunk as before, the load latency under the arithmetic.
+    __shared__ double rmean[2][SB_J];
+    if (tid < 2 * SB_J) rmean[tid / SB_J][tid % SB_J] = (tid < SB_J ? ra : rb)[2 * (tid % SB_J) + 1];
+    constexpr int NEA = (CH * SB_J + 255) / 256, NEB = ((CH + ND - 1) * SB_J + 255) / 256;
+    double pa[NEA], pb[NEB];
+    auto fetch = [&](int c0) {                               // thread -> (frame, band), coalesced along frames per band row
+#pragma unroll
+        for (int i = 0; i < NEA; ++i) {
+            const int e = tid + 256 * i, j = e / CH, r = e - j * CH, sidx = c0 + r;
+            pa[i] = (e < CH * SB_J && sidx < na) ? A[(size_t)j * ws.NA + sidx] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NEB; ++i) {
+            const int e = tid + 256 * i, j = e / (CH + ND - 1), r = e - j * (CH + ND - 1), sidx = c0 + D0 + r;
+            pb[i] = (e < (CH + ND - 1) * SB_J && sidx >= 0 && sidx < na) ? Bm[(size_t)j * ws.NA + sidx] : 0.0;
+        }
+    };
+    auto commit = [&](int c0) {                              // a[c0 .. c0 + CH) and b[c0 + D0 .. c0 + CH + D0 + ND - 1), zeros outside [0, na)
+#pragma unroll
+        for (int i = 0; i < NEA; ++i) {
+            const int e = tid + 256 * i, j = e / CH, r = e - j * CH, sidx = c0 + r;
+            if (e < CH * SB_J) sa[r][j] = (sidx < na) ? pa[i] - rmean[0][j] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NEB; ++i) {
+            const int e = tid + 256 * i, j = e / (CH + ND - 1), r = e - j * (CH + ND - 1), sidx = c0 + D0 + r;
+            if (e < (CH + ND - 1) * SB_J) sb[r][j] = (sidx >= 0 && sidx < na) ? pb[i] - rmean[1][j] : 0.0;
+        }
+    };
+    // (only the 29-lag instantiation is pipelined: the 15-lag ones run four workgroups per CU at 98 registers and hide the staging behind
+    //  each other - with the prefetch registers they drop to three and take 540 instead of 455 us)
+    constexpr bool PIPE = ND > 15;
+    if (PIPE && s0 < s1) fetch(s0);
     for (int c0 = s0; c0 < s1; c0 += CH) {
-        __syncthreads();
-        // stage a[c0 .. c0 + CH) and b[c0 + D0 .. c0 + CH + D0 + ND - 1): thread -> (frame, band), coalesced along frames per band row
-        for (int e = tid; e < CH * SB_J; e += 256) {
-            const int j = e / CH, r = e - j * CH, sidx = c0 + r;
-            sa[r][j] = (sidx < na) ? A[(size_t)j * ws.NA + sidx] - ra[2 * j + 1] : 0.0;
+        __syncthreads();                                    // the previous chunk's reads of sa / sb are done (and rmean is visible)
+        if constexpr (PIPE) commit(c0);
+        else {                                              // element by element: a[c0 .. c0 + CH) and b[c0 + D0 .. c0 + CH + D0 + ND - 1)
+            for (int e = tid; e < CH * SB_J; e += 256) {
+                const int j = e / CH, r = e - j * CH, sidx = c0 + r;
+                sa[r][j] = (sidx < na) ? A[(size_t)j * ws.NA + sidx] - rmean[0][j] : 0.0;
+            }
+            for (int e = tid; e < (CH + ND - 1) * SB_J; e += 256) {
+                const int j = e / (CH + ND - 1), r = e - j * (CH + ND - 1), sidx = c0 + D0 + r;
+                sb[r][j] = (sidx >= 0 && sidx < na) ? Bm[(size_t)j * ws.NA + sidx] - rmean[1][j] : 0.0;
+            }
         }
-        for (int e = tid; e < (CH + ND - 1) * SB_J; e += 256) {
-            const int j = e / (CH + ND - 1), r = e - j * (CH + ND - 1), sidx = c0 + D0 + r;
-            sb[r][j] = (sidx >= 0 && sidx < na) ? Bm[(size_t)j * ws.NA + sidx] - rb[2 * j + 1] : 0.0;
-        }
         __syncthreads();
+        if (PIPE && c0 + CH < s1) fetch(c0 + CH);
         if (c0 == s0) {                                     // window = b[s0 + D0 .. s0 + D0 + ND - 2] in slots 0 .. ND - 2
 #pragma unroll
             for (int q = 0; q < ND - 1; ++q) w[q] = sb[q][j2];
@@ -1340,7 +1379,9 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
     if (eig) {
+        nele_eigh_cluster_batch_hint = (phase == 3) ? 32 : 64;      // phase 3 runs beside the G-step: leave half of the chip to it (eigh.hip)
         int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
+        nele_eigh_cluster_batch_hint = 0;
         if (st) return st;
         if (phase == 3 && !siib_lag_path()) {               // clean-signal half of the projections, beside whatever the caller overlaps
             hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
