@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_raw.sh "siib_|eigh_bisect|eigh_wy|estoi_" tools/siib_ab.py 256 63871 > gpurun_out/siib_pmc3.txt 2>&1
-python tools/pmc_table.py gpurun_out/siib_pmc3.txt
+bash tools/pmc_raw.sh "${1:-siib_|eigh_}" ${2:-tools/siib_ab.py} ${3:-256} ${4:-63871} > gpurun_out/s3_pmc.txt 2>&1
+python tools/pmc_table.py gpurun_out/s3_pmc.txt
