@@ -37,6 +37,34 @@ __device__ __forceinline__ float band_energy(const float* tmp, int i) {
     return (float)acc;
 }
 
+// The same sums with the per-bin weights from LDS tables: band_energy() pays a float64 division per term on the one wave that runs it
+// (PMC: stft_band_wave_kernel and band_from_psd_kernel are bound by instruction issue, and the divisions are most of it).
+// frw[k] = (float)(j / size), omw[k] = (float)(1 - j / size) for bin k = g0 + j of its band - the very expressions above, evaluated once
+// per workgroup by one thread per BAND (<= 14 bins each; a per-bin fill that searches its band costs more than it saves: measured), so
+// every product and the order of the float64 sum are unchanged: bit-identical.
+__device__ __forceinline__ void band_weights_init(float* __restrict__ frw, float* __restrict__ omw) {
+    const int i = threadIdx.x;
+    if (i <= NELE_NBANDS - 2) {
+        const int g0 = c_gmt[i], size = c_gmt[i + 1] - g0;
+        for (int j = 0; j < size; ++j) {
+            frw[g0 + j] = (float)((double)j / (double)size);
+            omw[g0 + j] = (float)(1.0 - (double)j / (double)size);
+        }
+    }
+}
+__device__ __forceinline__ float band_energy_w(const float* tmp, const float* __restrict__ frw, const float* __restrict__ omw, int i) {
+    double acc = 0.0;
+    if (i >= 1) {
+        const int g0 = c_gmt[i - 1], g1 = c_gmt[i];
+        for (int k = g0; k < g1; ++k) acc += (double)(frw[k] * tmp[k]);
+    }
+    if (i <= NELE_NBANDS - 2) {
+        const int g0 = c_gmt[i], g1 = c_gmt[i + 1];
+        for (int k = g0; k < g1; ++k) acc += (double)(omw[k] * tmp[k]);
+    }
+    return (float)acc;
+}
+
 // np.abs(complex64) as numpy >= 1.25 computes it on FMA-capable x86 hosts (SIMD loop
 // loops_unary_complex: larger * sqrt(fma(r, r, 1)), r = smaller / larger), so that |X|^2 is
 // bit-identical to the oracle's and threshold decisions downstream (IMCRA, VAD) see the same values.
@@ -123,9 +151,10 @@ __global__ __launch_bounds__(256) void stft_band_wave_kernel(const float* __rest
     __shared__ double2 tw[256];
     __shared__ double hw[NELE_NFFT];
     __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
-    __shared__ float tmp[4][2][NELE_NBINS + 3];
+    __shared__ float frw[NELE_NBINS + 3], omw[NELE_NBINS + 3];
     const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const float* x = wav + (size_t)b * L;
+    if (band) band_weights_init(frw, omw);
     int Tb = T;
     if (lens) { L = min(lens[b], L); Tb = 1 + L / NELE_HOP; }
     {
@@ -165,25 +194,38 @@ __global__ __launch_bounds__(256) void stft_band_wave_kernel(const float* __rest
         }
         fft512_wave<false>(v, xw, tw, lane);
         fft512_wave_store(v, xw, lane);
-        for (int k = lane; k < NELE_NBINS; k += 64) {
-            const double2 zk = xw[fftw_slot(k)], zn = xw[fftw_slot((NELE_NFFT - k) & (NELE_NFFT - 1))];
-            const float2 A = make_float2((float)(0.5 * (zk.x + zn.x)), (float)(0.5 * (zk.y - zn.y)));
-            const float2 Bv = make_float2((float)(0.5 * (zk.y + zn.y)), (float)(0.5 * (zn.x - zk.x)));
-            if (spec) {
-                spec[((size_t)b * T + t0) * NELE_NBINS + k] = A;
-                if (has1) spec[((size_t)b * T + t1) * NELE_NBINS + k] = Bv;
+        float p0[5], p1[5];                                 // |X|^2 of the lane's bins, both frames
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int k = lane + 64 * q;
+            if (k < NELE_NBINS) {
+                const double2 zk = xw[fftw_slot(k)], zn = xw[fftw_slot((NELE_NFFT - k) & (NELE_NFFT - 1))];
+                const float2 A = make_float2((float)(0.5 * (zk.x + zn.x)), (float)(0.5 * (zk.y - zn.y)));
+                const float2 Bv = make_float2((float)(0.5 * (zk.y + zn.y)), (float)(0.5 * (zn.x - zk.x)));
+                if (spec) {
+                    spec[((size_t)b * T + t0) * NELE_NBINS + k] = A;
+                    if (has1) spec[((size_t)b * T + t1) * NELE_NBINS + k] = Bv;
+                }
+                const float m0 = np_cabsf(A.x, A.y);
+                const float m1 = np_cabsf(Bv.x, Bv.y);
+                p0[q] = m0 * m0;
+                p1[q] = m1 * m1;
             }
-            const float m0 = np_cabsf(A.x, A.y);
-            const float m1 = np_cabsf(Bv.x, Bv.y);
-            tmp[wv][0][k] = m0 * m0;
-            tmp[wv][1][k] = m1 * m1;
         }
-        fftw_wave_sync();
         if (band) {
-            band[((size_t)b * T + t0) * NELE_NBANDS + lane] = pow_f32(band_energy(tmp[wv][0], lane), power);
-            if (has1) band[((size_t)b * T + t1) * NELE_NBANDS + lane] = pow_f32(band_energy(tmp[wv][1], lane), power);
+            fftw_wave_sync();                               // every lane has read its bins: the exchange buffer is free for |X|^2 (float32)
+            float* tmp0 = reinterpret_cast<float*>(xw);
+            float* tmp1 = tmp0 + NELE_NBINS + 3;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int k = lane + 64 * q;
+                if (k < NELE_NBINS) { tmp0[k] = p0[q]; tmp1[k] = p1[q]; }
+            }
+            fftw_wave_sync();
+            band[((size_t)b * T + t0) * NELE_NBANDS + lane] = pow_f32(band_energy_w(tmp0, frw, omw, lane), power);
+            if (has1) band[((size_t)b * T + t1) * NELE_NBANDS + lane] = pow_f32(band_energy_w(tmp1, frw, omw, lane), power);
         }
-        fftw_wave_sync();                                   // tmp / xw are rewritten by the next pair
+        fftw_wave_sync();                                   // xw is rewritten by the next pair
     }
 }
 
@@ -351,7 +393,9 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
 // band feature of sqrt(PSD) for every frame at once (audio_util.py:446-451): grid (ceil(T / 4), B), block 256 = 4 frames x 64 bands
 __global__ __launch_bounds__(256) void band_from_psd_kernel(const float* __restrict__ psd, int T, float power, float* __restrict__ band) {
     __shared__ float tmp[4][NELE_NBINS + 3];
+    __shared__ float frw[NELE_NBINS + 3], omw[NELE_NBINS + 3];
     const int b = blockIdx.y, l0 = blockIdx.x * 4;
+    band_weights_init(frw, omw);
     for (int e = threadIdx.x; e < 4 * NELE_NBINS; e += 256) {
         const int f = e / NELE_NBINS, k = e - f * NELE_NBINS;
         if (l0 + f < T) {
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(256) void band_from_psd_kernel(const float* __restr
     }
     __syncthreads();
     const int f = threadIdx.x >> 6, i = threadIdx.x & 63;
-    if (l0 + f < T) band[((size_t)b * T + l0 + f) * NELE_NBANDS + i] = pow_f32(band_energy(tmp[f], i), power);
+    if (l0 + f < T) band[((size_t)b * T + l0 + f) * NELE_NBANDS + i] = pow_f32(band_energy_w(tmp[f], frw, omw, i), power);
 }
 
 // band[i] = band[i] ** power in place (the tail of imcra_band_kernel, parallel over frames)
