@@ -1316,7 +1316,8 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
             }
             LUE(1, k) = b_out;
             LUE(2, k + 1) = c_out;
-            LUE(3, k) = d2_out;
+            // (the second superdiagonal of U is not stored: d2[k] = e[k + 1] where step k interchanged rows, else 0 - the back substitution
+            //  rebuilds it from the interchange masks and the LDS copy of e: 15 % less HBM traffic in a kernel that is bound by it)
             LUE(5, k) = r;
             {                                           // element t = k + 1 of the start vector meets c[t] (see the forward sweep below)
                 const double y = lcg(rs);
@@ -1388,18 +1389,22 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
         asum = 0.0;
         s2 = 0.0;
         {
-            auto bload = [&](int cb, double2 (&xr)[IV_B / 2], double2 (&rr)[IV_B / 2], double2 (&br)[IV_B / 2], double2 (&dr)[IV_B / 2]) {
+            auto bload = [&](int cb, double2 (&xr)[IV_B / 2], double2 (&rr)[IV_B / 2], double2 (&br)[IV_B / 2], unsigned& mk) {
 #pragma unroll
                 for (int u = 0; u < IV_B / 2; ++u) {
                     const int pr = min((IV_B / 2) * cb + u, npairs - 1);
                     xr[u] = LUP(4, pr);
                     rr[u] = LUP(5, pr);
                     br[u] = LUP(1, pr);
-                    dr[u] = LUP(3, pr);
                 }
+                // interchange bits of steps k = IV_B cb .. IV_B cb + IV_B - 1 (bit k + 1 of the mask words: may straddle two of them)
+                const int p0 = IV_B * cb + 1, wd = p0 >> 5, sh = p0 & 31;
+                const unsigned lo = (unsigned)pinm[(size_t)wd * EG_MAXN + j], hi = (unsigned)pinm[(size_t)(wd + 1) * EG_MAXN + j];
+                mk = (unsigned)((((unsigned long long)hi << 32) | lo) >> sh);
             };
-            auto bstep = [&](int k, double xv, double rv, double bv, double dv) {
+            auto bstep = [&](int k, double xv, double rv, double bv, unsigned bit) {
                 if (k <= n - 1) {
+                    const double dv = (k <= n - 3 && bit) ? e[k + 1] : 0.0;
                     double temp = sclb * xv - ((k <= n - 2) ? bv : 0.0) * y1 - ((k <= n - 3) ? dv : 0.0) * y2;
                     double xk = temp * rv;
                     if (!(fabs(xk) <= bignum)) {                   // slow path: the reference's pivot perturbation
@@ -1426,23 +1431,23 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
                     s2 += xk * xk;
                 }
             };
-            auto bproc = [&](int cb, const double2 (&xr)[IV_B / 2], const double2 (&rr)[IV_B / 2], const double2 (&br)[IV_B / 2],
-                             const double2 (&dr)[IV_B / 2]) {
+            auto bproc = [&](int cb, const double2 (&xr)[IV_B / 2], const double2 (&rr)[IV_B / 2], const double2 (&br)[IV_B / 2], unsigned mk) {
 #pragma unroll
                 for (int u = IV_B / 2 - 1; u >= 0; --u) {
                     const int k = IV_B * cb + 2 * u;
-                    bstep(k + 1, xr[u].y, rr[u].y, br[u].y, dr[u].y);
-                    bstep(k, xr[u].x, rr[u].x, br[u].x, dr[u].x);
+                    bstep(k + 1, xr[u].y, rr[u].y, br[u].y, (mk >> (2 * u + 1)) & 1u);
+                    bstep(k, xr[u].x, rr[u].x, br[u].x, (mk >> (2 * u)) & 1u);
                 }
             };
-            double2 xA[IV_B / 2], rA[IV_B / 2], bA[IV_B / 2], dA[IV_B / 2], xB[IV_B / 2], rB[IV_B / 2], bB[IV_B / 2], dB[IV_B / 2];
-            bload(cbtop, xA, rA, bA, dA);
+            double2 xA[IV_B / 2], rA[IV_B / 2], bA[IV_B / 2], xB[IV_B / 2], rB[IV_B / 2], bB[IV_B / 2];
+            unsigned mA = 0, mB = 0;
+            bload(cbtop, xA, rA, bA, mA);
             for (int cb = cbtop; cb >= 0; cb -= 2) {
-                if (cb - 1 >= 0) bload(cb - 1, xB, rB, bB, dB);
-                bproc(cb, xA, rA, bA, dA);
+                if (cb - 1 >= 0) bload(cb - 1, xB, rB, bB, mB);
+                bproc(cb, xA, rA, bA, mA);
                 if (cb - 1 >= 0) {
-                    if (cb - 2 >= 0) bload(cb - 2, xA, rA, bA, dA);
-                    bproc(cb - 1, xB, rB, bB, dB);
+                    if (cb - 2 >= 0) bload(cb - 2, xA, rA, bA, mA);
+                    bproc(cb - 1, xB, rB, bB, mB);
                 }
             }
         }
