@@ -278,6 +278,87 @@ __global__ __launch_bounds__(256) void estoi_tob_kernel(EstoiWs ws) {
     }
 }
 
+// The same, one WAVE per kept frame with the transform in registers (fft512_wave, third session of round 3; NELE_ESTOI_TOBW=0 = the
+// kernel above): twiddles and the window once per workgroup of 4 x ETW_NP frames, no workgroup barrier per frame; only the bins of the
+// fifteen bands (7 .. 218) are unpacked.  grid (ceil(F / (4 ETW_NP)), B), block 256.
+#define ETW_NP 2
+__global__ __launch_bounds__(256) void estoi_tob_wave_kernel(EstoiWs ws) {
+    __shared__ double2 tw[256];
+    __shared__ double hw[ES_NFRAME];
+    __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
+    const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int nk = ws.nkept[b];
+    {
+        double sn, cs;
+        sincospi((double)tid / 256.0, &sn, &cs);
+        tw[tid] = make_double2(cs, -sn);
+        hw[tid] = hann_sym256(tid);
+    }
+    __syncthreads();
+    if ((int)blockIdx.x * ETW_NP * 4 >= nk) return;
+    const int* keep = ws.keep + (size_t)b * ws.F;
+    const double* x = ws.xr + (size_t)b * 2 * ws.n10;
+    const double* y = x + ws.n10;
+    double2* xw = xs[wv];
+    double* p2x = reinterpret_cast<double*>(xw);            // |X|^2 / |Y|^2 of the band bins overlay the exchange buffer
+    double* p2y = p2x + 256;
+    for (int it = 0; it < ETW_NP; ++it) {
+        const int k = ((int)blockIdx.x * ETW_NP + it) * 4 + wv;
+        if (k >= nk) break;
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int j = fftw_n(lane, r);                  // sample j of frame k of the silence-removed signal (zero padding behind 256)
+            double xs_ = 0.0, ys_ = 0.0;
+            if (j < ES_NFRAME) {
+                // x_sil[128 k + j] = sum over kept frames kk covering it of w[o] * x[128 f_kk + o], lower kk first
+                int kk0, o0, kk1, o1;
+                if (j < ES_HOP) { kk0 = k - 1; o0 = j + ES_HOP; kk1 = k; o1 = j; }
+                else { kk0 = k; o0 = j; kk1 = k + 1; o1 = j - ES_HOP; }
+                if (kk0 >= 0 && kk0 < nk) {
+                    const double w = hw[o0];
+                    const size_t p = (size_t)keep[kk0] * ES_HOP + o0;
+                    xs_ += w * x[p];
+                    ys_ += w * y[p];
+                }
+                if (kk1 >= 0 && kk1 < nk) {
+                    const double w = hw[o1];
+                    const size_t p = (size_t)keep[kk1] * ES_HOP + o1;
+                    xs_ += w * x[p];
+                    ys_ += w * y[p];
+                }
+                const double w = hw[j];
+                xs_ *= w; ys_ *= w;
+            }
+            v[r] = make_double2(xs_, ys_);
+        }
+        fft512_wave<false>(v, xw, tw, lane);
+        fft512_wave_store(v, xw, lane);
+        double px[4], py[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = lane + 64 * i;                    // bins 0 .. 255; the bands end at 218
+            const double2 zk = xw[fftw_slot(q)], zn = xw[fftw_slot((512 - q) & 511)];
+            const double ar = 0.5 * (zk.x + zn.x), ai = 0.5 * (zk.y - zn.y);
+            const double br = 0.5 * (zk.y + zn.y), bi = 0.5 * (zn.x - zk.x);
+            px[i] = ar * ar + ai * ai;
+            py[i] = br * br + bi * bi;
+        }
+        fftw_wave_sync();                                   // every lane has read its bins
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p2x[lane + 64 * i] = px[i]; p2y[lane + 64 * i] = py[i]; }
+        fftw_wave_sync();
+        if (lane < 2 * ES_NB) {
+            const int sig = lane / ES_NB, band = lane - sig * ES_NB;
+            const double* pp = sig ? p2y : p2x;
+            double a = 0.0;
+            for (int q = c_tob_lo[band]; q < c_tob_hi[band]; ++q) a += pp[q];
+            ws.tob[(((size_t)b * 2 + sig) * ES_NB + band) * ws.F + k] = sqrt(a);
+        }
+        fftw_wave_sync();                                   // the buffer is restaged by the next frame
+    }
+}
+
 // grid (F, B), block 64: segment m = frames m .. m+29
 __global__ __launch_bounds__(64) void estoi_seg_kernel(EstoiWs ws) {
     __shared__ double sx[ES_NB][ES_NSEG + 1], sy[ES_NB][ES_NSEG + 1];
@@ -398,7 +479,10 @@ extern "C" int nele_metric_estoi_var(const float* x, const float* y, const int* 
         hipLaunchKernelGGL(estoi_resample_kernel, dim3((n10 + 255) / 256, B, 2), dim3(256), 0, s, x, y, h, L, ws);
     }
     hipLaunchKernelGGL(estoi_vad_kernel, dim3(B), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(estoi_tob_kernel, dim3(F, B), dim3(256), 0, s, ws);
+    static int tobw = -1;                                  // NELE_ESTOI_TOBW=0: the workgroup-per-frame kernel (A/B diagnostic)
+    if (tobw < 0) { const char* e_ = getenv("NELE_ESTOI_TOBW"); tobw = !(e_ && e_[0] == '0'); }
+    if (tobw) hipLaunchKernelGGL(estoi_tob_wave_kernel, dim3((F + 4 * ETW_NP - 1) / (4 * ETW_NP), B), dim3(256), 0, s, ws);
+    else hipLaunchKernelGGL(estoi_tob_kernel, dim3(F, B), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(estoi_seg_kernel, dim3(F, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(estoi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     NELE_CHECK_LAUNCH("nele_metric_estoi");

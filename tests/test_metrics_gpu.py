@@ -310,6 +310,21 @@ def test_estoi_five_output_resampler_is_bit_identical_to_the_output_per_thread_o
     assert np.array_equal(res[0], res[1])
 
 
+def test_estoi_wave_per_frame_third_octave_kernel_matches_the_workgroup_kernel(tmp_path):
+    """The third-octave analysis runs one wave per kept frame with the 512-point transform in registers (fft512_wave).  Same transform,
+    but estoi.hip is compiled with FMA contraction, so the two kernels may round differently: scores against the workgroup-per-frame
+    kernel (NELE_ESTOI_TOBW=0, read once per process) to float32 resolution - whole and ragged batches, short files."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('estoi_tobw_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_ESTOI_TOBW=flag), timeout=240)
+        res.append(np.load(out))
+    assert np.all(np.isfinite(res[0])) and res[0].shape == (11,)
+    np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=1e-7)
+
+
 _HASPI_AB_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
