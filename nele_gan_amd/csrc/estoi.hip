@@ -192,10 +192,14 @@ __global__ __launch_bounds__(256) void estoi_vad_kernel(EstoiWs ws) {
     double* en = ws.en + (size_t)b * ws.F;
     const int Fb = es_frames(ws, b);
     double mx = -1e300;
+    double hwj[ES_NFRAME / 64];                              // the lane's four window values, once (not a float64 cospi per frame and sample)
+#pragma unroll
+    for (int i = 0; i < ES_NFRAME / 64; ++i) hwj[i] = hann_sym256(lane + 64 * i);
     for (int f = wave; f < Fb; f += 4) {
         double s = 0.0;
-        for (int j = lane; j < ES_NFRAME; j += 64) {
-            const double v = hann_sym256(j) * x[(size_t)f * ES_HOP + j];
+#pragma unroll
+        for (int i = 0; i < ES_NFRAME / 64; ++i) {
+            const double v = hwj[i] * x[(size_t)f * ES_HOP + lane + 64 * i];
             s += v * v;
         }
         s = wave_sum(s);
