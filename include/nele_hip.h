@@ -296,6 +296,11 @@ int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, c
  * (x may be NULL).  Phase 0 runs 3 then 4, so the split is bit-identical to the one-shot call. */
 int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
                           void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info, int phase, void* stream);
+/* pyhaspi2.py:362-365: the reference dithers the envelopes in EVERY haspi_v2 call with np.random.randn(n_active, 32) rows (x, then y)
+ * from numpy's global generator.  This fills the `dither` argument of nele_metric_haspi* with rows that are a pure function of
+ * (seed, utt_ids[b], signal, active-frame index, channel): the same on whichever rank / in whichever batch the utterance is scored
+ * (SURVEY 8e).  utt_ids [B] int64 (device), out [B][2][nsub][32] float64 (device), nsub = nele_metric_haspi_nsub(L, fs_in). */
+int nele_haspi_dither_rows(const long long* utt_ids, unsigned long long seed, int B, int nsub, double* out, void* stream);
 /* haspi_v2(x, fx, y, fy, HL) for a hearing-impaired listener (pyhaspi2.py:76-107 with eb_LossParameters :779-807 and the HLx / HL
  * split of eb_EarModel :1155-1166).  hl6_host: HOST pointer to the audiogram at 250, 500, 1000, 2000, 4000, 6000 Hz in dB HL (NULL =
  * normal hearing); itype 0 = the reference signal is heard with normal hearing (haspi_v2, haspi), 2 = both signals with the loss

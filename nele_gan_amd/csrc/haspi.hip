@@ -2277,3 +2277,29 @@ extern "C" int nele_metric_haspi(const float* x, const float* y, int B, int L, i
 }
 
 #include "haspi_quality.h"
+
+// ---- per-utterance dither rows (pyhaspi2.py:362-365: `thrNerve * np.random.randn(n_active, 32)` for x, then for y, on every call).
+// The reference draws from numpy's global generator, i.e. the draws depend on the order in which a process happens to score its files.
+// Here a row is a pure function of (seed, utterance id, signal, active-frame index, channel) - the same whichever rank scores the
+// utterance and whatever else shares its batch ("identical RNG seeds for HASPI dither per utterance id, not per rank").
+// splitmix64 counter hash -> two 53-bit uniforms -> Box-Muller in float64.  out [B][2][nsub][32] (the `dither` argument of
+// nele_metric_haspi*).  oracle/haspi.py:dither_rows is the numpy statement of the same function.
+__global__ __launch_bounds__(256) void haspi_dither_rows_kernel(const long long* __restrict__ ids, unsigned long long seed, int nsub,
+                                                                double* __restrict__ out) {
+    const int b = blockIdx.z, sig = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;                  // k * 32 + ch
+    if (e >= nsub * HP_NCH) return;
+    const unsigned long long key = hq_mix(seed ^ hq_mix((unsigned long long)ids[b]));
+    const unsigned long long idx = ((unsigned long long)sig << 40) | (unsigned long long)e;
+    const unsigned long long r1 = hq_mix(key ^ hq_mix(2ull * idx)), r2 = hq_mix(key ^ hq_mix(2ull * idx + 1ull));
+    const double u1 = ((double)(r1 >> 11) + 1.0) * 0x1.0p-53;      // (0, 1]
+    const double u2 = (double)(r2 >> 11) * 0x1.0p-53;              // [0, 1)
+    out[(((size_t)b * 2 + sig) * nsub) * HP_NCH + e] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+extern "C" int nele_haspi_dither_rows(const long long* utt_ids, unsigned long long seed, int B, int nsub, double* out, void* stream) {
+    NELE_CHECK_ARG(utt_ids && out && B > 0 && nsub > 0, "nele_haspi_dither_rows: bad arguments");
+    hipLaunchKernelGGL(haspi_dither_rows_kernel, dim3((nsub * HP_NCH + 255) / 256, 2, B), dim3(256), 0, as_stream(stream), utt_ids, seed, nsub, out);
+    NELE_CHECK_LAUNCH("nele_haspi_dither_rows");
+    return NELE_OK;
+}

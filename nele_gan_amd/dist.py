@@ -61,6 +61,16 @@ def allreduce_max_int(value, device='cpu'):
     return int(t.item())
 
 
+def allreduce_max_ints(values, device='cpu'):
+    """Element-wise max over ranks of a short list of host integers in ONE collective (e.g. step count, flags and an error flag that every
+    rank must see before any of them raises: a rank that raises alone leaves the others waiting in the next all-reduce)."""
+    if world_size() == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.tolist()]
+
+
 def backend_is_nccl():
     return is_dist() and dist.get_backend() == 'nccl'
 

@@ -57,6 +57,9 @@ _lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_haspi_nsub.restype = c_int
 _lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
 
+declare('nele_haspi_dither_rows', [_P, ctypes.c_ulonglong, c_int, c_int, _P, _P])
+_lib._SIGS['nele_haspi_dither_rows'] = _lib.lib.nele_haspi_dither_rows.argtypes
+
 declare('nele_eigh_sym_batched', [_P, c_int, c_int, _P, _P, _P, c_longlong, _P])
 _lib._SIGS['nele_eigh_sym_batched'] = _lib.lib.nele_eigh_sym_batched.argtypes
 _lib.lib.nele_eigh_workspace_bytes.argtypes = [c_int, c_int]
@@ -256,6 +259,20 @@ def batch_haspi(x, y, fs=16000, dither=None, seed=None, return_info=False, lengt
     if return_info:
         return raw, mapped, info
     return raw, mapped
+
+
+def haspi_dither_rows(utt_ids, seed, L, fs=16000, device=None):
+    """Dither rows [B, 2, nsub, 32] float64 for batch_haspi / HaspiSplit, drawn per UTTERANCE ID (pyhaspi2.py:362-365 draws
+    np.random.randn rows on every call; here a row is a pure function of (seed, id, signal, frame, channel), so an utterance is
+    scored alike on any rank and in any batch - SURVEY 8e).  utt_ids: [B] integers."""
+    ids = torch.as_tensor(utt_ids)
+    device = device or (ids.device if ids.is_cuda else 'cuda')
+    ids = ids.to(device=device, dtype=torch.int64).contiguous()
+    B = ids.shape[0]
+    nsub = _lib.lib.nele_metric_haspi_nsub(int(L), int(fs))
+    out = torch.empty((B, 2, nsub, 32), dtype=torch.float64, device=ids.device)
+    call('nele_haspi_dither_rows', ptr(ids), int(seed) & 0xFFFFFFFFFFFFFFFF, B, nsub, ptr(out), stream())
+    return out
 
 
 class HaspiSplit:

@@ -161,12 +161,15 @@ def _lru_get(cache, key, make):
 
 
 def _check_generation(ctx, name):
-    if ctx.key not in ctx.module._bufs:
-        raise RuntimeError("%s: backward() after %d other (batch, frames) shapes went through the module - the cached activations of "
-                           "this graph have been evicted (raise NELE_MAX_BUFFER_SHAPES)" % (name, MAX_BUFFER_SHAPES))
     """The activation buffers are cached per (B, T): a second forward of the same shape overwrites what the first graph's backward
     pass needs.  Each forward bumps the buffer set's generation; a backward whose generation is stale raises instead of silently
     differentiating the wrong activations."""
+    if ctx.key not in ctx.module._bufs:
+        raise RuntimeError("%s: backward() after %d other (batch, frames) shapes went through the module - the cached activations of "
+                           "this graph have been evicted (raise NELE_MAX_BUFFER_SHAPES)" % (name, MAX_BUFFER_SHAPES))
+    if getattr(ctx, 'precision', None) is not None and ctx.module.precision != ctx.precision:
+        raise RuntimeError("%s: `precision` changed from %r to %r between forward() and backward() - the cached activations were written "
+                           "for the forward pass's operand type" % (name, ctx.precision, ctx.module.precision))
     if ctx.module._bufs[ctx.key].gen != ctx.gen:
         raise RuntimeError("%s: backward() after another forward pass of the same (batch, frames) shape - the cached activations of "
                            "this graph have been overwritten (run backward before the next forward of that shape)" % name)
@@ -213,6 +216,7 @@ class _GFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, anchor, module):
         ctx.module = module
+        ctx.precision = module.precision
         ctx.key = module._forward_impl(x, y)
         ctx.gen = module._bufs[ctx.key].gen
         mask = module._last_mask
@@ -423,6 +427,7 @@ class _DBuffers:
         self.B, self.T = B, T
         self.gen = 0
         self.wvalid = None
+        self.prepjobs = None               # (key, ctypes job tables) of the batched weight-layout launches for this shape
         H, W, C = 64, T, 4
         self.dims = [(H, W, C)]
         self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
@@ -487,6 +492,7 @@ class _DFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, din, anchor, module, frames=None):
         ctx.module = module
+        ctx.precision = module.precision
         ctx.key = module._forward_impl(din, frames)
         ctx.wvalid = module._bufs[ctx.key].wvalid
         ctx.gen = module._bufs[ctx.key].gen
@@ -594,6 +600,25 @@ class _DiscriminatorBase(nn.Module):
         ev.record(torch.cuda.current_stream())
         self._prepared = (key, self.training, ev)
 
+    def advance_power_iteration(self, dev=None):
+        """One spectral-norm power iteration of every layer (what a training-mode forward pass does first, model.py:105-116), no data.
+        An empty data-parallel step (this rank has run out of batches) calls it so that weight_u / weight_v advance in lock-step with
+        the ranks that ran a real forward pass: all replicas then normalise by the same sigma and rank 0's checkpoint is what a
+        single-GPU run of the same steps would hold."""
+        if not self.training:
+            return
+        dev = _norm_dev(dev or next(self.parameters()).device)
+        self._flat.ensure(dev)
+        w = self._weights(dev)
+        mods = self._sn_modules()
+        pp = (c_void_p * (3 * len(mods)))()
+        dd = (ctypes.c_int * (2 * len(mods)))()
+        for i, m in enumerate(mods):
+            pp[3 * i], pp[3 * i + 1], pp[3 * i + 2] = m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr()
+            dd[2 * i] = m.weight_orig.shape[0]
+            dd[2 * i + 1] = m.weight_orig.numel() // m.weight_orig.shape[0]
+        call('nele_spectral_norm', pp, dd, len(mods), ptr(w['sigma']), 1, stream())
+
     def _prepare_inline(self, key, bf, w, power_iter=True):
         n_iter = 1 if (self.training and power_iter) else 0
         # spectral norm: power iteration (train mode) + sigma for all 8 layers in one launch (model.py:105-116)
@@ -608,8 +633,9 @@ class _DiscriminatorBase(nn.Module):
         use16 = self.precision == 'bf16'
         if use16:
             # every layer's weight layouts in two launches (float32 GEMM / data-gradient layouts, then the bf16 fragment streams)
-            jk = ('prepjobs', key, self.layers[0].weight_orig.data_ptr(), self.layers[-1].weight_orig.data_ptr())
-            if jk not in w:
+            # the ctypes job tables of this shape live on its buffer set, so the LRU eviction of the set drops them too
+            jk = (id(w), self.layers[0].weight_orig.data_ptr(), self.layers[-1].weight_orig.data_ptr())
+            if bf.prepjobs is None or bf.prepjobs[0] != jk:
                 cin, cpad = self._cin, 4
                 pj, dj, fj, ej = [], [], [], []
                 cj, gj = [], []
@@ -630,10 +656,10 @@ class _DiscriminatorBase(nn.Module):
                         fj += [w['wb'][l].data_ptr(), w['wbf16'][l].data_ptr()]
                         ej += [cpad, k * k * cout, k * cout, k]
                     cin = cpad = cout
-                w[jk] = ((c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5,
-                         (c_void_p * max(1, len(fj)))(*fj), (ctypes.c_int * max(1, len(ej)))(*ej), len(ej) // 4,
-                         (c_void_p * max(1, len(cj)))(*cj), (ctypes.c_int * max(1, len(gj)))(*gj), len(gj) // 4)
-            pja, dja, npj, fja, eja, nfj, cja, gja, ncj = w[jk]
+                bf.prepjobs = (jk, ((c_void_p * len(pj))(*pj), (ctypes.c_int * len(dj))(*dj), len(dj) // 5,
+                                    (c_void_p * max(1, len(fj)))(*fj), (ctypes.c_int * max(1, len(ej)))(*ej), len(ej) // 4,
+                                    (c_void_p * max(1, len(cj)))(*cj), (ctypes.c_int * max(1, len(gj)))(*gj), len(gj) // 4))
+            pja, dja, npj, fja, eja, nfj, cja, gja, ncj = bf.prepjobs[1]
             call('nele_weight_prep_batch', pja, dja, npj, stream())
             if nfj:
                 call('nele_weight_prep_frag16_batch', fja, eja, nfj, stream())

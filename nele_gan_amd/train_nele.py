@@ -48,7 +48,16 @@ def parse_metrics(target_metric):
 
 
 class GanTrainer:
-    def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666):
+    def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666,
+                 haspi_dither=None, dither_seed=0):
+        """haspi_dither: None = HASPI targets without the IHC firing jitter (deterministic); 'utterance' = the reference's semantics
+        (pyhaspi2.py:362-365 dithers every call): standard-normal rows drawn per UTTERANCE ID from a counter-based generator
+        (``dither_seed``, utterance id) - not per rank or per batch position, so a sharded run scores an utterance exactly
+        as a single-GPU run does.  The ids come with the batch (``utt_ids``; default: position in the batch)."""
+        if haspi_dither not in (None, 'utterance'):
+            raise ValueError("haspi_dither must be None or 'utterance'")
+        self.haspi_dither = haspi_dither
+        self.dither_seed = int(dither_seed)
         self.metrics = parse_metrics(target_metric)
         self.device = M._norm_dev(device)            # indexed ('cuda' -> 'cuda:0'): torch.device('cuda') != torch.device('cuda:0')
         torch.manual_seed(seed)                      # same initial weights on every rank
@@ -95,6 +104,21 @@ class GanTrainer:
             else:
                 ndist.allreduce_weighted_mean_(g, float(weight))
 
+    @staticmethod
+    def _advance_sn(module):
+        """Empty data-parallel step: the power iteration a real step's forward pass would have run (replicas keep identical u, v)."""
+        if module is not None and hasattr(module, 'advance_power_iteration'):
+            module.advance_power_iteration()
+
+    def _dither(self, x, utt_ids):
+        """HASPI dither rows [B, 2, nsub, 32] of this batch (haspi_dither='utterance'), or None."""
+        if self.haspi_dither is None:
+            return None
+        B, L = x.shape
+        if utt_ids is None:
+            utt_ids = torch.arange(B, dtype=torch.int64, device=x.device)
+        return mt.haspi_dither_rows(utt_ids, self.dither_seed, L, device=x.device)
+
     # ---------------------------------------------------------------- features (dataloader.py:30-42)
     def features(self, clean_wav, noise_wav, lengths=None):
         """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64, frames).
@@ -130,6 +154,9 @@ class GanTrainer:
         parallelism: ranks may hold different batch sizes / batch counts; None = plain mean over ranks); ``clean_band=None`` = an empty
         step that only joins the collective (this rank has run out of batches)."""
         if clean_band is None:
+            # a real G-step runs D's (and D_Qua's) training-mode forward pass, which advances their spectral-norm u / v once
+            self._advance_sn(self.D)
+            self._advance_sn(self.D_Qua)
             self.optimizer_g.zero_grad()
             self._allreduce_grads(self.G, 0 if weight is None else weight)
             self.optimizer_g.step()
@@ -203,12 +230,12 @@ class GanTrainer:
         return st
 
     # ---------------------------------------------------------------- true metric targets (train_nele.py:318-340)
-    def _metric(self, m, x, y, which, lengths=None):
+    def _metric(self, m, x, y, which, lengths=None, utt_ids=None):
         if m == 'siib':
             raw, mapped, info = mt.batch_siib(x, y, return_info=True, lengths=lengths)
             self._note_status(which, siib_info=info)
         elif m == 'haspi':
-            raw, mapped, info = mt.batch_haspi(x, y, return_info=True, lengths=lengths)
+            raw, mapped, info = mt.batch_haspi(x, y, return_info=True, lengths=lengths, dither=self._dither(x, utt_ids))
             self._note_status(which, haspi_info=info)
         else:
             raw, mapped = mt.batch_estoi(x, y, lengths=lengths)
@@ -221,10 +248,11 @@ class GanTrainer:
         return None if lengths is None else (torch.div(lengths, 256, rounding_mode='floor') * 256).to(torch.int32)
 
     @torch.no_grad()
-    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True):
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None):
         """[B, n_metrics] targets of (clean, enhanced + noise) (audio_util.py:120-203).  lengths [B]: samples of each utterance inside the
         padded batch; resynth=True: ``enh_wav`` came out of ``generate`` (each row holds 256 * (L // 256) samples); False: ``lengths``
-        already are min(clean, enhanced) per utterance (the pre-enhanced 'DRC' examples, audio_util.py:267-321)."""
+        already are min(clean, enhanced) per utterance (the pre-enhanced 'DRC' examples, audio_util.py:267-321).
+        utt_ids [B] int64: utterance ids for the per-utterance HASPI dither (haspi_dither='utterance')."""
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
         x = clean_wav[:, :L].contiguous()
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
@@ -235,9 +263,55 @@ class GanTrainer:
             lengths = torch.clamp(lengths, max=L)
         cols = []
         for m in self.metrics:
-            raw, mapped = self._metric(m, x, y, 'main', lengths)
+            raw, mapped = self._metric(m, x, y, 'main', lengths, utt_ids)
             cols.append(mapped if norm else raw)
         return torch.stack(cols, dim=1)
+
+    @torch.no_grad()
+    def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None):
+        """Targets of TWO degraded versions of one clean batch - the generated example and the pre-enhanced ('DRC') one, which the loop
+        scores back to back (train_nele.py:318-340) - with the clean-signal work done once: SIIB's VAD / clean spectra / covariance /
+        eigen-decomposition (its KLT basis) and HASPI's whole reference-signal chain depend on the clean signal only
+        (metrics.SiibSplit / HaspiSplit: clean_part() once, degraded_part() twice).  -> (targets_enh, targets_drc), each bit-identical
+        to a true_metrics() call of its own.  Falls back to two full calls when the two comparisons do not see the same clean samples
+        (different truncation lengths, audio_util.py:134-137)."""
+        lengths = au._i32(lengths, self.device)
+        L = min(clean_wav.shape[1], enh_wav.shape[1])
+        Ld = min(clean_wav.shape[1], drc_wav.shape[1])
+        ml_e = self.enhanced_lengths(lengths)
+        ml_d = None
+        if drc_lengths is not None or lengths is not None:
+            full = lambda t, w: torch.full((w.shape[0],), w.shape[1], dtype=torch.int32, device=self.device) if t is None else au._i32(t, self.device)
+            ml_d = torch.clamp(torch.minimum(full(drc_lengths, drc_wav), full(lengths, clean_wav)), max=Ld)
+        same = (L == Ld) and ((ml_e is None and ml_d is None) or (ml_e is not None and ml_d is not None and bool(torch.equal(ml_e, ml_d))))
+        if not same:
+            return (self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids),
+                    self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids))
+        x = clean_wav[:, :L].contiguous()
+        ys = [(enh_wav[:, :L] + noise_wav[:, :L]).contiguous(), (drc_wav[:, :L] + noise_wav[:, :L]).contiguous()]
+        pick = (lambda r, m_: m_) if norm else (lambda r, m_: r)
+        cols = [{}, {}]
+        for m in self.metrics:
+            if m == 'siib':
+                sp = mt.SiibSplit(x, lengths=ml_e, owner=self._ws)
+                sp.clean_part()
+                for k, y in enumerate(ys):
+                    raw, mapped = sp.degraded_part(y)
+                    cols[k][m] = pick(raw, mapped).clone()
+                    self._note_status('main', siib_info=sp.info)
+            elif m == 'haspi':
+                hp = mt.HaspiSplit(x, lengths=ml_e, owner=self._ws)
+                dz = self._dither(x, utt_ids)
+                hp.clean_part(dither=dz)
+                for k, y in enumerate(ys):
+                    raw, mapped = hp.degraded_part(y, dither=dz)
+                    cols[k][m] = pick(raw, mapped).clone()
+                    self._note_status('main', haspi_info=hp.info)
+            else:
+                for k, y in enumerate(ys):
+                    raw, mapped = mt.batch_estoi(x, y, lengths=ml_e)
+                    cols[k][m] = pick(raw, mapped)
+        return tuple(torch.stack([c[m] for m in self.metrics], dim=1) for c in cols)
 
     # ---------------------------------------------------------------- D-step (train_nele.py:349-367)
     def d_inputs(self, enh_wav, noise_band, clean_band, lengths=None, resynth=True):
@@ -275,12 +349,16 @@ class GanTrainer:
         if has_qua and din is not None and target_qua is None:
             raise ValueError("d_step: this step trains D_Qua (has_qua) but the batch carries no quality targets")
         self.optimizer_d.zero_grad()
+        if din is None:
+            self._advance_sn(self.D)                 # empty step: the power iteration the other ranks' forward passes run
         score = self.D.forward_packed(din, frames) if din is not None else None
         score_qua = None
         if has_qua:
             self.optimizer_dqua.zero_grad()
             if din is not None:                      # both forward passes first, as the reference (train_nele.py:356-357)
                 score_qua = self.D_Qua.forward_packed(self.quality_inputs(din), frames)
+            else:
+                self._advance_sn(self.D_Qua)
         loss = self._d_finish(score, target, weight)
         if has_qua:
             if score_qua is not None:
@@ -302,7 +380,7 @@ class GanTrainer:
         return loss.detach() if loss is not None else None
 
     # ---------------------------------------------------------------- one canonical step
-    def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features):
+    def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features, utt_ids=None):
         """Everything of a step that needs only its INPUTS, enqueued on the side streams behind event ``after``: the clean-signal
         halves of SIIB (VAD .. eigen-decomposition .. clean projections) and HASPI (the whole reference-signal chain) and, with
         ``with_features``, the features of both waveforms.  -> dict."""
@@ -314,7 +392,8 @@ class GanTrainer:
         L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
         lengths = au._i32(lengths, self.device)
         mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
-        w = {'clean': clean_wav, 'noise': noise_wav, 'lengths': lengths, 'mlens': mlens, 'split': None, 'hsplit': None, 'feats': None}
+        w = {'clean': clean_wav, 'noise': noise_wav, 'lengths': lengths, 'mlens': mlens, 'split': None, 'hsplit': None, 'feats': None,
+             'dither': None, 'utt_ids': utt_ids}
         with torch.cuda.stream(side):
             side.wait_event(after)
             w['x'] = clean_wav[:, :L].contiguous()
@@ -329,7 +408,8 @@ class GanTrainer:
                 side2.wait_event(after)
                 side2.wait_event(x_ready)
                 w['hsplit'] = mt.HaspiSplit(w['x'], lengths=mlens, owner=self._ws)
-                w['hsplit'].clean_part()
+                w['dither'] = self._dither(w['x'], utt_ids)
+                w['hsplit'].clean_part(dither=w['dither'])
         if with_features:
             if self._fside is None:
                 self._fside = ops.side_stream(self.device)
@@ -345,7 +425,7 @@ class GanTrainer:
                 w['feats_ready'].record(fs_)
         return w
 
-    def prefetch(self, clean_wav, noise_wav, lengths=None, after=None):
+    def prefetch(self, clean_wav, noise_wav, lengths=None, after=None, utt_ids=None):
         """The input-only work of the NEXT batch, as the reference's DataLoader workers prepare the features of upcoming items
         while the current one trains (dataloader.py:86-92, 8 workers).  canonical_step(..., next_batch=...) calls this at the point where
         the current step's targets are done, so that the work fills the D backward pass (the one phase of a step in which the side
@@ -354,9 +434,9 @@ class GanTrainer:
         if after is None:
             after = torch.cuda.Event()
             after.record(torch.cuda.current_stream())
-        return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True)
+        return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True, utt_ids=utt_ids)
 
-    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None):
+    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None, utt_ids=None):
         """features -> G-step -> generate -> true metrics -> D-step on the same batch.  lengths [B] (optional): samples of each
         utterance inside the padded batch (every utterance needs >= 21 frames, i.e. 5120 samples, for D).
         pre: what prefetch() returned for THIS batch (its input-only work is then already in flight or done);
@@ -383,7 +463,7 @@ class GanTrainer:
             p1.wait_event(start)                           # after the previous step's D update
             self.D.prepare(B_, T_, self.device)
         if pre is None:
-            pre = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False)
+            pre = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False, utt_ids=utt_ids)
         else:
             assert pre['clean'] is clean_wav and pre['noise'] is noise_wav, "canonical_step: `pre` belongs to another batch"
         side = self._side
@@ -427,10 +507,10 @@ class GanTrainer:
             side2.wait_event(y_ready)
             for m in self.metrics:
                 if m == 'haspi' and hsplit is not None:
-                    cols[m] = hsplit.degraded_part(y)[1]
+                    cols[m] = hsplit.degraded_part(y, dither=pre['dither'])[1]
                     haspi_info = hsplit.info
                 elif m == 'haspi':
-                    _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True, lengths=mlens)
+                    _, cols[m], haspi_info = mt.batch_haspi(x, y, return_info=True, lengths=mlens, dither=self._dither(x, pre.get('utt_ids')))
                 elif m != 'siib' and m not in cols:
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y, lengths=mlens)[1]
             others = torch.cuda.Event()
@@ -456,7 +536,8 @@ class GanTrainer:
         noise_wav.record_stream(side)
         self.prefetched = None
         if next_batch is not None:                          # the next batch's input-only work fills the D backward pass
-            self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done)
+            self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done,
+                                            utt_ids=next_batch[3] if len(next_batch) > 3 else None)
         main.wait_event(done)
         ld = self._d_finish(score, tgt)
         return lg, ld, tgt
@@ -489,21 +570,24 @@ class GanTrainer:
 
     def _d_pass(self, lst, batch):
         random.shuffle(lst)
-        chunks = self._padded_chunks(lst, batch)
-        n_steps = len(chunks)
         # D_Qua is stepped in this pass iff the samples carry quality targets: one decision per pass, the same on every rank (a rank
-        # whose shard is shorter joins the D_Qua collectives with empty steps; mixed presence is an error)
-        hq = [c[2] is not None for c in chunks]
-        if any(hq) != all(hq):
-            raise ValueError("d_epoch: quality targets must be given for every sample of a pass or for none")
-        has_qua = int(self.D_Qua is not None and bool(hq) and hq[0])
+        # whose shard is shorter joins the D_Qua collectives with empty steps; mixed presence is an error).  The decision AND the error
+        # are collective: every rank learns of a mixed pass in the same all-reduce and raises, so no rank enters the step loop (and its
+        # gradient all-reduces) alone and waits for the collective timeout.
+        hq = [len(c) > 2 and c[2] is not None for c in lst]
+        mixed = int(any(hq) != all(hq))
+        with_q = int(bool(hq) and all(hq))
+        without_q = int(bool(hq) and not any(hq))
+        chunks = self._padded_chunks(lst, batch) if not mixed else []
+        n_steps = len(chunks)
         if self.world > 1:
             # ranks hold different shards: every rank must join the same number of all-reduces
-            n_steps = ndist.allreduce_max_int(n_steps, self.device)
-            g_has = ndist.allreduce_max_int(has_qua, self.device)
-            if chunks and g_has != has_qua:
-                raise ValueError("d_epoch: some ranks carry quality targets and others do not")
-            has_qua = g_has
+            n_steps, with_q, without_q, mixed = ndist.allreduce_max_ints([n_steps, with_q, without_q, mixed], self.device)
+        if mixed:
+            raise ValueError("d_epoch: quality targets must be given for every sample of a pass or for none")
+        if with_q and without_q:
+            raise ValueError("d_epoch: some ranks carry quality targets and others do not")
+        has_qua = int(self.D_Qua is not None and bool(with_q))
         for k in range(n_steps):
             if k < len(chunks):
                 din, tgt, tq, frames = chunks[k]
@@ -541,7 +625,8 @@ class GanTrainer:
         optional 'drc': pre-enhanced wav [B,L] (the MultiEnh example of the same utterance, train_nele.py:333-340), optional
         'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua),
         optional 'lengths': [B] samples of each utterance inside the zero-padded batch (files of different lengths side by side, as
-        the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths')}.
+        the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths'),
+        optional 'ids': [B] int64 utterance ids (haspi_dither='utterance': the dither rows follow the utterance, not the rank)}.
         Under data parallelism every rank passes its own shard of batches; ranks may hold different batch counts and sizes (empty
         G-steps / D-steps join the collectives, gradients are item-weighted means, the validation means run over all ranks).
           1. G-steps over the training batches - from epoch 2 on (:122-156; epoch 1 fits D to the untrained generator first)
@@ -579,7 +664,7 @@ class GanTrainer:
             enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f.get('frames'))
             if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
                 self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch, lengths=b.get('lengths'))
-            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths')))
+            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids')))
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
             acc = torch.zeros(n_m + 1, dtype=torch.float64, device=self.device)
@@ -608,18 +693,17 @@ class GanTrainer:
             enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=frames)
             if sample_dir is not None and 'names' in b:
                 out['sample_files'] += self.write_samples(enh, b['names'], sample_dir + '/For_discriminator_training', gan_epoch, lengths=lens)
-            tgt = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens)
+            dl = b.get('drc_lengths', lens)
+            if b.get('drc') is not None:
+                # generated + pre-enhanced ('DRC') example of the same utterances (:318-340; audio_util.py:267-321; the DRC file keeps its
+                # own length): one pass over the clean signal for both when they are compared over the same samples (audio_util.py:134-137)
+                tgt, tgt_d = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'))
+            else:
+                tgt = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'))
             din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
             qua = b.get('qua')
             samples += self._items(din, tgt, qua, frames)
             if b.get('drc') is not None:
-                # the pre-enhanced ('DRC') example of the same utterance (:333-340; audio_util.py:267-321): its own file, its own length
-                dl = b.get('drc_lengths', lens)
-                ml = None
-                if dl is not None or lens is not None:
-                    full = lambda t, w: torch.full((w.shape[0],), w.shape[1], dtype=torch.int32, device=self.device) if t is None else au._i32(t, self.device)
-                    ml = torch.minimum(full(dl, b['drc']), full(lens, b['clean']))       # audio_util.py:134-137
-                tgt_d = self.true_metrics(b['clean'], b['drc'], b['noise'], lengths=ml, resynth=False)
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
                 samples += self._items(din_d, tgt_d, b.get('drc_qua'), frames)
         out['samples'] = len(samples)

@@ -374,6 +374,33 @@ def cep_coef(xdB, ydB, thrCep=2.5, thrNerve=0.1, nbasis=6, dither_x=None, dither
 MOD_CF = np.array([2, 6, 10, 16, 25, 40, 64, 100, 160, 256])
 
 
+def _mix64(z):
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    z = (z + np.uint64(0x9E3779B97F4A7C15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def dither_rows(utt_id, seed, nsub):
+    """The per-utterance dither draws of the HIP path (csrc/haspi.hip: haspi_dither_rows_kernel) restated in numpy: standard normals
+    [2, nsub, 32] (x rows, y rows) as a pure function of (seed, utterance id, signal, frame, channel).  The REFERENCE draws
+    np.random.randn(n_active, 32) from numpy's global generator on every call (pyhaspi2.py:362-365); which normals are drawn is not
+    part of its contract, that they are i.i.d. N(0, 1) per (active frame, channel) is."""
+    with np.errstate(over='ignore'):
+        key = _mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ _mix64(np.array([utt_id & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)))[0]
+        e = np.arange(nsub * NCHAN, dtype=np.uint64)
+        out = np.empty((2, nsub, NCHAN))
+        for sig in range(2):
+            idx = (np.uint64(sig) << np.uint64(40)) | e
+            r1 = _mix64(key ^ _mix64(np.uint64(2) * idx))
+            r2 = _mix64(key ^ _mix64(np.uint64(2) * idx + np.uint64(1)))
+            u1 = ((r1 >> np.uint64(11)).astype(np.float64) + 1.0) * 2.0 ** -53
+            u2 = (r2 >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+            out[sig] = (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).reshape(nsub, NCHAN)
+    return out
+
+
 def mod_filters(fsub=2560):
     """pyhaspi2.py:275-305: FIR windows (np.hanning(nfir+1) normalised) and half lengths."""
     cf = MOD_CF

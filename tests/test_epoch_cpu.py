@@ -43,9 +43,13 @@ def _recording_trainer(log):
         log.append('generate')
         return torch.zeros(cb.shape[0], 256 * (T - 1))
 
-    def true_metrics(c, e, n, norm=True, lengths=None, resynth=True):
+    def true_metrics(c, e, n, norm=True, lengths=None, resynth=True, utt_ids=None):
         log.append('metrics' if norm else 'metrics_raw')
         return torch.full((c.shape[0], 2), 0.25)
+
+    def true_metrics_pair(c, e, d, n, norm=True, lengths=None, drc_lengths=None, utt_ids=None):
+        log.append('metrics_pair')
+        return torch.full((c.shape[0], 2), 0.25), torch.full((c.shape[0], 2), 0.25)
 
     def d_inputs(e, nb, cb, lengths=None, resynth=True):
         log.append('d_inputs')
@@ -59,6 +63,7 @@ def _recording_trainer(log):
 
     tr.features, tr.g_step, tr.generate, tr.true_metrics = features, g_step, generate, true_metrics
     tr.d_inputs, tr.d_epoch, tr.save_checkpoint = d_inputs, d_epoch, save_checkpoint
+    tr.true_metrics_pair = true_metrics_pair
     tr.check_status = lambda raise_on_error=True: {}
     return tr
 
@@ -82,8 +87,8 @@ def test_epoch_one_has_no_generator_step_and_the_reference_order(tmp_path):
     assert 'g_step' not in log and out['g_steps'] == 0 and out['g_loss'] is None
     assert log == ['features', 'generate', 'metrics_raw',                       # validation
                    'checkpoint',
-                   'features', 'generate', 'metrics', 'd_inputs', 'metrics', 'd_inputs',   # batch 0: generated + DRC example
-                   'features', 'generate', 'metrics', 'd_inputs', 'metrics', 'd_inputs',   # batch 1
+                   'features', 'generate', 'metrics_pair', 'd_inputs', 'd_inputs',   # batch 0: generated + DRC example, clean-signal work once
+                   'features', 'generate', 'metrics_pair', 'd_inputs', 'd_inputs',   # batch 1
                    'd_epoch:8']
     assert out['samples'] == 8
     line = open(tmp_path / 'log.txt').read()
@@ -130,7 +135,11 @@ class _TinyD(torch.nn.Module):
     def flat_parameters(self):
         return self._f
 
+    def advance_power_iteration(self, dev=None):
+        self.sn_steps = getattr(self, 'sn_steps', 0) + 1       # stands for weight_u / weight_v: one power iteration per training forward
+
     def forward_packed(self, din, frames=None):
+        self.advance_power_iteration()
         self._w = self._f.flat.detach().clone().requires_grad_(True)
         return torch.sigmoid(din.mean(dim=(1, 2, 3)).unsqueeze(1) * self._w[0] + self._w[1])
 
@@ -182,7 +191,7 @@ def _dp_worker(rank, world, port, out):
     tr.history = [items[i] for i in range(lo, hi)] * 8   # 48 / 40 items of history: replay positions < 40 // 30 ... drawn on rank 0
     tr.d_epoch(items[lo:hi], batch=2)
     res = {'w': tr.D.flat_parameters().flat.numpy().copy(), 'steps': tr.optimizer_d.steps, 'step_d': tr.step_d,
-                 'hist': len(tr.history)}
+                 'hist': len(tr.history), 'sn': tr.D.sn_steps}
     # one explicit weighted step: rank 0 contributes 3 items, rank 1 one item -> the global mean over 4 items
     g = torch.tensor([float(rank + 1), 2.0 * (rank + 1)])
     nd.allreduce_weighted_mean_(g, 3 if rank == 0 else 1)
@@ -209,6 +218,7 @@ def test_data_parallel_d_epoch_on_ragged_shards_world2():
     mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r0, r1 = out[0], out[1]
     assert r0['steps'] == r1['steps'] and r0['step_d'] == r1['step_d']            # same number of optimiser steps / all-reduces
+    assert r0['sn'] == r1['sn'] == r0['steps']                                    # empty steps advance the spectral-norm iteration too
     np.testing.assert_array_equal(r0['w'], r1['w'])                               # replicas identical after the epoch
     assert not np.array_equal(r0['w'], np.array([0.3, -0.1], dtype=np.float32))   # and they did move
     np.testing.assert_allclose(r0['wmean'], [(3 * 1 + 1 * 2) / 4.0, (3 * 2 + 1 * 4) / 4.0])
@@ -255,7 +265,9 @@ def _dp_epoch_worker(rank, world, port, out):
         return loss.detach()
     tr.g_step = g_step
     tr.generate = lambda cb, nb, spec, rms_target=0.0, frames=None: cb.reshape(cb.shape[0], -1)[:, :256 * (T - 1)].clone()
-    tr.true_metrics = lambda c, e, n, norm=True, lengths=None, resynth=True: torch.full((c.shape[0], 2), 0.2 + 0.1 * rank)
+    tr.true_metrics = lambda c, e, n, norm=True, lengths=None, resynth=True, utt_ids=None: torch.full((c.shape[0], 2), 0.2 + 0.1 * rank)
+    tr.true_metrics_pair = lambda c, e, d, n, norm=True, lengths=None, drc_lengths=None, utt_ids=None: (
+        torch.full((c.shape[0], 2), 0.2 + 0.1 * rank), torch.full((c.shape[0], 2), 0.2 + 0.1 * rank))
     tr.d_inputs = lambda e, nb, cb, lengths=None, resynth=True: cb.reshape(cb.shape[0], T, 64, 1).transpose(1, 2).repeat(1, 1, 1, 4).contiguous()
     tr.check_status = lambda raise_on_error=True: {}
     random.seed(5 + rank)
@@ -268,7 +280,8 @@ def _dp_epoch_worker(rank, world, port, out):
     res = tr.run_epoch(2, train, valid, d_batch=4)
     out[rank] = {'g': tr.G.flat_parameters().flat.numpy().copy(), 'd': tr.D.flat_parameters().flat.numpy().copy(),
                  'q': tr.D_Qua.flat_parameters().flat.numpy().copy(), 'gs': tr.optimizer_g.steps, 'ds': tr.optimizer_d.steps,
-                 'qs': tr.optimizer_dqua.steps, 'valid': res['valid'], 'g_steps': res['g_steps']}
+                 'qs': tr.optimizer_dqua.steps, 'valid': res['valid'], 'g_steps': res['g_steps'],
+                 'sn_d': tr.D.sn_steps, 'sn_q': tr.D_Qua.sn_steps}
     dist.destroy_process_group()
 
 
@@ -283,3 +296,33 @@ def test_data_parallel_epoch_with_ragged_batch_counts_and_quality_discriminator_
         np.testing.assert_array_equal(r0[k], r1[k])                               # replicas identical
         assert not np.array_equal(r0[k], np.array([0.3, -0.1], dtype=np.float32))
     assert r0['valid'] == r1['valid'] and r0['valid']['siib'] == pytest.approx(0.2)   # rank 1 logs the global mean (rank 0's shard only)
+    # spectral-norm buffers in lock-step: the empty G-steps / D-steps of the rank that ran out advanced u, v like the real ones
+    # (the real G-step's D / D_Qua forward passes are stubbed out here, so only the empty steps of rank 1 count on the G side)
+    assert r0['sn_d'] - r0['ds'] == 0 and r1['sn_d'] - r1['ds'] == 2 and r1['sn_q'] - r1['qs'] == 2
+
+
+def _dp_mixed_worker(rank, world, port, out):
+    """Rank 0's samples carry quality targets, rank 1's do not: BOTH ranks must raise (a rank that raises alone leaves the other in the
+    next all-reduce until the collective times out)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    tr = _bare_trainer()
+    tr.world = world
+    tr.D, tr.D_Qua = _TinyD(), _TinyD()
+    tr.optimizer_d, tr.optimizer_dqua = _Sgd(tr.D), _Sgd(tr.D_Qua)
+    tr.MSELoss = torch.nn.MSELoss()
+    items = [(torch.zeros(64, 30, 4), torch.tensor([0.5]), torch.tensor([0.5, 0.5]) if rank == 0 else None) for _ in range(3)]
+    try:
+        tr._d_pass(items, 2)
+        out[rank] = 'no error'
+    except ValueError as e:
+        out[rank] = str(e)
+    dist.destroy_process_group()
+
+
+def test_mixed_quality_targets_across_ranks_raise_on_every_rank_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_mixed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert 'some ranks carry quality targets' in out[0] and 'some ranks carry quality targets' in out[1]

@@ -98,3 +98,122 @@ def test_d_epoch_three_passes_and_history_replay():
     assert seen == [4, 1, 4, 3, 4, 1]                               # batches of at most 4
     assert len(tr.history) == 65
     assert not torch.equal(w0, tr.D.layers[4].weight_orig.detach())
+
+
+def test_configs0_toy_train_triple_batch2_estoi_only_vs_cpu_oracle():
+    """BASELINE configs[0] exactly: the toy_dataset/Train triple duplicated to batch 2 (16 kHz, L = 33 536, T = 132), ESTOI-only loss
+    (D out-dim 1): ONE canonical step on the device against the CPU oracle's loop (oracle/step.py = the reference's train_nele.py
+    stages) on the same files and the same initial weights."""
+    import os
+    from nele_gan_amd import dataio
+    from nele_gan_amd.train_nele import GanTrainer
+    from oracle.step import CpuStep
+    toy = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'toy')
+    names = sorted(n for n in os.listdir(toy) if n.endswith('.wav'))
+    clean = [n for n in names if 'clean' in n.lower() and 'train' in n.lower()]
+    noise = [n for n in names if 'noise' in n.lower() and 'train' in n.lower()]
+    assert clean and noise, names
+    c1, sr = dataio.read_wav(os.path.join(toy, clean[0]))
+    v1, _ = dataio.read_wav(os.path.join(toy, noise[0]))
+    assert sr == 16000
+    L = min(len(c1), len(v1))
+    c = np.stack([c1[:L], c1[:L]]).astype(np.float32)
+    v = np.stack([v1[:L], v1[:L]]).astype(np.float32)
+    assert L == 33536
+    tr = GanTrainer('estoi')
+    assert tr.D._nout == 1
+    g0 = {k: t.detach().cpu().clone() for k, t in tr.G.state_dict().items()}
+    d0 = {k: t.detach().cpu().clone() for k, t in tr.D.state_dict().items()}
+    cpu = CpuStep(g0, d0, metrics=('estoi',))
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    lg, ld, tgt = tr.canonical_step(cw, nw)
+    enh = tr._last_enh
+    cb, cm, cp, nb = cpu.features(c, v)
+    lg_ref = cpu.g_step(cb, nb)
+    assert float(lg) == pytest.approx(lg_ref, rel=1e-4)
+    enh_ref = cpu.generate(cb, nb, cm, cp)
+    assert enh.shape == (2, 256 * 131)
+    for b in range(2):
+        d = np.abs(enh[b].cpu().numpy() - enh_ref[b])
+        assert d.max() <= 1.5 / 32768 and np.mean(d > 1e-7) < 0.02
+    tgt_ref = cpu.targets(c, [e for e in enh.cpu().numpy()], v)
+    np.testing.assert_allclose(tgt.cpu().numpy(), tgt_ref, rtol=1e-4)
+    assert tgt.shape == (2, 1) and float((tgt[0] - tgt[1]).abs()) == 0.0        # the two copies score alike
+    ld_ref = cpu.d_step([e for e in enh.cpu().numpy()], nb, cb, tgt_ref)
+    assert float(ld) == pytest.approx(ld_ref, rel=2e-4)
+    for k, t in tr.D.state_dict().items():
+        np.testing.assert_allclose(t.cpu().numpy(), cpu.d[k].detach().numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+    for k, t in tr.G.state_dict().items():
+        np.testing.assert_allclose(t.cpu().numpy(), cpu.g[k].detach().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_true_metrics_pair_equals_two_calls():
+    """The generated and the pre-enhanced example of one clean batch scored with the clean-signal work done once
+    (train_nele.py:318-340): bit-identical to two full true_metrics() calls, with and without per-utterance lengths, and the
+    fallback when the two comparisons see different lengths."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    B, L = 3, 25600
+    c, v = synth.batch(B, L, start=40)
+    tr = GanTrainer('siib&haspi&estoi')
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    enh = (cw * 1.2).contiguous()
+    drc = (cw * 0.7 + 0.1 * nw).contiguous()
+    a1 = tr.true_metrics(cw, enh, nw).clone()
+    a2 = tr.true_metrics(cw, drc, nw, resynth=False).clone()
+    p1, p2 = tr.true_metrics_pair(cw, enh, drc, nw)
+    assert torch.equal(a1, p1) and torch.equal(a2, p2)
+    assert float((p1 - p2).abs().max()) > 1e-3
+    lens = torch.tensor([25600, 20480, 23040], dtype=torch.int32)
+    b1 = tr.true_metrics(cw, enh, nw, lengths=lens, norm=False).clone()
+    b2 = tr.true_metrics(cw, drc, nw, lengths=lens, resynth=False, norm=False).clone()
+    q1, q2 = tr.true_metrics_pair(cw, enh, drc, nw, lengths=lens, drc_lengths=lens, norm=False)
+    assert torch.equal(b1, q1) and torch.equal(b2, q2)
+    # different truncation (the DRC file is shorter): two full calls, same values as by hand
+    dl = torch.tensor([25600, 19000, 23040], dtype=torch.int32)
+    ml = torch.minimum(dl, lens)
+    e2 = tr.true_metrics(cw, drc, nw, lengths=ml, resynth=False).clone()
+    r1, r2 = tr.true_metrics_pair(cw, enh, drc, nw, lengths=lens, drc_lengths=dl)
+    assert torch.equal(r2, e2)
+    tr.check_status()
+
+
+def test_haspi_dither_per_utterance_id_vs_oracle_and_batch_independent():
+    """pyhaspi2.py:362-365 dithers every call.  haspi_dither='utterance': the rows are a function of (seed, utterance id) - the kernel's
+    draws equal oracle/haspi.py:dither_rows, the HASPI target with them equals the oracle's haspi_v2 given the same draws (1e-4), and
+    an utterance scores the same in another batch position / batch composition (what a sharded run needs)."""
+    from nele_gan_amd import metrics as mt
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    from oracle import haspi as H
+    B, L = 3, 32000
+    c, v = synth.batch(B, L, start=60)
+    y = (0.8 * c + v).astype(np.float32)
+    ids = torch.tensor([1007, 5, 123456789012], dtype=torch.int64)
+    rows = mt.haspi_dither_rows(ids, 11, L)
+    nsub = rows.shape[2]
+    for k in range(B):
+        np.testing.assert_allclose(rows[k].cpu().numpy(), H.dither_rows(int(ids[k]), 11, nsub), rtol=0, atol=1e-12)
+    tr = GanTrainer('haspi', haspi_dither='utterance', dither_seed=11)
+    cw, yw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(v).cuda()
+    zero = torch.zeros_like(nw)
+    t = tr.true_metrics(cw, yw, zero, norm=False, resynth=False, utt_ids=ids)[:, 0].cpu().numpy()
+    t_plain = GanTrainer('haspi').true_metrics(cw, yw, zero, norm=False, resynth=False)[:, 0].cpu().numpy()
+    assert np.abs(t - t_plain).max() > 1e-6                                  # the dither is on
+    raw, _, info = mt.batch_haspi(cw, yw, dither=rows, return_info=True)
+    for k in range(B):
+        na = int(info[k, 0])
+        d = rows[k].cpu().numpy()
+        ref, _ = H.haspi_v2(c[k], 16000, y[k], 16000, dither_x=d[0, :na], dither_y=d[1, :na])
+        assert t[k] == pytest.approx(ref, rel=1e-4)
+    # the same utterances in another order / another batch: same scores, bit for bit
+    perm = [2, 0]
+    t2 = tr.true_metrics(cw[perm].contiguous(), yw[perm].contiguous(), zero[perm].contiguous(), norm=False, resynth=False,
+                         utt_ids=ids[perm])[:, 0].cpu().numpy()
+    assert t2[0] == t[2] and t2[1] == t[0]
+    # and through the canonical step's split path (clean part beside the G-step): finite, and different from the undithered targets
+    tr3 = GanTrainer('haspi', haspi_dither='utterance', dither_seed=11)
+    tr4 = GanTrainer('haspi')
+    _, _, tg3 = tr3.canonical_step(cw, nw, utt_ids=ids)
+    _, _, tg4 = tr4.canonical_step(cw, nw)
+    assert bool(torch.isfinite(tg3).all()) and float((tg3 - tg4).abs().max()) > 0
