@@ -32,10 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+F64_PEAK_TFLOPS = 78.6            # MI355X_MICROARCH.md: float64, vector FMA and v_mfma_f64_16x16x4 alike
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
-PROFILE_ROUND = 'r03'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
+PROFILE_ROUND = 'r04'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
 
 
 def csrc_sha():
@@ -340,8 +341,10 @@ def main():
     ops.PROFILE = {'gstep.' + tag: [], tag: [], wtag: []}
     from nele_gan_amd import _lib
     htag = 'haspi_bank_gain_kernel'    # the HBM-side figure: HASPI's signal filter bank + compression-gain pass, timed by the library's HIP-event hook
-    if 'haspi' in metrics:
-        _lib.profile_begin(htag)
+    etag = 'eigh_tridiag_cluster'      # the float64 figure: the cluster tridiagonalisation of SIIB's 420 x 420 covariance (largest kernel of the r03 step)
+    armed = ([htag] if 'haspi' in metrics else []) + ([etag] if 'siib' in metrics else [])
+    if armed:
+        _lib.profile_begin(','.join(armed))
     stage_ev = []
     barrier()
     t0 = time.perf_counter()
@@ -368,7 +371,9 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    hbm_ms = _lib.profile_collect() if 'haspi' in metrics else []
+    hbm_ms = _lib.profile_collect_tag(htag) if 'haspi' in metrics else []
+    eig_ms = _lib.profile_collect_tag(etag) if 'siib' in metrics else []
+    _lib.profile_begin(None)
     prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
     prof = prof_g + prof_d
     prof_w = ops.PROFILE[wtag]
@@ -404,8 +409,8 @@ def main():
     if rank == 0:
         T = 1 + a.length // 256
         # HBM bytes per launch (PMC FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950-corrected) and MFMA-busy figures of the
-        # SAME command on this tree: profiles/r02/traffic.json (tools/prof_r02.sh + tools/make_traffic_json.py); counters cannot be
-        # read from inside the process, so the line carries them only for the workload the committed passes were taken on
+        # SAME command on this tree: profiles/<PROFILE_ROUND>/traffic.json (tools/prof_round.sh + tools/make_traffic_json.py); counters
+        # cannot be read from inside the process, so the line carries them only for the workload the committed passes were taken on
         pmc = {}
         pmc_note = 'no committed PMC passes for this workload'
         try:
@@ -473,6 +478,33 @@ def main():
                                    'frac': h_bytes / (h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    'traffic': pmc.get('haspi_bank_scan_kernel<true, true, false, true>', {}).get('hbm_bytes_corrected'), 'launch_ms': h_ms,
                                    'algorithmic_bytes': h_bytes, 'launches_timed': len(hbm_ms), 'limited_by': 'float64 issue rate (recurrences), not HBM'}
+        if eig_ms:
+            # Householder tridiagonalisation of the 420 x 420 clean covariance, the steps the cluster kernel runs (trailing size 419 .. 256;
+            # 4 workgroups per matrix hold the trailing matrix in registers): step k costs 4 m^2 flops (symmetric matrix-vector product +
+            # rank-2 update, m = n - 1 - k).  Inside a training step SIIB's clean part asks for 32 matrices per launch (half of the chip).
+            n_e, m_hand = 420, 256
+            f_mat = float(sum(4 * (n_e - 1 - k) ** 2 for k in range(n_e - m_hand)))
+            per_launch = min(a.batch, 32)
+            e_ms = sum(eig_ms) / len(eig_ms)
+            out['roofline_f64'] = {'bound': 'mfma', 'kernel': 'eigh_tridiag_cluster4_kernel (oracle/siib.py:97 np.linalg.eigh -> Householder steps 0..%d of %d on %d matrices per launch; float64 FMA, '
+                                                               'latency-bound cross-workgroup chain)' % (n_e - m_hand - 1, n_e - 2, per_launch),
+                                   'achieved': f_mat * per_launch / (e_ms * 1e-3) / 1e12, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': f_mat * per_launch / (e_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
+                                   'traffic': pmc.get('eigh_tridiag_cluster4_kernel', {}).get('hbm_bytes_corrected'), 'launch_ms': e_ms,
+                                   'launches_timed': len(eig_ms), 'flops_per_launch': f_mat * per_launch}
+        # `roofline` = the kernel with the largest time per step among the timed ones (the r03 verdict: the line's first figure must not be
+        # the step's best kernel); the dense-conv figure stays as `roofline_mfma`
+        out['roofline_mfma'] = out['roofline']
+        cands = {'roofline_mfma': kernel_ms * len(prof) / max(1, a.steps)}
+        if prof_w:
+            cands['roofline_wgrad'] = out['roofline_wgrad']['launch_ms'] * len(prof_w) / a.steps
+        if hbm_ms:
+            cands['roofline_hbm'] = sum(hbm_ms) / a.steps
+        if eig_ms:
+            cands['roofline_f64'] = sum(eig_ms) / a.steps
+        top = max(cands, key=cands.get)
+        out['roofline'] = dict(out[top], nominated='largest time per step among the timed kernels',
+                               ms_per_step_by_kernel={k: round(v, 3) for k, v in cands.items()}, same_as=top)
         if a.breakdown and stage_ev:
             names = ['features', 'g_step', 'generate', 'metrics', 'd_step']
             br = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev) / len(stage_ev) for i, n in enumerate(names)}
@@ -499,9 +531,9 @@ def main():
                 out['predicted_strong_scaling_8'] = {'value': out['global1024']['ms_per_step'] / (out['shard128']['ms_per_step'] + ar),
                                                      't_1024_on_1_gpu_ms': out['global1024']['ms_per_step'], 't_128_shard_ms': out['shard128']['ms_per_step'],
                                                      'allreduce_ms_assumed': ar, 'note': 'predicted from two 1-GPU measurements; not a multi-GPU run'}
-            out['siib_parity_note'] = ('at L %% 200 == 0 (the headline length 64 000) the replicated signal is exactly frame-periodic and the clean '
+            out['siib_parity_note'] = ('at L % 200 == 0 (the headline length 64 000) the replicated signal is exactly frame-periodic and the clean '
                                        'covariance is rank deficient: this build (oracle and kernels) drops components with eigenvalue <= 1e-10 max, '
-                                       'the reference (pysiib) scores them from rounding noise - 1 %% .. 23 %% higher raw SIIB on the bench utterances '
+                                       'the reference (pysiib) scores them from rounding noise - 1 % .. 23 % higher raw SIIB on the bench utterances '
                                        '(tests/test_oracle_metrics.py, DESIGN 2); the 1e-4 SIIB claim holds at lengths that are no multiple of 100 '
                                        '(`nonperiodic`, L = 63 871)')
     ee = None

@@ -25,10 +25,12 @@ int nele_version(void);
 const char* nele_last_error_string(void);
 int nele_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 
-/* Measurement hook (no reference counterpart): HIP-event timing of one kernel that is launched from inside a multi-kernel entry
- * point.  nele_profile_begin(tag) arms it for the launch sites tagged `tag` (e.g. "haspi_gain_lp_sl_kernel"; NULL disarms);
- * nele_profile_collect waits for the recorded launches and writes their durations in milliseconds (returns how many). */
-int nele_profile_begin(const char* tag);
+/* Measurement hook (no reference counterpart): HIP-event timing of single kernels that are launched from inside multi-kernel entry
+ * points, on the stream they run on.  nele_profile_begin(tags) arms it for the launch sites whose tag is in the comma-separated list
+ * (e.g. "eigh_tridiag_cluster,haspi_bank_gain_kernel"; NULL disarms); nele_profile_collect_tag waits for the recorded launches of one
+ * tag and writes their durations in milliseconds (returns how many; stays armed); nele_profile_collect = the first tag, then disarm. */
+int nele_profile_begin(const char* tags);
+int nele_profile_collect_tag(const char* tag, float* ms_out, int max_n);
 int nele_profile_collect(float* ms_out, int max_n);
 
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */

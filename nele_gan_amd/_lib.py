@@ -44,6 +44,7 @@ _SIGS = {
     'nele_wav_post': [c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'nele_profile_begin': [ctypes.c_char_p],
     'nele_profile_collect': [c_void_p, c_int],
+    'nele_profile_collect_tag': [ctypes.c_char_p, c_void_p, c_int],
     'nele_stft_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft_var': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -93,8 +94,15 @@ def stream():
 
 
 def profile_begin(tag):
-    """Arm the library's HIP-event hook for the launch sites tagged ``tag`` (None disarms)."""
+    """Arm the library's HIP-event hook for the launch sites tagged ``tag`` (a name or a comma-separated list; None disarms)."""
     lib.nele_profile_begin(tag.encode() if tag else None)
+
+
+def profile_collect_tag(tag, max_n=8192):
+    """-> list of durations (ms) of the launches tagged ``tag`` since profile_begin (synchronises on them; the hook stays armed)."""
+    buf = (c_float * max_n)()
+    n = lib.nele_profile_collect_tag(tag.encode(), buf, max_n)
+    return [float(buf[i]) for i in range(n)]
 
 
 def profile_collect(max_n=4096):

@@ -27,40 +27,79 @@ extern "C" int nele_device_info(int* cu_count, int* wave_size, char* arch, int a
     return NELE_OK;
 }
 
+bool nele_first_use_on_device(unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)
+    const unsigned long long bit = 1ull << dev;
+    if (*mask & bit) return false;
+    *mask |= bit;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------ per-kernel timing hook
 // bench.py's roofline figure needs the duration of ONE kernel that is launched from inside a multi-kernel entry point, measured with
 // HIP events on the stream the kernel runs on.  nele_profile_begin(tag) arms the hook; every launch site wrapped in NELE_PROF(tag, ...)
 // whose tag matches records a start / stop event pair around its launch; nele_profile_collect synchronises those events and returns
 // the elapsed milliseconds.  Not thread-safe by design (one Python thread drives the library); costs one string compare when idle.
+#include <string>
 #include <vector>
-static char g_prof_tag[64] = "";
-static std::vector<hipEvent_t> g_prof_ev;
+static std::vector<std::string> g_prof_tags;             // armed tags (nele_profile_begin("a,b,c") arms several)
+static std::vector<std::vector<hipEvent_t>> g_prof_ev;   // per tag: start / stop pairs
 
-bool nele_prof_match(const char* tag) { return g_prof_tag[0] && strcmp(g_prof_tag, tag) == 0; }
+static int prof_index(const char* tag) {
+    for (size_t k = 0; k < g_prof_tags.size(); ++k)
+        if (g_prof_tags[k] == tag) return (int)k;
+    return -1;
+}
+static int g_prof_cur = -1;                               // tag of the launch site between its two marks
+bool nele_prof_match(const char* tag) {
+    if (g_prof_tags.empty()) return false;
+    g_prof_cur = prof_index(tag);
+    return g_prof_cur >= 0;
+}
 void nele_prof_mark(hipStream_t s) {
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
+    if (g_prof_cur < 0 || hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);
-    g_prof_ev.push_back(e);
+    g_prof_ev[g_prof_cur].push_back(e);
 }
 
-extern "C" int nele_profile_begin(const char* tag) {
-    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+extern "C" int nele_profile_begin(const char* tags) {
+    for (auto& v : g_prof_ev)
+        for (hipEvent_t e : v) (void)hipEventDestroy(e);
     g_prof_ev.clear();
-    g_prof_tag[0] = 0;
-    if (tag) { strncpy(g_prof_tag, tag, sizeof(g_prof_tag) - 1); g_prof_tag[sizeof(g_prof_tag) - 1] = 0; }
+    g_prof_tags.clear();
+    g_prof_cur = -1;
+    if (tags) {
+        std::string all(tags), cur;
+        for (size_t k = 0; k <= all.size(); ++k) {
+            if (k == all.size() || all[k] == ',') { if (!cur.empty()) g_prof_tags.push_back(cur); cur.clear(); }
+            else cur.push_back(all[k]);
+        }
+        g_prof_ev.resize(g_prof_tags.size());
+    }
     return NELE_OK;
 }
 
-extern "C" int nele_profile_collect(float* ms_out, int max_n) {
-    const int n = (int)(g_prof_ev.size() / 2);
+// durations (ms) of the launches tagged `tag` since nele_profile_begin (synchronises on them); the hook stays armed
+extern "C" int nele_profile_collect_tag(const char* tag, float* ms_out, int max_n) {
+    const int ti = tag ? prof_index(tag) : (g_prof_tags.empty() ? -1 : 0);
+    if (ti < 0) return 0;
+    const std::vector<hipEvent_t>& ev = g_prof_ev[ti];
+    const int n = (int)(ev.size() / 2);
     int k = 0;
     for (; k < n && k < max_n; ++k) {
-        if (hipEventSynchronize(g_prof_ev[2 * k + 1]) != hipSuccess) break;
+        if (hipEventSynchronize(ev[2 * k + 1]) != hipSuccess) break;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof_ev[2 * k], g_prof_ev[2 * k + 1]) != hipSuccess) break;
+        if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) break;
         if (ms_out) ms_out[k] = ms;
     }
+    return k;
+}
+
+// the first armed tag's durations, then disarm (the round-1 form of the hook)
+extern "C" int nele_profile_collect(float* ms_out, int max_n) {
+    const int k = nele_profile_collect_tag(nullptr, ms_out, max_n);
     (void)nele_profile_begin(nullptr);
     return k;
 }

@@ -20,7 +20,8 @@
 int nele_set_error(int code, const char* fmt, ...);
 
 // csrc/eigh.hip (also part of the public C ABI)
-extern __attribute__((visibility("hidden"))) int nele_eigh_cluster_batch_hint;   // eigh.hip: matrices per cluster launch for the next call (0 = default; a hint only)
+__attribute__((visibility("hidden"))) int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, void* workspace,
+                                                                   long long workspace_bytes, void* stream, int cluster_batch);
 extern "C" long long nele_eigh_workspace_bytes(int B, int n);
 extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
                                      void* stream);
@@ -38,6 +39,10 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
     } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// csrc/capi.hip: true the first time it is called with this mask on the CURRENT device (one-time hipFuncSetAttribute blocks: a process
+// that switches devices must set the attribute on each of them)
+bool nele_first_use_on_device(unsigned long long* mask);
 
 // csrc/capi.hip: HIP-event pair around one tagged launch when nele_profile_begin(tag) armed it (bench.py's roofline figures)
 bool nele_prof_match(const char* tag);

@@ -1716,6 +1716,191 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient, bf16 in memory, DMA double buffer
+// Round 4.  conv_wgrad_tile16_kernel ran at MFMA-busy 0.35 (D.conv5) .. 0.07 (D.conv2): one kernel row per workgroup, i.e. every staged
+// position tile was fetched KH times and used for 1 / KH of the arithmetic; the dOut tile travelled through registers; and a tile's
+// staging (one memory latency, 5.6 k clocks) was only hidden by the OTHER workgroup of the CU.  This kernel is for the layers whose
+// input activation AND output gradient are bfloat16 in memory (D.conv2 .. conv5 in bf16 mode):
+//  * a workgroup owns KR kernel rows (all of them for D.conv2 .. conv4, three of nine for D.conv5): the halo holds TH + KR - 1 input
+//    rows and the dOut tile is staged once for KR x the MFMAs.  The (kernel row, 16-wide reduction tile) work items are dealt
+//    round-robin to the 8 waves; a wave keeps NT x NJ accumulator tiles for the whole kernel;
+//  * BOTH operands go global -> LDS by DMA (global_load_lds_dwordx4, 1 KB pieces, per-lane source addresses): no staging registers,
+//    no conversion.  The dOut image is [positions][NP] with the conflict-free row stride of tr_frag; lanes that land on pad columns
+//    or on positions outside the output read from row 0 of the utterance's zero-bordered gradient buffer (zeros);
+//  * two LDS buffers: the DMA of tile t + 1 is issued right after the barrier that opens tile t and lands under tile t's MFMAs -
+//    one barrier per tile, no exposed memory latency; one 512-thread workgroup per CU (two waves per SIMD).
+// Partials [group][N][Ktot] + bias partials, reduced by wgrad_reduce_kernel as before (fixed order: deterministic).
+#define WD_TW 64
+#define WD_MAXHP 6           // halo DMA pieces per wave and tile (host checks)
+#define WD_MAXDP 3           // dOut DMA pieces per wave and tile
+struct WgradDmaArgs {
+    const __bf16* A;
+    const __bf16* dOut;
+    float* part;             // [G][N][Ktot]
+    float* bpart;            // [G][N] or null
+    int N, KH, KW, KR, nkt;
+    int nth, ntw, ntiles, G;
+    ConvGeom g;
+};
+
+template <int NT, int NJ, int TH>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(WgradDmaArgs p) {
+    constexpr int NP = WT_NP_OF(NT);
+    constexpr int NPOS = TH * WD_TW, NS = NPOS / 32;                  // positions per tile, reduction steps of 32 positions
+    constexpr int NDP = NPOS * NP / 512;                              // DMA pieces of the dOut image (exact: NP is 16, 48 or 80)
+    extern __shared__ __attribute__((aligned(16))) __bf16 wd_lds[];   // 2 x { halo [TH + KR - 1][RS], WT_SLACK, dOut [NPOS][NP] }
+    __shared__ float bred[32][64];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsub = p.KH / p.KR;                                     // workgroups that share a group's tiles: ids of one XCD
+    int grp, rest;
+    if (nsub > 1 && (p.G & 7) == 0) {
+        const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+        rest = slot % nsub;
+        grp = (slot / nsub) * 8 + xcd;
+    } else {
+        rest = blockIdx.x % nsub;
+        grp = blockIdx.x / nsub;
+    }
+    const int kh0 = rest * p.KR;
+    const int HR = TH + p.KR - 1, wcols = WD_TW + p.KW - 1, RS = wcols * g.C;
+    const int himg = HR * RS, dtoff = himg + WT_SLACK, bufsz = dtoff + NPOS * NP;
+    const int nitems = p.KR * p.nkt;
+    // ---- this wave's work items q = wave + 8 jj -> (kernel row kr, reduction tile): element offset of the B fragment inside the halo image
+    int boff[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int q = min(wave + 8 * jj, nitems - 1), kr = q / p.nkt;
+        boff[jj] = kr * RS + 16 * (q - kr * p.nkt);
+    }
+    f32x4 acc[NT][NJ];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < WT_SLACK; e += 512) { wd_lds[himg + e] = (__bf16)0.f; wd_lds[bufsz + himg + e] = (__bf16)0.f; }
+    // ---- tile-invariant parts of the DMA source addresses
+    const int npc = (himg + 511) >> 9;
+    int hrow[WD_MAXHP], hel[WD_MAXHP];
+#pragma unroll
+    for (int u = 0; u < WD_MAXHP; ++u) {
+        const int ef = min(512 * (wave + 8 * u) + 8 * lane, himg - 8);
+        hrow[u] = ef / RS;
+        hel[u] = ef - hrow[u] * RS;
+    }
+    int dofs[WD_MAXDP], drc[WD_MAXDP];                                // dOut pieces: offset inside the utterance's buffer, (row << 8 | column) or -1 for pad columns
+#pragma unroll
+    for (int u = 0; u < WD_MAXDP; ++u) {
+        const int e = 512 * (wave + 8 * u) + 8 * lane;
+        const int pos = e / NP, col = e - pos * NP, r = pos >> 6, c = pos & 63;
+        dofs[u] = ((r + g.oh0) * g.OW + c + g.ow0) * g.OC + col;
+        drc[u] = (col < p.N && wave + 8 * u < NDP) ? ((r << 8) | c) : -1;
+    }
+    auto issue = [&](int t, __bf16* buf) {
+        const int tw_i = t % p.ntw, rem = t / p.ntw, th_i = rem % p.nth, b = rem / p.nth;
+        const int ho0 = th_i * TH, wo0 = tw_i * WD_TW, wi0 = wo0 + g.iw0;
+        const int vcols = max(0, min(wcols, g.W - wi0));
+        const int emax = max(vcols * g.C - 8, 0), himax = g.H - 1;
+        const __bf16* src0 = p.A + (((size_t)b * g.H) * g.W + wi0) * g.C;
+#pragma unroll
+        for (int u = 0; u < WD_MAXHP; ++u) {
+            const int k = wave + 8 * u;
+            if (k < npc) {
+                const int hi = min(ho0 + hrow[u] + kh0 + g.ih0, himax);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (size_t)hi * g.W * g.C + min(hel[u], emax)),
+                                                 (__attribute__((address_space(3))) void*)(buf + 512 * k), 16, 0, 0);
+            }
+        }
+        const __bf16* dimg = p.dOut + (size_t)b * g.OH * g.OW * g.OC;   // row 0 of the bordered buffer is zero: the source of everything outside
+        const int tofs = (ho0 * g.OW + wo0) * g.OC;
+#pragma unroll
+        for (int u = 0; u < WD_MAXDP; ++u) {
+            const int k = wave + 8 * u;
+            if (k < NDP) {
+                const bool ok = drc[u] >= 0 && (ho0 + (drc[u] >> 8) < g.Hout) && (wo0 + (drc[u] & 255) < g.Wout);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dimg + (ok ? tofs + dofs[u] : 0)),
+                                                 (__attribute__((address_space(3))) void*)(buf + dtoff + 512 * k), 16, 0, 0);
+            }
+        }
+    };
+    const bool want_bias = (p.bpart != nullptr) && (kh0 == 0);
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int bnq = tid & 15, bp0 = tid >> 4;                            // bias: n quad, first position (32 position groups)
+    // lane parts of the tr_frag addresses (see tr_frag): row (4 (g & 1) + 16 (g >> 1) + q), 4 elements at 4 pq
+    const int lg_ = lane >> 4, lq_ = (lane & 15) >> 2, lpq = lane & 3;
+    const int lrow = 4 * (lg_ & 1) + 16 * (lg_ >> 1) + lq_;
+    const int la_off = lrow * NP + 4 * lpq, lb_off = lrow * g.C + 4 * lpq;
+    const int ldb8 = 8 * g.C;
+
+    int t = grp, it = 0;
+    if (t < p.ntiles) issue(t, wd_lds);
+    for (; t < p.ntiles; t += p.G, ++it) {
+        __bf16* buf = wd_lds + (it & 1) * bufsz;
+        __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this wave's pieces of tile t have landed
+        __syncthreads();                                   // ... everyone's; and every wave is done with the other buffer (tile t - G)
+        if (t + p.G < p.ntiles) issue(t + p.G, wd_lds + ((it + 1) & 1) * bufsz);
+        const __bf16* dt = buf + dtoff;
+        if (want_bias && 4 * bnq < p.N) {
+#pragma unroll
+            for (int u = 0; u < NPOS / 32; ++u) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(dt + (bp0 + 32 * u) * NP + 4 * bnq);
+                bq[0] += (float)v[0]; bq[1] += (float)v[1]; bq[2] += (float)v[2]; bq[3] += (float)v[3];
+            }
+        }
+#pragma unroll 1
+        for (int ks = 0; ks < NS; ++ks) {
+            const __bf16* ha = dt + ks * 32 * NP + la_off;
+            const __bf16* hb = buf + (ks >> 1) * RS + (ks & 1) * 32 * g.C + lb_off;
+            bf16x8 af[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i + 8 * NP));
+                af[i][0] = lo[0]; af[i][1] = lo[1]; af[i][2] = lo[2]; af[i][3] = lo[3]; af[i][4] = hi[0]; af[i][5] = hi[1]; af[i][6] = hi[2]; af[i][7] = hi[3];
+            }
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(hb + boff[jj]));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(hb + boff[jj] + ldb8));
+                bf16x8 bf;
+                bf[0] = lo[0]; bf[1] = lo[1]; bf[2] = lo[2]; bf[3] = lo[3]; bf[4] = hi[0]; bf[5] = hi[1]; bf[6] = hi[2]; bf[7] = hi[3];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][jj], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partials: acc[i][jj][reg] = dW[n = 16 i + 4 lg + reg][(kh0 + kr) * seglen + 16 tile + li]
+    const int li = lane & 15, lgp = lane >> 4;
+    float* part = p.part + (size_t)grp * p.N * g.Ktot;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int q = wave + 8 * jj;
+        if (q >= nitems) continue;
+        const int kr = q / p.nkt, kk = 16 * (q - kr * p.nkt) + li;
+        if (kk >= g.seglen) continue;
+        const int col = (kh0 + kr) * g.seglen + kk;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int n = 16 * i + 4 * lgp + reg;
+                if (n < p.N) part[(size_t)n * g.Ktot + col] = acc[i][jj][reg];
+            }
+    }
+    if (want_bias) {                                      // fold the 32 threads that share an n quad
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bred[bp0][4 * bnq + q] = bq[q];
+        __syncthreads();
+        if (tid < 64 && tid < p.N) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) sum += bred[q][tid];
+            p.bpart[(size_t)grp * p.N + tid] = sum;
+        }
+    }
+}
+
 // Pointwise (1 x 1) layer with 4 input channels and N <= 8 outputs (D's first layer: 3 -> 8): the weight gradient is a plain reduction
 // over the M output positions, 16 B + 32 B per row - memory bound, no matrix cores.  grid = splits workgroups of 1024 threads,
 // rows strided over all threads, 4N + N accumulators per thread, fixed-order wave / workgroup reduction.  part [splits][N][4].
@@ -2182,6 +2367,8 @@ extern "C" long long nele_conv_wgrad_workspace_floats(int M, int N, int Ktot, in
     if (splits_out) *splits_out = splits;
     int slots = splits;                                    // the 2-D tile kernel uses up to 64 workgroup groups
     if (slots < 64) slots = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
+    // the DMA kernel (bf16 activations and gradients in memory) runs one workgroup per CU and kernel-row block: up to 256 groups
+    if (N <= 64 && slots < 256) slots = max_splits < 256 ? (max_splits > slots ? max_splits : slots) : 256;
     return (long long)slots * ((long long)N * Ktot + N);
 }
 
@@ -2197,6 +2384,11 @@ extern "C" int nele_conv_wgrad(const float* A, const float* dOut, float* workspa
 extern "C" int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* workspace, long long workspace_floats, int M, int N,
                                     const int* geom, int KH, int KW, int Cvalid, float* dW, float* db, int accumulate, void* stream) {
     return conv_wgrad_impl(A, dOut, workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 1, stream);
+}
+static bool wgrad_dma_on() {                               // NELE_WGRAD_DMA=0: the one-kernel-row tile kernel for bf16 operands too (A/B diagnostic)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NELE_WGRAD_DMA"); on = !(e && e[0] == '0'); }
+    return on != 0;
 }
 static bool wgrad_tile_eligible(int M, int N, const ConvGeom& g, int KH, int KW) {
     static int wt_on = -1;
@@ -2291,7 +2483,58 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         if (genv > 0 && genv < G) G = genv;
     }
     bool tiled = false;
-    if (bf16 && (sliced || wgrad_tile_eligible(M, N, p.g, KH, KW))) {
+    // ---- DMA double-buffer kernel: both operands bf16 in memory (D.conv2 .. conv5 in bf16 mode)
+    if (a16 && d16 && wgrad_dma_on()) {
+        const ConvGeom& gg = p.g;
+        const int nkt_ = (gg.seglen + 15) / 16, NT_ = (N + 15) / 16;
+        // kernel rows per workgroup: the largest divisor of KH whose accumulators fit (NT x items-per-wave tiles of 4 registers: 176 at most)
+        int KR = 0;
+        for (int cand = KH; cand >= 1; --cand)
+            if (KH % cand == 0 && NT_ * ((cand * nkt_ + 7) / 8) <= 44) { KR = cand; break; }
+        const int NJ_ = KR ? (KR * nkt_ + 7) / 8 : 0;
+        int TH_ = 0;
+        for (int cand = 4; cand >= 2 && KR; cand -= 2) {
+            const long long bufsz = (long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + WT_SLACK + (long long)cand * WD_TW * WT_NP_OF(NT_);
+            const int npc = (int)(((long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + 511) / 512), ndp = cand * WD_TW * WT_NP_OF(NT_) / 512;
+            if (bufsz * 4 <= 150 * 1024 && npc <= 8 * WD_MAXHP && ndp <= 8 * WD_MAXDP) { TH_ = cand; break; }
+        }
+        // compiled shapes (NT, NJ, TH): D.conv5 (4, 11, 2), D.conv4 (3, 13, 4), D.conv3 (2, 4, 4), D.conv2 (1, 1, 4)
+        const bool shape_ok = (NT_ == 4 && NJ_ == 11 && TH_ == 2) || (NT_ == 3 && NJ_ == 13 && TH_ == 4) || (NT_ == 2 && NJ_ == 4 && TH_ == 4) ||
+                              (NT_ == 1 && NJ_ == 1 && TH_ == 4);
+        if (KR && TH_ && shape_ok && N <= 64 && N == gg.OC && gg.C % 8 == 0 && KW * gg.C == gg.seglen && gg.oh0 >= 1 && gg.Wout >= 1 &&
+            M % (gg.Hout * gg.Wout) == 0 && (long long)(M / (gg.Hout * gg.Wout)) * gg.OH * gg.OW * gg.OC < (1ll << 31) &&
+            (long long)gg.OH * gg.OW * gg.OC < (1 << 30)) {
+            WgradDmaArgs t;
+            t.A = reinterpret_cast<const __bf16*>(A); t.dOut = reinterpret_cast<const __bf16*>(dOut); t.part = workspace;
+            t.N = N; t.KH = KH; t.KW = KW; t.KR = KR; t.nkt = nkt_; t.g = gg;
+            const int Bt_ = M / (gg.Hout * gg.Wout);
+            t.nth = (gg.Hout + TH_ - 1) / TH_; t.ntw = (gg.Wout + WD_TW - 1) / WD_TW; t.ntiles = Bt_ * t.nth * t.ntw;
+            static int ncu_d = 0;
+            if (!ncu_d) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu_d, hipDeviceAttributeMultiprocessorCount, dev); if (ncu_d <= 0) ncu_d = 256; }
+            const int nsub = KH / KR;
+            const long long slots_ws = workspace_floats / ((long long)N * gg.Ktot + N);
+            int Gd = (ncu_d / nsub) & ~7;                   // one workgroup per CU
+            if (Gd > slots_ws) Gd = (int)(slots_ws & ~7ll);
+            if (Gd > t.ntiles) Gd = t.ntiles;
+            if (Gd >= 1) {
+                t.G = Gd;
+                t.bpart = db ? workspace + (size_t)Gd * N * gg.Ktot : nullptr;
+                const size_t lds = (size_t)((long long)(TH_ + KR - 1) * (WD_TW + KW - 1) * gg.C + WT_SLACK + (long long)TH_ * WD_TW * WT_NP_OF(NT_)) * 4;
+                const dim3 grid(nsub * Gd);
+#define WD_LAUNCH(NT__, NJ__, TH__) do { static unsigned long long once_ = 0; \
+                    if (nele_first_use_on_device(&once_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma_kernel<NT__, NJ__, TH__>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
+                    hipLaunchKernelGGL((conv_wgrad_dma_kernel<NT__, NJ__, TH__>), grid, dim3(512), lds, s, t); } while (0)
+                if (NT_ == 4) WD_LAUNCH(4, 11, 2); else if (NT_ == 3) WD_LAUNCH(3, 13, 4); else if (NT_ == 2) WD_LAUNCH(2, 4, 4); else WD_LAUNCH(1, 1, 4);
+#undef WD_LAUNCH
+                NELE_CHECK_LAUNCH("nele_conv_wgrad(dma)");
+                tiled = true;
+                splits = Gd;
+                p.part = workspace;
+                p.bpart = t.bpart;
+            }
+        }
+    }
+    if (!tiled && bf16 && (sliced || wgrad_tile_eligible(M, N, p.g, KH, KW))) {
         WgradTileArgs t;
         t.A = A; t.dOut = dOut; t.part = workspace; t.N = Nt; t.B = Bt; t.KH = KH; t.KW = KW; t.d16 = d16;
         t.ics = p.g.C; t.subs_n = subs_n; t.subs_c = subs_c; t.Kfull = p.g.Ktot;

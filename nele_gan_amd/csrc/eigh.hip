@@ -1758,15 +1758,19 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     return o;
 }
 
-// matrices per cluster launch asked for by the caller of the next nele_eigh_sym_batched (0 = no preference; a performance hint only)
-__attribute__((visibility("hidden"))) int nele_eigh_cluster_batch_hint = 0;
-
 extern "C" long long nele_eigh_workspace_bytes(int B, int n) { return (long long)eigh_layout(B, n, nullptr, nullptr); }
 
 // A [B][n][n] symmetric (destroyed: holds the Householder reflectors on exit) -> lam [B][n] ascending,
 // U [B][n][n] with row j = eigenvector j.  U may alias A? No: U must be a different buffer.
 extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
                                      void* stream) {
+    return nele_eigh_sym_batched_ex(A, n, B, lam, U, workspace, workspace_bytes, stream, 0);
+}
+
+// Internal entry point (not exported): `cluster_batch` = matrices per cluster launch the caller wants (8 .. 64, 0 = no preference: 64).
+// An explicit argument - it used to be a mutable global "hint" set around the call, which two host threads could read crosswise.
+int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes, void* stream,
+                             int cluster_batch) {
     NELE_CHECK_ARG(A && lam && U && workspace && B > 0 && n >= 2, "nele_eigh_sym_batched: bad arguments");
     NELE_CHECK_ARG(A != U, "nele_eigh_sym_batched: U must not alias A");
     if (n > EG_MAXN) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_eigh_sym_batched: n=%d > %d", n, EG_MAXN);
@@ -1820,15 +1824,16 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
             // B = 256 step, alternating on one box: 45.4 / 45.5 / 46.0 against 46.1 / 46.2 / 46.3 ms (second session), 42.8 / 42.5
             // against 43.7 / 43.3 ms (third session; 48 per launch: 42.9 / 42.4) - the default since the second measurement.
             // The caller says which: SIIB's clean-signal phase inside a training step (nele_metric_siib phase 3, which runs beside the
-            // G-step) asks for 32 through nele_eigh_cluster_batch_hint; a stand-alone call (one-shot SIIB, nele_eigh_sym_batched by
+            // G-step) asks for 32 through nele_eigh_sym_batched_ex's argument; a stand-alone call (one-shot SIIB, nele_eigh_sym_batched by
             // itself) has nothing to share the chip with and takes 64 - one SIIB call at B = 256 is 17 ms that way and 21.5 ms with 32.
             static int p4_env = -1;
             if (p4_env < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_env = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 0; }
-            const int hint = nele_eigh_cluster_batch_hint;
+            const int hint = cluster_batch;
             const int p4_batch = p4_env ? p4_env : (hint >= 8 && hint <= 64 ? hint / 8 * 8 : 64);
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
-                hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop);
+                NELE_PROF("eigh_tridiag_cluster", s,
+                          hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop));
             }
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);

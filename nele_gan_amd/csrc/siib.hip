@@ -1286,6 +1286,12 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     TAKE(U, double, (size_t)B * SB_D * SB_D);
     TAKE(eigws, char, (size_t)nele_eigh_workspace_bytes(B, SB_D));
     TAKE(part, double, (size_t)B * SB_D * NTL * 3);
+    // Frame segments of the lag-product kernel: more workgroups at small batches.  NOTE (documented non-invariance): the partial sums
+    // of an utterance are added in segment order, so the association of its covariance sums - and with it the last bits of its score -
+    // depends on the batch-size class (B < 48 / < 128 / >= 128) it is scored in; the products and their order inside a segment do not.
+    // Folding the segments inside one workgroup (the same association for every B) costs the 29-lag kernel 58 more registers on top
+    // of 256 + 20 spilled; always writing four partials costs 0.84 GB of traffic per B = 256 call.  tests/test_metrics_gpu.py compares
+    // B = 1, 50 and 130 (equal at the float32 precision of the returned score).
     const int nseg = B >= 128 ? 1 : (B >= 48 ? 2 : 4);
     if (siib_lag_path()) {
         // the lag path needs neither the stacked frames nor the kept clean projections: Xs / px shrink to nothing
@@ -1382,9 +1388,8 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
     if (eig) {
-        nele_eigh_cluster_batch_hint = (phase == 3) ? 32 : 64;      // phase 3 runs beside the G-step: leave half of the chip to it (eigh.hip)
-        int st = nele_eigh_sym_batched(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream);
-        nele_eigh_cluster_batch_hint = 0;
+        // phase 3 runs beside the G-step: 32 matrices per cluster launch leave half of the chip to it (eigh.hip)
+        int st = nele_eigh_sym_batched_ex(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream, (phase == 3) ? 32 : 64);
         if (st) return st;
         if (phase == 3 && !siib_lag_path()) {               // clean-signal half of the projections, beside whatever the caller overlaps
             hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);

@@ -469,3 +469,26 @@ def test_haspi_per_utterance_lengths_in_one_padded_batch(mt):
         r1, _, i1 = mt.batch_haspi(c[b:b + 1, :n], y[b:b + 1, :n], return_info=True)
         assert raw[b] == pytest.approx(float(r1[0]), rel=1e-6), (b, raw[b], float(r1[0]))   # chunk seams sit elsewhere: warm-up residue 1e-20
         assert info[b, 0] == int(i1[0, 0])
+
+
+def test_siib_score_of_an_utterance_across_batch_size_classes(mt):
+    """csrc/siib.hip sums the lag-product partials of an utterance in segment order and picks the number of segments from the batch size
+    (more workgroups at small batches): the association of the covariance sums depends on the batch-size class (documented there).  An
+    utterance's raw score (a float32 output) in a batch of 1, of 50 and of 130 agrees to 1e-6 relative; M / frame counts are identical."""
+    from nele_gan_amd import synth
+    L = 24000
+    c, v = synth.batch(2, L, start=900)
+    y = (0.8 * c + v).astype(np.float32)
+    ref = None
+    for B in (1, 50, 130):
+        x_ = torch.from_numpy(np.repeat(c[:1], B, axis=0)).cuda()
+        y_ = torch.from_numpy(np.repeat(y[:1], B, axis=0)).cuda()
+        x_[B - 1], y_[B - 1] = torch.from_numpy(c[1]).cuda(), torch.from_numpy(y[1]).cuda()     # not all rows alike
+        if B == 1:
+            x_, y_ = torch.from_numpy(c[:1]).cuda(), torch.from_numpy(y[:1]).cuda()
+        raw, _, info = mt.batch_siib(x_, y_, return_info=True)
+        r0, i0 = float(raw[0].double()), info[0].cpu().numpy()
+        if ref is None:
+            ref = (r0, i0)
+        assert abs(r0 - ref[0]) <= 1e-6 * abs(ref[0])            # the raw score is returned as float32
+        np.testing.assert_array_equal(i0[:3], ref[1][:3])

@@ -319,7 +319,7 @@ def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, 
     """Round 3: in bf16 mode the activations of conv1..conv4 and the output gradients of conv2..conv5 are STORED as bfloat16
     (csrc/conv16.hip; nele_conv_wgrad_bf16_a16d16).  Every consumer of those tensors rounded them to bf16 while staging them, so the MFMA
     operands are the same numbers as with float32 buffers (NELE_CONV16=0: the round-2 kernels), accumulated over k in the same order:
-    scores, input gradient and every weight gradient must be BIT-identical.  Only the bias gradients of conv2..conv5 sum bf16-rounded
+    scores and input gradient must be BIT-identical, the weight gradients equal up to their summation order (round 4, see below).  Only the bias gradients of conv2..conv5 sum bf16-rounded
     instead of float32 output gradients (the same documented effect as for conv5 in round 2)."""
     B, T = 3, 251
     torch.manual_seed(6)
@@ -346,6 +346,10 @@ def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, 
     for k in g0:
         if '.bias' in k and k.startswith('layers.') and not k.startswith('layers.0.'):
             torch.testing.assert_close(g1[k], g0[k], rtol=8e-3, atol=8e-3 * float(g0[k].abs().max()))
+        elif 'weight' in k and k.startswith('layers.') and not k.startswith('layers.0.'):
+            # round 4: with both operands bf16 in memory the weight gradients of conv2..conv5 run on conv_wgrad_dma_kernel (several kernel
+            # rows per workgroup, other position-tile groups): the same bf16 products, float32 sums in another order
+            torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=4e-6 * float(g0[k].abs().max()))
         else:
             assert torch.equal(g1[k], g0[k]), k
 
