@@ -278,6 +278,10 @@ int nele_metric_siib_var(const float* x, const float* y, const int* lengths, int
 long long nele_eigh_workspace_bytes(int B, int n);
 int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
                           void* stream);
+/* Matrices of the last nele_eigh_sym_batched call on `workspace` whose cluster tridiagonalisation gave up (its workgroups were not
+ * co-resident within the spin limit, e.g. another process holds the GPU) and were redone by the single-workgroup repair kernel.
+ * Synchronises the device.  0 on a GPU the launch fits on. */
+int nele_eigh_repaired(void* workspace, int B, int n);
 
 /* intel.py:108-114 HASPI_Wrapper[_raw]_harvard -> pyHASPI/pyhaspi2.py:76-107 haspi_v2(x, fs, y, fs), HL = 0.
  * fs_in: any rate up to 24000 Hz (below it the signals are resampled to 24 kHz as librosa.resample = resampy kaiser_best + fix_length,

@@ -1848,25 +1848,51 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(WgradDmaArgs p) 
                 bq[0] += (float)v[0]; bq[1] += (float)v[1]; bq[2] += (float)v[2]; bq[3] += (float)v[3];
             }
         }
-#pragma unroll 1
-        for (int ks = 0; ks < NS; ++ks) {
-            const __bf16* ha = dt + ks * 32 * NP + la_off;
-            const __bf16* hb = buf + (ks >> 1) * RS + (ks & 1) * 32 * g.C + lb_off;
-            bf16x8 af[NT];
+        // ---- F = NS x NJ work items (reduction step ks, item jj) as ONE unrolled software pipeline: the B fragment of item f + LA and the
+        // A fragments of the step that starts LA items ahead are requested before the MFMAs of item f (a read-then-multiply item left
+        // one LDS latency exposed per item: MFMA-busy 0.55); sched_barrier pins the order, the wait-count pass then waits only for
+        // the fragment an item needs.
+        {
+            constexpr int F = NS * NJ;
+            constexpr int LA = NT >= 3 ? 2 : (NT == 2 ? 3 : 6);             // look-ahead in items (an item = NT MFMAs of 16 cycles)
+            constexpr int AS = LA / NJ + 2;                                  // A-fragment sets in flight
+            bf16x8 bring[LA + 1], aring[AS][NT];
+            auto rdA = [&](int ks, bf16x8 (&a)[NT]) {
+                const __bf16* ha = dt + ks * 32 * NP + la_off;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i + 8 * NP));
-                af[i][0] = lo[0]; af[i][1] = lo[1]; af[i][2] = lo[2]; af[i][3] = lo[3]; af[i][4] = hi[0]; af[i][5] = hi[1]; af[i][6] = hi[2]; af[i][7] = hi[3];
-            }
+                for (int i = 0; i < NT; ++i) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ha + 16 * i + 8 * NP));
+                    a[i][0] = lo[0]; a[i][1] = lo[1]; a[i][2] = lo[2]; a[i][3] = lo[3]; a[i][4] = hi[0]; a[i][5] = hi[1]; a[i][6] = hi[2]; a[i][7] = hi[3];
+                }
+            };
+            auto rdB = [&](int ks, int jj) {
+                const __bf16* hb = buf + (ks >> 1) * RS + (ks & 1) * 32 * g.C + lb_off + boff[jj];
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)hb);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(hb + ldb8));
+                bf16x8 r;
+                r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+                return r;
+            };
+            // prologue: the A sets of the steps that start within the first LA items, the B fragments of items 0 .. LA - 1
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(hb + boff[jj]));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(hb + boff[jj] + ldb8));
-                bf16x8 bf;
-                bf[0] = lo[0]; bf[1] = lo[1]; bf[2] = lo[2]; bf[3] = lo[3]; bf[4] = hi[0]; bf[5] = hi[1]; bf[6] = hi[2]; bf[7] = hi[3];
+            for (int ks = 0; ks < NS; ++ks)
+                if (ks * NJ <= LA) rdA(ks, aring[ks % AS]);
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][jj], 0, 0, 0);
+            for (int f = 0; f < LA; ++f)
+                if (f < F) bring[f % (LA + 1)] = rdB(f / NJ, f % NJ);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const int ks = f / NJ, jj = f % NJ;
+                if (f + LA < F) {
+                    const int fn = f + LA, ksn = fn / NJ;
+                    bring[fn % (LA + 1)] = rdB(ksn, fn % NJ);
+                    if (fn % NJ == 0 && ksn * NJ > LA) rdA(ksn, aring[ksn % AS]);     // first item of a later step: its A set
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aring[ks % AS][i], bring[f % (LA + 1)], acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -2493,13 +2519,15 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
             if (KH % cand == 0 && NT_ * ((cand * nkt_ + 7) / 8) <= 44) { KR = cand; break; }
         const int NJ_ = KR ? (KR * nkt_ + 7) / 8 : 0;
         int TH_ = 0;
-        for (int cand = 4; cand >= 2 && KR; cand -= 2) {
+        static int th_env = -1;                              // NELE_WGRAD_DMA_TH=2|3|4: cap on the tile height (A/B diagnostic)
+        if (th_env < 0) { const char* e = getenv("NELE_WGRAD_DMA_TH"); th_env = e ? atoi(e) : 4; }
+        for (int cand = th_env < 4 ? th_env : 4; cand >= 2 && KR; --cand) {
             const long long bufsz = (long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + WT_SLACK + (long long)cand * WD_TW * WT_NP_OF(NT_);
             const int npc = (int)(((long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + 511) / 512), ndp = cand * WD_TW * WT_NP_OF(NT_) / 512;
             if (bufsz * 4 <= 150 * 1024 && npc <= 8 * WD_MAXHP && ndp <= 8 * WD_MAXDP) { TH_ = cand; break; }
         }
-        // compiled shapes (NT, NJ, TH): D.conv5 (4, 11, 2), D.conv4 (3, 13, 4), D.conv3 (2, 4, 4), D.conv2 (1, 1, 4)
-        const bool shape_ok = (NT_ == 4 && NJ_ == 11 && TH_ == 2) || (NT_ == 3 && NJ_ == 13 && TH_ == 4) || (NT_ == 2 && NJ_ == 4 && TH_ == 4) ||
+        // compiled shapes (NT, NJ, TH): D.conv5 (4, 11, 3 | 2), D.conv4 (3, 13, 4), D.conv3 (2, 4, 4), D.conv2 (1, 1, 4)
+        const bool shape_ok = (NT_ == 4 && NJ_ == 11 && (TH_ == 2 || TH_ == 3)) || (NT_ == 3 && NJ_ == 13 && TH_ == 4) || (NT_ == 2 && NJ_ == 4 && TH_ == 4) ||
                               (NT_ == 1 && NJ_ == 1 && TH_ == 4);
         if (KR && TH_ && shape_ok && N <= 64 && N == gg.OC && gg.C % 8 == 0 && KW * gg.C == gg.seglen && gg.oh0 >= 1 && gg.Wout >= 1 &&
             M % (gg.Hout * gg.Wout) == 0 && (long long)(M / (gg.Hout * gg.Wout)) * gg.OH * gg.OW * gg.OC < (1ll << 31) &&
@@ -2524,7 +2552,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
 #define WD_LAUNCH(NT__, NJ__, TH__) do { static unsigned long long once_ = 0; \
                     if (nele_first_use_on_device(&once_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma_kernel<NT__, NJ__, TH__>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
                     hipLaunchKernelGGL((conv_wgrad_dma_kernel<NT__, NJ__, TH__>), grid, dim3(512), lds, s, t); } while (0)
-                if (NT_ == 4) WD_LAUNCH(4, 11, 2); else if (NT_ == 3) WD_LAUNCH(3, 13, 4); else if (NT_ == 2) WD_LAUNCH(2, 4, 4); else WD_LAUNCH(1, 1, 4);
+                if (NT_ == 4 && TH_ == 3) WD_LAUNCH(4, 11, 3); else if (NT_ == 4) WD_LAUNCH(4, 11, 2); else if (NT_ == 3) WD_LAUNCH(3, 13, 4); else if (NT_ == 2) WD_LAUNCH(2, 4, 4); else WD_LAUNCH(1, 1, 4);
 #undef WD_LAUNCH
                 NELE_CHECK_LAUNCH("nele_conv_wgrad(dma)");
                 tiled = true;

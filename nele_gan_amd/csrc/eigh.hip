@@ -29,6 +29,8 @@ struct EighWs {
     double* lu;     // [B][6][(n+2)/2][EG_MAXN][2]
     int* pin;       // [B][n][EG_MAXN]
     uint4* xch;     // [B][2][2][EG_MAXN] cluster tridiagonalisation: tagged exchange slots (zeroed per call)
+    int* flag;      // [B + 1] cluster tridiagonalisation gave up on matrix b (its workgroups were not co-resident within the spin limit):
+                    //         the single-workgroup kernels skip it and eigh_tridiag_repair_kernel redoes it; [B] = matrices repaired (zeroed per call)
 };
 
 // ------------------------------------------------------------------------------------------ e1
@@ -61,15 +63,12 @@ __device__ __forceinline__ void eigh_house(double* v, int m, double* red, double
 // Six workgroup barriers per step: (1,2) reduce p.v, (3,4) reduce ||x'||^2 of the next pivot row, (5) publish the next
 // Householder vector, (6) end of the fused pass.  Vectors ping-pong between two LDS slots; the two row groups of the pass
 // leave their partial matrix-vector products in separate arrays that the next step adds on the fly.
-__global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
+__device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
+                                                 double* __restrict__ tau) {
     __shared__ double vb[2][EG_MAXN], wv[EG_MAXN], pa[EG_MAXN], pb2[EG_MAXN];
     __shared__ double red[16];
     __shared__ double s_tau, s_scale, s_beta;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    double* A = Aall + (size_t)b * n * n;
-    double* d = ws.d + (size_t)b * n;
-    double* e = ws.e + (size_t)b * n;
-    double* tau = ws.tau + (size_t)b * n;
+    const int tid = threadIdx.x;
     // step 0: v from row 0, p = A22 v by a plain pass (two row groups -> pa, pb2)
     {
         const int m = n - 1;
@@ -170,6 +169,30 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
         betak = betan;
     }
     if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
+}
+
+__global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
+    const int b = blockIdx.x;
+    eigh_tridiag_one(Aall + (size_t)b * n * n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
+}
+
+// Repair of the matrices the cluster kernels gave up on (ws.flag[b] != 0: some of a matrix's workgroups were not scheduled within the
+// spin limit - another process on the GPU, a debugger, a launch larger than the chip).  The cluster kernels keep the trailing matrix in
+// registers and only ever write reflector rows into the strict UPPER triangle of A before their hand-over, which a matrix that gave up
+// never reaches: its lower triangle and diagonal still hold the original matrix.  One workgroup mirrors them back and runs the
+// memory-streaming single-workgroup tridiagonalisation (slow: ~3 ms for one 420 x 420 matrix; it never runs on a GPU the launch fits on).
+// grid B, block 1024; unflagged matrices return at once.
+__global__ __launch_bounds__(1024) void eigh_tridiag_repair_kernel(double* __restrict__ Aall, int n, EighWs ws, int B) {
+    const int b = blockIdx.x;
+    if (ws.flag[b] == 0) return;
+    double* A = Aall + (size_t)b * n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += 1024) {
+        const int r = idx / n, c = idx - r * n;
+        if (c > r) A[idx] = A[(size_t)c * n + r];
+    }
+    __syncthreads();
+    eigh_tridiag_one(A, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
+    if (threadIdx.x == 0) atomicAdd(&ws.flag[B], 1);
 }
 
 
@@ -385,7 +408,8 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 #endif
                 if (__all(ok)) break;
                 if (++spins > EC_SPIN_LIMIT) {             // never hang the device: poison the output instead
-                    if (i < n) d[i] = __builtin_nan("");
+                    if (i < n) d[i] = __builtin_nan("");       // (overwritten by eigh_tridiag_repair_kernel, which redoes this matrix)
+                    if (tid == 0) ws.flag[b] = 1;
                     return;
                 }
 #ifndef EC_NOSLEEP
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 // workgroup) lives in LDS.
 #define E4_P 4
 #define E4_RI 28
-__global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop) {
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop, int fail_every) {
     __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
     __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
     __shared__ double accb[16][128];
@@ -426,6 +450,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
     const int slot = g >> 3, p = slot & 3, mloc = (g & 7) + 8 * (slot >> 2);
     if (mloc >= Bc) return;
     const int b = b0 + mloc;
+    if (fail_every > 0 && b % fail_every == 0) {           // test hook (NELE_EIGH_FAIL_EVERY): behave as if this matrix's workgroups had given up
+        if (tid == 0 && p == 0) ws.flag[b] = 1;
+        return;
+    }
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
@@ -595,7 +623,8 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
                 }
                 if (__all(ok)) break;
                 if (++spins > EC_SPIN_LIMIT) {
-                    if (i < n) d[i] = __builtin_nan("");
+                    if (i < n) d[i] = __builtin_nan("");       // (overwritten by eigh_tridiag_repair_kernel, which redoes this matrix)
+                    if (tid == 0) ws.flag[b] = 1;
                     return;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -652,6 +681,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
     __shared__ double red0[8], red1[8];
     __shared__ double s_alpha, s_ppiv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+    if (ws.flag[b] != 0) return;                         // the cluster kernel gave up on this matrix: eigh_tridiag_repair_kernel redoes it
     const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
@@ -788,6 +818,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restric
     __shared__ double red0[8], red1[8];
     __shared__ double s_alpha, s_ppiv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+    if (ws.flag[b] != 0) return;                         // the cluster kernel gave up on this matrix: eigh_tridiag_repair_kernel redoes it
     const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1, m <= EM_M
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
@@ -946,6 +977,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
     __shared__ double red0[8], red1[8];
     __shared__ double s_alpha, s_ppiv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+    if (ws.flag[b] != 0) return;                         // the cluster kernel gave up on this matrix: eigh_tridiag_repair_kernel redoes it
     const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1, m <= EM_M + EX_E
     const int E = max(m - EM_M, 0);                      // its first E rows / columns live in the LDS strip, the rest in registers
     double* S = em_strip;
@@ -1754,11 +1786,23 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     TAKE(lu, double, (size_t)B * 6 * (n + 2) * EG_MAXN);
     TAKE(pin, int, (size_t)B * n * EG_MAXN);
     TAKE(xch, uint4, (size_t)B * 4 * EG_MAXN);
+    TAKE(flag, int, (size_t)B + 64);
 #undef TAKE
     return o;
 }
 
 extern "C" long long nele_eigh_workspace_bytes(int B, int n) { return (long long)eigh_layout(B, n, nullptr, nullptr); }
+
+// Matrices of the LAST nele_eigh_sym_batched call on this workspace that the cluster tridiagonalisation gave up on and the single-workgroup
+// repair kernel redid (synchronises the device; 0 on a GPU the launch fits on).  -1 on error.
+extern "C" int nele_eigh_repaired(void* workspace, int B, int n) {
+    if (!workspace || B <= 0 || n < 2) return -1;
+    EighWs ws;
+    eigh_layout(B, n, &ws, (char*)workspace);
+    int v = -1;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, ws.flag + B, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 
 // A [B][n][n] symmetric (destroyed: holds the Householder reflectors on exit) -> lam [B][n] ascending,
 // U [B][n][n] with row j = eigenvector j.  U may alias A? No: U must be a different buffer.
@@ -1794,6 +1838,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     }
     if (cluster_cap >= 8) {
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
+        if (hipMemsetAsync(ws.flag, 0, sizeof(int) * ((size_t)B + 1), s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
         // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
         static int p4_on = -1;
@@ -1830,10 +1875,12 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             if (p4_env < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_env = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 0; }
             const int hint = cluster_batch;
             const int p4_batch = p4_env ? p4_env : (hint >= 8 && hint <= 64 ? hint / 8 * 8 : 64);
+            static int fail_every = -1;                     // NELE_EIGH_FAIL_EVERY=k (tests): every k-th matrix takes the give-up / repair path
+            if (fail_every < 0) { const char* e_ = getenv("NELE_EIGH_FAIL_EVERY"); fail_every = e_ ? atoi(e_) : 0; }
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 NELE_PROF("eigh_tridiag_cluster", s,
-                          hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop));
+                          hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop, fail_every));
             }
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);
@@ -1850,6 +1897,8 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
         }
         }
+        // matrices a cluster launch gave up on (never on a GPU the launch fits on): redone by one workgroup each instead of NaN results
+        hipLaunchKernelGGL(eigh_tridiag_repair_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B);
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }

@@ -62,6 +62,9 @@ _lib._SIGS['nele_haspi_dither_rows'] = _lib.lib.nele_haspi_dither_rows.argtypes
 
 declare('nele_eigh_sym_batched', [_P, c_int, c_int, _P, _P, _P, c_longlong, _P])
 _lib._SIGS['nele_eigh_sym_batched'] = _lib.lib.nele_eigh_sym_batched.argtypes
+_lib.lib.nele_eigh_repaired.argtypes = [_P, c_int, c_int]
+_lib.lib.nele_eigh_repaired.restype = c_int
+_lib._SIGS['nele_eigh_repaired'] = _lib.lib.nele_eigh_repaired.argtypes
 _lib.lib.nele_eigh_workspace_bytes.argtypes = [c_int, c_int]
 _lib.lib.nele_eigh_workspace_bytes.restype = c_longlong
 _lib._SIGS['nele_eigh_workspace_bytes'] = _lib.lib.nele_eigh_workspace_bytes.argtypes
@@ -87,14 +90,17 @@ def release_workspaces():
     _ws_cache.clear()
 
 
-def eigh_batched(A):
-    """A [B,n,n] float64 symmetric (device) -> (eigenvalues [B,n] ascending, U [B,n,n] with rows = eigenvectors)."""
+def eigh_batched(A, return_repaired=False):
+    """A [B,n,n] float64 symmetric (device) -> (eigenvalues [B,n] ascending, U [B,n,n] with rows = eigenvectors).
+    return_repaired: also the number of matrices the cluster tridiagonalisation gave up on and the repair kernel redid (synchronises)."""
     A = A.clone().contiguous()
     B, n, _ = A.shape
     lam = torch.empty((B, n), dtype=torch.float64, device=A.device)
     U = torch.empty_like(A)
     ws = _workspace('eigh', _lib.lib.nele_eigh_workspace_bytes(B, n), A.device)
     call('nele_eigh_sym_batched', ptr(A), n, B, ptr(lam), ptr(U), ptr(ws), ws.numel(), stream())
+    if return_repaired:
+        return lam, U, int(_lib.lib.nele_eigh_repaired(ptr(ws), B, n))
     return lam, U
 
 

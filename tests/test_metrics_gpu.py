@@ -492,3 +492,52 @@ def test_siib_score_of_an_utterance_across_batch_size_classes(mt):
             ref = (r0, i0)
         assert abs(r0 - ref[0]) <= 1e-6 * abs(ref[0])            # the raw score is returned as float32
         np.testing.assert_array_equal(i0[:3], ref[1][:3])
+
+
+_REPAIR_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for n, B in ((420, 8), (300, 5)):
+    rs = np.random.RandomState(n)
+    A = np.zeros((B, n, n))
+    for b in range(B):
+        G = rs.randn(n, 3 * n) * np.exp(-0.01 * np.arange(3 * n))[None, :]
+        A[b] = G @ G.T / (3 * n)
+    lam, U, rep = mt.eigh_batched(torch.from_numpy(A).cuda(), return_repaired=True)
+    lam, U = lam.cpu().numpy(), U.cpu().numpy()
+    worst = [0.0, 0.0, 0.0]
+    for b in range(B):
+        ref = np.linalg.eigvalsh(A[b])
+        V = U[b].T
+        worst[0] = max(worst[0], np.abs(lam[b] - ref).max() / ref.max())
+        worst[1] = max(worst[1], np.abs(V.T @ V - np.eye(n)).max())
+        worst[2] = max(worst[2], np.abs(A[b] @ V - V * lam[b][None, :]).max() / ref.max())
+    out += [float(rep)] + worst
+c, v = synth.batch(4, 32000, start=91)
+raw, _, info = mt.batch_siib(c, 0.8 * c + v, return_info=True)
+out += list(raw.double().cpu().numpy()) + list(info[:, 3].double().cpu().numpy())
+np.save(sys.argv[2], np.array(out))
+'''
+
+
+def test_cluster_tridiagonalisation_give_up_is_repaired_not_poisoned(tmp_path):
+    """Round 4: when the workgroups of a matrix are not co-resident within the spin limit the cluster kernel used to poison the matrix
+    with NaN (the optimiser step was then masked).  Now it flags the matrix and one workgroup redoes it from the untouched lower
+    triangle (eigh_tridiag_repair_kernel).  NELE_EIGH_FAIL_EVERY=3 (read once per process) sends every third matrix down that path:
+    same accuracy against numpy as the fast path, the repair count is reported, and SIIB scores equal the unforced run's."""
+    import subprocess
+    import sys
+    res = []
+    for k in ('3', '0'):
+        out = str(tmp_path / ('repair_%s.npy' % k))
+        subprocess.run([sys.executable, '-c', _REPAIR_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_EIGH_FAIL_EVERY=k), timeout=240)
+        res.append(np.load(out))
+    forced, plain = res
+    assert forced[0] == 3 and forced[4] == 2 and plain[0] == 0 and plain[4] == 0           # matrices 0, 3, 6 of 8; 0, 3 of 5
+    for r in (forced, plain):
+        for o in (0, 4):
+            assert r[o + 1] < 1e-13 and r[o + 2] < 1e-8 and r[o + 3] < 1e-11
+    np.testing.assert_allclose(forced[8:12], plain[8:12], rtol=1e-6)                       # SIIB raw scores (float32 outputs)
+    assert np.all(forced[12:] == plain[12:]) and np.all(np.isfinite(forced))
