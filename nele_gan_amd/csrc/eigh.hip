@@ -665,6 +665,241 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ e1, second cluster stage: 2 workgroups per matrix
+// Round 4.  The four-workgroup kernel above needs a quarter of a CU's registers per 105 columns of a 420 x 420 matrix, whatever is left
+// of it: 64 matrices fill the chip, a batch of 256 takes four rounds of the same latency chain.  Once the trailing block has shrunk
+// to EC2_M = 320 rows it fits TWO register files (column-cyclic over two workgroups: 160 column slots = 4 register columns + 1 LDS
+// column per lane, 20 row slots of 16): 128 matrices per launch, half as many rounds for the steps from 320 down to the hand-over to
+// the single-workgroup kernel at 256.  Same algorithm, exchange protocol and hand-over state as eigh_tridiag_cluster4_kernel; indices are
+// LOCAL to the trailing block (global row = base + local row), the state comes from the previous stage through ws.zt / A exactly as
+// eigh_tridiag_mid_kernel takes it.  Tags continue the step numbering of the first stage (the exchange slots are zeroed once per call).
+#define EC2_P 2
+#define EC2_RI 20
+#define EC2_NR 4
+#define EC2_M (16 * EC2_RI)
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_first, int s_stop) {
+    extern __shared__ double ec2_col[];                    // aL[EC2_RI][16][32]: the fifth column slot of every lane
+    __shared__ __attribute__((aligned(16))) double vperm[3][EC2_M + 64];   // v, w, v_next at [(r & 15) * EC2_RI + (r >> 4)]
+    __shared__ double vnat[EC2_M], wnat[EC2_M];
+    __shared__ double accb[16][32 * (EC2_NR + 1)];
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = g >> 3, p = slot & 1, mloc = (g & 7) + 8 * (slot >> 1);
+    if (mloc >= Bc) return;
+    const int b = b0 + mloc;
+    if (ws.flag[b] != 0) return;                           // the first stage gave up on this matrix
+    const int base = s_first + 1, m = n - base;            // trailing block = rows / columns base .. n-1, m <= EC2_M
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;
+    double (*aL)[16][32] = reinterpret_cast<double (*)[16][32]>(ec2_col);
+
+    const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
+    int cc[EC2_NR + 1];                                    // local columns of this lane: p + 2 (cl0 + 32 j)
+#pragma unroll
+    for (int j = 0; j <= EC2_NR; ++j) cc[j] = p + EC2_P * (cl0 + 32 * j);
+    double a[EC2_NR][EC2_RI];
+#pragma unroll
+    for (int ri = 0; ri < EC2_RI; ++ri) {
+        const int r = rs + 16 * ri;
+#pragma unroll
+        for (int j = 0; j < EC2_NR; ++j) a[j][ri] = (r < m && cc[j] < m) ? A[(size_t)(base + r) * n + base + cc[j]] : 0.0;
+        aL[ri][rs][cl0] = (r < m && cc[EC2_NR] < m) ? A[(size_t)(base + r) * n + base + cc[EC2_NR]] : 0.0;
+    }
+    const int il = tid, i = base + tid;                    // vector element owned by this thread: local / global index
+    const bool own = il < m;
+    const int pi = (il & 15) * EC2_RI + (il >> 4);         // permuted slot (il < EC2_M)
+    double v_i = 0.0, tk = 0.0, p_i = 0.0, col_i = 0.0;
+    {
+        const double* st = ws.zt + (size_t)b * n * EG_MAXN;
+        if (own) { v_i = st[i]; p_i = st[EG_MAXN + i]; col_i = st[2 * EG_MAXN + i]; }
+        tk = st[3 * EG_MAXN];
+    }
+    __syncthreads();
+    for (int s = s_first; s <= n - 2; ++s) {
+        const bool in = own && (i >= s + 1);
+        double w_i = 0.0, wpiv = 0.0;
+        {
+            if (own && i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wv] = pv;
+            __syncthreads();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (own && i == s + 2) s_alpha = x_i;
+            double ss = (own && i >= s + 3) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wv] = ss;
+            __syncthreads();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
+            }
+            vn_i = (own && i == s + 2) ? 1.0 : ((own && i > s + 2) ? x_i * scn : 0.0);
+        }
+        if (p == ((s + 1) & 1)) {                          // one of the two workgroups records the step (both hold the same vectors)
+            if (own && i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+            if (own && i >= s + 2) A[(size_t)(s + 1) * n + i] = vn_i;
+        }
+        if (s == n - 2) break;
+        if (il < EC2_M) {
+            vnat[il] = v_i; wnat[il] = w_i;
+            vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i;
+        }
+        __syncthreads();
+        // ---- fused pass: x = a - v_r w_c - w_r v_c ; acc_c += x * vnext_r  (4 register columns + 1 LDS column; dead rows / columns are updated harmlessly)
+        const int lo = s + 2 - base;                       // first live local index
+        {
+            // the columns go in groups of two (as in eigh_tridiag_mid_kernel): v_c, w_c and acc_c of all five columns beside the 80-double block
+            // spilled 111 registers; the row vectors are re-read from LDS per group
+            const int ri0 = (lo - rs + 15) >> 4;
+            const double2* pv0 = reinterpret_cast<const double2*>(&vperm[0][rs * EC2_RI]);
+            const double2* pv1 = reinterpret_cast<const double2*>(&vperm[1][rs * EC2_RI]);
+            const double2* pv2 = reinterpret_cast<const double2*>(&vperm[2][rs * EC2_RI]);
+#pragma unroll
+            for (int h = 0; h < EC2_NR / 2; ++h) {
+                double acc[2], vc[2], wc[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = 2 * h + u;
+                    const bool ok = cc[j] < m;
+                    acc[u] = 0.0;
+                    vc[u] = ok ? vnat[min(cc[j], EC2_M - 1)] : 0.0;
+                    wc[u] = ok ? wnat[min(cc[j], EC2_M - 1)] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < EC2_RI / 2; ++q) {
+                    if (2 * q + 1 >= ri0) {                // rows rs + 16 (2q), rs + 16 (2q + 1)
+                        const double2 vr = pv0[q], wr = pv1[q], nr = pv2[q];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int j = 2 * h + u;
+                            double x0 = a[j][2 * q], x1 = a[j][2 * q + 1];
+                            x0 -= vr.x * wc[u] + wr.x * vc[u];
+                            x1 -= vr.y * wc[u] + wr.y * vc[u];
+                            a[j][2 * q] = x0; a[j][2 * q + 1] = x1;
+                            acc[u] += x0 * nr.x + x1 * nr.y;
+                        }
+                    }
+                }
+                accb[rs][cl0 + 32 * (2 * h)] = acc[0];
+                accb[rs][cl0 + 32 * (2 * h + 1)] = acc[1];
+            }
+            {                                              // the LDS column
+                const bool ok = cc[EC2_NR] < m;
+                const double vcl = ok ? vnat[min(cc[EC2_NR], EC2_M - 1)] : 0.0, wcl = ok ? wnat[min(cc[EC2_NR], EC2_M - 1)] : 0.0;
+                double accl = 0.0;
+#pragma unroll
+                for (int q = 0; q < EC2_RI / 2; ++q) {
+                    if (2 * q + 1 >= ri0) {
+                        const double2 vr = pv0[q], wr = pv1[q], nr = pv2[q];
+                        double u0 = aL[2 * q][rs][cl0], u1 = aL[2 * q + 1][rs][cl0];
+                        u0 -= vr.x * wcl + wr.x * vcl;
+                        u1 -= vr.y * wcl + wr.y * vcl;
+                        aL[2 * q][rs][cl0] = u0; aL[2 * q + 1][rs][cl0] = u1;
+                        accl += u0 * nr.x + u1 * nr.y;
+                    }
+                }
+                accb[rs][cl0 + 32 * EC2_NR] = accl;
+            }
+        }
+        const unsigned tag = (unsigned)(s + 3);
+        u32x4* xp = xch + (size_t)((s + 1) & 1) * 2 * EG_MAXN;
+        if (rs == (lo & 15)) {                             // every workgroup publishes its part of pivot row s + 2 (local row lo)
+            const int rq = lo >> 4;
+            double rv[EC2_NR] = {0.0, 0.0, 0.0, 0.0};
+            switch (rq) {
+#define EC2_CASE(k) case k: _Pragma("unroll") for (int j = 0; j < EC2_NR; ++j) rv[j] = a[j][k]; break;
+                EC2_CASE(0) EC2_CASE(1) EC2_CASE(2) EC2_CASE(3) EC2_CASE(4) EC2_CASE(5) EC2_CASE(6) EC2_CASE(7) EC2_CASE(8) EC2_CASE(9)
+                EC2_CASE(10) EC2_CASE(11) EC2_CASE(12) EC2_CASE(13) EC2_CASE(14) EC2_CASE(15) EC2_CASE(16) EC2_CASE(17) EC2_CASE(18) EC2_CASE(19)
+#undef EC2_CASE
+            }
+#pragma unroll
+            for (int j = 0; j < EC2_NR; ++j)
+                if (cc[j] >= lo && cc[j] < m) st_tagged(&xp[EG_MAXN + cc[j]], rv[j], tag);
+            if (cc[EC2_NR] >= lo && cc[EC2_NR] < m) st_tagged(&xp[EG_MAXN + cc[EC2_NR]], aL[rq][rs][cl0], tag);
+        }
+        __syncthreads();
+        if (tid < 32 * (EC2_NR + 1)) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += accb[q][tid];
+            const int c = p + EC2_P * tid;                 // accb column tid = cl0 + 32 j  <->  local column p + 2 (cl0 + 32 j)
+            if (c >= lo && c < m) st_tagged(&xp[c], t, tag);
+        }
+        const bool need = own && (il >= lo);
+        if (__any(need)) {
+            u32x4 qp, qc;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (need) {
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(qp), "=&v"(qc) : "v"(&xp[il]), "v"(&xp[EG_MAXN + il]) : "memory");
+                    ok = (qp.y == tag) && (qp.w == tag) && (qc.y == tag) && (qc.w == tag);
+                }
+                if (__all(ok)) break;
+                if (++spins > EC_SPIN_LIMIT) {             // never hang the device (see eigh_tridiag_cluster4_kernel); this stage's give-up
+                    if (own) d[i] = __builtin_nan("");     // cannot be redone from the lower triangle (the block has been updated in place):
+                    if (tid == 0) ws.flag[b] = 2;          // the matrix stays poisoned and the optimiser step is masked, as before round 4
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (need) { p_i = tagged_value(qp); col_i = tagged_value(qc); }
+        }
+        v_i = vn_i;
+        tk = tn;
+        if (s == s_stop) break;
+    }
+    if (s_stop >= s_first && s_stop < n - 2) {
+        // hand-over to the single-workgroup kernel (outside the step loop: inside it the compiler kept the 100 store addresses live across
+        // the loop - 92 spilled registers): trailing block (rows / columns >= s_stop + 2) back to A in place, per-element state to ws.zt
+        int lbv = s_stop + 2 - base;
+        asm volatile("" : "+v"(lbv));                      // (not a loop invariant the optimiser may hoist above the loop)
+        const int lb = lbv;
+#pragma unroll
+        for (int ri = 0; ri < EC2_RI; ++ri) {
+            const int r = rs + 16 * ri;
+            if (r >= lb && r < m) {
+#pragma unroll
+                for (int j = 0; j < EC2_NR; ++j)
+                    if (cc[j] >= lb && cc[j] < m) A[(size_t)(base + r) * n + base + cc[j]] = a[j][ri];
+                if (cc[EC2_NR] >= lb && cc[EC2_NR] < m) A[(size_t)(base + r) * n + base + cc[EC2_NR]] = aL[ri][rs][cl0];
+            }
+        }
+        if (p == 0 && own) {
+            double* st = ws.zt + (size_t)b * n * EG_MAXN;
+            st[i] = v_i; st[EG_MAXN + i] = p_i; st[2 * EG_MAXN + i] = col_i;
+            if (il == 0) st[3 * EG_MAXN] = tk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ e1, tail
 // The last ET_M = 128 steps of the tridiagonalisation (and whole matrices with n <= 128) in ONE workgroup per matrix with the trailing
 // block in LDS: the cluster kernel's step costs 5 us whatever is left of the matrix (exchange, peer wait), and a 128 x 128 block needs
@@ -1863,6 +2098,17 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             }
             const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
+            // second cluster stage (round 4): once 320 rows are left, two workgroups per matrix hold the block - twice the matrices per launch
+            // for the steps from 320 down to the single-workgroup hand-over (NELE_EIGH_C2=0: the four-workgroup kernel runs them all)
+            static int c2_on = -1;
+            if (c2_on < 0) {
+                const char* e_ = getenv("NELE_EIGH_C2");
+                c2_on = !(e_ && e_[0] == '0');
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_cluster2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(sizeof(double) * EC2_RI * 16 * 32));
+            }
+            const bool two_stage = c2_on && s_stop >= 0 && mhand < EC2_M && n > EC2_M + 8;
+            const int s_stop1 = two_stage ? n - EC2_M - 2 : s_stop;
             // NELE_EIGH_P4_BATCH: matrices per launch (32 = half of the chip inside a training step, 64 = all of it otherwise).  The spinning workgroups own
             // their CU - registers full, issue slots mostly idle - so 32 per launch (twice the launches) leaves room for the step's other
             // streams while the chain's own time doubles (8 x 1.2 instead of 4 x 1.2 ms per 256 matrices).  Measured twice on the
@@ -1880,7 +2126,16 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 NELE_PROF("eigh_tridiag_cluster", s,
-                          hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop, fail_every));
+                          hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop1, fail_every));
+            }
+            if (two_stage) {
+                const int c2_batch = 2 * p4_batch;
+                for (int b0 = 0; b0 < B; b0 += c2_batch) {
+                    const int Bc = (B - b0 < c2_batch) ? B - b0 : c2_batch;
+                    NELE_PROF("eigh_tridiag_cluster", s,
+                              hipLaunchKernelGGL(eigh_tridiag_cluster2_kernel, dim3(16 * ((Bc + 7) / 8)), dim3(512), sizeof(double) * EC2_RI * 16 * 32, s, A, n, b0,
+                                                 Bc, ws, s_stop1 + 1, s_stop));
+                }
             }
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);
