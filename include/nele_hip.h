@@ -24,6 +24,9 @@ extern "C" {
 int nele_version(void);
 const char* nele_last_error_string(void);
 int nele_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+/* 0 for the product library (libnele_hip.so: one path per operation, no environment switch is read); 1 for the test library built from
+ * the same sources with -DNELE_AB (libnele_hip_ab.so), in which the superseded kernel variants exist and NELE_* switches select them. */
+int nele_build_has_ab_switches(void);
 
 /* Measurement hook (no reference counterpart): HIP-event timing of single kernels that are launched from inside multi-kernel entry
  * points, on the stream they run on.  nele_profile_begin(tags) arms it for the launch sites whose tag is in the comma-separated list

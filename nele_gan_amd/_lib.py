@@ -38,6 +38,7 @@ lib.nele_last_error_string.restype = ctypes.c_char_p
 # name -> argtypes (all return int status); mirrors include/nele_hip.h
 _SIGS = {
     'nele_device_info': [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.c_char_p, c_int],
+    'nele_build_has_ab_switches': [],
     'nele_stft_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft': [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],

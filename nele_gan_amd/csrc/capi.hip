@@ -27,6 +27,21 @@ extern "C" int nele_device_info(int* cu_count, int* wave_size, char* arch, int a
     return NELE_OK;
 }
 
+#ifdef NELE_AB
+#include <cstdlib>
+int nele_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+#endif
+extern "C" int nele_build_has_ab_switches(void) {
+#ifdef NELE_AB
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 bool nele_first_use_on_device(unsigned long long* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)

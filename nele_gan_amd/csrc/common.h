@@ -40,9 +40,27 @@ extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, doubl
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- A/B switches.  The PRODUCT library (libnele_hip.so) has ONE path per operation: NELE_SWITCH_INT(name, default) is the constant
+// `default` there, so the dispatch of every superseded variant folds away at compile time.  The TEST library libnele_hip_ab.so (same
+// sources and ABI, built with -DNELE_AB by the same Makefile) reads the environment once per process; the A/B tests under tests/ and
+// the scripts under tools/ load it through NELE_LIB.  Nothing in the product path reads the environment.
+#ifdef NELE_AB
+int nele_env_int(const char* name, int dflt);              // csrc/capi.hip: atoi(getenv(name)) or dflt
+#define NELE_SWITCH_INT(name, dflt) ([]() -> int { static const int v_ = nele_env_int(name, dflt); return v_; }())
+#define NELE_AB_ONLY(...) __VA_ARGS__                      // launches of superseded kernels (their definitions sit in #ifdef NELE_AB)
+#else
+#define NELE_SWITCH_INT(name, dflt) (dflt)
+#define NELE_AB_ONLY(...)
+#endif
+
 // csrc/capi.hip: true the first time it is called with this mask on the CURRENT device (one-time hipFuncSetAttribute blocks: a process
 // that switches devices must set the attribute on each of them)
 bool nele_first_use_on_device(unsigned long long* mask);
+#define NELE_ONCE_PER_DEVICE(body)                                   \
+    do {                                                             \
+        static unsigned long long once_mask_ = 0;                    \
+        if (nele_first_use_on_device(&once_mask_)) { body; }         \
+    } while (0)
 
 // csrc/capi.hip: HIP-event pair around one tagged launch when nele_profile_begin(tag) armed it (bench.py's roofline figures)
 bool nele_prof_match(const char* tag);

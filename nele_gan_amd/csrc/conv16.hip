@@ -385,13 +385,12 @@ struct C16Plan { int TN, TH, NR, RSP, lgC, swz_sh, swz_mask, sps; size_t lds; };
 static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
     if (N < 4 || N > 64 || (N & 3) || g.C < 8 || g.C > 64 || (g.C & 7) || KH < 2 || KW < 2 || KW > 9 || KH > 9) return false;
     if (g.seglen != KW * g.C || g.Ktot != KH * KW * g.C) return false;
-    if (getenv("NELE_CONV16") && atoi(getenv("NELE_CONV16")) == 0) return false;
     C16Plan q;
     q.TN = (N + 15) >> 4;
     q.sps = (g.seglen + 31) >> 5;
     const int nsteps = KH * q.sps;
     // tile rows: 8 where the layer is bound by memory (little work per staged byte) and the registers / LDS allow, else 4
-    const int th_env = getenv("NELE_CONV16_TH") ? atoi(getenv("NELE_CONV16_TH")) : 0;
+    const int th_env = NELE_SWITCH_INT("NELE_CONV16_TH", 0);
     int th = (nsteps * q.TN <= 64 && q.TN <= 2) ? 8 : 4;      // (TN >= 3 with 8 rows does not fit 256 registers)
     if (th_env == 4 || (th_env == 8 && q.TN <= 2)) th = th_env;
     q.TH = th;
@@ -452,10 +451,9 @@ extern "C" int nele_conv16_weight_prep_batch(const void* const* ptrs_host, const
 
 template <int TN, int TH, bool OUT16>
 static void c16_launch(const Conv16Args& a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;            // (per device: a process that switches devices sets the attribute on each)
+    if (nele_first_use_on_device(&attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_kernel<TN, TH, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((conv16_kernel<TN, TH, OUT16>), grid, dim3(256), lds, s, a);
 }

@@ -2135,13 +2135,12 @@ extern "C" int nele_conv_span(const float* A, const float* Wfrag, const float* b
     const size_t lds = ((size_t)GEMM_BM * p.g.C + (size_t)maxrun * (KW - 1) * p.g.C) * sizeof(float);
     const int gx = (M + GEMM_BM - 1) / GEMM_BM;
     hipStream_t s = as_stream(stream);
-    static bool attr_done = false;
-    if (!attr_done) {  // allow > 64 KB of dynamic LDS
+    static unsigned long long attr_done = 0;            // (per device: a process that switches devices sets the attribute on each)
+    if (nele_first_use_on_device(&attr_done)) {  // allow > 64 KB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
     }
     switch (p.NT) {
         case 1: hipLaunchKernelGGL(conv_span_kernel<1>, dim3(gx), dim3(256), lds, s, p); break;
@@ -2211,10 +2210,8 @@ static int conv1d16_sb(const ConvGeom& g, int N, int KH, int KW, size_t* lds_out
 // the metric streams' workgroups beside it, and at B = 256 the step is bound by the sum of all kernels, not by the convolutions.  (The
 // converse also holds: 4-row tiles make the kernel 17 % slower alone and the step 0.5 ms faster.)  Hence opt-in.
 static int tile16_th(const ConvGeom& g, int N, int KH, int KW) {
-    static int tall = -1;
-    if (tall < 0) { const char* e = getenv("NELE_CONV_TALL"); tall = (e && e[0] == '1'); }
-    static int force = -1;                                     // NELE_CONV_TH=4|8: force one tile height where it fits (A/B)
-    if (force < 0) { const char* e = getenv("NELE_CONV_TH"); force = e ? atoi(e) : 0; }
+    const int tall = NELE_SWITCH_INT("NELE_CONV_TALL", 0);
+    const int force = NELE_SWITCH_INT("NELE_CONV_TH", 0);                                     // NELE_CONV_TH=4|8: force one tile height where it fits (A/B)
     if (force == 4 || force == 8 || force == 10 || force == 11 || force == 13) {
         if ((force == 4 || g.Hout >= 8) && tile16_lds(g, N, KH, KW, force)) return force;
     }
@@ -2290,8 +2287,7 @@ static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* b
     NELE_CHECK_ARG(!(epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_BIAS_EXPTANH) || bias, "nele_conv_span_bf16: epilogue needs bias");
     NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux, "nele_conv_span_bf16: epilogue needs aux");
     hipStream_t s = as_stream(stream);
-    static int tile_on = -1;
-    if (tile_on < 0) { const char* e = getenv("NELE_CONV_TILE"); tile_on = !(e && e[0] == '0'); }
+    const int tile_on = NELE_SWITCH_INT("NELE_CONV_TILE", 1);
     const int th = (tile_on && p.g.Wout >= 32) ? tile16_th(p.g, N, KH, KW) : 0;
     {   // Conv1d / Linear geometry (KH = 1): strip kernel
         size_t clds = 0;
@@ -2301,17 +2297,15 @@ static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* b
             t.A = A; t.Wfrag = p.Wfrag; t.bias = bias; t.aux = aux; t.out = out; t.N = N; t.NT = p.NT; t.epi = epi; t.slope = slope;
             t.KH = KH; t.KW = KW; t.steps_per_seg = p.g.seglen / 32; t.g = p.g; t.SB = csb; t.dbg = nullptr;
             const int BH = M / p.g.Wout;
-            static bool cattr = false;
-            if (!cattr) {
+            static unsigned long long cattr = 0;            // (per device: a process that switches devices sets the attribute on each)
+            if (nele_first_use_on_device(&cattr)) {
 #define C1D_ATTR(TN_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_tile16_kernel<TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                 C1D_ATTR(1); C1D_ATTR(2); C1D_ATTR(3); C1D_ATTR(4);
 #undef C1D_ATTR
-                cattr = true;
             }
             const int nchunksN = (N > 64) ? N / 64 : 1, TNsel = (N >= 64) ? 4 : p.NT;
             const int nstrips = ((p.g.Wout + C1D_TW - 1) / C1D_TW) * BH;
-            static int walk_on = -1;                       // NELE_CONV1D_WALK=0: one workgroup per (strip, N chunk) at every batch (A/B)
-            if (walk_on < 0) { const char* e = getenv("NELE_CONV1D_WALK"); walk_on = !(e && e[0] == '0'); }
+            const int walk_on = NELE_SWITCH_INT("NELE_CONV1D_WALK", 1);                       // NELE_CONV1D_WALK=0: one workgroup per (strip, N chunk) at every batch (A/B)
             const size_t ep_bytes = 4 * 16 * 68 * 4;
             const bool walk = walk_on && nchunksN > 1 && nstrips >= 256 && clds + 4096 + ep_bytes <= 158 * 1024;
             t.ntiles = walk ? 1 : nchunksN; t.ncl = walk ? nchunksN : 1; t.SBH = BH;
@@ -2333,8 +2327,8 @@ static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* b
         t.KH = KH; t.KW = KW; t.steps_per_seg = p.steps_per_seg; t.g = p.g; t.SB = tile16_sb(p.g); t.dbg = nullptr;
         const int B_ = M / (p.g.Hout * p.g.Wout);
         const size_t lds = tile16_lds(p.g, N, KH, KW, th);
-        static bool tattr = false;
-        if (!tattr) {
+        static unsigned long long tattr = 0;            // (per device: a process that switches devices sets the attribute on each)
+        if (nele_first_use_on_device(&tattr)) {
 #define TILE16_ATTR(TN_, TH_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<TN_, TH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
             TILE16_ATTR(1, 8); TILE16_ATTR(2, 8); TILE16_ATTR(3, 8); TILE16_ATTR(4, 8);
             TILE16_ATTR(1, 4); TILE16_ATTR(2, 4); TILE16_ATTR(3, 4); TILE16_ATTR(4, 4);
@@ -2342,7 +2336,6 @@ static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* b
             TILE16_ATTR(1, 11); TILE16_ATTR(2, 11); TILE16_ATTR(3, 11); TILE16_ATTR(4, 11);
             TILE16_ATTR(1, 13); TILE16_ATTR(2, 13); TILE16_ATTR(3, 13); TILE16_ATTR(4, 13);
 #undef TILE16_ATTR
-            tattr = true;
         }
         t.ntiles = ((p.g.Wout + TILE16_TW - 1) / TILE16_TW) * ((p.g.Hout + th - 1) / th) * B_;
         const dim3 grid((unsigned)((t.ntiles + 7) / 8 * 8));      // a multiple of 8: every XCD gets the same number of ids
@@ -2364,13 +2357,12 @@ static int conv_span_bf16_impl(const float* A, const void* Wfrag, const float* b
     const int cp16 = p.g.C + SPAN16_PAD(p.g.C);
     const size_t lds = ((size_t)SPAN16_BM * cp16 + (size_t)maxrun * (KW - 1) * cp16 + 64) * 2;
     const int gx = ((M + SPAN16_BM - 1) / SPAN16_BM + 7) / 8 * 8;     // a multiple of 8: the same number of ids per XCD
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;            // (per device: a process that switches devices sets the attribute on each)
+    if (nele_first_use_on_device(&attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_span16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
     }
     switch (p.NT) {
         case 1: hipLaunchKernelGGL(conv_span16_kernel<1>, dim3(gx), dim3(256), lds, s, p); break;
@@ -2412,13 +2404,11 @@ extern "C" int nele_conv_wgrad_bf16(const float* A, const float* dOut, float* wo
     return conv_wgrad_impl(A, dOut, workspace, workspace_floats, M, N, geom, KH, KW, Cvalid, dW, db, accumulate, 1, stream);
 }
 static bool wgrad_dma_on() {                               // NELE_WGRAD_DMA=0: the one-kernel-row tile kernel for bf16 operands too (A/B diagnostic)
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NELE_WGRAD_DMA"); on = !(e && e[0] == '0'); }
+    const int on = NELE_SWITCH_INT("NELE_WGRAD_DMA", 1);
     return on != 0;
 }
 static bool wgrad_tile_eligible(int M, int N, const ConvGeom& g, int KH, int KW) {
-    static int wt_on = -1;
-    if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
+    const int wt_on = NELE_SWITCH_INT("NELE_WGRAD_TILE", 1);
     const int nkt = (g.seglen + 15) / 16;
     const long long wt_lds = ((long long)WT_TH * (WT_TW + KW - 1) * g.C + WT_SLACK + 256 * WT_NP_OF((N + 15) / 16)) * 2;
     return wt_on && N <= 64 && g.C % 8 == 0 && KW * g.C == g.seglen && nkt <= 28 && g.Wout >= 32 && wt_lds <= 76 * 1024 &&
@@ -2480,8 +2470,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
     hipStream_t s = as_stream(stream);
     // 2-D tile kernel (bf16): one kernel row per workgroup, accumulators in registers over all position tiles
-    static int wt_on = -1;
-    if (wt_on < 0) { const char* e = getenv("NELE_WGRAD_TILE"); wt_on = !(e && e[0] == '0'); }
+    const int wt_on = NELE_SWITCH_INT("NELE_WGRAD_TILE", 1);
     // Layers too wide for one workgroup's accumulators (N > 64 or more than 28 reduction tiles per kernel row: the generator's Conv1d
     // layers, 256 x 7 x 256) run on the same tile kernel as subs_n x subs_c sub-problems of 64 output x 64 input channels that share
     // every group's position tiles; a Conv1d batch is viewed as ONE image whose rows are the utterances (KH = 1: rows are independent),
@@ -2504,8 +2493,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     int G = (max_splits < 64) ? (max_splits > splits ? max_splits : splits) : 64;
     if (G < splits) G = splits;
     {   // experiment knob: fewer groups = fewer partials to reduce, but fewer workgroups to pull the memory system
-        static int genv = -1;
-        if (genv < 0) { const char* e = getenv("NELE_WGRAD_GROUPS"); genv = e ? atoi(e) : 0; }
+        const int genv = NELE_SWITCH_INT("NELE_WGRAD_GROUPS", 0);
         if (genv > 0 && genv < G) G = genv;
     }
     bool tiled = false;
@@ -2519,8 +2507,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
             if (KH % cand == 0 && NT_ * ((cand * nkt_ + 7) / 8) <= 44) { KR = cand; break; }
         const int NJ_ = KR ? (KR * nkt_ + 7) / 8 : 0;
         int TH_ = 0;
-        static int th_env = -1;                              // NELE_WGRAD_DMA_TH=2|3|4: cap on the tile height (A/B diagnostic)
-        if (th_env < 0) { const char* e = getenv("NELE_WGRAD_DMA_TH"); th_env = e ? atoi(e) : 4; }
+        const int th_env = NELE_SWITCH_INT("NELE_WGRAD_DMA_TH", 4);                              // NELE_WGRAD_DMA_TH=2|3|4: cap on the tile height (A/B diagnostic)
         for (int cand = th_env < 4 ? th_env : 4; cand >= 2 && KR; --cand) {
             const long long bufsz = (long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + WT_SLACK + (long long)cand * WD_TW * WT_NP_OF(NT_);
             const int npc = (int)(((long long)(cand + KR - 1) * (WD_TW + KW - 1) * gg.C + 511) / 512), ndp = cand * WD_TW * WT_NP_OF(NT_) / 512;
@@ -2592,12 +2579,11 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
                     const int by_regs = 512 / ((fa.numRegs + 7) & ~7);
                     if (by_regs >= 1 && by_regs < occ) occ = by_regs;
                 }
-                if (getenv("NELE_DEBUG_WGRAD")) fprintf(stderr, "wgrad tile <%d,%d>: occupancy %d (regs %d, lds %lld + %zu)\n", ni, ki, occ, fa.numRegs, wt_lds, fa.sharedSizeBytes);
+                if (NELE_SWITCH_INT("NELE_DEBUG_WGRAD", 0)) fprintf(stderr, "wgrad tile <%d,%d>: occupancy %d (regs %d, lds %lld + %zu)\n", ni, ki, occ, fa.numRegs, wt_lds, fa.sharedSizeBytes);
                 occ_tab[ni][ki] = occ;
             }
             const long long slots = (long long)ncu * occ_tab[ni][ki];
-            static int gauto = -1;                        // NELE_WGRAD_AUTOGROUPS=0: the fixed 64 groups (A/B diagnostic)
-            if (gauto < 0) { const char* e = getenv("NELE_WGRAD_AUTOGROUPS"); gauto = !(e && e[0] == '0'); }
+            const int gauto = NELE_SWITCH_INT("NELE_WGRAD_AUTOGROUPS", 1);                        // NELE_WGRAD_AUTOGROUPS=0: the fixed 64 groups (A/B diagnostic)
             if (gauto && G >= 16) {
                 long long best = -1;
                 int bestG = G;
@@ -2612,15 +2598,14 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
         t.G = G; t.g = gt;
         t.bpart = db ? workspace + (size_t)G * N * p.g.Ktot : nullptr;
         const dim3 grid(wg_per_group * G);
-        static bool wattr = false;
-        if (!wattr) {
+        static unsigned long long wattr = 0;            // (per device: a process that switches devices sets the attribute on each)
+        if (nele_first_use_on_device(&wattr)) {
 #define WT_ATTR(NT_, K_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tile16_kernel<NT_, K_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); } while (0)
             WT_ATTR(1, 2); WT_ATTR(2, 2); WT_ATTR(3, 2); WT_ATTR(4, 2); WT_ATTR(1, 4); WT_ATTR(2, 4); WT_ATTR(3, 4); WT_ATTR(4, 4);
             WT_ATTR(1, 7); WT_ATTR(2, 7); WT_ATTR(3, 7); WT_ATTR(4, 7);
 #undef WT_ATTR
-            wattr = true;
         }
 #define WT_LAUNCH(NT_, K_) do { if (a16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true, true>), grid, dim3(256), (size_t)wt_lds, s, t); \
                                 else if (d16) hipLaunchKernelGGL((conv_wgrad_tile16_kernel<NT_, K_, true>), grid, dim3(256), (size_t)wt_lds, s, t); \

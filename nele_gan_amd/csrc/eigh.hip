@@ -910,6 +910,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
 // step loop below those are the reflector row and d / e / tau, which nothing in the kernel reads back - waiting for their
 // acknowledgement at every barrier is a store round trip per step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
     extern __shared__ double et_sm[];                    // Am[m][m]
     __shared__ double vs[ET_M], wv[ET_M], vn[ET_M], part[8][ET_M];
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
     if (tid == 0 && b == 0) for (int j = 0; j < 9; ++j) ws.lamp[j] = (double)tacc[j];
 #endif
 }
+#endif  // NELE_AB
 
 // ------------------------------------------------------------------------------------------ e1, middle + tail in registers
 // The last EM_M = 224 steps in ONE workgroup per matrix with the trailing block in REGISTERS (a thread holds 7 columns x 14 rows): no
@@ -1045,6 +1047,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_tail_kernel(double* __restri
 #define EM_RI 14
 #define EM_NC 7
 #define EM_M (16 * EM_RI)
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
     __shared__ __attribute__((aligned(16))) double vperm[3][EM_M + 64];   // v, w, v_next at [(r & 15) * (EM_RI) + (r >> 4)]
     __shared__ double vnat[EM_M], wnat[EM_M];
@@ -1190,6 +1193,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restric
         // the next iteration's first barrier orders these reads against its LDS writes
     }
 }
+#endif  // NELE_AB
 
 // The same with up to EX_E = 32 more rows / columns: the trailing block's FIRST E = m - 224 rows (the ones eliminated first) sit in an LDS
 // strip S[E][256] (full rows: the E x E corner is stored twice, the off-diagonal block once), the other 224 x 224 in registers as above.
@@ -1746,6 +1750,7 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
 // is one barrier per 8 reflectors.  The result is written as U[j][i] (row j = eigenvector j), the layout the SIIB
 // projection reads.
 #define BT_CH 8
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 template <int BT_Q>     // 16-row groups held per lane: 28 covers n <= 448 (SIIB: 420), 32 covers EG_MAXN
 __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double* __restrict__ Aall, int n, EighWs ws, double* __restrict__ U) {
     // reflector chunk in LDS, PERMUTED: element i of reflector r at r * RS + (i & 15) * BT_Q + (i >> 4), so the BT_Q values a lane needs
@@ -1838,6 +1843,7 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
         if (i < n && j0 + 1 < n) Ub[(size_t)(j0 + 1) * n + i] = z1[q];
     }
 }
+#endif  // NELE_AB
 
 // ------------------------------------------------------------------------------------------ e4, blocked (compact WY) on the matrix cores
 // The reflector-by-reflector kernel above is bound by LDS instruction issue (2 x BT_Q reads per reflector and wave for 4 x BT_Q FMAs):
@@ -2061,52 +2067,37 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     static int cluster_cap = -1;                           // matrices per cluster launch (multiple of 8), 0 = unavailable
     if (cluster_cap < 0) {
         int dev = 0, ncu = 0, occ = 0;
-        const char* env = getenv("NELE_EIGH_CLUSTER");
-        if (env && env[0] == '0') cluster_cap = 0;
+        if (!NELE_SWITCH_INT("NELE_EIGH_CLUSTER", 1)) cluster_cap = 0;
         else if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(eigh_tridiag_cluster_kernel), 512, 0) == hipSuccess)
             cluster_cap = ((long long)ncu * (occ > 0 ? 1 : 0) / (8 * EC_P)) * 8;   // one workgroup per CU: never rely on sharing a CU
         else cluster_cap = 0;
         if (cluster_cap > 32) cluster_cap = 32;
-        const char* capenv = getenv("NELE_EIGH_CLUSTER_CAP");    // matrices per launch (multiple of 8): fewer leaves CUs to other streams
-        if (capenv && atoi(capenv) >= 8 && atoi(capenv) < cluster_cap) cluster_cap = atoi(capenv) / 8 * 8;
+        const int capenv = NELE_SWITCH_INT("NELE_EIGH_CLUSTER_CAP", 0);    // matrices per launch (multiple of 8): fewer leaves CUs to other streams
+        if (capenv >= 8 && capenv < cluster_cap) cluster_cap = capenv / 8 * 8;
     }
     if (cluster_cap >= 8) {
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         if (hipMemsetAsync(ws.flag, 0, sizeof(int) * ((size_t)B + 1), s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
         // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
-        static int p4_on = -1;
-        if (p4_on < 0) { const char* e = getenv("NELE_EIGH_P4"); p4_on = !(e && e[0] == '0'); }
+        const int p4_on = NELE_SWITCH_INT("NELE_EIGH_P4", 1);
         if (p4_on && n <= 16 * E4_RI && cluster_cap >= 32) {
             // four workgroups per matrix: 64 matrices per launch would fill the chip; 32 use half of it.  The last ET_M steps run in
             // eigh_tridiag_tail_kernel (one workgroup per matrix, block in LDS): s_stop = last iteration of the cluster kernel
-            static int tail_on = -1;
-            if (tail_on < 0) {
-                const char* e_ = getenv("NELE_EIGH_TAIL");
-                tail_on = !(e_ && e_[0] == '0');
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(sizeof(double) * ET_M * ET_M));
-            }
-            static int mid_on = -1;                        // NELE_EIGH_MID=0: hand over to the LDS tail kernel at 128 instead (A/B diagnostic)
-            if (mid_on < 0) { const char* e_ = getenv("NELE_EIGH_MID"); mid_on = !(e_ && e_[0] == '0'); }
-            static int midx_on = -1;                       // NELE_EIGH_MIDX=0: hand over at 224 (registers only) instead of 256 (registers + LDS strip)
-            if (midx_on < 0) {
-                const char* e_ = getenv("NELE_EIGH_MIDX");
-                midx_on = !(e_ && e_[0] == '0');
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
-            }
+            const int tail_on = NELE_SWITCH_INT("NELE_EIGH_TAIL", 1);
+            NELE_AB_ONLY(NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                        (int)(sizeof(double) * ET_M * ET_M)));)
+            const int mid_on = NELE_SWITCH_INT("NELE_EIGH_MID", 1);                        // NELE_EIGH_MID=0: hand over to the LDS tail kernel at 128 instead (A/B diagnostic)
+            const int midx_on = NELE_SWITCH_INT("NELE_EIGH_MIDX", 1);   // =0: hand over at 224 (registers only) instead of 256 (registers + LDS strip)
+            NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
             const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
             // second cluster stage (round 4): once 320 rows are left, two workgroups per matrix hold the block - twice the matrices per launch
             // for the steps from 320 down to the single-workgroup hand-over (NELE_EIGH_C2=0: the four-workgroup kernel runs them all)
-            static int c2_on = -1;
-            if (c2_on < 0) {
-                const char* e_ = getenv("NELE_EIGH_C2");
-                c2_on = !(e_ && e_[0] == '0');
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_cluster2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(sizeof(double) * EC2_RI * 16 * 32));
-            }
+            const int c2_on = NELE_SWITCH_INT("NELE_EIGH_C2", 1);
+            NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_cluster2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)(sizeof(double) * EC2_RI * 16 * 32)));
             const bool two_stage = c2_on && s_stop >= 0 && mhand < EC2_M && n > EC2_M + 8;
             const int s_stop1 = two_stage ? n - EC2_M - 2 : s_stop;
             // NELE_EIGH_P4_BATCH: matrices per launch (32 = half of the chip inside a training step, 64 = all of it otherwise).  The spinning workgroups own
@@ -2117,12 +2108,11 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             // The caller says which: SIIB's clean-signal phase inside a training step (nele_metric_siib phase 3, which runs beside the
             // G-step) asks for 32 through nele_eigh_sym_batched_ex's argument; a stand-alone call (one-shot SIIB, nele_eigh_sym_batched by
             // itself) has nothing to share the chip with and takes 64 - one SIIB call at B = 256 is 17 ms that way and 21.5 ms with 32.
-            static int p4_env = -1;
-            if (p4_env < 0) { const char* e_ = getenv("NELE_EIGH_P4_BATCH"); p4_env = (e_ && atoi(e_) >= 8 && atoi(e_) <= 64) ? atoi(e_) / 8 * 8 : 0; }
+            const int p4_raw = NELE_SWITCH_INT("NELE_EIGH_P4_BATCH", 0);
+            const int p4_env = (p4_raw >= 8 && p4_raw <= 64) ? p4_raw / 8 * 8 : 0;
             const int hint = cluster_batch;
             const int p4_batch = p4_env ? p4_env : (hint >= 8 && hint <= 64 ? hint / 8 * 8 : 64);
-            static int fail_every = -1;                     // NELE_EIGH_FAIL_EVERY=k (tests): every k-th matrix takes the give-up / repair path
-            if (fail_every < 0) { const char* e_ = getenv("NELE_EIGH_FAIL_EVERY"); fail_every = e_ ? atoi(e_) : 0; }
+            const int fail_every = NELE_SWITCH_INT("NELE_EIGH_FAIL_EVERY", 0);                     // NELE_EIGH_FAIL_EVERY=k (tests): every k-th matrix takes the give-up / repair path
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 NELE_PROF("eigh_tridiag_cluster", s,
@@ -2140,12 +2130,11 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);
                 if (mhand == EM_M + EX_E) hipLaunchKernelGGL(eigh_tridiag_midx_kernel, dim3(B), dim3(512), sizeof(double) * EX_E * EX_LD, s, A, n, ws, s_stop + 1);
-                else if (mhand == EM_M) hipLaunchKernelGGL(eigh_tridiag_mid_kernel, dim3(B), dim3(512), 0, s, A, n, ws, s_stop + 1);
-                else hipLaunchKernelGGL(eigh_tridiag_tail_kernel, dim3(B), dim3(512), sizeof(double) * (size_t)mt * mt, s, A, n, ws, s_stop + 1);
+                NELE_AB_ONLY(else if (mhand == EM_M) hipLaunchKernelGGL(eigh_tridiag_mid_kernel, dim3(B), dim3(512), 0, s, A, n, ws, s_stop + 1);
+                             else hipLaunchKernelGGL(eigh_tridiag_tail_kernel, dim3(B), dim3(512), sizeof(double) * (size_t)mt * mt, s, A, n, ws, s_stop + 1);)
             }
         } else {
-        static int split_small = -1;
-        if (split_small < 0) { const char* e = getenv("NELE_EIGH_SPLIT"); split_small = !(e && e[0] == '0'); }
+        const int split_small = NELE_SWITCH_INT("NELE_EIGH_SPLIT", 1);
         const int per = (split_small && B <= 32 && cluster_cap >= 32) ? 16 : cluster_cap;
         for (int b0 = 0; b0 < B; b0 += per) {
             const int Bc = (B - b0 < per) ? B - b0 : per;
@@ -2158,33 +2147,27 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }
     hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 256 / EG_NL - 1) / (256 / EG_NL), B), dim3(256), 0, s, n, ws, lam);
-    static int iv_extra = -1;
     // sweeps after the growth criterion is met: LAPACK's dstein uses EXTRA = 2 and documents "should be at least 1"; with the eigenvalues
     // bisected to 1 ulp one is enough for every test matrix (eigenvalues 1e-13, residual 1e-11, orthogonality 1e-8, SIIB unchanged to 17
     // digits) and saves a quarter of this kernel's HBM traffic (its work arrays: 108 KB per eigenvector); 0 fails the residual test
-    if (iv_extra < 0) { const char* e_ = getenv("NELE_EIGH_INVIT_EXTRA"); iv_extra = e_ ? atoi(e_) : 1; }
+    const int iv_extra = NELE_SWITCH_INT("NELE_EIGH_INVIT_EXTRA", 1);
     hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);
     const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * 16 * (n <= 448 ? 28 : 32) + 2 * BT_CH);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-        attr_done = true;
-    }
-    static int wy_on = -1;                                  // NELE_EIGH_WY=0: the reflector-by-reflector back-transformation (A/B diagnostic)
-    if (wy_on < 0) {
-        const char* e_ = getenv("NELE_EIGH_WY");
-        wy_on = !(e_ && e_[0] == '0');
+    const int wy_on = NELE_SWITCH_INT("NELE_EIGH_WY", 1);   // =0: the reflector-by-reflector back-transformation (A/B diagnostic)
+    NELE_ONCE_PER_DEVICE({
+        NELE_AB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_wy_kernel<27>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_backtransform_wy_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    }
+    });
     if (wy_on) {
         const int nblk = (n - 1 + WY_NB - 1) / WY_NB;
         hipLaunchKernelGGL(eigh_wy_t_kernel, dim3(nblk, B), dim3(256), 0, s, A, n, ws);
         if (n <= 432) hipLaunchKernelGGL(eigh_backtransform_wy_kernel<27>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 432 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
         else hipLaunchKernelGGL(eigh_backtransform_wy_kernel<32>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 512 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
-    } else if (n <= 448) hipLaunchKernelGGL(eigh_backtransform_kernel<28>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
-    else hipLaunchKernelGGL(eigh_backtransform_kernel<32>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
+    }
+    NELE_AB_ONLY(else if (n <= 448) hipLaunchKernelGGL(eigh_backtransform_kernel<28>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);
+                 else hipLaunchKernelGGL(eigh_backtransform_kernel<32>, dim3((n + 31) / 32, B), dim3(256), lds, s, A, n, ws, U);)
     NELE_CHECK_LAUNCH("nele_eigh_sym_batched");
     return NELE_OK;
 }

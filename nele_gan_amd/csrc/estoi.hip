@@ -87,6 +87,7 @@ __global__ void estoi_filter_kernel(double* __restrict__ h) {
 // conflicts: 1.2 ms per call at B = 256).  The input samples a block needs are staged in LDS too.
 #define ES_NPH ((2 * ES_HALF + 1 + 4) / 5)            // taps per phase (117)
 #define ES_XIN ((256 * 8 + 2 * ES_HALF) / 5 + 4)     // input samples under 256 consecutive outputs
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void estoi_resample_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const double* __restrict__ h, int L, EstoiWs ws) {
     __shared__ double hp[5][ES_NPH + 1];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void estoi_resample_kernel(const float* __rest
     for (int n = n_lo; n <= n_hi; ++n) acc += (double)xs[n - nb0] * hp[p][mtop - n];
     ws.xr[((size_t)b * 2 + sig) * ws.n10 + i] = acc;
 }
+#endif  // NELE_AB
 
 // ---- the same resampler, a thread per group of FIVE consecutive outputs (second session of round 3).  The kernel above pays two LDS reads
 // and a conversion per tap and is bound by the LDS pipe.  Outputs i = 5 g + r (r = 0..4) have the phases p = (8 i + 290) mod 5 = {0, 3, 1, 4, 2}
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void estoi_vad_kernel(EstoiWs ws) {
 }
 
 // grid (F, B), block 256: kept frame k of the silence-removed signals
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void estoi_tob_kernel(EstoiWs ws) {
     __shared__ Fft512Lds s;
     __shared__ double p2[2][NELE_NBINS];
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(256) void estoi_tob_kernel(EstoiWs ws) {
         ws.tob[(((size_t)b * 2 + sig) * ES_NB + band) * ws.F + k] = sqrt(a);
     }
 }
+#endif  // NELE_AB
 
 // The same, one WAVE per kept frame with the transform in registers (fft512_wave, third session of round 3; NELE_ESTOI_TOBW=0 = the
 // kernel above): twiddles and the window once per workgroup of 4 x ETW_NP frames, no workgroup barrier per frame; only the bins of the
@@ -474,19 +478,17 @@ extern "C" int nele_metric_estoi_var(const float* x, const float* y, const int* 
     ws.dseg = (double*)p;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(estoi_filter_kernel, dim3(1), dim3(1024), 0, s, h);
-    static int rs5 = -1;                                   // NELE_ESTOI_RS5=0: the output-per-thread resampler (A/B diagnostic)
-    if (rs5 < 0) { const char* e_ = getenv("NELE_ESTOI_RS5"); rs5 = !(e_ && e_[0] == '0'); }
+    const int rs5 = NELE_SWITCH_INT("NELE_ESTOI_RS5", 1);                                   // NELE_ESTOI_RS5=0: the output-per-thread resampler (A/B diagnostic)
     if (rs5) {
         hipLaunchKernelGGL(estoi_taps_kernel, dim3(1), dim3(256), 0, s, h);
         hipLaunchKernelGGL(estoi_resample5_kernel, dim3((n10 + 1279) / 1280, B, 2), dim3(256), 0, s, x, y, h + ES_HPAD, L, ws);
     } else {
-        hipLaunchKernelGGL(estoi_resample_kernel, dim3((n10 + 255) / 256, B, 2), dim3(256), 0, s, x, y, h, L, ws);
+        NELE_AB_ONLY(hipLaunchKernelGGL(estoi_resample_kernel, dim3((n10 + 255) / 256, B, 2), dim3(256), 0, s, x, y, h, L, ws);)
     }
     hipLaunchKernelGGL(estoi_vad_kernel, dim3(B), dim3(256), 0, s, ws);
-    static int tobw = -1;                                  // NELE_ESTOI_TOBW=0: the workgroup-per-frame kernel (A/B diagnostic)
-    if (tobw < 0) { const char* e_ = getenv("NELE_ESTOI_TOBW"); tobw = !(e_ && e_[0] == '0'); }
+    const int tobw = NELE_SWITCH_INT("NELE_ESTOI_TOBW", 1);                                  // NELE_ESTOI_TOBW=0: the workgroup-per-frame kernel (A/B diagnostic)
     if (tobw) hipLaunchKernelGGL(estoi_tob_wave_kernel, dim3((F + 4 * ETW_NP - 1) / (4 * ETW_NP), B), dim3(256), 0, s, ws);
-    else hipLaunchKernelGGL(estoi_tob_kernel, dim3(F, B), dim3(256), 0, s, ws);
+    else { NELE_AB_ONLY(hipLaunchKernelGGL(estoi_tob_kernel, dim3(F, B), dim3(256), 0, s, ws);) }
     hipLaunchKernelGGL(estoi_seg_kernel, dim3(F, B), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(estoi_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, raw, mapped, B);
     NELE_CHECK_LAUNCH("nele_metric_estoi");

@@ -85,6 +85,7 @@ __device__ __forceinline__ double hann512(int n) { return 0.5 - 0.5 * cospi((dou
 // grid (ceil(T/2), B), block 256.  Frames 2p and 2p+1 share one complex FFT.
 // lens (may be NULL): samples of each utterance inside the padded [B][L] buffer (the reference handles files of any length one at a
 // time, dataloader.py:30-42); frames at or behind a short row's own count T_b = 1 + L_b / 256 are written as zeros.
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict__ wav, int L, int T, float power,
                                                         float2* __restrict__ spec, float* __restrict__ band, const int* __restrict__ lens) {
     __shared__ Fft512Lds s;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
         }
     }
 }
+#endif  // NELE_AB
 
 // ---- the same STFT, one WAVE per frame pair with the transform in registers (fft512_wave: two LDS exchanges instead of nine workgroup
 // barriers; same butterflies, same twiddles, same window values: bit-identical spectra and band features, tests/test_features_gpu.py).
@@ -438,6 +440,7 @@ __device__ __forceinline__ double band_gain_sqrt_at(const float* __restrict__ a2
     return sqrt((double)g);
 }
 
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
                                                          int T, float* __restrict__ wav, const int* __restrict__ tlens) {
     __shared__ Fft512Lds s;
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict
         wav[(size_t)b * (NELE_HOP * (T - 1)) + (size_t)NELE_HOP * fa + n] = y / wss;
     }
 }
+#endif  // NELE_AB
 
 // ---- the same resynthesis, one WAVE per output hop with the inverse transform in registers (fft512_wave<true>): the lane that holds
 // X[64 m + lane] holds both halves it needs (frame fa's second half in v[m + 4].x, frame fb's first half in v[m].y), so nothing is
@@ -581,14 +585,13 @@ extern "C" int nele_stft_band_var(const float* wav, const int* lengths, int B, i
     NELE_CHECK_ARG(L > NELE_HOP, "nele_stft_band: L=%d must exceed 256 (reflect padding)", L);
     NELE_CHECK_ARG(spec || band, "nele_stft_band: no output requested");
     const int T = 1 + L / NELE_HOP;
-    static int wave_on = -1;                                // NELE_STFT_WAVE=0: the workgroup-per-frame-pair kernels (A/B diagnostic)
-    if (wave_on < 0) { const char* e_ = getenv("NELE_STFT_WAVE"); wave_on = !(e_ && e_[0] == '0'); }
+    const int wave_on = NELE_SWITCH_INT("NELE_STFT_WAVE", 1);                                // NELE_STFT_WAVE=0: the workgroup-per-frame-pair kernels (A/B diagnostic)
     if (wave_on) {
         dim3 grid(((T + 1) / 2 + 4 * STW_NP - 1) / (4 * STW_NP), B);
         hipLaunchKernelGGL(stft_band_wave_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
     } else {
-        dim3 grid((T + 1) / 2, B);
-        hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
+        NELE_AB_ONLY(dim3 grid((T + 1) / 2, B);
+                     hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);)
     }
     NELE_CHECK_LAUNCH("nele_stft_band");
     return NELE_OK;
@@ -670,13 +673,13 @@ extern "C" int nele_interp_band_gain(const float* bandE, int N, double* g, void*
 extern "C" int nele_gain_istft_var(const float* alpha2, const void* spec, const int* frames, int B, int T, float* wav, void* stream) {
     NELE_CHECK_ARG(spec && wav && B > 0, "nele_gain_istft: bad arguments");
     NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
-    static int wave_on = -1;                                // NELE_STFT_WAVE=0: the workgroup-per-hop kernel (A/B diagnostic)
-    if (wave_on < 0) { const char* e_ = getenv("NELE_STFT_WAVE"); wave_on = !(e_ && e_[0] == '0'); }
+    const int wave_on = NELE_SWITCH_INT("NELE_STFT_WAVE", 1);                                // NELE_STFT_WAVE=0: the workgroup-per-hop kernel (A/B diagnostic)
     if (wave_on)
         hipLaunchKernelGGL(gain_istft_wave_kernel, dim3((T - 1 + 4 * STW_NP - 1) / (4 * STW_NP), B), dim3(256), 0, as_stream(stream), alpha2,
                            (const float2*)spec, T, wav, frames);
-    else
-        hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);
+    else {
+        NELE_AB_ONLY(hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);)
+    }
     NELE_CHECK_LAUNCH("nele_gain_istft");
     return NELE_OK;
 }

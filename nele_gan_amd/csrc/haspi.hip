@@ -450,6 +450,7 @@ __global__ void haspi_resample_gain_kernel(HaspiWs ws, int sig0, int nsig) {
 // All serial kernels below move samples in register chunks of HP_CH: the loads of a chunk are issued back to back (one
 // memory latency per chunk instead of one per sample), then the recurrence runs out of registers.
 #define HP_CH 32
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws, int sig0, int nsig) {
     const int b = blockIdx.x, sig = sig0 + threadIdx.x;
     if ((int)threadIdx.x >= nsig) return;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(64) void haspi_midear_kernel(HaspiWs ws, int sig0, 
         for (int u = 0; u < HP_CH; ++u) dst[n0 + u] = yo[u];
     }
 }
+#endif  // NELE_AB
 
 // The same filter, parallel over chunks: the slowest pole of the cascade has modulus 0.937 (high-pass section) and 0.937^1024 = 2e-29,
 // so a thread that starts 1024 samples before its 2048-sample chunk from a zero state reproduces the serial filter to well below the
@@ -999,6 +1001,7 @@ __global__ void haspi_bw_kernel(HaspiWs ws, int sig0, int nsig) {
 }
 
 // ---- h3: control bank + bandwidth adjustment. grid (2, B), block 64
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws, int sig0) {
     const int b = blockIdx.y, sig = sig0 + blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch), bw1 = hp_bw1(ch);
@@ -1018,8 +1021,10 @@ __global__ __launch_bounds__(64) void haspi_control_kernel(HaspiWs ws, int sig0)
         ws.bw[((size_t)b * 2 + sig) * HP_NCH + ch] = BW;
     }
 }
+#endif  // NELE_AB
 
 // ---- h4: signal bank. grid (2, B), block 64
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws, int sig0) {
     const int b = blockIdx.y, sig = sig0 + blockIdx.x, lane = threadIdx.x, part = lane >> 5, ch = lane & 31;
     const double cf = hp_cfreq(ch);
@@ -1028,8 +1033,10 @@ __global__ __launch_bounds__(64) void haspi_signal_kernel(HaspiWs ws, int sig0) 
     hp_env_t* out = ws.env + (((size_t)b * 2 + sig) * ws.n24p) * HP_NCH + ch;
     (void)hp_gammatone_wave(xin, hp_n24(ws, b), hp_gt(BW, cf), cf, part, out);
 }
+#endif  // NELE_AB
 
 // ---- h5: compression gain from the control envelope (pyhaspi2.py:982-991), point-wise, in place on ctl
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ void haspi_gain_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) {
     // the grid stride is a multiple of 32, so a thread stays on one channel: its control-filter gain is computed once
     const int ch = (int)(threadIdx.x & 31);
@@ -1045,8 +1052,10 @@ __global__ void haspi_gain_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig
         ws.ctl[i] = (hp_env_t)exp(g * (2.302585092994046 / 20.0));   // 10^(g/20)
     }
 }
+#endif  // NELE_AB
 
 // ---- h6: gain low-pass lfilter([b,b],[1,a]) (pyhaspi2.py:992-995), serial, in place on ctl (one stream per lane). grid B, block 64
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws, int sig0, int nsig, int nrows) {
     const int lane = threadIdx.x, idx = 2 * blockIdx.x + (lane >> 5);
     if (idx >= nrows) return;
@@ -1067,9 +1076,11 @@ __global__ __launch_bounds__(64) void haspi_gainlp_kernel(HaspiWs ws, int sig0, 
         for (int u = 0; u < HP_CH; ++u) g[(size_t)(n0 + u) * HP_NCH] = (hp_env_t)gx[u];
     }
 }
+#endif  // NELE_AB
 
 // ---- h7: compressed envelope = filtered gain * envelope (pyhaspi2.py:997) and eb_EnvSL2 (pyhaspi2.py:1080-1088), point-wise
 // grid (blocks, 2 B): blockIdx.y = (utterance, signal), whose adjusted bandwidth fixes the signal filter's gain per channel
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) {
     const int ch = (int)(threadIdx.x & 31), row = hp_row(blockIdx.y, sig0, nsig);
     const double sgain = hp_gt(ws.bw[(size_t)row * HP_NCH + ch], hp_cfreq(ch)).gain;
@@ -1082,6 +1093,7 @@ __global__ void haspi_sl_kernel(HaspiWs ws, size_t per_row, int sig0, int nsig) 
         ws.env[i] = (hp_env_t)(y < 0.0 ? 0.0 : y);
     }
 }
+#endif  // NELE_AB
 
 // ---- h5-h7 fused: compression gain (point-wise) -> gain low-pass lfilter([b,b],[1,a]) -> compressed envelope in dB SL, one pass.
 // The three separate kernels moved 12.6 GB arrays (B = 256) through HBM seven times for 22 ms.  The low-pass is a first-order
@@ -1191,6 +1203,7 @@ __global__ __launch_bounds__(32) void haspi_ihc_prefix_kernel(HaspiWs ws, int si
 // cache lines per load instruction, 4.2 ms per call at B = 256.
 // grid (ceil(chunks / 4), rows), block 128 = 4 chunks x 32 channels.
 #define IF_L 51
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0, int nsig) {
     __shared__ float ring[64][128];
     const int tid = threadIdx.x, ch = tid & 31, row = hp_row(blockIdx.y, sig0, nsig), b = row >> 1;
@@ -1278,6 +1291,7 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir_kernel(HaspiWs ws, int sig0
         if (yi >= 0 && yi < nsub) lp[(size_t)yi * HP_NCH] = yv;
     }
 }
+#endif  // NELE_AB
 
 // The same pass in groups of NINE samples.  Outputs are 9 samples apart, so with groups that start on multiples of 9 a lane's output
 // always falls on the SAME sample u_lane = (26 - shift) mod 9 of a group: the phase counters, bounds tests and output selects of the
@@ -1375,6 +1389,7 @@ __global__ __launch_bounds__(128) void haspi_ihc_fir9_kernel(HaspiWs ws, int sig
 }
 
 // ---- h8: eb_IHCadapt (pyhaspi2.py:1028-1078), serial, in place on env. grid B, block 64
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int nsig, int nrows) {
     const int lane = threadIdx.x, idx = 2 * blockIdx.x + (lane >> 5);
     if (idx >= nrows) return;
@@ -1397,6 +1412,7 @@ __global__ __launch_bounds__(64) void haspi_ihc_kernel(HaspiWs ws, int sig0, int
         for (int u = 0; u < HP_CH; ++u) e[(size_t)(n0 + u) * HP_NCH] = (hp_env_t)ex[u];
     }
 }
+#endif  // NELE_AB
 
 // ---- h9a: group-delay shifts from BWx (pyhaspi2.py:1098-1131; both envelopes use BWx, :1239-1240). grid B, block 64
 __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
@@ -1429,6 +1445,7 @@ __global__ __launch_bounds__(64) void haspi_shift_kernel(HaspiWs ws) {
 // applied while loading) are staged in LDS once; thread = (sub-frame, channel).
 #define EF_SUB 16
 #define EF_SPAN (EF_SUB * HP_SPACE + HP_NFILT)
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0) {
     __shared__ double xs[EF_SPAN][HP_NCH + 1];
     const int b = blockIdx.y, sig = sig0 + blockIdx.z, tid = threadIdx.x, ch = tid & 31;
@@ -1467,6 +1484,7 @@ __global__ __launch_bounds__(256) void haspi_envfilt_kernel(HaspiWs ws, int sig0
         ws.lp[(((size_t)b * 2 + sig) * ws.nlp + i) * HP_NCH + ch] = acc;
     }
 }
+#endif  // NELE_AB
 
 // ---- h10: ebm_CepCoef (pyhaspi2.py:342-375), parallel over sub-sampled frames (one block per utterance walking 10 667 frames - 32
 // float64 pow() each for the silence gate - took 0.75 ms alone and 4.8 ms beside the convolutions):
@@ -1482,6 +1500,7 @@ __device__ __forceinline__ void hp_stage_lp(const HaspiWs& ws, int b, const doub
     const int di = hp_lp_di(ws, b, threadIdx.x & 31);      // (CP_F is a multiple of 32: a thread keeps its channel)
     for (int e = threadIdx.x; e < CP_F * HP_NCH; e += CP_F) tile[e >> 5][e & 31] = ((e >> 5) < nfr) ? hp_lp_at(lp, i0 + (e >> 5), e & 31, di) : 0.0;
 }
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
     __shared__ double tile[CP_F][HP_NCH + 1];
     __shared__ int scan[CP_F];
@@ -1508,7 +1527,9 @@ __global__ __launch_bounds__(CP_F) void haspi_gate_kernel(HaspiWs ws) {
     if (i < ws.nsub) ws.grank[(size_t)b * ws.nsub + i] = k ? scan[tid] - 1 : -1;
     if (tid == CP_F - 1) ws.gcnt[(size_t)b * ws.ngb + blockIdx.x] = scan[CP_F - 1];
 }
+#endif  // NELE_AB
 // grid B, block 64 (one lane works: at most a few dozen blocks)
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ void haspi_gate_scan_kernel(HaspiWs ws) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
@@ -1519,7 +1540,9 @@ __global__ void haspi_gate_scan_kernel(HaspiWs ws) {
     ws.info[2 * b] = tot;
     ws.info[2 * b + 1] = (tot <= 1) ? 1 : 0;
 }
+#endif  // NELE_AB
 // grid (blocks of CP_F frames, B, nsig), block CP_F
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const double* __restrict__ dither, double thr_nerve, int sig0) {
     __shared__ double tile[CP_F][HP_NCH + 1];
     __shared__ double cepm[HP_NCH][HP_NBASIS];
@@ -1563,7 +1586,9 @@ __global__ __launch_bounds__(CP_F) void haspi_cepstra_kernel(HaspiWs ws, const d
         ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + blockIdx.x) * HP_NBASIS + tid] = t;
     }
 }
+#endif  // NELE_AB
 // grid (B, nsig), block 64
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
     const int b = blockIdx.x, sig = sig0 + blockIdx.y, q = threadIdx.x;
     if (q >= HP_NBASIS || ws.info[2 * b + 1]) return;
@@ -1572,6 +1597,7 @@ __global__ void haspi_cepmean_kernel(HaspiWs ws, int sig0) {
     for (int g = 0; g < nb; ++g) t += ws.cpsum[((((size_t)b * 2 + sig) * ws.ngb) + g) * HP_NBASIS + q];
     ws.cmean[((size_t)b * 2 + sig) * HP_NBASIS + q] = t / (double)ws.info[2 * b];
 }
+#endif  // NELE_AB
 
 // ---- h10, one block per utterance (round-2 start; kept behind NELE_HASPI_CEP_SERIAL=1): it takes 0.75 ms alone against 0.15 ms for the
 // parallel kernels above, and 4.8 ms inside a step - but see the note at its launch site.
@@ -1710,6 +1736,7 @@ __constant__ int c_modnfir[HP_NMOD] = {614, 614, 614, 384, 244, 152, 96, 60, 38,
 // SIG = 1 (degraded part): filter the processed signal's sequence and correlate it with the stored xf (ebm_ModCorr).
 // Each pass stages (v cos, v sin) of ONE signal: half of the LDS and of the per-tap work of a joint pass; the reference half runs
 // before the enhanced signal exists (GanTrainer overlaps it with the G-step).
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 template <int SIG>
 __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
     __shared__ __attribute__((aligned(16))) double2 sq[4 * MF_L4];   // (v cos, v sin) of one sequence element: one 16-byte read per tap
@@ -1794,6 +1821,7 @@ __global__ __launch_bounds__(256) void haspi_mod_direct_kernel(HaspiWs ws) {
         ws.cm[((size_t)b * HP_NBASIS + basis) * HP_NMOD + k] = cm;
     }
 }
+#endif  // NELE_AB
 
 // ---- h11, sliding form (the default).  The modulation filters are Hann windows, b[i] = (0.5 - 0.5 cos(2 pi i / L)) / (L / 2),
 // i = 0..L (L = nfir; both end taps are zero), so the FIR is a combination of three sliding sums over exactly one period L:
@@ -2040,7 +2068,7 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
     TAKE(bw, double, (size_t)B * 2 * HP_NCH);
     TAKE(loss, double, 2 * 5 * HP_NCH);
     int lc = GS_LC;
-    { static int lcenv = -1; if (lcenv < 0) { const char* e_ = getenv("NELE_HASPI_LC"); lcenv = e_ ? atoi(e_) : 0; } if (lcenv >= GS_LC) lc = lcenv / GS_LC * GS_LC; }
+    { const int lcenv = NELE_SWITCH_INT("NELE_HASPI_LC", 0); if (lcenv >= GS_LC) lc = lcenv / GS_LC * GS_LC; }
     while ((n24p + lc - 1) / lc > GS_MAXC) lc += GS_LC;
     const int nchunk = (n24p + lc - 1) / lc, ncg = (n24p + (lc < GL_N ? lc : GL_N) - 1) / (lc < GL_N ? lc : GL_N);
     TAKE(ssp, double, (size_t)B * 2 * nchunk * HP_NCH);
@@ -2082,12 +2110,11 @@ extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
 struct HaspiFlags { int bank_gain, par_iir, fused_gain, fir9; };
 static const HaspiFlags& haspi_flags() {
     static HaspiFlags f = [] {
-        auto on = [](const char* name) { const char* e_ = getenv(name); return (int)!(e_ && e_[0] == '0'); };
         HaspiFlags v;
-        v.bank_gain = on("NELE_HASPI_BANK_GAIN");          // =0: the gain pass as its own kernel
-        v.par_iir = on("NELE_HASPI_PAR_IIR");              // =0: the serial recurrence kernels
-        v.fused_gain = on("NELE_HASPI_FUSED_GAIN");
-        v.fir9 = on("NELE_HASPI_FIR9");                    // =0: the 8-sample-group IHC + envelope-filter kernel with per-sample phase counters
+        v.bank_gain = NELE_SWITCH_INT("NELE_HASPI_BANK_GAIN", 1) != 0;   // =0: the gain pass as its own kernel
+        v.par_iir = NELE_SWITCH_INT("NELE_HASPI_PAR_IIR", 1) != 0;       // =0: the serial recurrence kernels
+        v.fused_gain = NELE_SWITCH_INT("NELE_HASPI_FUSED_GAIN", 1) != 0;
+        v.fir9 = NELE_SWITCH_INT("NELE_HASPI_FIR9", 1) != 0;             // =0: the 8-sample-group IHC + envelope-filter kernel with per-sample phase counters
         return v;
     }();
     return f;
@@ -2115,8 +2142,7 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
     ws.fmul = 1;
     hipLaunchKernelGGL(haspi_rms_kernel, dim3(B, nsig), dim3(256), 0, s, x, y, L, fs_in, ws, sig0);
     if (fs_in != 24000) {
-        static int rs3 = -1;                               // NELE_HASPI_RS3=0: the output-per-thread kernel at 16 kHz too (A/B diagnostic)
-        if (rs3 < 0) { const char* e_ = getenv("NELE_HASPI_RS3"); rs3 = !(e_ && e_[0] == '0'); }
+        const int rs3 = NELE_SWITCH_INT("NELE_HASPI_RS3", 1);                               // NELE_HASPI_RS3=0: the output-per-thread kernel at 16 kHz too (A/B diagnostic)
         if (fs_in == 16000 && rs3)
             hipLaunchKernelGGL(haspi_resample3_kernel, dim3((ws.n24 + RS_CH - 1) / RS_CH, nsig, B), dim3(256), 0, s, x, y, L, ws, sig0);
         else
@@ -2124,28 +2150,27 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         hipLaunchKernelGGL(haspi_resample_gain_kernel, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
     }
     if (par_iir) hipLaunchKernelGGL(haspi_midear_par_kernel, dim3(((ws.n24p + ME_N - 1) / ME_N + 63) / 64, rows), dim3(64), 0, s, ws, sig0, nsig);
-    else hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);
+    else { NELE_AB_ONLY(hipLaunchKernelGGL(haspi_midear_kernel, dim3(B), dim3(64), 0, s, ws, sig0, nsig);) }
     if (par_iir) {
         if (sig0 == 0) hipLaunchKernelGGL(haspi_pmat_kernel, dim3(1), dim3(128), 0, s, ws, ws.lc, 0, 0, 1);   // control bank: per channel only
-        static int tail1 = -1;                             // NELE_HASPI_TAIL1=0: pass 1 over whole chunks (A/B diagnostic)
-        if (tail1 < 0) { const char* e_ = getenv("NELE_HASPI_TAIL1"); tail1 = e_ ? atoi(e_) : 1; }
+        const int tail1 = NELE_SWITCH_INT("NELE_HASPI_TAIL1", 1);                             // NELE_HASPI_TAIL1=0: pass 1 over whole chunks (A/B diagnostic)
         if (tail1) hipLaunchKernelGGL(haspi_bank_tail_kernel<false>, dim3(8 * 4 * ((ws.nchunk + 63) / 64) * ((rows + 7) / 8)), dim3(512), 0, s, ws, sig0, nsig, tail1 >= 2 ? tail1 - 1 : 0, rows);
-        else hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else { NELE_AB_ONLY(hipLaunchKernelGGL((haspi_bank_scan_kernel<false, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);) }
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<false>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL((haspi_bank_scan_kernel<false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         hipLaunchKernelGGL(haspi_bw_kernel, dim3(rows), dim3(32), 0, s, ws, sig0, nsig);
         hipLaunchKernelGGL(haspi_pmat_kernel, dim3(rows), dim3(128), 0, s, ws, ws.lc, 1, sig0, nsig);
         if (tail1) hipLaunchKernelGGL(haspi_bank_tail_kernel<true>, dim3(8 * 4 * ((ws.nchunk + 63) / 64) * ((rows + 7) / 8)), dim3(512), 0, s, ws, sig0, nsig, tail1 >= 2 ? tail1 - 1 : 0, rows);
-        else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else { NELE_AB_ONLY(hipLaunchKernelGGL((haspi_bank_scan_kernel<true, false>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);) }
         hipLaunchKernelGGL(haspi_bank_prefix_kernel<true>, dim3(rows), dim3(64), 0, s, ws, sig0, nsig);
         if (quality) hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
         else if (in_bank)
             NELE_PROF("haspi_bank_gain_kernel", s,
                       hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true, false, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0));
-        else hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);
+        else { NELE_AB_ONLY(hipLaunchKernelGGL((haspi_bank_scan_kernel<true, true>), dim3((ws.nchunk + 1) / 2, nsig, B), dim3(64), 0, s, ws, sig0);) }
     } else {
-        hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
-        hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
+        NELE_AB_ONLY(hipLaunchKernelGGL(haspi_control_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);
+                     hipLaunchKernelGGL(haspi_signal_kernel, dim3(nsig, B), dim3(64), 0, s, ws, sig0);)
     }
     if (sig0 == 0) hipLaunchKernelGGL(haspi_shift_kernel, dim3(B), dim3(64), 0, s, ws);       // group-delay shifts come from BWx alone (+ constant tables)
     if (fused_gain && par_iir) {
@@ -2156,9 +2181,11 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         if (quality) return;                                   // haspi_quality.h goes on from the dB-SL envelope + IHC start states
         const dim3 fgrid((ws.n24p + 4 * ws.lcg * ws.fmul - 1) / (4 * ws.lcg * ws.fmul), rows);
         if (ws.lp_raw) hipLaunchKernelGGL(haspi_ihc_fir9_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
-        else hipLaunchKernelGGL(haspi_ihc_fir_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);
+        else { NELE_AB_ONLY(hipLaunchKernelGGL(haspi_ihc_fir_kernel, fgrid, dim3(128), 0, s, ws, sig0, nsig);) }
         return;                                                // the envelope filter is part of it
-    } else {                                                   // the serial passes of the first version (A/B switch)
+    }
+#ifdef NELE_AB
+    else {                                                     // the serial passes of the first version (A/B switch)
         if (fused_gain) {
             hipLaunchKernelGGL(haspi_gain_lp_sl_kernel, dim3((ws.n24p + 8 * GL_N - 1) / (8 * GL_N), rows), dim3(256), 0, s, ws, sig0, nsig);
         } else {
@@ -2171,6 +2198,7 @@ static void haspi_chain(const float* x, const float* y, int B, int L, int fs_in,
         hipLaunchKernelGGL(haspi_ihc_kernel, dim3((rows + 1) / 2), dim3(64), 0, s, ws, sig0, nsig, rows);
     }
     hipLaunchKernelGGL(haspi_envfilt_kernel, dim3((ws.nsub + EF_SUB - 1) / EF_SUB, B, nsig), dim3(256), 0, s, ws, sig0);
+#endif  // NELE_AB
 }
 
 // dither: NULL (no dither: deterministic) or standard normals [B][2][nsub][32]; row k perturbs the k-th ACTIVE
@@ -2231,10 +2259,8 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
     // tools/ab.sh) the step is 76.0 ms with the serial kernel and 78.2 ms with the parallel one: the GPU is saturated by the step's own
     // streams, and a side-stream kernel that bursts over every CU (87 M float64 pow() in the silence gate) takes more from the main
     // chain than its own chain gains.  Splitting HASPI into row groups (a narrower footprint throughout) did not help (78-79 ms).
-    static int cep_serial = -1;
-    if (cep_serial < 0) { const char* e_ = getenv("NELE_HASPI_CEP_SERIAL"); cep_serial = !(e_ && e_[0] == '0'); }
-    static int mod_direct = -1;                            // NELE_HASPI_MOD_DIRECT=1: direct-form modulation FIR (A/B diagnostic)
-    if (mod_direct < 0) { const char* e_ = getenv("NELE_HASPI_MOD_DIRECT"); mod_direct = (e_ && e_[0] == '1'); }
+    const int cep_serial = NELE_SWITCH_INT("NELE_HASPI_CEP_SERIAL", 1);
+    const int mod_direct = NELE_SWITCH_INT("NELE_HASPI_MOD_DIRECT", 0);                            // NELE_HASPI_MOD_DIRECT=1: direct-form modulation FIR (A/B diagnostic)
     NELE_CHECK_ARG((ws.nsub + MS_TC - 1) / MS_TC <= MS_MAXC, "nele_metric_haspi: signal too long (%d sub-sampled frames)", ws.nsub);
     if (phase == 0 || phase == 3) {
         if (fs_in != 24000) haspi_build_window(ws, s);
@@ -2242,12 +2268,12 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
         if (cep_serial) {
             hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 1, 0, 1);
         } else {
-            hipLaunchKernelGGL(haspi_gate_kernel, dim3(ws.ngb, B), dim3(CP_F), 0, s, ws);
-            hipLaunchKernelGGL(haspi_gate_scan_kernel, dim3(B), dim3(64), 0, s, ws);
-            hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 0);
-            hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 0);
+            NELE_AB_ONLY(hipLaunchKernelGGL(haspi_gate_kernel, dim3(ws.ngb, B), dim3(CP_F), 0, s, ws);
+                         hipLaunchKernelGGL(haspi_gate_scan_kernel, dim3(B), dim3(64), 0, s, ws);
+                         hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 0);
+                         hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 0);)
         }
-        if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        if (mod_direct) { NELE_AB_ONLY(hipLaunchKernelGGL(haspi_mod_direct_kernel<0>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);) }
         else hipLaunchKernelGGL(haspi_mod_slide_kernel<0>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
     }
     if (phase == 0 || phase == 4) {
@@ -2255,10 +2281,10 @@ static int haspi_var_impl(const float* x, const float* y, const int* lengths, in
         if (cep_serial) {
             hipLaunchKernelGGL(haspi_cep_kernel, dim3(B), dim3(256), 0, s, ws, dither, 0.1, 0, 1, 1);
         } else {
-            hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 1);
-            hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 1);
+            NELE_AB_ONLY(hipLaunchKernelGGL(haspi_cepstra_kernel, dim3(ws.ngb, B, 1), dim3(CP_F), 0, s, ws, dither, 0.1, 1);
+                         hipLaunchKernelGGL(haspi_cepmean_kernel, dim3(B, 1), dim3(64), 0, s, ws, 1);)
         }
-        if (mod_direct) hipLaunchKernelGGL(haspi_mod_direct_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);
+        if (mod_direct) { NELE_AB_ONLY(hipLaunchKernelGGL(haspi_mod_direct_kernel<1>, dim3(HP_NMOD, HP_NBASIS - 1, B), dim3(256), 0, s, ws);) }
         else {
             hipLaunchKernelGGL(haspi_mod_slide_kernel<1>, dim3((ws.nsub + MS_TC - 1) / MS_TC, B), dim3(64), 0, s, ws);
             hipLaunchKernelGGL(haspi_modcorr_kernel, dim3(B), dim3(64), 0, s, ws);

@@ -250,6 +250,7 @@ __device__ constexpr Tw20 make_tw20() {
     for (int i = 0; i < 20; ++i) { t.c[i] = cc[i]; t.s[i] = ss[i]; }
     return t;
 }
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict__ x, const float* __restrict__ y, int L, SiibWs ws, int sig0,
                                                         int sig1) {   // signals sig0..sig1 (0 = clean x, 1 = degraded y)
     constexpr Tw20 tw = make_tw20();
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
         }
     }
 }
+#endif  // NELE_AB
 
 // s3, wave-autonomous form (round 3, third session; NELE_SIIB_SPECW=0 = the kernel above).  The kernel above runs at one wave per SIMD
 // (502 registers: with the 20-point twiddles as literals the compiler pre-multiplies and keeps hundreds of products live; 64 KB of
@@ -718,6 +720,7 @@ __global__ __launch_bounds__(64) void siib_mask_kernel(SiibWs ws, int sig0) {
 // grid (28 bands, B, signals), block 256, dynamic LDS NA doubles: s5.  The 15 stacked rows of a band are shifted copies of ONE row of
 // the masked spectrum: it is read once into LDS (the version with one block per stacked row read every band row 30 times), the 15
 // window means are summed from there in the same thread-strided order as before (bit-identical), and the 15 rows go out.
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws, int sig0) {
     extern __shared__ double sk_v[];                     // v[t] = masked band value - its row mean
     __shared__ double red[8];
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(256) void siib_stack_kernel(SiibWs ws, int sig0) {
         for (int t = tid; t < ws.NA; t += 256) dst[t] = (t < ncols) ? sk_v[t + k] - mu : 0.0;
     }
 }
+#endif  // NELE_AB
 
 // ---------------------------------------------------------------- float64 MFMA GEMMs
 // v_mfma_f64_16x16x4_f64: A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15], D reg q of lane l = D[(l>>4) + 4q][l&15].
@@ -759,6 +763,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // C[b][i][j] = scale_b * sum_t Xs[b][0][i][t] * Xs[b][0][j][t]   (s6).  grid (7, 7, B): lower-triangle 64x64 tiles only, mirrored
 // on store.  Waves 2x2, 32x32 per wave.  Columns >= n_cols of Xs are zero padded and NA is a multiple of 64, so K needs no guard;
 // rows >= 420 are clamped (they only reach outputs that are never stored).
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
     __shared__ __attribute__((aligned(16))) double As[2][16][SG_LD], Bs[2][16][SG_LD];
     // 1-D grid, XCD-aware (workgroup id w runs on XCD w % 8): all tiles of an utterance get ids of one XCD, so that its L2 serves the row
@@ -820,6 +825,7 @@ __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
                 }
             }
 }
+#endif  // NELE_AB
 
 // s8: P = U X for both signals (U rows = eigenvectors, [420][420]; X [420][NA]); per 64x64 tile of P emit the row-wise partial
 // sums of Xp^2, Yp^2, Xp*Yp.  grid (NTL, 7, B).  Waves 4x1: a wave owns 16 eigenvectors x 64 frames of both signals, so the row
@@ -827,6 +833,7 @@ __global__ __launch_bounds__(256) void siib_cov_kernel(SiibWs ws) {
 // MODE 0: both signals (one-shot call).  MODE 1: clean signal only - its projections are kept (ws.px, accumulator order) together
 // with the sum of squares; MODE 2: degraded signal only, the clean projections are read back.  1 + 2 perform exactly the MFMA
 // sequences of 0, so the split is bit-identical; it takes half of the projection off the path that waits for the enhanced signal.
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 template <int MODE>
 __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
     __shared__ __attribute__((aligned(32))) double Us[2][16][SG_LD], Xt[2][16][SG_LD], Yt[2][16][SG_LD];
@@ -908,6 +915,7 @@ __global__ __launch_bounds__(256) void siib_proj_kernel(SiibWs ws) {
         }
     }
 }
+#endif  // NELE_AB
 
 
 // ---------------------------------------------------------------- second moments of the stacked frames from LAG PRODUCTS (round 3)
@@ -1220,6 +1228,7 @@ __global__ __launch_bounds__(512) void siib_final_lag_kernel(SiibWs ws, float* _
 }
 
 // s9: one block (512 threads >= 420) per utterance
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(512) void siib_final_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped) {
     __shared__ double red[8];
     const int b = blockIdx.x, j = threadIdx.x;
@@ -1244,6 +1253,7 @@ __global__ __launch_bounds__(512) void siib_final_kernel(SiibWs ws, float* __res
         if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.06 * (v - 32.0))));
     }
 }
+#endif  // NELE_AB
 
 // ------------------------------------------------------------------------------------------ C ABI
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1263,7 +1273,7 @@ static void siib_dims(int L, int* NT, int* NA, int* NTL) {
 
 // NELE_SIIB_LAG=0: covariance and projections from the stacked frames (the round-2 kernels; A/B switch)
 static bool siib_lag_path() {
-    static const bool on = [] { const char* e = getenv("NELE_SIIB_LAG"); return !(e && e[0] == '0'); }();
+    const bool on = NELE_SWITCH_INT("NELE_SIIB_LAG", 1) != 0;
     return on;
 }
 
@@ -1333,7 +1343,7 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
     hipStream_t s = as_stream(stream);
     int g = L, r = SB_SHIFT;
     while (r) { const int t = g % r; g = r; r = t; }
-    static const bool dedup = [] { const char* e = getenv("NELE_SIIB_DEDUP"); return !(e && e[0] == '0'); }();
+    const bool dedup = NELE_SWITCH_INT("NELE_SIIB_DEDUP", 1) != 0;
     // frame period of the tiled signal (NELE_SIIB_DEDUP=0: A/B switch, every frame computed; per-utterance lengths: every row has its
     // own period, the shortcut is not taken)
     const int Pf = (dedup && !lengths) ? L / g : 0x7fffffff;
@@ -1355,19 +1365,16 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
     }
     if (sx || sy) {
         const int sig0 = sx ? 0 : 1, sig1 = sy ? 1 : 0, nsig = sig1 - sig0 + 1;
-        static const bool specw = [] { const char* e = getenv("NELE_SIIB_SPECW"); return !(e && e[0] == '0'); }();
+        const bool specw = NELE_SWITCH_INT("NELE_SIIB_SPECW", 1) != 0;
         if (specw)
             hipLaunchKernelGGL(siib_spec_wave_kernel, dim3((ws.NA + SP_F * SPW_NG - 1) / (SP_F * SPW_NG), B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
-        else
-            hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);
+        else {
+            NELE_AB_ONLY(hipLaunchKernelGGL(siib_spec_kernel, dim3((ws.NA + SP_F - 1) / SP_F, B), dim3(128), 0, s, x, y, L, ws, sig0, sig1);)
+        }
         hipLaunchKernelGGL(siib_spread_kernel, dim3((ws.NA + 255) / 256, B), dim3(256), 0, s, ws, Pf, sig0, sig1);
         hipLaunchKernelGGL(siib_rowmin_kernel, dim3(SB_J, B, nsig), dim3(256), 0, s, ws, sig0);
         hipLaunchKernelGGL(siib_mask_kernel, dim3(B, nsig), dim3(64), 0, s, ws, sig0);
-        static bool sk_attr = false;
-        if (!sk_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(siib_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-            sk_attr = true;
-        }
+        NELE_AB_ONLY(NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(siib_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));)
         if (siib_lag_path()) {
             hipLaunchKernelGGL(siib_mu_kernel, dim3(B, nsig), dim3(256), 0, s, ws, sig0);
             const dim3 lg(4, ws.nseg, B);
@@ -1381,9 +1388,9 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
                 hipLaunchKernelGGL(siib_assemble_kernel<1>, dim3(15, B), dim3(256), 0, s, ws);
             }
         } else {
-            NELE_CHECK_ARG((size_t)ws.NA * sizeof(double) <= 152 * 1024, "nele_metric_siib: signal too long (%d active frames)", ws.NA);
-            hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_J, B, nsig), dim3(256), sizeof(double) * (size_t)ws.NA, s, ws, sig0);
-            if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+            NELE_AB_ONLY(NELE_CHECK_ARG((size_t)ws.NA * sizeof(double) <= 152 * 1024, "nele_metric_siib: signal too long (%d active frames)", ws.NA);
+                         hipLaunchKernelGGL(siib_stack_kernel, dim3(SB_J, B, nsig), dim3(256), sizeof(double) * (size_t)ws.NA, s, ws, sig0);
+                         if (sx) hipLaunchKernelGGL(siib_cov_kernel, dim3(49 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);)
         }
         NELE_CHECK_LAUNCH("nele_metric_siib(front)");
     }
@@ -1392,7 +1399,7 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
         int st = nele_eigh_sym_batched_ex(ws.C, SB_D, B, ws.lam, ws.U, ws.eigws, nele_eigh_workspace_bytes(B, SB_D), stream, (phase == 3) ? 32 : 64);
         if (st) return st;
         if (phase == 3 && !siib_lag_path()) {               // clean-signal half of the projections, beside whatever the caller overlaps
-            hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+            NELE_AB_ONLY(hipLaunchKernelGGL(siib_proj_kernel<1>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);)
             NELE_CHECK_LAUNCH("nele_metric_siib(clean projections)");
         }
     }
@@ -1402,9 +1409,9 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
         NELE_CHECK_LAUNCH("nele_metric_siib(back, lag path)");
     } else if (fin) {
-        if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
-        else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
-        hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
+        NELE_AB_ONLY(if (phase == 4) hipLaunchKernelGGL(siib_proj_kernel<2>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+                     else hipLaunchKernelGGL(siib_proj_kernel<0>, dim3(7 * ws.NTL * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
+                     hipLaunchKernelGGL(siib_final_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);)
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
         NELE_CHECK_LAUNCH("nele_metric_siib(back)");
     }

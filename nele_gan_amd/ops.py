@@ -86,6 +86,12 @@ class Geom:
         self.arr = (c_int * 15)(*vals)
 
 
+# Module-level test knobs (tests monkeypatch them; nothing reads the environment): False = the discriminator keeps float32 activations /
+# a float32 pooling gradient in memory - the round-2 kernels, which remain the path for geometries the bf16-in-memory kernels decline.
+CONV16 = True
+GRAD16 = True
+
+
 def side_stream(device):
     """A new side stream - or, with NELE_SERIAL=1 (diagnostic: every kernel then runs alone and a rocprofv3 kernel trace shows
     isolated durations), the current stream itself, which serialises the whole step.
@@ -143,7 +149,7 @@ def span16_supported(B, N, g):
 
 def grad16_supported(B, N_dgrad, g_dgrad, N_wgrad, g_wgrad):
     """Can this layer's output gradient live in memory as bfloat16?  (data gradient on the span kernel, weight gradient on the tile kernel)"""
-    if os.environ.get('NELE_GRAD16', '1') == '0':
+    if not GRAD16:
         return False
     return bool(_lib.lib.nele_conv_span_bf16_a16_supported(B * g_dgrad.Hout * g_dgrad.Wout, N_dgrad, g_dgrad.arr, g_dgrad.KH, g_dgrad.KW)) and \
         bool(_lib.lib.nele_conv_wgrad_bf16_d16_supported(B * g_wgrad.Hout * g_wgrad.Wout, N_wgrad, g_wgrad.arr, g_wgrad.KH, g_wgrad.KW))
@@ -173,6 +179,8 @@ def conv_span_bf16(A, Wfrag, bias, aux, out, B, N, epi, g, tag=None):
 
 def conv16_supported(B, N, g):
     """Can this layer run on the bf16-activation tile kernel (csrc/conv16.hip)?"""
+    if not CONV16:
+        return False
     return bool(_lib.lib.nele_conv16_supported(B * g.Hout * g.Wout, N, g.arr, g.KH, g.KW))
 
 

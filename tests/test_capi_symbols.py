@@ -41,3 +41,21 @@ def test_invalid_arguments_are_reported_without_a_gpu():
     st = _lib.lib.nele_stft_band(None, 0, 0, 0.0, None, None, None)
     assert st == -1
     assert b'nele_stft_band' in _lib.lib.nele_last_error_string()
+
+
+def test_product_library_has_no_switches_and_the_test_library_exports_the_same_abi():
+    """libnele_hip.so (product): NELE_* environment switches are compile-time constants, the superseded kernel variants are not built.
+    libnele_hip_ab.so (tests / tools, -DNELE_AB): same sources, same exported symbols, switches read from the environment."""
+    prod = ctypes.CDLL(os.path.join(ROOT, 'nele_gan_amd', 'libnele_hip.so'))
+    ab_path = os.path.join(ROOT, 'nele_gan_amd', 'libnele_hip_ab.so')
+    assert os.path.exists(ab_path), "make -C nele_gan_amd/csrc builds both libraries"
+    ab = ctypes.CDLL(ab_path)
+    assert prod.nele_build_has_ab_switches() == 0 and ab.nele_build_has_ab_switches() == 1
+    missing = [s for s in declared_symbols() if not hasattr(ab, s)]
+    assert not missing, missing
+    # no getenv in the product library's import table
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--undefined-only', os.path.join(ROOT, 'nele_gan_amd', 'libnele_hip.so')], stdout=subprocess.PIPE, text=True).stdout
+    assert 'getenv' not in nm
+    nm_ab = subprocess.run(['nm', '-D', '--undefined-only', ab_path], stdout=subprocess.PIPE, text=True).stdout
+    assert 'getenv' in nm_ab

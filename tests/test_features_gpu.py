@@ -3,6 +3,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import ab_env
 
 pytestmark = pytest.mark.gpu
 
@@ -189,7 +190,7 @@ def test_wave_per_transform_stft_istft_are_bit_identical_to_the_workgroup_kernel
     for flag in ('1', '0'):
         out = str(tmp_path / ('stft_wave_%s.npy' % flag))
         subprocess.run([sys.executable, '-c', _STFT_AB_CHILD, os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out], check=True,
-                       env=dict(os.environ, NELE_STFT_WAVE=flag), timeout=240)
+                       env=ab_env(NELE_STFT_WAVE=flag), timeout=240)
         res.append(np.load(out))
     assert res[0].shape == res[1].shape and np.all(np.isfinite(res[0]))
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))

@@ -4,6 +4,7 @@ import wave
 
 import numpy as np
 import pytest
+from conftest import ab_env
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
@@ -241,7 +242,7 @@ def test_siib_lag_products_equal_the_stacked_frame_gemms(tmp_path):
     res = []
     for flag in ('1', '0'):
         out = str(tmp_path / ('siib_lag_%s.npy' % flag))
-        subprocess.run([sys.executable, '-c', _LAG_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_SIIB_LAG=flag), timeout=240)
+        subprocess.run([sys.executable, '-c', _LAG_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_SIIB_LAG=flag), timeout=240)
         res.append(np.load(out))
     assert np.all(np.isfinite(res[0])) and res[0].shape == res[1].shape
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
@@ -273,7 +274,7 @@ def test_siib_wave_autonomous_spectrum_kernel_matches_the_workgroup_kernel(tmp_p
     res = []
     for flag in ('1', '0'):
         out = str(tmp_path / ('siib_specw_%s.npy' % flag))
-        subprocess.run([sys.executable, '-c', _SPECW_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_SIIB_SPECW=flag), timeout=240)
+        subprocess.run([sys.executable, '-c', _SPECW_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_SIIB_SPECW=flag), timeout=240)
         res.append(np.load(out))
     assert np.all(np.isfinite(res[0])) and res[0].shape == res[1].shape
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
@@ -304,7 +305,7 @@ def test_estoi_five_output_resampler_is_bit_identical_to_the_output_per_thread_o
     res = []
     for flag in ('1', '0'):
         out = str(tmp_path / ('estoi_rs5_%s.npy' % flag))
-        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_ESTOI_RS5=flag), timeout=240)
+        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_ESTOI_RS5=flag), timeout=240)
         res.append(np.load(out))
     assert np.all(np.isfinite(res[0])) and res[0].shape == (11,)
     assert np.array_equal(res[0], res[1])
@@ -319,7 +320,7 @@ def test_estoi_wave_per_frame_third_octave_kernel_matches_the_workgroup_kernel(t
     res = []
     for flag in ('1', '0'):
         out = str(tmp_path / ('estoi_tobw_%s.npy' % flag))
-        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_ESTOI_TOBW=flag), timeout=240)
+        subprocess.run([sys.executable, '-c', _ESTOI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_ESTOI_TOBW=flag), timeout=240)
         res.append(np.load(out))
     assert np.all(np.isfinite(res[0])) and res[0].shape == (11,)
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=1e-7)
@@ -343,7 +344,7 @@ def test_haspi_chunk_parallel_filters_equal_the_serial_ones(tmp_path):
     res = []
     for env in ({}, {'NELE_HASPI_PAR_IIR': '0', 'NELE_HASPI_FUSED_GAIN': '0'}):
         out = str(tmp_path / ('haspi_%d.npy' % len(res)))
-        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **env), timeout=240)
+        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(**env), timeout=240)
         res.append(np.load(out))
     assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
@@ -357,7 +358,7 @@ def test_haspi_sliding_modulation_filters_equal_the_direct_fir(tmp_path):
     res = []
     for env in ({}, {'NELE_HASPI_MOD_DIRECT': '1'}):
         out = str(tmp_path / ('haspi_mod_%d.npy' % len(res)))
-        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **env), timeout=240)
+        subprocess.run([sys.executable, '-c', _HASPI_AB_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(**env), timeout=240)
         res.append(np.load(out))
     assert res[0].shape == (4,) and np.all(np.isfinite(res[0]))
     np.testing.assert_allclose(res[0], res[1], rtol=3e-7, atol=0)          # float32 outputs: at most a couple of ulps apart
@@ -387,7 +388,7 @@ def test_haspi_round3_kernels_equal_the_ones_they_replace(tmp_path, env):
     res = []
     for e in ({}, env):
         out = str(tmp_path / ('haspi_r3_%d.npy' % len(res)))
-        subprocess.run([sys.executable, '-c', _HASPI_RAGGED_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, **e), timeout=240)
+        subprocess.run([sys.executable, '-c', _HASPI_RAGGED_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(**e), timeout=240)
         res.append(np.load(out))
     assert res[0].shape == (5,) and np.all(np.isfinite(res[0]))
     np.testing.assert_allclose(res[0], res[1], rtol=1e-6, atol=0)           # float32 outputs; multiply-add chains differ in the last bits
@@ -532,7 +533,7 @@ def test_cluster_tridiagonalisation_give_up_is_repaired_not_poisoned(tmp_path):
     res = []
     for k in ('3', '0'):
         out = str(tmp_path / ('repair_%s.npy' % k))
-        subprocess.run([sys.executable, '-c', _REPAIR_CHILD, os.path.dirname(HERE), out], check=True, env=dict(os.environ, NELE_EIGH_FAIL_EVERY=k), timeout=240)
+        subprocess.run([sys.executable, '-c', _REPAIR_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_FAIL_EVERY=k), timeout=240)
         res.append(np.load(out))
     forced, plain = res
     assert forced[0] == 3 and forced[4] == 2 and plain[0] == 0 and plain[4] == 0           # matrices 0, 3, 6 of 8; 0, 3 of 5

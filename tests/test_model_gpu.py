@@ -285,7 +285,7 @@ def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, 
     """bf16 mode stores the last conv layer's output gradient (the pooling gradient) as bfloat16 where the span / tile kernels take it
     (nele_gap_mlp_bwd_var16 -> nele_conv_span_bf16_a16 + nele_conv_wgrad_bf16_d16).  Both consumers round that operand to bf16 anyway, so
     everything the data-gradient chain produces - the input gradient and every other layer's weight gradient - must be BIT-identical to the
-    float32-buffer path (NELE_GRAD16=0), conv5's weight gradient too (same bf16 operands, same accumulation order); only conv5's bias
+    float32-buffer path (ops.GRAD16 = False), conv5's weight gradient too (same bf16 operands, same accumulation order); only conv5's bias
     gradient sums bf16-rounded instead of float32 values - and since the pooling gradient takes just two values per (utterance, channel),
     that rounding does not average out: up to 2^-8 relative, inside the documented bf16-mode tolerance (3e-2)."""
     from nele_gan_amd import ops
@@ -293,9 +293,9 @@ def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, 
     torch.manual_seed(5)
     x = torch.rand(B, 3, 64, T, device='cuda') * 2
     res = {}
-    monkeypatch.setenv('NELE_CONV16', '0')        # the round-2 kernels (float32 activations in memory): the fallback for geometries conv16 declines
+    monkeypatch.setattr(ops, 'CONV16', False)        # the round-2 kernels (float32 activations in memory): the fallback for geometries conv16 declines
     for flag in ('1', '0'):
-        monkeypatch.setenv('NELE_GRAD16', flag)
+        monkeypatch.setattr(ops, 'GRAD16', flag == '1')
         D = load_recipe(mods.Discriminator(), 33)
         D.precision = 'bf16'
         D.eval()
@@ -318,15 +318,16 @@ def test_bf16_pooling_gradient_buffer_gives_the_float32_buffers_gradients(mods, 
 def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, monkeypatch):
     """Round 3: in bf16 mode the activations of conv1..conv4 and the output gradients of conv2..conv5 are STORED as bfloat16
     (csrc/conv16.hip; nele_conv_wgrad_bf16_a16d16).  Every consumer of those tensors rounded them to bf16 while staging them, so the MFMA
-    operands are the same numbers as with float32 buffers (NELE_CONV16=0: the round-2 kernels), accumulated over k in the same order:
+    operands are the same numbers as with float32 buffers (ops.CONV16 = False: the round-2 kernels), accumulated over k in the same order:
     scores and input gradient must be BIT-identical, the weight gradients equal up to their summation order (round 4, see below).  Only the bias gradients of conv2..conv5 sum bf16-rounded
     instead of float32 output gradients (the same documented effect as for conv5 in round 2)."""
+    from nele_gan_amd import ops
     B, T = 3, 251
     torch.manual_seed(6)
     x = torch.rand(B, 3, 64, T, device='cuda') * 2
     res = {}
     for flag in ('1', '0'):
-        monkeypatch.setenv('NELE_CONV16', flag)
+        monkeypatch.setattr(ops, 'CONV16', flag == '1')
         D = load_recipe(mods.Discriminator(), 34)
         D.precision = 'bf16'
         D.eval()
