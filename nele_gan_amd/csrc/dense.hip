@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
 // Partials [group][N][Ktot] + bias partials, reduced by wgrad_reduce_kernel as before (fixed order: deterministic).
 #define WD_TW 64
 #define WD_MAXHP 6           // halo DMA pieces per wave and tile (host checks)
-#define WD_MAXDP 3           // dOut DMA pieces per wave and tile
+#define WD_MAXDP 4           // dOut DMA pieces per wave and tile
 struct WgradDmaArgs {
     const __bf16* A;
     const __bf16* dOut;

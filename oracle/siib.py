@@ -14,8 +14,11 @@ restates the published algorithm:
   I = -1/2 log2(1 - rho_p^2 rho^2) with rho_p = 0.75, SIIB = R/K * sum(I) clamped at 0.
 Deliberate, documented deviation: components whose KLT eigenvalue is <= 1e-10 * the largest carry
 no information (I = 0).  They only arise when the replicated signal is exactly frame-periodic
-(L a multiple of 200) and the covariance is rank deficient; there the reference's result is
-rounding noise (~1e-3 relative) that no second implementation can reproduce.
+(L a multiple of 200: 170-260 of the 420 components; L a multiple of 100: a handful) and the
+covariance is rank deficient; there the reference scores rounding noise that no second
+implementation can reproduce.  Size of the effect on the bench utterances (DESIGN.md section 2,
+tests/test_oracle_metrics.py): raw SIIB 1 % .. 23 % below the uncut value at L = 64 000,
+2e-4 .. 2e-3 at L = 63 900, exactly zero at lengths that are no multiple of 100 (any real file).
 """
 import numpy as np
 
