@@ -63,7 +63,7 @@ __device__ __forceinline__ void eigh_house(double* v, int m, double* red, double
 // Six workgroup barriers per step: (1,2) reduce p.v, (3,4) reduce ||x'||^2 of the next pivot row, (5) publish the next
 // Householder vector, (6) end of the fused pass.  Vectors ping-pong between two LDS slots; the two row groups of the pass
 // leave their partial matrix-vector products in separate arrays that the next step adds on the fly.
-__device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
+__device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, int lda, double* __restrict__ d, double* __restrict__ e,
                                                  double* __restrict__ tau) {
     __shared__ double vb[2][EG_MAXN], wv[EG_MAXN], pa[EG_MAXN], pb2[EG_MAXN];
     __shared__ double red[16];
@@ -76,11 +76,11 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
         for (int i = tid; i < m; i += 1024) v[i] = A[1 + i];
         __syncthreads();
         eigh_house(v, m, red, &s_tau, &s_scale, &s_beta);
-        double* A22 = A + (size_t)n + 1;
+        double* A22 = A + (size_t)lda + 1;
         const int c = tid & 511, grp = tid >> 9;
         double acc = 0.0;
         if (c < m)
-            for (int r = grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * v[r];
+            for (int r = grp; r < m; r += 2) acc += A22[(size_t)r * lda + c] * v[r];
         if (c < m) (grp ? pb2 : pa)[c] = acc;
         __syncthreads();
     }
@@ -89,9 +89,9 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
         const int m = n - k - 1, cur = k & 1;
         double* v = vb[cur];
         double* vn = vb[cur ^ 1];
-        double* rowk = A + (size_t)k * n + k + 1;
-        double* A22 = A + (size_t)(k + 1) * n + (k + 1);
-        if (tid == 0) { d[k] = A[(size_t)k * n + k]; e[k] = betak; tau[k] = tk; }
+        double* rowk = A + (size_t)k * lda + k + 1;
+        double* A22 = A + (size_t)(k + 1) * lda + (k + 1);
+        if (tid == 0) { d[k] = A[(size_t)k * lda + k]; e[k] = betak; tau[k] = tk; }
         // (1,2) p.v with p = tau * (pa + pb2)
         double pv = 0.0;
         for (int i = tid; i < m; i += 1024) {
@@ -144,22 +144,22 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
                 if (tk != 0.0) {
                     int r = 1 + grp;
                     for (; r + 6 < m; r += 8) {
-                        double x0 = A22[(size_t)r * n + c], x1 = A22[(size_t)(r + 2) * n + c], x2 = A22[(size_t)(r + 4) * n + c],
-                               x3 = A22[(size_t)(r + 6) * n + c];
+                        double x0 = A22[(size_t)r * lda + c], x1 = A22[(size_t)(r + 2) * lda + c], x2 = A22[(size_t)(r + 4) * lda + c],
+                               x3 = A22[(size_t)(r + 6) * lda + c];
                         x0 -= v[r] * wc + wv[r] * vc; x1 -= v[r + 2] * wc + wv[r + 2] * vc;
                         x2 -= v[r + 4] * wc + wv[r + 4] * vc; x3 -= v[r + 6] * wc + wv[r + 6] * vc;
-                        A22[(size_t)r * n + c] = x0; A22[(size_t)(r + 2) * n + c] = x1; A22[(size_t)(r + 4) * n + c] = x2;
-                        A22[(size_t)(r + 6) * n + c] = x3;
+                        A22[(size_t)r * lda + c] = x0; A22[(size_t)(r + 2) * lda + c] = x1; A22[(size_t)(r + 4) * lda + c] = x2;
+                        A22[(size_t)(r + 6) * lda + c] = x3;
                         acc += x0 * vn[r - 1] + x1 * vn[r + 1] + x2 * vn[r + 3] + x3 * vn[r + 5];
                     }
                     for (; r < m; r += 2) {
-                        double x0 = A22[(size_t)r * n + c];
+                        double x0 = A22[(size_t)r * lda + c];
                         x0 -= v[r] * wc + wv[r] * vc;
-                        A22[(size_t)r * n + c] = x0;
+                        A22[(size_t)r * lda + c] = x0;
                         acc += x0 * vn[r - 1];
                     }
                 } else {
-                    for (int r = 1 + grp; r < m; r += 2) acc += A22[(size_t)r * n + c] * vn[r - 1];
+                    for (int r = 1 + grp; r < m; r += 2) acc += A22[(size_t)r * lda + c] * vn[r - 1];
                 }
                 (grp ? pb2 : pa)[c - 1] = acc;
             }
@@ -168,12 +168,12 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
         tk = tn_;
         betak = betan;
     }
-    if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
+    if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * lda + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
 }
 
 __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
     const int b = blockIdx.x;
-    eigh_tridiag_one(Aall + (size_t)b * n * n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
+    eigh_tridiag_one(Aall + (size_t)b * n * n, n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
 }
 
 // Repair of the matrices the cluster kernels gave up on (ws.flag[b] != 0: some of a matrix's workgroups were not scheduled within the
@@ -184,15 +184,56 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
 // grid B, block 1024; unflagged matrices return at once.
 __global__ __launch_bounds__(1024) void eigh_tridiag_repair_kernel(double* __restrict__ Aall, int n, EighWs ws, int B) {
     const int b = blockIdx.x;
-    if (ws.flag[b] == 0) return;
+    if (ws.flag[b] != 1) return;
     double* A = Aall + (size_t)b * n * n;
     for (int idx = threadIdx.x; idx < n * n; idx += 1024) {
         const int r = idx / n, c = idx - r * n;
         if (c > r) A[idx] = A[(size_t)c * n + r];
     }
     __syncthreads();
-    eigh_tridiag_one(A, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
+    eigh_tridiag_one(A, n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
     if (threadIdx.x == 0) atomicAdd(&ws.flag[B], 1);
+}
+
+// The same for a give-up inside the SECOND cluster stage (ws.flag[b] == 2).  The block has been updated in place by then, so there is
+// no original matrix to go back to - but the first stage's hand-over is still there: the trailing block (rows / columns >= base =
+// s_first + 1, updated through reflector s_first - 1) sits in A, where the second stage has only written reflector rows into its strict
+// UPPER triangle, and ws.zt holds the pending reflector s_first (vector v, tau) with its matrix-vector product p.  One workgroup
+// mirrors the block's lower triangle back, applies the pending reflector (w = tau p - (tau / 2)(tau p . v) v, A -= v w^T + w v^T) and
+// tridiagonalises what is left - an ordinary symmetric m x m problem with leading dimension n - with the memory-streaming kernel;
+// d / e / tau / the reflector rows from base on are rewritten.  grid B, block 1024; other matrices return at once.
+__global__ __launch_bounds__(1024) void eigh_tridiag_repair2_kernel(double* __restrict__ Aall, int n, EighWs ws, int B, int s_first) {
+    __shared__ double vv[EG_MAXN], ww[EG_MAXN];
+    __shared__ double red2[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (ws.flag[b] != 2) return;
+    const int base = s_first + 1, m = n - base;
+    double* A = Aall + (size_t)b * n * n;
+    double* Ab = A + (size_t)base * n + base;              // the trailing block, leading dimension n
+    const double* st = ws.zt + (size_t)b * n * EG_MAXN;
+    const double tk = st[3 * EG_MAXN];
+    double pv = 0.0;
+    for (int i = tid; i < m; i += 1024) {
+        const double v = st[base + i], pp = st[EG_MAXN + base + i];
+        vv[i] = v;
+        ww[i] = tk * pp;
+        pv += tk * pp * v;
+    }
+    for (int idx = tid; idx < m * m; idx += 1024) {         // lower -> upper (the second stage's reflector rows go)
+        const int r = idx / m, c = idx - r * m;
+        if (c > r) Ab[(size_t)r * n + c] = Ab[(size_t)c * n + r];
+    }
+    pv = block_sum(pv, red2);                              // (barriers inside: vv / ww / the mirrored block are visible behind it)
+    const double al = -0.5 * tk * pv;
+    for (int i = tid; i < m; i += 1024) ww[i] += al * vv[i];
+    __syncthreads();
+    for (int idx = tid; idx < m * m; idx += 1024) {
+        const int r = idx / m, c = idx - r * m;
+        Ab[(size_t)r * n + c] -= vv[r] * ww[c] + ww[r] * vv[c];
+    }
+    __syncthreads();
+    eigh_tridiag_one(Ab, m, n, ws.d + (size_t)b * n + base, ws.e + (size_t)b * n + base, ws.tau + (size_t)b * n + base);
+    if (tid == 0) atomicAdd(&ws.flag[B], 1);
 }
 
 
@@ -450,7 +491,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
     const int slot = g >> 3, p = slot & 3, mloc = (g & 7) + 8 * (slot >> 2);
     if (mloc >= Bc) return;
     const int b = b0 + mloc;
-    if (fail_every > 0 && b % fail_every == 0) {           // test hook (NELE_EIGH_FAIL_EVERY): behave as if this matrix's workgroups had given up
+    if (fail_every > 0 && b % fail_every == 0) {           // test hook (NELE_EIGH_FAIL_EVERY=k > 0; -k: the second stage): behave as if this matrix's workgroups had given up
         if (tid == 0 && p == 0) ws.flag[b] = 1;
         return;
     }
@@ -677,7 +718,8 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 #define EC2_RI 20
 #define EC2_NR 4
 #define EC2_M (16 * EC2_RI)
-__global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_first, int s_stop) {
+__global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_first, int s_stop,
+                                                                    int fail_every) {
     extern __shared__ double ec2_col[];                    // aL[EC2_RI][16][32]: the fifth column slot of every lane
     __shared__ __attribute__((aligned(16))) double vperm[3][EC2_M + 64];   // v, w, v_next at [(r & 15) * EC2_RI + (r >> 4)]
     __shared__ double vnat[EC2_M], wnat[EC2_M];
@@ -689,6 +731,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
     if (mloc >= Bc) return;
     const int b = b0 + mloc;
     if (ws.flag[b] != 0) return;                           // the first stage gave up on this matrix
+    if (fail_every < 0 && b % (-fail_every) == 0) {        // test hook (NELE_EIGH_FAIL_EVERY=-k): this stage gives up on every k-th matrix
+        if (tid == 0 && p == 0) ws.flag[b] = 2;
+        return;
+    }
     const int base = s_first + 1, m = n - base;            // trailing block = rows / columns base .. n-1, m <= EC2_M
     double* A = Aall + (size_t)b * n * n;
     double* d = ws.d + (size_t)b * n;
@@ -863,9 +909,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
                     ok = (qp.y == tag) && (qp.w == tag) && (qc.y == tag) && (qc.w == tag);
                 }
                 if (__all(ok)) break;
-                if (++spins > EC_SPIN_LIMIT) {             // never hang the device (see eigh_tridiag_cluster4_kernel); this stage's give-up
-                    if (own) d[i] = __builtin_nan("");     // cannot be redone from the lower triangle (the block has been updated in place):
-                    if (tid == 0) ws.flag[b] = 2;          // the matrix stays poisoned and the optimiser step is masked, as before round 4
+                if (++spins > EC_SPIN_LIMIT) {             // never hang the device (see eigh_tridiag_cluster4_kernel): give up, and
+                    if (own) d[i] = __builtin_nan("");     // eigh_tridiag_repair2_kernel restarts this matrix from the first stage's hand-over
+                    if (tid == 0) ws.flag[b] = 2;
                     return;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -2076,6 +2122,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
         const int capenv = NELE_SWITCH_INT("NELE_EIGH_CLUSTER_CAP", 0);    // matrices per launch (multiple of 8): fewer leaves CUs to other streams
         if (capenv >= 8 && capenv < cluster_cap) cluster_cap = capenv / 8 * 8;
     }
+    int c2_first = -1;                                     // first step of the second cluster stage when it runs (its give-ups are repaired from there)
     if (cluster_cap >= 8) {
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         if (hipMemsetAsync(ws.flag, 0, sizeof(int) * ((size_t)B + 1), s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
@@ -2119,12 +2166,13 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
                           hipLaunchKernelGGL(eigh_tridiag_cluster4_kernel, dim3(32 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws, s_stop1, fail_every));
             }
             if (two_stage) {
+                c2_first = s_stop1 + 1;
                 const int c2_batch = 2 * p4_batch;
                 for (int b0 = 0; b0 < B; b0 += c2_batch) {
                     const int Bc = (B - b0 < c2_batch) ? B - b0 : c2_batch;
                     NELE_PROF("eigh_tridiag_cluster", s,
                               hipLaunchKernelGGL(eigh_tridiag_cluster2_kernel, dim3(16 * ((Bc + 7) / 8)), dim3(512), sizeof(double) * EC2_RI * 16 * 32, s, A, n, b0,
-                                                 Bc, ws, s_stop1 + 1, s_stop));
+                                                 Bc, ws, s_stop1 + 1, s_stop, fail_every));
                 }
             }
             if (s_stop >= -1) {
@@ -2143,6 +2191,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
         }
         // matrices a cluster launch gave up on (never on a GPU the launch fits on): redone by one workgroup each instead of NaN results
         hipLaunchKernelGGL(eigh_tridiag_repair_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B);
+        if (c2_first >= 0) hipLaunchKernelGGL(eigh_tridiag_repair2_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B, c2_first);
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }

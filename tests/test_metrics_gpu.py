@@ -531,13 +531,17 @@ def test_cluster_tridiagonalisation_give_up_is_repaired_not_poisoned(tmp_path):
     import subprocess
     import sys
     res = []
-    for k in ('3', '0'):
+    for k in ('3', '0', '-3'):
         out = str(tmp_path / ('repair_%s.npy' % k))
         subprocess.run([sys.executable, '-c', _REPAIR_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_FAIL_EVERY=k), timeout=240)
         res.append(np.load(out))
-    forced, plain = res
+    forced, plain, forced2 = res
     assert forced[0] == 3 and forced[4] == 2 and plain[0] == 0 and plain[4] == 0           # matrices 0, 3, 6 of 8; 0, 3 of 5
-    for r in (forced, plain):
+    # -3: the give-up happens in the SECOND cluster stage (two workgroups per matrix, from 320 rows on; n = 300 has no such stage): the
+    # matrix restarts from the first stage's hand-over (eigh_tridiag_repair2_kernel)
+    assert forced2[0] == 3 and forced2[4] == 0
+    np.testing.assert_allclose(forced2[8:12], plain[8:12], rtol=1e-6)
+    for r in (forced, plain, forced2):
         for o in (0, 4):
             assert r[o + 1] < 1e-13 and r[o + 2] < 1e-8 and r[o + 3] < 1e-11
     np.testing.assert_allclose(forced[8:12], plain[8:12], rtol=1e-6)                       # SIIB raw scores (float32 outputs)
