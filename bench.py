@@ -460,10 +460,11 @@ def main():
             # D.conv5 weight gradient: dW[64][3888] = dY^T im2col(X), an MFMA-bound GEMM (arithmetic intensity ~1000 FLOP/B)
             w_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof_w) / len(prof_w)
             w_flops = flops                                            # same M, N, K as the forward pass
-            out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_tile16_kernel<4,7> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
+            out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_dma_kernel<4,11,3> + wgrad_reduce_kernel (%s: Conv2d 48->64 9x9 weight gradient)' % wtag,
                                      'achieved': w_flops / (w_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                                      'frac': w_flops / (w_ms * 1e-3) / 1e12 / peak,
-                                     'traffic': (pmc.get('conv_wgrad_tile16_kernel<4, 7, true, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, true>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, false>') or pmc.get('conv_wgrad_tile16_kernel<4, 7>') or {}).get('hbm_bytes_corrected'),
+                                     'traffic': (pmc.get('conv_wgrad_dma_kernel<4, 11, 3>') or pmc.get('conv_wgrad_dma_kernel<4, 11, 2>') or pmc.get('conv_wgrad_tile16_kernel<4, 7, true, true>') or {}).get('hbm_bytes_corrected'),
+                                     'mfma_busy_frac': (pmc.get('conv_wgrad_dma_kernel<4, 11, 3>') or pmc.get('conv_wgrad_dma_kernel<4, 11, 2>') or {}).get('mfma_busy_frac'),
                                      'algorithmic_bytes': prof_w[0][2], 'launch_ms': w_ms, 'launches_timed': len(prof_w)}
         if hbm_ms:
             # HASPI signal filter bank (pass 2) + compression gain + gain low-pass + dB SL + IHC pass 1, one launch per signal per step - the

@@ -3,7 +3,7 @@
 #   kernel trace + stats (multi-stream and NELE_SERIAL=1), FETCH_SIZE and WRITE_SIZE in separate PMC passes, one SQ pass (MFMA busy).
 # The bench runs with --no-isolated / no companions / no CPU leg: the kernel statistics hold the timed steps' own launches only
 # (1 warm-up + 3 timed steps = 4 steps).  Summaries -> gpurun_out/<round>_prof/  (copy what is to be judged into profiles/<round>/)
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}_prof; rm -rf $O; mkdir -p $O
 ARGS="--steps 3 --warmup 1 --cpu-utts 0 --companions 0 --no-isolated"
 cd /tmp
