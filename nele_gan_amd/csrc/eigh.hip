@@ -1550,6 +1550,7 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
 #ifndef IV_B
 #define IV_B 16     // backward-sweep chunk (steps)
 #endif
+#ifdef NELE_AB                                          // superseded variant: only in the test library (libnele_hip_ab.so)
 __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const double* __restrict__ lam_in, int extra) {
     __shared__ double d[EG_MAXN], e[EG_MAXN];
     const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
@@ -1786,6 +1787,258 @@ __global__ __launch_bounds__(64) void eigh_invit_kernel(int n, EighWs ws, const 
     }
 #undef LUP
 #undef LUE
+}
+#endif  // NELE_AB
+
+// ------------------------------------------------------------------------------------------ e3, round 4: factors recomputed, not stored
+// eigh_invit_kernel above keeps the LU factors of T - x I (b, the multipliers c, 1 / pivot) in global work arrays and moves 57 KB per
+// eigenvector at the HBM rate the chip sustains (6.2 GB per 256 matrices, 1.39 ms): the kernel is bound by exactly that traffic while its
+// arithmetic units idle.  The factorisation is a three-value forward recurrence (a, b, scale1) over d and e, which sit in LDS - a few
+// multiply-adds, a compare and one division per step.  This kernel stores NOTHING of it but a checkpoint (a, b, scale1) every IV2_C
+// steps (53 doubles per eigenvector where the arrays took 1260): the forward elimination of a later sweep recomputes the factors in
+// lock-step, the back substitution recomputes each chunk of IV2_C steps forward from its checkpoint into registers and then walks it
+// backwards.  Same operations on the same operands in the same order as the stored form - bit-identical eigenvectors (A/B test against
+// eigh_invit_kernel, which stays in the test library) - with the iterate as the only array that travels: 30 KB per eigenvector.
+#ifndef IV2_C
+#define IV2_C 16           // steps per checkpoint / back-substitution chunk (registers: two factor values per step)
+#endif
+#ifndef IV2_OCC
+#define IV2_OCC 2          // waves per SIMD the register budget is cut for (measured: 16 / 2 868 us, 8 / 3 949, 8 / 4 1061, 32 / 1 1348 per 256 matrices)
+#endif
+#ifndef IV2_FC
+#define IV2_FC 8           // iterate elements per prefetch chunk of the forward sweep
+#endif
+__global__ __launch_bounds__(64, IV2_OCC) void eigh_invit2_kernel(int n, EighWs ws, const double* __restrict__ lam_in, int extra) {
+    __shared__ double d[EG_MAXN], e[EG_MAXN];
+    const int b = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < n; i += 64) { d[i] = ws.d[(size_t)b * n + i]; e[i] = ws.e[(size_t)b * n + i]; }
+    __syncthreads();
+    if (j >= n) return;
+    const int npairs = (n + 2) >> 1;
+    double2* lub = reinterpret_cast<double2*>(ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN);
+    double* z = ws.zt + (size_t)b * n * EG_MAXN + j;
+    // the iterate: array 4 of the old layout ([pair][thread][2]); checkpoints: arrays 0 .. 2 reused as [chunk][3][thread]
+#define X2P(pr) lub[((size_t)4 * npairs + (pr)) * EG_MAXN + j]
+#define X2E(i) (reinterpret_cast<double*>(&X2P((i) >> 1))[(i) & 1])
+    double* ckp = reinterpret_cast<double*>(lub) + j;
+#define CK2(c, q) ckp[((size_t)(c) * 3 + (q)) * EG_MAXN]
+    const double eps = 2.220446049250313e-16, sfmin = 2.2250738585072014e-308, bignum = 1.0 / sfmin;
+    double xj;
+    {   // dstein: shifts closer than 10 eps |x| to their (already separated) predecessor are pushed apart
+        const double* lam = lam_in + (size_t)b * n;
+        int s0 = j;
+        while (s0 > 0 && lam[s0] - lam[s0 - 1] < 10.0 * fabs(eps * lam[s0]) && j - s0 < 64) --s0;
+        double prev = lam[s0];
+        for (int i = s0 + 1; i <= j; ++i) {
+            double x = lam[i];
+            const double pertol = 10.0 * fabs(eps * x);
+            if (x - prev < pertol) x = prev + pertol;
+            prev = x;
+        }
+        xj = prev;
+    }
+    double onenrm = fabs(d[0]) + (n > 1 ? fabs(e[0]) : 0.0);
+    if (n > 1) onenrm = fmax(onenrm, fabs(d[n - 1]) + fabs(e[n - 2]));
+    for (int i = 1; i < n - 1; ++i) onenrm = fmax(onenrm, fabs(d[i]) + fabs(e[i - 1]) + fabs(e[i]));
+    const double dtpcrt = sqrt(0.1 / (double)n);
+    const unsigned int rs0 = 0x9E3779B9u * (unsigned)(j + 1) + 12345u;
+    auto lcg = [](unsigned int& rs) {
+        rs = rs * 1664525u + 1013904223u;
+        return ((double)(rs >> 8) / 8388608.0) - 1.0;
+    };
+    // one step of dlagtf (LU of T - xj I with partial pivoting): (acur, bcur, scale1) -> the same after step k; outputs of the step
+    struct Fst { double acur, bcur, scale1; };
+    auto fact = [&](int k, Fst& st, double& a_out, double& b_out, double& c_out, double& d2_out, double& r, bool& swapped) {
+        // branch-free form of eigh_invit_kernel's three-way step (same expressions, selected): the lanes of a wave take different
+        // branches at almost every step, and one IEEE division per step instead of one per taken branch is what this kernel is bound by
+        const double ak = st.acur, bk = st.bcur, ak1 = d[k + 1] - xj, ck = e[k];
+        const double bk1 = (k < n - 2) ? e[k + 1] : 0.0;
+        const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
+        const bool czero = (ck == 0.0);
+        swapped = !czero && !(ak != 0.0 && fabs(ck) * st.scale1 <= fabs(ak) * scale2);
+#ifdef IV2_FASTDIV
+        {   // reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp, not correctly rounded: NOT bit-identical with the stored-factor kernel)
+            const double pv_ = swapped ? ck : ak;
+            double r_ = __builtin_amdgcn_rcp(pv_);
+            r_ = r_ * (2.0 - pv_ * r_);
+            r_ = r_ * (2.0 - pv_ * r_);
+            r = r_;
+        }
+#else
+        r = 1.0 / (swapped ? ck : ak);
+#endif
+        const double cn = czero ? ck : ck * r;              // no interchange: multiplier (ck itself, i.e. zero, when ck == 0)
+        const double an = czero ? ak1 : ak1 - cn * bk;
+        const double mult = ak * r;                          // interchange
+        const double as = bk - mult * ak1, bs = -mult * bk1;
+        a_out = swapped ? ck : ak;
+        b_out = swapped ? ak1 : bk;
+        c_out = swapped ? mult : cn;
+        d2_out = swapped ? bk1 : 0.0;
+        st.scale1 = swapped ? st.scale1 : scale2;
+        st.acur = swapped ? as : an;
+        st.bcur = swapped ? bs : bk1;
+    };
+    const Fst st0 = {d[0] - xj, (n > 1) ? e[0] : 0.0, fabs(d[0] - xj) + ((n > 1) ? fabs(e[0]) : 0.0)};
+    double asum = 0.0, s2 = 0.0;
+    {
+        unsigned int rs = rs0;
+        for (int i = 0; i < n; ++i) asum += fabs(lcg(rs));
+    }
+    // ---- factorisation + the first forward elimination (on the unscaled start vector: see eigh_invit_kernel); checkpoints, masks
+    double tol = 0.0, alast, rlast;
+    {
+        Fst st = st0;
+        unsigned int rs = rs0;
+        double yprev = lcg(rs);
+        for (int k = 0; k < n - 1; ++k) {
+            if ((k & (IV2_C - 1)) == 0) { CK2(k / IV2_C, 0) = st.acur; CK2(k / IV2_C, 1) = st.bcur; CK2(k / IV2_C, 2) = st.scale1; }
+            double a_out, b_out, c_out, d2_out, r;
+            bool swapped;
+            fact(k, st, a_out, b_out, c_out, d2_out, r, swapped);
+            const double y = lcg(rs);
+            if (!swapped) { X2E(k) = yprev; yprev = y - c_out * yprev; }
+            else { X2E(k) = y; yprev = yprev - c_out * y; }
+            tol = fmax(fmax(tol, fabs(a_out)), fmax(fabs(b_out), fabs(d2_out)));
+        }
+        if (((n - 1) & (IV2_C - 1)) == 0) { CK2((n - 1) / IV2_C, 0) = st.acur; CK2((n - 1) / IV2_C, 1) = st.bcur; CK2((n - 1) / IV2_C, 2) = st.scale1; }
+        rlast = 1.0 / st.acur;
+        X2E(n - 1) = yprev;
+        alast = fabs(st.acur);
+        tol = fmax(tol, alast) * eps;
+        if (tol == 0.0) tol = eps;
+    }
+    const int cbtop = (n - 1) / IV2_C;                 // backward chunks over k, cb = cbtop .. 0
+    int nrmchk = 0;
+    for (int its = 0; its < 8; ++its) {
+        const double scl = (double)n * onenrm * fmax(eps, alast) / asum;
+        // ---- forward elimination: the factors are recomputed in lock-step (element t meets the multiplier of step t - 1)
+        if (its > 0) {
+            Fst st = st0;
+            double yprev = scl * X2E(0);
+            constexpr int FC = IV2_FC;
+            const int nfc = (n + FC - 1) / FC;
+            auto fload = [&](int ci, double2 (&yk)[FC / 2]) {
+#pragma unroll
+                for (int u = 0; u < FC / 2; ++u) yk[u] = X2P(min((FC / 2) * ci + u, npairs - 1));
+            };
+            auto fproc = [&](int ci, const double2 (&yk)[FC / 2]) {
+#pragma unroll
+                for (int u = 0; u < FC; ++u) {
+                    const int t = FC * ci + u;
+                    if (t >= 1 && t <= n - 1) {
+                        double a_out, b_out, c_out, d2_out, r;
+                        bool swapped;
+                        fact(t - 1, st, a_out, b_out, c_out, d2_out, r, swapped);
+                        const double y = scl * ((u & 1) ? yk[u >> 1].y : yk[u >> 1].x);
+                        if (!swapped) { X2E(t - 1) = yprev; yprev = y - c_out * yprev; }
+                        else { X2E(t - 1) = y; yprev = yprev - c_out * y; }
+                    }
+                }
+            };
+            double2 yA[FC / 2], yB[FC / 2];
+            fload(0, yA);
+            for (int ci = 0; ci < nfc; ci += 2) {
+                if (ci + 1 < nfc) fload(ci + 1, yB);
+                fproc(ci, yA);
+                if (ci + 1 < nfc) {
+                    if (ci + 2 < nfc) fload(ci + 2, yA);
+                    fproc(ci + 1, yB);
+                }
+            }
+            X2E(n - 1) = yprev;
+        }
+        // ---- back substitution, perturbing tiny pivots (job = -1): per chunk, factors forward from the checkpoint, then backwards
+        const double sclb = (its == 0) ? scl : 1.0;
+        double y1 = 0.0, y2 = 0.0;   // x[k+1], x[k+2]
+        double nrm = 0.0;
+        asum = 0.0;
+        s2 = 0.0;
+        {
+            auto bload = [&](int cb, double2 (&xr)[IV2_C / 2], Fst& ck) {
+#pragma unroll
+                for (int u = 0; u < IV2_C / 2; ++u) xr[u] = X2P(min((IV2_C / 2) * cb + u, npairs - 1));
+                ck.acur = CK2(cb, 0); ck.bcur = CK2(cb, 1); ck.scale1 = CK2(cb, 2);
+            };
+            auto bproc = [&](int cb, const double2 (&xr)[IV2_C / 2], Fst st) {
+                double rr[IV2_C], bb[IV2_C];
+                unsigned sw = 0;
+#pragma unroll
+                for (int u = 0; u < IV2_C; ++u) {
+                    const int k = IV2_C * cb + u;
+                    rr[u] = 0.0; bb[u] = 0.0;
+                    if (k <= n - 2) {
+                        double a_out, c_out, d2_out;
+                        bool swapped;
+                        fact(k, st, a_out, bb[u], c_out, d2_out, rr[u], swapped);
+                        if (swapped) sw |= 1u << u;
+                    } else if (k == n - 1) rr[u] = rlast;
+                }
+#pragma unroll
+                for (int u = IV2_C - 1; u >= 0; --u) {
+                    const int k = IV2_C * cb + u;
+                    if (k <= n - 1) {
+                        const double xv = (u & 1) ? xr[u >> 1].y : xr[u >> 1].x;
+                        const double rv = rr[u], bv = bb[u];
+                        const double dv = (k <= n - 3 && ((sw >> u) & 1u)) ? e[k + 1] : 0.0;
+                        double temp = sclb * xv - ((k <= n - 2) ? bv : 0.0) * y1 - ((k <= n - 3) ? dv : 0.0) * y2;
+                        double xk = temp * rv;
+                        if (!(fabs(xk) <= bignum)) {                   // slow path: the reference's pivot perturbation
+                            double ak = 1.0 / rv;
+                            double pert = copysign(tol, ak);
+                            for (int guard = 0; guard < 200; ++guard) {
+                                const double absak = fabs(ak);
+                                if (absak < 1.0) {
+                                    if (absak < sfmin) {
+                                        if (absak == 0.0 || fabs(temp) * sfmin > absak) { ak += pert; pert *= 2.0; continue; }
+                                        temp *= bignum;
+                                        ak *= bignum;
+                                    } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
+                                }
+                                break;
+                            }
+                            xk = temp / ak;
+                        }
+                        X2E(k) = xk;
+                        y2 = y1;
+                        y1 = xk;
+                        nrm = fmax(nrm, fabs(xk));
+                        asum += fabs(xk);
+                        s2 += xk * xk;
+                    }
+                }
+            };
+            double2 xA[IV2_C / 2], xB[IV2_C / 2];
+            Fst cA, cB;
+            bload(cbtop, xA, cA);
+            for (int cb = cbtop; cb >= 0; cb -= 2) {
+                if (cb - 1 >= 0) bload(cb - 1, xB, cB);
+                bproc(cb, xA, cA);
+                if (cb - 1 >= 0) {
+                    if (cb - 2 >= 0) bload(cb - 2, xA, cA);
+                    bproc(cb - 1, xB, cB);
+                }
+            }
+        }
+        if (nrm < dtpcrt) continue;
+        if (++nrmchk < extra + 1) continue;   // dstein: EXTRA more sweeps after the growth criterion is met
+        break;
+    }
+    const double inv = 1.0 / sqrt(s2);
+    for (int p0 = 0; p0 < npairs; p0 += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = X2P(min(p0 + u, npairs - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 2 * (p0 + u);
+            if (i < n) z[(size_t)i * EG_MAXN] = t[u].x * inv;
+            if (i + 1 < n) z[(size_t)(i + 1) * EG_MAXN] = t[u].y * inv;
+        }
+    }
+#undef X2P
+#undef X2E
+#undef CK2
 }
 
 // ------------------------------------------------------------------------------------------ e4
@@ -2200,7 +2453,9 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     // bisected to 1 ulp one is enough for every test matrix (eigenvalues 1e-13, residual 1e-11, orthogonality 1e-8, SIIB unchanged to 17
     // digits) and saves a quarter of this kernel's HBM traffic (its work arrays: 108 KB per eigenvector); 0 fails the residual test
     const int iv_extra = NELE_SWITCH_INT("NELE_EIGH_INVIT_EXTRA", 1);
-    hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);
+    // NELE_EIGH_INVIT_STORE=1 (test library): the kernel that stores the LU factors instead of recomputing them (bit-identical; 6.2 GB per 256 matrices)
+    if (NELE_SWITCH_INT("NELE_EIGH_INVIT_STORE", 0)) { NELE_AB_ONLY(hipLaunchKernelGGL(eigh_invit_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);) }
+    else hipLaunchKernelGGL(eigh_invit2_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, n, ws, lam, iv_extra);
     const size_t lds = sizeof(double) * (2 * (size_t)BT_CH * 16 * (n <= 448 ? 28 : 32) + 2 * BT_CH);
     const int wy_on = NELE_SWITCH_INT("NELE_EIGH_WY", 1);   // =0: the reflector-by-reflector back-transformation (A/B diagnostic)
     NELE_ONCE_PER_DEVICE({

@@ -546,3 +546,36 @@ def test_cluster_tridiagonalisation_give_up_is_repaired_not_poisoned(tmp_path):
             assert r[o + 1] < 1e-13 and r[o + 2] < 1e-8 and r[o + 3] < 1e-11
     np.testing.assert_allclose(forced[8:12], plain[8:12], rtol=1e-6)                       # SIIB raw scores (float32 outputs)
     assert np.all(forced[12:] == plain[12:]) and np.all(np.isfinite(forced))
+
+
+_INVIT_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt
+out = []
+for n, B in ((420, 3), (257, 2), (64, 2), (17, 2)):
+    rs = np.random.RandomState(1000 + n)
+    A = np.zeros((B, n, n))
+    for b in range(B):
+        G = rs.randn(n, 3 * n) * np.exp(-0.01 * np.arange(3 * n))[None, :]
+        A[b] = G @ G.T / (3 * n)
+    lam, U = mt.eigh_batched(torch.from_numpy(A).cuda())
+    out += [lam.cpu().numpy().ravel(), U.cpu().numpy().ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_inverse_iteration_with_recomputed_factors_is_bit_identical_to_the_stored_form(tmp_path):
+    """Round 4: eigh_invit2_kernel keeps no LU factors (b, multipliers, 1 / pivot: 57 KB of traffic per eigenvector, the kernel was
+    HBM-bound on them) but a checkpoint of the three-value forward recurrence every 16 steps, recomputes the factors in lock-step with
+    the forward elimination and chunk by chunk ahead of the back substitution: the same operations on the same operands in the same
+    order.  A/B against eigh_invit_kernel (NELE_EIGH_INVIT_STORE=1, test library) at n with partial last chunks / pairs: eigenvalues and
+    eigenvectors bit for bit."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('0', '1'):
+        out = str(tmp_path / ('invit_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _INVIT_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_INVIT_STORE=flag), timeout=240)
+        res.append(np.load(out))
+    assert np.all(np.isfinite(res[0])) and res[0].tobytes() == res[1].tobytes()

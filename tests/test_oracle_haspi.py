@@ -137,3 +137,16 @@ def test_hearing_loss_oracle_matches_the_reference(golden_dir):
         np.testing.assert_allclose([q[0], q[1], q[2]] + list(q[3]), G[tag + '_hasqi'], rtol=1e-10)
     with pytest.raises(NotImplementedError):
         H.ear_model(x, 24000, y, 24000, HL=HL_MILD, itype=1)             # NAL-R: eb_NALR raises in the reference too
+
+
+def test_per_utterance_dither_rows_are_a_pure_function_of_seed_and_id():
+    """oracle/haspi.py:dither_rows (the numpy statement of csrc/haspi.hip:haspi_dither_rows_kernel; the GPU test compares the two):
+    standard normals per (signal, frame, channel), reproducible, independent of how many frames are asked for, different per id / seed."""
+    a = H.dither_rows(123456789012, 11, 400)
+    assert a.shape == (2, 400, 32) and a.dtype == np.float64
+    np.testing.assert_array_equal(a, H.dither_rows(123456789012, 11, 400))
+    np.testing.assert_array_equal(a[:, :150], H.dither_rows(123456789012, 11, 150))          # row k does not depend on nsub
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02 and np.abs(a).max() < 6.0
+    assert abs(np.corrcoef(a[0].ravel(), a[1].ravel())[0, 1]) < 0.03                           # x rows and y rows are different draws
+    b, c = H.dither_rows(123456789013, 11, 400), H.dither_rows(123456789012, 12, 400)
+    assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 0.03 and abs(np.corrcoef(a.ravel(), c.ravel())[0, 1]) < 0.03
