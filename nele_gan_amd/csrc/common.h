@@ -134,6 +134,16 @@ __device__ __forceinline__ double lane_xor32(double v) {
     return __longlong_as_double(((long long)h << 32) | (long long)l);
 }
 
+// value held by lane (l ^ 16): v_permlane16_swap (gfx950), no LDS crossbar
+__device__ __forceinline__ double lane_xor16(double v) {
+    const long long u = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    const bool up = (threadIdx.x & 16) != 0;
+    const unsigned l = up ? lo[0] : lo[1], h = up ? hi[0] : hi[1];
+    return __longlong_as_double(((long long)h << 32) | (long long)l);
+}
+
 // Block-wide sum of doubles through LDS scratch (>= blockDim/64 doubles); result to all threads.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     v = wave_sum(v);

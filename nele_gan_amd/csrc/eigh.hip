@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #define EG_MAXN 512
+#define EG_XCH 8        // tagged exchange slot blocks per matrix: 2 parities x up to 4 kinds (the symmetric first stage uses all)
 
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 struct EighWs {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
     double* tau = ws.tau + (size_t)b * n;
-    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;   // [parity][0: A v | 1: raw pivot column][EG_MAXN]
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * EG_XCH * EG_MAXN;   // [parity][0: A v | 1: raw pivot column][EG_MAXN]
 
     // thread tile: 2 columns x 32 rows.  column slots cl0 = lane & 31, cl0 + 32 (c = p + 8 * slot); row slot rs = 2 * wave + (lane >> 5),
     // rows r = rs + 16 * ri: the 32 lanes of a half-wave share their row values (LDS broadcast), each row value feeds 2 columns.
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
     double* tau = ws.tau + (size_t)b * n;
-    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * EG_XCH * EG_MAXN;
 
     const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
     const int c0 = p + E4_P * cl0, c1 = c0 + E4_P * 32, c2 = c0 + E4_P * 64, c3 = c0 + E4_P * 96;
@@ -706,6 +707,372 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ e1, first cluster stage on the LOWER TRIANGLE: 2 workgroups per matrix
+// Round 4.  eigh_tridiag_cluster4_kernel holds the full 420 x 420 trailing matrix in the registers of four CUs - 64 matrices fill the
+// chip.  The matrix is symmetric: its lower triangle (incl. the diagonal) fits TWO register files + 108 KB of LDS, so 128 matrices run
+// per launch and a batch of 256 takes two rounds of the latency chain instead of four.  Same algorithm, exchange protocol, records
+// and hand-over as the four-workgroup kernel; what changes is the fused pass:
+//   * a thread (row class rs = 16 classes, column class cl0 = 32 classes; workgroup p owns the columns c = p + 2 (cl0 + 32 j)) stores
+//     element (r, c) only for r >= c: column slot j holds the row slots ri = 4 j .. 26 (r = rs + 16 ri), 105 slots per thread - 78 in
+//     registers (j = 1 .. 6), the 27 of j = 0 in LDS (those columns are eliminated first: the LDS traffic ends after 64 steps); the
+//     (at most four) slots of a column that lie above the diagonal are kept at exactly zero;
+//   * y = A v_next needs BOTH directions now: the column sums sum_{r >= c} x_rc n_r as before (over a thread's row slots, then over the
+//     16 row classes through LDS) and the row sums sum_{c < r} x_rc n_c - over a thread's 7 column slots, then over the 32 column
+//     classes of a half wave by a reduce-scatter butterfly (lane xor 16 through the LDS crossbar, then row_ror:8 / row_half_mirror /
+//     two quad permutations: 31 exchanged values per lane), after which lane cl0 holds the complete row sum of row slot ri = cl0;
+//   * the exchange carries four kinds of tagged slots per step: column partial of the owner, row partial of each workgroup, and the
+//     next pivot COLUMN (the lower triangle holds column s + 2 from the diagonal down: it equals the pivot row), published by the 16
+//     threads of the owning workgroup that hold it.  p_i = (column partial + row partial 0) + row partial 1, the same on both sides.
+#define ECS_P 2
+#define ECS_RI 27
+#define ECS_LD 28                       // row-vector stride per row class (even: double2 reads)
+#define ECS_NJ 7
+#define ECS_NREG 78                     // slots of j = 1 .. 6
+__host__ __device__ constexpr int ecs_off(int j) { return j == 1 ? 0 : j == 2 ? 23 : j == 3 ? 42 : j == 4 ? 57 : j == 5 ? 68 : 75; }
+__host__ __device__ constexpr int ecs_len(int j) { return ECS_RI - 4 * j; }
+
+#ifdef ECS_PROF
+__device__ unsigned long long ecs_prof[8];     // shader clocks of thread 0 of workgroup 0 per phase, summed over the steps (diagnostic build)
+#define ECS_T(j) do { const unsigned long long t1_ = __builtin_readcyclecounter(); pacc_[j] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define ECS_T(j)
+#endif
+__global__ __launch_bounds__(512) void eigh_tridiag_clusters_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop, int fail_every) {
+    extern __shared__ double ecs_col[];                    // aL[ECS_RI][16][32]: column slot j = 0 of every lane
+    __shared__ __attribute__((aligned(16))) double vperm[3][16 * ECS_LD];   // v, w, v_next at [(r & 15) * ECS_LD + (r >> 4)]
+    __shared__ double accb[16][32 * ECS_NJ];
+    __shared__ double prow[16 * ECS_LD];                   // the next pivot column on its way from its 16 holders to one publishing thread per row
+    __shared__ double red0[8], red1[8];
+    __shared__ double s_alpha, s_ppiv;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = g >> 3, p = slot & 1, mloc = (g & 7) + 8 * (slot >> 1);
+    if (mloc >= Bc) return;
+    const int b = b0 + mloc;
+    if (fail_every > 0 && b % fail_every == 0) {           // test hook (see eigh_tridiag_cluster4_kernel)
+        if (tid == 0 && p == 0) ws.flag[b] = 1;
+        return;
+    }
+    double* A = Aall + (size_t)b * n * n;
+    double* d = ws.d + (size_t)b * n;
+    double* e = ws.e + (size_t)b * n;
+    double* tau = ws.tau + (size_t)b * n;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * EG_XCH * EG_MAXN;
+    double (*aL)[16][32] = reinterpret_cast<double (*)[16][32]>(ecs_col);
+
+    const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
+    const int t0 = p + 2 * cl0 - rs;                       // slot k of a column is on / below the diagonal iff 16 k >= t0
+    const int kmin = t0 <= 0 ? 0 : (t0 + 15) >> 4;         // 0 .. 4
+    const int kdiag = (t0 >= 0 && (t0 & 15) == 0) ? (t0 >> 4) : -1;   // the slot that IS the diagonal element (every column alike)
+    int cc[ECS_NJ];
+#pragma unroll
+    for (int j = 0; j < ECS_NJ; ++j) cc[j] = p + ECS_P * (cl0 + 32 * j);
+    double a[ECS_NREG];
+    // ---- load the lower triangle (r >= c)
+#pragma unroll
+    for (int k = 0; k < ECS_RI; ++k) {
+        const int r = rs + 16 * k;
+        aL[k][rs][cl0] = (k >= kmin && r < n && cc[0] < n) ? A[(size_t)r * n + cc[0]] : 0.0;
+    }
+#pragma unroll
+    for (int j = 1; j < ECS_NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < ecs_len(j); ++k) {
+            const int r = rs + 16 * (4 * j + k);
+            a[ecs_off(j) + k] = (k >= kmin && r < n && cc[j] < n) ? A[(size_t)r * n + cc[j]] : 0.0;
+        }
+    const int i = tid;
+    const int pi = (i & 15) * ECS_LD + (i >> 4);           // permuted slot of vector element i (i < 16 * ECS_LD = 448)
+    double v_i = 0.0, tk = 0.0, p_i = 0.0;
+    double col_i = (i < n) ? A[i] : 0.0;                   // column 0 (= row 0)
+    int s_done = -2;
+#ifdef ECS_PROF
+    unsigned long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
+#endif
+    for (int s = -1; s <= n - 2; ++s) {
+        const bool in = (i >= s + 1) && (i < n);
+        double w_i = 0.0, wpiv = 0.0;
+        if (s >= 0) {
+            if (i == s + 1) s_ppiv = p_i;
+            double pv = in ? tk * p_i * v_i : 0.0;
+            pv = wave_sum_dpp(pv);
+            if (lane == 0) red0[wv] = pv;
+            __syncthreads();
+            pv = ((red0[0] + red0[1]) + (red0[2] + red0[3])) + ((red0[4] + red0[5]) + (red0[6] + red0[7]));
+            const double al = -0.5 * tk * pv;
+            w_i = in ? tk * p_i + al * v_i : 0.0;
+            wpiv = tk * s_ppiv + al;
+        }
+        const double x_i = in ? col_i - v_i * wpiv - w_i : 0.0;
+        double tn = 0.0, betan = 0.0, vn_i = 0.0;
+        if (s + 2 <= n - 1) {
+            if (i == s + 2) s_alpha = x_i;
+            double ss = (i >= s + 3 && i < n) ? x_i * x_i : 0.0;
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red1[wv] = ss;
+            __syncthreads();
+            ss = ((red1[0] + red1[1]) + (red1[2] + red1[3])) + ((red1[4] + red1[5]) + (red1[6] + red1[7]));
+            const double alpha = s_alpha;
+            double scn = 0.0;
+            betan = alpha;
+            if (ss > 0.0) {
+                const double s2 = alpha * alpha + ss, aa = fabs(alpha);
+                double y = __builtin_amdgcn_rsq(s2);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                y = y * (1.5 - 0.5 * s2 * y * y);
+                const double nrm = s2 * y;
+                betan = alpha >= 0.0 ? -nrm : nrm;
+                tn = 1.0 + aa * y;
+                const double dd = aa + nrm;
+                double r = __builtin_amdgcn_rcp(dd);
+                r = r * (2.0 - dd * r);
+                r = r * (2.0 - dd * r);
+                scn = alpha >= 0.0 ? r : -r;
+            }
+            vn_i = (i == s + 2) ? 1.0 : ((i > s + 2 && i < n) ? x_i * scn : 0.0);
+        }
+        // (the record of step -1 is deferred until after this step's exchange: see eigh_tridiag_cluster4_kernel)
+        if (s >= 0 && p == ((s + 1) & 1)) {
+            if (i == s + 1) { d[s + 1] = x_i; e[s + 1] = betan; tau[s + 1] = tn; }
+            if (i >= s + 2 && i < n) A[(size_t)(s + 1) * n + i] = vn_i;
+        }
+        if (s == n - 2) break;
+        if (i < 16 * ECS_LD) { vperm[0][pi] = v_i; vperm[1][pi] = w_i; vperm[2][pi] = vn_i; }
+        __syncthreads();
+        ECS_T(0);
+        const int lo = s + 2;                              // first live row / column
+        const int ri0 = (lo - rs + 15) >> 4;               // first live row slot of this row class
+        const double* pv0 = &vperm[0][rs * ECS_LD];
+        const double* pv1 = &vperm[1][rs * ECS_LD];
+        const double* pv2 = &vperm[2][rs * ECS_LD];
+        const double2* pq0 = reinterpret_cast<const double2*>(pv0);
+        const double2* pq1 = reinterpret_cast<const double2*>(pv1);
+        const double2* pq2 = reinterpret_cast<const double2*>(pv2);
+        double nc[ECS_NJ];                                 // v_next at this lane's columns (row-sum sweep)
+#pragma unroll
+        for (int j = 0; j < ECS_NJ; ++j) nc[j] = (cc[j] < n) ? vperm[2][(cc[j] & 15) * ECS_LD + (cc[j] >> 4)] : 0.0;
+        const bool live0 = cc[0] >= lo && cc[0] < n;       // the LDS column of this lane is still part of the trailing matrix
+        // ---- sweep 1: x = a - v_r w_c - w_r v_c (slots above the diagonal stay zero); column sums acc_c += x * vnext_r.  Row vectors as
+        // 16-byte pairs, read once per column pair (the kernel is bound by its LDS instruction count: 390 per thread and step with 8-byte
+        // reads and a crossbar shuffle for lane xor 16 - 18 us per step; a single rows-outer sweep needs 270 registers and spilled 164).
+        {   // the LDS column (j = 0); skipped once this lane's column is eliminated (c < lo: no update reaches it, its v_next is zero)
+            double acc = 0.0;
+            if (live0) {
+                const int pc = (cc[0] & 15) * ECS_LD + (cc[0] >> 4);
+                const double vc = vperm[0][pc], wc = vperm[1][pc];
+#pragma unroll
+                for (int q = 0; q < (ECS_RI + 1) / 2; ++q) {
+                    if (2 * q + 1 >= ri0) {
+                        const double2 vr = pq0[q], wr = pq1[q], nr = pq2[q];
+                        {
+                            const int k = 2 * q;
+                            double x = aL[k][rs][cl0];
+                            x -= vr.x * wc + wr.x * vc;
+                            if (k < 4 && k < kmin) x = 0.0;
+                            aL[k][rs][cl0] = x;
+                            acc += x * nr.x;
+                        }
+                        if (2 * q + 1 < ECS_RI) {
+                            const int k = 2 * q + 1;
+                            double x = aL[k < ECS_RI ? k : 0][rs][cl0];
+                            x -= vr.y * wc + wr.y * vc;
+                            if (k < 4 && k < kmin) x = 0.0;
+                            aL[k < ECS_RI ? k : 0][rs][cl0] = x;
+                            acc += x * nr.y;
+                        }
+                    }
+                }
+            }
+            accb[rs][cl0] = acc;
+        }
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {                      // register columns in pairs (2h + 1, 2h + 2)
+            const int j1 = 2 * h + 1, j2 = 2 * h + 2;
+            const bool ok1 = cc[j1] < n, ok2 = cc[j2] < n;
+            const int pc1 = ok1 ? (cc[j1] & 15) * ECS_LD + (cc[j1] >> 4) : 0, pc2 = ok2 ? (cc[j2] & 15) * ECS_LD + (cc[j2] >> 4) : 0;
+            const double vc1 = ok1 ? vperm[0][pc1] : 0.0, wc1 = ok1 ? vperm[1][pc1] : 0.0;
+            const double vc2 = ok2 ? vperm[0][pc2] : 0.0, wc2 = ok2 ? vperm[1][pc2] : 0.0;
+            double acc1 = 0.0, acc2 = 0.0;
+#pragma unroll
+            for (int q = 2 * j1; q < (ECS_RI + 1) / 2; ++q) {   // row pairs (2q, 2q + 1) from row slot 4 j1 on
+                if (2 * q + 1 >= ri0) {
+                    const double2 vr = pq0[q], wr = pq1[q], nr = pq2[q];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int ri = 2 * q + hh, k = ri - 4 * j1;
+                        if (ri < ECS_RI) {
+                            const double vrr = hh ? vr.y : vr.x, wrr = hh ? wr.y : wr.x, nrr = hh ? nr.y : nr.x;
+                            double x = a[ecs_off(j1) + (k < ecs_len(j1) ? k : 0)];
+                            x -= vrr * wc1 + wrr * vc1;
+                            if (k < 4 && k < kmin) x = 0.0;
+                            a[ecs_off(j1) + (k < ecs_len(j1) ? k : 0)] = x;
+                            acc1 += x * nrr;
+                            if (k >= 4) {                  // the same row in column j2 (its slot k - 4)
+                                const int k2 = k - 4 < 0 ? 0 : k - 4;
+                                double y = a[ecs_off(j2) + k2];
+                                y -= vrr * wc2 + wrr * vc2;
+                                if (k2 < 4 && k2 < kmin) y = 0.0;
+                                a[ecs_off(j2) + k2] = y;
+                                acc2 += y * nrr;
+                            }
+                        }
+                    }
+                }
+            }
+            accb[rs][cl0 + 32 * j1] = acc1;
+            accb[rs][cl0 + 32 * j2] = acc2;
+        }
+        ECS_T(1);
+        // ---- the next pivot column (column lo from the diagonal down = pivot row of the full matrix) is held by 16 threads of the owning
+        // workgroup, 27 entries each: they hand it to LDS, one thread per row publishes it behind the barrier below (27 tagged stores per
+        // holder took 6.7 k of the step's 39 k clocks)
+        const unsigned tag = (unsigned)(s + 3);
+        u32x4* xp = xch + (size_t)((s + 1) & 1) * 4 * EG_MAXN;
+        const bool owner = p == (lo & 1);
+        if (owner && cl0 == (((lo - p) >> 1) & 31)) {
+            const int js = ((lo - p) >> 1) >> 5;           // 0 or 1 while lo < 128 (the host hands over long before)
+            if (js == 0) {
+#pragma unroll
+                for (int k = 0; k < ECS_RI; ++k) prow[rs + 16 * k] = aL[k][rs][cl0];
+            } else {
+#pragma unroll
+                for (int k = 0; k < ecs_len(1); ++k) prow[rs + 16 * (4 + k)] = a[ecs_off(1) + k];
+            }
+        }
+        ECS_T(2);
+        // ---- sweep 2: row sums over this lane's columns (the diagonal element belongs to the column sum only), reduce-scattered over the
+        // 32 column classes of the half wave as they appear: stage A pairs row slots (t, t + 16) across lane xor 16 (v_permlane16_swap), B
+        // (t, t + 8) across xor 8 (row_ror:8), C / D / E the two mirrors and the quad swap - depth-first, one pending value per level
+        // (all sixteen stage-A values alive at once: 189 spilled registers, 40 us per step)
+        double u1;
+        {
+            const bool hi16 = (cl0 & 16) != 0, b3 = (cl0 & 8) != 0, b2 = (cl0 & 4) != 0, b1 = (cl0 & 2) != 0, b0_ = (cl0 & 1) != 0;
+            auto rowsum = [&](int ri) {                    // ri is a compile-time constant at every call site (full unroll)
+                double r = 0.0;
+#pragma unroll
+                for (int j = 0; j < ECS_NJ; ++j) {
+                    const int k = ri - 4 * j;
+                    if (ri < ECS_RI && k >= 0 && k < ecs_len(j)) {
+                        const int kk = k < 0 ? 0 : k;
+                        const double x = (j == 0) ? (live0 ? aL[kk][rs][cl0] : 0.0) : a[(j == 0 ? 0 : ecs_off(j)) + kk];
+                        const double term = x * nc[j];
+                        r += (kk < 4 && kk == kdiag) ? 0.0 : term;
+                    }
+                }
+                return r;
+            };
+            double u2[2];
+#pragma unroll
+            for (int e_ = 0; e_ < 2; ++e_) {
+                double u4[2];
+#pragma unroll
+                for (int d_ = 0; d_ < 2; ++d_) {
+                    double u8[2];
+#pragma unroll
+                    for (int c_ = 0; c_ < 2; ++c_) {
+                        double u16[2];
+#pragma unroll
+                        for (int b_ = 0; b_ < 2; ++b_) {
+                            const int t = e_ + 2 * d_ + 4 * c_ + 8 * b_;
+                            const double r1 = rowsum(t), r2 = rowsum(t + 16);
+                            const double send = hi16 ? r1 : r2, keep = hi16 ? r2 : r1;
+                            u16[b_] = keep + lane_xor16(send);
+                        }
+                        const double send = b3 ? u16[0] : u16[1], keep = b3 ? u16[1] : u16[0];
+                        u8[c_] = keep + dpp_move<0x128>(send);                                          // row_ror:8
+                    }
+                    const double send = b2 ? u8[0] : u8[1], keep = b2 ? u8[1] : u8[0];
+                    u4[d_] = keep + dpp_move<0x141>(send);                                              // row_half_mirror
+                }
+                const double send = b1 ? u4[0] : u4[1], keep = b1 ? u4[1] : u4[0];
+                u2[e_] = keep + dpp_move<0x1B>(send);                                                   // quad_perm [3,2,1,0]
+            }
+            const double send = b0_ ? u2[0] : u2[1], keep = b0_ ? u2[1] : u2[0];
+            u1 = keep + dpp_move<0xB1>(send);                                                           // quad_perm [1,0,3,2]
+        }
+        ECS_T(3);
+        // lane cl0 now holds this workgroup's row sum of row slot ri = cl0
+        {
+            const int r = rs + 16 * cl0;
+            if (cl0 < ECS_RI && r >= lo && r < n) st_tagged(&xp[(1 + p) * EG_MAXN + r], u1, tag);
+        }
+        __syncthreads();
+        if (tid < 32 * ECS_NJ) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += accb[q][tid];
+            const int c = p + ECS_P * tid;
+            if (c >= lo && c < n) st_tagged(&xp[c], t, tag);
+        }
+        if (owner && i >= lo && i < n) st_tagged(&xp[3 * EG_MAXN + i], prow[i], tag);
+        ECS_T(4);
+        const bool need = (i >= lo) && (i < n);
+        if (__any(need)) {
+            u32x4 q0, q1, q2, q3;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (need) {
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                                 : "v"(&xp[i]), "v"(&xp[EG_MAXN + i]), "v"(&xp[2 * EG_MAXN + i]), "v"(&xp[3 * EG_MAXN + i]) : "memory");
+                    ok = (q0.y == tag) && (q0.w == tag) && (q1.y == tag) && (q1.w == tag) && (q2.y == tag) && (q2.w == tag) && (q3.y == tag) && (q3.w == tag);
+                }
+                if (__all(ok)) break;
+                if (++spins > EC_SPIN_LIMIT) {             // never hang the device; eigh_tridiag_repair_kernel redoes this matrix
+                    if (i < n) d[i] = __builtin_nan("");
+                    if (tid == 0) ws.flag[b] = 1;
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (need) { p_i = (tagged_value(q0) + tagged_value(q1)) + tagged_value(q2); col_i = tagged_value(q3); }
+        }
+        ECS_T(5);
+        if (s == -1 && p == 0) {                             // deferred record of step -1
+            if (i == 0) { d[0] = x_i; e[0] = betan; tau[0] = tn; }
+            if (i >= 1 && i < n) A[i] = vn_i;
+        }
+        v_i = vn_i;
+        tk = tn;
+        if (s == s_stop) { s_done = s; break; }
+    }
+#ifdef ECS_PROF
+    if (tid == 0 && g == 0) for (int q_ = 0; q_ < 8; ++q_) ecs_prof[q_] = pacc_[q_];
+#endif
+    if (s_done >= -1 && s_done == s_stop) {
+        // hand-over to the second stage (full storage): the trailing block (rows / columns >= s_stop + 2) back to A, BOTH triangles; state to ws.zt
+        int lbv = s_stop + 2;
+        asm volatile("" : "+v"(lbv));                      // (not an invariant to hoist above the step loop: see eigh_tridiag_cluster2_kernel)
+        const int lb = lbv;
+#pragma unroll
+        for (int k = 0; k < ECS_RI; ++k) {
+            const int r = rs + 16 * k, c = cc[0];
+            if (k >= kmin && r >= lb && r < n && c >= lb && c < n) {
+                const double x = aL[k][rs][cl0];
+                A[(size_t)r * n + c] = x;
+                A[(size_t)c * n + r] = x;
+            }
+        }
+#pragma unroll
+        for (int j = 1; j < ECS_NJ; ++j)
+#pragma unroll
+            for (int k = 0; k < ecs_len(j); ++k) {
+                const int r = rs + 16 * (4 * j + k), c = cc[j];
+                if (k >= kmin && r >= lb && r < n && c >= lb && c < n) {
+                    const double x = a[ecs_off(j) + k];
+                    A[(size_t)r * n + c] = x;
+                    A[(size_t)c * n + r] = x;
+                }
+            }
+        if (p == 0 && i < n) {
+            double* st = ws.zt + (size_t)b * n * EG_MAXN;
+            st[i] = v_i; st[EG_MAXN + i] = p_i; st[2 * EG_MAXN + i] = col_i;
+            if (i == 0) st[3 * EG_MAXN] = tk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ e1, second cluster stage: 2 workgroups per matrix
 // Round 4.  The four-workgroup kernel above needs a quarter of a CU's registers per 105 columns of a 420 x 420 matrix, whatever is left
 // of it: 64 matrices fill the chip, a batch of 256 takes four rounds of the same latency chain.  Once the trailing block has shrunk
@@ -740,7 +1107,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
     double* d = ws.d + (size_t)b * n;
     double* e = ws.e + (size_t)b * n;
     double* tau = ws.tau + (size_t)b * n;
-    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * 4 * EG_MAXN;
+    u32x4* xch = reinterpret_cast<u32x4*>(ws.xch) + (size_t)b * EG_XCH * EG_MAXN;
     double (*aL)[16][32] = reinterpret_cast<double (*)[16][32]>(ec2_col);
 
     const int cl0 = lane & 31, rs = 2 * wv + (lane >> 5);
@@ -2325,12 +2692,18 @@ static size_t eigh_layout(int B, int n, EighWs* w, char* base) {
     TAKE(zt, double, (size_t)B * n * EG_MAXN);
     TAKE(lu, double, (size_t)B * 6 * (n + 2) * EG_MAXN);
     TAKE(pin, int, (size_t)B * n * EG_MAXN);
-    TAKE(xch, uint4, (size_t)B * 4 * EG_MAXN);
+    TAKE(xch, uint4, (size_t)B * EG_XCH * EG_MAXN);
     TAKE(flag, int, (size_t)B + 64);
 #undef TAKE
     return o;
 }
 
+#ifdef ECS_PROF
+extern "C" int nele_ecs_prof_read(unsigned long long* out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(ecs_prof), sizeof(unsigned long long) * 8) != hipSuccess;
+}
+#endif
 extern "C" long long nele_eigh_workspace_bytes(int B, int n) { return (long long)eigh_layout(B, n, nullptr, nullptr); }
 
 // Matrices of the LAST nele_eigh_sym_batched call on this workspace that the cluster tridiagonalisation gave up on and the single-workgroup
@@ -2377,7 +2750,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     }
     int c2_first = -1;                                     // first step of the second cluster stage when it runs (its give-ups are repaired from there)
     if (cluster_cap >= 8) {
-        if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * 4 * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
+        if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * EG_XCH * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         if (hipMemsetAsync(ws.flag, 0, sizeof(int) * ((size_t)B + 1), s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in
         // two half-size launches, which leaves half of the CUs to the other streams (measured 2 % on the whole step at B = 32)
@@ -2400,6 +2773,11 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
                                                            (int)(sizeof(double) * EC2_RI * 16 * 32)));
             const bool two_stage = c2_on && s_stop >= 0 && mhand < EC2_M && n > EC2_M + 8;
             const int s_stop1 = two_stage ? n - EC2_M - 2 : s_stop;
+            // first stage on the lower triangle with two workgroups per matrix (round 4; NELE_EIGH_SYM=0: the four-workgroup full-storage kernel)
+            const int sym_on = NELE_SWITCH_INT("NELE_EIGH_SYM", 1);
+            NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_clusters_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)(sizeof(double) * ECS_RI * 16 * 32)));
+            const bool sym_stage = sym_on && two_stage && n <= 16 * ECS_RI && s_stop1 + 2 < 128;
             // NELE_EIGH_P4_BATCH: matrices per launch (32 = half of the chip inside a training step, 64 = all of it otherwise).  The spinning workgroups own
             // their CU - registers full, issue slots mostly idle - so 32 per launch (twice the launches) leaves room for the step's other
             // streams while the chain's own time doubles (8 x 1.2 instead of 4 x 1.2 ms per 256 matrices).  Measured twice on the
@@ -2413,6 +2791,15 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             const int hint = cluster_batch;
             const int p4_batch = p4_env ? p4_env : (hint >= 8 && hint <= 64 ? hint / 8 * 8 : 64);
             const int fail_every = NELE_SWITCH_INT("NELE_EIGH_FAIL_EVERY", 0);                     // NELE_EIGH_FAIL_EVERY=k (tests): every k-th matrix takes the give-up / repair path
+            if (sym_stage) {
+                const int cs_batch = 2 * p4_batch;
+                for (int b0 = 0; b0 < B; b0 += cs_batch) {
+                    const int Bc = (B - b0 < cs_batch) ? B - b0 : cs_batch;
+                    NELE_PROF("eigh_tridiag_cluster", s,
+                              hipLaunchKernelGGL(eigh_tridiag_clusters_kernel, dim3(16 * ((Bc + 7) / 8)), dim3(512), sizeof(double) * ECS_RI * 16 * 32, s, A, n, b0, Bc,
+                                                 ws, s_stop1, fail_every));
+                }
+            } else
             for (int b0 = 0; b0 < B; b0 += p4_batch) {
                 const int Bc = (B - b0 < p4_batch) ? B - b0 : p4_batch;
                 NELE_PROF("eigh_tridiag_cluster", s,

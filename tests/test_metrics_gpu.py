@@ -579,3 +579,55 @@ def test_inverse_iteration_with_recomputed_factors_is_bit_identical_to_the_store
         subprocess.run([sys.executable, '-c', _INVIT_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_INVIT_STORE=flag), timeout=240)
         res.append(np.load(out))
     assert np.all(np.isfinite(res[0])) and res[0].tobytes() == res[1].tobytes()
+
+
+_SYM_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt, synth
+out = []
+for n, B in ((420, 5), (432, 2), (400, 3), (340, 2)):
+    rs = np.random.RandomState(2000 + n)
+    A = np.zeros((B, n, n))
+    for b in range(B):
+        G = rs.randn(n, 3 * n) * np.exp(-0.01 * np.arange(3 * n))[None, :]
+        A[b] = G @ G.T / (3 * n)
+    lam, U = mt.eigh_batched(torch.from_numpy(A).cuda())
+    lam, U = lam.cpu().numpy(), U.cpu().numpy()
+    worst = [0.0, 0.0]
+    for b in range(B):
+        V = U[b].T
+        worst[0] = max(worst[0], np.abs(V.T @ V - np.eye(n)).max())
+        worst[1] = max(worst[1], np.abs(A[b] @ V - V * lam[b][None, :]).max() / np.abs(lam[b]).max())
+    out += [lam.ravel() / np.abs(lam).max(), np.array(worst)]
+c, v = synth.batch(3, 40000, start=95)
+raw, _, info = mt.batch_siib(c, 0.8 * c + v, return_info=True)
+out += [raw.double().cpu().numpy(), info.double().cpu().numpy().ravel()]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_symmetric_first_cluster_stage_agrees_with_the_full_storage_kernel(tmp_path):
+    """Round 4: the first tridiagonalisation stage holds only the LOWER triangle of the trailing matrix (two workgroups per matrix instead
+    of four: column sums as before, row sums by a reduce-scatter over the 32 column classes of a half wave, four kinds of exchange
+    slots).  Same Householder recurrences in another summation order: eigenvalues agree with the four-workgroup full-storage kernel
+    (NELE_EIGH_SYM=0, test library) to 1e-13 of the largest, orthogonality / residual stay at their level, SIIB scores to float32
+    precision; n = 432 is the largest order the layout takes (27 row slots of 16), 340 has only 18 first-stage steps."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('sym_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _SYM_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_SYM=flag), timeout=240)
+        res.append(np.load(out))
+    a, b = res
+    assert a.shape == b.shape and np.all(np.isfinite(a))
+    nl = 420 * 5 + 2 + 432 * 2 + 2 + 400 * 3 + 2 + 340 * 2 + 2
+    np.testing.assert_allclose(a[:nl], b[:nl], rtol=0, atol=1e-8)          # (includes the orthogonality / residual pairs, all < 1e-8)
+    pos = 0
+    for n, B in ((420, 5), (432, 2), (400, 3), (340, 2)):
+        np.testing.assert_allclose(a[pos:pos + n * B], b[pos:pos + n * B], rtol=0, atol=1e-13)
+        assert a[pos + n * B] < 1e-8 and a[pos + n * B + 1] < 1e-11
+        pos += n * B + 2
+    np.testing.assert_allclose(a[nl:nl + 3], b[nl:nl + 3], rtol=1e-6)
+    assert np.all(a[nl + 3:] == b[nl + 3:])

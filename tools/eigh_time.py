@@ -45,6 +45,13 @@ def main():
     err_l = max(np.abs(lam_h[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(k))
     res = max(np.abs(A_h[i] @ U_h[i].T - U_h[i].T * lam_h[i][None, :]).max() / np.abs(ref[i]).max() for i in range(k))
     orth = max(np.abs(U_h[i] @ U_h[i].T - np.eye(n)).max() for i in range(k))
+    if hasattr(_lib.lib, 'nele_ecs_prof_read'):        # -DECS_PROF build (tools/variants.sh eigh prof:"-DECS_PROF"): phase clocks of the symmetric first stage
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        _lib.lib.nele_ecs_prof_read(buf)
+        names = ['vector work + 3 barriers', 'sweep 1 (update, column sums)', 'pivot column publish', 'sweep 2 (row sums, reduce-scatter)', 'barrier, column reduce, publish', 'poll']
+        tot = float(sum(buf[:6])) or 1.0
+        print('symmetric first stage, shader clocks per phase over its steps: ' + '; '.join('%s %.0f k (%.0f %%)' % (nm, buf[k] / 1e3, 100.0 * buf[k] / tot) for k, nm in enumerate(names)))
     print('eigh B=%d n=%d: ms per call %s (min %.3f); eigenvalue err %.2e residual %.2e orthogonality %.2e' % (
         B, n, ' '.join('%.3f' % t for t in ts), min(ts), err_l, res, orth))
 
