@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -x -q -m gpu 2>&1 | tail -4
