@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4f
-bash tools/ab.sh "NELE_EIGH_SYM=0" "NELE_EIGH_SYM=1" 2>&1 | tee gpurun_out/r4f/ab_sym.txt
+bash tools/ab.sh "NELE_EIGH_P4_BATCH=32" "NELE_EIGH_P4_BATCH=64" "NELE_EIGH_P4_BATCH=16" 2>&1 | tee gpurun_out/r4f/ab_batch.txt
