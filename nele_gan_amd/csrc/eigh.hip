@@ -1824,48 +1824,66 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
 // 801 / 331 us, NL = 1 (plain bisection) 780 / 487 us - since the loads left the dependent chain the kernel is issue-bound at every batch
 // size, and fewer lanes per eigenvalue mean fewer sweeps in total (136, 92, 68, 53 per eigenvalue); below NL = 4 the small batch runs out
 // of waves.  One value for every batch size: the converged midpoint depends on NL, and a matrix's result must not depend on its batch.
+// Round 4 (tools/r4_q.sh, kernel time under rocprofv3, 256 / 32 matrices): sign history + exponent pre-check (see sturm below) 946 -> 788 us;
+// shared grids: none 788 / 231, one level 733 / 212, two 726 / 226, three 776 / 257, four 842 / 277 us; scalar loads 691 / 243;
+// with them NL = 2 645 / 331 (one level 630 / 306), NL = 8 1000 / 236 - NL stays 4.
 #ifndef EG_NL
 #define EG_NL 4      // lanes per eigenvalue: (EG_NL + 1)-section per round
 #endif
-__global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
-    __shared__ double2 sde[EG_MAXN];          // {d_i, e_{i-1}^2}: one 16-byte broadcast read per recurrence step
+#ifndef EG_GRID
+#define EG_GRID 2    // levels of the workgroup's shared 512-point grid ahead of the per-eigenvalue search (0 = none)
+#endif
+// eigh_sde_kernel: grid (B), block 256.  {d_i, e_{i-1}^2} pairs of one matrix + its Gershgorin interval, norm and pivmin, written to the head
+// of the matrix's (still unused) inverse-iteration work area: the Sturm sweeps read the pairs with wave-uniform indices, i.e. by SCALAR
+// loads (two s_load_dwordx16 per eight steps) instead of one 16-byte LDS broadcast read per step and wave - 1 KB of LDS return
+// bandwidth per wave and step, 8 clocks of the CU's one LDS pipe beside 5 clocks of the wave's share of its SIMD.  Measured: 726 -> 691 us
+// per 256 matrices (243 against 226 us at 32 matrices, where the unprefetched scalar loads show); the prologue of the seven
+// workgroups per matrix (loads, four block reductions) is gone as well.
+#define EG_SDE_STRIDE(n) ((size_t)6 * ((n) + 2) * EG_MAXN)        // doubles per matrix in ws.lu
+__global__ __launch_bounds__(256) void eigh_sde_kernel(int n, EighWs ws) {
     __shared__ double red[8];
-    constexpr int NL = EG_NL, PER = 256 / NL;
-    constexpr double inv = 1.0 / (double)(NL + 1);
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, t = lane & (NL - 1);
-    const int j = blockIdx.x * PER + tid / NL;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const double* d = ws.d + (size_t)b * n;
     const double* e = ws.e + (size_t)b * n;
+    double2* out = reinterpret_cast<double2*>(ws.lu + (size_t)b * EG_SDE_STRIDE(n));
     double gl = 1e300, gu = -1e300, tn = 0.0, e2m = 0.0;
     for (int i = tid; i < n; i += 256) {
         const double di = d[i];
         const double ej = (i < n - 1) ? e[i] : 0.0;
         const double em = (i > 0) ? e[i - 1] : 0.0;
-        sde[i] = make_double2(di, em * em);
+        out[i] = make_double2(di, em * em);
         const double r = fabs(ej) + fabs(em);
         gl = fmin(gl, di - r);
         gu = fmax(gu, di + r);
         tn = fmax(tn, fabs(di) + r);
         e2m = fmax(e2m, ej * ej);
     }
-    __syncthreads();
     const double glo = -block_max(-gl, red), ghi = block_max(gu, red), tnorm = block_max(tn, red);
-    const double eps = 2.220446049250313e-16, safemn = 2.2250738585072014e-308;
+    const double safemn = 2.2250738585072014e-308;
     const double pivmin = fmax(safemn, safemn * block_max(e2m, red));
+    if (tid == 0) { out[n] = make_double2(glo, ghi); out[n + 1] = make_double2(tnorm, pivmin); }
+}
+
+__global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, double* __restrict__ lam_out) {
+    constexpr int NL = EG_NL, PER = 256 / NL;
+    constexpr double inv = 1.0 / (double)(NL + 1);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, t = lane & (NL - 1);
+    const int j = blockIdx.x * PER + tid / NL;
+    const double2* __restrict__ sde = reinterpret_cast<const double2*>(ws.lu + (size_t)b * EG_SDE_STRIDE(n));   // uniform indices below: scalar loads
+    const double glo = sde[n].x, ghi = sde[n].y, tnorm = sde[n + 1].x, pivmin = sde[n + 1].y;
+    const double eps = 2.220446049250313e-16;
     double lo = glo - 2.0 * tnorm * eps * n - 2.0 * pivmin, hi = ghi + 2.0 * tnorm * eps * n + 2.0 * pivmin;
-    bool active = j < n;
-    for (int it = 0; it < 96; ++it) {
-        const double w = hi - lo;
-        const double x = lo + w * (double)(t + 1) * inv;
-        const double x1 = lo + w * inv, xl = lo + w * (double)NL * inv;
-        if (!(w > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || x1 <= lo || xl >= hi) active = false;
-        if (!__any(active)) break;
+    // Sturm count at x.  Per step three float64 operations and ONE integer operation: the sign bit of every p_i is shifted into a
+    // history word (v_alignbit) and the sign changes are counted once per eight steps (popcount of history ^ history >> 1) - the
+    // xor / shift / add per step of the first version were 2.5 of its 5.5 issue slots per step.  The range check of the running pair
+    // looks at the exponent field first (one bit-field extract, one compare, one wave-uniform branch): the float64 comparisons against
+    // 1e+-100 and the rescaling only run when some lane is outside 2^+-331, and decide exactly as before (same counts, same bits)
+    auto sturm = [&](double x) -> int {
         double p0 = 1.0, p1 = sde[0].x - x;
         if (p1 == 0.0) p1 = -pivmin;
-        int cnt = (p1 < 0.0) ? 1 : 0;
+        unsigned hist = (unsigned)__double2hiint(p1) >> 31;        // bit 0 = sign of the newest p
+        int cnt = (int)hist;                                       // p_{-1} = 1 > 0
         int i = 1;
-        // blocks of eight steps with a fixed trip count: the eight LDS reads are issued together ahead of the dependent chain (a
-        // variable-trip inner loop left one LDS latency exposed per step - most of this kernel's time)
         for (; i + 8 <= n; i += 8) {
             double2 de[8];
 #pragma unroll
@@ -1875,13 +1893,17 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
                 // an exact zero needs no repair here: the recurrence continues with p3 = -e^2 p1 and its sign bit counts as positive, which can
                 // only misplace the count AT a point that is exactly an eigenvalue of a leading block - the interval still closes around it
                 const double p2 = (de[u].x - x) * p1 - de[u].y * p0;
-                cnt += (int)((unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31);   // sign change (no NaNs here)
+                hist = __builtin_amdgcn_alignbit(hist, (unsigned)__double2hiint(p2), 31);     // (hist << 1) | sign(p2)
                 p0 = p1;
                 p1 = p2;
             }
-            const double ap = fabs(p1);                    // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
-            if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
-            else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
+            cnt += __popc((hist ^ (hist >> 1)) & 0xffu);           // changes between the nine newest signs
+            const unsigned ex = ((unsigned)__double2hiint(p1) >> 20) & 0x7ffu;
+            if (__any((unsigned)(ex - (1023u - 331u)) > 662u)) {   // |d - x| + e^2 grows a term by < 1e8 per step here: 8 steps are safe
+                const double ap = fabs(p1);
+                if (ap > 1e100) { p0 *= 1e-100; p1 *= 1e-100; }
+                else if (ap < 1e-100) { p0 *= 1e100; p1 *= 1e100; }
+            }
         }
         for (; i < n; ++i) {
             const double2 de = sde[i];
@@ -1890,6 +1912,57 @@ __global__ __launch_bounds__(256) void eigh_bisect_kernel(int n, EighWs ws, doub
             p0 = p1;
             p1 = p2;
         }
+        return cnt;
+    };
+    bool active = j < n;
+#if EG_GRID > 0
+    // ---- shared grids ahead of the per-eigenvalue search.  The first rounds of all eigenvalues of a matrix look at the same interval:
+    // the workgroup counts once at 2 x 256 points of the range that still holds ITS 64 eigenvalues (level 0: the Gershgorin interval;
+    // then the hull of their brackets, which for a clustered spectrum is a sliver of it) and every eigenvalue takes the grid cell whose
+    // ends bracket its index - two sweeps per thread buy log5(513) = 3.9 multisection rounds of four sweeps on the first level and
+    // 1.2 (evenly spread spectrum) to 3.9 (cluster) on the following ones.  A bracket found by binary search over the counts is valid
+    // whether or not rounding left them monotone: the search keeps count[a] <= j < count[b] and ends at b = a + 1.
+    {
+        constexpr int NG = 512;
+        __shared__ int gcnt[NG];
+        __shared__ double ghull[2][4];
+        double rl = lo, rh = hi;
+        for (int lev = 0; lev < EG_GRID; ++lev) {
+            const double gw = rh - rl;
+            if (!(gw > 0.0)) break;                                // (uniform)
+            constexpr double ginv = 1.0 / (double)(NG + 1);
+#pragma unroll 1
+            for (int k = tid; k < NG; k += 256) gcnt[k] = sturm(rl + gw * ((double)(k + 1) * ginv));
+            __syncthreads();
+            if (j < n) {
+                int a = -1, bnd = NG;                              // virtual ends: count(rl) <= j < count(rh)
+                while (bnd - a > 1) {
+                    const int mid = (a + bnd) >> 1;
+                    if (gcnt[mid] <= j) a = mid; else bnd = mid;
+                }
+                lo = (a < 0) ? rl : rl + gw * ((double)(a + 1) * ginv);
+                hi = (bnd >= NG) ? rh : rl + gw * ((double)(bnd + 1) * ginv);
+            }
+            if (lev + 1 < EG_GRID) {                               // hull of this workgroup's brackets
+                double hl = (j < n) ? lo : 1e300, hh = (j < n) ? hi : -1e300;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { hl = fmin(hl, __shfl_xor(hl, o, 64)); hh = fmax(hh, __shfl_xor(hh, o, 64)); }
+                if (lane == 0) { ghull[0][tid >> 6] = hl; ghull[1][tid >> 6] = hh; }
+                __syncthreads();
+                rl = fmin(fmin(ghull[0][0], ghull[0][1]), fmin(ghull[0][2], ghull[0][3]));
+                rh = fmax(fmax(ghull[1][0], ghull[1][1]), fmax(ghull[1][2], ghull[1][3]));
+            }
+            __syncthreads();
+        }
+    }
+#endif
+    for (int it = 0; it < 96; ++it) {
+        const double w = hi - lo;
+        const double x = lo + w * (double)(t + 1) * inv;
+        const double x1 = lo + w * inv, xl = lo + w * (double)NL * inv;
+        if (!(w > fmax(eps * tnorm, 2.0 * eps * fmax(fabs(lo), fabs(hi))) + 2.0 * pivmin) || x1 <= lo || xl >= hi) active = false;
+        if (!__any(active)) break;
+        const int cnt = sturm(x);
         const unsigned long long bal = __ballot(cnt <= j);
         const int m = __popc((unsigned)((bal >> (lane & (64 - NL))) & ((1ull << NL) - 1ull)));   // points of this group with count <= j
         if (active) {
@@ -2835,6 +2908,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }
+    hipLaunchKernelGGL(eigh_sde_kernel, dim3(B), dim3(256), 0, s, n, ws);
     hipLaunchKernelGGL(eigh_bisect_kernel, dim3((n + 256 / EG_NL - 1) / (256 / EG_NL), B), dim3(256), 0, s, n, ws, lam);
     // sweeps after the growth criterion is met: LAPACK's dstein uses EXTRA = 2 and documents "should be at least 1"; with the eigenvalues
     // bisected to 1 ulp one is enough for every test matrix (eigenvalues 1e-13, residual 1e-11, orthogonality 1e-8, SIIB unchanged to 17
