@@ -89,8 +89,15 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
-    """The current torch HIP stream as a hipStream_t."""
+    """The current torch HIP stream as a hipStream_t.  (torch.cuda.current_stream() builds a Stream object through three Python layers:
+    10 us a call, 0.5 ms of a B = 32 step's 4 ms of host time; the raw accessor is the same lookup without the object.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return c_void_p(_raw_stream(_raw_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

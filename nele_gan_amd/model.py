@@ -75,19 +75,26 @@ class FlatParams:
         self.module = module
         self.flat = None
         self.grad = None
+        self._plist = None       # [(parameter, offset)] of the flattened module (ensure() fills it)
 
     def params(self):
         return [p for p in self.module.parameters()]
 
     def valid(self, device):
-        device = _norm_dev(device)
-        if self.flat is None or self.flat.device != device:
+        """True while every parameter (and its gradient) is still the view into the flat buffers that ensure() made.  Checked on every
+        forward / prepare (ten times per training step), so it walks the list ensure() kept instead of module.parameters() - the
+        recursive enumeration was 75 of this call's 100 us.  Replacing a parameter's storage (.to(), .data = ...) is noticed here;
+        ADDING a parameter to a module after its first forward pass is not supported."""
+        if self.flat is None or self._plist is None:
             return False
-        off = 0
-        for p in self.params():
-            if p.data_ptr() != self.flat.data_ptr() + 4 * off or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+        device = _norm_dev(device)
+        if self.flat.device != device:
+            return False
+        f0, g0 = self.flat.data_ptr(), self.grad.data_ptr()
+        for p, off in self._plist:
+            g = p.grad
+            if g is None or p.data_ptr() != f0 + off or g.data_ptr() != g0 + off:
                 return False
-            off += p.numel()
         return True
 
     def ensure(self, device):
@@ -117,6 +124,10 @@ class FlatParams:
             p.grad = grad[off:off + k].view(p.shape)
             off += k
         self.flat, self.grad = flat, grad
+        self._plist, off = [], 0
+        for p in ps:
+            self._plist.append((p, 4 * off))
+            off += p.numel()
 
 
 class _Anchor:

@@ -82,6 +82,14 @@ class GanTrainer:
         self._fside = None
         self._last_enh = None                        # enhanced batch of the last canonical_step (parity tests read it)
         self.prefetched = None                       # input-only work of the next batch (canonical_step(next_batch=...))
+        # Early prefetch (small batches): the next batch's input-only work is enqueued at the START of a step, so that its latency chain
+        # (SIIB's eigen-decomposition: 3.5 ms at B = 32 whatever else runs) overlaps the whole step instead of heading the next one.
+        # Two sets of metric workspaces alternate (batch k's degraded-signal half still needs batch k's eigenvectors while batch
+        # k + 1's are computed); _sets[i] is the parked workspace dict while set 1 - i is the active one (self._ws).
+        self.early_prefetch_max_batch = 64
+        self._sets = [None, {}]
+        self._cur_set = 0
+        self._wstreams_plain = None                  # D's weight-gradient streams outside the pipelined step (see _pipeline_queues)
         self.split_haspi = os.environ.get('NELE_HASPI_SPLIT', '1') != '0'   # HASPI's clean-signal half beside the G-step (A/B switch)
         # metric status, accumulated on the device without a host synchronisation and read by check_status():
         # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
@@ -214,8 +222,8 @@ class GanTrainer:
         skipped because their gradient was not finite (a NaN target or a poisoned eigen-decomposition must not reach the weights).
         Call once per epoch (run_epoch does)."""
         cur = torch.cuda.current_stream() if self.device.type == 'cuda' else None
-        for st_ in (self._side, self._side2):        # the 'side' accumulator is updated on a side stream BEHIND the event the main stream waits on
-            if cur is not None and st_ is not None:
+        for st_ in self._all_side_streams():         # the 'side' accumulators are updated on a side stream BEHIND the event the main stream waits on
+            if cur is not None:
                 cur.wait_stream(st_)
         tot = torch.zeros(3, dtype=torch.int64)
         for acc in self._status.values():
@@ -380,6 +388,42 @@ class GanTrainer:
         return loss.detach() if loss is not None else None
 
     # ---------------------------------------------------------------- one canonical step
+    def _use_set(self, i):
+        """Make metric-workspace set i (0 or 1) the active one (self._ws); the other set is parked."""
+        if i == self._cur_set:
+            return
+        self._sets[self._cur_set] = self._ws
+        self._ws = self._sets[i]
+        self._sets[i] = None
+        self._cur_set = i
+
+    def _all_side_streams(self):
+        return [st_ for st_ in (self._side, self._side2, self._fside) if st_ is not None]
+
+    def _pipeline_queues(self, on):
+        """The HIP runtime multiplexes all streams onto four hardware queues: the default stream has its own; side streams get
+        the other three in the order of their first use and share them beyond the third.  In a plain step the trainer's six side streams
+        pair up in phases that never overlap.  In the pipelined step the next batch's eigen-decomposition occupies the metric stream's
+        queue with 1 ms kernels for the WHOLE step and whatever shares that queue waits behind them (kernel trace at B = 32: G's or D's
+        weight gradients, + 0.9 ms per step, whichever of their streams the runtime happened to put there).  So while pipelining only
+        THREE side streams are in use - the first three the trainer ever touched, one queue each: the metric stream carries the long
+        chain alone, the weight gradients of G and D ride on the feature stream and the second metric stream, which are idle in those
+        phases."""
+        dev = self.device
+        if self._side is None:
+            self._side = ops.side_stream(dev)
+        if self._side2 is None:
+            self._side2 = ops.side_stream(dev)
+        if self._fside is None:
+            self._fside = ops.side_stream(dev)
+        if on and self._wstreams_plain is None:
+            self._wstreams_plain = (self.D._wstream, self.G._wstream)
+            self.D._wstream = (self._fside, self._side2)
+            self.G._wstream = self._fside
+        elif not on and self._wstreams_plain is not None:
+            self.D._wstream, self.G._wstream = self._wstreams_plain
+            self._wstreams_plain = None
+
     def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features, utt_ids=None):
         """Everything of a step that needs only its INPUTS, enqueued on the side streams behind event ``after``: the clean-signal
         halves of SIIB (VAD .. eigen-decomposition .. clean projections) and HASPI (the whole reference-signal chain) and, with
@@ -393,7 +437,7 @@ class GanTrainer:
         lengths = au._i32(lengths, self.device)
         mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
         w = {'clean': clean_wav, 'noise': noise_wav, 'lengths': lengths, 'mlens': mlens, 'split': None, 'hsplit': None, 'feats': None,
-             'dither': None, 'utt_ids': utt_ids}
+             'dither': None, 'utt_ids': utt_ids, 'set': self._cur_set, 'clean_done': None, 'clean_stream': None}
         with torch.cuda.stream(side):
             side.wait_event(after)
             w['x'] = clean_wav[:, :L].contiguous()
@@ -402,6 +446,9 @@ class GanTrainer:
             if 'siib' in self.metrics:
                 w['split'] = mt.SiibSplit(w['x'], lengths=mlens, owner=self._ws)
                 w['split'].clean_part()
+            w['clean_done'] = torch.cuda.Event()
+            w['clean_done'].record(side)
+            w['clean_stream'] = side
         if 'haspi' in self.metrics and self.split_haspi:
             # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
             with torch.cuda.stream(side2):
@@ -436,12 +483,15 @@ class GanTrainer:
             after.record(torch.cuda.current_stream())
         return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True, utt_ids=utt_ids)
 
-    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None, utt_ids=None):
+    def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None, utt_ids=None, early=None):
         """features -> G-step -> generate -> true metrics -> D-step on the same batch.  lengths [B] (optional): samples of each
         utterance inside the padded batch (every utterance needs >= 21 frames, i.e. 5120 samples, for D).
         pre: what prefetch() returned for THIS batch (its input-only work is then already in flight or done);
-        next_batch: (clean, noise[, lengths]) of the following step - its input-only work is enqueued behind this step's targets and the
-        result left in ``self.prefetched``."""
+        next_batch: (clean, noise[, lengths[, ids]]) of the following step - its input-only work is enqueued behind this step's targets
+        (large batches: it fills the D backward pass) or, ``early`` (default: batches of at most ``early_prefetch_max_batch``), at the
+        start of this step on the second set of side streams and workspaces: a small batch leaves most of the GPU idle and its step
+        is as long as its longest dependent chain - SIIB's clean-signal half with the eigen-decomposition, 4.2 of 5.8 ms at B = 32 -
+        which then runs a step ahead.  The result is left in ``self.prefetched``; bit-identical either way."""
         # The metric kernels run on a side stream.  (1) Everything SIIB derives from the CLEAN signal alone - VAD, clean spectra,
         # the covariance and its eigen-decomposition (the KLT basis) - is enqueued first and runs beside features / G-step /
         # generate.  (2) Once the enhanced signal exists the remaining metric work follows on the side stream while the main
@@ -451,6 +501,12 @@ class GanTrainer:
         start = torch.cuda.Event()
         start.record(main)
         B_, T_ = clean_wav.shape[0], 1 + clean_wav.shape[1] // 256
+        if early is None:
+            early = B_ <= self.early_prefetch_max_batch
+        early = bool(early) and next_batch is not None and not torch.cuda.is_current_stream_capturing()
+        if pre is not None:
+            self._use_set(pre.get('set', self._cur_set))    # the workspaces that hold this batch's clean-signal halves
+        self._pipeline_queues(early)
         if self._fside is None:
             self._fside = ops.side_stream(self.device)
         if self._side2 is None:
@@ -458,7 +514,7 @@ class GanTrainer:
         # D's spectral-norm iteration and weight layouts depend on its parameters only: they run on a side stream ahead of each of D's two
         # forward passes (beside the generator's forward pass / beside generate) instead of at the head of those passes.  With a
         # prefetched batch the metric side stream already carries HASPI's clean half: the feature stream (idle then) takes it.
-        p1 = self._fside if pre is not None else self._side2
+        p1 = self._fside if (pre is not None and not early) else self._side2
         with torch.cuda.stream(p1):
             p1.wait_event(start)                           # after the previous step's D update
             self.D.prepare(B_, T_, self.device)
@@ -466,6 +522,15 @@ class GanTrainer:
             pre = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False, utt_ids=utt_ids)
         else:
             assert pre['clean'] is clean_wav and pre['noise'] is noise_wav, "canonical_step: `pre` belongs to another batch"
+        early_pre = None
+        if early:
+            # the next batch's input-only work, now: features on the feature stream, SIIB's clean-signal half on the metric stream (whose
+            # hardware queue it has to itself, _pipeline_queues), HASPI's on the second metric stream - into the OTHER workspace set
+            mine = self._cur_set
+            self._use_set(1 - mine)
+            early_pre = self._input_only_work(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, start,
+                                              with_features=True, utt_ids=next_batch[3] if len(next_batch) > 3 else None)
+            self._use_set(mine)
         side = self._side
         lengths, mlens, x, split, hsplit = pre['lengths'], pre['mlens'], pre['x'], pre['split'], pre['hsplit']
         if feats is None and pre['feats'] is not None:
@@ -492,8 +557,14 @@ class GanTrainer:
             self._side2 = ops.side_stream(self.device)
         side2 = self._side2
         cols = {}
+        if early:
+            # the metric stream is busy with the next batch's clean-signal chain: this batch's degraded-signal half (and ESTOI behind it)
+            # takes the feature stream, behind the event that closed its own clean-signal half
+            side = self._fside
         with torch.cuda.stream(side):
             side.wait_event(ready)
+            if pre['clean_done'] is not None and side != pre['clean_stream']:   # (same stream: FIFO; a self-wait also upsets ROCm's stream capture)
+                side.wait_event(pre['clean_done'])
             y = (enh + noise_wav[:, :L]).contiguous()
             y_ready = torch.cuda.Event()
             y_ready.record(side)
@@ -520,9 +591,10 @@ class GanTrainer:
         with torch.cuda.stream(side):
             done = torch.cuda.Event()
             done.record(side)                               # SIIB's degraded part (and ESTOI behind it) is complete
-            self._note_status('side', siib_info=split.info if split is not None else None)
+            self._note_status('fside' if early else 'side', siib_info=split.info if split is not None else None)
         for t in (x, y):
             t.record_stream(side2)
+            t.record_stream(side)
         din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lengths)
         self.optimizer_d.zero_grad()
         score = self.D.forward_packed(din, frames)
@@ -531,8 +603,8 @@ class GanTrainer:
         enh.record_stream(side)
         clean_wav.record_stream(side)
         noise_wav.record_stream(side)
-        self.prefetched = None
-        if next_batch is not None:                          # the next batch's input-only work fills the D backward pass
+        self.prefetched = early_pre
+        if next_batch is not None and early_pre is None:    # the next batch's input-only work fills the D backward pass
             self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done,
                                             utt_ids=next_batch[3] if len(next_batch) > 3 else None)
         # Both metric streams join the MAIN stream (behind D's forward pass, which does not need the targets), and the [B, n_metrics]
@@ -549,7 +621,7 @@ class GanTrainer:
         return lg, ld, tgt
 
     def _join_side_streams(self, main):
-        for st_ in (self._side, self._side2, self._fside) + tuple(self.D._wstream or ()) + ((self.G._wstream,) if self.G._wstream is not None else ()):
+        for st_ in tuple(self._all_side_streams()) + tuple(self.D._wstream or ()) + ((self.G._wstream,) if self.G._wstream is not None else ()):
             if st_ is not None:
                 main.wait_stream(st_)
 

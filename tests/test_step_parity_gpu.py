@@ -111,13 +111,43 @@ def test_prefetched_pipeline_is_bit_identical_to_plain_steps():
     pre = a.prefetch(*batches[0])
     for k in range(3):
         cur, nxt = batches[k % 2], batches[(k + 1) % 2]
-        ra = a.canonical_step(cur[0], cur[1], pre=pre, next_batch=nxt)
+        ra = a.canonical_step(cur[0], cur[1], pre=pre, next_batch=nxt, early=False)
         pre = a.prefetched
         rb = b.canonical_step(cur[0], cur[1])
         torch.cuda.synchronize()
         assert torch.equal(ra[2], rb[2]) and float(ra[0]) == float(rb[0]) and float(ra[1]) == float(rb[1]), k
         assert torch.equal(a._last_enh, b._last_enh)
         assert torch.equal(a.G.flat_parameters().flat, b.G.flat_parameters().flat) and torch.equal(a.D.flat_parameters().flat, b.D.flat_parameters().flat)
+    assert all(x == 0 for x in a.check_status().values())
+
+
+@pytest.mark.parametrize('metric', ['siib&estoi', 'siib&haspi&estoi'])
+def test_early_prefetch_on_the_second_stream_set_is_bit_identical_to_plain_steps(metric):
+    """Small batches: canonical_step(next_batch=...) enqueues the next batch's input-only work at the START of the step, on the second
+    set of side streams and metric workspaces (the sets alternate from step to step).  Five steps over three different batches - a
+    batch's clean-signal halves are computed while the previous batch's degraded halves, D-step and targets are still in flight -
+    must reproduce the plain sequence bit for bit, and both sets must have been used."""
+    from nele_gan_amd import synth
+    batches = []
+    for st in (40, 140, 260):
+        c, v = synth.batch(3, 24000, start=st)
+        batches.append((torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()))
+    a = _trainer(metric, 'bf16')
+    b = _trainer(metric, 'bf16')
+    assert batches[0][0].shape[0] <= a.early_prefetch_max_batch
+    pre, sets = None, set()
+    for k in range(5):
+        cur, nxt = batches[k % 3], batches[(k + 1) % 3]
+        ra = a.canonical_step(cur[0], cur[1], pre=pre, next_batch=nxt)
+        pre = a.prefetched
+        assert pre is not None and pre['set'] != a._cur_set
+        sets.add(a._cur_set)
+        rb = b.canonical_step(cur[0], cur[1])
+        torch.cuda.synchronize()
+        assert torch.equal(ra[2], rb[2]) and float(ra[0]) == float(rb[0]) and float(ra[1]) == float(rb[1]), k
+        assert torch.equal(a._last_enh, b._last_enh)
+        assert torch.equal(a.G.flat_parameters().flat, b.G.flat_parameters().flat) and torch.equal(a.D.flat_parameters().flat, b.D.flat_parameters().flat)
+    assert sets == {0, 1}
     assert all(x == 0 for x in a.check_status().values())
 
 
