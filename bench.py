@@ -495,17 +495,17 @@ def main():
                                    'algorithmic_bytes': h_bytes, 'launches_timed': len(hbm_ms), 'limited_by': 'float64 issue rate (recurrences), not HBM'}
         if eig_ms:
             # Householder tridiagonalisation of the 420 x 420 clean covariance, the steps the two cluster stages run (trailing size 419 .. 256:
-            # four workgroups per matrix hold the trailing matrix in registers down to 320 rows, two from there; both launch sites carry
-            # the tag): step k costs 4 m^2 flops (symmetric matrix-vector product + rank-2 update, m = n - 1 - k).  Inside a training step
+            # two workgroups per matrix hold the lower triangle of the trailing matrix in registers + LDS down to 320 rows, the full
+            # matrix from there; both launch sites carry the tag): step k costs 4 m^2 flops (symmetric matrix-vector product + rank-2 update, m = n - 1 - k).  Inside a training step
             # SIIB's clean part asks for 32 / 64 matrices per launch (half of the chip).  achieved = flops of one step's launches / their time.
             n_e, m_hand = 420, 256
             f_mat = float(sum(4 * (n_e - 1 - k) ** 2 for k in range(n_e - m_hand)))
             e_step_ms = sum(eig_ms) / a.steps
-            out['roofline_f64'] = {'bound': 'mfma', 'kernel': 'eigh_tridiag_cluster4_kernel + eigh_tridiag_cluster2_kernel (oracle/siib.py:97 np.linalg.eigh -> Householder steps 0..%d of %d on '
+            out['roofline_f64'] = {'bound': 'mfma', 'kernel': 'eigh_tridiag_clusters_kernel + eigh_tridiag_cluster2_kernel (oracle/siib.py:97 np.linalg.eigh -> Householder steps 0..%d of %d on '
                                                                '%d matrices per step; float64 FMA, latency-bound cross-workgroup chain)' % (n_e - m_hand - 1, n_e - 2, a.batch),
                                    'achieved': f_mat * a.batch / (e_step_ms * 1e-3) / 1e12, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': f_mat * a.batch / (e_step_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
-                                   'traffic': pmc.get('eigh_tridiag_cluster4_kernel', {}).get('hbm_bytes_corrected'), 'launch_ms': sum(eig_ms) / len(eig_ms),
+                                   'traffic': pmc.get('eigh_tridiag_clusters_kernel', {}).get('hbm_bytes_corrected'), 'launch_ms': sum(eig_ms) / len(eig_ms),
                                    'launches_timed': len(eig_ms), 'launches_per_step': len(eig_ms) / a.steps, 'ms_per_step': e_step_ms,
                                    'flops_per_step': f_mat * a.batch}
         # `roofline` = the kernel with the largest time per step among the timed ones (the r03 verdict: the line's first figure must not be

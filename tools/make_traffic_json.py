@@ -21,7 +21,7 @@ WANT = ('conv_wgrad_dma_kernel<4, 11, 3>', 'conv_wgrad_dma_kernel<4, 11, 2>', 'c
         'siib_quad_kernel', 'siib_lag_kernel<0, 1, -14, 29>', 'eigh_invit_kernel', 'eigh_bisect_kernel', 'conv_wgrad_tile16_kernel<1, 2, true, true>', 'haspi_bank_scan_kernel<true, true, false, true>', 'haspi_bank_scan_kernel<false, true, false, false>',
         'eigh_backtransform_wy_kernel', 'eigh_tridiag_mid_kernel', 'siib_stack_kernel',
         'haspi_mod_slide_kernel<1>', 'stft_band_kernel', 'gain_istft_kernel', 'siib_proj_kernel<2>', 'siib_cov_kernel',
-        'eigh_tridiag_cluster4_kernel', 'conv1d_tile16_kernel<4>', 'adam_guarded_kernel',
+        'eigh_tridiag_cluster4_kernel', 'eigh_tridiag_clusters_kernel', 'eigh_invit2_kernel', 'conv1d_tile16_kernel<4>', 'adam_guarded_kernel',
         'siib_spec_wave_kernel', 'siib_spec_kernel', 'siib_db_kernel', 'stft_band_wave_kernel', 'gain_istft_wave_kernel', 'eigh_tridiag_midx_kernel', 'estoi_resample5_kernel')
 
 
