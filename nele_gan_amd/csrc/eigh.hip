@@ -2592,47 +2592,66 @@ __global__ __launch_bounds__(256, 2) void eigh_backtransform_kernel(const double
 // with v_mfma_f64_16x16x4_f64.  A wave keeps 16 eigenvectors in the MFMA accumulator layout (reg q of lane l = row (l >> 4) + 4 q of the
 // 16-row tile, column l & 15) for the whole kernel: a k-step t of the first product takes rows 4 t + (l >> 4), which IS register t of the
 // tile, and the W / W' tiles feed the next product the same way - no shuffles, one 8-byte LDS read (the V or T operand) per MFMA.
-// eigh_wy_t_kernel: grid (blocks of 16 reflectors, B), block 256: -T per block -> ws.lu (free once the inverse iteration is done).
+// eigh_wy_t_kernel: grid (ceil(blocks of 16 reflectors / 4), B), block 256 = one wave per block: -T per block -> ws.lu (free once the inverse iteration is done).
 #define WY_NB 16
 #define WY_LD 17
+// Round 4, second session: one WAVE per block of 16 reflectors, four blocks per workgroup, no staged copy of V.  The Gram matrix G = V V^T is a
+// chain of v_mfma_f64_16x16x4 whose A and B operands are the SAME register (lane l: V[l & 15][4 t + (l >> 4)], read straight from A's
+// reflector rows), four independent accumulators; the 16-column recurrence for T runs with a row of T per lane in registers.  The first
+// version staged V in 57 KB of LDS per workgroup and spent two LDS reads per multiply-add on the Gram matrix: 283 us per 256 matrices
+// for 54 KB of input per block.
 __global__ __launch_bounds__(256) void eigh_wy_t_kernel(const double* __restrict__ Aall, int n, EighWs ws) {
-    __shared__ double V[WY_NB][EG_MAXN + 1];
-    __shared__ double G[WY_NB][WY_LD], T[WY_NB][WY_LD], tau_s[WY_NB];
-    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    __shared__ double Gs[4][WY_NB][WY_LD];
+    const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int nblk = (n - 1 + WY_NB - 1) / WY_NB;
+    const int c = 4 * blockIdx.x + wv;
+    if (c >= nblk) return;                                              // (wave-uniform; no workgroup barrier below)
     const int khi = n - 2 - WY_NB * c, klo = khi - (WY_NB - 1);          // reflectors klo .. khi (those with k < 0 do not exist: tau = 0)
     const double* A = Aall + (size_t)b * n * n;
-    const int lo = max(klo + 1, 0), nr = n - lo;                      // rows <= klo are zero in every reflector of the block
-    for (int idx = tid; idx < WY_NB * nr; idx += 256) {
-        const int r = idx / nr, i = lo + idx - r * nr, k = klo + r;
-        V[r][i] = (k >= 0 && i > k) ? A[(size_t)k * n + i] : 0.0;
-    }
-    if (tid < WY_NB) tau_s[tid] = (klo + tid >= 0) ? ws.tau[(size_t)b * n + klo + tid] : 0.0;
-    __syncthreads();
-    {
-        const int i = tid >> 4, j = tid & 15;
-        double g = 0.0;
-        for (int r = lo; r < n; ++r) g += V[i][r] * V[j][r];
-        G[i][j] = g;
-        T[i][j] = 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {                                                    // one wave, lanes 0..15 = rows of T: no workgroup barriers
-        for (int j = 0; j < WY_NB; ++j) {                              // column j from columns 0 .. j-1
-            if (tid < j) {
-                double t = 0.0;
-                for (int m = tid; m < j; ++m) t += T[tid][m] * G[m][j];
-                T[tid][j] = -tau_s[j] * t;
-            } else if (tid == j) {
-                T[j][j] = tau_s[j];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int lo = max(klo + 1, 0);                                    // rows <= klo are zero in every reflector of the block
+    const int k = klo + li;                                            // this lane's reflector
+    const double* vrow = A + (size_t)max(k, 0) * n;
+    const int nt = (n - lo + 3) >> 2;
+    f64x4_t acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    // 32 k-steps per batch with all 32 loads in flight (the reflector rows come from HBM: a batch costs one memory latency whatever its
+    // size); steps behind the last row are masked, not peeled - a scalar remainder loop would pay that latency per step
+    for (int t = 0; t < nt; t += 32) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int i = lo + 4 * (t + u) + g;
+            v[u] = (k >= 0 && i > k && i < n) ? vrow[i] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc[u & 3], 0, 0, 0);
     }
-    __syncthreads();
-    double* out = ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN + (size_t)c * 256;
-    out[tid] = -T[tid >> 4][tid & 15];
+    double (*G)[WY_LD] = Gs[wv];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)                                         // accumulator register q of lane l: row (l >> 4) + 4 q, column l & 15
+        G[g + 4 * q][li] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
+    const double tau_l = (lane < WY_NB && klo + lane >= 0) ? ws.tau[(size_t)b * n + klo + lane] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // T column by column: T[:j, j] = -tau_j T[:j, :j] G[:j, j].  Lane r keeps ROW r of T in registers (entries right of the columns done
+    // so far are still zero, entries left of the diagonal stay zero), so column j is 120 multiply-adds over compile-time indices with
+    // G[m][j] as LDS broadcast reads - no exchange between the lanes at all (the first version went through LDS and a wave barrier per column)
+    double Trow[WY_NB];
+#pragma unroll
+    for (int j = 0; j < WY_NB; ++j) {
+        const double tau_j = __shfl(tau_l, j, 64);
+        double tt = 0.0;
+#pragma unroll
+        for (int m = 0; m < j; ++m) tt += Trow[m] * G[m][j];
+        Trow[j] = (lane < j) ? -tau_j * tt : ((lane == j) ? tau_j : 0.0);
+    }
+    if (lane < WY_NB) {
+        double* out = ws.lu + (size_t)b * 6 * (n + 2) * EG_MAXN + (size_t)c * 256 + lane * WY_NB;
+#pragma unroll
+        for (int m = 0; m < WY_NB; ++m) out[m] = -Trow[m];
+    }
 }
 
 // grid (ceil(n / 64), B), block 256: wave w holds eigenvectors 64 blockIdx.x + 16 w ... + 15.  One workgroup per CU (the two V buffers
@@ -2837,7 +2856,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             const int mid_on = NELE_SWITCH_INT("NELE_EIGH_MID", 1);                        // NELE_EIGH_MID=0: hand over to the LDS tail kernel at 128 instead (A/B diagnostic)
             const int midx_on = NELE_SWITCH_INT("NELE_EIGH_MIDX", 1);   // =0: hand over at 224 (registers only) instead of 256 (registers + LDS strip)
             NELE_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_midx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-            const int mhand = (tail_on && mid_on) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
+            const int mhand = (tail_on != 0 && mid_on != 0) ? (midx_on ? EM_M + EX_E : EM_M) : ET_M;
             const int s_stop = (tail_on && n > mhand + 2) ? n - mhand - 2 : -2;
             // second cluster stage (round 4): once 320 rows are left, two workgroups per matrix hold the block - twice the matrices per launch
             // for the steps from 320 down to the single-workgroup hand-over (NELE_EIGH_C2=0: the four-workgroup kernel runs them all)
@@ -2927,7 +2946,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     });
     if (wy_on) {
         const int nblk = (n - 1 + WY_NB - 1) / WY_NB;
-        hipLaunchKernelGGL(eigh_wy_t_kernel, dim3(nblk, B), dim3(256), 0, s, A, n, ws);
+        hipLaunchKernelGGL(eigh_wy_t_kernel, dim3((nblk + 3) / 4, B), dim3(256), 0, s, A, n, ws);
         if (n <= 432) hipLaunchKernelGGL(eigh_backtransform_wy_kernel<27>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 432 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
         else hipLaunchKernelGGL(eigh_backtransform_wy_kernel<32>, dim3((n + 63) / 64, B), dim3(256), sizeof(double) * (2 * 512 * WY_LD + 2 * 16 * WY_LD), s, A, n, ws, U);
     }
