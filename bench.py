@@ -225,7 +225,8 @@ def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None
 def epoch_equivalent(tr, cw, nw, K, utts):
     """The reference's per-utterance work mix of one GAN epoch (train_nele.py:110-429): one G-step, one generated sample, true targets of
     the generated and of the pre-enhanced 'DRC' example, and 2 x 3 D-steps (both examples in each of the three passes; the 1/30 history
-    replay of pass B is left out).  Plain sequence on the current stream - no cross-stage overlap - so this is a lower bound."""
+    replay of pass B is left out).  The stages follow each other on the current stream - no cross-stage overlap, so this is a lower bound;
+    inside the target stage the three metrics run on their own streams (GanTrainer.true_metrics_pair, as run_epoch calls it)."""
     import torch
     drc = (cw * 1.5).contiguous()                       # stands for the pre-enhanced example of the same utterances
     def unit():
@@ -248,7 +249,7 @@ def epoch_equivalent(tr, cw, nw, K, utts):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
     return {'value': utts / dt, 'unit': 'utterances/s', 'ms_per_unit': dt * 1e3,
-            'mix': '1 G-step + generate + targets of 2 examples (clean-signal work shared) + 6 D-steps per batch, sequential'}
+            'mix': '1 G-step + generate + targets of 2 examples (clean-signal work shared; SIIB / HASPI / ESTOI on three streams) + 6 D-steps per batch, stages in sequence'}
 
 
 def main():

@@ -47,6 +47,62 @@ def parse_metrics(target_metric):
     return names
 
 
+class _MetricFork:
+    """See GanTrainer._metric_fork."""
+
+    def __init__(self, tr, inputs):
+        self.tr, self.inputs, self.outs, self.used = tr, [t for t in inputs if t is not None], [], []
+        self.multi = (tr.device.type == 'cuda' and len(tr.metrics) > 1 and tr.metric_streams and not torch.cuda.is_current_stream_capturing())
+        if self.multi:
+            self.main = torch.cuda.current_stream()
+            self.ev0 = torch.cuda.Event()
+            self.ev0.record(self.main)
+
+    def on(self, m):
+        return _MetricForkCtx(self, m)
+
+    def out(self, t):
+        self.outs.append(t)
+        return t
+
+    def join(self):
+        if not self.multi:
+            return
+        for st in self.used:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.main.wait_event(ev)
+            for t in self.inputs:
+                t.record_stream(st)
+        for t in self.outs:
+            t.record_stream(self.main)
+
+
+class _MetricForkCtx:
+    def __init__(self, fork, m):
+        self.fork, self.m, self.ctx = fork, m, None
+
+    def __enter__(self):
+        f = self.fork
+        if not f.multi:
+            return 'main'
+        name = {'siib': '_side', 'haspi': '_side2'}.get(self.m, '_fside')
+        if getattr(f.tr, name) is None:
+            setattr(f.tr, name, ops.side_stream(f.tr.device))
+        st = getattr(f.tr, name)
+        if st not in f.used:
+            f.used.append(st)
+            st.wait_event(f.ev0)
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        return name[1:]
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class GanTrainer:
     def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666,
                  haspi_dither=None, dither_seed=0):
@@ -87,6 +143,7 @@ class GanTrainer:
         # Two sets of metric workspaces alternate (batch k's degraded-signal half still needs batch k's eigenvectors while batch
         # k + 1's are computed); _sets[i] is the parked workspace dict while set 1 - i is the active one (self._ws).
         self.early_prefetch_max_batch = 64
+        self.metric_streams = True                   # true_metrics / true_metrics_pair: one stream per metric (False: all on the current stream)
         self._sets = [None, {}]
         self._cur_set = 0
         self._wstreams_plain = None                  # D's weight-gradient streams outside the pipelined step (see _pipeline_queues)
@@ -255,6 +312,12 @@ class GanTrainer:
         also what the metrics see (min of the clean and the enhanced length, audio_util.py:134-141)."""
         return None if lengths is None else (torch.div(lengths, 256, rounding_mode='floor') * 256).to(torch.int32)
 
+    def _metric_fork(self, inputs):
+        """Fork / join of the metric calls of one batch: SIIB on the metric stream, HASPI on the second one, everything else (ESTOI) on the
+        feature stream - three dependency chains that share nothing but their inputs (canonical_step runs them the same way).  One
+        metric, a CPU trainer or a stream capture in progress: everything stays on the current stream."""
+        return _MetricFork(self, inputs)
+
     @torch.no_grad()
     def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None):
         """[B, n_metrics] targets of (clean, enhanced + noise) (audio_util.py:120-203).  lengths [B]: samples of each utterance inside the
@@ -270,9 +333,12 @@ class GanTrainer:
         elif lengths is not None:
             lengths = torch.clamp(lengths, max=L)
         cols = []
+        fork = self._metric_fork((x, y))
         for m in self.metrics:
-            raw, mapped = self._metric(m, x, y, 'main', lengths, utt_ids)
-            cols.append(mapped if norm else raw)
+            with fork.on(m) as which:
+                raw, mapped = self._metric(m, x, y, which, lengths, utt_ids)
+                cols.append(fork.out(mapped if norm else raw))
+        fork.join()
         return torch.stack(cols, dim=1)
 
     @torch.no_grad()
@@ -299,26 +365,29 @@ class GanTrainer:
         ys = [(enh_wav[:, :L] + noise_wav[:, :L]).contiguous(), (drc_wav[:, :L] + noise_wav[:, :L]).contiguous()]
         pick = (lambda r, m_: m_) if norm else (lambda r, m_: r)
         cols = [{}, {}]
+        fork = self._metric_fork([x] + ys)
         for m in self.metrics:
-            if m == 'siib':
-                sp = mt.SiibSplit(x, lengths=ml_e, owner=self._ws)
-                sp.clean_part()
-                for k, y in enumerate(ys):
-                    raw, mapped = sp.degraded_part(y)
-                    cols[k][m] = pick(raw, mapped).clone()
-                    self._note_status('main', siib_info=sp.info)
-            elif m == 'haspi':
-                hp = mt.HaspiSplit(x, lengths=ml_e, owner=self._ws)
-                dz = self._dither(x, utt_ids)
-                hp.clean_part(dither=dz)
-                for k, y in enumerate(ys):
-                    raw, mapped = hp.degraded_part(y, dither=dz)
-                    cols[k][m] = pick(raw, mapped).clone()
-                    self._note_status('main', haspi_info=hp.info)
-            else:
-                for k, y in enumerate(ys):
-                    raw, mapped = mt.batch_estoi(x, y, lengths=ml_e)
-                    cols[k][m] = pick(raw, mapped)
+            with fork.on(m) as which:
+                if m == 'siib':
+                    sp = mt.SiibSplit(x, lengths=ml_e, owner=self._ws)
+                    sp.clean_part()
+                    for k, y in enumerate(ys):
+                        raw, mapped = sp.degraded_part(y)
+                        cols[k][m] = fork.out(pick(raw, mapped).clone())
+                        self._note_status(which, siib_info=sp.info)
+                elif m == 'haspi':
+                    hp = mt.HaspiSplit(x, lengths=ml_e, owner=self._ws)
+                    dz = self._dither(x, utt_ids)
+                    hp.clean_part(dither=dz)
+                    for k, y in enumerate(ys):
+                        raw, mapped = hp.degraded_part(y, dither=dz)
+                        cols[k][m] = fork.out(pick(raw, mapped).clone())
+                        self._note_status(which, haspi_info=hp.info)
+                else:
+                    for k, y in enumerate(ys):
+                        raw, mapped = mt.batch_estoi(x, y, lengths=ml_e)
+                        cols[k][m] = fork.out(pick(raw, mapped))
+        fork.join()
         return tuple(torch.stack([c[m] for m in self.metrics], dim=1) for c in cols)
 
     # ---------------------------------------------------------------- D-step (train_nele.py:349-367)

@@ -176,6 +176,14 @@ def test_true_metrics_pair_equals_two_calls():
     r1, r2 = tr.true_metrics_pair(cw, enh, drc, nw, lengths=lens, drc_lengths=dl)
     assert torch.equal(r2, e2)
     tr.check_status()
+    # the three metrics run on their own streams (SIIB / HASPI / ESTOI: nothing shared but the inputs); one stream gives the same bits
+    ts = GanTrainer('siib&haspi&estoi')
+    ts.metric_streams = False
+    s1, s2 = ts.true_metrics_pair(cw, enh, drc, nw, lengths=lens, drc_lengths=lens, norm=False)
+    assert torch.equal(s1, q1) and torch.equal(s2, q2)
+    assert torch.equal(ts.true_metrics(cw, enh, nw).clone(), a1)
+    assert ts._side is None and tr._side is not None and tr._side2 is not None and tr._fside is not None
+    ts.check_status()
 
 
 def test_haspi_dither_per_utterance_id_vs_oracle_and_batch_independent():
