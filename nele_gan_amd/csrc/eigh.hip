@@ -256,14 +256,51 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_repair2_kernel(double* __re
 #define EC_SPIN_LIMIT (1u << 22)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void st_tagged(u32x4* p, double v, unsigned tag) {
+// Exchange stores.  `sc1` (write-through, the line is DROPPED from the XCD's L2) is visible to every CU of the device; `sc0` keeps the
+// line in the XCD's L2, where the consumer's L1-bypassing poll finds it without a trip through the fabric - the consumer of a slot is
+// always a workgroup of the SAME matrix, which the blockIdx mapping puts on the same XCD (workgroup g runs on XCD g % 8).  That
+// placement is a property of the dispatcher, not of the ISA, so it is PROBED once per device (eigh_xch_probe_kernel: pairs of
+// workgroups laid out like the real launches ping-pong tagged slots with `sc0` stores); only if every pair got through does the
+// device-side flag ec_store_keep switch the cluster kernels over.  Measured: 6.93 -> 6.60 ms per 256 matrices (cluster stages
+// 2.31 + 0.88 -> 2.10 + 0.78 ms); a step costs two dependent exchanges.
+__device__ int ec_store_keep = 0;
+__device__ int ec_probe_ticket = 0, ec_probe_ok = 0;
+__device__ __forceinline__ void st_tagged(int keep, u32x4* p, double v, unsigned tag) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
     u32x4 q;
     q.x = (unsigned)u; q.y = tag; q.z = (unsigned)(u >> 32); q.w = tag;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+    if (keep) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(q) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
 }
 __device__ __forceinline__ double tagged_value(u32x4 q) {
     return __longlong_as_double((long long)(((unsigned long long)q.z << 32) | q.x));
+}
+__device__ __forceinline__ int ec_keep_flag() { return __builtin_amdgcn_readfirstlane(*(volatile int*)&ec_store_keep); }
+// grid 16 * pairs / 8 (the two-workgroup kernels' layout: workgroup g = 16 (m >> 3) + 8 p + (m & 7) is half p of pair m), block 64.
+// Every pair plays `rounds` rounds of ping-pong through two slots with the store flavour under test; the consumer has polled a slot's
+// previous value before the next one is stored, so a copy that another L2 kept would be stale for good and run into the spin limit.
+__global__ __launch_bounds__(64) void eigh_xch_probe_kernel(u32x4* slots, int pairs, int rounds) {
+    const int g = blockIdx.x, slot = g >> 3, p = slot & 1, m = (g & 7) + 8 * (slot >> 1);
+    if (m >= pairs || threadIdx.x != 0) return;
+    u32x4* mine = slots + 2 * m + p;                 // written by this half
+    const u32x4* theirs = slots + 2 * m + (1 - p);
+    bool ok = true;
+    for (int r = 1; r <= rounds && ok; ++r) {
+        if (p == 0) st_tagged(1, mine, (double)r, (unsigned)r);
+        unsigned spins = 0;
+        u32x4 q;
+        do {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(theirs) : "memory");
+        } while ((q.y != (unsigned)r || q.w != (unsigned)r) && ++spins < (1u << 16));
+        ok = (q.y == (unsigned)r && q.w == (unsigned)r && tagged_value(q) == (double)r);
+        if (p == 1 && ok) st_tagged(1, mine, (double)r, (unsigned)r);
+    }
+    if (ok) atomicAdd(&ec_probe_ok, 1);
+    __threadfence();
+    if (atomicAdd(&ec_probe_ticket, 1) == 2 * pairs - 1) {         // the last half to finish decides
+        __threadfence();
+        ec_store_keep = (atomicAdd(&ec_probe_ok, 0) == 2 * pairs) ? 1 : 0;
+    }
 }
 __device__ __forceinline__ double block_sum1(double v, double* slot) {   // one barrier; slot[16] is not reused before 2 more barriers
     v = wave_sum(v);
@@ -276,6 +313,7 @@ __device__ __forceinline__ double block_sum1(double v, double* slot) {   // one 
 }
 
 __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws) {
+    const int keep_ = ec_keep_flag();              // exchange stores may stay in the XCD's L2 (probed once per device)
     __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
     __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
     __shared__ double accb[16][64];
@@ -421,8 +459,8 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
                 EC_CASE(24) EC_CASE(25) EC_CASE(26) EC_CASE(27) EC_CASE(28) EC_CASE(29) EC_CASE(30) EC_CASE(31)
 #undef EC_CASE
             }
-            if (c0 >= s + 2 && c0 < n) st_tagged(&xp[EG_MAXN + c0], r0, tag);
-            if (c1 >= s + 2 && c1 < n) st_tagged(&xp[EG_MAXN + c1], r1, tag);
+            if (c0 >= s + 2 && c0 < n) st_tagged(keep_, &xp[EG_MAXN + c0], r0, tag);
+            if (c1 >= s + 2 && c1 < n) st_tagged(keep_, &xp[EG_MAXN + c1], r1, tag);
         }
         __syncthreads();
         if (tid < 64) {
@@ -430,7 +468,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += accb[q][tid];
             const int cc = p + EC_P * tid;
-            if (cc >= s + 2 && cc < n) st_tagged(&xp[cc], t, tag);
+            if (cc >= s + 2 && cc < n) st_tagged(keep_, &xp[cc], t, tag);
         }
         EC_T(4);
         // ---- consume the peers' slots for step s + 1
@@ -482,6 +520,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster_kernel(double* __res
 #define E4_P 4
 #define E4_RI 28
 __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop, int fail_every) {
+    const int keep_ = ec_keep_flag();              // exchange stores may stay in the XCD's L2 (probed once per device)
     __shared__ __attribute__((aligned(16))) double vperm[3][EG_MAXN];   // v, w, v_next at [(r & 15) * 32 + (r >> 4)]
     __shared__ double vnat[EG_MAXN], wnat[EG_MAXN];
     __shared__ double accb[16][128];
@@ -638,10 +677,10 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
                 EC_CASE(24) EC_CASE(25) EC_CASE(26) EC_CASE(27)
 #undef EC_CASE
             }
-            if (c0 >= s + 2 && c0 < n) st_tagged(&xp[EG_MAXN + c0], r0, tag);
-            if (c1 >= s + 2 && c1 < n) st_tagged(&xp[EG_MAXN + c1], r1, tag);
-            if (c2 >= s + 2 && c2 < n) st_tagged(&xp[EG_MAXN + c2], r2, tag);
-            if (has3 && c3 >= s + 2 && c3 < n) st_tagged(&xp[EG_MAXN + c3], aL[rq][rs][cl0], tag);
+            if (c0 >= s + 2 && c0 < n) st_tagged(keep_, &xp[EG_MAXN + c0], r0, tag);
+            if (c1 >= s + 2 && c1 < n) st_tagged(keep_, &xp[EG_MAXN + c1], r1, tag);
+            if (c2 >= s + 2 && c2 < n) st_tagged(keep_, &xp[EG_MAXN + c2], r2, tag);
+            if (has3 && c3 >= s + 2 && c3 < n) st_tagged(keep_, &xp[EG_MAXN + c3], aL[rq][rs][cl0], tag);
         }
         __syncthreads();
         if (tid < 128) {
@@ -649,7 +688,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster4_kernel(double* __re
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += accb[q][tid];
             const int cc = p + E4_P * tid;
-            if (tid < 112 && cc >= s + 2 && cc < n) st_tagged(&xp[cc], t, tag);
+            if (tid < 112 && cc >= s + 2 && cc < n) st_tagged(keep_, &xp[cc], t, tag);
         }
         EC_T(4);
         const bool need = (i >= s + 2) && (i < n);
@@ -738,6 +777,7 @@ __device__ unsigned long long ecs_prof[8];     // shader clocks of thread 0 of w
 #define ECS_T(j)
 #endif
 __global__ __launch_bounds__(512) void eigh_tridiag_clusters_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_stop, int fail_every) {
+    const int keep_ = ec_keep_flag();              // exchange stores may stay in the XCD's L2 (probed once per device)
     extern __shared__ double ecs_col[];                    // aL[ECS_RI][16][32]: column slot j = 0 of every lane
     __shared__ __attribute__((aligned(16))) double vperm[3][16 * ECS_LD];   // v, w, v_next at [(r & 15) * ECS_LD + (r >> 4)]
     __shared__ double accb[16][32 * ECS_NJ];
@@ -993,7 +1033,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_clusters_kernel(double* __re
         // lane cl0 now holds this workgroup's row sum of row slot ri = cl0
         {
             const int r = rs + 16 * cl0;
-            if (cl0 < ECS_RI && r >= lo && r < n) st_tagged(&xp[(1 + p) * EG_MAXN + r], u1, tag);
+            if (cl0 < ECS_RI && r >= lo && r < n) st_tagged(keep_, &xp[(1 + p) * EG_MAXN + r], u1, tag);
         }
         __syncthreads();
         if (tid < 32 * ECS_NJ) {
@@ -1001,9 +1041,9 @@ __global__ __launch_bounds__(512) void eigh_tridiag_clusters_kernel(double* __re
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += accb[q][tid];
             const int c = p + ECS_P * tid;
-            if (c >= lo && c < n) st_tagged(&xp[c], t, tag);
+            if (c >= lo && c < n) st_tagged(keep_, &xp[c], t, tag);
         }
-        if (owner && i >= lo && i < n) st_tagged(&xp[3 * EG_MAXN + i], prow[i], tag);
+        if (owner && i >= lo && i < n) st_tagged(keep_, &xp[3 * EG_MAXN + i], prow[i], tag);
         ECS_T(4);
         const bool need = (i >= lo) && (i < n);
         if (__any(need)) {
@@ -1087,6 +1127,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_clusters_kernel(double* __re
 #define EC2_M (16 * EC2_RI)
 __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __restrict__ Aall, int n, int b0, int Bc, EighWs ws, int s_first, int s_stop,
                                                                     int fail_every) {
+    const int keep_ = ec_keep_flag();              // exchange stores may stay in the XCD's L2 (probed once per device)
     extern __shared__ double ec2_col[];                    // aL[EC2_RI][16][32]: the fifth column slot of every lane
     __shared__ __attribute__((aligned(16))) double vperm[3][EC2_M + 64];   // v, w, v_next at [(r & 15) * EC2_RI + (r >> 4)]
     __shared__ double vnat[EC2_M], wnat[EC2_M];
@@ -1253,8 +1294,8 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
             }
 #pragma unroll
             for (int j = 0; j < EC2_NR; ++j)
-                if (cc[j] >= lo && cc[j] < m) st_tagged(&xp[EG_MAXN + cc[j]], rv[j], tag);
-            if (cc[EC2_NR] >= lo && cc[EC2_NR] < m) st_tagged(&xp[EG_MAXN + cc[EC2_NR]], aL[rq][rs][cl0], tag);
+                if (cc[j] >= lo && cc[j] < m) st_tagged(keep_, &xp[EG_MAXN + cc[j]], rv[j], tag);
+            if (cc[EC2_NR] >= lo && cc[EC2_NR] < m) st_tagged(keep_, &xp[EG_MAXN + cc[EC2_NR]], aL[rq][rs][cl0], tag);
         }
         __syncthreads();
         if (tid < 32 * (EC2_NR + 1)) {
@@ -1262,7 +1303,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_cluster2_kernel(double* __re
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += accb[q][tid];
             const int c = p + EC2_P * tid;                 // accb column tid = cl0 + 32 j  <->  local column p + 2 (cl0 + 32 j)
-            if (c >= lo && c < m) st_tagged(&xp[c], t, tag);
+            if (c >= lo && c < m) st_tagged(keep_, &xp[c], t, tag);
         }
         const bool need = own && (il >= lo);
         if (__any(need)) {
@@ -2842,6 +2883,15 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
     }
     int c2_first = -1;                                     // first step of the second cluster stage when it runs (its give-ups are repaired from there)
     if (cluster_cap >= 8) {
+        // once per device: may the exchange stores stay in the XCD's L2 (st_tagged)?  128 pairs of workgroups = one per CU, laid out like
+        // the two-workgroup launches, 64 rounds of ping-pong each; the device-side flag stays 0 (write-through stores) unless all pass.
+        // NELE_EIGH_XCH_KEEP=0 (test library) skips the probe.
+        if (NELE_SWITCH_INT("NELE_EIGH_XCH_KEEP", 1)) {
+            NELE_ONCE_PER_DEVICE({
+                if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * 256, s) == hipSuccess)
+                    hipLaunchKernelGGL(eigh_xch_probe_kernel, dim3(256), dim3(64), 0, s, reinterpret_cast<u32x4*>(ws.xch), 128, 64);
+            });
+        }
         if (hipMemsetAsync(ws.xch, 0, sizeof(uint4) * (size_t)B * EG_XCH * EG_MAXN, s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         if (hipMemsetAsync(ws.flag, 0, sizeof(int) * ((size_t)B + 1), s) != hipSuccess) return nele_set_error(NELE_ERR_HIP, "nele_eigh_sym_batched: memset failed");
         // a launch owns 8 CUs per matrix for ~2 ms whatever the count (the kernel is latency-bound per matrix): small batches go in

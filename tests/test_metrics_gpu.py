@@ -631,3 +631,40 @@ def test_symmetric_first_cluster_stage_agrees_with_the_full_storage_kernel(tmp_p
         pos += n * B + 2
     np.testing.assert_allclose(a[nl:nl + 3], b[nl:nl + 3], rtol=1e-6)
     assert np.all(a[nl + 3:] == b[nl + 3:])
+
+
+_KEEP_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nele_gan_amd import metrics as mt
+out = []
+for n, B in ((420, 40), (300, 9)):
+    rs = np.random.RandomState(3000 + n)
+    A = np.zeros((B, n, n))
+    for b in range(B):
+        G = rs.randn(n, 3 * n) * np.exp(-0.01 * np.arange(3 * n))[None, :]
+        A[b] = G @ G.T / (3 * n)
+    At = torch.from_numpy(A).cuda()
+    for rep in range(2):                      # the first call of a process launches the probe; the second runs with its verdict
+        lam, U, repaired = mt.eigh_batched(At, return_repaired=True)
+    out += [lam.cpu().numpy().ravel(), U.cpu().numpy().ravel(), np.array([float(repaired)])]
+np.save(sys.argv[2], np.concatenate(out))
+'''
+
+
+def test_exchange_stores_kept_in_the_xcd_l2_give_the_same_bits_and_no_give_ups(tmp_path):
+    """Round 4, second session: the cluster kernels' tagged exchange stores stay in the XCD's L2 (`sc0`) once eigh_xch_probe_kernel has
+    shown, once per device, that the workgroups of a matrix do sit on one XCD (128 workgroup pairs laid out like the real launches,
+    64 ping-pong rounds each); otherwise they are written through (`sc1`), as before.  Same arithmetic either way: eigenvalues and
+    eigenvectors are bit-identical to NELE_EIGH_XCH_KEEP=0 (test library), and no matrix runs into the spin limit (repaired == 0)."""
+    import subprocess
+    import sys
+    res = []
+    for flag in ('1', '0'):
+        out = str(tmp_path / ('keep_%s.npy' % flag))
+        subprocess.run([sys.executable, '-c', _KEEP_CHILD, os.path.dirname(HERE), out], check=True, env=ab_env(NELE_EIGH_XCH_KEEP=flag), timeout=240)
+        res.append(np.load(out))
+    a, b = res
+    assert a.shape == b.shape and np.all(np.isfinite(a)) and np.array_equal(a, b)
+    n1 = 420 * 40 + 420 * 420 * 40
+    assert a[n1] == 0.0 and a[-1] == 0.0
