@@ -157,14 +157,14 @@ def inference_rate(tr, batch, K, rank):
             'realtime_factor': batch * 8.0 / dt}
 
 
-def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None):
+def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None):
     """The canonical step of another workload on this GPU (fresh trainer, 2 warm-up steps, `steps` timed steps)."""
     import gc
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
     try:
-        return _companion(a, metric_str, batch, length, steps, main_tr, precision)
+        return _companion(a, metric_str, batch, length, steps, main_tr, precision, pipe)
     except Exception as e:                                  # a companion must not take the headline line down with it
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300]), 'batch': batch, 'samples_per_utterance': length, 'metrics': metric_str}
     finally:
@@ -172,7 +172,7 @@ def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None)
         torch.cuda.empty_cache()                            # multi-GB metric workspaces of the companion's trainer
 
 
-def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None):
+def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None):
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
@@ -211,13 +211,16 @@ def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None
         assert bool(torch.isfinite(tgt).all()) and bool(torch.isfinite(ld))
         tr.check_status()
         return dt
-    pipe = batch <= tr.early_prefetch_max_batch or os.environ.get('NELE_PREFETCH', '0') == '1'
+    if pipe is None:
+        pipe = batch <= tr.early_prefetch_max_batch or os.environ.get('NELE_PREFETCH', '0') == '1'
     dt_plain = timed(False)
     dt = timed(True) if pipe else dt_plain
     out = {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_step': dt * 1e3, 'batch': batch, 'samples_per_utterance': length,
            'metrics': metric_str, 'steps': steps, 'dtype': precision or a.precision}
     if pipe:
-        out['pipeline'] = "next batch's input-only work (features, clean-signal halves of the metrics) enqueued at the start of the step (canonical_step(next_batch=...))"
+        out['pipeline'] = ("next batch's input-only work (features, clean-signal halves of the metrics) enqueued at the start of the step (canonical_step(next_batch=...))"
+                           if batch <= tr.early_prefetch_max_batch else
+                           "next batch's features enqueued behind this step's targets (canonical_step(next_batch=...), late_prefetch = 'features')")
         out['ms_per_step_plain'] = dt_plain * 1e3
     return out
 
@@ -541,6 +544,9 @@ def main():
             # whole global batch on one GPU.  predicted ratio = t(1024) / (t(128) + the step's two gradient all-reduces); the all-reduce
             # figure is an ESTIMATE (8.37 MB + 1.37 MB float32 over an 8-rank RCCL ring on xGMI, latency-bound) until an 8-GPU
             # node measures `allreduce_ms_per_step`
+            # the headline workload with the next batch's FEATURES prefetched behind the targets (what a DataLoader-fed loop can do at any batch
+            # size; `value` itself stays the plain step: every step strictly on its own)
+            out['headline_pipelined'] = companion(a, a.metrics, a.batch, a.length, 6, tr, pipe=True)
             out['shard128'] = companion(a, a.metrics, 128, a.length, 6, tr)
             out['global1024'] = companion(a, a.metrics, 1024, a.length, 3, tr)
             if 'ms_per_step' in out['shard128'] and 'ms_per_step' in out['global1024']:

@@ -143,6 +143,10 @@ class GanTrainer:
         # Two sets of metric workspaces alternate (batch k's degraded-signal half still needs batch k's eigenvectors while batch
         # k + 1's are computed); _sets[i] is the parked workspace dict while set 1 - i is the active one (self._ws).
         self.early_prefetch_max_batch = 64
+        # what a LARGE batch's canonical_step(next_batch=...) enqueues behind its targets: 'features' (STFT / band energies / IMCRA of the
+        # next batch fill the D backward pass: 38.1 -> 37.7 ms at B = 256) or 'all' (the metrics' clean-signal halves too: 40.1 ms - the
+        # GPU is saturated, they only slow the D-step's critical chain down)
+        self.late_prefetch = 'features'
         self.metric_streams = True                   # true_metrics / true_metrics_pair: one stream per metric (False: all on the current stream)
         self._sets = [None, {}]
         self._cur_set = 0
@@ -493,7 +497,7 @@ class GanTrainer:
             self.D._wstream, self.G._wstream = self._wstreams_plain
             self._wstreams_plain = None
 
-    def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features, utt_ids=None):
+    def _input_only_work(self, clean_wav, noise_wav, lengths, after, with_features, utt_ids=None, with_metrics=True):
         """Everything of a step that needs only its INPUTS, enqueued on the side streams behind event ``after``: the clean-signal
         halves of SIIB (VAD .. eigen-decomposition .. clean projections) and HASPI (the whole reference-signal chain) and, with
         ``with_features``, the features of both waveforms.  -> dict."""
@@ -506,19 +510,19 @@ class GanTrainer:
         lengths = au._i32(lengths, self.device)
         mlens = self.enhanced_lengths(lengths)             # what the metrics see of each utterance (audio_util.py:134-141)
         w = {'clean': clean_wav, 'noise': noise_wav, 'lengths': lengths, 'mlens': mlens, 'split': None, 'hsplit': None, 'feats': None,
-             'dither': None, 'utt_ids': utt_ids, 'set': self._cur_set, 'clean_done': None, 'clean_stream': None}
+             'dither': None, 'utt_ids': utt_ids, 'set': self._cur_set, 'clean_done': None, 'clean_stream': None, 'metrics': bool(with_metrics)}
         with torch.cuda.stream(side):
             side.wait_event(after)
             w['x'] = clean_wav[:, :L].contiguous()
             x_ready = torch.cuda.Event()
             x_ready.record(side)
-            if 'siib' in self.metrics:
+            if 'siib' in self.metrics and with_metrics:
                 w['split'] = mt.SiibSplit(w['x'], lengths=mlens, owner=self._ws)
                 w['split'].clean_part()
             w['clean_done'] = torch.cuda.Event()
             w['clean_done'].record(side)
             w['clean_stream'] = side
-        if 'haspi' in self.metrics and self.split_haspi:
+        if 'haspi' in self.metrics and self.split_haspi and with_metrics:
             # HASPI's reference-signal half (ear model .. modulation filters of the CLEAN signal) needs no enhanced signal either
             with torch.cuda.stream(side2):
                 side2.wait_event(after)
@@ -541,7 +545,7 @@ class GanTrainer:
                 w['feats_ready'].record(fs_)
         return w
 
-    def prefetch(self, clean_wav, noise_wav, lengths=None, after=None, utt_ids=None):
+    def prefetch(self, clean_wav, noise_wav, lengths=None, after=None, utt_ids=None, with_metrics=True):
         """The input-only work of the NEXT batch, as the reference's DataLoader workers prepare the features of upcoming items
         while the current one trains (dataloader.py:86-92, 8 workers).  canonical_step(..., next_batch=...) calls this at the point where
         the current step's targets are done, so that the work fills the D backward pass (the one phase of a step in which the side
@@ -550,7 +554,7 @@ class GanTrainer:
         if after is None:
             after = torch.cuda.Event()
             after.record(torch.cuda.current_stream())
-        return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True, utt_ids=utt_ids)
+        return self._input_only_work(clean_wav, noise_wav, lengths, after, with_features=True, utt_ids=utt_ids, with_metrics=with_metrics)
 
     def canonical_step(self, clean_wav, noise_wav, feats=None, lengths=None, pre=None, next_batch=None, utt_ids=None, early=None):
         """features -> G-step -> generate -> true metrics -> D-step on the same batch.  lengths [B] (optional): samples of each
@@ -587,10 +591,14 @@ class GanTrainer:
         with torch.cuda.stream(p1):
             p1.wait_event(start)                           # after the previous step's D update
             self.D.prepare(B_, T_, self.device)
-        if pre is None:
-            pre = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False, utt_ids=utt_ids)
-        else:
+        if pre is not None:
             assert pre['clean'] is clean_wav and pre['noise'] is noise_wav, "canonical_step: `pre` belongs to another batch"
+        if pre is None or not pre['metrics']:
+            # nothing prefetched, or the features only (late_prefetch = 'features'): the metrics' clean-signal halves start with the step
+            mine_ = self._input_only_work(clean_wav, noise_wav, lengths, start, with_features=False, utt_ids=utt_ids)
+            if pre is not None:
+                mine_['feats'], mine_['feats_ready'] = pre['feats'], pre['feats_ready']
+            pre = mine_
         early_pre = None
         if early:
             # the next batch's input-only work, now: features on the feature stream, SIIB's clean-signal half on the metric stream (whose
@@ -675,7 +683,7 @@ class GanTrainer:
         self.prefetched = early_pre
         if next_batch is not None and early_pre is None:    # the next batch's input-only work fills the D backward pass
             self.prefetched = self.prefetch(next_batch[0], next_batch[1], next_batch[2] if len(next_batch) > 2 else None, after=done,
-                                            utt_ids=next_batch[3] if len(next_batch) > 3 else None)
+                                            utt_ids=next_batch[3] if len(next_batch) > 3 else None, with_metrics=self.late_prefetch == 'all')
         # Both metric streams join the MAIN stream (behind D's forward pass, which does not need the targets), and the [B, n_metrics]
         # target tensor is stacked there.  (Until round 4 the second metric stream joined the first one, which stacked: ROCm 7's stream
         # capture segfaults in hipStreamEndCapture on that side-stream-into-side-stream join - tools/graph_probe2.py v3.)

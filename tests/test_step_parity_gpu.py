@@ -98,9 +98,11 @@ def test_delayed_side_streams_do_not_change_the_step():
         assert len(tr.D._bufs) == 1 and len(tr.G._bufs) == 1
 
 
-def test_prefetched_pipeline_is_bit_identical_to_plain_steps():
-    """canonical_step(pre=..., next_batch=...) moves the input-only work of batch k + 1 (features, SIIB / HASPI clean halves) behind the
-    targets of batch k.  Three steps over two alternating batches must reproduce the plain step-by-step sequence bit for bit."""
+@pytest.mark.parametrize('what', ['all', 'features'])
+def test_prefetched_pipeline_is_bit_identical_to_plain_steps(what):
+    """canonical_step(pre=..., next_batch=..., early=False) moves the input-only work of batch k + 1 (late_prefetch = 'all': features, SIIB /
+    HASPI clean halves; 'features': the features only, the default for large batches) behind the targets of batch k.  Three steps over two
+    alternating batches must reproduce the plain step-by-step sequence bit for bit."""
     from nele_gan_amd import synth
     batches = []
     for st in (40, 140):
@@ -108,7 +110,8 @@ def test_prefetched_pipeline_is_bit_identical_to_plain_steps():
         batches.append((torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()))
     a = _trainer('siib&haspi&estoi', 'bf16')
     b = _trainer('siib&haspi&estoi', 'bf16')
-    pre = a.prefetch(*batches[0])
+    a.late_prefetch = what
+    pre = a.prefetch(*batches[0], with_metrics=(what == 'all'))
     for k in range(3):
         cur, nxt = batches[k % 2], batches[(k + 1) % 2]
         ra = a.canonical_step(cur[0], cur[1], pre=pre, next_batch=nxt, early=False)

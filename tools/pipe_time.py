@@ -11,12 +11,13 @@ tr = GanTrainer(target_metric=M)
 tr.D.precision = 'bf16'; tr.G.precision = 'bf16'
 c, v = synth.batch(B, 64000, start=0)
 cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
-for mode in ('plain', 'late', 'early', 'plain', 'early'):
+for mode in (sys.argv[4].split(',') if len(sys.argv) > 4 else ('plain', 'late', 'early', 'plain', 'early')):
     pre = None
     def one():
         global pre
         if mode == 'plain':
             return tr.canonical_step(cw, nw)
+        tr.late_prefetch = 'features' if mode == 'feats' else 'all'
         r = tr.canonical_step(cw, nw, pre=pre, next_batch=(cw, nw), early=(mode == 'early'))
         pre = tr.prefetched
         return r
