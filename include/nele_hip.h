@@ -27,6 +27,11 @@ int nele_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 /* 0 for the product library (libnele_hip.so: one path per operation, no environment switch is read); 1 for the test library built from
  * the same sources with -DNELE_AB (libnele_hip_ab.so), in which the superseded kernel variants exist and NELE_* switches select them. */
 int nele_build_has_ab_switches(void);
+/* Measurement aid (no reference counterpart): one wave that idles for `microseconds` on `stream`.  The HIP runtime multiplexes streams
+ * onto a handful of hardware queues; a caller that keeps a long dependent chain on one stream (train_nele.py's pipelined small-batch
+ * step) finds out which of its other streams share that queue by parking this kernel on the first and timing a trivial kernel on the
+ * others. */
+int nele_stream_spin(double microseconds, void* stream);
 
 /* Measurement hook (no reference counterpart): HIP-event timing of single kernels that are launched from inside multi-kernel entry
  * points, on the stream they run on.  nele_profile_begin(tags) arms it for the launch sites whose tag is in the comma-separated list

@@ -42,6 +42,19 @@ extern "C" int nele_build_has_ab_switches(void) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ stream / hardware-queue probe
+// One wave that does nothing for `ticks` of the 100 MHz wall clock.  The host side (GanTrainer._pipeline_queues) parks it on one stream
+// and times a trivial kernel on another: streams that the runtime mapped onto the same hardware queue run strictly one after the other.
+__global__ void nele_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int nele_stream_spin(double microseconds, void* stream) {
+    if (!(microseconds >= 0.0) || microseconds > 1e5) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_stream_spin: 0 .. 100 000 us");
+    hipLaunchKernelGGL(nele_spin_kernel, dim3(1), dim3(64), 0, as_stream(stream), (long long)(microseconds * 100.0));
+    return hipGetLastError() == hipSuccess ? NELE_OK : nele_set_error(NELE_ERR_HIP, "nele_stream_spin: launch failed");
+}
+
 bool nele_first_use_on_device(unsigned long long* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)

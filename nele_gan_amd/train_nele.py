@@ -11,6 +11,7 @@ batch 1 with wav files on disk as the hand-off between G, the metrics and D), th
 normalisation stays per utterance, and gradients are averaged across ranks with one flat RCCL
 all-reduce per model per optimiser step when torch.distributed is initialised.
 """
+import ctypes
 import os
 import random
 
@@ -151,6 +152,7 @@ class GanTrainer:
         self._sets = [None, {}]
         self._cur_set = 0
         self._wstreams_plain = None                  # D's weight-gradient streams outside the pipelined step (see _pipeline_queues)
+        self._queues_checked = False                 # _pipeline_queues has verified that the three pipelined streams sit on three hardware queues
         self.split_haspi = os.environ.get('NELE_HASPI_SPLIT', '1') != '0'   # HASPI's clean-signal half beside the G-step (A/B switch)
         # metric status, accumulated on the device without a host synchronisation and read by check_status():
         # [SIIB undefined (too few active frames: pysiib raises), SIIB clamped (M / frame caps hit: truncated score),
@@ -473,15 +475,34 @@ class GanTrainer:
     def _all_side_streams(self):
         return [st_ for st_ in (self._side, self._side2, self._fside) if st_ is not None]
 
+    def _shares_queue(self, a, b, spin_us=300.0):
+        """Does a kernel on stream ``b`` wait behind a kernel running on stream ``a`` (same hardware queue)?  Parks one idle wave on ``a`` for
+        ``spin_us`` and times a trivial kernel on ``b``: on another queue it finishes long before the spin does.  Synchronises (called
+        a handful of times, once per trainer)."""
+        from ._lib import call
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        t = torch.zeros(64, device=dev)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(a):
+            call('nele_stream_spin', float(spin_us), ctypes.c_void_p(a.cuda_stream))
+            ea.record(a)
+        with torch.cuda.stream(b):
+            t.add_(1.0)
+            eb.record(b)
+        torch.cuda.synchronize(dev)
+        return eb.elapsed_time(ea) < 0.5 * spin_us * 1e-3       # b's kernel ended less than half a spin before the spin did (or after it)
+
     def _pipeline_queues(self, on):
         """The HIP runtime multiplexes all streams onto four hardware queues: the default stream has its own; side streams get
-        the other three in the order of their first use and share them beyond the third.  In a plain step the trainer's six side streams
+        the other three, in an order the runtime decides, and share them beyond the third.  In a plain step the trainer's six side streams
         pair up in phases that never overlap.  In the pipelined step the next batch's eigen-decomposition occupies the metric stream's
         queue with 1 ms kernels for the WHOLE step and whatever shares that queue waits behind them (kernel trace at B = 32: G's or D's
         weight gradients, + 0.9 ms per step, whichever of their streams the runtime happened to put there).  So while pipelining only
-        THREE side streams are in use - the first three the trainer ever touched, one queue each: the metric stream carries the long
-        chain alone, the weight gradients of G and D ride on the feature stream and the second metric stream, which are idle in those
-        phases."""
+        THREE side streams are in use, one queue each: the metric stream carries the long chain alone; the weight gradients of G and D
+        ride on the feature stream and the second metric stream, which are idle in those phases.  That the three do sit on three
+        queues is MEASURED once per trainer (_shares_queue: an idle wave parked on the metric stream, a trivial kernel timed on the other);
+        a stream that shares the metric stream's queue is replaced by a fresh one that does not."""
         dev = self.device
         if self._side is None:
             self._side = ops.side_stream(dev)
@@ -489,6 +510,13 @@ class GanTrainer:
             self._side2 = ops.side_stream(dev)
         if self._fside is None:
             self._fside = ops.side_stream(dev)
+        if on and not self._queues_checked and dev.type == 'cuda' and self._side != torch.cuda.current_stream(dev):
+            self._queues_checked = True
+            for name in ('_side2', '_fside'):
+                tries = 0
+                while self._shares_queue(self._side, getattr(self, name)) and tries < 8:
+                    setattr(self, name, torch.cuda.Stream(device=dev))
+                    tries += 1
         if on and self._wstreams_plain is None:
             self._wstreams_plain = (self.D._wstream, self.G._wstream)
             self.D._wstream = (self._fside, self._side2)

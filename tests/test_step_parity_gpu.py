@@ -154,6 +154,27 @@ def test_early_prefetch_on_the_second_stream_set_is_bit_identical_to_plain_steps
     assert all(x == 0 for x in a.check_status().values())
 
 
+def test_pipelined_streams_are_measured_onto_three_hardware_queues():
+    """The pipelined step keeps the next batch's eigen-decomposition on the metric stream for a whole step, so nothing else may share that
+    stream's hardware queue (the runtime multiplexes streams onto four).  GanTrainer._shares_queue measures it (an idle wave parked on one
+    stream by nele_stream_spin, a trivial kernel timed on the other): a stream shares a queue with itself, and after _pipeline_queues
+    neither the feature stream nor the second metric stream shares the metric stream's - even when twelve other streams were
+    touched first."""
+    tr = _trainer('siib&estoi', 'bf16')
+    noise = [torch.cuda.Stream() for _ in range(12)]
+    for st in noise:                                        # make the runtime hand out its queues before the trainer asks
+        with torch.cuda.stream(st):
+            torch.zeros(8, device='cuda').add_(1.0)
+    torch.cuda.synchronize()
+    tr._pipeline_queues(True)
+    assert tr._shares_queue(tr._side, tr._side)
+    assert not tr._shares_queue(tr._side, tr._fside)
+    assert not tr._shares_queue(tr._side, tr._side2)
+    assert tr.D._wstream == (tr._fside, tr._side2) and tr.G._wstream == tr._fside
+    tr._pipeline_queues(False)
+    assert tr.D._wstream is None or tr._fside not in tr.D._wstream
+
+
 # tolerances of the bf16 operand mode against the float32 ORACLE (8-bit mantissa operands, float32 accumulation; DESIGN 4.1)
 BF16 = dict(score_abs=4e-3, loss_rel=3e-2, mask_rel=8e-2, grad_l2=0.12, grad_cos=0.99, enh_rel_l2=5e-2)
 
