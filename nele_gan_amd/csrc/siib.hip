@@ -389,6 +389,9 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
 // (what is left by diagnostic builds: band stage 1.1 ms, sample / table loads 0.5 ms, the transform itself 1.3 ms, instruction-issue
 // bound - every wave64 instruction takes four cycles and only 40 % of them are float64 arithmetic).
 #define SPW_NG 4
+#ifndef SPW_BLK
+#define SPW_BLK 10        // filter rows of the band stage in flight per block (divides 100): 2 2.87, 4 2.62, 5 2.61, 10 2.53, 20 2.62, 25 2.82, 50 2.78 ms
+#endif                   // per call at B = 256, L = 63 871 (both signals; tools/r4_sp.sh) - the stage is not waiting for L2, more loads in flight only cost registers
 // cos / sin (2 pi t / 20): the kernel reads entries 1 .. 4 (the four magnitudes) as scalars
 __constant__ double c_dft20c[20] = {1.0, 0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
                                     -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
@@ -526,16 +529,16 @@ __global__ __launch_bounds__(128, 2) void siib_spec_wave_kernel(const float* __r
             sb_wave_sync();
             // band energies of the wave's three frames: out[f][j] = sum_q |X_f[q]|^2 g2[j][q]
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-            // bins 100 bp .. 100 bp + 99 in four blocks of 25 filter rows, all loads of a block in flight; bin 200 belongs to half 1
+            // bins 100 bp .. 100 bp + 99 in blocks of SPW_BLK filter rows, all loads of a block in flight; bin 200 belongs to half 1
             const double g200 = ws.g2t[200 * SB_J + bj];
 #pragma unroll 1
-            for (int c = 0; c < 4; ++c) {
-                double gq[25];
+            for (int c = 0; c < 100 / SPW_BLK; ++c) {
+                double gq[SPW_BLK];
 #pragma unroll
-                for (int u = 0; u < 25; ++u) gq[u] = gp[(25 * c + u) * SB_J];
+                for (int u = 0; u < SPW_BLK; ++u) gq[u] = gp[(SPW_BLK * c + u) * SB_J];
 #pragma unroll
-                for (int u = 0; u < 25; ++u) {
-                    const int q = 25 * c + u;
+                for (int u = 0; u < SPW_BLK; ++u) {
+                    const int q = SPW_BLK * c + u;
                     e0 += gq[u] * P0[q]; e1 += gq[u] * P1[q]; e2 += gq[u] * P2[q];
                 }
             }
