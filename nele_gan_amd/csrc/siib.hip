@@ -388,7 +388,9 @@ __global__ __launch_bounds__(128) void siib_spec_kernel(const float* __restrict_
 // last float32 bit or two (tests/test_metrics_gpu.py).  Measured at B = 256, L = 63 871, both signals in one launch: 5.73 -> 2.79 ms
 // (what is left by diagnostic builds: band stage 1.1 ms, sample / table loads 0.5 ms, the transform itself 1.3 ms, instruction-issue
 // bound - every wave64 instruction takes four cycles and only 40 % of them are float64 arithmetic).
-#define SPW_NG 4
+#ifndef SPW_NG
+#define SPW_NG 1         // groups of SP_F frames a workgroup walks: 1 2.43, 2 2.46, 4 2.52, 8 2.59, 16 2.73 ms per call (B = 256, L = 63 871)
+#endif
 #ifndef SPW_BLK
 #define SPW_BLK 10        // filter rows of the band stage in flight per block (divides 100): 2 2.87, 4 2.62, 5 2.61, 10 2.53, 20 2.62, 25 2.82, 50 2.78 ms
 #endif                   // per call at B = 256, L = 63 871 (both signals; tools/r4_sp.sh) - the stage is not waiting for L2, more loads in flight only cost registers
