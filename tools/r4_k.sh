@@ -10,3 +10,7 @@ mkdir -p gpurun_out/r04_prof/out; cp profiles/r04/traffic.json gpurun_out/r04_pr
 python tools/kstats.py gpurun_out/r04_prof/stats 4 8
 python tools/kstats.py gpurun_out/r04_prof/stats_serial 4 16
 python bench.py > gpurun_out/r04_prof/out/bench_default.json 2> gpurun_out/r04_prof/out/bench_default.err; tail -c 300 gpurun_out/r04_prof/out/bench_default.json
+# the eigensolver alone (256 matrices of order 420 in one call: the figure the r03 verdict's "<= 7 ms" is about)
+cd /tmp; rm -rf /tmp/pe; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -- python3 $GRAFT_REPO_ROOT/tools/eigh_time.py 256 420 3 > /tmp/pe.log 2>&1
+cd $GRAFT_REPO_ROOT; cp /tmp/pe/*/*_kernel_stats.csv gpurun_out/r04_prof/out/eigh_standalone_kernel_stats.csv; tail -1 /tmp/pe.log | tee gpurun_out/r04_prof/out/eigh_standalone.txt
+timeout 100 python tools/eigh_time.py 256 420 5 2>&1 | tail -1 | tee -a gpurun_out/r04_prof/out/eigh_standalone.txt
