@@ -382,7 +382,7 @@ __global__ void conv16_frag_kernel(C16FragJobs J) {
 
 // ------------------------------------------------------------------------------------------ host side
 struct C16Plan { int TN, TH, NR, RSP, lgC, swz_sh, swz_mask, sps; size_t lds; };
-static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
+static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl, int epi = EPI_NONE) {
     if (N < 4 || N > 64 || (N & 3) || g.C < 8 || g.C > 64 || (g.C & 7) || KH < 2 || KW < 2 || KW > 9 || KH > 9) return false;
     if (g.seglen != KW * g.C || g.Ktot != KH * KW * g.C) return false;
     C16Plan q;
@@ -392,6 +392,10 @@ static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl) {
     // tile rows: 8 where the layer is bound by memory (little work per staged byte) and the registers / LDS allow, else 4
     const int th_env = NELE_SWITCH_INT("NELE_CONV16_TH", 0);
     int th = (nsteps * q.TN <= 64 && q.TN <= 2) ? 8 : 4;      // (TN >= 3 with 8 rows does not fit 256 registers)
+    // ... except for data gradients: their epilogue loads the forward activation for the LeakyReLU mask, and twice the workgroups hide that
+    // latency better than 8-row tiles save prologues (conv3's data gradient 0.285 -> 0.222 ms, conv2's 0.137 -> 0.118 at B = 256; the
+    // forward passes of the same layers lose 4 - 8 % with 4 rows)
+    if (epi == EPI_MASK_LRELU_GRAD) th = 4;
     if (th_env == 4 || (th_env == 8 && q.TN <= 2)) th = th_env;
     q.TH = th;
     // 16-byte fragment reads of 16 consecutive positions: conflict-free at stride 16, 32 and 96 bytes (C = 8, 16, 48); at 64 / 128 bytes
@@ -466,7 +470,7 @@ extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias
     ConvGeom g;
     memcpy(&g, geom, sizeof(ConvGeom));
     C16Plan pl;
-    if (!c16_plan(N, g, KH, KW, &pl)) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv16: unsupported geometry (C %d N %d %dx%d)", g.C, N, KH, KW);
+    if (!c16_plan(N, g, KH, KW, &pl, epi)) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_conv16: unsupported geometry (C %d N %d %dx%d)", g.C, N, KH, KW);
     NELE_CHECK_ARG(epi == EPI_NONE || epi == EPI_BIAS || epi == EPI_BIAS_LRELU || epi == EPI_MASK_LRELU_GRAD, "nele_conv16: epilogue %d", epi);
     NELE_CHECK_ARG(epi != EPI_MASK_LRELU_GRAD || aux16, "nele_conv16: the mask epilogue needs the forward activation");
     NELE_CHECK_ARG((epi != EPI_BIAS && epi != EPI_BIAS_LRELU) || bias, "nele_conv16: bias missing");
