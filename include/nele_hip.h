@@ -71,9 +71,12 @@ int nele_gain_istft(const float* alpha2, const void* spec, int B, int T, float* 
 int nele_gain_istft_var(const float* alpha2, const void* spec, const int* frames, int B, int T, float* wav, void* stream);
 
 /* inference.py:109 (enh / rms(enh) * target_rms, skipped when target_rms <= 0) and the PCM_16
- * write/read round trip of train_nele.py:313 + dataloader.py:58 (pcm16 != 0).  In place on wav [B][N]. */
-int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, void* stream);
-int nele_wav_post_var(float* wav, const int* frames, int B, int N, float target_rms, int pcm16, void* stream);   /* row b has 256 (frames[b] - 1) samples */
+ * write/read round trip of train_nele.py:313 + dataloader.py:58 (pcm16 != 0).  In place on wav [B][N].
+ * workspace: nele_wav_post_workspace_doubles(B, N) float64 values (per-chunk sums of squares; only read when target_rms > 0, else NULL). */
+long long nele_wav_post_workspace_doubles(int B, int N);
+int nele_wav_post(float* wav, int B, int N, float target_rms, int pcm16, double* workspace, void* stream);
+int nele_wav_post_var(float* wav, const int* frames, int B, int N, float target_rms, int pcm16, double* workspace,
+                      void* stream);   /* row b has 256 (frames[b] - 1) samples */
 
 /* ---- dense layers: convolution as implicit GEMM on the f32 matrix cores (csrc/dense.hip) ------- */
 

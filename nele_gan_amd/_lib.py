@@ -43,14 +43,14 @@ _SIGS = {
     'nele_stft_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft': [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
-    'nele_wav_post': [c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'nele_wav_post': [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'nele_profile_begin': [ctypes.c_char_p],
     'nele_profile_collect': [c_void_p, c_int],
     'nele_profile_collect_tag': [ctypes.c_char_p, c_void_p, c_int],
     'nele_stft_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft_var': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
-    'nele_wav_post_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'nele_wav_post_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'nele_compute_band_E': [c_void_p, c_int, c_void_p, c_void_p],
     'nele_interp_band_gain': [c_void_p, c_int, c_void_p, c_void_p],
 }
@@ -65,6 +65,9 @@ def declare(name, argtypes):
 
 for _n, _a in _SIGS.items():
     declare(_n, _a)
+lib.nele_wav_post_workspace_doubles.argtypes = [c_int, c_int]
+lib.nele_wav_post_workspace_doubles.restype = c_longlong
+_SIGS['nele_wav_post_workspace_doubles'] = lib.nele_wav_post_workspace_doubles.argtypes
 
 
 def check(status, name=''):

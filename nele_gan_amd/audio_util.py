@@ -93,7 +93,10 @@ def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False, frames=None):
     frames = _i32(frames, spec.device)
     call('nele_gain_istft_var', ptr(alpha2), ptr(spec), ptr(frames), B, T, ptr(wav), stream())
     if rms_target > 0 or pcm16:
-        call('nele_wav_post_var', ptr(wav), ptr(frames), B, wav.shape[1], float(rms_target), int(bool(pcm16)), stream())
+        ws = None
+        if rms_target > 0:
+            ws = torch.empty(int(_lib.lib.nele_wav_post_workspace_doubles(B, wav.shape[1])), dtype=torch.float64, device=wav.device)
+        call('nele_wav_post_var', ptr(wav), ptr(frames), B, wav.shape[1], float(rms_target), int(bool(pcm16)), ptr(ws), stream())
     return wav
 
 
@@ -101,7 +104,7 @@ def pcm16_roundtrip(wav):
     """In-place emulation of sf.write(..., 'PCM_16') followed by librosa.load."""
     wav = wav.contiguous()
     B = 1 if wav.dim() == 1 else wav.shape[0]
-    call('nele_wav_post', ptr(wav), B, wav.shape[-1], 0.0, 1, stream())
+    call('nele_wav_post', ptr(wav), B, wav.shape[-1], 0.0, 1, None, stream())
     return wav
 
 

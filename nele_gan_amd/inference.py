@@ -1,12 +1,19 @@
 """Enhancement path of the reference ``inference.py`` (inference.py:79-117), batched on the GPU:
 features -> G (eval) -> mask * beta2 -> resynthesis -> enh / rms(enh) * 0.03 -> PCM_16.
 
-``Enhancer.enhance``      one padded batch resident in HBM (optional per-utterance lengths)
-``enhance_files``         the reference's loop over a file list (inference.py:79-117): files of any lengths are decoded on the
-                          host, padded side by side in batches, enhanced, and written as '<name>@1.wav' PCM_16; with
-                          torch.distributed initialised every rank takes a contiguous shard of the list (BASELINE configs[4]:
-                          data-parallel enhancement, pure replicas, no collective).
+``Enhancer.enhance``         one padded batch resident in HBM (optional per-utterance lengths), on the current stream
+``Enhancer.enhance_stream``  a sequence of batches with several of them in flight on their own streams: the noise branch of a batch
+                             (STFT -> IMCRA, a scan that is serial over frames and fills a fraction of the chip) runs under the
+                             generator of the batch before it; results come out in order, bit-identical to ``enhance``
+``enhance_files``            the reference's loop over a file list (inference.py:79-117): files of any lengths are decoded on a
+                             small thread pool, padded side by side in batches, staged through pinned host buffers, enhanced with
+                             ``enhance_stream`` and written as '<name>@1.wav' PCM_16; with torch.distributed initialised every
+                             rank takes a contiguous shard of the list (BASELINE configs[4]: data-parallel enhancement, pure
+                             replicas, no collective).
 """
+import collections
+import os
+
 import torch
 
 from . import audio_util as au
@@ -21,18 +28,15 @@ fs = 16000
 
 class Enhancer:
     def __init__(self, chkpt_path=None, device='cuda', G=None):
-        self.device = torch.device(device)
+        self.device = M._norm_dev(device)
         self.G = G if G is not None else M.Generator_Conv1D_cLN()
         if chkpt_path is not None:
             self.G.load_state_dict(torch.load(chkpt_path, map_location='cpu')['enhance-model'])   # inference.py:71-72
         self.G = self.G.to(self.device)
         self.G.eval()
+        self._slots = []                # streams of enhance_stream, created on first use and kept (the runtime maps streams to hardware queues once)
 
-    @torch.no_grad()
-    def enhance(self, clean_wav, noise_wav, pcm16=True, lengths=None):
-        """clean_wav, noise_wav [B,L] -> enhanced wav [B, 256*(T-1)] at RMS 0.03 (inference.py:99-115).
-        lengths [B] (optional): samples of each utterance inside the padded batch; row b of the result then holds
-        256 * (lengths[b] // 256) samples followed by zeros, and its RMS is taken over those samples."""
+    def _enhance_impl(self, clean_wav, noise_wav, pcm16, lengths):
         lengths = au._i32(lengths, self.device)
         frames = au.frames_of(lengths)
         clean_spec, clean_band = au.stft_band(clean_wav, p_power, lengths=lengths)
@@ -42,10 +46,92 @@ class Enhancer:
         alpha2 = M.normed_alpha2(mask, clean_band, inv_p, frames=frames)
         return au.gain_istft(alpha2, clean_spec, rms_target=0.030, pcm16=pcm16, frames=frames)
 
+    @torch.no_grad()
+    def enhance(self, clean_wav, noise_wav, pcm16=True, lengths=None):
+        """clean_wav, noise_wav [B,L] -> enhanced wav [B, 256*(T-1)] at RMS 0.03 (inference.py:99-115).
+        lengths [B] (optional): samples of each utterance inside the padded batch; row b of the result then holds
+        256 * (lengths[b] // 256) samples followed by zeros, and its RMS is taken over those samples."""
+        return self._enhance_impl(clean_wav, noise_wav, pcm16, lengths)
 
-def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True):
+    @torch.no_grad()
+    def enhance_stream(self, batches, inflight=3, pcm16=True):
+        """batches: iterable of (clean_wav [B,L], noise_wav [B,L]) or (clean_wav, noise_wav, lengths) device tensors (shapes may differ
+        from batch to batch).  Generator of the enhanced batches, in order; each equals ``enhance`` of the same batch bit for bit.
+
+        Up to ``inflight`` batches are enqueued before the oldest result is handed out, each on a stream of its own with its own set
+        of generator activation buffers (``Generator_Conv1D_cLN.buffer_slot``); the generator's weight layouts are written once
+        (``freeze_weights``) and only read afterwards.  One batch by itself is a chain of kernels of which the IMCRA scan (serial over
+        the frames, 1 / 8 .. 1 / 4 of the chip) and the per-utterance tails leave most of the GPU idle: with three batches in flight those
+        phases run under another batch's generator (inference.py:79-117 is a loop over independent files).
+        The consumer's current stream waits for a result before it is yielded; the result stays valid until the consumer drops it."""
+        if self.device.type != 'cuda':
+            raise RuntimeError("nele_gan_amd: the enhancement path runs on the GPU only (no CPU fallback)")
+        inflight = max(1, int(inflight))
+        while len(self._slots) < inflight:
+            self._slots.append(ops.side_stream(self.device))
+        G = self.G
+        slot0 = G.buffer_slot
+        caller = torch.cuda.current_stream(self.device)
+        frozen = G.freeze_weights(self.device)
+        pending = collections.deque()
+
+        def hand_out():
+            out, done, st = pending.popleft()
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            out.record_stream(cur)
+            return out
+
+        try:
+            for k, batch in enumerate(batches):
+                if len(pending) >= inflight:
+                    yield hand_out()
+                clean_wav, noise_wav = batch[0], batch[1]
+                lengths = batch[2] if len(batch) > 2 else None
+                st = self._slots[k % inflight]
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(self.device))       # the inputs (and, first round, the frozen layouts) exist
+                G.buffer_slot = ('stream', k % inflight)
+                with torch.cuda.stream(st):
+                    st.wait_event(ready)
+                    if k < inflight:
+                        st.wait_event(frozen)
+                    out = self._enhance_impl(clean_wav, noise_wav, pcm16, lengths)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                for t in (clean_wav, noise_wav):
+                    if t.is_cuda:
+                        t.record_stream(st)
+                pending.append((out, done, st))
+            while pending:
+                yield hand_out()
+        finally:
+            G.buffer_slot = slot0
+            G.unfreeze_weights()
+            for _, done, _ in pending:                                   # a consumer that stopped early: nothing may still write when we return
+                done.synchronize()
+
+
+def _decode_pair(clean_path, noise_path):
+    from . import dataio
+    c, sr = dataio.load(clean_path)
+    assert sr == 16000                                                   # inference.py:85-88
+    n, sr = dataio.load(noise_path)
+    assert sr == 16000
+    m = min(len(c), len(n))
+    return c[:m], n[:m]
+
+
+def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=4,
+                  pad_to=4096):
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
-    Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard."""
+    Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.
+
+    Host side (the reference: one file at a time, librosa.load + sf.write in the main process): wav decoding on ``workers`` threads
+    (numpy's frombuffer / astype release the GIL), batches padded to a multiple of ``pad_to`` samples (few distinct shapes: the
+    generator's activation buffers are cached per shape), staged through pinned host buffers with asynchronous copies in both
+    directions, ``inflight`` batches on the GPU at a time (enhance_stream); files are written while later batches run."""
+    import concurrent.futures as cf
     import numpy as np
     from . import dataio
     dataio.creatdir(output_path)
@@ -54,26 +140,76 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
     order = mine
     if sort_by_length:
         # batches of similar lengths waste less padding; the output list keeps the caller's order
-        sizes = {i: __import__('os').path.getsize(file_list[i]) for i in mine}
+        sizes = {i: os.path.getsize(file_list[i]) for i in mine}
         order = sorted(mine, key=lambda i: sizes[i])
+    groups = [order[k:k + batch] for k in range(0, len(order), batch)]
+    dev = enhancer.device
     written = {}
-    for k in range(0, len(order), batch):
-        sel = order[k:k + batch]
-        cl, ns = [], []
-        for i in sel:
-            c, sr = dataio.load(file_list[i])
-            assert sr == 16000                                       # inference.py:85-88
-            n, sr = dataio.load(noise_path + file_list[i].split('/')[-1])
-            assert sr == 16000
-            m = min(len(c), len(n))
-            cl.append(c[:m]); ns.append(n[:m])
-        cp, lens = dataio.pad_batch(cl)
-        npad, _ = dataio.pad_batch(ns)
-        enh = enhancer.enhance(torch.from_numpy(cp).to(enhancer.device), torch.from_numpy(npad).to(enhancer.device), pcm16=True,
-                               lengths=torch.from_numpy(lens)).cpu().numpy()
-        for r, i in enumerate(sel):
-            name = file_list[i].split('/')[-1]
-            path = dataio.enhanced_name(output_path, name, epoch_tag)
-            dataio.write_wav_pcm16(path, enh[r, :256 * (int(lens[r]) // 256)], fs, quantised=True)
-            written[i] = path
+    copy_in = torch.cuda.Stream(device=dev)
+    copy_out = torch.cuda.Stream(device=dev)
+    pool = cf.ThreadPoolExecutor(max_workers=max(1, int(workers)))
+
+    def decode(sel):
+        return [pool.submit(_decode_pair, file_list[i], noise_path + file_list[i].split('/')[-1]) for i in sel]
+
+    def stage(futs):
+        """decoded files -> (clean, noise, lengths) on the device through pinned buffers (asynchronous copy on its own stream)"""
+        pairs = [f.result() for f in futs]
+        lens = np.asarray([len(c) for c, _ in pairs], dtype=np.int32)
+        Lmax = int((int(lens.max()) + pad_to - 1) // pad_to * pad_to) if pad_to else int(lens.max())
+        hc = torch.zeros((len(pairs), Lmax), dtype=torch.float32).pin_memory()
+        hn = torch.zeros((len(pairs), Lmax), dtype=torch.float32).pin_memory()
+        for r, (c, n) in enumerate(pairs):
+            hc[r, :len(c)] = torch.from_numpy(c)
+            hn[r, :len(n)] = torch.from_numpy(n)
+        with torch.cuda.stream(copy_in):
+            dc = hc.to(dev, non_blocking=True)
+            dn = hn.to(dev, non_blocking=True)
+            dl = torch.from_numpy(lens).pin_memory().to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_in)
+        return dc, dn, dl, ev, lens, (hc, hn)
+
+    def batches():
+        nxt = decode(groups[0]) if groups else None
+        for g in range(len(groups)):
+            futs = nxt
+            nxt = decode(groups[g + 1]) if g + 1 < len(groups) else None   # the next group decodes while this one is staged and enqueued
+            dc, dn, dl, ev, lens, keep = stage(futs)
+            torch.cuda.current_stream(dev).wait_event(ev)
+            meta.append((groups[g], lens, keep))
+            yield dc, dn, dl
+
+    meta = []
+    outq = collections.deque()
+
+    def flush(block_all):
+        while outq and (block_all or outq[0][1].query()):
+            host, ev, sel, lens = outq.popleft()
+            ev.synchronize()
+            arr = host.numpy()
+            for r, i in enumerate(sel):
+                name = file_list[i].split('/')[-1]
+                path = dataio.enhanced_name(output_path, name, epoch_tag)
+                dataio.write_wav_pcm16(path, arr[r, :256 * (int(lens[r]) // 256)], fs, quantised=True)
+                written[i] = path
+
+    try:
+        for g, enh in enumerate(enhancer.enhance_stream(batches(), inflight=inflight, pcm16=True)):
+            sel, lens, _keep = meta[g]
+            meta[g] = None
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_out):
+                copy_out.wait_event(done)
+                host = torch.empty(enh.shape, dtype=torch.float32).pin_memory()
+                host.copy_(enh, non_blocking=True)
+                enh.record_stream(copy_out)
+                ev = torch.cuda.Event()
+                ev.record(copy_out)
+            outq.append((host, ev, sel, lens))
+            flush(False)
+        flush(True)
+    finally:
+        pool.shutdown(wait=True)
     return [written[i] for i in mine]

@@ -271,6 +271,11 @@ class Generator_Conv1D_cLN(nn.Module):
         self.overlap_wgrad = True          # weight gradients on a second stream beside the data-gradient chain
         self._last_mask = None
         self.precision = 'f32'            # 'bf16': bf16 MFMA operands (f32 accumulate) in the Conv1d / Linear GEMMs (fwd, dgrad, wgrad)
+        # Several forward passes in flight on different streams (inference.Enhancer.enhance_stream): each stream names its own activation
+        # buffer set through `buffer_slot`, and the weight layouts - shared by all of them - are written ONCE by freeze_weights() instead
+        # of at the head of every forward pass (a rewrite, even of identical values, beside another stream's reads is a race).
+        self.buffer_slot = 0
+        self._weights_frozen = False
 
     # ---- plumbing
     def flat_parameters(self, device=None):
@@ -325,8 +330,24 @@ class Generator_Conv1D_cLN(nn.Module):
         return wf, wb
 
     def _get_bufs(self, B, T, dev):
-        key = (B, T, str(_norm_dev(dev)))
+        key = (B, T, str(_norm_dev(dev)), self.buffer_slot)
         return key, _lru_get(self._bufs, key, lambda: _GBuffers(B, T, dev))
+
+    def freeze_weights(self, dev=None):
+        """Write the GEMM / fragment layouts of the current parameters now (current stream) and skip that step in the forward passes
+        that follow, until unfreeze_weights().  For evaluation loops whose parameters do not change (inference.py:79-117): forward
+        passes on several streams then only READ the layouts.  Returns an event recorded behind the layout kernels."""
+        dev = _norm_dev(dev or next(self.parameters()).device)
+        self._flat.ensure(dev)
+        self._weights_frozen = False
+        self._prep_weights(dev)
+        self._weights_frozen = True
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return ev
+
+    def unfreeze_weights(self):
+        self._weights_frozen = False
 
     def _gemm(self, A, q, back, bias, aux, out, B, N, epi, g):
         """Conv1d / Linear GEMM of layer q (forward or data-gradient weights): the strip tile kernel in bf16 mode where the
@@ -352,7 +373,11 @@ class Generator_Conv1D_cLN(nn.Module):
         B, T, _ = x.shape
         key, bf = self._get_bufs(B, T, dev)
         bf.gen += 1
-        wf, wb = self._prep_weights(dev)
+        if self._weights_frozen:
+            if torch.is_grad_enabled() and self.training:
+                raise RuntimeError("Generator_Conv1D_cLN: freeze_weights() is for evaluation loops; call unfreeze_weights() before training")
+        else:
+            self._prep_weights(dev)
         b16 = self.precision == 'bf16'
         call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
         for l, (cin, cout, k) in enumerate(_G_LAYERS):

@@ -223,3 +223,52 @@ def test_inference_on_eight_second_utterances_matches_the_oracle():
         d = np.abs(out[b] - ref[b])
         assert d.max() <= 1.5 / 32768 and np.mean(d > 1e-7) < 0.02     # PCM_16: rare one-LSB rounding flips (as test_train_gpu.py:34-36)
         assert np.sqrt(np.mean(out[b].astype(np.float64) ** 2)) == pytest.approx(0.03, rel=2e-4)
+
+
+@pytest.mark.parametrize('inflight', [1, 3, 4])
+def test_enhance_stream_is_bit_identical_to_enhance(inflight):
+    """inference.py:79-117 is a loop over independent files: Enhancer.enhance_stream keeps several batches in flight on their own streams
+    (own generator activation buffers, weight layouts written once) and must return, in order, exactly what enhance() returns."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.inference import Enhancer
+    torch.manual_seed(5)
+    e = Enhancer()
+    e.G.precision = 'bf16'
+    shapes = [(3, 40000, None), (2, 64000, [64000, 50000]), (3, 40000, None), (4, 128000, None), (2, 64000, [33536, 64000]), (3, 40000, None),
+              (4, 128000, None)]
+    batches = []
+    for k, (B, L, lens) in enumerate(shapes):
+        c, v = synth.batch(B, L, start=100 * k)
+        item = (torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda())
+        if lens is not None:
+            item = item + (torch.tensor(lens, dtype=torch.int32),)
+        batches.append(item)
+    ref = [e.enhance(b[0], b[1], lengths=b[2] if len(b) > 2 else None).clone() for b in batches]
+    # a delayed first stream must not change anything either (the spin parks 20 ms of idle work in front of slot 0's kernels)
+    outs = []
+    for k, o in enumerate(e.enhance_stream(iter(batches), inflight=inflight)):
+        outs.append(o)
+    assert len(outs) == len(ref)
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape and torch.equal(o, r)
+    assert e.G.buffer_slot == 0 and not e.G._weights_frozen
+    # the generator trains again afterwards (weight layouts are rewritten per forward pass once unfrozen)
+    e.G.train()
+    m = e.G(torch.rand(1, 30, 64, device='cuda'), torch.rand(1, 30, 64, device='cuda'))
+    m.sum().backward()
+    e.G.eval()
+
+
+def test_enhance_stream_survives_a_consumer_that_stops_early():
+    from nele_gan_amd import synth
+    from nele_gan_amd.inference import Enhancer
+    torch.manual_seed(5)
+    e = Enhancer()
+    c, v = synth.batch(2, 40000, start=7)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    ref = e.enhance(cw, nw)
+    gen = e.enhance_stream([(cw, nw)] * 6, inflight=3)
+    first = next(gen)
+    gen.close()                                                          # GeneratorExit inside the loop: pending batches are waited for, G unfrozen
+    assert torch.equal(first, ref) and not e.G._weights_frozen and e.G.buffer_slot == 0
+    assert torch.equal(e.enhance(cw, nw), ref)

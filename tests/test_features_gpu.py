@@ -140,13 +140,45 @@ def test_wav_post_rms_and_pcm16(au):
     x = (0.1 * rs.randn(2, 5000)).astype(np.float32)
     t = torch.from_numpy(x.copy()).cuda()
     from nele_gan_amd._lib import call, ptr, stream
-    call('nele_wav_post', ptr(t), 2, 5000, 0.03, 1, stream())
+    from nele_gan_amd import _lib
+    ws = torch.empty(int(_lib.lib.nele_wav_post_workspace_doubles(2, 5000)), dtype=torch.float64, device='cuda')
+    call('nele_wav_post', ptr(t), 2, 5000, 0.03, 1, ptr(ws), stream())
+    with pytest.raises(ValueError):                                      # the rms normalisation without its workspace is an argument error
+        call('nele_wav_post', ptr(t), 2, 5000, 0.03, 1, None, stream())
     y = t.cpu().numpy()
     for b in range(2):
         ref = x[b] / np.sqrt(np.mean(x[b] ** 2)) * np.float32(0.03)
         ref = np.clip(np.rint(ref * 32767.0), -32768, 32767) / 32768.0
         assert np.abs(y[b] - ref).max() <= 1.0 / 32768 + 1e-9          # at most one LSB (rounding ties)
         assert np.mean(np.abs(y[b] - ref) > 1e-9) < 1e-3
+
+
+def test_wav_post_rms_is_batch_and_padding_invariant(au):
+    """The rms of an utterance is summed in chunk order from per-chunk partials: the same bits whether the utterance is scored alone,
+    inside a batch, or inside a longer padded batch (inference.py:109 is per file)."""
+    rs = np.random.RandomState(3)
+    x = (0.05 * rs.randn(3, 128000)).astype(np.float32)
+    full = au.gain_istft.__globals__['torch'].from_numpy(x.copy()).cuda()
+    from nele_gan_amd import _lib
+    from nele_gan_amd._lib import call, ptr, stream
+
+    def post(t, frames=None):
+        B, N = t.shape
+        ws = torch.empty(int(_lib.lib.nele_wav_post_workspace_doubles(B, N)), dtype=torch.float64, device='cuda')
+        call('nele_wav_post_var', ptr(t), ptr(frames), B, N, 0.03, 1, ptr(ws), stream())
+        return t.cpu().numpy()
+
+    yb = post(full.clone())
+    for b in range(3):
+        assert np.array_equal(post(full[b:b + 1].clone())[0], yb[b])
+    # utterance 1 cut to 300 frames (76 544 samples) inside a padded batch == the same samples scored at their own length
+    frames = torch.tensor([501, 300, 501], dtype=torch.int32, device='cuda')
+    cut = full.clone()
+    cut[1, 256 * 299:] = 0
+    yp = post(cut.clone(), frames)
+    alone = post(full[1:2, :256 * 299].clone())
+    assert np.array_equal(yp[1, :256 * 299], alone[0]) and not yp[1, 256 * 299:].any()
+    assert np.array_equal(yp[0], yb[0]) and np.array_equal(yp[2], yb[2])
 
 
 def test_errors_surface_as_exceptions(au):

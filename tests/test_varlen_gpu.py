@@ -164,3 +164,8 @@ def test_enhance_files_writes_the_reference_layout(tmp_path):
         ref = e.enhance(torch.from_numpy(c[:m]).cuda().unsqueeze(0), torch.from_numpy(n[:m]).cuda().unsqueeze(0))[0].cpu().numpy()
         np.testing.assert_array_equal(got, ref)                           # PCM_16 grid on both sides: exact
         assert np.sqrt(np.mean(got.astype(np.float64) ** 2)) == pytest.approx(0.03, rel=2e-3)
+    # one file per batch, three batches in flight, no length bucketing, in list order: the same files byte for byte
+    out1 = enhance_files(e, files + files[:1], str(tmp_path / 'Noise') + '/', str(tmp_path / 'Enh1'), batch=1, sort_by_length=False, pad_to=0)
+    assert [os.path.basename(p) for p in out1] == ['Train@1.wav', 'Test@1.wav', 'Train@1.wav']
+    for a, b in zip(out, out1):
+        assert open(a, 'rb').read() == open(b, 'rb').read()
