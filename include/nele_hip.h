@@ -188,6 +188,29 @@ int nele_colsum(const float* part, int rows, int cols, float* out, int accumulat
 /* two column sums of equal shape in one launch (cLN gain and bias partials) */
 int nele_colsum2(const float* part0, float* out0, const float* part1, float* out1, int rows, int cols, int accumulate, void* stream);
 
+/* ---- generator layers on bf16 activations (csrc/glayer.hip), bf16 mode --------------------------------------------------------
+ * One launch per layer of model.py:83-91: causal Conv1d (Chomp1d = K - 1 zero rows in front of the time axis) + bias + cumulative layer
+ * norm (model.py:168-205) + LeakyReLU, bf16 MFMA operands / float32 accumulate, statistics in float64.  Layers: Cin a multiple of 64,
+ * N = 64 or 256 output channels, K <= 9 (nele_glayer16_supported); everything else stays on nele_conv_span_bf16 + nele_cln_fwd. */
+int nele_glayer16_supported(int Cin, int N, int K);
+long long nele_glayer16_wfrag_elems(int Cin, int N, int K);      /* bf16 elements of a layer's weight fragment stream */
+long long nele_glayer16_carry_bytes(int B, int T);               /* strip-carry workspace (T > 256 frames); zero it once */
+/* jobs <= 16; ptrs_host[2 j] = Wg float32 [N][K * Cin] in k order (tap, channel) (nele_weight_prep's forward layout, or the flipped one for
+ * a data gradient), ptrs_host[2 j + 1] = the fragment stream; dims_host[3 j ..] = {N, Cin, K} */
+int nele_glayer16_weight_prep_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream);
+/* model.py:85-86 cat(x, y) as the first layer's bf16 input [B][T + pad][128] (rows < pad stay zero) */
+int nele_g_pack16(const float* x, const float* y, void* out16, int B, int T, int pad, void* stream);
+/* A16 [B][T + K - 1][Cin] bf16 -> out16 [B][T + padn][N] bf16 (rows padn ..: the next layer's input).  Optional outputs (NULL = not
+ * written): Y [B][T][N] float32 = convolution + bias, mean / rstd [B][T] (what nele_cln_bwd reads), out32 = the activation in float32,
+ * same layout as out16.  carry: nele_glayer16_carry_bytes(B, T) zero-initialised bytes, read and written when T > 256; token: a non-zero
+ * value that differs from call to call on the same carry buffer (a counter). */
+int nele_glayer16_fwd(const void* A16, const void* Wfrag, const float* bias, const float* gain, const float* beta, float* Y, float* mean,
+                      float* rstd, void* out16, float* out32, void* carry, unsigned token, int B, int T, int Cin, int N, int K, int padn,
+                      float slope, void* stream);
+/* The convolution alone, float32 result [B][T][N] (no bias): a layer's data gradient = this over the END-padded bf16 output gradient
+ * [B][T + K - 1][Cin = the layer's output channels] with the flipped weights (N = the layer's input channels). */
+int nele_glayer16_conv(const void* A16, const void* Wfrag, float* out32, int B, int T, int Cin, int N, int K, void* stream);
+
 /* Gradient of model.py:98 exp(3.2*tanh(o)) given the mask itself. */
 int nele_exptanh_bwd(const float* dmask, const float* mask, float* dout, long long n, void* stream);
 

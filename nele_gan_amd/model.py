@@ -187,32 +187,63 @@ def _check_generation(ctx, name):
 
 
 class _GBuffers:
+    """Activation buffers of one (B, T) shape.  Two tiers: the float32 set of the per-layer kernels (float32 mode; every backward pass)
+    and the bfloat16 inputs of the fused layer kernel (csrc/glayer.hip, bf16 mode).  An evaluation-only user (inference.Enhancer: several
+    buffer sets, one per batch in flight) never touches the float32 tier, so it is allocated on first use."""
+
     def __init__(self, B, T, dev):
-        self.B, self.T = B, T
+        self.B, self.T, self.dev = B, T, dev
         self.gen = 0
-        self.inp = []      # time-padded inputs of each conv [B][T+K-1][Cin]
-        self.Y = []        # raw conv outputs [B][T][Cout]
-        self.mean, self.rstd = [], []
+        self.a5 = _empty((B, T, 64), dev)
+        self.h1 = _empty((B, T, 64), dev)
+        self.gfc = Geom(1, T, 64, 1, T, 1, 1, 1, T, 64)
+        self.nchunks = int(ops._lib.lib.nele_cln_chunks(T))
+        self._f32 = False
+        self._bwd = False
+        self._b16 = False
+        self.token = 0
+
+    def next_token(self):
+        self.token = self.token % 0xFFFFFFF0 + 1          # never 0 (the zero-initialised carry slots must not match)
+        return self.token
+
+    def need_b16(self):
+        """bf16 conv inputs [B][T+K-1][Cin] (time left-padded with K-1 zero rows) + the strip-carry slots of the fused layer kernel"""
+        if self._b16:
+            return
+        B, T, dev = self.B, self.T, self.dev
+        self.inp16 = [torch.zeros((B, T + k - 1, cin), dtype=torch.bfloat16, device=dev) for (cin, cout, k) in _G_LAYERS]
+        self.carry = torch.zeros(max(32, int(ops._lib.lib.nele_glayer16_carry_bytes(B, T))), dtype=torch.uint8, device=dev)
+        self._b16 = True
+
+    def need_f32(self):
+        """float32 tier: time-padded inputs of each conv [B][T+K-1][Cin], raw conv outputs [B][T][Cout], per-frame statistics"""
+        if self._f32:
+            return
+        B, T, dev = self.B, self.T, self.dev
+        self.inp, self.Y, self.mean, self.rstd = [], [], [], []
         for (cin, cout, k) in _G_LAYERS:
             self.inp.append(_zeros((B, T + k - 1, cin), dev))
             self.Y.append(_empty((B, T, cout), dev))
             self.mean.append(_empty((B, T), dev))
             self.rstd.append(_empty((B, T), dev))
-        self.a5 = _empty((B, T, 64), dev)
-        self.h1 = _empty((B, T, 64), dev)
         # forward geometries: H=1 conv over the padded time axis
         self.gf = [Geom(1, T + k - 1, cin, 1, T, 1, k, 1, T, cout) for (cin, cout, k) in _G_LAYERS]
-        self.gfc = Geom(1, T, 64, 1, T, 1, 1, 1, T, 64)
-        # backward buffers
+        self.cln_scratch = torch.empty((B, T, 2), dtype=torch.float64, device=dev)
+        self._f32 = True
+
+    def need_bwd(self):
+        if self._bwd:
+            return
+        self.need_f32()
+        B, T, dev = self.B, self.T, self.dev
         self.dY = [_zeros((B, T + k - 1, cout), dev) for (cin, cout, k) in _G_LAYERS]   # END-padded
         self.dA = [_empty((B, T, cin), dev) for (cin, cout, k) in _G_LAYERS]              # grad wrt conv input (index l: input of layer l)
         self.da5 = _empty((B, T, 64), dev)
         self.do2 = _empty((B, T, 64), dev)
         self.dpre1 = _empty((B, T, 64), dev)
-        self.nchunks = int(ops._lib.lib.nele_cln_chunks(T))
         self.gpart = _empty((B * self.nchunks, 256), dev)
         self.bpart = _empty((B * self.nchunks, 256), dev)
-        self.cln_scratch = torch.empty((B, T, 2), dtype=torch.float64, device=dev)
         # data-gradient geometries: input = END-padded dY_l [B][T+k-1][cout], output = dA_l [B][T][cin]
         self.gb = [Geom(1, T + k - 1, cout, 1, T, 1, k, 1, T, cin) for (cin, cout, k) in _G_LAYERS]
         # weight-gradient geometries: A = padded input of layer l, dOut = dY_l (buffer width T+k-1)
@@ -221,6 +252,7 @@ class _GBuffers:
         nws = max([ops.wgrad_workspace_floats(B, cout, g) for (cin, cout, k), g in zip(_G_LAYERS, self.gw)] +
                   [ops.wgrad_workspace_floats(B, 64, self.gwfc)])
         self.ws = _empty((nws,), dev)
+        self._bwd = True
 
 
 class _GFn(torch.autograd.Function):
@@ -228,7 +260,7 @@ class _GFn(torch.autograd.Function):
     def forward(ctx, x, y, anchor, module):
         ctx.module = module
         ctx.precision = module.precision
-        ctx.key = module._forward_impl(x, y)
+        ctx.key = module._forward_impl(x, y, need_bwd=True)
         ctx.gen = module._bufs[ctx.key].gen
         mask = module._last_mask
         module._last_mask = None             # the output must not stay reachable from ctx except through save_for_backward:
@@ -276,6 +308,8 @@ class Generator_Conv1D_cLN(nn.Module):
         # of at the head of every forward pass (a rewrite, even of identical values, beside another stream's reads is a race).
         self.buffer_slot = 0
         self._weights_frozen = False
+        self.fused = True                 # bf16 mode: one fused launch per layer (conv + bias + cLN + LeakyReLU, csrc/glayer.hip) where the shapes allow
+        self.fused_ok = False
 
     # ---- plumbing
     def flat_parameters(self, device=None):
@@ -298,6 +332,13 @@ class Generator_Conv1D_cLN(nn.Module):
             self._wf16 = ([torch.zeros(ops.frag16_elems(nf, sf, 1), dtype=torch.bfloat16, device=dev) for (nf, sf, nb_, sb_) in dims],
                           [torch.zeros(ops.frag16_elems(nb_, sb_, 1), dtype=torch.bfloat16, device=dev) for (nf, sf, nb_, sb_) in dims])
             self._wf16dims = dims
+            # fragment streams of the fused layer kernel (csrc/glayer.hip): forward [cout][k*cin] and flipped data-gradient [cin][k*cout]
+            self.fused_ok = all(ops.glayer16_supported(cin, cout, k) for (cin, cout, k) in _G_LAYERS)
+            self._wgl = None
+            if self.fused_ok:
+                self._wgl = ([torch.zeros(ops.glayer16_wfrag_elems(cin, cout, k), dtype=torch.bfloat16, device=dev) for (cin, cout, k) in _G_LAYERS],
+                             [torch.zeros(ops.glayer16_wfrag_elems(cout, cin, k), dtype=torch.bfloat16, device=dev) if l > 0 else None
+                              for l, (cin, cout, k) in enumerate(_G_LAYERS)])
         return self._wf
 
     def _prep_weights(self, dev):
@@ -327,6 +368,15 @@ class Generator_Conv1D_cLN(nn.Module):
                 self._fragjobs = (ck, (c_void_p * len(fj))(*fj), (ctypes.c_int * len(ej))(*ej), len(ej) // 4)
             _, fja, eja, nfj = self._fragjobs
             call('nele_weight_prep_frag16_batch', fja, eja, nfj, stream())   # 16 fragment streams in one launch
+            if self.fused and self.fused_ok:
+                if getattr(self, '_gljobs', None) is None or self._gljobs[0] != ck:
+                    gj, hj = [], []
+                    for l, (cin, cout, k) in enumerate(_G_LAYERS):
+                        gj += [wf[l].data_ptr(), self._wgl[0][l].data_ptr()]
+                        hj += [cout, cin, k]
+                    self._gljobs = (ck, (c_void_p * len(gj))(*gj), (ctypes.c_int * len(hj))(*hj), len(hj) // 3)
+                _, gja, hja, ngj = self._gljobs
+                call('nele_glayer16_weight_prep_batch', gja, hja, ngj, stream())
         return wf, wb
 
     def _get_bufs(self, B, T, dev):
@@ -363,7 +413,7 @@ class Generator_Conv1D_cLN(nn.Module):
         ops.conv_gemm(A, (self._wf[1] if back else self._wf[0])[q], bias, aux, out, B, N, epi, g, bf16=b16)
 
     # ---- forward (model.py:83-98)
-    def _forward_impl(self, x, y):
+    def _forward_impl(self, x, y, need_bwd=False):
         if x.dim() != 3 or x.shape[2] != 64 or y.shape != x.shape:
             raise ValueError("Generator_Conv1D_cLN.forward: x and y must both be [B, T, 64]")
         if not x.is_cuda:
@@ -379,16 +429,40 @@ class Generator_Conv1D_cLN(nn.Module):
         else:
             self._prep_weights(dev)
         b16 = self.precision == 'bf16'
-        call('nele_g_pack', ptr(x.contiguous().float()), ptr(y.contiguous().float()), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
-        for l, (cin, cout, k) in enumerate(_G_LAYERS):
-            seq = self.convolutions[l]
-            self._gemm(bf.inp[l], l, False, seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l])
-            if l + 1 < len(_G_LAYERS):
-                nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
-            else:
-                nxt, pad = bf.a5, 0
-            call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
-                 ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
+        xs, ys = x.contiguous().float(), y.contiguous().float()
+        if b16 and self.fused and self.fused_ok:
+            # one launch per layer; the float32 copies of the activations, the raw convolutions and the per-frame statistics are written
+            # only for a backward pass
+            bf.need_b16()
+            if need_bwd:
+                bf.need_bwd()
+            call('nele_g_pack16', ptr(xs), ptr(ys), ptr(bf.inp16[0]), B, T, _G_LAYERS[0][2] - 1, stream())
+            if need_bwd:
+                call('nele_g_pack', ptr(xs), ptr(ys), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
+            nl = len(_G_LAYERS)
+            for l, (cin, cout, k) in enumerate(_G_LAYERS):
+                seq = self.convolutions[l]
+                last = l + 1 == nl
+                padn = 0 if last else _G_LAYERS[l + 1][2] - 1
+                out16 = None if last else bf.inp16[l + 1]
+                out32 = bf.a5 if last else (bf.inp[l + 1] if need_bwd else None)
+                call('nele_glayer16_fwd', ptr(bf.inp16[l]), ptr(self._wgl[0][l]), ptr(seq[0].conv.bias), ptr(seq[2].gain0), ptr(seq[2].bias0),
+                     ptr(bf.Y[l]) if need_bwd else None, ptr(bf.mean[l]) if need_bwd else None, ptr(bf.rstd[l]) if need_bwd else None,
+                     ptr(out16), ptr(out32), ptr(bf.carry), bf.next_token(), B, T, cin, cout, k, padn, SLOPE, stream())
+        else:
+            bf.need_f32()
+            if need_bwd:
+                bf.need_bwd()
+            call('nele_g_pack', ptr(xs), ptr(ys), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
+            for l, (cin, cout, k) in enumerate(_G_LAYERS):
+                seq = self.convolutions[l]
+                self._gemm(bf.inp[l], l, False, seq[0].conv.bias, None, bf.Y[l], B, cout, EPI_BIAS, bf.gf[l])
+                if l + 1 < len(_G_LAYERS):
+                    nxt, pad = bf.inp[l + 1], _G_LAYERS[l + 1][2] - 1
+                else:
+                    nxt, pad = bf.a5, 0
+                call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
+                     ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
         self._gemm(bf.a5, 6, False, self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
         mask = _empty((B, T, 64), dev)
         self._gemm(bf.h1, 7, False, self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
@@ -405,6 +479,7 @@ class Generator_Conv1D_cLN(nn.Module):
     # ---- backward: accumulates into the flat gradient buffer
     def _backward_impl(self, dmask, key, mask):
         bf = self._bufs[key]
+        bf.need_bwd()
         B, T = bf.B, bf.T
         # data-gradient chain on the current stream, weight gradients on a second stream beside it (see _DiscriminatorBase)
         main = torch.cuda.current_stream()

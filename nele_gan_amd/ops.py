@@ -33,6 +33,11 @@ _SIGS = {
     'nele_conv16_pointwise_fwd': [_P, _P, _P, _P, c_longlong, c_int, c_float, _P],
     'nele_conv_wgrad_bf16_a16d16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
+    'nele_g_pack16': [_P, _P, _P, c_int, c_int, c_int, _P],
+    'nele_glayer16_supported': [c_int, c_int, c_int],
+    'nele_glayer16_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
+    'nele_glayer16_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_glayer16_conv': [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_chunks': [c_int],
@@ -69,6 +74,10 @@ _lib._SIGS['nele_weight_frag16_elems'] = _lib.lib.nele_weight_frag16_elems.argty
 _lib.lib.nele_conv16_wfrag_elems.argtypes = [c_int, c_int, c_int]
 _lib.lib.nele_conv16_wfrag_elems.restype = c_longlong
 _lib._SIGS['nele_conv16_wfrag_elems'] = _lib.lib.nele_conv16_wfrag_elems.argtypes
+for _n in ('nele_glayer16_wfrag_elems', 'nele_glayer16_carry_bytes'):
+    getattr(_lib.lib, _n).argtypes = [c_int, c_int, c_int] if _n.endswith('elems') else [c_int, c_int]
+    getattr(_lib.lib, _n).restype = c_longlong
+    _lib._SIGS[_n] = getattr(_lib.lib, _n).argtypes
 _lib.lib.nele_conv_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int)]
 _lib.lib.nele_conv_wgrad_workspace_floats.restype = c_longlong
 _lib._SIGS['nele_conv_wgrad_workspace_floats'] = _lib.lib.nele_conv_wgrad_workspace_floats.argtypes
@@ -214,6 +223,15 @@ def conv16(A16, Wfrag, bias, aux16, out, B, N, epi, g, tag=None):
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
+
+
+def glayer16_supported(cin, cout, k):
+    """Does the fused layer kernel (conv + bias + cLN + LeakyReLU on bf16 activations, csrc/glayer.hip) take this Conv1d?"""
+    return bool(_lib.lib.nele_glayer16_supported(cin, cout, k))
+
+
+def glayer16_wfrag_elems(cin, cout, k):
+    return int(_lib.lib.nele_glayer16_wfrag_elems(cin, cout, k))
 
 
 def wgrad_workspace_floats(B, N, g):

@@ -383,3 +383,97 @@ def test_bf16_activation_kernels_at_edge_frame_counts(mods, B, T):
     close(res['bf16'][1], res['f32'][1], 1e-1, 'input gradient')
     for k, g0 in res['f32'][2].items():
         close(res['bf16'][2][k], g0, 4e-2, k)
+
+
+# ------------------------------------------------------------------ round 5: fused generator layers on bf16 activations (csrc/glayer.hip)
+def _torch_layer(a16, W, bias, gain, beta, K, slope=0.3):
+    """One layer of model.py:83-91 in float64 on the bf16-rounded operands the kernel multiplies: causal Conv1d + cLN + LeakyReLU."""
+    x = a16.double()                                                      # [B, T + K - 1, Cin], left-padded
+    w = W.to(torch.bfloat16).double()                                     # [N, Cin, K]
+    y = torch.nn.functional.conv1d(x.transpose(1, 2), w) + bias.double()[None, :, None]          # [B, N, T]
+    B, N, T = y.shape
+    s = y.sum(1).cumsum(1)
+    q = (y * y).sum(1).cumsum(1)
+    n = N * torch.arange(1, T + 1, device=y.device, dtype=torch.float64)[None]
+    m = s / n
+    var = (q - 2 * m * s) / n + m * m
+    xh = (y - m[:, None]) / torch.sqrt(var[:, None] + 1e-8)
+    o = xh * gain.double()[None, :, None] + beta.double()[None, :, None]
+    o = torch.where(o > 0, o, slope * o)
+    return y.transpose(1, 2), m, 1.0 / torch.sqrt(var + 1e-8), o.transpose(1, 2)
+
+
+@pytest.mark.parametrize('B,T,cin,cout,K', [(2, 40, 128, 256, 5), (3, 251, 256, 256, 7), (2, 501, 256, 256, 7), (1, 700, 256, 64, 5), (2, 256, 64, 256, 5),
+                                            (1, 257, 256, 256, 7)])
+def test_fused_generator_layer_against_torch_float64(mods, B, T, cin, cout, K):
+    """nele_glayer16_fwd (conv + bias + cLN + LeakyReLU in one launch, strips of 256 frames chained through the carry slots) against the
+    same arithmetic in float64 on the same bf16-rounded operands: the raw convolution to float32 accumulation noise, mean / rstd / the
+    activation to 1e-5, the bf16 output to one bf16 rounding.  T = 40 .. 700: one, two and three strips, ragged last strips."""
+    from nele_gan_amd import ops
+    from nele_gan_amd._lib import call, ptr, stream
+    import ctypes
+    assert ops.glayer16_supported(cin, cout, K)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    W = (torch.randn(cout, cin, K, generator=g) / np.sqrt(cin * K)).cuda()
+    bias, gain, beta = (0.1 * torch.randn(cout, generator=g)).cuda(), (1 + 0.2 * torch.randn(cout, generator=g)).cuda(), (0.1 * torch.randn(cout, generator=g)).cuda()
+    a = torch.randn(B, T, cin, generator=g).cuda()
+    a16 = torch.zeros(B, T + K - 1, cin, dtype=torch.bfloat16, device='cuda')
+    a16[:, K - 1:] = a.to(torch.bfloat16)
+    # GEMM layout [N][K * Cin] in k order (tap, channel), then the fragment stream
+    wg = W.permute(0, 2, 1).reshape(cout, K * cin).contiguous()
+    wfr = torch.zeros(ops.glayer16_wfrag_elems(cin, cout, K), dtype=torch.bfloat16, device='cuda')
+    call('nele_glayer16_weight_prep_batch', (ctypes.c_void_p * 2)(wg.data_ptr(), wfr.data_ptr()), (ctypes.c_int * 3)(cout, cin, K), 1, stream())
+    padn = 6
+    Y = torch.empty(B, T, cout, device='cuda'); mean = torch.empty(B, T, device='cuda'); rstd = torch.empty(B, T, device='cuda')
+    out16 = torch.zeros(B, T + padn, cout, dtype=torch.bfloat16, device='cuda'); out32 = torch.zeros(B, T + padn, cout, device='cuda')
+    carry = torch.zeros(max(32, int(ops._lib.lib.nele_glayer16_carry_bytes(B, T))), dtype=torch.uint8, device='cuda')
+    for token in (1, 2):                                                  # twice on the same carry buffer: stale slots must not match
+        call('nele_glayer16_fwd', ptr(a16), ptr(wfr), ptr(bias), ptr(gain), ptr(beta), ptr(Y), ptr(mean), ptr(rstd), ptr(out16), ptr(out32), ptr(carry),
+             token, B, T, cin, cout, K, padn, 0.3, stream())
+    ry, rm, rr, ro = _torch_layer(a16, W, bias, gain, beta, K)
+    scale = float(ry.abs().max())
+    assert float((Y.double() - ry).abs().max()) <= 2e-5 * scale           # float32 accumulation over up to 1792 products
+    np.testing.assert_allclose(mean.cpu().numpy(), rm.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(rstd.cpu().numpy(), rr.cpu().numpy(), rtol=2e-5)
+    assert float((out32[:, padn:].double() - ro).abs().max()) <= 1e-4 * float(ro.abs().max())
+    assert not out32[:, :padn].any() and not out16[:, :padn].any()       # the padding rows are left alone
+    assert torch.equal(out16[:, padn:], out32[:, padn:].to(torch.bfloat16))
+    # outputs that are not asked for are not needed: evaluation writes the bf16 activation only
+    o2 = torch.zeros_like(out16)
+    call('nele_glayer16_fwd', ptr(a16), ptr(wfr), ptr(bias), ptr(gain), ptr(beta), None, None, None, ptr(o2), None, ptr(carry), 3, B, T, cin, cout, K, padn, 0.3,
+         stream())
+    assert torch.equal(o2, out16)
+    # the convolution alone (the data-gradient form)
+    d = torch.empty(B, T, cout, device='cuda')
+    call('nele_glayer16_conv', ptr(a16), ptr(wfr), ptr(d), B, T, cin, cout, K, stream())
+    assert float((d.double() - (ry - bias.double())).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('B,T', [(2, 40), (3, 251), (2, 501), (1, 600)])
+def test_fused_generator_equals_per_layer_kernels_in_bf16_mode(mods, B, T):
+    """Generator_Conv1D_cLN in bf16 mode: the fused layer path (bf16 activations in memory) against the per-layer kernels (float32
+    activations rounded while staged).  The same bf16 products; the float32 sums run in another order, so a layer's activations differ
+    in the last float32 bits and a few of them round to the neighbouring bf16 value (2^-8 relative) on their way into the next layer:
+    the masks (exp(3.2 tanh(.)) of the sixth layer's output) agree to a fraction of the bf16-against-float32 tolerance (6e-2, test above).
+    The backward pass consumes the float32 copies the fused forward pass writes; the gradients agree likewise."""
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.rand(B, T, 64, generator=g).cuda(), torch.rand(B, T, 64, generator=g).cuda()
+    gw = torch.randn(B, T, 64, generator=g).cuda()
+    res = {}
+    for fused in (False, True):
+        G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+        G.precision = 'bf16'
+        G.fused = fused
+        mask = G(x, y)
+        G.flat_parameters().grad.zero_()
+        (mask * gw).sum().backward()
+        G.eval()
+        with torch.no_grad():
+            me = G(x, y)
+        res[fused] = (mask.detach().clone(), G.flat_parameters().grad.clone(), me.clone())
+    a, b = res[False], res[True]
+    assert float((a[0] - b[0]).abs().max()) <= 1e-2 * float(a[0].abs().max())
+    assert float((a[0] - b[0]).norm()) <= 1e-2 * float(a[0].norm())
+    assert float((a[2] - b[2]).abs().max()) <= 1e-2 * float(a[2].abs().max())
+    assert torch.equal(b[0], b[2])                                        # train- and eval-mode forward passes of the fused path: the same kernels
+    assert float((a[1] - b[1]).norm()) <= 2e-2 * float(a[1].norm())
