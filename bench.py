@@ -136,25 +136,70 @@ def cpu_baseline(metrics, length, n_utt, seed_start=9000):
                       % (n_utt, length / 16000.0, '+'.join(metrics), n_feat, n_torch, n_metric, dt, ncpu, {k: round(t, 2) for k, t in step.times.items()})}
 
 
-def inference_rate(tr, batch, K, rank):
-    """inference.py:79-117 on a batch of 8 s utterances (BASELINE configs[4] per GPU: pure replicas, no collective)."""
+def inference_rate(tr, batch, K, rank, sweep=(64, 256, 512)):
+    """inference.py:79-117 on batches of 8 s utterances (BASELINE configs[4] per GPU: pure replicas, no collective).
+    `value` = Enhancer.enhance_stream with 3 batches in flight (each batch on its own stream: the IMCRA scan and the per-utterance tails of
+    one batch run under the generator of another; results bit-identical to the single-stream path, tests/test_epoch_gpu.py); the
+    single-stream rate, the IMCRA scan alone and other batch sizes are reported beside it.  Two roofline fractions for the whole path:
+    SURVEY 8d's algorithmic work per utterance at T = 501 - 2.093 GFLOP in the generator (bf16 MFMA) and 3.5 MB of HBM traffic."""
     import torch
-    from nele_gan_amd import synth
-    from nele_gan_amd.inference import Enhancer
-    c, v = synth.batch(batch, 128000, start=5000 + rank * batch)
-    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    from nele_gan_amd import _lib, synth
+    from nele_gan_amd import audio_util as au
+    from nele_gan_amd.inference import Enhancer, p_power
     enh = Enhancer(G=tr.G)
     enh.G.precision = tr.G.precision
-    enh.enhance(cw, nw)
+
+    def rate(B, steps, inflight):
+        c, v = synth.batch(min(B, 128), 128000, start=5000 + rank * 128)
+        if B > c.shape[0]:
+            import numpy as np
+            c, v = np.tile(c, (B // c.shape[0] + 1, 1))[:B], np.tile(v, (B // v.shape[0] + 1, 1))[:B]
+        cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+        if inflight == 0:
+            enh.enhance(cw, nw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = enh.enhance(cw, nw)
+        else:
+            for out in enh.enhance_stream([(cw, nw)] * (inflight + 1), inflight=inflight):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for out in enh.enhance_stream([(cw, nw)] * steps, inflight=inflight):
+                pass
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, cw, nw
+
+    dt, cw, nw = rate(batch, 4 * K, 3)
+    dt1, _, _ = rate(batch, K, 0)
+    # the IMCRA scan alone (serial over the 501 frames; B workgroups)
+    spec, _ = au.stft_band(nw, p_power, want_band=False)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    au.imcra_band(spec, p_power)
+    ev[0].record()
+    for _ in range(5):
+        au.imcra_band(spec, p_power)
+    ev[1].record()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        out = enh.enhance(cw, nw)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / K
+    imcra_ms = ev[0].elapsed_time(ev[1]) / 5
+    out = {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_batch': dt * 1e3, 'utterance_seconds': 8.0, 'batch': batch, 'batches_in_flight': 3,
+           'realtime_factor': batch * 8.0 / dt, 'single_stream': {'value': batch / dt1, 'ms_per_batch': dt1 * 1e3}, 'imcra_ms': imcra_ms,
+           'roofline': {'mfma': {'achieved': 2.093e9 * batch / dt / 1e12, 'peak': BF16_MFMA_PEAK_TFLOPS if tr.G.precision == 'bf16' else F32_MFMA_PEAK_TFLOPS,
+                                 'unit': 'TFLOP/s', 'flops_per_utterance': 2.093e9},
+                        'hbm': {'achieved': 3.5e6 * batch / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'bytes_per_utterance': 3.5e6}},
+           'by_batch': {}}
+    for k in ('mfma', 'hbm'):
+        out['roofline'][k]['frac'] = out['roofline'][k]['achieved'] / out['roofline'][k]['peak']
+    for B in sweep:
+        try:
+            d, _, _ = rate(B, max(4, 2 * K * 128 // B), 3)
+            out['by_batch'][str(B)] = {'value': B / d, 'ms_per_batch': d * 1e3}
+        except Exception as e:                               # a sweep point must not take the line down
+            out['by_batch'][str(B)] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+        torch.cuda.empty_cache()
     tr.G.train()
-    return {'value': batch / dt, 'unit': 'utterances/s', 'ms_per_batch': dt * 1e3, 'utterance_seconds': 8.0, 'batch': batch,
-            'realtime_factor': batch * 8.0 / dt}
+    return out
 
 
 def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None):
@@ -471,6 +516,7 @@ def main():
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops,
                          'pmc_source': pmc_note},
             'ranks_seen': ranks_seen,
+            'step_status': status if not a.breakdown else None,      # device-side counters of the timed region + warm-up (GanTrainer.check_status): eigh_repaired must be 0
         }
         if allreduce_ms is not None:
             out['allreduce_ms_per_step'] = allreduce_ms

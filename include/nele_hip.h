@@ -32,6 +32,10 @@ int nele_build_has_ab_switches(void);
  * step) finds out which of its other streams share that queue by parking this kernel on the first and timing a trivial kernel on the
  * others. */
 int nele_stream_spin(double microseconds, void* stream);
+/* Test aid: `workgroups` workgroups of 1024 threads, each holding `lds_bytes` of LDS (160 KB = a whole CU for LDS-using kernels), idle for
+ * `microseconds` on `stream`: stands for kernels that stay resident on part of the GPU while the path runs (a collective library's channels,
+ * another process).  tests/test_metrics_gpu.py runs the batched eigensolver beside it and records time and give-ups. */
+int nele_stream_occupy(int workgroups, int lds_bytes, double microseconds, void* stream);
 
 /* Measurement hook (no reference counterpart): HIP-event timing of single kernels that are launched from inside multi-kernel entry
  * points, on the stream they run on.  nele_profile_begin(tags) arms it for the launch sites whose tag is in the comma-separated list
@@ -290,7 +294,8 @@ int nele_metric_estoi_var(const float* x, const float* y, const int* lengths, in
 /* intel.py:57-100 SIIB_Wrapper[_raw]_harvard: VAD (intel.py:37-50), replication rule (intel.py:93-97) and
  * pysiib.SIIB(x, y, 16000, gauss=True) (algorithm restated, oracle/siib.py).  info [B][4] (may be NULL) =
  * {replication factor M, frames of the tiled signal, active frames, status bits: 1 M clamped, 4 active-frame
- * buffer clamped, 8 not enough active frames (reference raises; raw = NaN)}.  The KLT eigenvectors come from
+ * buffer clamped, 8 not enough active frames (reference raises; raw = NaN), 32 the utterance's covariance took the eigensolver's repair
+ * path (nele_eigh_repaired: score unaffected, the call was slower)}.  The KLT eigenvectors come from
  * nele_eigh_sym_batched below. */
 long long nele_metric_siib_workspace_bytes(int B, int L);
 int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,

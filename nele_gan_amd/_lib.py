@@ -40,6 +40,7 @@ _SIGS = {
     'nele_device_info': [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.c_char_p, c_int],
     'nele_build_has_ab_switches': [],
     'nele_stream_spin': [ctypes.c_double, c_void_p],
+    'nele_stream_occupy': [c_int, c_int, ctypes.c_double, c_void_p],
     'nele_stft_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band': [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_gain_istft': [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],

@@ -55,6 +55,25 @@ extern "C" int nele_stream_spin(double microseconds, void* stream) {
     return hipGetLastError() == hipSuccess ? NELE_OK : nele_set_error(NELE_ERR_HIP, "nele_stream_spin: launch failed");
 }
 
+// Measurement / test aid: `workgroups` workgroups of 1024 threads that each claim `lds_bytes` of LDS and idle for `microseconds` - a stand-in
+// for kernels that stay resident on part of the chip while the path runs (the channels of a collective library, another process): with
+// lds_bytes = 160 KB one workgroup takes a whole CU out of service for LDS-using kernels.
+__global__ __launch_bounds__(1024) void nele_occupy_kernel(long long ticks) {
+    extern __shared__ int occ_lds[];
+    if (threadIdx.x == 0) occ_lds[0] = 1;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int nele_stream_occupy(int workgroups, int lds_bytes, double microseconds, void* stream) {
+    if (workgroups < 1 || workgroups > 4096 || lds_bytes < 4 || lds_bytes > 160 * 1024 || !(microseconds >= 0.0) || microseconds > 1e6)
+        return nele_set_error(NELE_ERR_INVALID_ARG, "nele_stream_occupy: 1 .. 4096 workgroups, 4 .. 163 840 bytes of LDS, 0 .. 1 000 000 us");
+    static unsigned long long attr = 0;
+    if (nele_first_use_on_device(&attr))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nele_occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(nele_occupy_kernel, dim3(workgroups), dim3(1024), (size_t)lds_bytes, as_stream(stream), (long long)(microseconds * 100.0));
+    return hipGetLastError() == hipSuccess ? NELE_OK : nele_set_error(NELE_ERR_HIP, "nele_stream_occupy: launch failed");
+}
+
 bool nele_first_use_on_device(unsigned long long* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)

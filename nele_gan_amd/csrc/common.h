@@ -22,6 +22,7 @@ int nele_set_error(int code, const char* fmt, ...);
 // csrc/eigh.hip (also part of the public C ABI)
 __attribute__((visibility("hidden"))) int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, void* workspace,
                                                                    long long workspace_bytes, void* stream, int cluster_batch);
+__attribute__((visibility("hidden"))) const int* nele_eigh_flags(void* workspace, int B, int n);
 extern "C" long long nele_eigh_workspace_bytes(int B, int n);
 extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
                                      void* stream);

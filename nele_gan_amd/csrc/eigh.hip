@@ -64,25 +64,36 @@ __device__ __forceinline__ void eigh_house(double* v, int m, double* red, double
 // Six workgroup barriers per step: (1,2) reduce p.v, (3,4) reduce ||x'||^2 of the next pivot row, (5) publish the next
 // Householder vector, (6) end of the fused pass.  Vectors ping-pong between two LDS slots; the two row groups of the pass
 // leave their partial matrix-vector products in separate arrays that the next step adds on the fly.
-__device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, int lda, double* __restrict__ d, double* __restrict__ e,
-                                                 double* __restrict__ tau) {
-    __shared__ double vb[2][EG_MAXN], wv[EG_MAXN], pa[EG_MAXN], pb2[EG_MAXN];
-    __shared__ double red[16];
-    __shared__ double s_tau, s_scale, s_beta;
+// NT threads (the stand-alone kernels run it with a workgroup of a thousand and twenty-four, the repair path inside
+// eigh_tridiag_midx_kernel with 512).  sh: EG_TRI_SH doubles of LDS scratch.
+#define EG_TRI_SH (5 * EG_MAXN + 24)
+template <int NT>
+__device__ __forceinline__ void eigh_tridiag_one_t(double* __restrict__ A, int n, int lda, double* __restrict__ d, double* __restrict__ e,
+                                                   double* __restrict__ tau, double* __restrict__ sh) {
+    constexpr int HALF = NT / 2;                           // threads per row group of the fused pass
+    double (*vb)[EG_MAXN] = reinterpret_cast<double (*)[EG_MAXN]>(sh);
+    double* wv = sh + 2 * EG_MAXN;
+    double* pa = sh + 3 * EG_MAXN;
+    double* pb2 = sh + 4 * EG_MAXN;
+    double* red = sh + 5 * EG_MAXN;
+    double& s_tau = sh[5 * EG_MAXN + 16];
+    double& s_scale = sh[5 * EG_MAXN + 17];
+    double& s_beta = sh[5 * EG_MAXN + 18];
     const int tid = threadIdx.x;
     // step 0: v from row 0, p = A22 v by a plain pass (two row groups -> pa, pb2)
     {
         const int m = n - 1;
         double* v = vb[0];
-        for (int i = tid; i < m; i += 1024) v[i] = A[1 + i];
+        for (int i = tid; i < m; i += NT) v[i] = A[1 + i];
         __syncthreads();
         eigh_house(v, m, red, &s_tau, &s_scale, &s_beta);
         double* A22 = A + (size_t)lda + 1;
-        const int c = tid & 511, grp = tid >> 9;
-        double acc = 0.0;
-        if (c < m)
+        const int grp = tid / HALF;
+        for (int c = tid % HALF; c < m; c += HALF) {
+            double acc = 0.0;
             for (int r = grp; r < m; r += 2) acc += A22[(size_t)r * lda + c] * v[r];
-        if (c < m) (grp ? pb2 : pa)[c] = acc;
+            (grp ? pb2 : pa)[c] = acc;
+        }
         __syncthreads();
     }
     double tk = s_tau, betak = s_beta;     // every thread carries tau_k / beta_k in registers
@@ -95,7 +106,7 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
         if (tid == 0) { d[k] = A[(size_t)k * lda + k]; e[k] = betak; tau[k] = tk; }
         // (1,2) p.v with p = tau * (pa + pb2)
         double pv = 0.0;
-        for (int i = tid; i < m; i += 1024) {
+        for (int i = tid; i < m; i += NT) {
             const double vi = v[i];
             rowk[i] = vi;                                  // keep the reflector in row k
             pv += tk * (pa[i] + pb2[i]) * vi;
@@ -112,7 +123,7 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
         const int m2 = m - 1;
         const double v0 = v[0];
         double ss = 0.0;
-        for (int i = tid; i < m; i += 1024) {
+        for (int i = tid; i < m; i += NT) {
             const double wi = tk * (pa[i] + pb2[i]) + al * v[i];
             wv[i] = wi;
             if (i >= 1) {
@@ -134,13 +145,13 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
             }
         }
         __syncthreads();                                   // everyone has read vn[0] before it is overwritten
-        for (int i = tid; i < m2; i += 1024) vn[i] = (i == 0) ? 1.0 : vn[i] * scn;
+        for (int i = tid; i < m2; i += NT) vn[i] = (i == 0) ? 1.0 : vn[i] * scn;
         __syncthreads();                                   // (5)
         // fused pass: thread = column c, two row groups; x = A22[r][c] - v_r w_c - w_r v_c; acc += x * vn[r-1]
-        {
-            const int c = tid & 511, grp = tid >> 9;
+        for (int c = tid % HALF; c < m; c += HALF) {
+            const int grp = tid / HALF;
             double acc = 0.0;
-            if (c >= 1 && c < m) {
+            if (c >= 1) {
                 const double vc = v[c], wc = wv[c];
                 if (tk != 0.0) {
                     int r = 1 + grp;
@@ -171,6 +182,11 @@ __device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, 
     }
     if (tid == 0) { d[n - 1] = A[(size_t)(n - 1) * lda + (n - 1)]; e[n - 1] = 0.0; tau[n - 1] = 0.0; }
 }
+__device__ __forceinline__ void eigh_tridiag_one(double* __restrict__ A, int n, int lda, double* __restrict__ d, double* __restrict__ e,
+                                                 double* __restrict__ tau) {
+    __shared__ double tri_sh[EG_TRI_SH];
+    eigh_tridiag_one_t<1024>(A, n, lda, d, e, tau, tri_sh);
+}
 
 __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__ Aall, int n, EighWs ws) {
     const int b = blockIdx.x;
@@ -183,17 +199,21 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(double* __restrict__
 // never reaches: its lower triangle and diagonal still hold the original matrix.  One workgroup mirrors them back and runs the
 // memory-streaming single-workgroup tridiagonalisation (slow: ~3 ms for one 420 x 420 matrix; it never runs on a GPU the launch fits on).
 // grid B, block 1024; unflagged matrices return at once.
-__global__ __launch_bounds__(1024) void eigh_tridiag_repair_kernel(double* __restrict__ Aall, int n, EighWs ws, int B) {
-    const int b = blockIdx.x;
-    if (ws.flag[b] != 1) return;
-    double* A = Aall + (size_t)b * n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 1024) {
+template <int NT>
+__device__ __forceinline__ void eigh_repair1(double* __restrict__ A, int n, EighWs ws, int b, int B, double* __restrict__ sh) {
+    for (int idx = threadIdx.x; idx < n * n; idx += NT) {
         const int r = idx / n, c = idx - r * n;
         if (c > r) A[idx] = A[(size_t)c * n + r];
     }
     __syncthreads();
-    eigh_tridiag_one(A, n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n);
+    eigh_tridiag_one_t<NT>(A, n, n, ws.d + (size_t)b * n, ws.e + (size_t)b * n, ws.tau + (size_t)b * n, sh);
     if (threadIdx.x == 0) atomicAdd(&ws.flag[B], 1);
+}
+__global__ __launch_bounds__(1024) void eigh_tridiag_repair_kernel(double* __restrict__ Aall, int n, EighWs ws, int B) {
+    __shared__ double tri_sh[EG_TRI_SH];
+    const int b = blockIdx.x;
+    if (ws.flag[b] != 1) return;
+    eigh_repair1<1024>(Aall + (size_t)b * n * n, n, ws, b, B, tri_sh);
 }
 
 // The same for a give-up inside the SECOND cluster stage (ws.flag[b] == 2).  The block has been updated in place by then, so there is
@@ -202,39 +222,46 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_repair_kernel(double* __res
 // UPPER triangle, and ws.zt holds the pending reflector s_first (vector v, tau) with its matrix-vector product p.  One workgroup
 // mirrors the block's lower triangle back, applies the pending reflector (w = tau p - (tau / 2)(tau p . v) v, A -= v w^T + w v^T) and
 // tridiagonalises what is left - an ordinary symmetric m x m problem with leading dimension n - with the memory-streaming kernel;
-// d / e / tau / the reflector rows from base on are rewritten.  grid B, block 1024; other matrices return at once.
-__global__ __launch_bounds__(1024) void eigh_tridiag_repair2_kernel(double* __restrict__ Aall, int n, EighWs ws, int B, int s_first) {
-    __shared__ double vv[EG_MAXN], ww[EG_MAXN];
-    __shared__ double red2[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (ws.flag[b] != 2) return;
+// d / e / tau / the reflector rows from base on are rewritten.  sh: EG_REPAIR_SH doubles.
+#define EG_REPAIR_SH (EG_TRI_SH + 2 * EG_MAXN + 16)
+template <int NT>
+__device__ __forceinline__ void eigh_repair2(double* __restrict__ A, int n, EighWs ws, int b, int B, int s_first, double* __restrict__ sh) {
+    double* vv = sh + EG_TRI_SH;
+    double* ww = vv + EG_MAXN;
+    double* red2 = ww + EG_MAXN;
+    const int tid = threadIdx.x;
     const int base = s_first + 1, m = n - base;
-    double* A = Aall + (size_t)b * n * n;
     double* Ab = A + (size_t)base * n + base;              // the trailing block, leading dimension n
     const double* st = ws.zt + (size_t)b * n * EG_MAXN;
     const double tk = st[3 * EG_MAXN];
     double pv = 0.0;
-    for (int i = tid; i < m; i += 1024) {
+    for (int i = tid; i < m; i += NT) {
         const double v = st[base + i], pp = st[EG_MAXN + base + i];
         vv[i] = v;
         ww[i] = tk * pp;
         pv += tk * pp * v;
     }
-    for (int idx = tid; idx < m * m; idx += 1024) {         // lower -> upper (the second stage's reflector rows go)
+    for (int idx = tid; idx < m * m; idx += NT) {           // lower -> upper (the second stage's reflector rows go)
         const int r = idx / m, c = idx - r * m;
         if (c > r) Ab[(size_t)r * n + c] = Ab[(size_t)c * n + r];
     }
     pv = block_sum(pv, red2);                              // (barriers inside: vv / ww / the mirrored block are visible behind it)
     const double al = -0.5 * tk * pv;
-    for (int i = tid; i < m; i += 1024) ww[i] += al * vv[i];
+    for (int i = tid; i < m; i += NT) ww[i] += al * vv[i];
     __syncthreads();
-    for (int idx = tid; idx < m * m; idx += 1024) {
+    for (int idx = tid; idx < m * m; idx += NT) {
         const int r = idx / m, c = idx - r * m;
         Ab[(size_t)r * n + c] -= vv[r] * ww[c] + ww[r] * vv[c];
     }
     __syncthreads();
-    eigh_tridiag_one(Ab, m, n, ws.d + (size_t)b * n + base, ws.e + (size_t)b * n + base, ws.tau + (size_t)b * n + base);
+    eigh_tridiag_one_t<NT>(Ab, m, n, ws.d + (size_t)b * n + base, ws.e + (size_t)b * n + base, ws.tau + (size_t)b * n + base, sh);
     if (tid == 0) atomicAdd(&ws.flag[B], 1);
+}
+__global__ __launch_bounds__(1024) void eigh_tridiag_repair2_kernel(double* __restrict__ Aall, int n, EighWs ws, int B, int s_first) {
+    __shared__ double rep_sh[EG_REPAIR_SH];
+    const int b = blockIdx.x;
+    if (ws.flag[b] != 2) return;
+    eigh_repair2<1024>(Aall + (size_t)b * n * n, n, ws, b, B, s_first, rep_sh);
 }
 
 
@@ -1659,7 +1686,7 @@ __global__ __launch_bounds__(512) void eigh_tridiag_mid_kernel(double* __restric
 #define EX_E 32                       // (48 rows x 272 columns, 102 KB, measured: the step gains nothing more - 44.9 / 44.9 / 45.4 against 44.9 / 45.2 / 45.2 ms)
 #define EX_LD 256
 #endif
-__global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first) {
+__global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restrict__ Aall, int n, EighWs ws, int s_first, int B, int c2_first) {
     extern __shared__ double em_strip[];                  // S[E][EX_LD]: rows 0 .. E-1 of the trailing block, all its columns
     __shared__ __attribute__((aligned(16))) double vperm[3][EM_M + 64];   // v, w, v_next of the register block at [(r & 15) * (EM_RI) + (r >> 4)]
     __shared__ double vL[EX_LD], wL[EX_LD], nL[EX_LD];    // the same vectors over the whole trailing block, natural order (strip passes)
@@ -1670,7 +1697,19 @@ __global__ __launch_bounds__(512) void eigh_tridiag_midx_kernel(double* __restri
     __shared__ double red0[8], red1[8];
     __shared__ double s_alpha, s_ppiv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
-    if (ws.flag[b] != 0) return;                         // the cluster kernel gave up on this matrix: eigh_tridiag_repair_kernel redoes it
+    {
+        // A matrix the cluster kernels gave up on (its workgroups were not co-resident within the spin limit - never on a GPU the launch
+        // fits on) is redone HERE, by this workgroup, from what the cluster stage left intact (eigh_repair1 / eigh_repair2; the strip's
+        // 64 KB are the scratch).  Until round 5 two fat repair kernels (B workgroups of 16 waves each) were launched for every batch just
+        // to test this flag: 4.8 us alone, but 0.2 - 1.3 ms inside a training step, where such workgroups wait for whole CUs.
+        const int fl = ws.flag[b];
+        if (fl != 0) {
+            static_assert(EG_REPAIR_SH <= EX_E * EX_LD, "the repair scratch must fit into the strip");
+            if (fl == 1) eigh_repair1<512>(Aall + (size_t)b * n * n, n, ws, b, B, em_strip);
+            else if (fl == 2 && c2_first >= 0) eigh_repair2<512>(Aall + (size_t)b * n * n, n, ws, b, B, c2_first, em_strip);
+            return;
+        }
+    }
     const int base = s_first + 1, m = n - base;          // trailing block = rows / columns base .. n-1, m <= EM_M + EX_E
     const int E = max(m - EM_M, 0);                      // its first E rows / columns live in the LDS strip, the rest in registers
     double* S = em_strip;
@@ -2850,6 +2889,14 @@ extern "C" int nele_eigh_repaired(void* workspace, int B, int n) {
     return v;
 }
 
+// Device pointer to the per-matrix give-up flags of a workspace ([B] ints, non-zero = the matrix took the repair path in the last call;
+// [B] = how many).  Internal (SIIB folds it into its status word so that a training loop can count repairs without a synchronisation).
+const int* nele_eigh_flags(void* workspace, int B, int n) {
+    EighWs ws;
+    eigh_layout(B, n, &ws, (char*)workspace);
+    return ws.flag;
+}
+
 // A [B][n][n] symmetric (destroyed: holds the Householder reflectors on exit) -> lam [B][n] ascending,
 // U [B][n][n] with row j = eigenvector j.  U may alias A? No: U must be a different buffer.
 extern "C" int nele_eigh_sym_batched(double* A, int n, int B, double* lam, double* U, void* workspace, long long workspace_bytes,
@@ -2882,6 +2929,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
         if (capenv >= 8 && capenv < cluster_cap) cluster_cap = capenv / 8 * 8;
     }
     int c2_first = -1;                                     // first step of the second cluster stage when it runs (its give-ups are repaired from there)
+    bool repaired_inline = false;                          // eigh_tridiag_midx_kernel redoes flagged matrices itself
     if (cluster_cap >= 8) {
         // once per device: may the exchange stores stay in the XCD's L2 (st_tagged)?  128 pairs of workgroups = one per CU, laid out like
         // the two-workgroup launches, 64 rounds of ping-pong each; the device-side flag stays 0 (write-through stores) unless all pass.
@@ -2959,7 +3007,7 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             }
             if (s_stop >= -1) {
                 const int mt = n - (s_stop + 2);
-                if (mhand == EM_M + EX_E) hipLaunchKernelGGL(eigh_tridiag_midx_kernel, dim3(B), dim3(512), sizeof(double) * EX_E * EX_LD, s, A, n, ws, s_stop + 1);
+                if (mhand == EM_M + EX_E) { hipLaunchKernelGGL(eigh_tridiag_midx_kernel, dim3(B), dim3(512), sizeof(double) * EX_E * EX_LD, s, A, n, ws, s_stop + 1, B, c2_first); repaired_inline = true; }
                 NELE_AB_ONLY(else if (mhand == EM_M) hipLaunchKernelGGL(eigh_tridiag_mid_kernel, dim3(B), dim3(512), 0, s, A, n, ws, s_stop + 1);
                              else hipLaunchKernelGGL(eigh_tridiag_tail_kernel, dim3(B), dim3(512), sizeof(double) * (size_t)mt * mt, s, A, n, ws, s_stop + 1);)
             }
@@ -2971,9 +3019,12 @@ int nele_eigh_sym_batched_ex(double* A, int n, int B, double* lam, double* U, vo
             hipLaunchKernelGGL(eigh_tridiag_cluster_kernel, dim3(64 * ((Bc + 7) / 8)), dim3(512), 0, s, A, n, b0, Bc, ws);
         }
         }
-        // matrices a cluster launch gave up on (never on a GPU the launch fits on): redone by one workgroup each instead of NaN results
-        hipLaunchKernelGGL(eigh_tridiag_repair_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B);
-        if (c2_first >= 0) hipLaunchKernelGGL(eigh_tridiag_repair2_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B, c2_first);
+        // matrices a cluster launch gave up on (never on a GPU the launch fits on): redone by one workgroup each instead of NaN results -
+        // inside eigh_tridiag_midx_kernel where that kernel runs (the two-stage cluster path: SIIB's n = 420), else by these two
+        if (!repaired_inline) {
+            hipLaunchKernelGGL(eigh_tridiag_repair_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B);
+            if (c2_first >= 0) hipLaunchKernelGGL(eigh_tridiag_repair2_kernel, dim3(B), dim3(1024), 0, s, A, n, ws, B, c2_first);
+        }
     } else {
         hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(B), dim3(1024), 0, s, A, n, ws);
     }

@@ -1205,10 +1205,10 @@ __global__ __launch_bounds__(256) void siib_quad_kernel(SiibWs ws) {
 }
 
 // score from the eigenvalues and the quadratic forms (lag path); same decisions as siib_final_kernel
-__global__ __launch_bounds__(512) void siib_final_lag_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped) {
+__global__ __launch_bounds__(512) void siib_final_lag_kernel(SiibWs ws, float* __restrict__ raw, float* __restrict__ mapped, const int* __restrict__ eigflag) {
     __shared__ double red[8];
     const int b = blockIdx.x, j = threadIdx.x;
-    const int* info = ws.info + 4 * b;
+    int* info = ws.info + 4 * b;
     const double* lam = ws.lam + (size_t)b * SB_D;
     const int ncols = info[2] - SB_K + 1;
     double lmax = -1e300;
@@ -1229,6 +1229,9 @@ __global__ __launch_bounds__(512) void siib_final_lag_kernel(SiibWs ws, float* _
         if (info[3] & (8 | 16)) v = nan("");
         if (raw) raw[b] = (float)v;
         if (mapped) mapped[b] = (float)(1.0 / (1.0 + exp(-0.06 * (v - 32.0))));
+        // status bit 32: this utterance's covariance went through the eigensolver's repair path (its cluster tridiagonalisation gave up:
+        // the score is as accurate as ever, the step was slower) - counted by the training loop without a synchronisation
+        if (eigflag && eigflag[b] != 0) info[3] |= 32;
     }
 }
 
@@ -1410,7 +1413,7 @@ extern "C" int nele_metric_siib_var(const float* x, const float* y, const int* l
     }
     if (fin && siib_lag_path()) {
         hipLaunchKernelGGL(siib_quad_kernel, dim3(7 * 14 * 8 * ((B + 7) / 8)), dim3(256), 0, s, ws);
-        hipLaunchKernelGGL(siib_final_lag_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped);
+        hipLaunchKernelGGL(siib_final_lag_kernel, dim3(B), dim3(512), 0, s, ws, raw, mapped, nele_eigh_flags(ws.eigws, B, SB_D));
         if (info_out) (void)hipMemcpyAsync(info_out, ws.info, sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToDevice, s);
         NELE_CHECK_LAUNCH("nele_metric_siib(back, lag path)");
     } else if (fin) {

@@ -272,10 +272,11 @@ class GanTrainer:
         """Fold a metric call's per-utterance status into the device-side counters of accumulator ``which`` on the current stream."""
         acc = self._status.get(which)
         if acc is None:
-            acc = self._status[which] = torch.zeros(3, dtype=torch.int64, device=self.device)
+            acc = self._status[which] = torch.zeros(4, dtype=torch.int64, device=self.device)
         if siib_info is not None:
             st = siib_info[:, 3]
             acc[0:2] += torch.stack((((st & 24) != 0).sum(), ((st & 7) != 0).sum()))
+            acc[3:4] += ((st & 32) != 0).sum()       # covariances that went through the eigensolver's repair path (slower, not wrong)
         if haspi_info is not None:
             acc[2:3] += (haspi_info[:, 1] != 0).sum()
 
@@ -288,10 +289,13 @@ class GanTrainer:
         for st_ in self._all_side_streams():         # the 'side' accumulators are updated on a side stream BEHIND the event the main stream waits on
             if cur is not None:
                 cur.wait_stream(st_)
-        tot = torch.zeros(3, dtype=torch.int64)
+        tot = torch.zeros(4, dtype=torch.int64)
         for acc in self._status.values():
             tot += acc.cpu()
-        st = {'siib_undefined': int(tot[0]), 'siib_clamped': int(tot[1]), 'haspi_below_threshold': int(tot[2]),
+        # eigh_repaired: SIIB covariances whose cluster tridiagonalisation gave up (its workgroups were not co-resident within the spin
+        # limit: another process on the GPU, resident communication kernels) and were redone by one workgroup each - correct scores, but
+        # ~3 ms per matrix instead of 25 us: a non-zero count explains a slow step, it is not an error
+        st = {'siib_undefined': int(tot[0]), 'siib_clamped': int(tot[1]), 'haspi_below_threshold': int(tot[2]), 'eigh_repaired': int(tot[3]),
               'skipped_g_steps': self.optimizer_g.skipped_steps(), 'skipped_d_steps': self.optimizer_d.skipped_steps(),
               'skipped_dqua_steps': self.optimizer_dqua.skipped_steps() if self.optimizer_dqua is not None else 0}
         if raise_on_error and any(st[k] for k in ('siib_undefined', 'haspi_below_threshold', 'skipped_g_steps', 'skipped_d_steps',
