@@ -401,11 +401,17 @@ def main():
         one_step()
     tag = 'D.conv5.fwd'           # D's 5th conv forward: every launch of the timed region (one in the G-step, one in the D-step per step)
     wtag = 'D.conv5.wgrad'        # the memory-side companion figure: D's 5th conv weight gradient (events on its own stream; includes its partial reduction)
-    ops.PROFILE = {'gstep.' + tag: [], tag: [], wtag: []}
     from nele_gan_amd import _lib
+    # bf16 mode: the two dense figures come from the library's own HIP-event hook (shape-specific tags of nele_conv16 / nele_conv_wgrad_*), so
+    # that the timed steps run exactly as a training loop runs them - G and D passes replayed from their recorded job tables (nele_gen_fwd /
+    # nele_disc_bwd ..., one foreign call per pass).  float32 mode (other kernels, no tags): torch events around the per-layer calls.
+    T_ = 1 + a.length // 256
+    lib_tags = a.precision == 'bf16'
+    ctag, wltag = 'conv16_N64_K3888_e2', 'wgrad_N64_K3888'
+    ops.PROFILE = None if lib_tags else {'gstep.' + tag: [], tag: [], wtag: []}
     htag = 'haspi_bank_gain_kernel'    # the HBM-side figure: HASPI's signal filter bank + compression-gain pass, timed by the library's HIP-event hook
     etag = 'eigh_tridiag_cluster'      # the float64 figure: the cluster tridiagonalisation of SIIB's 420 x 420 covariance (largest kernel of the r03 step)
-    armed = ([htag] if 'haspi' in metrics else []) + ([etag] if 'siib' in metrics else [])
+    armed = ([htag] if 'haspi' in metrics else []) + ([etag] if 'siib' in metrics else []) + ([ctag, wltag] if lib_tags else [])
     if armed:
         _lib.profile_begin(','.join(armed))
     stage_ev = []
@@ -436,24 +442,45 @@ def main():
         dt = float(t.item())
     hbm_ms = _lib.profile_collect_tag(htag) if 'haspi' in metrics else []
     eig_ms = _lib.profile_collect_tag(etag) if 'siib' in metrics else []
+
+    class _Ms:                                               # a measured duration with torch.cuda.Event's interface
+        def __init__(self, ms):
+            self.ms = ms
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    def as_events(ms_list, work):
+        return [(_Ms(0.0), _Ms(m), work) for m in ms_list]
+
+    if lib_tags:
+        conv_flops = 2.0 * a.batch * 44 * (T_ - 20) * 64 * 3888
+        cms = _lib.profile_collect_tag(ctag)                 # launches alternate: G-step's D forward, D-step's D forward
+        prof_g, prof_d = as_events(cms[0::2], conv_flops), as_events(cms[1::2], conv_flops)
+        wbytes = 4.0 * (a.batch * 52 * (T_ - 12) * 48 + a.batch * 44 * (T_ - 20) * 64 + 64 * 3888)
+        prof_w = as_events(_lib.profile_collect_tag(wltag), wbytes)
+    else:
+        prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
+        prof_w = ops.PROFILE[wtag]
     _lib.profile_begin(None)
-    prof_g, prof_d = ops.PROFILE['gstep.' + tag], ops.PROFILE[tag]
     prof = prof_g + prof_d
-    prof_w = ops.PROFILE[wtag]
     # the same launch on an otherwise idle GPU (after the timed region): inside the step the kernel shares the CUs with the metric
     # stream (SIIB's clean-signal part, incl. the all-CU tridiagonalisation, runs beside the G-step), which inflates its duration
     iso_tag = 'iso.D.conv5.fwd'
-    ops.PROFILE = {iso_tag: []}
+    ops.PROFILE = None if lib_tags else {iso_tag: []}
     torch.cuda.synchronize()
     iso = []
     if not a.no_isolated:            # profiling runs switch this off: the per-step kernel sums must hold the step's own launches only
         tr.D.eval()
         tr.D.profile_prefix = 'iso.'
+        if lib_tags:
+            _lib.profile_begin(ctag)
         with torch.no_grad():
             for _ in range(6):
                 tr.D.forward_packed(tr._last_din)
         torch.cuda.synchronize()
-        iso = ops.PROFILE[iso_tag][1:]
+        iso = as_events(_lib.profile_collect_tag(ctag), conv_flops)[1:] if lib_tags else ops.PROFILE[iso_tag][1:]
+        _lib.profile_begin(None)
         tr.D.profile_prefix = ''
         tr.D.train()
     ops.PROFILE = None

@@ -45,6 +45,48 @@ int nele_profile_begin(const char* tags);
 int nele_profile_collect_tag(const char* tag, float* ms_out, int max_n);
 int nele_profile_collect(float* ms_out, int max_n);
 
+/* ---- composite entry points of the dense part: job tables (csrc/plan.hip) ---------------------------------------------------------
+ * model.py:83-98 Generator_Conv1D_cLN.forward, :118-132 Discriminator.forward and their autograd, each as ONE call.
+ * A pass is a fixed sequence of the per-layer entry points below over a few streams; a PLAN is that sequence recorded once per shape
+ * (nele_plan_create: operation + arguments, each argument a constant or "slot k + offset" of a small per-call array) and
+ * nele_plan_run enqueues it: same kernels, order, streams and hand-over events as the per-layer calls, bit-identical results, one
+ * foreign-function call instead of 25 .. 60.  The host mirror records its own per-layer loop the first time it sees a shape
+ * (nele_gan_amd/_lib.py), so the layer logic exists once; a reference-side binding may build the tables itself the same way.
+ * Operations: every entry point of this header whose last parameter is the stream (nele_plan_op_id(name); csrc/plan_ops.inc is generated
+ * from this header by tools/gen_plan_ops.py).  streams_host [nstreams]: index 0 = the caller's stream, 1.. = the side streams the plan was
+ * recorded with (weight gradients run beside the data-gradient chain). */
+#define NELE_PLAN_MAXARGS 24
+typedef struct nele_plan_job {
+    int op;                               /* nele_plan_op_id("nele_...") */
+    int nargs;                            /* parameters of that entry point, the stream included */
+    int stream;                           /* index into streams_host */
+    int slot[NELE_PLAN_MAXARGS];          /* -1: the argument is ival / fval; k >= 0: it is slots_host[k] + ival (pointers / counters that change per call) */
+    long long ival[NELE_PLAN_MAXARGS];    /* integers and pointers (pointers to host arrays must stay valid for the plan's lifetime) */
+    double fval[NELE_PLAN_MAXARGS];       /* float / double arguments */
+} nele_plan_job;
+int nele_plan_op_id(const char* name);    /* -1: not an operation */
+int nele_plan_op_nargs(int op);
+int nele_plan_create(const nele_plan_job* jobs, int njobs, int nslots, int nstreams, void** plan_out);
+int nele_plan_run(void* plan, void* const* streams_host, int nstreams, const long long* slots_host, int nslots);
+int nele_plan_destroy(void* plan);
+/* model.py:83-98.  Slots 0 .. 3 of the plan = x [B][T][64], y [B][T][64], mask [B][T][64] (out), token (nele_glayer16_fwd's counter: the
+ * plan uses token, token + 1, ..). */
+int nele_gen_fwd(void* plan, const float* x, const float* y, float* mask, unsigned token, void* const* streams_host, int nstreams);
+/* autograd of the above: slots 0, 1 = dmask, mask; parameter gradients accumulate into the flat gradient buffer the plan was recorded on */
+int nele_gen_bwd(void* plan, const float* dmask, const float* mask, void* const* streams_host, int nstreams);
+/* model.py:118-132 (Discriminator / Discriminator_Quality).  Slots 0 .. 2 = din [B][64][T][4], wvalid [B] or NULL, score [B][nout] (out) */
+int nele_disc_fwd(void* plan, const float* din, const int* wvalid, float* score, void* const* streams_host, int nstreams);
+/* autograd of the above: slots 0 .. 3 = dscore, score, wvalid, din (the forward pass's input: the first layer's weight gradient reads it);
+ * the input gradient lands in the buffer the plan was recorded with */
+int nele_disc_bwd(void* plan, const float* dscore, const float* score, const int* wvalid, const float* din, void* const* streams_host, int nstreams);
+/* Hand-over events between the streams of a pass (hipEvent, timing disabled), recordable as plan operations */
+int nele_event_create(void** event_out);
+int nele_event_destroy(void* event);
+int nele_event_record(void* event, void* stream);
+int nele_stream_wait_event(void* event, void* stream);
+/* dst[i] += src[i] (bias gradients: the reduced partials of a weight-gradient call added to the flat gradient buffer) */
+int nele_vec_add(float* dst, const float* src, long long n, void* stream);
+
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */
 
 /* audio_util.py:53-58 STFT (librosa 0.7.1: reflect pad 256, periodic Hann 512, hop 256),

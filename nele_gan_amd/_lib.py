@@ -66,6 +66,25 @@ def declare(name, argtypes):
 
 for _n, _a in _SIGS.items():
     declare(_n, _a)
+_SIGS.update({
+    'nele_event_record': [c_void_p, c_void_p],
+    'nele_stream_wait_event': [c_void_p, c_void_p],
+    'nele_vec_add': [c_void_p, c_void_p, c_longlong, c_void_p],
+    'nele_event_create': [ctypes.POINTER(c_void_p)],
+    'nele_event_destroy': [c_void_p],
+    'nele_plan_op_id': [ctypes.c_char_p],
+    'nele_plan_op_nargs': [c_int],
+    'nele_plan_create': [ctypes.c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
+    'nele_plan_run': [c_void_p, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_longlong), c_int],
+    'nele_plan_destroy': [c_void_p],
+    'nele_gen_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, ctypes.POINTER(c_void_p), c_int],
+    'nele_gen_bwd': [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
+    'nele_disc_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
+    'nele_disc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
+})
+for _n in ('nele_event_record', 'nele_stream_wait_event', 'nele_vec_add', 'nele_event_create', 'nele_event_destroy', 'nele_plan_op_id', 'nele_plan_op_nargs',
+           'nele_plan_create', 'nele_plan_run', 'nele_plan_destroy', 'nele_gen_fwd', 'nele_gen_bwd', 'nele_disc_fwd', 'nele_disc_bwd'):
+    declare(_n, _SIGS[_n])
 lib.nele_wav_post_workspace_doubles.argtypes = [c_int, c_int]
 lib.nele_wav_post_workspace_doubles.restype = c_longlong
 _SIGS['nele_wav_post_workspace_doubles'] = lib.nele_wav_post_workspace_doubles.argtypes
@@ -79,7 +98,139 @@ def check(status, name=''):
         raise NeleError("%s failed (status %d): %s" % (name, status, msg))
 
 
+# ------------------------------------------------------------------ job tables (csrc/plan.hip): record a pass once, replay it with one call
+PLAN_MAXARGS = 24
+
+
+class nele_plan_job(ctypes.Structure):
+    _fields_ = [('op', c_int), ('nargs', c_int), ('stream', c_int), ('slot', c_int * PLAN_MAXARGS), ('ival', c_longlong * PLAN_MAXARGS),
+                ('fval', c_double * PLAN_MAXARGS)]
+
+
+class DynInt:
+    """An integer argument that changes from call to call (a counter): value = slot value + offset.  ctypes passes ``_as_parameter_``."""
+
+    def __init__(self, slot, off, base):
+        self.slot, self.off = int(slot), int(off)
+        self._as_parameter_ = int(base) + int(off)
+
+
+def _addr(a, keep):
+    if a is None:
+        return 0
+    if isinstance(a, int):
+        return a
+    if isinstance(a, c_void_p):
+        return a.value or 0
+    if isinstance(a, ctypes.Array):
+        keep.append(a)                                   # host arrays (geometries, pointer tables) must outlive the plan
+        return ctypes.addressof(a)
+    if isinstance(a, ctypes._Pointer):
+        keep.append(a)
+        return ctypes.cast(a, c_void_p).value or 0
+    raise TypeError("plan recorder: cannot take the address of %r" % (a,))
+
+
+class PlanRecorder:
+    """Collects the library calls of a pass while they execute (call() below appends to the active recorder).  ``dyn``: per slot either
+    (address, nbytes) of a tensor whose address changes from call to call - every pointer argument inside that range is recorded as
+    slot + offset - or None for a scalar slot (DynInt arguments)."""
+
+    def __init__(self, main_stream, dyn):
+        self.main = main_stream or 0
+        self.streams = [self.main]
+        self.dyn = list(dyn)
+        self.jobs, self.keep = [], []
+
+    def add(self, name, args):
+        sig = _SIGS.get(name)
+        op = lib.nele_plan_op_id(name.encode())
+        if sig is None or op < 0:
+            raise NeleError("plan recorder: %s is not a plan operation (inside a recorded pass every call must be a stream-enqueuing entry point)" % name)
+        if len(args) != len(sig) or len(args) > PLAN_MAXARGS:
+            raise NeleError("plan recorder: %s takes %d arguments, got %d" % (name, len(sig), len(args)))
+        j = nele_plan_job()
+        j.op, j.nargs = op, len(args)
+        for i, (a, t) in enumerate(zip(args, sig)):
+            j.slot[i] = -1
+            if i == len(args) - 1:                        # the stream
+                h = _addr(a, self.keep)
+                if h not in self.streams:
+                    self.streams.append(h)
+                j.stream = self.streams.index(h)
+            elif isinstance(a, DynInt):
+                j.slot[i], j.ival[i] = a.slot, a.off
+            elif t in (c_float, c_double):
+                j.fval[i] = float(a)
+            elif t in (c_int, c_longlong, ctypes.c_uint, ctypes.c_ulonglong):
+                j.ival[i] = int(a)
+            else:                                          # a pointer
+                v = _addr(a, self.keep)
+                j.ival[i] = v
+                if v:
+                    for k, rng in enumerate(self.dyn):
+                        if rng is not None and rng[0] <= v < rng[0] + max(1, rng[1]):
+                            j.slot[i], j.ival[i] = k, v - rng[0]
+                            break
+        self.jobs.append(j)
+
+    def finish(self):
+        return Plan(self)
+
+
+class Plan:
+    def __init__(self, rec):
+        self.n = len(rec.jobs)
+        self._jobs = (nele_plan_job * self.n)(*rec.jobs)
+        self._keep = rec.keep
+        self.nslots = len(rec.dyn)
+        self.streams = (c_void_p * len(rec.streams))(*rec.streams)
+        self.side = tuple(rec.streams[1:])
+        h = c_void_p()
+        check(lib.nele_plan_create(self._jobs, self.n, self.nslots, len(rec.streams), ctypes.byref(h)), 'nele_plan_create')
+        self.handle = h
+
+    def run(self, *slots):
+        """Enqueue the recorded pass: streams[0] = the current stream, the side streams as recorded."""
+        self.streams[0] = _raw_stream(_raw_device()) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+        arr = (c_longlong * self.nslots)(*slots)
+        check(lib.nele_plan_run(self.handle, self.streams, len(self.streams), arr, self.nslots), 'nele_plan_run')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.nele_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_recorder = None
+PLANS = True          # False: every pass is driven call by call (tests compare the two; bench.py reports both host times)
+
+
+class recording:
+    """with recording(dyn) as rec: ...library calls...   ->  rec.finish() is the plan of what ran."""
+
+    def __init__(self, dyn):
+        self.dyn = dyn
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise NeleError("plan recorder: recordings do not nest")
+        _recorder = PlanRecorder(stream().value, self.dyn)
+        return _recorder
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        return False
+
+
 def call(name, *args):
+    if _recorder is not None:
+        _recorder.add(name, args)
     check(getattr(lib, name)(*args), name)
 
 

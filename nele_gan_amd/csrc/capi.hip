@@ -99,6 +99,7 @@ static int prof_index(const char* tag) {
     return -1;
 }
 static int g_prof_cur = -1;                               // tag of the launch site between its two marks
+bool nele_prof_armed() { return !g_prof_tags.empty(); }
 bool nele_prof_match(const char* tag) {
     if (g_prof_tags.empty()) return false;
     g_prof_cur = prof_index(tag);

@@ -64,6 +64,7 @@ bool nele_first_use_on_device(unsigned long long* mask);
     } while (0)
 
 // csrc/capi.hip: HIP-event pair around one tagged launch when nele_profile_begin(tag) armed it (bench.py's roofline figures)
+bool nele_prof_armed();
 bool nele_prof_match(const char* tag);
 void nele_prof_mark(hipStream_t s);
 #define NELE_PROF(tag, stream, launch)                      \

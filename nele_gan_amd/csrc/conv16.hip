@@ -486,7 +486,10 @@ extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias
     hipStream_t s = as_stream(stream);
 #define C16_GO(TN_, TH_) do { if (out_bf16) c16_launch<TN_, TH_, true>(a, grid, pl.lds, s); else c16_launch<TN_, TH_, false>(a, grid, pl.lds, s); } while (0)
 #define C16_PICK(TH_) switch (pl.TN) { case 1: C16_GO(1, TH_); break; case 2: C16_GO(2, TH_); break; case 3: C16_GO(3, TH_); break; default: C16_GO(4, TH_); break; }
-    NELE_PROF("conv16_kernel", s, if (pl.TH == 8) { C16_PICK(8); } else { C16_PICK(4); });
+    // measurement hook: "conv16_kernel" = every launch; "conv16_N<N>_K<Ktot>_e<epi>" = one layer's (D.conv5 forward: conv16_N64_K3888_e2)
+    char ptag[48] = "conv16_kernel";
+    if (nele_prof_armed() && !nele_prof_match("conv16_kernel")) snprintf(ptag, sizeof(ptag), "conv16_N%d_K%d_e%d", N, g.Ktot, epi);
+    NELE_PROF(ptag, s, if (pl.TH == 8) { C16_PICK(8); } else { C16_PICK(4); });
 #undef C16_PICK
 #undef C16_GO
     NELE_CHECK_LAUNCH("conv16_kernel");

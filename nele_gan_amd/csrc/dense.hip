@@ -2469,6 +2469,14 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     p.part = workspace;
     p.bpart = db ? workspace + (size_t)splits * N * p.g.Ktot : nullptr;
     hipStream_t s = as_stream(stream);
+    // measurement hook: "wgrad_N<N>_K<Ktot>" times one layer's weight gradient including its partial reduction (D.conv5: wgrad_N64_K3888)
+    bool prof_w = false;
+    if (nele_prof_armed()) {
+        char ptag[48];
+        snprintf(ptag, sizeof(ptag), "wgrad_N%d_K%d", N, p.g.Ktot);
+        prof_w = nele_prof_match(ptag);
+        if (prof_w) nele_prof_mark(s);
+    }
     // 2-D tile kernel (bf16): one kernel row per workgroup, accumulators in registers over all position tiles
     const int wt_on = NELE_SWITCH_INT("NELE_WGRAD_TILE", 1);
     // Layers too wide for one workgroup's accumulators (N > 64 or more than 28 reduction tiles per kernel row: the generator's Conv1d
@@ -2644,6 +2652,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min(1024, (total + 255) / 256)), dim3(256), 0, s, p.part, p.bpart, splits, N, KH, KW,
                        p.g.C, Cvalid, dW, db, accumulate);
     NELE_CHECK_LAUNCH("nele_conv_wgrad(reduce)");
+    if (prof_w) nele_prof_mark(s);
     return NELE_OK;
 }
 

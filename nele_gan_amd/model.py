@@ -22,6 +22,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
+from . import _lib
 from ._lib import c_void_p, call, ptr, stream
 from .ops import EPI_BIAS, EPI_BIAS_EXPTANH, EPI_BIAS_LRELU, EPI_MASK_LRELU_GRAD, EPI_NONE, SLOPE, Geom
 
@@ -202,10 +203,15 @@ class _GBuffers:
         self._bwd = False
         self._b16 = False
         self.token = 0
+        self.plans = {}                                    # recorded passes of this shape (_lib.Plan), dropped with the buffer set
+        self.events = ops.Events()
 
-    def next_token(self):
-        self.token = self.token % 0xFFFFFFF0 + 1          # never 0 (the zero-initialised carry slots must not match)
-        return self.token
+    def reserve_tokens(self, n):
+        """n consecutive carry tokens for the fused layer launches of one forward pass; never 0 (zero-initialised slots must not match)"""
+        if self.token + n >= 0xFFFFFFF0:
+            self.token = 0
+        self.token += n
+        return self.token - n + 1
 
     def need_b16(self):
         """bf16 conv inputs [B][T+K-1][Cin] (time left-padded with K-1 zero rows) + the strip-carry slots of the fused layer kernel"""
@@ -312,6 +318,12 @@ class Generator_Conv1D_cLN(nn.Module):
         self.fused_ok = False
 
     # ---- plumbing
+    def train(self, mode=True):
+        """The sub-modules are parameter containers that are never called: only this module's own flag means anything, and
+        nn.Module.train's walk over the 35 of them cost 0.12 ms per G.eval() / G.train() pair of every generate() call."""
+        self.training = bool(mode)
+        return self
+
     def flat_parameters(self, device=None):
         device = device or next(self.parameters()).device
         self._flat.ensure(device)
@@ -423,14 +435,33 @@ class Generator_Conv1D_cLN(nn.Module):
         B, T, _ = x.shape
         key, bf = self._get_bufs(B, T, dev)
         bf.gen += 1
-        if self._weights_frozen:
-            if torch.is_grad_enabled() and self.training:
-                raise RuntimeError("Generator_Conv1D_cLN: freeze_weights() is for evaluation loops; call unfreeze_weights() before training")
-        else:
-            self._prep_weights(dev)
-        b16 = self.precision == 'bf16'
+        if self._weights_frozen and torch.is_grad_enabled() and self.training:
+            raise RuntimeError("Generator_Conv1D_cLN: freeze_weights() is for evaluation loops; call unfreeze_weights() before training")
+        self._weights(dev)
+        fused = self.precision == 'bf16' and self.fused and self.fused_ok
         xs, ys = x.contiguous().float(), y.contiguous().float()
-        if b16 and self.fused and self.fused_ok:
+        mask = _empty((B, T, 64), dev)
+        tok0 = bf.reserve_tokens(len(_G_LAYERS))
+        # the pass as ONE call (nele_gen_fwd on the job table recorded the first time this shape / mode came by), or call by call
+        pkey = ('fwd', bool(need_bwd), self.precision, fused, self._weights_frozen, self._flat.flat.data_ptr(), self._wf[0][0].data_ptr())
+        plan = bf.plans.get(pkey) if ops.plans_enabled() else None
+        if plan is not None:
+            plan.streams[0] = stream()
+            call('nele_gen_fwd', plan.handle, ptr(xs), ptr(ys), ptr(mask), tok0, plan.streams, len(plan.streams))
+        elif ops.plans_enabled():
+            with _lib.recording([ops.rng(xs), ops.rng(ys), ops.rng(mask), None]) as rec:
+                self._forward_live(xs, ys, mask, bf, need_bwd, fused, tok0)
+            bf.plans[pkey] = rec.finish()
+        else:
+            self._forward_live(xs, ys, mask, bf, need_bwd, fused, tok0)
+        self._last_mask = mask
+        return key
+
+    def _forward_live(self, xs, ys, mask, bf, need_bwd, fused, tok0):
+        B, T, dev = bf.B, bf.T, xs.device
+        if not self._weights_frozen:
+            self._prep_weights(dev)
+        if fused:
             # one launch per layer; the float32 copies of the activations, the raw convolutions and the per-frame statistics are written
             # only for a backward pass
             bf.need_b16()
@@ -448,7 +479,7 @@ class Generator_Conv1D_cLN(nn.Module):
                 out32 = bf.a5 if last else (bf.inp[l + 1] if need_bwd else None)
                 call('nele_glayer16_fwd', ptr(bf.inp16[l]), ptr(self._wgl[0][l]), ptr(seq[0].conv.bias), ptr(seq[2].gain0), ptr(seq[2].bias0),
                      ptr(bf.Y[l]) if need_bwd else None, ptr(bf.mean[l]) if need_bwd else None, ptr(bf.rstd[l]) if need_bwd else None,
-                     ptr(out16), ptr(out32), ptr(bf.carry), bf.next_token(), B, T, cin, cout, k, padn, SLOPE, stream())
+                     ptr(out16), ptr(out32), ptr(bf.carry), _lib.DynInt(3, l, tok0), B, T, cin, cout, k, padn, SLOPE, stream())
         else:
             bf.need_f32()
             if need_bwd:
@@ -464,10 +495,7 @@ class Generator_Conv1D_cLN(nn.Module):
                 call('nele_cln_fwd', ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(nxt), ptr(bf.mean[l]), ptr(bf.rstd[l]),
                      ptr(bf.cln_scratch), B, T, cout, pad, SLOPE, stream())
         self._gemm(bf.a5, 6, False, self.fc1.bias, None, bf.h1, B, 64, EPI_BIAS_LRELU, bf.gfc)
-        mask = _empty((B, T, 64), dev)
         self._gemm(bf.h1, 7, False, self.fc2.bias, None, mask, B, 64, EPI_BIAS_EXPTANH, bf.gfc)
-        self._last_mask = mask
-        return key
 
     def forward(self, x, y):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -480,27 +508,40 @@ class Generator_Conv1D_cLN(nn.Module):
     def _backward_impl(self, dmask, key, mask):
         bf = self._bufs[key]
         bf.need_bwd()
-        B, T = bf.B, bf.T
-        # data-gradient chain on the current stream, weight gradients on a second stream beside it (see _DiscriminatorBase)
-        main = torch.cuda.current_stream()
         wst = None
         if self.overlap_wgrad:
             if self._wstream is None:
                 self._wstream = ops.side_stream(dmask.device)
             wst = self._wstream
+        pkey = ('bwd', self.precision, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr())
+        plan = bf.plans.get(pkey) if ops.plans_enabled() else None
+        if plan is not None:
+            plan.streams[0] = stream()
+            call('nele_gen_bwd', plan.handle, ptr(dmask), ptr(mask), plan.streams, len(plan.streams))
+        elif ops.plans_enabled():
+            with _lib.recording([ops.rng(dmask), ops.rng(mask)]) as rec:
+                self._backward_live(dmask, mask, bf, wst)
+            bf.plans[pkey] = rec.finish()
+        else:
+            self._backward_live(dmask, mask, bf, wst)
+
+    def _backward_live(self, dmask, mask, bf, wst):
+        B, T = bf.B, bf.T
+        # data-gradient chain on the current stream, weight gradients on a second stream beside it (see _DiscriminatorBase)
+        main = torch.cuda.current_stream()
+        if wst is not None and wst == main:
+            wst = None
         b16w = self.precision == 'bf16'
+        ev = bf.events
+        ev.start()
 
         def wgrad(A, dOut, N, g, Cvalid, dW, db, bf16=False):
             if wst is None:
                 ops.conv_wgrad(A, dOut, bf.ws, B, N, g, Cvalid, dW, db, bf16=bf16)
                 return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            ctx = torch.cuda.stream(wst)
-            ctx.__enter__()
-            wst.wait_event(ev)
-            ops.conv_wgrad(A, dOut, bf.ws, B, N, g, Cvalid, dW, db, bf16=bf16)
-            ctx.__exit__(None, None, None)
+            ops.hand_over(ev, main, wst)
+            with torch.cuda.stream(wst):
+                ops.conv_wgrad(A, dOut, bf.ws, B, N, g, Cvalid, dW, db, bf16=bf16)
 
         call('nele_exptanh_bwd', ptr(dmask), ptr(mask), ptr(bf.do2), dmask.numel(), stream())
         # fc2
@@ -521,9 +562,7 @@ class Generator_Conv1D_cLN(nn.Module):
                 self._gemm(bf.dY[l], l, True, None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
                 dact = bf.dA[l]
         if wst is not None:
-            done = torch.cuda.Event()
-            done.record(wst)
-            main.wait_event(done)
+            ops.hand_over(ev, wst, main)
 
 
 # ================================================================== Discriminators
@@ -539,6 +578,8 @@ class _DBuffers:
         self.gen = 0
         self.wvalid = None
         self.prepjobs = None               # (key, ctypes job tables) of the batched weight-layout launches for this shape
+        self.plans = {}                    # recorded passes of this shape (_lib.Plan), dropped with the buffer set
+        self.events = ops.Events()
         H, W, C = 64, T, 4
         self.dims = [(H, W, C)]
         self.act, self.gf, self.gbuf, self.gb, self.gw, self.pad = [], [], [], [], [], []
@@ -666,6 +707,11 @@ class _DiscriminatorBase(nn.Module):
 
     def _sn_modules(self):
         return list(self.layers) + [self.fc1, self.fc2, self.fc3]
+
+    def train(self, mode=True):
+        """see Generator_Conv1D_cLN.train (the spectral-norm hooks of the sub-modules never run: the power iteration is nele_spectral_norm)"""
+        self.training = bool(mode)
+        return self
 
     def _weights(self, dev):
         dev = _norm_dev(dev)
@@ -817,6 +863,26 @@ class _DiscriminatorBase(nn.Module):
         bf.gen += 1
         a = din.contiguous()
         bf.din = a
+        score = _empty((B, self._nout), dev)
+        # padded batch of utterances of different lengths: the pooling runs over each utterance's own valid output columns (frames - 20)
+        bf.wvalid = None if frames is None else (frames.to(device=dev, dtype=torch.int32) - 20).contiguous()
+        # the conv stack + head as ONE call (nele_disc_fwd on the job table recorded the first time this shape / mode came by), or call by call
+        pkey = ('fwd', self.precision, self.profile_prefix, bf.wvalid is None, self._flat.flat.data_ptr(), w['sigma'].data_ptr())
+        plan = bf.plans.get(pkey) if ops.plans_enabled() else None
+        if plan is not None:
+            plan.streams[0] = stream()
+            call('nele_disc_fwd', plan.handle, ptr(a), ptr(bf.wvalid), ptr(score), plan.streams, len(plan.streams))
+        elif ops.plans_enabled():
+            with _lib.recording([ops.rng(a), None if bf.wvalid is None else ops.rng(bf.wvalid), ops.rng(score)]) as rec:
+                self._forward_live(a, bf, w, score)
+            bf.plans[pkey] = rec.finish()
+        else:
+            self._forward_live(a, bf, w, score)
+        self._last_score = score
+        return key
+
+    def _forward_live(self, a, bf, w, score):
+        B = bf.B
         for l, (cout, k) in enumerate(_D_CONVS):
             if bf.c16:
                 # bf16 activations in memory: conv1 as a float32 pointwise stream, conv2..conv5 on the ring / DMA tile kernel
@@ -832,13 +898,8 @@ class _DiscriminatorBase(nn.Module):
             else:
                 ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
-        score = _empty((B, self._nout), dev)
-        # padded batch of utterances of different lengths: the pooling runs over each utterance's own valid output columns (frames - 20)
-        bf.wvalid = None if frames is None else (frames.to(device=dev, dtype=torch.int32) - 20).contiguous()
         call('nele_gap_mlp_fwd_var', ptr(a), B, bf.P, bf.dims[-1][1], ptr(bf.wvalid), self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1),
              ptr(bf.h2), ptr(score), ptr(bf.scratch64), stream())
-        self._last_score = score
-        return key
 
     def forward_packed(self, din, frames=None):
         """din: channels-last [B,64,T,4] (ops.d_pack / energy-norm output).  frames [B] (optional): STFT frames of each utterance
@@ -857,35 +918,53 @@ class _DiscriminatorBase(nn.Module):
 
     def _backward_impl(self, dscore, key, need_din, score, wvalid=None):
         bf = self._bufs[key]
-        B = bf.B
         w = self._w
-        nout = self._nout
         wgrad = self.weight_grad_enabled
-        Ho, Wo, _ = bf.dims[-1]
-        p5 = bf.pad[-1]
-        g16 = self.precision == 'bf16' and (bf.grad16_ok or bf.c16)
-        if g16 and not bf.c16 and bf.gbuf16 is None:
-            bf.gbuf16 = torch.zeros(bf.gbuf[-1].shape, dtype=torch.bfloat16, device=bf.gbuf[-1].device)
-        glast = bf.gbuf16 if (g16 and not bf.c16) else bf.gbuf[-1]      # the last layer's output gradient, as its two consumers read it
-        call('nele_gap_mlp_bwd_var16' if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
-             self._mlp_ptrs(w), nout, SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1),
-             ptr(bf.dpooled), ptr(glast), stream())
-        ddin = None
-        # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
-        # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on two more streams
-        # beside the chain and join at the end.  In the D-step this tail is fully exposed (nothing else is left to overlap).
-        main = torch.cuda.current_stream()
         wsts = None
         if wgrad and self.overlap_wgrad:
             if self._wstream is None:
                 self._wstream = (ops.side_stream(dscore.device), ops.side_stream(dscore.device))
             wsts = self._wstream
-            ev0 = torch.cuda.Event()
-            ev0.record(main)                             # dz1..dz3 and gbuf[-1] exist
+        g16 = self.precision == 'bf16' and (bf.grad16_ok or bf.c16)
+        if g16 and not bf.c16 and bf.gbuf16 is None:
+            bf.gbuf16 = torch.zeros(bf.gbuf[-1].shape, dtype=torch.bfloat16, device=bf.gbuf[-1].device)
+        pkey = ('bwd', self.precision, bool(need_din), bool(wgrad), None if wsts is None else tuple(q.cuda_stream for q in wsts), wvalid is None,
+                self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), w['sigma'].data_ptr())
+        plan = bf.plans.get(pkey) if ops.plans_enabled() else None
+        if plan is not None:
+            plan.streams[0] = stream()
+            call('nele_disc_bwd', plan.handle, ptr(dscore), ptr(score), ptr(wvalid), ptr(bf.din), plan.streams, len(plan.streams))
+        elif ops.plans_enabled():
+            with _lib.recording([ops.rng(dscore), ops.rng(score), None if wvalid is None else ops.rng(wvalid), ops.rng(bf.din)]) as rec:
+                self._backward_live(dscore, bf, w, need_din, score, wvalid, wgrad, wsts, g16)
+            bf.plans[pkey] = rec.finish()
+        else:
+            self._backward_live(dscore, bf, w, need_din, score, wvalid, wgrad, wsts, g16)
+        return bf.ddin if need_din else None
+
+    def _backward_live(self, dscore, bf, w, need_din, score, wvalid, wgrad, wsts, g16):
+        B = bf.B
+        nout = self._nout
+        Ho, Wo, _ = bf.dims[-1]
+        p5 = bf.pad[-1]
+        glast = bf.gbuf16 if (g16 and not bf.c16) else bf.gbuf[-1]      # the last layer's output gradient, as its two consumers read it
+        call('nele_gap_mlp_bwd_var16' if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
+             self._mlp_ptrs(w), nout, SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1),
+             ptr(bf.dpooled), ptr(glast), stream())
+        # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its
+        # spectral-norm chain rule and bias gradient) only needs that layer's output gradient, so those run on two more streams
+        # beside the chain and join at the end.  In the D-step this tail is fully exposed (nothing else is left to overlap).
+        main = torch.cuda.current_stream()
+        if wsts is not None and (wsts[0] == main or wsts[1] == main):
+            wsts = None
+        ev = bf.events
+        ev.start()
+        if wsts is not None:
             for q in wsts:
-                q.wait_event(ev0)
+                ops.hand_over(ev, main, q)                # dz1..dz3 and gbuf[-1] exist
         if wgrad:
             # the three FC layers' weight gradients: a dozen small launches, on the second weight-gradient stream (its temporaries)
+            ctx = None
             if wsts is not None:
                 ctx = torch.cuda.stream(wsts[1])
                 ctx.__enter__()
@@ -897,8 +976,8 @@ class _DiscriminatorBase(nn.Module):
                 call('nele_mlp_wgrad', ptr(dz), ptr(xin), B, N, K, ptr(tw), c_void_p(tmpb.data_ptr()), stream())
                 call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * li), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
-                m.bias.grad.add_(tmpb)
-            if wsts is not None:
+                ops.vec_add_(m.bias.grad, tmpb)
+            if ctx is not None:
                 ctx.__exit__(None, None, None)
         for l in range(len(_D_CONVS) - 1, -1, -1):
             cout, k = _D_CONVS[l]
@@ -914,19 +993,18 @@ class _DiscriminatorBase(nn.Module):
                 tw, wsb, sc = (bf.tmpw, bf.ws, bf.scratch64) if q == 0 else (bf.tmpw2, bf.ws2, bf.scratch64b)
                 tmpb = tw[N * K:N * K + N]
                 wst = wsts[q] if wsts is not None else None
+                ctx = None
                 if wst is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(main)                      # gbuf[l] is complete at this point of the current stream
+                    ops.hand_over(ev, main, wst)          # gbuf[l] is complete at this point of the current stream
                     ctx = torch.cuda.stream(wst)
                     ctx.__enter__()
-                    wst.wait_event(ev)
                 ops.conv_wgrad(a_in, glast if l == len(_D_CONVS) - 1 else bf.gbuf[l], wsb, B, cout, bf.gw[l], cin_valid, tw, tmpb, accumulate=False,
                                bf16=(self.precision == 'bf16' and l > 0),
                                tag='D.conv%d.wgrad' % (l + 1))
                 call('nele_sn_grad', ptr(tw), ptr(m.weight_orig), ptr(m.weight_u), ptr(m.weight_v),
                      c_void_p(w['sigma'].data_ptr() + 4 * l), N, K, ptr(m.weight_orig.grad), 1, ptr(sc), stream())
-                m.bias.grad.add_(tmpb)
-                if wst is not None:
+                ops.vec_add_(m.bias.grad, tmpb)
+                if ctx is not None:
                     ctx.__exit__(None, None, None)
             if l > 0 and bf.c16:
                 ops.conv16(bf.gbuf[l], w['wb16c'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
@@ -940,13 +1018,9 @@ class _DiscriminatorBase(nn.Module):
                     ops.conv_gemm(bf.gbuf[l], w['wb'][l], None, bf.act[l - 1], bf.gbuf[l - 1], B, Ci, EPI_MASK_LRELU_GRAD, bf.gb[l], tag='D.conv%d.dgrad' % (l + 1))
             elif need_din:
                 ops.conv_gemm(bf.gbuf[0], w['wb'][0], None, None, bf.ddin, B, 4, EPI_NONE, bf.gb[0])
-                ddin = bf.ddin
         if wsts is not None:
             for q in wsts:
-                done = torch.cuda.Event()
-                done.record(q)
-                main.wait_event(done)
-        return ddin
+                ops.hand_over(ev, q, main)
 
 
 class Discriminator(_DiscriminatorBase):

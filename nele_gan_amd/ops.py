@@ -111,6 +111,55 @@ def side_stream(device):
     return torch.cuda.Stream(device=device)
 
 
+class Events:
+    """Hand-over events between the streams of one pass, created once per buffer set and addressed by position: a recorded plan
+    (_lib.PlanRecorder) holds their handles, so the n-th fork of a pass must always use the n-th event."""
+
+    def __init__(self):
+        self.ev = []
+        self.k = 0
+
+    def start(self):
+        self.k = 0
+
+    def next(self):
+        if self.k == len(self.ev):
+            h = c_void_p()
+            _lib.check(_lib.lib.nele_event_create(ctypes.byref(h)), 'nele_event_create')
+            self.ev.append(h)
+        self.k += 1
+        return self.ev[self.k - 1]
+
+    def __del__(self):
+        try:
+            for h in self.ev:
+                _lib.lib.nele_event_destroy(h)
+        except Exception:
+            pass
+
+
+def hand_over(events, src, dst):
+    """stream ``dst`` waits for everything enqueued on stream ``src`` so far (two plan-recordable library calls)."""
+    ev = events.next()
+    call('nele_event_record', ev, c_void_p(src.cuda_stream))
+    call('nele_stream_wait_event', ev, c_void_p(dst.cuda_stream))
+
+
+def vec_add_(dst, src):
+    """dst += src (float32, same length) as a plan-recordable library call."""
+    call('nele_vec_add', c_void_p(dst.data_ptr()), c_void_p(src.data_ptr()), dst.numel(), stream())
+
+
+def plans_enabled():
+    """Passes are replayed from recorded job tables unless switched off (_lib.PLANS) or a torch-event profile of single launches is armed."""
+    return _lib.PLANS and PROFILE is None
+
+
+def rng(t):
+    """(address, bytes) of a tensor for PlanRecorder's dynamic slots"""
+    return (t.data_ptr(), t.numel() * t.element_size())
+
+
 # bench.py sets PROFILE = {tag: [(start_event, end_event), ...]} to time one tagged kernel with HIP events
 # recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None

@@ -59,3 +59,16 @@ def test_product_library_has_no_switches_and_the_test_library_exports_the_same_a
     assert 'getenv' not in nm
     nm_ab = subprocess.run(['nm', '-D', '--undefined-only', ab_path], stdout=subprocess.PIPE, text=True).stdout
     assert 'getenv' in nm_ab
+
+
+def test_plan_operation_table_is_generated_from_the_header():
+    """csrc/plan_ops.inc (the dispatch table of nele_plan_run) is generated from include/nele_hip.h by tools/gen_plan_ops.py."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_plan_ops.py'), '--check'])
+    assert r.returncode == 0, "include/nele_hip.h changed: run python tools/gen_plan_ops.py and rebuild"
+    from nele_gan_amd import _lib
+    for name in ('nele_conv16', 'nele_glayer16_fwd', 'nele_cln_bwd', 'nele_event_record', 'nele_vec_add', 'nele_gap_mlp_bwd_var16'):
+        op = _lib.lib.nele_plan_op_id(name.encode())
+        assert op >= 0 and _lib.lib.nele_plan_op_nargs(op) == len(_lib._SIGS[name]), name
+    assert _lib.lib.nele_plan_op_id(b'nele_version') == -1

@@ -480,3 +480,78 @@ def test_fused_generator_equals_per_layer_kernels_in_bf16_mode(mods, B, T):
     assert float((a[2] - b[2]).abs().max()) <= 1e-2 * float(a[2].abs().max())
     assert torch.equal(b[0], b[2])                                        # train- and eval-mode forward passes of the fused path: the same kernels
     assert float((a[1] - b[1]).norm()) <= 6e-2 * float(a[1].norm())
+
+
+# ------------------------------------------------------------------ round 5: composite entry points (recorded job tables, csrc/plan.hip)
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+def test_recorded_plans_replay_bit_identically(mods, prec):
+    """nele_gen_fwd / nele_gen_bwd / nele_disc_fwd / nele_disc_bwd enqueue the job table that the host mirror recorded from its own per-layer
+    loop the first time a shape came by.  Call-by-call (_lib.PLANS = False), the recording pass and every replay must give the same bits:
+    masks, scores, input gradients and the flat parameter gradients of G and D, over two different batches (the per-call pointers - inputs,
+    outputs, carry tokens - are the plan's slots), with D's weight gradients on (D-step) and off (G-step) and a padded batch."""
+    from nele_gan_amd import _lib
+    B, T = 3, 300                                                          # two strips of the fused generator layers
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.rand(B, T, 64, generator=g).cuda(), torch.rand(B, T, 64, generator=g).cuda(), torch.randn(B, T, 64, generator=g).cuda(),
+                torch.rand(B, 64, T, 4, generator=g).cuda(), torch.randn(B, 3, generator=g).cuda()) for _ in range(3)]
+    frames = torch.tensor([300, 180, 251], dtype=torch.int32, device='cuda')
+
+    def run(plans):
+        _lib.PLANS = plans
+        try:
+            G = load_recipe(mods.Generator_Conv1D_cLN(), 101)
+            D = load_recipe(mods.Discriminator(), 202)
+            G.precision = D.precision = prec
+            out = []
+            for it, (x, y, gw, din, ds) in enumerate(batches):
+                mask = G(x, y)
+                G.flat_parameters().grad.zero_()
+                (mask * gw).sum().backward()
+                d_in = din.clone().requires_grad_(True)
+                D.weight_grad_enabled = it != 1                            # the G-step form in between
+                D.flat_parameters().grad.zero_()
+                score = D.forward_packed(d_in, frames if it == 2 else None)
+                (score * ds).sum().backward()
+                D.weight_grad_enabled = True
+                out.append([t.detach().clone() for t in (mask, G.flat_parameters().grad, score, d_in.grad, D.flat_parameters().grad)])
+            with torch.no_grad():
+                G.eval()
+                out.append([G(batches[0][0], batches[0][1]).clone(), G(batches[1][0], batches[1][1]).clone()])
+            nplans = sum(len(b.plans) for b in G._bufs.values()) + sum(len(b.plans) for b in D._bufs.values())
+            return out, nplans
+        finally:
+            _lib.PLANS = True
+
+    live, n0 = run(False)
+    rec, n1 = run(True)
+    assert n0 == 0 and n1 >= 6                                             # G fwd (train, eval) + bwd, D fwd (2 forms) + bwd (3 forms)
+    for a, b in zip(live, rec):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
+def test_plan_run_reports_errors_and_slot_mismatches(mods):
+    from nele_gan_amd import _lib
+    import ctypes
+    j = _lib.nele_plan_job()
+    j.op, j.nargs, j.stream = _lib.lib.nele_plan_op_id(b'nele_vec_add'), 4, 0
+    for i in range(4):
+        j.slot[i] = -1
+    j.slot[0], j.slot[1] = 0, 1
+    j.ival[2] = 1000
+    h = ctypes.c_void_p()
+    arr = (_lib.nele_plan_job * 1)(j)
+    _lib.check(_lib.lib.nele_plan_create(arr, 1, 2, 1, ctypes.byref(h)), 'create')
+    a, b = torch.ones(1000, device='cuda'), torch.full((1000,), 2.0, device='cuda')
+    streams = (ctypes.c_void_p * 1)(_lib.stream())
+    slots = (ctypes.c_longlong * 2)(a.data_ptr(), b.data_ptr())
+    _lib.check(_lib.lib.nele_plan_run(h, streams, 1, slots, 2), 'run')
+    assert float(a.sum()) == 3000.0
+    assert _lib.lib.nele_plan_run(h, streams, 1, slots, 1) == -1           # too few slots
+    slots[1] = 0
+    assert _lib.lib.nele_plan_run(h, streams, 1, slots, 2) == -1           # the entry point's own argument check (null source)
+    assert b'nele_vec_add' in _lib.lib.nele_last_error_string()
+    j.nargs = 3
+    h2 = ctypes.c_void_p()
+    assert _lib.lib.nele_plan_create((_lib.nele_plan_job * 1)(j), 1, 2, 1, ctypes.byref(h2)) == -1
+    _lib.check(_lib.lib.nele_plan_destroy(h), 'destroy')
