@@ -94,8 +94,12 @@ def dry_run(a, world, rank):
         time.sleep(0.001 * (hi - lo) / 64.0)
     dt = time.perf_counter() - t0
     shard = torch.tensor([float(hi - lo)])
+    # BASELINE configs[4]: 10 000 utterances of 8 s, contiguous file shards (inference.enhance_files: dist.shard_range), batches of 128
+    ilo, ihi = ndist.shard_range(10000, rank, world)
+    ish = torch.tensor([float(ihi - ilo), float((ihi - ilo + 127) // 128)])
     if world > 1:
         dist.all_reduce(shard)
+        dist.all_reduce(ish)
         dist.barrier()
     if rank == 0:
         print(json.dumps({'metric': 'utterances/sec per GAN_epoch step (G+D+metric loss)', 'value': a.global_batch * a.steps / dt, 'unit': 'utterances/s',
@@ -103,7 +107,8 @@ def dry_run(a, world, rank):
                           'scaling': a.scaling, 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic', 'dry_run': True,
                           'config': {'workload': 'DRY RUN (CPU, gloo, no kernels): launcher + sharding + collectives only',
                                      'global_batch': a.global_batch, 'parallelism': 'dp%d' % world},
-                          'ranks_seen': int(ones.item()), 'shard_sum': int(shard.item()), 'shard_rank0': [lo, hi]}))
+                          'ranks_seen': int(ones.item()), 'shard_sum': int(shard.item()), 'shard_rank0': [lo, hi],
+                          'configs4': {'files': 10000, 'files_sharded': int(ish[0].item()), 'shard_rank0': [ilo, ihi], 'batches_of_128_all_ranks': int(ish[1].item())}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -202,14 +207,14 @@ def inference_rate(tr, batch, K, rank, sweep=(64, 256, 512)):
     return out
 
 
-def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None):
+def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None, serial=False):
     """The canonical step of another workload on this GPU (fresh trainer, 2 warm-up steps, `steps` timed steps)."""
     import gc
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
     try:
-        return _companion(a, metric_str, batch, length, steps, main_tr, precision, pipe)
+        return _companion(a, metric_str, batch, length, steps, main_tr, precision, pipe, serial)
     except Exception as e:                                  # a companion must not take the headline line down with it
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300]), 'batch': batch, 'samples_per_utterance': length, 'metrics': metric_str}
     finally:
@@ -217,7 +222,23 @@ def companion(a, metric_str, batch, length, steps, main_tr=None, precision=None,
         torch.cuda.empty_cache()                            # multi-GB metric workspaces of the companion's trainer
 
 
-def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None):
+def _companion(a, metric_str, batch, length, steps, main_tr=None, precision=None, pipe=None, serial=False):
+    import torch
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    if serial:
+        # every "side stream" of this trainer is the current stream (ops.side_stream): the whole step on ONE stream, kernels strictly in
+        # sequence - what the multi-stream schedule is worth, as a measured number
+        os.environ['NELE_SERIAL'] = '1'
+        main_tr = None
+    try:
+        return _companion_run(a, metric_str, batch, length, steps, main_tr, precision, pipe)
+    finally:
+        if serial:
+            os.environ.pop('NELE_SERIAL', None)
+
+
+def _companion_run(a, metric_str, batch, length, steps, main_tr, precision, pipe):
     import torch
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
@@ -298,6 +319,108 @@ def epoch_equivalent(tr, cw, nw, K, utts):
     dt = (time.perf_counter() - t0) / K
     return {'value': utts / dt, 'unit': 'utterances/s', 'ms_per_unit': dt * 1e3,
             'mix': '1 G-step + generate + targets of 2 examples (clean-signal work shared; SIIB / HASPI / ESTOI on three streams) + 6 D-steps per batch, stages in sequence'}
+
+
+def epoch_with_quality(a, cw, nw):
+    """GanTrainer.run_epoch itself - the reference's whole epoch body (train_nele.py:110-429) on the headline batch with the quality
+    discriminator ON (train_nele.py:150-152, 362-365: the reference always trains D_Qua; PESQ / ViSQOL are not built, so the targets are
+    synthetic constants), a pre-enhanced ('DRC') example per utterance and the 1/30 history replay of pass B: G-step with the
+    0.5 MSE(D_Qua) term, checkpoint-free, sample generation, targets of both examples (clean-signal work shared), three D passes over
+    2 x B items + replay, D and D_Qua stepped.  Timed over two epochs after a warm-up epoch that fills the history."""
+    import gc
+    import torch
+    from nele_gan_amd.train_nele import GanTrainer
+    try:
+        tr = GanTrainer(a.metrics, use_quality=True)
+        tr.D.precision = tr.G.precision = tr.D_Qua.precision = a.precision
+        B = cw.shape[0]
+        drc = (cw * 1.5).contiguous()
+        qua = torch.full((B, 2), 0.6, device=cw.device)
+        batches = [{'clean': cw, 'noise': nw, 'drc': drc, 'qua': qua, 'drc_qua': qua * 0.5}]
+        tr.run_epoch(2, batches, (), d_batch=B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = None
+        for ep in (3, 4):
+            res = tr.run_epoch(ep, batches, (), d_batch=B)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        return {'value': B / dt, 'unit': 'utterances/s', 'ms_per_epoch': dt * 1e3, 'utterances': B, 'd_steps_per_epoch': res['d_steps'], 'g_steps_per_epoch': res['g_steps'],
+                'history_items': len(tr.history),
+                'mix': 'GanTrainer.run_epoch: G-step incl. 0.5 MSE(D_Qua), generate, targets of generated + pre-enhanced example, 3 D passes over 2 B items + 1/30 replay, '
+                       'D and D_Qua stepped; quality targets synthetic (PESQ / ViSQOL not built)'}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def epoch_from_files(a, n_utt=256, batch=64):
+    """End to end from wav files: a synthetic corpus (PCM_16, lengths 3 .. 4 s, as the reference's folders of clean / noise files) is
+    written to tmpfs, then GanTrainer.run_epoch is fed from it through dataio.FileBatches (threaded decode, pinned staging, asynchronous
+    copies, two batches ahead) - the reference feeds its loop from 8 DataLoader workers (dataloader.py:86-98) and re-reads the files in
+    every stage.  Reported: utterances/s of the epoch fed from files, of the same epoch on batches already resident in HBM, and of the
+    loader alone (decode + upload)."""
+    import gc
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from nele_gan_amd import dataio, synth
+    from nele_gan_amd.train_nele import GanTrainer
+    root = tempfile.mkdtemp(prefix='nele_corpus_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        c, v = synth.batch(n_utt, 64000, start=40000)
+        rs = np.random.RandomState(0)
+        os.makedirs(root + '/Clean'); os.makedirs(root + '/Noise')
+        files = []
+        for i in range(n_utt):
+            L = int(rs.randint(48000, 64001))
+            dataio.write_wav_pcm16('%s/Clean/u%04d.wav' % (root, i), c[i, :L])
+            dataio.write_wav_pcm16('%s/Noise/u%04d.wav' % (root, i), v[i, :L])
+            files.append('%s/Clean/u%04d.wav' % (root, i))
+        tr = GanTrainer(a.metrics)
+        tr.D.precision = tr.G.precision = a.precision
+        nthreads = min(32, os.cpu_count() or 8)
+        fb = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=2)   # keep < batches: every pass over the list decodes again
+        tr.run_epoch(2, fb, (), d_batch=batch)                                # warm-up: buffer sets / plans of the padded shapes
+        torch.cuda.synchronize()
+        n0 = fb.decoded_files
+        t0 = time.perf_counter()
+        res = tr.run_epoch(3, fb, (), d_batch=batch)
+        torch.cuda.synchronize()
+        dt_files = time.perf_counter() - t0
+        decoded = fb.decoded_files - n0
+        fbm = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=0, keep=len(fb) + 1)
+        mem = [dict(fbm[i]) for i in range(len(fbm))]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.run_epoch(4, mem, (), d_batch=batch)
+        torch.cuda.synchronize()
+        dt_mem = time.perf_counter() - t0
+        fb2 = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=1)
+        for b in fb2:                                                       # first pass: the pinned staging buffers are allocated (milliseconds each)
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in fb2:                                                       # steady state: every file decoded again (keep = 1), buffers from the pool
+            pass
+        torch.cuda.synchronize()
+        dt_load = time.perf_counter() - t0
+        fb.close(); fb2.close(); fbm.close()
+        return {'value': n_utt / dt_files, 'unit': 'utterances/s', 'ms_per_epoch': dt_files * 1e3, 'utterances': n_utt, 'batch': batch,
+                'files_decoded_per_epoch': decoded, 'd_steps': res['d_steps'], 'g_steps': res['g_steps'],
+                'resident_batches': {'value': n_utt / dt_mem, 'ms_per_epoch': dt_mem * 1e3},
+                'loader_alone': {'value': n_utt / dt_load, 'unit': 'utterances/s (clean + noise wav decoded, padded, uploaded)', 'host_threads': nthreads,
+                                 'wav_MB_per_s': 2 * sum(os.path.getsize(f) for f in files) / dt_load / 1e6},
+                'mix': 'GanTrainer.run_epoch(epoch >= 2) over %d files of 3 .. 4 s in batches of %d: G-steps, generate, targets, 3 D passes + replay' % (n_utt, batch)}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -428,6 +551,7 @@ def main():
             ev[5].record(); stage_ev.append(ev)
         else:
             last = one_step()
+    tr._flush_d()                       # (several ranks: the last step's D update is deferred under the NEXT step's features; there is none)
     barrier()
     dt = time.perf_counter() - t0
     if not a.breakdown:
@@ -620,6 +744,8 @@ def main():
             # the headline workload with the next batch's FEATURES prefetched behind the targets (what a DataLoader-fed loop can do at any batch
             # size; `value` itself stays the plain step: every step strictly on its own)
             out['headline_pipelined'] = companion(a, a.metrics, a.batch, a.length, 6, tr, pipe=True)
+            # ... and with every kernel of the step on ONE stream (no side streams at all): what the seven-stream schedule buys
+            out['headline_one_stream'] = companion(a, a.metrics, a.batch, a.length, 4, None, pipe=False, serial=True)
             out['shard128'] = companion(a, a.metrics, 128, a.length, 6, tr)
             out['global1024'] = companion(a, a.metrics, 1024, a.length, 3, tr)
             if 'ms_per_step' in out['shard128'] and 'ms_per_step' in out['global1024']:
@@ -638,6 +764,9 @@ def main():
     if rank == 0:
         if ee is not None:
             out['epoch_equivalent'] = ee
+            if world == 1 and a.companions:
+                out['epoch_equivalent_qua'] = epoch_with_quality(a, cw, nw)
+                out['epoch_from_files'] = epoch_from_files(a)
         if world == 1 and a.cpu_utts > 0:
             out['cpu_baseline'] = cpu_baseline(metrics, a.length, a.cpu_utts)
         print(json.dumps(out))

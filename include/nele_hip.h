@@ -87,6 +87,11 @@ int nele_stream_wait_event(void* event, void* stream);
 /* dst[i] += src[i] (bias gradients: the reduced partials of a weight-gradient call added to the flat gradient buffer) */
 int nele_vec_add(float* dst, const float* src, long long n, void* stream);
 
+/* Host-side helper of the file hand-off (dataloader.py:34-37 librosa.load -> libsndfile): decodes a mono PCM_16 RIFF file into out_host [cap]
+ * float32 HOST memory (samples / 32768, zeros behind them); *n_out = samples, *sample_rate_out = rate.  No GPU work; a foreign-function call
+ * runs it outside the host language's interpreter lock, so loader threads decode in parallel.  Other wav flavours: NELE_ERR_UNSUPPORTED. */
+int nele_wav_decode_pcm16(const char* path, float* out_host, long long cap, long long* n_out, int* sample_rate_out);
+
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */
 
 /* audio_util.py:53-58 STFT (librosa 0.7.1: reflect pad 256, periodic Hann 512, hop 256),

@@ -74,6 +74,54 @@ extern "C" int nele_stream_occupy(int workgroups, int lds_bytes, double microsec
     return hipGetLastError() == hipSuccess ? NELE_OK : nele_set_error(NELE_ERR_HIP, "nele_stream_occupy: launch failed");
 }
 
+// ---- host-side wav decoding (no GPU work): the reference reads its wav files through libsndfile (librosa.load / sf.read, dataloader.py:34-37);
+// the host mirror's loader threads call this through ctypes, which releases the interpreter lock for the whole call - file read, RIFF walk
+// and the int16 -> float32 conversion run in parallel on the loader threads instead of taking turns in the interpreter.
+// Mono PCM_16 only (what the reference writes and reads); anything else returns NELE_ERR_UNSUPPORTED and the caller uses its general reader.
+// out [cap] float32 host memory (e.g. a row of a pinned staging buffer): samples / 32768, zeros behind them; *n_out = samples written.
+#include <cstdio>
+#include <cstdlib>
+extern "C" int nele_wav_decode_pcm16(const char* path, float* out_host, long long cap, long long* n_out, int* sample_rate_out) {
+    if (!path || !out_host || cap < 0 || !n_out) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_wav_decode_pcm16: bad arguments");
+    FILE* f = fopen(path, "rb");
+    if (!f) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_wav_decode_pcm16: cannot open %s", path);
+    unsigned char hd[12];
+    int st = NELE_ERR_UNSUPPORTED;
+    long long n = 0;
+    int fmt_ok = 0, sr = 0;
+    if (fread(hd, 1, 12, f) == 12 && !memcmp(hd, "RIFF", 4) && !memcmp(hd + 8, "WAVE", 4)) {
+        unsigned char ch[8];
+        while (fread(ch, 1, 8, f) == 8) {
+            const unsigned size = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((unsigned)ch[7] << 24);
+            if (!memcmp(ch, "fmt ", 4) && size >= 16) {
+                unsigned char fm[16];
+                if (fread(fm, 1, 16, f) != 16) break;
+                const int tag = fm[0] | (fm[1] << 8), nch = fm[2] | (fm[3] << 8), bits = fm[14] | (fm[15] << 8);
+                sr = fm[4] | (fm[5] << 8) | (fm[6] << 16) | (fm[7] << 24);
+                fmt_ok = (tag == 1 && nch == 1 && bits == 16);
+                if (fseek(f, (long)(size - 16 + (size & 1)), SEEK_CUR)) break;
+            } else if (!memcmp(ch, "data", 4)) {
+                if (!fmt_ok) break;
+                long long want = (long long)size / 2;
+                if (want > cap) want = cap;
+                // int16 samples are read into the tail of the output row and converted front to back (4 bytes written per 2 read)
+                short* raw = reinterpret_cast<short*>(out_host) + want;      // second half of the first `want` floats
+                const long long got = (long long)fread(raw, 2, (size_t)want, f);
+                for (long long i = 0; i < got; ++i) out_host[i] = (float)raw[i] * (1.0f / 32768.0f);
+                n = got;
+                st = NELE_OK;
+                break;
+            } else if (fseek(f, (long)(size + (size & 1)), SEEK_CUR)) break;
+        }
+    }
+    fclose(f);
+    if (st != NELE_OK) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_wav_decode_pcm16: %s is not a mono PCM_16 RIFF file", path);
+    for (long long i = n; i < cap; ++i) out_host[i] = 0.f;
+    *n_out = n;
+    if (sample_rate_out) *sample_rate_out = sr;
+    return NELE_OK;
+}
+
 bool nele_first_use_on_device(unsigned long long* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)

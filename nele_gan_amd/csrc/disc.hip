@@ -312,6 +312,15 @@ __global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restri
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard[1], 1);
         return;
     }
+    // torch.optim.Adam's bias correction counts the updates that HAPPENED: a masked step never existed for it.  bc1 / bc2_sqrt come from
+    // the host for update number `step`; when steps were masked before this one (guard[1] > 0, a rare event) the corrections are recomputed
+    // here for update number step - guard[1] (until round 5 the masked steps were counted: a documented deviation, now gone).
+    const int skipped = guard[1];
+    if (skipped > 0) {
+        const double eff = (double)(step - skipped);
+        bc1 = (float)(1.0 - pow((double)beta1, eff));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, eff));
+    }
     const float step_size = lr / bc1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i];

@@ -19,6 +19,11 @@ import numpy as np
 
 fs = 16000
 power_law = (1 / 6)
+try:                                                   # host-side C helper of libnele_hip.so (no GPU needed to call it)
+    from ._lib import lib as _nele_lib
+    _native_decode = _nele_lib.nele_wav_decode_pcm16
+except Exception:                                      # pragma: no cover
+    _native_decode = None
 
 
 # ------------------------------------------------------------------------------------------------ wav files
@@ -30,13 +35,14 @@ def read_wav(path):
     if len(data) < 12 or data[0:4] != b'RIFF' or data[8:12] != b'WAVE':
         raise ValueError('%s: not a RIFF/WAVE file' % path)
     pos, fmt, pcm = 12, None, None
+    view = memoryview(data)                                              # chunk bodies are views: the sample data is not copied before numpy reads it
     while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], struct.unpack('<I', data[pos + 4:pos + 8])[0]
-        body = data[pos + 8:pos + 8 + size]
+        cid, size = data[pos:pos + 4], struct.unpack_from('<I', data, pos + 4)[0]
+        body = view[pos + 8:pos + 8 + size]
         if cid == b'fmt ':
-            fmt = struct.unpack('<HHIIHH', body[:16])
+            fmt = struct.unpack_from('<HHIIHH', body, 0)
             if fmt[0] == 0xFFFE and len(body) >= 26:                     # WAVE_FORMAT_EXTENSIBLE: sub-format tag
-                fmt = (struct.unpack('<H', body[24:26])[0],) + fmt[1:]
+                fmt = (struct.unpack_from('<H', body, 24)[0],) + fmt[1:]
         elif cid == b'data':
             pcm = body
         pos += 8 + size + (size & 1)
@@ -64,6 +70,35 @@ def read_wav(path):
     if nch > 1:
         x = x[:len(x) // nch * nch].reshape(-1, nch).mean(axis=1).astype(np.float32)
     return x, sr
+
+
+def read_wav_into(path, out_row):
+    """Decode a mono PCM_16 file straight into ``out_row`` (float32 numpy row, e.g. a pinned staging buffer); zeros behind the signal.
+    -> (samples written, sample_rate), or None when the file is anything else (the caller falls back to read_wav)."""
+    if _native_decode is not None and out_row.flags['C_CONTIGUOUS'] and out_row.dtype == np.float32:
+        # the library's C reader: the whole call runs outside the interpreter lock (loader threads decode in parallel)
+        import ctypes
+        n, sr = ctypes.c_longlong(0), ctypes.c_int(0)
+        st = _native_decode(path.encode(), out_row.ctypes.data, out_row.shape[0], ctypes.byref(n), ctypes.byref(sr))
+        return (int(n.value), int(sr.value)) if st == 0 else None
+    with open(path, 'rb') as f:
+        data = f.read()
+    if len(data) < 44 or data[0:4] != b'RIFF' or data[8:12] != b'WAVE':
+        return None
+    pos, fmt, off, size = 12, None, -1, 0
+    while pos + 8 <= len(data):
+        cid, csz = data[pos:pos + 4], struct.unpack_from('<I', data, pos + 4)[0]
+        if cid == b'fmt ':
+            fmt = struct.unpack_from('<HHIIHH', data, pos + 8)
+        elif cid == b'data':
+            off, size = pos + 8, min(csz, len(data) - pos - 8)
+        pos += 8 + csz + (csz & 1)
+    if fmt is None or off < 0 or fmt[0] != 1 or fmt[1] != 1 or fmt[5] != 16:
+        return None
+    n = min(size // 2, out_row.shape[0])
+    np.multiply(np.frombuffer(data, dtype='<i2', count=n, offset=off), np.float32(1.0 / 32768.0), out=out_row[:n])   # == s / 32768 exactly (power of two)
+    out_row[n:] = 0.0
+    return n, fmt[2]
 
 
 def load(path, sr=None):
@@ -217,6 +252,132 @@ def read_batch_SIIB_DRC(clean_root, noise_root, enhanced_list):
 def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
     """audio_util.py:305-322."""
     return _read_batch('haspi', clean_root, noise_root, enhanced_list, True, drc=True)
+
+
+# ------------------------------------------------------------------------------------------------ batches from files, prefetched
+class FileBatches:
+    """A corpus on disk as the sequence of batch dicts GanTrainer.run_epoch takes ({'clean', 'noise', 'lengths', 'names'[, 'drc',
+    'drc_lengths']}, device tensors, files of any lengths padded side by side).  The reference feeds its loop from 8 DataLoader worker
+    processes (dataloader.py:86-98) and re-reads the wav files in every stage; here wav decoding runs on ``workers`` threads
+    (numpy's frombuffer / astype release the GIL), ``ahead`` batches are decoded beyond the one being asked for, and each batch is staged
+    through pinned host memory with an asynchronous copy on its own stream (the consumer's stream waits for that copy only).
+    ``seq[i]`` may be asked for repeatedly and in any order (run_epoch walks the list once for the G-steps and once for the sample
+    generation): a batch is decoded again when it is no longer cached, like the reference."""
+
+    def __init__(self, file_list, noise_path, batch=32, drc_path=None, workers=8, ahead=2, device='cuda', pad_to=4096, keep=4):
+        import concurrent.futures as cf
+        self.files, self.noise_path, self.drc_path = list(file_list), noise_path, drc_path
+        self.groups = [list(range(k, min(k + batch, len(self.files)))) for k in range(0, len(self.files), batch)]
+        self.pool = cf.ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self.ahead, self.pad_to, self.keep, self.device = int(ahead), int(pad_to), int(keep), device
+        self._pending, self._ready = {}, {}
+        self._pool_bufs = {}
+        self._copy = None
+        self.decoded_files = 0
+
+    def __len__(self):
+        return len(self.groups)
+
+    def _bound(self, path):
+        """upper bound of a file's samples from its size (exact for the 44-byte-header PCM_16 files the reference writes)"""
+        return max(1, (os.path.getsize(path) - 44 + 1) // 2)
+
+    def _decode_into(self, idx, rows):
+        """decode file idx into its rows of the group's pinned buffers -> (samples clean/noise, samples drc, name)"""
+        name = self.files[idx].split('/')[-1]
+        srcs = [self.files[idx], self.noise_path + name] + ([self.drc_path + name] if self.drc_path is not None else [])
+        got = []
+        for path, row in zip(srcs, rows):
+            r = read_wav_into(path, row)
+            if r is None:                                                  # not plain mono PCM_16: the general reader
+                x, sr = load(path)
+                n = min(len(x), row.shape[0])
+                row[:n] = x[:n]
+                row[n:] = 0.0
+                r = (n, sr)
+            assert r[1] == 16000                                           # dataloader.py:35
+            got.append(r[0])
+        m = min(got[0], got[1])                                            # the noise file is cut to the clean file's length and vice versa
+        rows[0][m:] = 0.0
+        rows[1][m:] = 0.0
+        return m, (got[2] if len(got) > 2 else None), name
+
+    def _pinned(self, shape):
+        """pinned staging buffer from a small pool (cudaHostAlloc per batch costs milliseconds); a buffer returns to the pool when the
+        batch that used it leaves the cache"""
+        import torch
+        lst = self._pool_bufs.setdefault(tuple(shape), [])
+        return lst.pop() if lst else torch.empty(shape, dtype=torch.float32).pin_memory()
+
+    def _submit(self, g):
+        if not (0 <= g < len(self.groups)) or g in self._pending or g in self._ready:
+            return
+        idxs = self.groups[g]
+        names = [self.files[i].split('/')[-1] for i in idxs]
+        Lmax = max(max(self._bound(self.files[i]), self._bound(self.noise_path + nm)) for i, nm in zip(idxs, names))
+        if self.pad_to:
+            Lmax = (Lmax + self.pad_to - 1) // self.pad_to * self.pad_to
+        n = len(idxs)
+        hc, hn = self._pinned((n, Lmax)), self._pinned((n, Lmax))
+        hd = None
+        if self.drc_path is not None:
+            Ld = max(self._bound(self.drc_path + nm) for nm in names)
+            if self.pad_to:
+                Ld = (Ld + self.pad_to - 1) // self.pad_to * self.pad_to
+            hd = self._pinned((n, max(Ld, Lmax)))
+        ac, an, ad = hc.numpy(), hn.numpy(), (hd.numpy() if hd is not None else None)
+        futs = [self.pool.submit(self._decode_into, i, [ac[r], an[r]] + ([ad[r]] if ad is not None else [])) for r, i in enumerate(idxs)]
+        self._pending[g] = (futs, hc, hn, hd)
+
+    def _stage(self, g):
+        import torch
+        futs, hc, hn, hd = self._pending.pop(g)
+        res = [f.result() for f in futs]
+        self.decoded_files += len(res)
+        lens = np.asarray([r[0] for r in res], dtype=np.int32)
+        if self._copy is None:
+            self._copy = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._copy):
+            b = {'clean': hc.to(self.device, non_blocking=True), 'noise': hn.to(self.device, non_blocking=True),
+                 'lengths': torch.from_numpy(lens).pin_memory().to(self.device, non_blocking=True), 'names': [r[2] for r in res]}
+            if hd is not None:
+                dlens = np.asarray([r[1] for r in res], dtype=np.int32)
+                b['drc'] = hd.to(self.device, non_blocking=True)
+                b['drc_lengths'] = torch.from_numpy(dlens).pin_memory().to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy)
+        self._ready[g] = (b, ev, (hc, hn, hd))
+        while len(self._ready) > self.keep:
+            _, ev_old, bufs = self._ready.pop(next(iter(self._ready)))
+            ev_old.synchronize()                                           # its upload is long done; the pinned buffers go back to the pool
+            for t in bufs:
+                if t is not None:
+                    self._pool_bufs.setdefault(tuple(t.shape), []).append(t)
+
+    def __getitem__(self, g):
+        import torch
+        if g < 0:
+            g += len(self.groups)
+        if not 0 <= g < len(self.groups):
+            raise IndexError(g)
+        for k in range(g, g + 1 + self.ahead):
+            self._submit(k)
+        if g not in self._ready:
+            self._stage(g)
+        b, ev, _ = self._ready[g]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in b.values():                                               # allocated on the copy stream, consumed on this one
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+        return b
+
+    def __iter__(self):
+        for g in range(len(self.groups)):
+            yield self[g]
+
+    def close(self):
+        self.pool.shutdown(wait=False)
 
 
 # ------------------------------------------------------------------------------------------------ datasets (dataloader.py)

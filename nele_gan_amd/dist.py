@@ -40,6 +40,23 @@ def allreduce_mean_(flat):
     return flat
 
 
+class PendingMean:
+    """A gradient bucket's mean over the ranks, started with async_op=True (RCCL runs it on its own stream: it proceeds beside whatever the
+    caller enqueues next) and completed by wait(): the caller's stream then waits for the collective and applies the 1 / world scale."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.w = world_size()
+        self.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True) if self.w > 1 else None
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            self.flat.mul_(1.0 / self.w)
+        return self.flat
+
+
 def allreduce_weighted_mean_(flat, weight):
     """In-place item-weighted mean over ranks: flat holds this rank's mean gradient over ``weight`` items (0 = none; the buffer is then
     all zeros).  One all-reduce for the bucket and one for the scalar count; ranks with nothing to add still take part."""

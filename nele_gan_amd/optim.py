@@ -28,9 +28,9 @@ class Adam:
         self._state().grad.zero_()
 
     def step(self):
-        """One Adam update.  A step whose gradient is not finite is skipped on the device (parameters and moments untouched); the step
-        number still advances, i.e. the bias correction of later steps counts the skipped one - documented deviation from an optimiser
-        that would have raised / produced NaN weights at that point."""
+        """One Adam update.  A step whose gradient is not finite is skipped on the device (parameters and moments untouched) and does not
+        count: the bias correction of later steps uses the number of updates that happened (step_count - skipped, read on the device), as
+        torch.optim.Adam would after a loop that simply did not call step() for that batch."""
         fp = self._state()
         self.step_count += 1
         ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.guard)

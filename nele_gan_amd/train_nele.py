@@ -160,6 +160,13 @@ class GanTrainer:
         self._status = {}
         self._ws = {}                                # metric workspaces of the split objects (multi-GB at B = 256): owned here, freed with the trainer
         self.world = ndist.world_size()
+        # Data parallelism ("overlap with the next batch's feature kernels"): the canonical step's LAST action is the all-reduce
+        # of D's gradients + Adam-D, and the next step's first work - the features of its batch - needs neither.  With overlap_allreduce the
+        # step ends by STARTING that all-reduce (async: RCCL's own stream) and the update is completed (_flush_d: wait, scale, Adam-D) by
+        # whatever touches D next - the following canonical_step does so right after enqueuing its features, so the collective's latency
+        # hides under them.  One rank: no collective, nothing is deferred.
+        self.overlap_allreduce = True
+        self._pending_d = None
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
                 ndist.broadcast_module_(m, 0)
@@ -174,6 +181,14 @@ class GanTrainer:
                 ndist.allreduce_mean_(g)
             else:
                 ndist.allreduce_weighted_mean_(g, float(weight))
+
+    def _flush_d(self):
+        """Complete a deferred D update (see overlap_allreduce): wait for the gradient all-reduce, scale, Adam-D."""
+        pend, self._pending_d = self._pending_d, None
+        if pend is not None:
+            pend.wait()
+            self.optimizer_d.step()
+            self.step_d += 1
 
     @staticmethod
     def _advance_sn(module):
@@ -224,6 +239,7 @@ class GanTrainer:
         """One optimiser step of G (train_nele.py:130-155).  ``weight``: number of utterances this rank contributes (run_epoch under data
         parallelism: ranks may hold different batch sizes / batch counts; None = plain mean over ranks); ``clean_band=None`` = an empty
         step that only joins the collective (this rank has run out of batches)."""
+        self._flush_d()
         if clean_band is None:
             # a real G-step runs D's (and D_Qua's) training-mode forward pass, which advances their spectral-norm u / v once
             self._advance_sn(self.D)
@@ -285,6 +301,7 @@ class GanTrainer:
         (SIIB with too few active frames, HASPI below threshold), truncated SIIB scores (replication / frame caps), and optimiser steps
         skipped because their gradient was not finite (a NaN target or a poisoned eigen-decomposition must not reach the weights).
         Call once per epoch (run_epoch does)."""
+        self._flush_d()
         cur = torch.cuda.current_stream() if self.device.type == 'cuda' else None
         for st_ in self._all_side_streams():         # the 'side' accumulators are updated on a side stream BEHIND the event the main stream waits on
             if cur is not None:
@@ -429,6 +446,7 @@ class GanTrainer:
         under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives.
         ``has_qua``: whether THIS optimiser step includes D_Qua - under data parallelism it must be the same on every rank (the D_Qua
         all-reduce is a collective), so d_epoch decides it once per pass for all ranks; None = decide from ``target_qua`` (single rank)."""
+        self._flush_d()
         if has_qua is None:
             has_qua = self.D_Qua is not None and target_qua is not None
         if has_qua and self.D_Qua is None:
@@ -456,11 +474,16 @@ class GanTrainer:
             self.optimizer_dqua.step()
         return loss
 
-    def _d_finish(self, score, target, weight=None):
+    def _d_finish(self, score, target, weight=None, defer=False):
+        """loss, backward, gradient all-reduce, Adam-D.  defer (canonical_step with overlap_allreduce on several ranks, equal shards): the
+        all-reduce is started asynchronously and the update is left to _flush_d()."""
         loss = None
         if score is not None:
             loss = self.MSELoss(score, target)
             loss.backward()
+        if defer and self.world > 1 and weight is None and self.overlap_allreduce:
+            self._pending_d = ndist.PendingMean(self.D.flat_parameters().grad)
+            return loss.detach() if loss is not None else None
         self._allreduce_grads(self.D, weight)
         self.optimizer_d.step()
         self.step_d += 1
@@ -602,6 +625,12 @@ class GanTrainer:
         # generate.  (2) Once the enhanced signal exists the remaining metric work follows on the side stream while the main
         # stream runs D's forward pass, which does not need the targets; the loss waits for them.
         main = torch.cuda.current_stream()
+        if self._pending_d is not None:
+            # the previous step's D update is still in flight (its gradient all-reduce runs on the collective library's stream): this batch's
+            # features need neither D nor its gradients, so they are enqueued first and the collective finishes under them
+            if feats is None and (pre is None or pre.get('feats') is None):
+                feats = self.features(clean_wav, noise_wav, lengths)
+            self._flush_d()
         L = 256 * (clean_wav.shape[1] // 256)              # length of the resynthesised signal (audio_util.py:76-110)
         start = torch.cuda.Event()
         start.record(main)
@@ -724,7 +753,7 @@ class GanTrainer:
         for v in cols.values():
             v.record_stream(main)
         tgt = torch.stack([cols[m] for m in self.metrics], dim=1)
-        ld = self._d_finish(score, tgt)
+        ld = self._d_finish(score, tgt, defer=True)
         if torch.cuda.is_current_stream_capturing():
             self._join_side_streams(main)                  # a captured step must end with every forked stream joined back
         return lg, ld, tgt
@@ -947,6 +976,7 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- checkpoints (train_nele.py:272-277)
     def save_checkpoint(self, path):
+        self._flush_d()
         sd = {'enhance-model': self.G.state_dict(), 'intel-model': self.D.state_dict()}
         if self.D_Qua is not None:
             sd['quality-model'] = self.D_Qua.state_dict()

@@ -41,3 +41,15 @@ def test_bench_weak_scaling_when_a_per_gpu_batch_is_given_and_single_rank_needs_
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = _run(['--gpus', '4', '--dry-run'], {'RANK': '0', 'WORLD_SIZE': '2', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_bench_gpus8_dry_run_covers_configs3_and_configs4_sharding():
+    """BASELINE configs[3] (1024 utterances over 8 ranks) and configs[4] (10 000 files over 8 ranks) as the launcher + sharding + collectives
+    of an 8-rank job on CPU: 128 utterances per rank, file shards of 1250 that cover the list exactly."""
+    r = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['scaling'] == 'strong'
+    assert out['config']['global_batch'] == 1024 and out['shard_sum'] == 1024 and out['shard_rank0'] == [0, 128]
+    c4 = out['configs4']
+    assert c4['files_sharded'] == 10000 and c4['shard_rank0'] == [0, 1250] and c4['batches_of_128_all_ranks'] == 8 * 10

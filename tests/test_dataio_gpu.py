@@ -126,3 +126,35 @@ def test_generated_samples_through_files_give_the_in_memory_targets(tmp_path):
     din = tr.d_inputs(enh, f['noise_band'], f['clean_band'])                 # packed [B, 64, T, 4]
     np.testing.assert_allclose(x3.permute(1, 2, 0).cpu().numpy(), din[2, :, :, :3].float().cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert 'EPOCH:7' in tr.validation_log_line(siib, [0.0], estoi, 7)
+
+
+def test_file_batches_prefetching_loader(tree):
+    """dataio.FileBatches: the corpus on disk as run_epoch's batch dicts - threaded decode, pinned staging, asynchronous upload, batches
+    decoded ahead, re-decoded after eviction (the reference re-reads its files in every stage, dataloader.py:30-42).  Contents equal
+    plain loads of the same files, in list order, whatever the access pattern."""
+    from nele_gan_amd import dataio
+    clean_root, noise_root, _ = tree
+    files = [clean_root + 'Train.wav', clean_root + 'Test.wav', clean_root + 'Train.wav', clean_root + 'Test.wav', clean_root + 'Train.wav']
+    fb = dataio.FileBatches(files, noise_root, batch=2, workers=3, ahead=1, keep=1, pad_to=4096, drc_path=clean_root)
+    assert len(fb) == 3
+
+    def check(b, idx):
+        assert b['names'] == [files[i].split('/')[-1] for i in idx]
+        assert b['clean'].shape == b['noise'].shape and b['clean'].shape[1] % 4096 == 0 and b['clean'].is_cuda
+        for r, i in enumerate(idx):
+            c, _ = dataio.load(files[i])
+            n, _ = dataio.load(noise_root + files[i].split('/')[-1])
+            m = min(len(c), len(n))
+            assert int(b['lengths'][r]) == m and int(b['drc_lengths'][r]) == len(c)
+            np.testing.assert_array_equal(b['clean'][r, :m].cpu().numpy(), c[:m])
+            np.testing.assert_array_equal(b['noise'][r, :m].cpu().numpy(), n[:m])
+            np.testing.assert_array_equal(b['drc'][r, :len(c)].cpu().numpy(), c)
+            assert not b['clean'][r, m:].any() and not b['noise'][r, m:].any()
+
+    for g, idx in ((0, [0, 1]), (1, [2, 3]), (2, [4]), (0, [0, 1]), (2, [4]), (-1, [4])):     # second pass and random access: re-decoded after eviction
+        check(fb[g], idx)
+    assert [b['names'] for b in fb] == [['Train.wav', 'Test.wav'], ['Train.wav', 'Test.wav'], ['Train.wav']]
+    assert fb.decoded_files >= 9
+    with pytest.raises(IndexError):
+        fb[3]
+    fb.close()

@@ -24,6 +24,8 @@ def _bare_trainer():
     tr.world = 1
     tr.pcm16 = True
     tr._status = {}
+    tr._pending_d = None
+    tr.overlap_allreduce = True
     return tr
 
 
@@ -326,3 +328,142 @@ def test_mixed_quality_targets_across_ranks_raise_on_every_rank_world2():
     out = mgr.dict()
     mp.spawn(_dp_mixed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert 'some ranks carry quality targets' in out[0] and 'some ranks carry quality targets' in out[1]
+
+
+# ------------------------------------------------------------------------------------------ world 4 and 8: collective ORDER per rank
+def _dp_worker_n(rank, world, port, out):
+    """d_epoch + two G-steps on `world` ranks with ragged shards (the last ranks hold fewer items, one rank holds a different batch size),
+    every torch.distributed collective logged: a rank whose sequence differs from the others' is the realistic multi-GPU failure (a hang in
+    the next collective), and it cannot be seen on one GPU."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import random
+    from nele_gan_amd import dist as nd
+    from nele_gan_amd.train_nele import GanTrainer
+    log = []
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, **kw):
+        log.append(('all_reduce', int(t.numel()), str(op)))
+        return real_ar(t, op=op, **kw)
+
+    def broadcast(t, src, **kw):
+        log.append(('broadcast', int(t.numel()), int(src)))
+        return real_bc(t, src, **kw)
+    dist.all_reduce, dist.broadcast = all_reduce, broadcast
+    tr = _bare_trainer()
+    tr.world = world
+    tr.G, tr.D = _TinyD(), _TinyD()
+    tr.optimizer_g, tr.optimizer_d = _Sgd(tr.G), _Sgd(tr.D)
+    tr.MSELoss = torch.nn.MSELoss()
+    orig_allreduce = tr._allreduce_grads
+
+    def allreduce(module, weight=None):
+        module.collect()
+        orig_allreduce(module, weight)
+    tr._allreduce_grads = allreduce
+    random.seed(100 + rank)
+    rs = np.random.RandomState(7)
+    n_items = 4 * world + 5                                # world 8: shards of 5, 5, 5, 5, 5, 4, 4, 4 -> 3 / 2 chunks of two
+    Ts = [30 + 10 * (i % 3) for i in range(n_items)]
+    items = [(torch.from_numpy(rs.rand(64, T, 4).astype(np.float32)), torch.tensor([float(rs.rand())])) for T in Ts]
+    lo, hi = nd.shard_range(len(items))
+    tr.history = [items[i] for i in range(lo, hi)] * 8
+    tr.d_epoch(items[lo:hi], batch=2)
+    # the G-step loop of run_epoch on ragged batch counts: ranks below world / 2 hold two batches, the others one
+    nb = 2 if rank < world // 2 else 1
+    n_g = nd.allreduce_max_int(nb)
+    for i in range(n_g):
+        if i < nb:
+            tr.optimizer_g.zero_grad()
+            x = torch.from_numpy(rs.rand(2 + rank % 2, 1, 30, 64).astype(np.float32))
+            loss = tr.MSELoss(tr.G.forward_packed(x), torch.ones(x.shape[0], 1))
+            tr.D.advance_power_iteration()             # stands for D's training-mode forward pass inside a real G-step
+            loss.backward()
+            tr._allreduce_grads(tr.G, x.shape[0])
+            tr.optimizer_g.step()
+        else:
+            GanTrainer.g_step(tr, None, None, weight=0)   # the product's empty step: joins the collective, advances D's u / v
+    out[rank] = {'log': log, 'd': tr.D.flat_parameters().flat.numpy().copy(), 'g': tr.G.flat_parameters().flat.numpy().copy(),
+                 'ds': tr.optimizer_d.steps, 'gs': tr.optimizer_g.steps, 'sn': tr.D.sn_steps, 'shard': (lo, hi)}
+    dist.all_reduce, dist.broadcast = real_ar, real_bc
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_every_rank_issues_the_same_collectives_in_the_same_order(world):
+    """BASELINE configs[3] runs on 8 ranks; the builder's and the driver's boxes have one GPU.  What can be checked without a second GPU:
+    on ragged shards (different item counts, batch sizes and chunk counts per rank) every rank of a 4- and an 8-rank gloo job issues the
+    same sequence of collectives (kind, payload size, reduce op), takes the same number of optimiser steps, advances the spectral-norm
+    iteration as often, and ends with bit-identical replicas."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker_n, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0 = out[0]
+    assert len(r0['log']) > 10
+    shards = sorted(out[r]['shard'] for r in range(world))
+    assert shards[0][0] == 0 and all(shards[i][1] == shards[i + 1][0] for i in range(world - 1)) and shards[-1][1] == 4 * world + 5
+    assert len({s[1] - s[0] for s in shards}) == 2                                # ragged on purpose
+    for r in range(1, world):
+        assert out[r]['log'] == r0['log'], 'rank %d issued other collectives than rank 0' % r
+        assert out[r]['ds'] == r0['ds'] and out[r]['gs'] == r0['gs'] == 2 and out[r]['sn'] == r0['sn']
+        np.testing.assert_array_equal(out[r]['d'], r0['d'])
+        np.testing.assert_array_equal(out[r]['g'], r0['g'])
+
+
+# ------------------------------------------------------------------------------------------ deferred D update (overlap_allreduce)
+def _dp_defer_worker(rank, world, port, out):
+    """The canonical step ends by STARTING the all-reduce of D's gradients (async) and leaves wait + Adam-D to whatever touches D next
+    (GanTrainer._flush_d).  Same weights as the synchronous form, the step counter advances at the flush, and every entry point that reads
+    or writes D flushes first."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nele_gan_amd.train_nele import GanTrainer
+    res = {}
+    for mode in ('sync', 'defer'):
+        tr = _bare_trainer()
+        tr.world = world
+        tr.D = _TinyD()
+        tr.optimizer_d = _Sgd(tr.D)
+        tr.MSELoss = torch.nn.MSELoss()
+        orig = tr._allreduce_grads
+
+        def allreduce(module, weight=None, _o=orig):
+            module.collect()
+            _o(module, weight)
+        tr._allreduce_grads = allreduce
+        rs = np.random.RandomState(3 + rank)
+        trace = []
+        for k in range(3):
+            x = torch.from_numpy(rs.rand(2, 64, 30, 4).astype(np.float32))
+            tgt = torch.from_numpy(rs.rand(2, 1).astype(np.float32))
+            tr.optimizer_d.zero_grad()
+            score = tr.D.forward_packed(x)
+            if mode == 'defer':
+                loss = tr.MSELoss(score, tgt)
+                loss.backward()
+                tr.D.collect()                                          # (the stub keeps its gradient outside the flat bucket until asked)
+                tr._pending_d = __import__('nele_gan_amd.dist', fromlist=['x']).PendingMean(tr.D.flat_parameters().grad)
+                trace.append((tr.step_d, tr.optimizer_d.steps))         # nothing applied yet
+                if k == 1:
+                    tr.check_status = GanTrainer.check_status.__get__(tr)   # any reader of D flushes: here through the next loop turn
+                tr._flush_d()
+            else:
+                tr._d_finish(score, tgt)
+            trace.append((tr.step_d, tr.optimizer_d.steps))
+        res[mode] = (tr.D.flat_parameters().flat.numpy().copy(), trace)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_deferred_d_update_equals_the_synchronous_one_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_defer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        np.testing.assert_array_equal(out[r]['sync'][0], out[r]['defer'][0])
+        assert out[r]['sync'][1] == [(1, 1), (2, 2), (3, 3)]
+        assert out[r]['defer'][1] == [(0, 0), (1, 1), (1, 1), (2, 2), (2, 2), (3, 3)]
+    np.testing.assert_array_equal(out[0]['defer'][0], out[1]['defer'][0])

@@ -225,3 +225,30 @@ def test_haspi_dither_per_utterance_id_vs_oracle_and_batch_independent():
     _, _, tg3 = tr3.canonical_step(cw, nw, utt_ids=ids)
     _, _, tg4 = tr4.canonical_step(cw, nw)
     assert bool(torch.isfinite(tg3).all()) and float((tg3 - tg4).abs().max()) > 0
+
+
+def test_adam_after_a_masked_step_matches_torch_adam_that_never_saw_it():
+    """nele_adam_step_guarded skips an update whose gradient is not finite; the bias correction of the following updates counts the updates
+    that happened (torch.optim.Adam's `step` state), not the calls (round-4 verdict item 8: the masked call used to be counted)."""
+    from nele_gan_amd import model as M
+    from nele_gan_amd.optim import Adam
+    torch.manual_seed(0)
+    D = M.Discriminator().cuda()
+    opt = Adam(D, lr=2.5e-4)
+    fp = D.flat_parameters()
+    ref_p = torch.nn.Parameter(fp.flat.detach().clone())
+    ref = torch.optim.Adam([ref_p], lr=2.5e-4)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    grads = [torch.randn(fp.flat.numel(), device='cuda', generator=g) * 0.1 for _ in range(5)]
+    for k, gr in enumerate(grads):
+        bad = k in (1, 3)
+        fp.grad.copy_(gr)
+        if bad:
+            fp.grad[123] = float('inf')
+        opt.step()
+        if not bad:
+            ref_p.grad = gr.clone()
+            ref.step()
+    assert opt.skipped_steps() == 2 and opt.step_count == 5
+    torch.testing.assert_close(fp.flat, ref_p.detach(), rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(opt.m, ref.state[ref_p]['exp_avg'], rtol=1e-5, atol=1e-7)        # (fused multiply-adds against torch's separate ops)
