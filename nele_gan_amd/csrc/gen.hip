@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, float* __restrict__ dY,
                                                       float* __restrict__ dgain_part, float* __restrict__ dbias_part, int T, int C, int pade,
-                                                      float slope) {
+                                                      float slope, __bf16* __restrict__ dY16) {
     __shared__ double ds[CLN_MAX_T], dq[CLN_MAX_T];
     const int b = blockIdx.y, tid = threadIdx.x, t0 = blockIdx.x * CLN_FR;
     for (int t = tid; t < T; t += 256) {
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
     const float* y = Y + ((size_t)b * T + t0) * C;
     const float* da = dAct + ((size_t)b * T + t0) * C;
     float* o = dY + ((size_t)b * (T + pade) + t0) * C;
+    __bf16* o16 = dY16 ? dY16 + ((size_t)b * (T + pade) + t0) * C : nullptr;       // the same gradient as bf16: the data-gradient convolution's operand
     const size_t prow = (size_t)b * gridDim.x + blockIdx.x;
     for (int c = tid; c < C; c += 256) {
         const float g = gain[c], bs = bias[c];
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
             const float dx = da[(size_t)f * C + c] * (x > 0.f ? 1.f : slope);
             dg += (double)dx * (double)xh;
             db += (double)dx;
-            o[(size_t)f * C + c] = dx * g * r + (float)ds[t] + 2.f * yy * (float)dq[t];
+            const float dyv = dx * g * r + (float)ds[t] + 2.f * yy * (float)dq[t];
+            o[(size_t)f * C + c] = dyv;
+            if (o16) o16[(size_t)f * C + c] = (__bf16)dyv;
         }
         dgain_part[prow * C + c] = (float)dg;
         dbias_part[prow * C + c] = (float)db;
@@ -380,7 +383,7 @@ extern "C" int nele_cln_fwd(const float* Y, const float* gain, const float* bias
 }
 
 extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
-                            const float* rstd, float* dY, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
+                            const float* rstd, float* dY, void* dY16, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
                             int pade, float slope, void* stream) {
     NELE_CHECK_ARG(dAct && Y && gain && bias && mean && rstd && dY && dgain_part && dbias_part && scratch && B > 0,
                    "nele_cln_bwd: bad arguments");
@@ -388,7 +391,7 @@ extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(cln_bwd_stats_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, dAct, Y, gain, bias, mean, rstd, scratch, T, C, slope);
     hipLaunchKernelGGL(cln_bwd_kernel, dim3((T + CLN_FR - 1) / CLN_FR, B), dim3(256), 0, s, dAct, Y, scratch, gain, bias, mean, rstd, dY,
-                       dgain_part, dbias_part, T, C, pade, slope);
+                       dgain_part, dbias_part, T, C, pade, slope, (__bf16*)dY16);
     NELE_CHECK_LAUNCH("nele_cln_bwd");
     return NELE_OK;
 }

@@ -244,6 +244,7 @@ class _GBuffers:
         self.need_f32()
         B, T, dev = self.B, self.T, self.dev
         self.dY = [_zeros((B, T + k - 1, cout), dev) for (cin, cout, k) in _G_LAYERS]   # END-padded
+        self.dY16 = None                                   # bf16 copies for the fused-path data gradient (need_dgrad16)
         self.dA = [_empty((B, T, cin), dev) for (cin, cout, k) in _G_LAYERS]              # grad wrt conv input (index l: input of layer l)
         self.da5 = _empty((B, T, 64), dev)
         self.do2 = _empty((B, T, 64), dev)
@@ -259,6 +260,12 @@ class _GBuffers:
                   [ops.wgrad_workspace_floats(B, 64, self.gwfc)])
         self.ws = _empty((nws,), dev)
         self._bwd = True
+
+    def need_dgrad16(self):
+        """END-padded bf16 output gradients [B][T+K-1][Cout]: what nele_glayer16_conv multiplies with the flipped weights"""
+        if self.dY16 is None:
+            self.dY16 = [torch.zeros((self.B, self.T + k - 1, cout), dtype=torch.bfloat16, device=self.dev) if l > 0 else None
+                         for l, (cin, cout, k) in enumerate(_G_LAYERS)]
 
 
 class _GFn(torch.autograd.Function):
@@ -386,6 +393,10 @@ class Generator_Conv1D_cLN(nn.Module):
                     for l, (cin, cout, k) in enumerate(_G_LAYERS):
                         gj += [wf[l].data_ptr(), self._wgl[0][l].data_ptr()]
                         hj += [cout, cin, k]
+                    for l, (cin, cout, k) in enumerate(_G_LAYERS):       # flipped layouts [cin][k * cout]: the data gradients of layers 1 .. 5
+                        if l > 0:
+                            gj += [wb[l].data_ptr(), self._wgl[1][l].data_ptr()]
+                            hj += [cin, cout, k]
                     self._gljobs = (ck, (c_void_p * len(gj))(*gj), (ctypes.c_int * len(hj))(*hj), len(hj) // 3)
                 _, gja, hja, ngj = self._gljobs
                 call('nele_glayer16_weight_prep_batch', gja, hja, ngj, stream())
@@ -513,19 +524,22 @@ class Generator_Conv1D_cLN(nn.Module):
             if self._wstream is None:
                 self._wstream = ops.side_stream(dmask.device)
             wst = self._wstream
-        pkey = ('bwd', self.precision, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr())
+        fused = self.precision == 'bf16' and self.fused and self.fused_ok
+        if fused:
+            bf.need_dgrad16()
+        pkey = ('bwd', self.precision, fused, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr())
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
             plan.streams[0] = stream()
             call('nele_gen_bwd', plan.handle, ptr(dmask), ptr(mask), plan.streams, len(plan.streams))
         elif ops.plans_enabled():
             with _lib.recording([ops.rng(dmask), ops.rng(mask)]) as rec:
-                self._backward_live(dmask, mask, bf, wst)
+                self._backward_live(dmask, mask, bf, wst, fused)
             bf.plans[pkey] = rec.finish()
         else:
-            self._backward_live(dmask, mask, bf, wst)
+            self._backward_live(dmask, mask, bf, wst, fused)
 
-    def _backward_live(self, dmask, mask, bf, wst):
+    def _backward_live(self, dmask, mask, bf, wst, fused=False):
         B, T = bf.B, bf.T
         # data-gradient chain on the current stream, weight gradients on a second stream beside it (see _DiscriminatorBase)
         main = torch.cuda.current_stream()
@@ -554,12 +568,17 @@ class Generator_Conv1D_cLN(nn.Module):
         for l in range(len(_G_LAYERS) - 1, -1, -1):
             cin, cout, k = _G_LAYERS[l]
             seq = self.convolutions[l]
+            d16 = bf.dY16[l] if (fused and l > 0) else None
             call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
-                 ptr(bf.dY[l]), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
+                 ptr(bf.dY[l]), ptr(d16), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
             call('nele_colsum2', ptr(bf.gpart), ptr(seq[2].gain0.grad), ptr(bf.bpart), ptr(seq[2].bias0.grad), B * bf.nchunks, cout, 1, stream())
             wgrad(bf.inp[l], bf.dY[l], cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=b16w)
             if l > 0:
-                self._gemm(bf.dY[l], l, True, None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
+                if fused:
+                    # data gradient = the layer kernel's plain-convolution form over the bf16 output gradient with the flipped weights
+                    call('nele_glayer16_conv', ptr(d16), ptr(self._wgl[1][l]), ptr(bf.dA[l]), B, T, cout, cin, k, stream())
+                else:
+                    self._gemm(bf.dY[l], l, True, None, None, bf.dA[l], B, cin, EPI_NONE, bf.gb[l])
                 dact = bf.dA[l]
         if wst is not None:
             ops.hand_over(ev, wst, main)

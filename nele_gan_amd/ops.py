@@ -39,7 +39,7 @@ _SIGS = {
     'nele_glayer16_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_glayer16_conv': [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'nele_cln_fwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
-    'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    'nele_cln_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
     'nele_cln_chunks': [c_int],
     'nele_colsum': [_P, c_int, c_int, _P, c_int, _P],
     'nele_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
