@@ -36,7 +36,7 @@ F64_PEAK_TFLOPS = 78.6            # MI355X_MICROARCH.md: float64, vector FMA and
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
-PROFILE_ROUND = 'r04'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
+PROFILE_ROUND = 'r05'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
 
 
 def csrc_sha():
@@ -384,21 +384,24 @@ def epoch_from_files(a, n_utt=256, batch=64):
         tr.D.precision = tr.G.precision = a.precision
         nthreads = min(32, os.cpu_count() or 8)
         fb = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=2)   # keep < batches: every pass over the list decodes again
-        tr.run_epoch(2, fb, (), d_batch=batch)                                # warm-up: buffer sets / plans of the padded shapes
+        for ep in (2, 3, 4):                                                  # warm-up: buffer sets / plans of the padded D shapes (shuffled chunks + replay)
+            tr.run_epoch(ep, fb, (), d_batch=batch)
         torch.cuda.synchronize()
         n0 = fb.decoded_files
         t0 = time.perf_counter()
-        res = tr.run_epoch(3, fb, (), d_batch=batch)
+        for ep in (5, 6):
+            res = tr.run_epoch(ep, fb, (), d_batch=batch)
         torch.cuda.synchronize()
-        dt_files = time.perf_counter() - t0
-        decoded = fb.decoded_files - n0
+        dt_files = (time.perf_counter() - t0) / 2
+        decoded = (fb.decoded_files - n0) // 2
         fbm = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=0, keep=len(fb) + 1)
         mem = [dict(fbm[i]) for i in range(len(fbm))]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr.run_epoch(4, mem, (), d_batch=batch)
+        for ep in (7, 8):
+            tr.run_epoch(ep, mem, (), d_batch=batch)
         torch.cuda.synchronize()
-        dt_mem = time.perf_counter() - t0
+        dt_mem = (time.perf_counter() - t0) / 2
         fb2 = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=1)
         for b in fb2:                                                       # first pass: the pinned staging buffers are allocated (milliseconds each)
             pass
@@ -732,7 +735,7 @@ def main():
             out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12, tr)
             # L = 63 871: no multiple of SIIB's 200-sample hop (nor of 100), like any real file - nothing repeats in the replicated signal,
             # so neither the frame-periodic shortcut nor the rank-deficient-component cut (deviation (i)) applies: this is the
-            # workload the 1e-4 SIIB parity claim holds on
+            # workload the 1e-4 SIIB claim against the build's oracle (parity with pysiib: unpinned) holds on
             out['nonperiodic'] = companion(a, a.metrics, a.batch, 63871, 4, tr)
             # the parity mode (float32 MFMA operands: what every golden-vector test runs in) on BASELINE configs[1]'s shape and on the headline's
             out['configs1_f32'] = companion(a, 'siib&estoi', 32, 64000, 8, tr, precision='f32')
@@ -756,7 +759,7 @@ def main():
             out['siib_parity_note'] = ('at L % 200 == 0 (the headline length 64 000) the replicated signal is exactly frame-periodic and the clean '
                                        'covariance is rank deficient: this build (oracle and kernels) drops components with eigenvalue <= 1e-10 max, '
                                        'the reference (pysiib) scores them from rounding noise - 1 % .. 23 % higher raw SIIB on the bench utterances '
-                                       '(tests/test_oracle_metrics.py, DESIGN 2); the 1e-4 SIIB claim holds at lengths that are no multiple of 100 '
+                                       '(tests/test_oracle_metrics.py, DESIGN 2); the 1e-4 SIIB claim - against the build\'s oracle, parity with pysiib being unpinned - holds at lengths that are no multiple of 100 '
                                        '(`nonperiodic`, L = 63 871)')
     ee = None
     if a.epoch_equivalent > 0:           # every rank takes part (g_step / d_step all-reduce when world > 1)

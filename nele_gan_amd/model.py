@@ -157,7 +157,7 @@ def _empty(shape, dev):
 _G_LAYERS = [(128, 256, 5), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 256, 7), (256, 64, 5)]
 
 
-MAX_BUFFER_SHAPES = int(os.environ.get('NELE_MAX_BUFFER_SHAPES', '6'))
+MAX_BUFFER_SHAPES = int(os.environ.get('NELE_MAX_BUFFER_SHAPES', '16'))   # (a corpus of files of many lengths: D batches of ~18 padded shapes; 288 GB of HBM)
 
 
 def _lru_get(cache, key, make):

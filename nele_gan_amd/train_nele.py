@@ -765,7 +765,7 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
     @staticmethod
-    def _padded_chunks(lst, batch, round_to=8):
+    def _padded_chunks(lst, batch, round_to=16):
         """Shuffled sample list -> batches of at most ``batch`` items in list order.  The reference trains D at batch 1 on utterances
         of any length (train_nele.py:349-367); here the items of a batch are zero-padded along the frame axis to the batch's longest
         (rounded up to a multiple of ``round_to`` so that few distinct buffer shapes occur) and carry their own frame counts, which

@@ -10,11 +10,11 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
-ROUND = sys.argv[6] if len(sys.argv) > 6 else 'r04'
+ROUND = sys.argv[6] if len(sys.argv) > 6 else 'r05'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 work = {'batch': int(sys.argv[2]), 'length': int(sys.argv[3]), 'metrics': sys.argv[4], 'precision': sys.argv[5]}
-WANT = ('conv_wgrad_dma_kernel<4, 11, 3>', 'conv_wgrad_dma_kernel<4, 11, 2>', 'conv_wgrad_dma_kernel<3, 13, 4>', 'conv_wgrad_dma_kernel<2, 4, 4>', 'conv_wgrad_dma_kernel<1, 1, 4>',
+WANT = ('glayer16_kernel<2, 8, 4, 0>', 'glayer16_kernel<2, 8, 4, 1>', 'glayer16_kernel<1, 4, 2, 0>', 'cln_bwd_kernel', 'conv_wgrad_dma_kernel<4, 11, 3>', 'conv_wgrad_dma_kernel<4, 11, 2>', 'conv_wgrad_dma_kernel<3, 13, 4>', 'conv_wgrad_dma_kernel<2, 4, 4>', 'conv_wgrad_dma_kernel<1, 1, 4>',
         'eigh_tridiag_cluster2_kernel', 'conv_wgrad_tile16_kernel<4, 7, false, false>', 'conv16_kernel<4, 4, false>', 'conv16_kernel<4, 4, true>', 'conv16_kernel<3, 4, true>', 'conv16_kernel<2, 4, true>', 'conv16_kernel<2, 8, true>', 'conv16_kernel<1, 8, true>', 'conv16_kernel<1, 8, false>', 'conv16_kernel<1, 4, true>',
         'conv_wgrad_tile16_kernel<4, 7, true, true>', 'conv_wgrad_tile16_kernel<3, 4, true, true>', 'conv_wgrad_tile16_kernel<2, 2, true, true>', 'conv_tile16_kernel<4, 8>', 'conv_tile16_kernel<3, 8>', 'conv_tile16_kernel<2, 8>', 'conv_tile16_kernel<3, 4>', 'conv_tile16_kernel<2, 4>', 'conv_tile16_kernel<1, 4>', 'conv_span16_kernel<3>', 'conv_wgrad_tile16_kernel<4, 7, true>', 'conv_wgrad_tile16_kernel<4, 7, false>', 'conv_wgrad_tile16_kernel<3, 4, false>',
         'haspi_gain_lp_sl_kernel', 'haspi_ihc_fir_kernel', 'haspi_ihc_fir9_kernel', 'haspi_mod_slide_kernel<0>', 'haspi_cep_kernel', 'haspi_resample_kernel', 'haspi_bank_tail_kernel<true>', 'haspi_bank_tail_kernel<false>',
