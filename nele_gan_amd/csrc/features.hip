@@ -482,17 +482,27 @@ __global__ __launch_bounds__(256) void gain_istft_kernel(const float* __restrict
 // ---- the same resynthesis, one WAVE per output hop with the inverse transform in registers (fft512_wave<true>): the lane that holds
 // X[64 m + lane] holds both halves it needs (frame fa's second half in v[m + 4].x, frame fb's first half in v[m].y), so nothing is
 // exchanged after the transform.  Bit-identical to gain_istft_kernel.  grid (ceil((T - 1) / (4 STW_NP)), B), block 256.
+// Round 5: a wave walks ISW_NH CONSECUTIVE hops, so the second frame of a hop (its spectrum bins and its 257 interpolated gains, each a
+// float64 square root) is the first frame of the next one and stays in the lane's registers; the interpolation weights
+// (float)(1 - j / size), (float)(j / size) of audio_util.py:100-106 come from a per-workgroup LDS table instead of a float64 division per
+// bin and frame.  Same products, same order: bit-identical.  grid (ceil((T - 1) / (4 ISW_NH)), B), block 256.
+#define ISW_NH 8
 __global__ __launch_bounds__(256) void gain_istft_wave_kernel(const float* __restrict__ alpha2, const float2* __restrict__ spec,
                                                               int T, float* __restrict__ wav, const int* __restrict__ tlens) {
     __shared__ double2 tw[256];
     __shared__ double hw[NELE_NFFT];
     __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
     __shared__ unsigned char bidx[NELE_NBINS + 3];        // band of every bin (the search of band_gain_sqrt, once per workgroup)
+    __shared__ float wlo[NELE_NBINS + 3], whi[NELE_NBINS + 3];
     const int b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     for (int k = tid; k < NELE_NBINS; k += 256) {
         int i = 0;
         while (i < NELE_NBANDS - 2 && c_gmt[i + 1] <= k) ++i;
         bidx[k] = (unsigned char)i;
+        const int size = c_gmt[i + 1] - c_gmt[i], jj = k - c_gmt[i];
+        const double frac = (double)jj / (double)size;
+        wlo[k] = (float)(1.0 - frac);
+        whi[k] = (float)frac;
     }
     {
         double sn, cs;
@@ -504,28 +514,48 @@ __global__ __launch_bounds__(256) void gain_istft_wave_kernel(const float* __res
     __syncthreads();
     double2* xw = xs[wv];
     float* out = wav + (size_t)b * (NELE_HOP * (T - 1));
-    for (int it = 0; it < STW_NP; ++it) {
-        const int fa = (blockIdx.x * STW_NP + it) * 4 + wv, fb = fa + 1;
+    const int Tb = tlens ? min(tlens[b], T) : T;
+    // gain of bin k of the frame whose band gains are a2 (interp_band_gain + np.sqrt, audio_util.py:93-110, 85)
+    auto gain = [&](const float* __restrict__ a2, int k) -> double {
+        if (!a2) return 1.0;                               // plain ISTFT (audio_util.py:60-65)
+        if (k <= 1) return sqrt(1e-4);
+        if (k == NELE_NBINS - 1) return sqrt(1e-2);
+        const int i = bidx[k];
+        const float g = wlo[k] * a2[i] + whi[k] * a2[i + 1];
+        return sqrt((double)g);
+    };
+    double gprev[5];
+    float2 xprev[5];
+    bool have = false;                                    // gprev / xprev hold frame fa of the coming hop
+    const int fa0 = (blockIdx.x * 4 + wv) * ISW_NH;
+    for (int it = 0; it < ISW_NH; ++it) {
+        const int fa = fa0 + it, fb = fa + 1;
         if (fa >= T - 1) break;
-        if (tlens && fb >= min(tlens[b], T)) {              // behind the end of a short row (its signal has 256 (T_b - 1) samples): zeros
+        if (fb >= Tb) {                                     // behind the end of a short row (its signal has 256 (T_b - 1) samples): zeros
 #pragma unroll
             for (int m = 0; m < 4; ++m) out[(size_t)NELE_HOP * fa + 64 * m + lane] = 0.f;
+            have = false;
             continue;
         }
-        const float* a2a = alpha2 ? alpha2 + ((size_t)b * T + fa) * NELE_NBANDS : nullptr;   // NULL: plain ISTFT (audio_util.py:60-65)
-        const float* a2b = a2a + NELE_NBANDS;
+        const float* a2a = alpha2 ? alpha2 + ((size_t)b * T + fa) * NELE_NBANDS : nullptr;
+        const float* a2b = alpha2 ? a2a + NELE_NBANDS : nullptr;
         const float2* Xa = spec + ((size_t)b * T + fa) * NELE_NBINS;
         const float2* Xb = Xa + NELE_NBINS;
-        for (int k = lane; k < NELE_NBINS; k += 64) {
-            const int bi_ = bidx[k];
-            const double ga = a2a ? band_gain_sqrt_at(a2a, k, bi_) : 1.0, gb = a2a ? band_gain_sqrt_at(a2b, k, bi_) : 1.0;
-            const float2 xa = Xa[k], xb = Xb[k];
-            double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
-            double br = gb * (double)xb.x, bi = gb * (double)xb.y;
-            if (k == 0 || k == NELE_NBINS - 1) { ai = 0.0; bi = 0.0; }  // c2r ignores these imaginary parts
-            xw[fftw_slot(fft512_brev(k))] = make_double2(ar - bi, ai + br);
-            if (k >= 1 && k <= 255) xw[fftw_slot(fft512_brev(NELE_NFFT - k))] = make_double2(ar + bi, br - ai);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int k = lane + 64 * q;
+            if (k < NELE_NBINS) {
+                const double ga = have ? gprev[q] : gain(a2a, k), gb = gain(a2b, k);
+                const float2 xa = have ? xprev[q] : Xa[k], xb = Xb[k];
+                gprev[q] = gb; xprev[q] = xb;
+                double ar = ga * (double)xa.x, ai = ga * (double)xa.y;
+                double br = gb * (double)xb.x, bi = gb * (double)xb.y;
+                if (k == 0 || k == NELE_NBINS - 1) { ai = 0.0; bi = 0.0; }  // c2r ignores these imaginary parts
+                xw[fftw_slot(fft512_brev(k))] = make_double2(ar - bi, ai + br);
+                if (k >= 1 && k <= 255) xw[fftw_slot(fft512_brev(NELE_NFFT - k))] = make_double2(ar + bi, br - ai);
+            }
         }
+        have = true;
         fftw_wave_sync();
         double2 v[8];
 #pragma unroll
@@ -682,7 +712,7 @@ extern "C" int nele_gain_istft_var(const float* alpha2, const void* spec, const 
     NELE_CHECK_ARG(T >= 2, "nele_gain_istft: T=%d < 2", T);
     const int wave_on = NELE_SWITCH_INT("NELE_STFT_WAVE", 1);                                // NELE_STFT_WAVE=0: the workgroup-per-hop kernel (A/B diagnostic)
     if (wave_on)
-        hipLaunchKernelGGL(gain_istft_wave_kernel, dim3((T - 1 + 4 * STW_NP - 1) / (4 * STW_NP), B), dim3(256), 0, as_stream(stream), alpha2,
+        hipLaunchKernelGGL(gain_istft_wave_kernel, dim3((T - 1 + 4 * ISW_NH - 1) / (4 * ISW_NH), B), dim3(256), 0, as_stream(stream), alpha2,
                            (const float2*)spec, T, wav, frames);
     else {
         NELE_AB_ONLY(hipLaunchKernelGGL(gain_istft_kernel, dim3(T - 1, B), dim3(256), 0, as_stream(stream), alpha2, (const float2*)spec, T, wav, frames);)
