@@ -43,11 +43,11 @@ struct SiibWs {
     double* lam;     // [B][420]
     double* part;    // [B][420][NTL][3]
     double* px;      // [B][7][NTL][16][256] projections of the clean signal in accumulator order (split mode: phase 3 -> phase 4)
-    double* lagp;    // [B][3][nseg][29][784] lag-product partials: pair 0 = (x, x), 1 = (y, y), 2 = (x, y)                     (lag path)
+    double* lagp;    // [B][3][SL_NSEG][29][784] lag-product partials: pair 0 = (x, x), 1 = (y, y), 2 = (x, y)                  (lag path)
     double* mu;      // [B][2][15][28] window means of the stacked rows                                                         (lag path)
     double* S2;      // [B][2][420][420] unscaled second-moment matrices of the stacked frames: Syy, sym(Sxy)                   (lag path)
     double* qpart;   // [B][420][14] partial quadratic forms u_k^T S u_k per column tile: 7 tiles of Syy, 7 of sym(Sxy)          (lag path)
-    int nseg;        // frame segments the lag products are split into (more workgroups at small batches)
+    int nseg;        // workgroup groups the SL_NSEG frame segments of the lag products are dealt to (1, 2 or 4: more workgroups at small batches)
     int NT, NA, NTL;
     int Bn;          // utterances in this call
     const int* lens; // [B] samples per utterance inside the padded [B][L] buffers, or NULL (every row has L samples)
@@ -966,6 +966,11 @@ __global__ __launch_bounds__(256) void siib_mu_kernel(SiibWs ws, int sig0) {
     }
 }
 
+// The lag products of an utterance are ALWAYS summed as SL_NSEG = 4 frame segments (boundaries from the utterance's own active-frame count),
+// each from zero, and combined as (s0 + s1) + (s2 + s3) by siib_assemble_kernel: how many workgroups share the segments (ws.nseg = 4, 2, 1 by
+// batch size) changes who computes a segment, not the association - an utterance's covariance, and so its SIIB score, does not depend on the
+// batch it is scored in.  (Until round 5 the segment boundaries followed ws.nseg: 1e-6 relative between batch-size classes.)
+#define SL_NSEG 4
 // L_ab partials.  grid (4, nseg, B), block 256: thread p = 256 blockIdx.x + tid < 784 owns the band pair (j1, j2) = (p / 28, p % 28)
 // and ND consecutive lags D0 .. D0 + ND - 1: b_j2[s + D0 .. s + D0 + ND - 1] lives in a ROTATING register window (slot = frame index
 // mod ND; the step loop is unrolled ND times so that every slot index is a compile-time constant), so a frame costs ND multiply-adds,
@@ -976,18 +981,16 @@ template <int SIGA, int SIGB, int D0, int ND>
 __global__ __launch_bounds__(256, (ND > 15 ? 2 : 4)) void siib_lag_kernel(SiibWs ws, int pair) {
     constexpr int CH = (SL_CH / ND) * ND;                    // frames per LDS chunk: whole window periods
     __shared__ double sa[CH][SB_J], sb[CH + ND - 1][SB_J];
-    const int b = blockIdx.z, seg = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+    const int b = blockIdx.z, tid = threadIdx.x, p = blockIdx.x * 256 + tid;
     const int na = ws.info[4 * b + 2];
     const int j1 = min(p, SB_J * SB_J - 1) / SB_J, j2 = min(p, SB_J * SB_J - 1) % SB_J;
-    const int per = ((na + ws.nseg - 1) / ws.nseg + CH - 1) / CH * CH;                   // frames per segment: whole chunks
-    const int s0 = seg * per, s1 = min(na, s0 + per);
+    const int per = ((na + SL_NSEG - 1) / SL_NSEG + CH - 1) / CH * CH;                   // frames per segment: whole chunks
+    const int spg = SL_NSEG / ws.nseg;                                                   // segments this workgroup walks, one after the other
     const double* A = ws.XL + ((size_t)b * 2 + SIGA) * SB_J * ws.NA;
     const double* Bm = ws.XL + ((size_t)b * 2 + SIGB) * SB_J * ws.NA;
     const double* ra = ws.rowstat + ((size_t)b * 2 + SIGA) * SB_J * 2;
     const double* rb = ws.rowstat + ((size_t)b * 2 + SIGB) * SB_J * 2;
     double acc[ND], w[ND];
-#pragma unroll
-    for (int d = 0; d < ND; ++d) { acc[d] = 0.0; w[d] = 0.0; }
     // Staging, software-pipelined (third session of round 3): a chunk's multiply-adds take 3 us, its staging loop - two dependent
     // global loads per element, 16 rounds - took 10 (PMC: the waves of this kernel waited 55 % of their time at two workgroups per
     // CU).  The raw values of chunk c + 1 are requested into registers before the multiply-adds of chunk c and stored (minus the row
@@ -1023,6 +1026,10 @@ __global__ __launch_bounds__(256, (ND > 15 ? 2 : 4)) void siib_lag_kernel(SiibWs
     // (only the 29-lag instantiation is pipelined: the 15-lag ones run four workgroups per CU at 98 registers and hide the staging behind
     //  each other - with the prefetch registers they drop to three and take 540 instead of 455 us)
     constexpr bool PIPE = ND > 15;
+    for (int seg = blockIdx.y * spg; seg < (int)(blockIdx.y + 1) * spg; ++seg) {
+    const int s0 = seg * per, s1 = min(na, s0 + per);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { acc[d] = 0.0; w[d] = 0.0; }
     if (PIPE && s0 < s1) fetch(s0);
     for (int c0 = s0; c0 < s1; c0 += CH) {
         __syncthreads();                                    // the previous chunk's reads of sa / sb are done (and rmean is visible)
@@ -1055,9 +1062,10 @@ __global__ __launch_bounds__(256, (ND > 15 ? 2 : 4)) void siib_lag_kernel(SiibWs
         }
     }
     if (p < SB_J * SB_J) {                                   // slot D + 14 of the 29 lag slots
-        double* out = ws.lagp + ((((size_t)b * 3 + pair) * ws.nseg + seg) * SL_ND + (D0 + 14)) * (SB_J * SB_J) + p;
+        double* out = ws.lagp + ((((size_t)b * 3 + pair) * SL_NSEG + seg) * SL_ND + (D0 + 14)) * (SB_J * SB_J) + p;
 #pragma unroll
         for (int d = 0; d < ND; ++d) out[(size_t)d * (SB_J * SB_J)] = acc[d];
+    }
     }
 }
 
@@ -1089,11 +1097,10 @@ __global__ __launch_bounds__(256) void siib_assemble_kernel(SiibWs ws) {
     for (int e = tid; e < 2 * SB_D; e += 256) mus[e / SB_D][e % SB_D] = ws.mu[(size_t)b * 2 * SB_D + e];
     __syncthreads();
     const double nc = (double)ncols, scale = 1.0 / (double)(ncols - 1);
-    auto lag = [&](int pair, int ja, int jb, int dd) {       // L_pair(ja, jb, dd), partials added in segment order
-        const double* lp = ws.lagp + (((size_t)b * 3 + pair) * ws.nseg * SL_ND + (dd + 14)) * (SB_J * SB_J) + ja * SB_J + jb;
-        double v = 0.0;
-        for (int sg = 0; sg < ws.nseg; ++sg) v += lp[(size_t)sg * SL_ND * (SB_J * SB_J)];
-        return v;
+    auto lag = [&](int pair, int ja, int jb, int dd) {       // L_pair(ja, jb, dd) = (s0 + s1) + (s2 + s3), whatever the batch size
+        const double* lp = ws.lagp + (((size_t)b * 3 + pair) * SL_NSEG * SL_ND + (dd + 14)) * (SB_J * SB_J) + ja * SB_J + jb;
+        const size_t st = (size_t)SL_ND * (SB_J * SB_J);
+        return (lp[0] + lp[st]) + (lp[2 * st] + lp[3 * st]);
     };
     for (int p = tid; p < SB_J * SB_J; p += 256) {
         const int j1 = p / SB_J, j2 = p - j1 * SB_J;
@@ -1313,7 +1320,7 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
     const int nseg = B >= 128 ? 1 : (B >= 48 ? 2 : 4);
     if (siib_lag_path()) {
         // the lag path needs neither the stacked frames nor the kept clean projections: Xs / px shrink to nothing
-        TAKE(lagp, double, (size_t)B * 3 * nseg * SL_ND * SB_J * SB_J);
+        TAKE(lagp, double, (size_t)B * 3 * SL_NSEG * SL_ND * SB_J * SB_J);
         TAKE(mu, double, (size_t)B * 2 * SB_D);
         TAKE(S2, double, (size_t)B * 2 * SB_D * SB_D);
         TAKE(qpart, double, (size_t)B * SB_D * 14);
