@@ -426,6 +426,52 @@ def epoch_from_files(a, n_utt=256, batch=64):
         torch.cuda.empty_cache()
 
 
+def inference_from_files(tr, n_utt=1024, batch=128):
+    """BASELINE configs[4] end to end on one GPU: inference.py:79-117 from wav files to wav files - a synthetic corpus of 8 s utterances
+    (clean + noise, PCM_16) on tmpfs, `inference.enhance_files` (threaded native decode into pinned rows, three batches in flight on the GPU,
+    threaded native PCM_16 writes) - the second pass over the whole list is timed (the first allocates the pinned staging buffers: tens of
+    milliseconds each)."""
+    import gc
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from nele_gan_amd import dataio, synth
+    from nele_gan_amd.inference import Enhancer, enhance_files
+    root = tempfile.mkdtemp(prefix='nele_infer_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        c, v = synth.batch(64, 128000, start=70000)
+        os.makedirs(root + '/Clean'); os.makedirs(root + '/Noise')
+        rs = np.random.RandomState(1)
+        files = []
+        for i in range(n_utt):
+            k, L = i % 64, int(rs.randint(112000, 128001))
+            dataio.write_wav_pcm16('%s/Clean/u%05d.wav' % (root, i), c[k, :L])
+            dataio.write_wav_pcm16('%s/Noise/u%05d.wav' % (root, i), v[(k + i // 64) % 64, :L])
+            files.append('%s/Clean/u%05d.wav' % (root, i))
+        enh = Enhancer(G=tr.G)
+        enh.G.precision = tr.G.precision
+        nthreads = min(32, os.cpu_count() or 8)
+        enhance_files(enh, files, root + '/Noise/', root + '/Warm', batch=batch, workers=nthreads)    # first pass: buffer sets, plans, pinned staging buffers
+        shutil.rmtree(root + '/Warm', ignore_errors=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = enhance_files(enh, files, root + '/Noise/', root + '/Enh', batch=batch, workers=nthreads)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tr.G.train()
+        nbytes = sum(os.path.getsize(f) for f in files) * 2 + sum(os.path.getsize(f) for f in out)
+        return {'value': n_utt / dt, 'unit': 'utterances/s', 'files': n_utt, 'utterance_seconds': '7 .. 8', 'batch': batch, 'host_threads': nthreads,
+                'wav_MB_per_s': nbytes / dt / 1e6, 'seconds': dt,
+                'path': 'wav files on tmpfs -> decode (C, threads) -> pinned -> GPU (3 batches in flight) -> pinned -> PCM_16 files (C, threads)'}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -731,6 +777,8 @@ def main():
             sys.stderr.write('stage ms: %s\n' % json.dumps({k: round(x, 3) for k, x in br.items()}))
         if a.inference > 0:
             out['inference'] = inference_rate(tr, min(a.batch, 128), a.inference, rank)
+            if world == 1 and a.companions:
+                out['inference_from_files'] = inference_from_files(tr)
         if world == 1 and a.companions:
             out['configs1'] = companion(a, 'siib&estoi', 32, 64000, 12, tr)
             # L = 63 871: no multiple of SIIB's 200-sample hop (nor of 100), like any real file - nothing repeats in the replicated signal,

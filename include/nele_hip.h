@@ -91,6 +91,10 @@ int nele_vec_add(float* dst, const float* src, long long n, void* stream);
  * float32 HOST memory (samples / 32768, zeros behind them); *n_out = samples, *sample_rate_out = rate.  No GPU work; a foreign-function call
  * runs it outside the host language's interpreter lock, so loader threads decode in parallel.  Other wav flavours: NELE_ERR_UNSUPPORTED. */
 int nele_wav_decode_pcm16(const char* path, float* out_host, long long cap, long long* n_out, int* sample_rate_out);
+/* ... and the writer (train_nele.py:198,313, inference.py:115 sf.write(..., 'PCM_16')): float32 HOST samples -> mono PCM_16 RIFF file.
+ * quantised = 0: lrintf(x * 32767) saturated, as libsndfile; != 0: the samples are values k / 32768 from nele_wav_post's PCM_16 emulation and
+ * are recovered exactly.  No GPU work; runs outside the host language's interpreter lock when called through a foreign-function interface. */
+int nele_wav_write_pcm16(const char* path, const float* wav_host, long long n, int sample_rate, int quantised);
 
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */
 

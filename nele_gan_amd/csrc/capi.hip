@@ -122,6 +122,34 @@ extern "C" int nele_wav_decode_pcm16(const char* path, float* out_host, long lon
     return NELE_OK;
 }
 
+// ... and the writer (train_nele.py:198,313, inference.py:115: sf.write(path, wav, 16000, 'PCM_16') -> libsndfile): float32 HOST samples ->
+// mono PCM_16 RIFF file.  quantised = 0: libsndfile's rule, lrintf(x * 32767) saturated (round half to even); quantised != 0: the samples
+// already went through the device-side PCM_16 emulation (values k / 32768, nele_wav_post): k is recovered exactly, nothing is rounded twice.
+extern "C" int nele_wav_write_pcm16(const char* path, const float* wav_host, long long n, int sample_rate, int quantised) {
+    if (!path || (!wav_host && n > 0) || n < 0 || n > 0x7fffff00LL / 2 || sample_rate <= 0)
+        return nele_set_error(NELE_ERR_INVALID_ARG, "nele_wav_write_pcm16: bad arguments");
+    const unsigned bytes = (unsigned)(2 * n);
+    unsigned char* buf = (unsigned char*)malloc(44 + (size_t)bytes);
+    if (!buf) return nele_set_error(NELE_ERR_HIP, "nele_wav_write_pcm16: out of host memory");
+    auto u32 = [&](int off, unsigned v) { buf[off] = v & 255; buf[off + 1] = (v >> 8) & 255; buf[off + 2] = (v >> 16) & 255; buf[off + 3] = (v >> 24) & 255; };
+    auto u16 = [&](int off, unsigned v) { buf[off] = v & 255; buf[off + 1] = (v >> 8) & 255; };
+    memcpy(buf, "RIFF", 4); u32(4, 36 + bytes); memcpy(buf + 8, "WAVEfmt ", 8); u32(16, 16); u16(20, 1); u16(22, 1);
+    u32(24, (unsigned)sample_rate); u32(28, (unsigned)sample_rate * 2); u16(32, 2); u16(34, 16); memcpy(buf + 36, "data", 4); u32(40, bytes);
+    short* out = reinterpret_cast<short*>(buf + 44);
+    const float scale = quantised ? 32768.0f : 32767.0f;
+    for (long long i = 0; i < n; ++i) {
+        float q = nearbyintf(wav_host[i] * scale);             // round half to even (the default rounding mode), as lrintf / numpy.rint
+        q = q < -32768.0f ? -32768.0f : (q > 32767.0f ? 32767.0f : q);
+        out[i] = (short)q;
+    }
+    FILE* f = fopen(path, "wb");
+    int st = NELE_OK;
+    if (!f || fwrite(buf, 1, 44 + (size_t)bytes, f) != 44 + (size_t)bytes) st = nele_set_error(NELE_ERR_INVALID_ARG, "nele_wav_write_pcm16: cannot write %s", path);
+    if (f) fclose(f);
+    free(buf);
+    return st;
+}
+
 bool nele_first_use_on_device(unsigned long long* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set the attribute again (idempotent)

@@ -115,6 +115,15 @@ def pcm16_quantise(wav):
     return np.clip(q, -32768, 32767).astype('<i2')
 
 
+def write_wav_pcm16_native(path, row, n, sr=fs, quantised=False):
+    """The same file through the library's C writer (nele_wav_write_pcm16): ``row`` a contiguous float32 numpy row (e.g. of a pinned staging
+    buffer), its first ``n`` samples.  Runs outside the interpreter lock - what the writer threads of inference.enhance_files call."""
+    import ctypes
+    st = _nele_lib.nele_wav_write_pcm16(path.encode(), ctypes.c_void_p(row.ctypes.data), int(n), int(sr), int(bool(quantised)))
+    if st != 0:
+        raise IOError(_nele_lib.nele_last_error_string().decode('utf-8', 'replace'))
+
+
 def write_wav_pcm16(path, wav, sr=fs, quantised=False):
     """sf.write(path, wav, sr, 'PCM_16').  ``quantised=True``: ``wav`` already went through the device-side PCM_16
     emulation (values k / 32768), so the samples are recovered exactly instead of being rounded a second time."""
@@ -254,6 +263,28 @@ def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
     return _read_batch('haspi', clean_root, noise_root, enhanced_list, True, drc=True)
 
 
+# ------------------------------------------------------------------------------------------------ pinned staging buffers
+# Page-locked host buffers cost milliseconds to allocate (tens for a 64 MB batch): they are pooled per shape for the life of the process and
+# shared by every loader / writer (FileBatches, inference.enhance_files).
+_PINNED = {}
+
+
+def pinned_get(shape):
+    import torch
+    lst = _PINNED.get(tuple(shape))
+    return lst.pop() if lst else torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+
+
+def pinned_put(t):
+    if t is not None:
+        _PINNED.setdefault(tuple(t.shape), []).append(t)
+
+
+def pinned_release():
+    """Drop the pooled buffers (they are re-created on demand)."""
+    _PINNED.clear()
+
+
 # ------------------------------------------------------------------------------------------------ batches from files, prefetched
 class FileBatches:
     """A corpus on disk as the sequence of batch dicts GanTrainer.run_epoch takes ({'clean', 'noise', 'lengths', 'names'[, 'drc',
@@ -268,10 +299,11 @@ class FileBatches:
         import concurrent.futures as cf
         self.files, self.noise_path, self.drc_path = list(file_list), noise_path, drc_path
         self.groups = [list(range(k, min(k + batch, len(self.files)))) for k in range(0, len(self.files), batch)]
-        self.pool = cf.ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self.workers = max(1, int(workers))
+        self.pool = cf.ThreadPoolExecutor(max_workers=self.workers)
         self.ahead, self.pad_to, self.keep, self.device = int(ahead), int(pad_to), int(keep), device
         self._pending, self._ready = {}, {}
-        self._pool_bufs = {}
+        self._bounds = {}
         self._copy = None
         self.decoded_files = 0
 
@@ -280,7 +312,10 @@ class FileBatches:
 
     def _bound(self, path):
         """upper bound of a file's samples from its size (exact for the 44-byte-header PCM_16 files the reference writes)"""
-        return max(1, (os.path.getsize(path) - 44 + 1) // 2)
+        b = self._bounds.get(path)
+        if b is None:
+            b = self._bounds[path] = max(1, (os.path.getsize(path) - 44 + 1) // 2)
+        return b
 
     def _decode_into(self, idx, rows):
         """decode file idx into its rows of the group's pinned buffers -> (samples clean/noise, samples drc, name)"""
@@ -305,9 +340,7 @@ class FileBatches:
     def _pinned(self, shape):
         """pinned staging buffer from a small pool (cudaHostAlloc per batch costs milliseconds); a buffer returns to the pool when the
         batch that used it leaves the cache"""
-        import torch
-        lst = self._pool_bufs.setdefault(tuple(shape), [])
-        return lst.pop() if lst else torch.empty(shape, dtype=torch.float32).pin_memory()
+        return pinned_get(shape)
 
     def _submit(self, g):
         if not (0 <= g < len(self.groups)) or g in self._pending or g in self._ready:
@@ -326,20 +359,27 @@ class FileBatches:
                 Ld = (Ld + self.pad_to - 1) // self.pad_to * self.pad_to
             hd = self._pinned((n, max(Ld, Lmax)))
         ac, an, ad = hc.numpy(), hn.numpy(), (hd.numpy() if hd is not None else None)
-        futs = [self.pool.submit(self._decode_into, i, [ac[r], an[r]] + ([ad[r]] if ad is not None else [])) for r, i in enumerate(idxs)]
+        # a task = a run of rows (submitting one task per file costs the submitting thread ~20 us each: more than the decode itself)
+        nt = max(1, min(self.workers, n))
+        per = (n + nt - 1) // nt
+
+        def run(r0):
+            return [self._decode_into(idxs[r], [ac[r], an[r]] + ([ad[r]] if ad is not None else [])) for r in range(r0, min(n, r0 + per))]
+        futs = [self.pool.submit(run, r0) for r0 in range(0, n, per)]
         self._pending[g] = (futs, hc, hn, hd)
 
     def _stage(self, g):
         import torch
         futs, hc, hn, hd = self._pending.pop(g)
-        res = [f.result() for f in futs]
+        res = [r for f in futs for r in f.result()]
         self.decoded_files += len(res)
         lens = np.asarray([r[0] for r in res], dtype=np.int32)
         if self._copy is None:
             self._copy = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self._copy):
             b = {'clean': hc.to(self.device, non_blocking=True), 'noise': hn.to(self.device, non_blocking=True),
-                 'lengths': torch.from_numpy(lens).pin_memory().to(self.device, non_blocking=True), 'names': [r[2] for r in res]}
+                 'lengths': torch.from_numpy(lens).pin_memory().to(self.device, non_blocking=True), 'names': [r[2] for r in res],
+                 'lengths_host': lens}
             if hd is not None:
                 dlens = np.asarray([r[1] for r in res], dtype=np.int32)
                 b['drc'] = hd.to(self.device, non_blocking=True)
@@ -351,8 +391,7 @@ class FileBatches:
             _, ev_old, bufs = self._ready.pop(next(iter(self._ready)))
             ev_old.synchronize()                                           # its upload is long done; the pinned buffers go back to the pool
             for t in bufs:
-                if t is not None:
-                    self._pool_bufs.setdefault(tuple(t.shape), []).append(t)
+                pinned_put(t)
 
     def __getitem__(self, g):
         import torch
@@ -377,7 +416,17 @@ class FileBatches:
             yield self[g]
 
     def close(self):
-        self.pool.shutdown(wait=False)
+        """Stop the decode threads and hand the staging buffers back to the process-wide pool."""
+        self.pool.shutdown(wait=True)
+        import torch
+        torch.cuda.synchronize()                                           # uploads still in flight read the pinned buffers
+        for _, _, bufs in self._ready.values():
+            for t in bufs:
+                pinned_put(t)
+        for _, hc, hn, hd in self._pending.values():
+            for t in (hc, hn, hd):
+                pinned_put(t)
+        self._ready, self._pending = {}, {}
 
 
 # ------------------------------------------------------------------------------------------------ datasets (dataloader.py)

@@ -112,25 +112,16 @@ class Enhancer:
                 done.synchronize()
 
 
-def _decode_pair(clean_path, noise_path):
-    from . import dataio
-    c, sr = dataio.load(clean_path)
-    assert sr == 16000                                                   # inference.py:85-88
-    n, sr = dataio.load(noise_path)
-    assert sr == 16000
-    m = min(len(c), len(n))
-    return c[:m], n[:m]
-
-
-def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=4,
+def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=8,
                   pad_to=4096):
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
     Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.
 
-    Host side (the reference: one file at a time, librosa.load + sf.write in the main process): wav decoding on ``workers`` threads
-    (numpy's frombuffer / astype release the GIL), batches padded to a multiple of ``pad_to`` samples (few distinct shapes: the
-    generator's activation buffers are cached per shape), staged through pinned host buffers with asynchronous copies in both
-    directions, ``inflight`` batches on the GPU at a time (enhance_stream); files are written while later batches run."""
+    Host side (the reference: one file at a time, librosa.load + sf.write in the main process): dataio.FileBatches decodes ``workers``
+    files at a time with the library's C reader straight into pinned staging rows (batches padded to a multiple of ``pad_to`` samples:
+    few distinct shapes, the generator's buffers are cached per shape) and uploads asynchronously, two batches ahead;
+    ``inflight`` batches are on the GPU at a time (enhance_stream); results come back through pinned buffers on a copy stream and are
+    written as PCM_16 by the same thread pool with the library's C writer while later batches run."""
     import concurrent.futures as cf
     import numpy as np
     from . import dataio
@@ -142,67 +133,54 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
         # batches of similar lengths waste less padding; the output list keeps the caller's order
         sizes = {i: os.path.getsize(file_list[i]) for i in mine}
         order = sorted(mine, key=lambda i: sizes[i])
-    groups = [order[k:k + batch] for k in range(0, len(order), batch)]
     dev = enhancer.device
+    fb = dataio.FileBatches([file_list[i] for i in order], noise_path, batch=batch, workers=workers, ahead=2, device=dev, pad_to=pad_to,
+                            keep=inflight + 2)
     written = {}
-    copy_in = torch.cuda.Stream(device=dev)
     copy_out = torch.cuda.Stream(device=dev)
     pool = cf.ThreadPoolExecutor(max_workers=max(1, int(workers)))
-
-    def decode(sel):
-        return [pool.submit(_decode_pair, file_list[i], noise_path + file_list[i].split('/')[-1]) for i in sel]
-
-    def stage(futs):
-        """decoded files -> (clean, noise, lengths) on the device through pinned buffers (asynchronous copy on its own stream)"""
-        pairs = [f.result() for f in futs]
-        lens = np.asarray([len(c) for c, _ in pairs], dtype=np.int32)
-        Lmax = int((int(lens.max()) + pad_to - 1) // pad_to * pad_to) if pad_to else int(lens.max())
-        hc = torch.zeros((len(pairs), Lmax), dtype=torch.float32).pin_memory()
-        hn = torch.zeros((len(pairs), Lmax), dtype=torch.float32).pin_memory()
-        for r, (c, n) in enumerate(pairs):
-            hc[r, :len(c)] = torch.from_numpy(c)
-            hn[r, :len(n)] = torch.from_numpy(n)
-        with torch.cuda.stream(copy_in):
-            dc = hc.to(dev, non_blocking=True)
-            dn = hn.to(dev, non_blocking=True)
-            dl = torch.from_numpy(lens).pin_memory().to(dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(copy_in)
-        return dc, dn, dl, ev, lens, (hc, hn)
+    meta, outq, writes = [], collections.deque(), []
 
     def batches():
-        nxt = decode(groups[0]) if groups else None
-        for g in range(len(groups)):
-            futs = nxt
-            nxt = decode(groups[g + 1]) if g + 1 < len(groups) else None   # the next group decodes while this one is staged and enqueued
-            dc, dn, dl, ev, lens, keep = stage(futs)
-            torch.cuda.current_stream(dev).wait_event(ev)
-            meta.append((groups[g], lens, keep))
-            yield dc, dn, dl
-
-    meta = []
-    outq = collections.deque()
+        for g in range(len(fb)):
+            b = fb[g]
+            meta.append((order[g * batch:(g + 1) * batch], b['lengths_host']))
+            yield b['clean'], b['noise'], b['lengths']
 
     def flush(block_all):
         while outq and (block_all or outq[0][1].query()):
             host, ev, sel, lens = outq.popleft()
             ev.synchronize()
             arr = host.numpy()
+            jobs = []
             for r, i in enumerate(sel):
                 name = file_list[i].split('/')[-1]
                 path = dataio.enhanced_name(output_path, name, epoch_tag)
-                dataio.write_wav_pcm16(path, arr[r, :256 * (int(lens[r]) // 256)], fs, quantised=True)
+                jobs.append((path, arr[r], 256 * (int(lens[r]) // 256)))
                 written[i] = path
+            nt = max(1, min(int(workers), len(jobs)))
+            per = (len(jobs) + nt - 1) // nt
+
+            def run(chunk):                                              # a task = a run of files (one task per file costs more to submit than to write)
+                for path, row, n in chunk:
+                    dataio.write_wav_pcm16_native(path, row, n, fs, True)
+            futs = [pool.submit(run, jobs[k:k + per]) for k in range(0, len(jobs), per)]
+            writes.append((futs, host))
+        while writes and (block_all or all(f.done() for f in writes[0][0])):
+            futs, host = writes.pop(0)
+            for f in futs:
+                f.result()                                               # re-raises a writer's error
+            dataio.pinned_put(host)                                     # the pinned buffer goes back to the pool
 
     try:
         for g, enh in enumerate(enhancer.enhance_stream(batches(), inflight=inflight, pcm16=True)):
-            sel, lens, _keep = meta[g]
+            sel, lens = meta[g]
             meta[g] = None
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(copy_out):
                 copy_out.wait_event(done)
-                host = torch.empty(enh.shape, dtype=torch.float32).pin_memory()
+                host = dataio.pinned_get(enh.shape)
                 host.copy_(enh, non_blocking=True)
                 enh.record_stream(copy_out)
                 ev = torch.cuda.Event()
@@ -212,4 +190,5 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
         flush(True)
     finally:
         pool.shutdown(wait=True)
+        fb.close()
     return [written[i] for i in mine]
