@@ -234,8 +234,9 @@ int nele_g_pack(const float* x, const float* y, float* out, int B, int T, int pa
 int nele_cln_chunks(int T);  /* frame chunks per utterance: rows of the partial buffers = B * nele_cln_chunks(T) */
 int nele_cln_fwd(const float* Y, const float* gain, const float* bias, float* out, float* mean, float* rstd, double* scratch,
                  int B, int T, int C, int pad, float slope, void* stream);   /* scratch: float64 [B][T][2] */
-/* Backward of the above: dAct [B][T][C] -> dY (rows 0..T-1 of the END-padded [B][T+pade][C]; dY16, may be NULL: the same values as
- * bf16 in a buffer of the same layout - the operand of nele_glayer16_conv's data gradient), gain/bias gradient partials
+/* Backward of the above: dAct [B][T][C] -> dY (rows 0..T-1 of the END-padded [B][T+pade][C]) and / or dY16 (the same values as bf16 in a
+ * buffer of the same layout: the operand of nele_glayer16_conv's data gradient and of nele_conv_wgrad_bf16_a16d16; either may be NULL,
+ * not both), gain/bias gradient partials
  * [B * nele_cln_chunks(T)][C] (reduce with nele_colsum). */
 int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
                  const float* rstd, float* dY, void* dY16, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,

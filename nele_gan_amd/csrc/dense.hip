@@ -1526,14 +1526,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile16_kernel(WgradTileArgs
         // a conv5 tile visit).  Rows / columns outside the input re-read the last valid ones: they only meet output positions outside
         // the output, whose dOut is staged as zero, and reduction columns >= seglen, which are never stored.
         if (A16) {
+            // (sliced problems - the generator's layers in bf16 mode, round 5: a position's 64-channel slice sits at position * ics + ic0)
             const int emax = max(vcols * g.C - 8, 0), himax = g.H - 1;
-            const __bf16* src0 = reinterpret_cast<const __bf16*>(p.A) + (((size_t)b * g.H) * g.W + wi0) * g.C;
+            const __bf16* src0 = reinterpret_cast<const __bf16*>(p.A) + (((size_t)b * g.H) * g.W + wi0) * p.ics + ic0;
             const int npc = (WT_TH * RS + 511) >> 9;
             for (int k = wave; k < npc; k += 4) {
                 const int ef = min(512 * k + 8 * lane, WT_TH * RS - 8);
-                const int r = (ef >= RS) + (ef >= 2 * RS) + (ef >= 3 * RS), e = ef - r * RS;
+                const int r = (ef >= RS) + (ef >= 2 * RS) + (ef >= 3 * RS), e = min(ef - r * RS, emax);
                 const int hi = min(ho0 + r + kh + g.ih0, himax);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (size_t)hi * g.W * g.C + min(e, emax)),
+                const int pos = e / g.C, within = e - pos * g.C;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + ((size_t)hi * g.W + pos) * p.ics + within),
                                                  (__attribute__((address_space(3))) void*)(halo + 512 * k), 16, 0, 0);
             }
         }
@@ -2487,7 +2489,7 @@ static int conv_wgrad_impl(const float* A, const float* dOut, float* workspace, 
     ConvGeom gt = p.g;                                     // geometry the tile kernel sees
     int Nt = N, subs_n = 1, subs_c = 1, Bt = M / (p.g.Hout * p.g.Wout);
     bool sliced = false;
-    if (bf16 && !d16 && wt_on && !wgrad_tile_eligible(M, N, p.g, KH, KW) && N % 64 == 0 && p.g.C % 64 == 0 && KW * p.g.C == p.g.seglen &&
+    if (bf16 && (!d16 || a16) && wt_on && !wgrad_tile_eligible(M, N, p.g, KH, KW) && N % 64 == 0 && p.g.C % 64 == 0 && KW * p.g.C == p.g.seglen &&
         KW * 4 <= 28 && p.g.Wout >= 32 && M % (p.g.Hout * p.g.Wout) == 0) {
         gt.C = 64; gt.seglen = KW * 64; gt.Ktot = KH * KW * 64;
         Nt = 64; subs_n = N / 64; subs_c = p.g.C / 64;

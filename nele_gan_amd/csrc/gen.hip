@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
     const int nfr = min(CLN_FR, T - t0);
     const float* y = Y + ((size_t)b * T + t0) * C;
     const float* da = dAct + ((size_t)b * T + t0) * C;
-    float* o = dY + ((size_t)b * (T + pade) + t0) * C;
+    float* o = dY ? dY + ((size_t)b * (T + pade) + t0) * C : nullptr;     // (either output may be absent, not both)
     __bf16* o16 = dY16 ? dY16 + ((size_t)b * (T + pade) + t0) * C : nullptr;       // the same gradient as bf16: the data-gradient convolution's operand
     const size_t prow = (size_t)b * gridDim.x + blockIdx.x;
     for (int c = tid; c < C; c += 256) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const float* __restrict__ 
             dg += (double)dx * (double)xh;
             db += (double)dx;
             const float dyv = dx * g * r + (float)ds[t] + 2.f * yy * (float)dq[t];
-            o[(size_t)f * C + c] = dyv;
+            if (o) o[(size_t)f * C + c] = dyv;
             if (o16) o16[(size_t)f * C + c] = (__bf16)dyv;
         }
         dgain_part[prow * C + c] = (float)dg;
@@ -385,7 +385,7 @@ extern "C" int nele_cln_fwd(const float* Y, const float* gain, const float* bias
 extern "C" int nele_cln_bwd(const float* dAct, const float* Y, const float* gain, const float* bias, const float* mean,
                             const float* rstd, float* dY, void* dY16, float* dgain_part, float* dbias_part, double* scratch, int B, int T, int C,
                             int pade, float slope, void* stream) {
-    NELE_CHECK_ARG(dAct && Y && gain && bias && mean && rstd && dY && dgain_part && dbias_part && scratch && B > 0,
+    NELE_CHECK_ARG(dAct && Y && gain && bias && mean && rstd && (dY || dY16) && dgain_part && dbias_part && scratch && B > 0,
                    "nele_cln_bwd: bad arguments");
     if (T > CLN_MAX_T) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_cln_bwd: T=%d > %d", T, CLN_MAX_T);
     hipStream_t s = as_stream(stream);

@@ -200,8 +200,11 @@ class _GBuffers:
         self.gfc = Geom(1, T, 64, 1, T, 1, 1, 1, T, 64)
         self.nchunks = int(ops._lib.lib.nele_cln_chunks(T))
         self._f32 = False
+        self._stats = False
         self._bwd = False
         self._b16 = False
+        self.dY = None
+        self.dY16 = None
         self.token = 0
         self.plans = {}                                    # recorded passes of this shape (_lib.Plan), dropped with the buffer set
         self.events = ops.Events()
@@ -222,29 +225,41 @@ class _GBuffers:
         self.carry = torch.zeros(max(32, int(ops._lib.lib.nele_glayer16_carry_bytes(B, T))), dtype=torch.uint8, device=dev)
         self._b16 = True
 
+    def need_stats(self):
+        """raw conv outputs [B][T][Cout] + per-frame statistics (what a backward pass reads)"""
+        if self._stats:
+            return
+        B, T, dev = self.B, self.T, self.dev
+        self.Y = [_empty((B, T, cout), dev) for (cin, cout, k) in _G_LAYERS]
+        self.mean = [_empty((B, T), dev) for _ in _G_LAYERS]
+        self.rstd = [_empty((B, T), dev) for _ in _G_LAYERS]
+        self.cln_scratch = torch.empty((B, T, 2), dtype=torch.float64, device=dev)
+        self._stats = True
+
     def need_f32(self):
-        """float32 tier: time-padded inputs of each conv [B][T+K-1][Cin], raw conv outputs [B][T][Cout], per-frame statistics"""
+        """float32 tier of the per-layer kernels: time-padded float32 inputs of each conv [B][T+K-1][Cin] (+ need_stats)"""
         if self._f32:
             return
+        self.need_stats()
         B, T, dev = self.B, self.T, self.dev
-        self.inp, self.Y, self.mean, self.rstd = [], [], [], []
-        for (cin, cout, k) in _G_LAYERS:
-            self.inp.append(_zeros((B, T + k - 1, cin), dev))
-            self.Y.append(_empty((B, T, cout), dev))
-            self.mean.append(_empty((B, T), dev))
-            self.rstd.append(_empty((B, T), dev))
+        self.inp = [_zeros((B, T + k - 1, cin), dev) for (cin, cout, k) in _G_LAYERS]
         # forward geometries: H=1 conv over the padded time axis
         self.gf = [Geom(1, T + k - 1, cin, 1, T, 1, k, 1, T, cout) for (cin, cout, k) in _G_LAYERS]
-        self.cln_scratch = torch.empty((B, T, 2), dtype=torch.float64, device=dev)
         self._f32 = True
 
-    def need_bwd(self):
+    def need_bwd(self, fused=False):
+        """fused (bf16 mode on the fused layer kernels): the convolution operands of the backward pass are the bf16 buffers - no float32
+        inputs, no float32 output gradients"""
+        if not fused and not self._f32:
+            self.need_f32()
+        if not fused and self.dY is None:
+            self.dY = [_zeros((self.B, self.T + k - 1, cout), self.dev) for (cin, cout, k) in _G_LAYERS]   # END-padded
+        if fused:
+            self.need_stats()
+            self.need_dgrad16()
         if self._bwd:
             return
-        self.need_f32()
         B, T, dev = self.B, self.T, self.dev
-        self.dY = [_zeros((B, T + k - 1, cout), dev) for (cin, cout, k) in _G_LAYERS]   # END-padded
-        self.dY16 = None                                   # bf16 copies for the fused-path data gradient (need_dgrad16)
         self.dA = [_empty((B, T, cin), dev) for (cin, cout, k) in _G_LAYERS]              # grad wrt conv input (index l: input of layer l)
         self.da5 = _empty((B, T, 64), dev)
         self.do2 = _empty((B, T, 64), dev)
@@ -264,8 +279,7 @@ class _GBuffers:
     def need_dgrad16(self):
         """END-padded bf16 output gradients [B][T+K-1][Cout]: what nele_glayer16_conv multiplies with the flipped weights"""
         if self.dY16 is None:
-            self.dY16 = [torch.zeros((self.B, self.T + k - 1, cout), dtype=torch.bfloat16, device=self.dev) if l > 0 else None
-                         for l, (cin, cout, k) in enumerate(_G_LAYERS)]
+            self.dY16 = [torch.zeros((self.B, self.T + k - 1, cout), dtype=torch.bfloat16, device=self.dev) for (cin, cout, k) in _G_LAYERS]
 
 
 class _GFn(torch.autograd.Function):
@@ -477,17 +491,15 @@ class Generator_Conv1D_cLN(nn.Module):
             # only for a backward pass
             bf.need_b16()
             if need_bwd:
-                bf.need_bwd()
+                bf.need_bwd(fused=True)
             call('nele_g_pack16', ptr(xs), ptr(ys), ptr(bf.inp16[0]), B, T, _G_LAYERS[0][2] - 1, stream())
-            if need_bwd:
-                call('nele_g_pack', ptr(xs), ptr(ys), ptr(bf.inp[0]), B, T, _G_LAYERS[0][2] - 1, stream())
             nl = len(_G_LAYERS)
             for l, (cin, cout, k) in enumerate(_G_LAYERS):
                 seq = self.convolutions[l]
                 last = l + 1 == nl
                 padn = 0 if last else _G_LAYERS[l + 1][2] - 1
                 out16 = None if last else bf.inp16[l + 1]
-                out32 = bf.a5 if last else (bf.inp[l + 1] if need_bwd else None)
+                out32 = bf.a5 if last else None              # (the Linear tail reads float32; every Conv1d operand is the bf16 buffer)
                 call('nele_glayer16_fwd', ptr(bf.inp16[l]), ptr(self._wgl[0][l]), ptr(seq[0].conv.bias), ptr(seq[2].gain0), ptr(seq[2].bias0),
                      ptr(bf.Y[l]) if need_bwd else None, ptr(bf.mean[l]) if need_bwd else None, ptr(bf.rstd[l]) if need_bwd else None,
                      ptr(out16), ptr(out32), ptr(bf.carry), _lib.DynInt(3, l, tok0), B, T, cin, cout, k, padn, SLOPE, stream())
@@ -518,15 +530,13 @@ class Generator_Conv1D_cLN(nn.Module):
     # ---- backward: accumulates into the flat gradient buffer
     def _backward_impl(self, dmask, key, mask):
         bf = self._bufs[key]
-        bf.need_bwd()
+        fused = self.precision == 'bf16' and self.fused and self.fused_ok
+        bf.need_bwd(fused=fused)
         wst = None
         if self.overlap_wgrad:
             if self._wstream is None:
                 self._wstream = ops.side_stream(dmask.device)
             wst = self._wstream
-        fused = self.precision == 'bf16' and self.fused and self.fused_ok
-        if fused:
-            bf.need_dgrad16()
         pkey = ('bwd', self.precision, fused, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr())
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
@@ -568,11 +578,16 @@ class Generator_Conv1D_cLN(nn.Module):
         for l in range(len(_G_LAYERS) - 1, -1, -1):
             cin, cout, k = _G_LAYERS[l]
             seq = self.convolutions[l]
-            d16 = bf.dY16[l] if (fused and l > 0) else None
+            # fused path: the output gradient exists as bf16 only - the operand of the weight gradient (beside the bf16 input) and of the
+            # data gradient; per-layer path: float32, converted while staged
+            d16 = bf.dY16[l] if fused else None
             call('nele_cln_bwd', ptr(dact), ptr(bf.Y[l]), ptr(seq[2].gain0), ptr(seq[2].bias0), ptr(bf.mean[l]), ptr(bf.rstd[l]),
-                 ptr(bf.dY[l]), ptr(d16), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
+                 None if fused else ptr(bf.dY[l]), ptr(d16), ptr(bf.gpart), ptr(bf.bpart), ptr(bf.cln_scratch), B, T, cout, k - 1, SLOPE, stream())
             call('nele_colsum2', ptr(bf.gpart), ptr(seq[2].gain0.grad), ptr(bf.bpart), ptr(seq[2].bias0.grad), B * bf.nchunks, cout, 1, stream())
-            wgrad(bf.inp[l], bf.dY[l], cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=b16w)
+            if fused:
+                wgrad(bf.inp16[l], d16, cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=True)
+            else:
+                wgrad(bf.inp[l], bf.dY[l], cout, bf.gw[l], cin, seq[0].conv.weight.grad, seq[0].conv.bias.grad, bf16=b16w)
             if l > 0:
                 if fused:
                     # data gradient = the layer kernel's plain-convolution form over the bf16 output gradient with the flipped weights
