@@ -449,6 +449,12 @@ class Generator_Conv1D_cLN(nn.Module):
                 return
         ops.conv_gemm(A, (self._wf[1] if back else self._wf[0])[q], bias, aux, out, B, N, epi, g, bf16=b16)
 
+    def _fused_for(self, T, need_bwd):
+        """bf16 mode: one fused launch per layer (csrc/glayer.hip) - for evaluation at any length; with a backward pass to follow only from
+        32 frames on (the weight gradient's tile kernel, which takes the bf16 operands the fused forward pass leaves, needs rows of >= 32
+        output positions; shorter utterances keep the float32 buffers of the per-layer kernels)."""
+        return self.precision == 'bf16' and self.fused and self.fused_ok and (not need_bwd or T >= 32)
+
     # ---- forward (model.py:83-98)
     def _forward_impl(self, x, y, need_bwd=False):
         if x.dim() != 3 or x.shape[2] != 64 or y.shape != x.shape:
@@ -463,7 +469,7 @@ class Generator_Conv1D_cLN(nn.Module):
         if self._weights_frozen and torch.is_grad_enabled() and self.training:
             raise RuntimeError("Generator_Conv1D_cLN: freeze_weights() is for evaluation loops; call unfreeze_weights() before training")
         self._weights(dev)
-        fused = self.precision == 'bf16' and self.fused and self.fused_ok
+        fused = self._fused_for(T, need_bwd)
         xs, ys = x.contiguous().float(), y.contiguous().float()
         mask = _empty((B, T, 64), dev)
         tok0 = bf.reserve_tokens(len(_G_LAYERS))
@@ -530,7 +536,7 @@ class Generator_Conv1D_cLN(nn.Module):
     # ---- backward: accumulates into the flat gradient buffer
     def _backward_impl(self, dmask, key, mask):
         bf = self._bufs[key]
-        fused = self.precision == 'bf16' and self.fused and self.fused_ok
+        fused = self._fused_for(bf.T, True)
         bf.need_bwd(fused=fused)
         wst = None
         if self.overlap_wgrad:

@@ -449,7 +449,7 @@ def test_fused_generator_layer_against_torch_float64(mods, B, T, cin, cout, K):
     assert float((d.double() - (ry - bias.double())).abs().max()) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize('B,T', [(2, 40), (3, 251), (2, 501), (1, 600)])
+@pytest.mark.parametrize('B,T', [(1, 30), (2, 40), (3, 251), (2, 501), (1, 600)])
 def test_fused_generator_equals_per_layer_kernels_in_bf16_mode(mods, B, T):
     """Generator_Conv1D_cLN in bf16 mode: the fused layer path (bf16 activations in memory) against the per-layer kernels (float32
     activations rounded while staged).  The same bf16 products; the float32 sums run in another order, so a layer's activations differ
@@ -478,7 +478,10 @@ def test_fused_generator_equals_per_layer_kernels_in_bf16_mode(mods, B, T):
     assert float((a[0] - b[0]).abs().max()) <= 1e-2 * float(a[0].abs().max())
     assert float((a[0] - b[0]).norm()) <= 1e-2 * float(a[0].norm())
     assert float((a[2] - b[2]).abs().max()) <= 1e-2 * float(a[2].abs().max())
-    assert torch.equal(b[0], b[2])                                        # train- and eval-mode forward passes of the fused path: the same kernels
+    if T >= 32:
+        assert torch.equal(b[0], b[2])                                    # train- and eval-mode forward passes of the fused path: the same kernels
+    else:                                                                 # below 32 frames a training pass keeps the per-layer kernels (model._fused_for)
+        assert torch.equal(b[0], a[0]) and float((b[0] - b[2]).abs().max()) <= 1e-2 * float(b[0].abs().max())
     assert float((a[1] - b[1]).norm()) <= 6e-2 * float(a[1].norm())
 
 
