@@ -524,10 +524,18 @@ def main():
 
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # NELE_BENCH_ONE_DEVICE=1 (test harness for 1-GPU boxes, never a measurement): every rank on device 0, buckets over gloo - the same
+    # sharding, deferred D update, barriers and max-over-ranks timing with the real kernels; the line carries "one_device_test": true
+    one_device = world > 1 and os.environ.get('NELE_BENCH_ONE_DEVICE', '0') == '1'
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from nele_gan_amd import dist as ndist
     from nele_gan_amd import ops, synth
@@ -716,6 +724,7 @@ def main():
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops,
                          'pmc_source': pmc_note},
             'ranks_seen': ranks_seen,
+            **({'one_device_test': True} if one_device else {}),
             'step_status': status if not a.breakdown else None,      # device-side counters of the timed region + warm-up (GanTrainer.check_status): eigh_repaired must be 0
         }
         if allreduce_ms is not None:

@@ -1,5 +1,7 @@
-"""GPU, two processes over RCCL (skipped when fewer than two devices are visible): replicas fed different utterance shards stay
-bit-identical over three canonical steps - the flat gradient all-reduce, the rank-0 broadcast and the deterministic kernels."""
+"""GPU, two processes: replicas fed different utterance shards stay bit-identical over three canonical steps - the flat gradient
+all-reduce, the rank-0 broadcast and the deterministic kernels.  Over RCCL on two devices (skipped when fewer are visible), and over gloo
+with BOTH ranks on device 0 (runs on a 1-GPU box: the same trainer code with the real kernels; gloo stages the buckets through the host),
+where the sharded run is also compared with one process that takes the whole batch."""
 import os
 import socket
 
@@ -17,20 +19,24 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, one_device=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    dev = 0 if one_device else rank
+    torch.cuda.set_device(dev)
+    if one_device:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
     from nele_gan_amd import dist as nd
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
     lo, hi = nd.shard_range(8)
     c, v = synth.batch(hi - lo, 24000, start=lo)
     cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
-    tr = GanTrainer('siib&estoi', device='cuda:%d' % rank, seed=666 + rank)      # different seeds: rank 0's weights must win
+    tr = GanTrainer('siib&estoi', device='cuda:%d' % dev, seed=666 + rank)       # different seeds: rank 0's weights must win
     for _ in range(3):
         tr.canonical_step(cw, nw)
     torch.cuda.synchronize()
@@ -51,3 +57,40 @@ def test_two_replicas_stay_bit_identical_over_three_steps():
     assert torch.equal(g0, g1) and torch.equal(d0, d1)
     assert all(torch.equal(a, b) for a, b in zip(b0, b1))                        # spectral-norm u, v
     assert all(x == 0 for x in s0.values()) and all(x == 0 for x in s1.values())
+
+
+def _whole_batch(out):
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(8, 24000, start=0)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    tr = GanTrainer('siib&estoi', device='cuda:0', seed=666)
+    for _ in range(3):
+        tr.canonical_step(cw, nw)
+    torch.cuda.synchronize()
+    out['whole'] = (tr.G.flat_parameters().flat.cpu(), tr.D.flat_parameters().flat.cpu())
+
+
+def test_two_ranks_on_one_device_over_gloo_match_each_other_and_the_whole_batch():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    g0, d0, b0, s0 = out[0]
+    g1, d1, b1, s1 = out[1]
+    assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    assert all(torch.equal(a, b) for a, b in zip(b0, b1))
+    assert all(x == 0 for x in s0.values()) and all(x == 0 for x in s1.values())
+    # two shards of 4 against one process with all 8 utterances: the mean of two shard means is the batch mean up to float32 rounding,
+    # the metric targets are per-utterance (batch-invariant kernels); three Adam steps amplify rounding differences, hence the tolerance
+    mp.spawn(_run_whole, args=(out,), nprocs=1, join=True)
+    gw, dw = out['whole']
+    # (an Adam step moves a weight by at most ~lr whatever the gradient's size: elements whose gradient is rounding noise may differ by that)
+    eg, ed = (g0 - gw).abs(), (d0 - dw).abs()
+    print('sharded vs whole: G max %.3e mean %.3e, D max %.3e mean %.3e' % (float(eg.max()), float(eg.mean()), float(ed.max()), float(ed.mean())))
+    assert float(eg.max()) <= 3 * 5e-4 * 1.5 and float(eg.mean()) <= 1e-5
+    assert float(ed.max()) <= 3 * 2.5e-4 * 1.5 and float(ed.mean()) <= 1e-4
+
+
+def _run_whole(_rank, out):
+    _whole_batch(out)
