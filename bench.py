@@ -358,8 +358,8 @@ def epoch_with_quality(a, cw, nw):
 
 def epoch_from_files(a, n_utt=256, batch=64):
     """End to end from wav files: a synthetic corpus (PCM_16, lengths 3 .. 4 s, as the reference's folders of clean / noise files) is
-    written to tmpfs, then GanTrainer.run_epoch is fed from it through dataio.FileBatches (threaded decode, pinned staging, asynchronous
-    copies, two batches ahead) - the reference feeds its loop from 8 DataLoader workers (dataloader.py:86-98) and re-reads the files in
+    written to tmpfs, then GanTrainer.run_epoch is fed from it through dataio.FileBatches (a batch of files per library call into pinned
+    int16 rows, asynchronous copies, int16 -> float32 on the device, two batches ahead) - the reference feeds its loop from 8 DataLoader workers (dataloader.py:86-98) and re-reads the files in
     every stage.  Reported: utterances/s of the epoch fed from files, of the same epoch on batches already resident in HBM, and of the
     loader alone (decode + upload)."""
     import gc
@@ -382,15 +382,15 @@ def epoch_from_files(a, n_utt=256, batch=64):
             files.append('%s/Clean/u%04d.wav' % (root, i))
         tr = GanTrainer(a.metrics)
         tr.D.precision = tr.G.precision = a.precision
-        nthreads = min(32, os.cpu_count() or 8)
+        nthreads = min(8, os.cpu_count() or 8)        # library threads per batch call (measured: 8 - 16 flat, 32 slower: the calls only move bytes)
         fb = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=2)   # keep < batches: every pass over the list decodes again
         for ep in (2, 3, 4):                                                  # warm-up: buffer sets / plans of the padded D shapes (shuffled chunks + replay)
-            tr.run_epoch(ep, fb, (), d_batch=batch)
+            tr.run_epoch(ep, fb, (), d_batch=batch, sample_dir=root + '/out')
         torch.cuda.synchronize()
         n0 = fb.decoded_files
         t0 = time.perf_counter()
-        for ep in (5, 6):
-            res = tr.run_epoch(ep, fb, (), d_batch=batch)
+        for ep in (5, 6):                                                     # the generated samples are written as name@epoch.wav like train_nele.py:309-313
+            res = tr.run_epoch(ep, fb, (), d_batch=batch, sample_dir=root + '/out')
         torch.cuda.synchronize()
         dt_files = (time.perf_counter() - t0) / 2
         decoded = (fb.decoded_files - n0) // 2
@@ -413,7 +413,7 @@ def epoch_from_files(a, n_utt=256, batch=64):
         dt_load = time.perf_counter() - t0
         fb.close(); fb2.close(); fbm.close()
         return {'value': n_utt / dt_files, 'unit': 'utterances/s', 'ms_per_epoch': dt_files * 1e3, 'utterances': n_utt, 'batch': batch,
-                'files_decoded_per_epoch': decoded, 'd_steps': res['d_steps'], 'g_steps': res['g_steps'],
+                'files_decoded_per_epoch': decoded, 'files_written_per_epoch': len(res.get('sample_files', ())), 'd_steps': res['d_steps'], 'g_steps': res['g_steps'],
                 'resident_batches': {'value': n_utt / dt_mem, 'ms_per_epoch': dt_mem * 1e3},
                 'loader_alone': {'value': n_utt / dt_load, 'unit': 'utterances/s (clean + noise wav decoded, padded, uploaded)', 'host_threads': nthreads,
                                  'wav_MB_per_s': 2 * sum(os.path.getsize(f) for f in files) / dt_load / 1e6},
@@ -426,11 +426,11 @@ def epoch_from_files(a, n_utt=256, batch=64):
         torch.cuda.empty_cache()
 
 
-def inference_from_files(tr, n_utt=1024, batch=128):
+def inference_from_files(tr, n_utt=4096, batch=128):
     """BASELINE configs[4] end to end on one GPU: inference.py:79-117 from wav files to wav files - a synthetic corpus of 8 s utterances
-    (clean + noise, PCM_16) on tmpfs, `inference.enhance_files` (threaded native decode into pinned rows, three batches in flight on the GPU,
-    threaded native PCM_16 writes) - the second pass over the whole list is timed (the first allocates the pinned staging buffers: tens of
-    milliseconds each)."""
+    (clean + noise, PCM_16) on tmpfs, `inference.enhance_files` (a batch of files per library call into pinned int16 rows, int16 over
+    PCIe both ways, conversions on the device, three batches in flight on the GPU) - the second pass over the whole list is timed (the
+    first allocates the pinned staging buffers: tens of milliseconds each)."""
     import gc
     import shutil
     import tempfile
@@ -451,7 +451,7 @@ def inference_from_files(tr, n_utt=1024, batch=128):
             files.append('%s/Clean/u%05d.wav' % (root, i))
         enh = Enhancer(G=tr.G)
         enh.G.precision = tr.G.precision
-        nthreads = min(32, os.cpu_count() or 8)
+        nthreads = min(8, os.cpu_count() or 8)        # library threads per batch call (measured: 8 - 16 flat, 32 slower: the calls only move bytes)
         enhance_files(enh, files, root + '/Noise/', root + '/Warm', batch=batch, workers=nthreads)    # first pass: buffer sets, plans, pinned staging buffers
         shutil.rmtree(root + '/Warm', ignore_errors=True)
         torch.cuda.synchronize()
@@ -463,7 +463,7 @@ def inference_from_files(tr, n_utt=1024, batch=128):
         nbytes = sum(os.path.getsize(f) for f in files) * 2 + sum(os.path.getsize(f) for f in out)
         return {'value': n_utt / dt, 'unit': 'utterances/s', 'files': n_utt, 'utterance_seconds': '7 .. 8', 'batch': batch, 'host_threads': nthreads,
                 'wav_MB_per_s': nbytes / dt / 1e6, 'seconds': dt,
-                'path': 'wav files on tmpfs -> decode (C, threads) -> pinned -> GPU (3 batches in flight) -> pinned -> PCM_16 files (C, threads)'}
+                'path': 'wav files on tmpfs -> int16 rows of a pinned buffer (one library call per batch) -> HBM -> float32 on the device -> 3 batches in flight -> int16 on the device -> pinned -> PCM_16 files (one library call per batch)'}
     except Exception as e:
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     finally:

@@ -95,6 +95,21 @@ int nele_wav_decode_pcm16(const char* path, float* out_host, long long cap, long
  * quantised = 0: lrintf(x * 32767) saturated, as libsndfile; != 0: the samples are values k / 32768 from nele_wav_post's PCM_16 emulation and
  * are recovered exactly.  No GPU work; runs outside the host language's interpreter lock when called through a foreign-function interface. */
 int nele_wav_write_pcm16(const char* path, const float* wav_host, long long n, int sample_rate, int quantised);
+/* The same hand-off a BATCH at a time, bytes only on the host (round 5; replaces the per-file librosa.load / sf.write of dataloader.py:34-40,
+ * inference.py:99-101,115): paths[n] mono PCM_16 files -> rows of out_host [n][row_stride] int16 HOST memory (pinned staging buffer), at most
+ * cap samples each, zeros behind them; n_out[i] = samples read, -1 = not mono PCM_16 (the caller's general reader takes that file),
+ * -2 = cannot open; sample_rate_out[n] may be NULL.  `threads` (1 .. 256) library threads share the files; no GPU work. */
+int nele_wav_read_pcm16_batch(const char* const* paths, int n, short* out_host, long long row_stride, long long cap, int* n_out,
+                              int* sample_rate_out, int threads);
+/* ... rows of in_host [n][row_stride] int16 HOST memory -> n mono PCM_16 RIFF files of n_samples[i] samples (sf.write(path, wav, 16000, 'PCM_16')) */
+int nele_wav_write_pcm16_batch(const char* const* paths, int n, const short* in_host, long long row_stride, const int* n_samples, int sample_rate,
+                               int threads);
+/* Device side of it: int16 rows -> float32 rows, out[b][i] = i < lengths[b] ? in[b][i] / 32768 : 0 for i < L (what sf.read returns for PCM_16;
+ * lengths [B] int32 device memory or NULL: the shorter of an utterance and its noise file, dataloader.py:38-40) ... */
+int nele_pcm16_to_float(const short* in, long long in_stride, const int* lengths, int B, long long L, float* out, long long out_stride, void* stream);
+/* ... and float32 rows -> the int16 sample values sf.write(..., 'PCM_16') stores: quantised != 0: input = values k / 32768 from the device-side
+ * PCM_16 emulation (nele_wav_post), recovered exactly; 0: libsndfile's lrintf(x * 32767), saturated. */
+int nele_float_to_pcm16(const float* in, long long in_stride, int B, long long L, short* out, long long out_stride, int quantised, void* stream);
 
 /* ---- signal features / resynthesis (csrc/features.hip) ---------------------------------------- */
 

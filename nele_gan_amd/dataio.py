@@ -124,6 +124,41 @@ def write_wav_pcm16_native(path, row, n, sr=fs, quantised=False):
         raise IOError(_nele_lib.nele_last_error_string().decode('utf-8', 'replace'))
 
 
+def _c_paths(paths):
+    import ctypes
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    return arr
+
+
+def read_wav_batch_pcm16(paths, out_rows, threads=8):
+    """A batch of mono PCM_16 files -> the rows of ``out_rows`` ([n][cap] int16 numpy view of e.g. a pinned staging buffer), read by the
+    library's own threads in ONE foreign call (no interpreter lock, no per-file Python).  -> (samples int32 [n] (-1: another wav flavour,
+    -2: unreadable), sample rates int32 [n])."""
+    import ctypes
+    n = len(paths)
+    assert out_rows.dtype == np.int16 and out_rows.ndim == 2 and out_rows.shape[0] >= n and out_rows.strides[1] == 2
+    got, sr = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    st = _nele_lib.nele_wav_read_pcm16_batch(ctypes.cast(_c_paths(paths), ctypes.c_void_p), n, ctypes.c_void_p(out_rows.ctypes.data),
+                                             out_rows.strides[0] // 2, out_rows.shape[1], ctypes.c_void_p(got.ctypes.data),
+                                             ctypes.c_void_p(sr.ctypes.data), max(1, min(256, int(threads))))
+    if st != 0:
+        raise IOError(_nele_lib.nele_last_error_string().decode('utf-8', 'replace'))
+    return got, sr
+
+
+def write_wav_batch_pcm16(paths, rows, n_samples, sr=fs, threads=8):
+    """Rows of ``rows`` ([n][>= max n_samples] int16: the sample values themselves) -> n mono PCM_16 files, written by the library's own
+    threads in one foreign call."""
+    import ctypes
+    n = len(paths)
+    assert rows.dtype == np.int16 and rows.ndim == 2 and rows.shape[0] >= n and rows.strides[1] == 2
+    ns = np.ascontiguousarray(np.asarray(n_samples, dtype=np.int32))
+    st = _nele_lib.nele_wav_write_pcm16_batch(ctypes.cast(_c_paths(paths), ctypes.c_void_p), n, ctypes.c_void_p(rows.ctypes.data), rows.strides[0] // 2,
+                                              ctypes.c_void_p(ns.ctypes.data), int(sr), max(1, min(256, int(threads))))
+    if st != 0:
+        raise IOError(_nele_lib.nele_last_error_string().decode('utf-8', 'replace'))
+
+
 def write_wav_pcm16(path, wav, sr=fs, quantised=False):
     """sf.write(path, wav, sr, 'PCM_16').  ``quantised=True``: ``wav`` already went through the device-side PCM_16
     emulation (values k / 32768), so the samples are recovered exactly instead of being rounded a second time."""
@@ -269,15 +304,16 @@ def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
 _PINNED = {}
 
 
-def pinned_get(shape):
+def pinned_get(shape, dtype=None):
     import torch
-    lst = _PINNED.get(tuple(shape))
-    return lst.pop() if lst else torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+    dtype = torch.float32 if dtype is None else dtype
+    lst = _PINNED.get((tuple(shape), dtype))
+    return lst.pop() if lst else torch.empty(tuple(shape), dtype=dtype).pin_memory()
 
 
 def pinned_put(t):
     if t is not None:
-        _PINNED.setdefault(tuple(t.shape), []).append(t)
+        _PINNED.setdefault((tuple(t.shape), t.dtype), []).append(t)
 
 
 def pinned_release():
@@ -295,8 +331,13 @@ class FileBatches:
     ``seq[i]`` may be asked for repeatedly and in any order (run_epoch walks the list once for the G-steps and once for the sample
     generation): a batch is decoded again when it is no longer cached, like the reference."""
 
-    def __init__(self, file_list, noise_path, batch=32, drc_path=None, workers=8, ahead=2, device='cuda', pad_to=4096, keep=4):
+    def __init__(self, file_list, noise_path, batch=32, drc_path=None, workers=8, ahead=2, device='cuda', pad_to=4096, keep=4, int16=True):
+        """``int16`` (default): a batch is read by ONE library call (nele_wav_read_pcm16_batch, ``workers`` library threads) into pinned int16
+        rows, uploaded as int16 and converted on the device (nele_pcm16_to_float: s / 32768, the padding and the samples behind the shorter
+        of clean / noise zeroed there).  A batch that holds any other wav flavour - and every batch with ``int16=False`` - takes the
+        per-file float32 path (read_wav_into / load on ``workers`` Python threads)."""
         import concurrent.futures as cf
+        self.int16 = bool(int16)
         self.files, self.noise_path, self.drc_path = list(file_list), noise_path, drc_path
         self.groups = [list(range(k, min(k + batch, len(self.files)))) for k in range(0, len(self.files), batch)]
         self.workers = max(1, int(workers))
@@ -342,7 +383,7 @@ class FileBatches:
         batch that used it leaves the cache"""
         return pinned_get(shape)
 
-    def _submit(self, g):
+    def _submit(self, g, force_f32=False):
         if not (0 <= g < len(self.groups)) or g in self._pending or g in self._ready:
             return
         idxs = self.groups[g]
@@ -351,13 +392,35 @@ class FileBatches:
         if self.pad_to:
             Lmax = (Lmax + self.pad_to - 1) // self.pad_to * self.pad_to
         n = len(idxs)
-        hc, hn = self._pinned((n, Lmax)), self._pinned((n, Lmax))
-        hd = None
+        Ld = 0
         if self.drc_path is not None:
             Ld = max(self._bound(self.drc_path + nm) for nm in names)
             if self.pad_to:
                 Ld = (Ld + self.pad_to - 1) // self.pad_to * self.pad_to
-            hd = self._pinned((n, max(Ld, Lmax)))
+            Ld = max(Ld, Lmax)
+        if self.int16 and not force_f32:
+            import torch
+            hc, hn = pinned_get((n, Lmax), torch.int16), pinned_get((n, Lmax), torch.int16)
+            hd = pinned_get((n, Ld), torch.int16) if self.drc_path is not None else None
+            sets = [([self.files[i] for i in idxs], hc), ([self.noise_path + nm for nm in names], hn)]
+            if hd is not None:
+                sets.append(([self.drc_path + nm for nm in names], hd))
+
+            def run_batch():                                               # one task per batch: the library's threads do the rest
+                out = []
+                for paths, h in sets:
+                    got, sr = read_wav_batch_pcm16(paths, h.numpy(), self.workers)
+                    if (got == -2).any():
+                        raise IOError('cannot read ' + paths[int(np.argmax(got == -2))])
+                    if (got < 0).any():
+                        return None                                        # another wav flavour in the batch: the float32 path
+                    assert (sr == 16000).all()                             # dataloader.py:35
+                    out.append(got)
+                return out
+            self._pending[g] = ('i16', self.pool.submit(run_batch), hc, hn, hd, names)
+            return
+        hc, hn = self._pinned((n, Lmax)), self._pinned((n, Lmax))
+        hd = self._pinned((n, Ld)) if self.drc_path is not None else None
         ac, an, ad = hc.numpy(), hn.numpy(), (hd.numpy() if hd is not None else None)
         # a task = a run of rows (submitting one task per file costs the submitting thread ~20 us each: more than the decode itself)
         nt = max(1, min(self.workers, n))
@@ -366,11 +429,50 @@ class FileBatches:
         def run(r0):
             return [self._decode_into(idxs[r], [ac[r], an[r]] + ([ad[r]] if ad is not None else [])) for r in range(r0, min(n, r0 + per))]
         futs = [self.pool.submit(run, r0) for r0 in range(0, n, per)]
-        self._pending[g] = (futs, hc, hn, hd)
+        self._pending[g] = ('f32', futs, hc, hn, hd, names)
+
+    def _stage_i16(self, g, got, hc, hn, hd, names):
+        """int16 staging rows -> device: upload, then s / 32768 with the rows cut to the shorter of clean / noise, all on the copy stream"""
+        import torch
+        from . import _lib
+        self.decoded_files += len(names)
+        lens = np.minimum(got[0], got[1]).astype(np.int32)
+        n, L = hc.shape
+        if self._copy is None:
+            self._copy = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._copy):
+            sh = self._copy.cuda_stream
+
+            def up(h, ln):
+                raw = h.to(self.device, non_blocking=True)
+                dl = torch.from_numpy(ln).pin_memory().to(self.device, non_blocking=True)
+                out = torch.empty(tuple(h.shape), dtype=torch.float32, device=self.device)
+                _lib.check(_lib.lib.nele_pcm16_to_float(raw.data_ptr(), h.shape[1], dl.data_ptr(), h.shape[0], h.shape[1], out.data_ptr(), h.shape[1], sh),
+                           'nele_pcm16_to_float')       # (not _lib.call: never part of a recorded pass)
+                return out, dl
+            clean, dl = up(hc, lens)
+            noise, _ = up(hn, lens)
+            b = {'clean': clean, 'noise': noise, 'lengths': dl, 'names': list(names), 'lengths_host': lens}
+            if hd is not None:
+                dlens = got[2].astype(np.int32)
+                b['drc'], b['drc_lengths'] = up(hd, dlens)
+            ev = torch.cuda.Event()
+            ev.record(self._copy)
+        self._ready[g] = (b, ev, (hc, hn, hd))
 
     def _stage(self, g):
         import torch
-        futs, hc, hn, hd = self._pending.pop(g)
+        kind, futs, hc, hn, hd, names = self._pending.pop(g)
+        if kind == 'i16':
+            got = futs.result()
+            if got is not None:
+                self._stage_i16(g, got, hc, hn, hd, names)
+                self._trim()
+                return
+            for t in (hc, hn, hd):                                        # not all plain PCM_16: this batch again through the general readers
+                pinned_put(t)
+            self._submit(g, force_f32=True)
+            kind, futs, hc, hn, hd, names = self._pending.pop(g)
         res = [r for f in futs for r in f.result()]
         self.decoded_files += len(res)
         lens = np.asarray([r[0] for r in res], dtype=np.int32)
@@ -387,6 +489,9 @@ class FileBatches:
             ev = torch.cuda.Event()
             ev.record(self._copy)
         self._ready[g] = (b, ev, (hc, hn, hd))
+        self._trim()
+
+    def _trim(self):
         while len(self._ready) > self.keep:
             _, ev_old, bufs = self._ready.pop(next(iter(self._ready)))
             ev_old.synchronize()                                           # its upload is long done; the pinned buffers go back to the pool
@@ -423,7 +528,7 @@ class FileBatches:
         for _, _, bufs in self._ready.values():
             for t in bufs:
                 pinned_put(t)
-        for _, hc, hn, hd in self._pending.values():
+        for _, _, hc, hn, hd, _ in self._pending.values():
             for t in (hc, hn, hd):
                 pinned_put(t)
         self._ready, self._pending = {}, {}

@@ -20,6 +20,7 @@ from . import audio_util as au
 from . import dist as ndist
 from . import model as M
 from . import ops
+from . import _lib
 
 p_power = (1 / 6)
 inv_p = 6
@@ -117,11 +118,13 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
     Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.
 
-    Host side (the reference: one file at a time, librosa.load + sf.write in the main process): dataio.FileBatches decodes ``workers``
-    files at a time with the library's C reader straight into pinned staging rows (batches padded to a multiple of ``pad_to`` samples:
-    few distinct shapes, the generator's buffers are cached per shape) and uploads asynchronously, two batches ahead;
-    ``inflight`` batches are on the GPU at a time (enhance_stream); results come back through pinned buffers on a copy stream and are
-    written as PCM_16 by the same thread pool with the library's C writer while later batches run."""
+    Host side (the reference: one file at a time, librosa.load + sf.write in the main process): dataio.FileBatches reads a batch per
+    library call (``workers`` library threads) straight into pinned int16 staging rows (batches padded to a multiple of ``pad_to``
+    samples: few distinct shapes, the generator's buffers are cached per shape), uploads asynchronously, two batches ahead, and
+    converts to float32 on the device;
+    ``inflight`` batches are on the GPU at a time (enhance_stream); results are converted to their int16 sample values on the device, come
+    back through pinned buffers on a copy stream and are written a batch per call by the library's own threads (nele_wav_write_pcm16_batch)
+    while later batches run.  The host moves bytes only: no sample is touched by the interpreter or converted on a CPU core."""
     import concurrent.futures as cf
     import numpy as np
     from . import dataio
@@ -138,7 +141,7 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
                             keep=inflight + 2)
     written = {}
     copy_out = torch.cuda.Stream(device=dev)
-    pool = cf.ThreadPoolExecutor(max_workers=max(1, int(workers)))
+    pool = cf.ThreadPoolExecutor(max_workers=inflight + 2)           # a task = one batch's write call
     meta, outq, writes = [], collections.deque(), []
 
     def batches():
@@ -151,25 +154,17 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
         while outq and (block_all or outq[0][1].query()):
             host, ev, sel, lens = outq.popleft()
             ev.synchronize()
-            arr = host.numpy()
-            jobs = []
-            for r, i in enumerate(sel):
-                name = file_list[i].split('/')[-1]
-                path = dataio.enhanced_name(output_path, name, epoch_tag)
-                jobs.append((path, arr[r], 256 * (int(lens[r]) // 256)))
+            paths = []
+            for i in sel:
+                path = dataio.enhanced_name(output_path, file_list[i].split('/')[-1], epoch_tag)
+                paths.append(path)
                 written[i] = path
-            nt = max(1, min(int(workers), len(jobs)))
-            per = (len(jobs) + nt - 1) // nt
-
-            def run(chunk):                                              # a task = a run of files (one task per file costs more to submit than to write)
-                for path, row, n in chunk:
-                    dataio.write_wav_pcm16_native(path, row, n, fs, True)
-            futs = [pool.submit(run, jobs[k:k + per]) for k in range(0, len(jobs), per)]
-            writes.append((futs, host))
-        while writes and (block_all or all(f.done() for f in writes[0][0])):
-            futs, host = writes.pop(0)
-            for f in futs:
-                f.result()                                               # re-raises a writer's error
+            ns = [256 * (int(n) // 256) for n in lens]
+            # one task per batch: the library's own threads write the files (nele_wav_write_pcm16_batch), no per-file work in the interpreter
+            writes.append((pool.submit(dataio.write_wav_batch_pcm16, paths, host.numpy(), ns, fs, workers), host))
+        while writes and (block_all or writes[0][0].done()):
+            fut, host = writes.pop(0)
+            fut.result()                                                 # re-raises a writer's error
             dataio.pinned_put(host)                                     # the pinned buffer goes back to the pool
 
     try:
@@ -180,9 +175,13 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
             done.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(copy_out):
                 copy_out.wait_event(done)
-                host = dataio.pinned_get(enh.shape)
-                host.copy_(enh, non_blocking=True)
+                # the PCM_16 emulation left values k / 32768: k itself goes to the host (half the bytes), the writer threads add headers
+                q = torch.empty(tuple(enh.shape), dtype=torch.int16, device=enh.device)
+                _lib.check(_lib.lib.nele_float_to_pcm16(enh.data_ptr(), enh.shape[1], enh.shape[0], enh.shape[1], q.data_ptr(), enh.shape[1], 1,
+                                                        copy_out.cuda_stream), 'nele_float_to_pcm16')
                 enh.record_stream(copy_out)
+                host = dataio.pinned_get(q.shape, torch.int16)
+                host.copy_(q, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_out)
             outq.append((host, ev, sel, lens))

@@ -884,7 +884,8 @@ class GanTrainer:
             f = fts(b)
             enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f.get('frames'))
             if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
-                self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch, lengths=b.get('lengths'))
+                self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch,
+                                   lengths=b.get('lengths_host', b.get('lengths')), wait=False)
             raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids')))
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
@@ -913,7 +914,8 @@ class GanTrainer:
             lens, frames = b.get('lengths'), f.get('frames')
             enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=frames)
             if sample_dir is not None and 'names' in b:
-                out['sample_files'] += self.write_samples(enh, b['names'], sample_dir + '/For_discriminator_training', gan_epoch, lengths=lens)
+                out['sample_files'] += self.write_samples(enh, b['names'], sample_dir + '/For_discriminator_training', gan_epoch,
+                                                          lengths=b.get('lengths_host', lens), wait=False)
             dl = b.get('drc_lengths', lens)
             if b.get('drc') is not None:
                 # generated + pre-enhanced ('DRC') example of the same utterances (:318-340; audio_util.py:267-321; the DRC file keeps its
@@ -931,6 +933,7 @@ class GanTrainer:
         d0 = self.step_d
         self.d_epoch(samples, batch=d_batch)                            # :342-426
         out['d_steps'] = self.step_d - d0
+        self.flush_writes()                                             # the epoch's sample files are on disk when it returns
         if check:
             out['status'] = self.check_status()
         return out
@@ -943,20 +946,59 @@ class GanTrainer:
                 for k in range(din.shape[0])]
 
     # ---------------------------------------------------------------- file hand-off (train_nele.py:303-340, 224-225)
-    def write_samples(self, enh_wav, wave_names, directory, gan_epoch, lengths=None):
+    def write_samples(self, enh_wav, wave_names, directory, gan_epoch, lengths=None, wait=True):
         """Enhanced batch -> '<directory>/<name>@<epoch>.wav' PCM_16 files, as the reference stores its generated D samples
         (train_nele.py:309-313).  ``enh_wav`` is what ``generate`` returned (already PCM_16-quantised when ``self.pcm16``);
-        lengths [B]: samples of the ORIGINAL utterances of a padded batch (file k then holds 256 * (lengths[k] // 256) samples)."""
+        lengths [B] (host list / array, or a tensor): samples of the ORIGINAL utterances of a padded batch (file k then holds
+        256 * (lengths[k] // 256) samples).
+
+        PCM_16 batches on the GPU leave as int16 sample values (nele_float_to_pcm16) through a pinned buffer and are written by the
+        library's own threads, one call per batch (nele_wav_write_pcm16_batch); ``wait=False`` hands that to a background thread - the
+        caller's stream is not synchronised - and ``flush_writes()`` waits for the files (run_epoch does before it returns)."""
         from . import dataio
         dataio.creatdir(directory)
+        if lengths is None:
+            lens = None
+        elif torch.is_tensor(lengths):
+            lens = [256 * (int(v) // 256) for v in lengths.tolist()]
+        else:
+            lens = [256 * (int(v) // 256) for v in lengths]
+        out = [dataio.enhanced_name(directory, name, gan_epoch) for name in wave_names]
+        if self.pcm16 and enh_wav.is_cuda and enh_wav.dim() == 2 and enh_wav.is_contiguous() and enh_wav.dtype == torch.float32:
+            from . import _lib
+            B, L = enh_wav.shape
+            q = torch.empty((B, L), dtype=torch.int16, device=enh_wav.device)
+            _lib.check(_lib.lib.nele_float_to_pcm16(enh_wav.data_ptr(), L, B, L, q.data_ptr(), L, 1, _lib.stream()), 'nele_float_to_pcm16')
+            host = dataio.pinned_get((B, L), torch.int16)
+            host.copy_(q, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ns = lens if lens is not None else [L] * B
+
+            def job():
+                ev.synchronize()
+                try:
+                    dataio.write_wav_batch_pcm16(out, host.numpy(), ns, fs, threads=8)
+                finally:
+                    dataio.pinned_put(host)
+            if wait:
+                job()
+            else:
+                if getattr(self, '_write_pool', None) is None:
+                    import concurrent.futures as cf
+                    self._write_pool, self._writes = cf.ThreadPoolExecutor(max_workers=1), []
+                self._writes.append(self._write_pool.submit(job))
+            return out
         host = enh_wav.detach().cpu().numpy()
-        lens = None if lengths is None else [256 * (int(v) // 256) for v in torch.as_tensor(lengths).tolist()]
-        out = []
-        for k, (w, name) in enumerate(zip(host, wave_names)):
-            path = dataio.enhanced_name(directory, name, gan_epoch)
+        for k, (w, path) in enumerate(zip(host, out)):
             dataio.write_wav_pcm16(path, w if lens is None else w[:lens[k]], fs, quantised=self.pcm16)
-            out.append(path)
         return out
+
+    def flush_writes(self):
+        """Wait for the sample files handed to the background writer (write_samples(wait=False)); re-raises a writer's error."""
+        pend, self._writes = getattr(self, '_writes', None) or [], []
+        for f in pend:
+            f.result()
 
     def score_lines(self, targets, enhanced_names):
         """[B, n_metrics] targets -> 's_siib,s_haspi,s_estoi,s_pesq,s_visqol,path' items of the reference's D training list

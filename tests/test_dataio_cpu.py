@@ -90,3 +90,40 @@ def test_listread_and_get_filepaths(tmp_path):
     assert dataio.ListRead(str(lst)) == ['a.wav', 'b.wav']
     dataio.creatdir(str(tmp_path / 'p' / 'q'))
     assert (tmp_path / 'p' / 'q').is_dir()
+
+
+def test_batch_reader_and_writer_move_the_same_samples_as_the_per_file_functions(tmp_path):
+    """nele_wav_read_pcm16_batch / nele_wav_write_pcm16_batch (host-only entry points of the library, several library threads): rows equal
+    the per-file reader's samples x 32768, zeros behind them, cut at the row length; other wav flavours are reported (-1), unreadable
+    files too (-2); written files are byte-identical to write_wav_pcm16 of the same samples."""
+    names = ['Train_Clean.wav', 'Train_Noise.wav', 'Test_Clean.wav']
+    paths = [os.path.join(TOY, n) for n in names]
+    f32 = tmp_path / 'f32.wav'
+    body = np.array([0.25, -0.5], dtype='<f4').tobytes()
+    f32.write_bytes(b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVE' + b'fmt ' + struct.pack('<IHHIIHH', 16, 3, 1, 16000, 64000, 4, 32) + b'data'
+                    + struct.pack('<I', len(body)) + body)
+    allp = paths + [str(f32), str(tmp_path / 'missing.wav')]
+    ref = [dataio.read_wav(p)[0] for p in paths]
+    for threads in (1, 3):
+        cap = max(len(r) for r in ref) + 100
+        rows = np.full((len(allp) + 1, cap), 7, dtype=np.int16)
+        got, sr = dataio.read_wav_batch_pcm16(allp, rows, threads=threads)
+        assert list(got) == [len(r) for r in ref] + [-1, -2] and list(sr[:3]) == [16000] * 3
+        for r, x in enumerate(ref):
+            assert np.array_equal(rows[r, :len(x)].astype(np.float32) / 32768.0, x) and not rows[r, len(x):].any()
+        assert not rows[3].any() and not rows[4].any() and (rows[5] == 7).all()          # failed rows are zeroed, rows beyond n untouched
+    short = np.zeros((3, 1000), dtype=np.int16)
+    got, _ = dataio.read_wav_batch_pcm16(paths, short, threads=2)                        # rows shorter than the files: cut, not overrun
+    assert list(got) == [1000] * 3 and np.array_equal(short[1].astype(np.float32) / 32768.0, ref[1][:1000])
+    # writer
+    rng = np.random.default_rng(5)
+    q = rng.integers(-32768, 32768, size=(4, 900)).astype(np.int16)
+    ns = [900, 0, 257, 512]
+    outs = [str(tmp_path / ('w%d.wav' % k)) for k in range(4)]
+    dataio.write_wav_batch_pcm16(outs, q, ns, threads=3)
+    for k, p in enumerate(outs):
+        one = str(tmp_path / 'one.wav')
+        dataio.write_wav_pcm16(one, q[k, :ns[k]].astype(np.float32) / 32768.0, quantised=True)
+        assert open(p, 'rb').read() == open(one, 'rb').read()
+    with pytest.raises(IOError):
+        dataio.write_wav_batch_pcm16([str(tmp_path / 'no_such_dir' / 'a.wav')], q, [10])

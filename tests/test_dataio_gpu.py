@@ -128,14 +128,15 @@ def test_generated_samples_through_files_give_the_in_memory_targets(tmp_path):
     assert 'EPOCH:7' in tr.validation_log_line(siib, [0.0], estoi, 7)
 
 
-def test_file_batches_prefetching_loader(tree):
+@pytest.mark.parametrize('int16', [True, False])
+def test_file_batches_prefetching_loader(tree, int16):
     """dataio.FileBatches: the corpus on disk as run_epoch's batch dicts - threaded decode, pinned staging, asynchronous upload, batches
     decoded ahead, re-decoded after eviction (the reference re-reads its files in every stage, dataloader.py:30-42).  Contents equal
     plain loads of the same files, in list order, whatever the access pattern."""
     from nele_gan_amd import dataio
     clean_root, noise_root, _ = tree
     files = [clean_root + 'Train.wav', clean_root + 'Test.wav', clean_root + 'Train.wav', clean_root + 'Test.wav', clean_root + 'Train.wav']
-    fb = dataio.FileBatches(files, noise_root, batch=2, workers=3, ahead=1, keep=1, pad_to=4096, drc_path=clean_root)
+    fb = dataio.FileBatches(files, noise_root, batch=2, workers=3, ahead=1, keep=1, pad_to=4096, drc_path=clean_root, int16=int16)
     assert len(fb) == 3
 
     def check(b, idx):
@@ -158,3 +159,63 @@ def test_file_batches_prefetching_loader(tree):
     with pytest.raises(IndexError):
         fb[3]
     fb.close()
+
+
+def test_file_batches_with_another_wav_flavour_in_a_batch(tree, tmp_path):
+    """A batch that holds a float32 wav cannot go through the int16 staging rows: that batch (only) takes the per-file float32 path;
+    the contents are what plain loads give either way."""
+    import shutil
+    import struct
+    from nele_gan_amd import dataio
+    clean_root, noise_root, _ = tree
+    croot, nroot = str(tmp_path / 'c') + '/', str(tmp_path / 'n') + '/'
+    os.makedirs(croot), os.makedirs(nroot)
+    for nm in ('Train.wav', 'Test.wav'):
+        shutil.copy(clean_root + nm, croot + nm)
+        shutil.copy(noise_root + nm, nroot + nm)
+    x, _ = dataio.load(clean_root + 'Train.wav')
+    body = x[:5000].astype('<f4').tobytes()
+    for root in (croot, nroot):
+        with open(root + 'F32.wav', 'wb') as f:
+            f.write(b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVE' + b'fmt ' + struct.pack('<IHHIIHH', 16, 3, 1, 16000, 64000, 4, 32) + b'data'
+                    + struct.pack('<I', len(body)) + body)
+    files = [croot + 'Train.wav', croot + 'F32.wav', croot + 'Test.wav']
+    fb = dataio.FileBatches(files, nroot, batch=2, workers=2, ahead=1, keep=2)
+    b0, b1 = fb[0], fb[1]
+    assert int(b0['lengths'][1]) == 5000
+    np.testing.assert_array_equal(b0['clean'][1, :5000].cpu().numpy(), x[:5000])
+    c0, _ = dataio.load(croot + 'Train.wav')
+    n0, _ = dataio.load(nroot + 'Train.wav')
+    m = min(len(c0), len(n0))
+    np.testing.assert_array_equal(b0['clean'][0, :m].cpu().numpy(), c0[:m])
+    np.testing.assert_array_equal(b0['noise'][0, :m].cpu().numpy(), n0[:m])
+    c2, _ = dataio.load(croot + 'Test.wav')
+    np.testing.assert_array_equal(b1['clean'][0, :int(b1['lengths'][0])].cpu().numpy(), c2[:int(b1['lengths'][0])])
+    fb.close()
+
+
+def test_pcm16_conversion_kernels():
+    """nele_pcm16_to_float: s / 32768 up to lengths[b], zeros behind (any stride / alignment); nele_float_to_pcm16: the integer of a
+    device-quantised sample exactly, libsndfile's lrintf(x * 32767) rule (ties to even, saturation) otherwise."""
+    from nele_gan_amd import _lib
+    rng = np.random.default_rng(11)
+    for B, L, stride in ((3, 4096, 4096), (2, 1001, 1003), (1, 7, 8)):
+        q = rng.integers(-32768, 32768, size=(B, stride)).astype(np.int16)
+        lens = rng.integers(0, L + 1, size=B).astype(np.int32)
+        lens[0] = L
+        dq, dl = torch.from_numpy(q).cuda(), torch.from_numpy(lens).cuda()
+        out = torch.full((B, stride), 9.0, device='cuda')
+        _lib.check(_lib.lib.nele_pcm16_to_float(dq.data_ptr(), stride, dl.data_ptr(), B, L, out.data_ptr(), stride, None), 'nele_pcm16_to_float')
+        o = out.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(o[b, :lens[b]], q[b, :lens[b]].astype(np.float32) / 32768.0)
+            assert not o[b, lens[b]:L].any() and (o[b, L:] == 9.0).all()
+        back = torch.zeros((B, stride), dtype=torch.int16, device='cuda')
+        full = torch.from_numpy(q.astype(np.float32) / 32768.0).cuda()
+        _lib.check(_lib.lib.nele_float_to_pcm16(full.data_ptr(), stride, B, L, back.data_ptr(), stride, 1, None), 'nele_float_to_pcm16')
+        assert np.array_equal(back.cpu().numpy()[:, :L], q[:, :L]) and not back.cpu().numpy()[:, L:].any()
+    x = np.array([[0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, 1.2, -1.2, 0.3, -0.7]], dtype=np.float32)
+    dx, di = torch.from_numpy(x).cuda(), torch.zeros((1, 8), dtype=torch.int16, device='cuda')
+    _lib.check(_lib.lib.nele_float_to_pcm16(dx.data_ptr(), 8, 1, 8, di.data_ptr(), 8, 0, None), 'nele_float_to_pcm16')
+    from oracle.step import pcm16_roundtrip
+    assert np.array_equal(di.cpu().numpy()[0].astype(np.float32) / 32768.0, pcm16_roundtrip(x[0]))
