@@ -247,19 +247,60 @@ def pad_batch(signals):
     return out, lens
 
 
+def _triples_on_device(clean_root, noise_root, enhanced_files, drc, threads=8):
+    """The (clean, enhanced + noise) pairs of ``_triple`` for a group of files, built on the GPU: the 3 n files are read by ONE library
+    call into pinned int16 rows, uploaded as int16, converted there (s / 32768, exact), rows cut to min(len(clean), len(enhanced))
+    (audio_util.py:134-137) and the noise added in float32 as numpy does.  -> (x [n, L], y [n, L] device float32, lengths int32 [n]),
+    or None when a file is not mono PCM_16 (the caller then reads the group file by file)."""
+    import torch
+    from . import _lib
+    names = [en.split('/')[-1] if drc else wave_name_of(en) + '.wav' for en in enhanced_files]
+    paths = [clean_root + nm for nm in names] + list(enhanced_files) + [noise_root + nm for nm in names]
+    n = len(names)
+    L = max(max(1, (os.path.getsize(p) - 44 + 1) // 2) for p in paths)
+    L = (L + 7) // 8 * 8
+    host = pinned_get((3 * n, L), torch.int16)
+    try:
+        got, sr = read_wav_batch_pcm16(paths, host.numpy(), threads)
+        if (got == -2).any():
+            raise IOError('cannot read ' + paths[int(np.argmax(got == -2))])
+        if (got < 0).any():
+            return None
+        if (sr != fs).any():
+            raise ValueError('%s: sample rate %d, expected %d' % (paths[int(np.argmax(sr != fs))], int(sr[np.argmax(sr != fs)]), fs))
+        lens = np.minimum(got[:n], got[n:2 * n]).astype(np.int32)
+        if (got[2 * n:] < lens).any():
+            raise ValueError('%s: noise file shorter than the utterance' % paths[2 * n + int(np.argmax(got[2 * n:] < lens))])
+        raw = host.cuda(non_blocking=True)
+        dl = torch.from_numpy(np.tile(lens, 3)).cuda()
+        f = torch.empty((3 * n, L), dtype=torch.float32, device='cuda')
+        _lib.check(_lib.lib.nele_pcm16_to_float(raw.data_ptr(), L, dl.data_ptr(), 3 * n, L, f.data_ptr(), L, _lib.stream()), 'nele_pcm16_to_float')
+        x, y = f[:n], f[n:2 * n] + f[2 * n:]
+        torch.cuda.current_stream().synchronize()                          # the pinned rows go back to the pool below
+        return x, y, lens
+    finally:
+        pinned_put(host)
+
+
 def _read_batch(kind, clean_root, noise_root, enhanced_list, norm, drc=False, max_batch=256):
     """Files of ANY lengths go side by side into one padded batch with per-utterance lengths: one kernel launch per metric and
-    ``max_batch`` files (the reference: one joblib process per file, audio_util.py:146)."""
+    ``max_batch`` files (the reference: one joblib process per file, audio_util.py:146).  Mono PCM_16 files (what the reference
+    writes) never become float32 on the host: see _triples_on_device."""
     import torch
     from . import metrics as mt
     fn = {'estoi': mt.batch_estoi, 'siib': mt.batch_siib, 'haspi': mt.batch_haspi}[kind]
-    pairs = [_triple(clean_root, noise_root, en, drc) for en in enhanced_list]
-    out = [None] * len(pairs)
-    for k in range(0, len(pairs), max_batch):
-        sel = list(range(k, min(k + max_batch, len(pairs))))
-        xp, lens = pad_batch([pairs[i][0] for i in sel])
-        yp, _ = pad_batch([pairs[i][1] for i in sel])
-        raw, mapped = fn(torch.from_numpy(xp).cuda(), torch.from_numpy(yp).cuda(), lengths=torch.from_numpy(lens))[:2]
+    out = [None] * len(enhanced_list)
+    for k in range(0, len(enhanced_list), max_batch):
+        sel = list(range(k, min(k + max_batch, len(enhanced_list))))
+        dev = _triples_on_device(clean_root, noise_root, [enhanced_list[i] for i in sel], drc) if torch.cuda.is_available() else None
+        if dev is not None:
+            x, y, lens = dev
+        else:
+            pairs = [_triple(clean_root, noise_root, enhanced_list[i], drc) for i in sel]
+            xp, lens = pad_batch([p[0] for p in pairs])
+            yp, _ = pad_batch([p[1] for p in pairs])
+            x, y = torch.from_numpy(xp).cuda(), torch.from_numpy(yp).cuda()
+        raw, mapped = fn(x, y, lengths=torch.from_numpy(lens))[:2]
         vals = (mapped if norm else raw).double().cpu().numpy()
         for i, v in zip(sel, vals):
             if not np.isfinite(v):

@@ -53,6 +53,24 @@ def test_read_batch_metrics_from_files_vs_oracle(tree):
             assert v == pytest.approx(ref, rel=2e-4, abs=2e-4)
 
 
+def test_read_batch_from_device_side_triples_equals_the_per_file_readers(tree, monkeypatch):
+    """read_batch_*: PCM_16 files are read a group per library call and paired / mixed on the GPU; the same list read file by file on the
+    host (the path other wav flavours take) gives the same pairs bit for bit and the same scores."""
+    from nele_gan_amd import dataio
+    clean_root, noise_root, names = tree
+    x, y, lens = dataio._triples_on_device(clean_root, noise_root, names, False)
+    for k, en in enumerate(names):
+        c, e = dataio._triple(clean_root, noise_root, en, False)
+        assert lens[k] == len(c)
+        np.testing.assert_array_equal(x[k, :lens[k]].cpu().numpy(), c)
+        np.testing.assert_array_equal(y[k, :lens[k]].cpu().numpy(), e)
+        assert not x[k, lens[k]:].any() and not y[k, lens[k]:].any()
+    fast = dataio.read_batch_SIIB(clean_root, noise_root, names, norm=False)
+    monkeypatch.setattr(dataio, '_triples_on_device', lambda *a, **k: None)
+    slow = dataio.read_batch_SIIB(clean_root, noise_root, names, norm=False)
+    assert fast == pytest.approx(slow, rel=1e-9)
+
+
 def test_drc_variant_uses_the_enhanced_files_own_name(tree, tmp_path):
     from nele_gan_amd import dataio
     clean_root, noise_root, names = tree
