@@ -229,6 +229,13 @@ long long nele_conv16_wfrag_elems(int N, int seglen, int KH);
 int nele_conv16_weight_prep_batch(const void* const* ptrs_host, const int* dims_host, int jobs, void* stream);
 int nele_conv16(const void* A16, const void* Wfrag, const float* bias, const void* aux16, void* out, int out_bf16, int M, int N, int epi,
                 float slope, const int* geom_host, int KH, int KW, void* stream);
+/* The last conv layer with the pooling fused into its epilogue (model.py:109,121-123: Conv2d -> LeakyReLU -> AdaptiveAvgPool2d(1)): out16
+ * [B][Hout][Wout][N] bf16 = LeakyReLU(conv + bias) (kept for the backward pass's LeakyReLU mask); gap_part [B][parts][N] float64 = sums of the
+ * float32 LeakyReLU outputs over each wave's positions with column < wvalid[b] (wvalid [B] int32 device memory or NULL: every column);
+ * parts = nele_conv16_gap_parts(N, geom, KH, KW) (0: unsupported geometry).  nele_gap_mlp_fwd_parts adds them in a fixed order. */
+int nele_conv16_gap_parts(int N, const int* geom_host, int KH, int KW);
+int nele_conv16_gap(const void* A16, const void* Wfrag, const float* bias, void* out16, int M, int N, float slope, const int* geom_host, int KH,
+                    int KW, const int* wvalid, double* gap_part, void* stream);
 /* The discriminator's first layer (1 x 1 Conv2d, 3 (+1 zero) -> 8 channels, model.py:105): in [M][4] float32 (the packed D input),
  * Wf [8][4] float32 (nele_weight_prep's forward layout), out16 [M][8] bf16 = LeakyReLU(W in + bias), exact float32 arithmetic. */
 int nele_conv16_pointwise_fwd(const float* in, const float* Wf, const float* bias, void* out16, long long M, int N, float slope, void* stream);
@@ -333,6 +340,13 @@ int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h
 int nele_gap_mlp_bwd_var16(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
                            const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
                            int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream);
+/* ... with the last conv layer's activation as bf16 as well (nele_conv16_gap's out16) */
+int nele_gap_mlp_bwd_var16a(const float* dscore, const float* score, const float* h1, const float* h2, const void* act16,
+                            const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                            int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream);
+/* The head of nele_gap_mlp_fwd_var alone, on pooled partial sums [B][nparts][64] float64 the producing conv kernel wrote (nele_conv16_gap) */
+int nele_gap_mlp_fwd_parts(const double* part, int nparts, int B, int P, int Wout, const int* wvalid, const float* const* mlp_host, int nout,
+                           float slope, float* pooled, float* h1, float* h2, float* score, void* stream);
 int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream);
 
 /* torch.optim.Adam (train_nele.py:89-91) on flat buffers; step counts from 1. */

@@ -54,6 +54,8 @@ struct Conv16Args {
     int RSP, NR;               // row stride in LDS (elements), ring rows
     int lgC, swz_sh, swz_mask; // unit u of position q sits at unit u ^ ((q >> swz_sh) & swz_mask) (C = 1 << lgC when swz_mask != 0)
     int ntiles, TH;
+    double* gap;               // pooled partial sums [B][parts][N] (EPI_BIAS_LRELU only; NULL = none), parts = tiles per image * 4 waves
+    const int* wvalid;         // valid output width per image for the pooling (NULL = Wout)
     ConvGeom g;
 };
 
@@ -248,6 +250,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
 #pragma unroll
         for (int q = 0; q < 4 * TN; ++q)
             bv[q] = ((p.epi == EPI_BIAS || p.epi == EPI_BIAS_LRELU) && n0 + q < p.N) ? p.bias[n0 + q] : 0.f;
+        // global average pooling fused into the last layer's forward pass (model.py:123 AdaptiveAvgPool2d(1) on the LeakyReLU output): every
+        // lane sums its positions' float32 results in float64; the 16 lanes of a channel group are added below and each wave stores one
+        // partial per channel - the consumer (gap_mlp_fwd_parts) adds the partials of an image in a fixed order
+        const bool pool = p.gap != nullptr;
+        const int wpool = pool ? (p.wvalid ? min(p.wvalid[b], g.Wout) : g.Wout) : 0;
+        double gs[4 * TN];
+#pragma unroll
+        for (int q = 0; q < 4 * TN; ++q) gs[q] = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int ho = ho0 + prow[k], wo = wo0 + 16 * pcol[k] + li;
@@ -260,6 +270,10 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             if (p.epi == EPI_BIAS_LRELU) {
 #pragma unroll
                 for (int q = 0; q < 4 * TN; ++q) v[q] = v[q] > 0.f ? v[q] : p.slope * v[q];
+                if (pool && wo < wpool) {
+#pragma unroll
+                    for (int q = 0; q < 4 * TN; ++q) gs[q] += (double)v[q];
+                }
             } else if (p.epi == EPI_MASK_LRELU_GRAD) {
                 const __bf16* xp = p.aux + (((size_t)b * g.Hout + ho) * g.Wout + wo) * p.N + n0;
 #pragma unroll
@@ -288,6 +302,20 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (n0 + 4 * j < p.N) *reinterpret_cast<float4*>(op + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            }
+        }
+        if (pool) {
+            const int ntw_ = (g.Wout + C16_TW - 1) / C16_TW, nth_ = (g.Hout + TH - 1) / TH;
+            const int part = ((ho0 / TH) * ntw_ + wo0 / C16_TW) * 4 + wave;
+            double* gp = p.gap + ((size_t)b * (ntw_ * nth_ * 4) + part) * p.N + n0;
+#pragma unroll
+            for (int q = 0; q < 4 * TN; ++q) {
+                double t = gs[q];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                if (li == 0 && n0 + q < p.N) gp[q] = t;
             }
         }
         C16_T(t_end);
@@ -464,8 +492,8 @@ static void c16_launch(const Conv16Args& a, dim3 grid, size_t lds, hipStream_t s
 
 // A16 [B][H][W][C] bf16, Wfrag from nele_conv16_weight_prep_batch, out bf16 (out_bf16 != 0) or float32; aux16: forward activation
 // (bf16, [B][Hout][Wout][N]) for EPI_MASK_LRELU_GRAD.  Reference op: F.conv2d + LeakyReLU (model.py:118-122) / its autograd.
-extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias, const void* aux16, void* out, int out_bf16, int M, int N, int epi,
-                           float slope, const int* geom, int KH, int KW, void* stream) {
+static int conv16_impl(const void* A16, const void* Wfrag, const float* bias, const void* aux16, void* out, int out_bf16, int M, int N, int epi,
+                       float slope, const int* geom, int KH, int KW, const int* wvalid, double* gap_part, void* stream) {
     NELE_CHECK_ARG(A16 && Wfrag && out && geom, "nele_conv16: null pointer");
     ConvGeom g;
     memcpy(&g, geom, sizeof(ConvGeom));
@@ -481,6 +509,7 @@ extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias
     a.A = (const __bf16*)A16; a.Wfrag = (const __bf16*)Wfrag; a.bias = bias; a.aux = (const __bf16*)aux16; a.out = out;
     a.N = N; a.epi = epi; a.slope = slope; a.KH = KH; a.KW = KW; a.sps = pl.sps; a.nsteps = KH * pl.sps;
     a.RSP = pl.RSP; a.NR = pl.NR; a.lgC = pl.lgC; a.swz_sh = pl.swz_sh; a.swz_mask = pl.swz_mask; a.TH = pl.TH; a.g = g;
+    a.gap = gap_part; a.wvalid = wvalid;
     a.ntiles = ((g.Wout + C16_TW - 1) / C16_TW) * ((g.Hout + pl.TH - 1) / pl.TH) * B;
     const dim3 grid((unsigned)((a.ntiles + 7) / 8 * 8));
     hipStream_t s = as_stream(stream);
@@ -494,4 +523,28 @@ extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias
 #undef C16_GO
     NELE_CHECK_LAUNCH("conv16_kernel");
     return NELE_OK;
+}
+
+extern "C" int nele_conv16(const void* A16, const void* Wfrag, const float* bias, const void* aux16, void* out, int out_bf16, int M, int N, int epi,
+                           float slope, const int* geom, int KH, int KW, void* stream) {
+    return conv16_impl(A16, Wfrag, bias, aux16, out, out_bf16, M, N, epi, slope, geom, KH, KW, nullptr, nullptr, stream);
+}
+
+// Partial sums per image that nele_conv16_gap writes for this geometry (tiles per image x 4 waves); 0 = unsupported geometry
+extern "C" int nele_conv16_gap_parts(int N, const int* geom, int KH, int KW) {
+    if (!geom) return 0;
+    ConvGeom g;
+    memcpy(&g, geom, sizeof(ConvGeom));
+    C16Plan pl;
+    if (!c16_plan(N, g, KH, KW, &pl, EPI_BIAS_LRELU)) return 0;
+    return ((g.Wout + C16_TW - 1) / C16_TW) * ((g.Hout + pl.TH - 1) / pl.TH) * 4;
+}
+
+// The discriminator's last conv layer with the pooling fused (model.py:109,121-123: Conv2d -> LeakyReLU -> AdaptiveAvgPool2d(1)): out16 =
+// bf16(LeakyReLU(conv + bias)) [B][Hout][Wout][N] (kept for the backward pass's LeakyReLU mask), gap_part [B][parts][N] float64 = sums of the
+// float32 LeakyReLU outputs over each wave's positions with column < wvalid[b] (wvalid NULL: all); parts = nele_conv16_gap_parts().
+extern "C" int nele_conv16_gap(const void* A16, const void* Wfrag, const float* bias, void* out16, int M, int N, float slope, const int* geom, int KH,
+                               int KW, const int* wvalid, double* gap_part, void* stream) {
+    NELE_CHECK_ARG(gap_part, "nele_conv16_gap: null pointer");
+    return conv16_impl(A16, Wfrag, bias, nullptr, out16, 1, M, N, EPI_BIAS_LRELU, slope, geom, KH, KW, wvalid, gap_part, stream);
 }

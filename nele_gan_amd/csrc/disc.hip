@@ -135,13 +135,13 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restric
 // One block per utterance: finish the pooling from the partial sums, then the 3-layer head.
 __global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const double* __restrict__ part, int P, MlpW w, int nout, float slope,
                                                           float* __restrict__ pooled, float* __restrict__ h1, float* __restrict__ h2,
-                                                          float* __restrict__ score, int Wout, const int* __restrict__ wvalid) {
+                                                          float* __restrict__ score, int Wout, const int* __restrict__ wvalid, int nparts) {
     __shared__ float sp[64], sh1[64], sh2[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (wvalid) P = (P / Wout) * min(wvalid[b], Wout);
     if (tid < 64) {
         double s = 0.0;
-        for (int ch = 0; ch < GAP_CHUNKS; ++ch) s += part[((size_t)b * GAP_CHUNKS + ch) * 64 + tid];
+        for (int ch = 0; ch < nparts; ++ch) s += part[((size_t)b * nparts + ch) * 64 + tid];
         const float m = (float)(s / (double)P);
         sp[tid] = m;
         pooled[(size_t)b * 64 + tid] = m;
@@ -221,8 +221,9 @@ __global__ __launch_bounds__(64) void mlp_bwd_kernel(const float* __restrict__ d
 // [B][OH][OW][64] at offset (oh0, ow0).
 // T = float, or __bf16: the consumers (the layer's data- and weight-gradient kernels) round their operands to bf16 anyway, and the data
 // gradient re-stages this buffer once per kernel row - half the bytes and no conversion there (see conv_span16_kernel).
-template <typename T>
-__global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, int Hout, int Wout, int OH, int OW,
+typedef __bf16 disc_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T, typename TA = float>
+__global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const TA* __restrict__ act, int Hout, int Wout, int OH, int OW,
                                int oh0, int ow0, float slope, T* __restrict__ gbuf, const int* __restrict__ wvalid) {
     const int b = blockIdx.y, P = Hout * Wout;
     const int wv = wvalid ? min(wvalid[b], Wout) : Wout;
@@ -231,7 +232,13 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, const float* _
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P * 16; i += gridDim.x * blockDim.x) {
         const int pos = i >> 4, c = (i & 15) * 4;
         const int ho = pos / Wout, wo = pos - ho * Wout;
-        const float4 a = *reinterpret_cast<const float4*>(act + ((size_t)b * P + pos) * 64 + c);
+        float4 a;
+        if constexpr (sizeof(TA) == 2) {                       // bf16 activation (the LeakyReLU mask only needs its sign): one 8-byte load
+            const disc_bf16x4 h = *reinterpret_cast<const disc_bf16x4*>(act + ((size_t)b * P + pos) * 64 + c);
+            a = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+            a = *reinterpret_cast<const float4*>(act + ((size_t)b * P + pos) * 64 + c);
+        }
         const float4 dp = *reinterpret_cast<const float4*>(dpooled + (size_t)b * 64 + c);
         const bool in = wo < wv;
         const float d0 = in ? dp.x * invP * (a.x > 0.f ? 1.f : slope) : 0.f, d1 = in ? dp.y * invP * (a.y > 0.f ? 1.f : slope) : 0.f;
@@ -376,13 +383,26 @@ extern "C" int nele_gap_mlp_fwd_var(const float* act, int B, int P, int Wout, co
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
     hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, as_stream(stream), act, P, scratch, Wout, wvalid);
-    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), scratch, P, w, nout, slope, pooled, h1, h2, score, Wout, wvalid);
+    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), scratch, P, w, nout, slope, pooled, h1, h2, score, Wout, wvalid, GAP_CHUNKS);
     NELE_CHECK_LAUNCH("nele_gap_mlp_fwd");
     return NELE_OK;
 }
 extern "C" int nele_gap_mlp_fwd(const float* act, int B, int P, const float* const* mlp_host, int nout, float slope, float* pooled, float* h1,
                                 float* h2, float* score, double* scratch, void* stream) {
     return nele_gap_mlp_fwd_var(act, B, P, P, nullptr, mlp_host, nout, slope, pooled, h1, h2, score, scratch, stream);
+}
+
+// The head alone, on pooled partial sums the producing conv kernel already wrote (nele_conv16_gap): part [B][nparts][64] float64.
+extern "C" int nele_gap_mlp_fwd_parts(const double* part, int nparts, int B, int P, int Wout, const int* wvalid, const float* const* mlp_host, int nout,
+                                      float slope, float* pooled, float* h1, float* h2, float* score, void* stream) {
+    NELE_CHECK_ARG(part && nparts > 0 && mlp_host && pooled && h1 && h2 && score && B > 0 && P > 0, "nele_gap_mlp_fwd_parts: bad arguments");
+    NELE_CHECK_ARG(nout >= 1 && nout <= 4, "nele_gap_mlp_fwd_parts: nout");
+    NELE_CHECK_ARG(Wout > 0 && P % Wout == 0, "nele_gap_mlp_fwd_parts: P=%d is not a multiple of the output width %d", P, Wout);
+    const float* const* mlp = mlp_host;
+    MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
+    hipLaunchKernelGGL(gap_mlp_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), part, P, w, nout, slope, pooled, h1, h2, score, Wout, wvalid, nparts);
+    NELE_CHECK_LAUNCH("nele_gap_mlp_fwd_parts");
+    return NELE_OK;
 }
 
 extern "C" int nele_gap_mlp_bwd_var(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
@@ -394,9 +414,10 @@ extern "C" int nele_gap_mlp_bwd(const float* dscore, const float* score, const f
     return nele_gap_mlp_bwd_var(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, nullptr, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled,
                                 gbuf, stream);
 }
-static int gap_mlp_bwd_impl(const float* dscore, const float* score, const float* h1, const float* h2, const float* act,
+static int gap_mlp_bwd_impl(const float* dscore, const float* score, const float* h1, const float* h2, const void* act,
                             const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
-                            int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf, int gbuf_bf16, void* stream) {
+                            int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf, int gbuf_bf16, void* stream,
+                            int act_bf16 = 0) {
     NELE_CHECK_ARG(dscore && score && h1 && h2 && mlp_host && dz3 && dz2 && dz1 && dpooled && B > 0, "nele_gap_mlp_bwd: bad arguments");
     const float* const* mlp = mlp_host;
     MlpW w = {mlp[0], mlp[1], mlp[2], mlp[3], mlp[4], mlp[5], mlp[6], mlp[7], mlp[8]};
@@ -406,10 +427,12 @@ static int gap_mlp_bwd_impl(const float* dscore, const float* score, const float
     if (gbuf) {
         NELE_CHECK_ARG(act, "nele_gap_mlp_bwd: act required for the pooling gradient");
         const int P = Hout * Wout;
-        if (gbuf_bf16) hipLaunchKernelGGL(gap_bwd_kernel<__bf16>, dim3(min(512, (P * 16 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout,
-                                          OH, OW, oh0, ow0, slope, (__bf16*)gbuf, wvalid);
-        else hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(min(512, (P * 16 + 255) / 256), B), dim3(256), 0, s, dpooled, act, Hout, Wout, OH, OW, oh0,
-                                ow0, slope, (float*)gbuf, wvalid);
+        if (gbuf_bf16 && act_bf16) hipLaunchKernelGGL((gap_bwd_kernel<__bf16, __bf16>), dim3(min(512, (P * 16 + 255) / 256), B), dim3(256), 0, s, dpooled,
+                                                      (const __bf16*)act, Hout, Wout, OH, OW, oh0, ow0, slope, (__bf16*)gbuf, wvalid);
+        else if (gbuf_bf16) hipLaunchKernelGGL((gap_bwd_kernel<__bf16, float>), dim3(min(512, (P * 16 + 255) / 256), B), dim3(256), 0, s, dpooled,
+                                               (const float*)act, Hout, Wout, OH, OW, oh0, ow0, slope, (__bf16*)gbuf, wvalid);
+        else hipLaunchKernelGGL((gap_bwd_kernel<float, float>), dim3(min(512, (P * 16 + 255) / 256), B), dim3(256), 0, s, dpooled, (const float*)act, Hout,
+                                Wout, OH, OW, oh0, ow0, slope, (float*)gbuf, wvalid);
         NELE_CHECK_LAUNCH("nele_gap_mlp_bwd(gap)");
     }
     return NELE_OK;
@@ -425,6 +448,14 @@ extern "C" int nele_gap_mlp_bwd_var16(const float* dscore, const float* score, c
                                       int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream) {
     return gap_mlp_bwd_impl(dscore, score, h1, h2, act, mlp_host, nout, slope, B, Hout, Wout, wvalid, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled, gbuf16,
                             1, stream);
+}
+
+// ... with the last conv layer's activation as bf16 too (nele_conv16_gap's out16: the mask only needs the sign)
+extern "C" int nele_gap_mlp_bwd_var16a(const float* dscore, const float* score, const float* h1, const float* h2, const void* act16,
+                                       const float* const* mlp_host, int nout, float slope, int B, int Hout, int Wout, const int* wvalid, int OH, int OW,
+                                       int oh0, int ow0, float* dz3, float* dz2, float* dz1, float* dpooled, void* gbuf16, void* stream) {
+    return gap_mlp_bwd_impl(dscore, score, h1, h2, act16, mlp_host, nout, slope, B, Hout, Wout, wvalid, OH, OW, oh0, ow0, dz3, dz2, dz1, dpooled, gbuf16,
+                            1, stream, 1);
 }
 
 extern "C" int nele_mlp_wgrad(const float* dz, const float* x, int B, int N, int K, float* dW, float* db, void* stream) {

@@ -655,7 +655,9 @@ class _DBuffers:
                                         ops.wgrad_tile_supported(B, _D_CONVS[l][0], self.gw[l]) for l in range(1, nl))
         b16 = torch.bfloat16
         for l, (ashape, gshape) in enumerate(shapes):
-            a16, g16 = self.c16 and l < nl - 1, self.c16 and l >= 1
+            # (the last layer's activation too: its pooling happens in the conv kernel's epilogue on the float32 results - nele_conv16_gap -
+            #  and the backward pass only needs the sign of the stored value)
+            a16, g16 = self.c16, self.c16 and l >= 1
             self.act.append(torch.empty(ashape, dtype=b16 if a16 else torch.float32, device=dev))
             # zero-bordered gradient buffer of this layer's OUTPUT
             self.gbuf.append(torch.zeros(gshape, dtype=b16 if g16 else torch.float32, device=dev))
@@ -668,6 +670,8 @@ class _DBuffers:
         self.grad16_ok = (not self.c16) and ops.grad16_supported(B, cins[-1], self.gb[-1], _D_CONVS[-1][0], self.gw[-1])
         self.gbuf16 = None
         self.P = self.dims[-1][0] * self.dims[-1][1]
+        self.gap_parts = ops.conv16_gap_parts(_D_CONVS[-1][0], self.gf[-1]) if self.c16 else 0
+        self.gap_part = torch.empty((B, self.gap_parts, 64), dtype=torch.float64, device=dev) if self.c16 else None
         self.pooled, self.h1, self.h2 = _empty((B, 64), dev), _empty((B, 64), dev), _empty((B, 16), dev)
         self.dz1, self.dz2, self.dz3, self.dpooled = _empty((B, 64), dev), _empty((B, 16), dev), _empty((B, 4), dev), _empty((B, 64), dev)
         nws = max(ops.wgrad_workspace_floats(B, cout, g) for (cout, k), g in zip(_D_CONVS, self.gw))
@@ -928,6 +932,9 @@ class _DiscriminatorBase(nn.Module):
                 # bf16 activations in memory: conv1 as a float32 pointwise stream, conv2..conv5 on the ring / DMA tile kernel
                 if l == 0:
                     ops.conv16_pointwise_fwd(a, w['wf'][0], self.layers[0].bias, bf.act[0])
+                elif l == len(_D_CONVS) - 1:
+                    ops.conv16_gap(a, w['wf16c'][l], self.layers[l].bias, bf.act[l], B, cout, bf.gf[l], bf.wvalid, bf.gap_part,
+                                   tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
                 else:
                     ops.conv16(a, w['wf16c'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l],
                                tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
@@ -938,8 +945,12 @@ class _DiscriminatorBase(nn.Module):
             else:
                 ops.conv_gemm(a, w['wf'][l], self.layers[l].bias, None, bf.act[l], B, cout, EPI_BIAS_LRELU, bf.gf[l], tag=self.profile_prefix + 'D.conv%d.fwd' % (l + 1))
             a = bf.act[l]
-        call('nele_gap_mlp_fwd_var', ptr(a), B, bf.P, bf.dims[-1][1], ptr(bf.wvalid), self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1),
-             ptr(bf.h2), ptr(score), ptr(bf.scratch64), stream())
+        if bf.c16:
+            call('nele_gap_mlp_fwd_parts', ptr(bf.gap_part), bf.gap_parts, B, bf.P, bf.dims[-1][1], ptr(bf.wvalid), self._mlp_ptrs(w), self._nout, SLOPE,
+                 ptr(bf.pooled), ptr(bf.h1), ptr(bf.h2), ptr(score), stream())
+        else:
+            call('nele_gap_mlp_fwd_var', ptr(a), B, bf.P, bf.dims[-1][1], ptr(bf.wvalid), self._mlp_ptrs(w), self._nout, SLOPE, ptr(bf.pooled), ptr(bf.h1),
+                 ptr(bf.h2), ptr(score), ptr(bf.scratch64), stream())
 
     def forward_packed(self, din, frames=None):
         """din: channels-last [B,64,T,4] (ops.d_pack / energy-norm output).  frames [B] (optional): STFT frames of each utterance
@@ -988,7 +999,7 @@ class _DiscriminatorBase(nn.Module):
         Ho, Wo, _ = bf.dims[-1]
         p5 = bf.pad[-1]
         glast = bf.gbuf16 if (g16 and not bf.c16) else bf.gbuf[-1]      # the last layer's output gradient, as its two consumers read it
-        call('nele_gap_mlp_bwd_var16' if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
+        call(('nele_gap_mlp_bwd_var16a' if bf.c16 else 'nele_gap_mlp_bwd_var16') if g16 else 'nele_gap_mlp_bwd_var', ptr(dscore), ptr(score), ptr(bf.h1), ptr(bf.h2), ptr(bf.act[-1]),
              self._mlp_ptrs(w), nout, SLOPE, B, Ho, Wo, ptr(wvalid), Ho + 2 * p5, Wo + 2 * p5, p5, p5, ptr(bf.dz3), ptr(bf.dz2), ptr(bf.dz1),
              ptr(bf.dpooled), ptr(glast), stream())
         # The data-gradient chain (layer l's needs layer l+1's) stays on the current stream; a layer's weight gradient (+ its

@@ -31,6 +31,8 @@ _SIGS = {
     'nele_conv16_weight_prep_batch': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P],
     'nele_conv16': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, _P],
     'nele_conv16_pointwise_fwd': [_P, _P, _P, _P, c_longlong, c_int, c_float, _P],
+    'nele_conv16_gap': [_P, _P, _P, _P, c_int, c_int, c_float, ctypes.POINTER(c_int), c_int, c_int, _P, _P, _P],
+    'nele_conv16_gap_parts': [c_int, ctypes.POINTER(c_int), c_int, c_int],
     'nele_conv_wgrad_bf16_a16d16': [_P, _P, _P, c_longlong, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, _P, _P, c_int, _P],
     'nele_g_pack': [_P, _P, _P, c_int, c_int, c_int, _P],
     'nele_g_pack16': [_P, _P, _P, c_int, c_int, c_int, _P],
@@ -61,6 +63,9 @@ _SIGS = {
                              c_int, _P, _P, _P, _P, _P, _P],
     'nele_gap_mlp_bwd_var16': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, _P, c_int, c_int, c_int,
                                c_int, _P, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_bwd_var16a': [_P, _P, _P, _P, _P, ctypes.POINTER(c_void_p), c_int, c_float, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                                c_int, _P, _P, _P, _P, _P, _P],
+    'nele_gap_mlp_fwd_parts': [_P, c_int, c_int, c_int, c_int, _P, ctypes.POINTER(c_void_p), c_int, c_float, _P, _P, _P, _P, _P],
     'nele_mlp_wgrad': [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     'nele_adam_step': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P],
     'nele_adam_step_guarded': [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P, _P],
@@ -269,6 +274,27 @@ def conv16(A16, Wfrag, bias, aux16, out, B, N, epi, g, tag=None):
         e0.record()
     call('nele_conv16', ptr(A16), ptr(Wfrag), ptr(bias), ptr(aux16), ptr(out), int(out.dtype == torch.bfloat16), M, N, epi, SLOPE, g.arr, g.KH, g.KW,
          stream())
+    if prof:
+        e1.record()
+        PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))
+
+
+def conv16_gap_parts(N, g):
+    """Pooled partial sums per image that conv16_gap writes for this geometry (0: unsupported)"""
+    return int(_lib.lib.nele_conv16_gap_parts(N, g.arr, g.KH, g.KW))
+
+
+def conv16_gap(A16, Wfrag, bias, out16, B, N, g, wvalid, gap_part, tag=None):
+    """The last conv layer with the global average pooling fused (model.py:109,121-123): out16 = bf16(LeakyReLU(conv + bias)),
+    gap_part [B][parts][N] float64 pooled partial sums over each image's valid columns."""
+    M = B * g.Hout * g.Wout
+    if A16.dtype != torch.bfloat16 or out16.dtype != torch.bfloat16 or gap_part.dtype != torch.float64:
+        raise ValueError('conv16_gap: bfloat16 activations and float64 partial sums')
+    prof = PROFILE is not None and tag in PROFILE
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call('nele_conv16_gap', ptr(A16), ptr(Wfrag), ptr(bias), ptr(out16), M, N, SLOPE, g.arr, g.KH, g.KW, ptr(wvalid), ptr(gap_part), stream())
     if prof:
         e1.record()
         PROFILE[tag].append((e0, e1, 2.0 * M * N * g.Ktot))

@@ -336,13 +336,15 @@ def test_bf16_activations_in_memory_change_nothing_but_the_bias_gradients(mods, 
         score.pow(2).sum().backward()
         bf = next(iter(D._bufs.values()))
         assert bf.c16 == (flag == '1')
-        assert (bf.act[0].dtype == torch.bfloat16) == (flag == '1') and bf.act[4].dtype == torch.float32 and bf.gbuf[0].dtype == torch.float32
+        assert (bf.act[0].dtype == torch.bfloat16) == (flag == '1') and (bf.act[4].dtype == torch.bfloat16) == (flag == '1') and bf.gbuf[0].dtype == torch.float32
         res[flag] = (score.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None},
-                     [a.float().clone() for a in bf.act])
-    s1, gin1, g1, a1 = res['1']
-    s0, gin0, g0, a0 = res['0']
+                     [a.float().clone() for a in bf.act], bf.pooled.clone())
+    s1, gin1, g1, a1, p1 = res['1']
+    s0, gin0, g0, a0, p0 = res['0']
+    # the pooling fused into conv5's epilogue (per-wave float64 partial sums of the float32 results) against the separate pooling pass
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
     for l in range(5):                                      # activations: what is stored is the bf16 rounding of what the float32 path stores
-        assert torch.equal(a1[l], a0[l].bfloat16().float() if l < 4 else a0[l]), 'activation of conv%d' % (l + 1)
+        assert torch.equal(a1[l], a0[l].bfloat16().float()), 'activation of conv%d' % (l + 1)      # (conv5 too: pooled from the float32 results in the conv kernel)
     assert torch.equal(s1, s0) and torch.equal(gin1, gin0)
     for k in g0:
         if '.bias' in k and k.startswith('layers.') and not k.startswith('layers.0.'):
