@@ -419,7 +419,7 @@ static bool c16_plan(int N, const ConvGeom& g, int KH, int KW, C16Plan* pl, int 
     const int nsteps = KH * q.sps;
     // tile rows: 8 where the layer is bound by memory (little work per staged byte) and the registers / LDS allow, else 4
     const int th_env = NELE_SWITCH_INT("NELE_CONV16_TH", 0);
-    int th = (nsteps * q.TN <= 64 && q.TN <= 2) ? 8 : 4;      // (TN >= 3 with 8 rows does not fit 256 registers)
+    int th = (nsteps * q.TN <= 64 && q.TN <= 2) ? 8 : 4;      // (TN >= 3 with 8 rows: 256 registers, fragments no longer double-buffered - D.conv5 forward 1.54 against 1.30 ms)
     // ... except for data gradients: their epilogue loads the forward activation for the LeakyReLU mask, and twice the workgroups hide that
     // latency better than 8-row tiles save prologues (conv3's data gradient 0.285 -> 0.222 ms, conv2's 0.137 -> 0.118 at B = 256; the
     // forward passes of the same layers lose 4 - 8 % with 4 rows)
