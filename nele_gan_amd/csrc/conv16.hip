@@ -310,11 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(Conv16Args p) {
             double* gp = p.gap + ((size_t)b * (ntw_ * nth_ * 4) + part) * p.N + n0;
 #pragma unroll
             for (int q = 0; q < 4 * TN; ++q) {
-                double t = gs[q];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                t += __shfl_xor(t, 8);
+                const double t = row16_sum_dpp(gs[q]);      // (DPP row operations: no traffic through the LDS crossbar this kernel is bound by)
                 if (li == 0 && n0 + q < p.N) gp[q] = t;
             }
         }

@@ -139,12 +139,20 @@ __global__ __launch_bounds__(256) void gap_mlp_fwd_kernel(const double* __restri
     __shared__ float sp[64], sh1[64], sh2[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (wvalid) P = (P / Wout) * min(wvalid[b], Wout);
-    if (tid < 64) {
+    {   // partial sums: four runs of consecutive partials per channel (one per wave), added in run order - the same association for every batch
+        __shared__ double sq[4][64];
+        const int c = tid & 63, q = tid >> 6, per = (nparts + 3) >> 2;
+        const int c0 = q * per, c1 = min(nparts, c0 + per);
         double s = 0.0;
-        for (int ch = 0; ch < nparts; ++ch) s += part[((size_t)b * nparts + ch) * 64 + tid];
-        const float m = (float)(s / (double)P);
-        sp[tid] = m;
-        pooled[(size_t)b * 64 + tid] = m;
+        for (int ch = c0; ch < c1; ++ch) s += part[((size_t)b * nparts + ch) * 64 + c];
+        sq[q][c] = s;
+        __syncthreads();
+        if (tid < 64) {
+            const double t = (sq[0][tid] + sq[1][tid]) + (sq[2][tid] + sq[3][tid]);
+            const float m = (float)(t / (double)P);
+            sp[tid] = m;
+            pooled[(size_t)b * 64 + tid] = m;
+        }
     }
     __syncthreads();
     if (tid < 64) {
