@@ -9,7 +9,8 @@ M = sys.argv[2] if len(sys.argv) > 2 else 'siib&estoi'
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 tr = GanTrainer(target_metric=M)
 tr.D.precision = 'bf16'; tr.G.precision = 'bf16'
-c, v = synth.batch(B, 64000, start=0)
+LEN = int(os.environ.get('PIPE_LEN', '64000'))
+c, v = synth.batch(B, LEN, start=0)
 cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
 for mode in (sys.argv[4].split(',') if len(sys.argv) > 4 else ('plain', 'late', 'early', 'plain', 'early')):
     pre = None
@@ -25,5 +26,5 @@ for mode in (sys.argv[4].split(',') if len(sys.argv) > 4 else ('plain', 'late', 
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(N): one()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print('B=%d %s %-6s %.3f ms/step (host enqueue %.3f)' % (B, M, mode, (t2 - t0) / N * 1e3, (t1 - t0) / N * 1e3))
+    print('B=%d L=%d %s %-6s %.3f ms/step (host enqueue %.3f)' % (B, LEN, M, mode, (t2 - t0) / N * 1e3, (t1 - t0) / N * 1e3))
 tr.check_status()
