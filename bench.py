@@ -695,7 +695,7 @@ def main():
                         PROFILE_ROUND, tj.get('csrc_sha'), csrc_sha())
         except Exception:
             pmc = {}
-        ckey = 'conv16_kernel<4, 4, false>'                    # D.conv5 forward: 48 -> 64 channels (TN = 4), 4-row tiles, float32 output
+        ckey = 'conv16_kernel<4, 4, true>'                     # D.conv5 forward: 48 -> 64 channels (TN = 4), 4-row tiles, bf16 output + pooled partial sums (nele_conv16_gap)
         traffic = pmc.get(ckey, {}).get('hbm_bytes_corrected')
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / max(1, len(prof))
         flops = prof[0][2] if prof else 0.0
@@ -715,7 +715,7 @@ def main():
                        'global_batch': a.batch * world, 'samples_per_utterance': a.length, 'frames': T, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma',
                          'kernel': '%s (%s: implicit-GEMM Conv2d 48->64 9x9, %s MFMA operands, f32 accumulate, M=%d N=64 K=3888)' % (
-                             'conv16_kernel<4,4,false>' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
+                             'conv16_kernel<4,4,true> via nele_conv16_gap' if a.precision == 'bf16' else 'conv_span_kernel<4>', tag, a.precision, a.batch * 44 * (T - 20)),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'mfma_busy_frac': pmc.get(ckey, {}).get('mfma_busy_frac'), 'launch_ms': kernel_ms,
                          'launch_ms_gstep': sum(e0.elapsed_time(e1) for e0, e1, _ in prof_g) / max(1, len(prof_g)),   # beside the half-GPU tridiagonalisation
