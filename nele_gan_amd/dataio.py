@@ -19,11 +19,8 @@ import numpy as np
 
 fs = 16000
 power_law = (1 / 6)
-try:                                                   # host-side C helper of libnele_hip.so (no GPU needed to call it)
-    from ._lib import lib as _nele_lib
-    _native_decode = _nele_lib.nele_wav_decode_pcm16
-except Exception:                                      # pragma: no cover
-    _native_decode = None
+from ._lib import lib as _nele_lib                     # host-side entry points of libnele_hip.so (no GPU needed to call them; no library, no package)
+_native_decode = _nele_lib.nele_wav_decode_pcm16
 
 
 # ------------------------------------------------------------------------------------------------ wav files
