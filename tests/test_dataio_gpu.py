@@ -133,6 +133,14 @@ def test_generated_samples_through_files_give_the_in_memory_targets(tmp_path):
     assert files[0].endswith('/temp/utt0@7.wav')
     back, _ = dataio.load(files[1])
     assert np.array_equal(back, enh[1].cpu().numpy())                        # bit-exact through the file
+    # the background batch writer (run_epoch's path) and the per-file Python writer store the same bytes, lengths cut to whole hops
+    lens = [L, L - 300, L - 1000]
+    bg = tr.write_samples(enh, names, str(tmp_path / 'out' / 'bg'), 7, lengths=lens, wait=False)
+    tr.flush_writes()
+    for k, pth in enumerate(bg):
+        ref_p = str(tmp_path / 'out' / ('ref%d.wav' % k))
+        dataio.write_wav_pcm16(ref_p, enh[k, :256 * (lens[k] // 256)].cpu().numpy(), quantised=True)
+        assert open(pth, 'rb').read() == open(ref_p, 'rb').read()
     siib = dataio.read_batch_SIIB(clean_root, noise_root, files, norm=True)
     estoi = dataio.read_batch_STOI(clean_root, noise_root, files, norm=True)
     np.testing.assert_allclose(np.stack([siib, estoi], 1), tgt, rtol=1e-6)
