@@ -54,7 +54,9 @@ void for_each_file(int n, int threads, F&& body) {
     };
     std::vector<std::thread> pool;
     pool.reserve(threads - 1);
-    for (int t = 1; t < threads; ++t) pool.emplace_back(loop);
+    for (int t = 1; t < threads; ++t) {
+        try { pool.emplace_back(loop); } catch (...) { break; }      // no more threads to be had: the ones that started share the files
+    }
     loop();
     for (auto& t : pool) t.join();
 }
