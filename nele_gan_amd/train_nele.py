@@ -440,10 +440,11 @@ class GanTrainer:
         din_q[..., 1] = din[..., 2]
         return din_q
 
-    def d_step(self, din, target, target_qua=None, weight=None, frames=None, has_qua=None):
+    def d_step(self, din, target, target_qua=None, weight=None, frames=None, has_qua=None, items=None):
         """One optimiser step of D on (din, target) - and of D_Qua on ([enh, clean], target_qua) when the quality discriminator is
         enabled and quality targets are given (train_nele.py:356-365).  ``weight``: number of items this rank contributes (d_epoch
         under data parallelism; None = plain mean over ranks); ``din=None`` = an empty step that only joins the collectives.
+        ``items``: the loss runs over the first ``items`` rows only (the rest are fill rows of a padded batch, _padded_chunks).
         ``has_qua``: whether THIS optimiser step includes D_Qua - under data parallelism it must be the same on every rank (the D_Qua
         all-reduce is a collective), so d_epoch decides it once per pass for all ranks; None = decide from ``target_qua`` (single rank)."""
         self._flush_d()
@@ -464,6 +465,10 @@ class GanTrainer:
                 score_qua = self.D_Qua.forward_packed(self.quality_inputs(din), frames)
             else:
                 self._advance_sn(self.D_Qua)
+        if items is not None and score is not None and items < score.shape[0]:
+            score, target = score[:items], target[:items]
+            if score_qua is not None:
+                score_qua, target_qua = score_qua[:items], target_qua[:items]
         loss = self._d_finish(score, target, weight)
         if has_qua:
             if score_qua is not None:
@@ -765,28 +770,39 @@ class GanTrainer:
 
     # ---------------------------------------------------------------- D epoch: 3 passes + replay (train_nele.py:342-426)
     @staticmethod
-    def _padded_chunks(lst, batch, round_to=16):
+    def _padded_chunks(lst, batch, round_to=16, fill=False):
         """Shuffled sample list -> batches of at most ``batch`` items in list order.  The reference trains D at batch 1 on utterances
         of any length (train_nele.py:349-367); here the items of a batch are zero-padded along the frame axis to the batch's longest
         (rounded up to a multiple of ``round_to`` so that few distinct buffer shapes occur) and carry their own frame counts, which
-        D's pooling honours (nele_gap_mlp_fwd_var).  -> list of (din [b,64,T,4], target [b,n], target_qua [b,2] | None, frames [b])."""
+        D's pooling honours (nele_gap_mlp_fwd_var).  -> list of (din [b,64,T,4], target [b,n], target_qua [b,2] | None, frames [b],
+        items): the loss runs over the first ``items`` rows.  ``fill``: the short last batch of a pass that has full ones is filled up to
+        ``batch`` rows with all-zero items (outside the loss: zero gradient rows) - the replay list grows every epoch, and a batch size
+        that has not occurred before costs a set of activation buffers and recorded passes (tens of milliseconds) for one step."""
         out = []
         for k in range(0, len(lst), batch):
             ch = lst[k:k + batch]
+            n = len(ch)
+            rows = batch if (fill and n < batch and len(lst) > batch) else n
             Ts = [int(c[0].shape[1]) for c in ch]
             Tm = (max(Ts) + round_to - 1) // round_to * round_to
             if all(t == Ts[0] for t in Ts):
+                Tm = Ts[0]
+            if rows == n and Tm == Ts[0] and all(t == Ts[0] for t in Ts):
                 din, frames = torch.stack([c[0] for c in ch]), None
             else:
-                din = ch[0][0].new_zeros((len(ch), 64, Tm, 4))
+                din = ch[0][0].new_zeros((rows, 64, Tm, 4))
                 for r, c in enumerate(ch):
                     din[r, :, :Ts[r]] = c[0]
-                frames = torch.tensor(Ts, dtype=torch.int32, device=din.device)
+                frames = None if all(t == Tm for t in Ts) else torch.tensor(Ts + [Tm] * (rows - n), dtype=torch.int32, device=din.device)
             hq = [len(c) > 2 and c[2] is not None for c in ch]
             if any(hq) != all(hq):
                 raise ValueError("d_epoch: quality targets must be given for every sample of a pass or for none")
-            tq = torch.stack([c[2] for c in ch]) if hq[0] else None
-            out.append((din, torch.stack([c[1] for c in ch]), tq, frames))
+
+            def rows_of(ts):
+                t = torch.stack(ts)
+                return t if rows == n else torch.cat([t, t.new_zeros((rows - n,) + tuple(t.shape[1:]))])
+            tq = rows_of([c[2] for c in ch]) if hq[0] else None
+            out.append((din, rows_of([c[1] for c in ch]), tq, frames, n))
         return out
 
     def _d_pass(self, lst, batch):
@@ -799,7 +815,7 @@ class GanTrainer:
         mixed = int(any(hq) != all(hq))
         with_q = int(bool(hq) and all(hq))
         without_q = int(bool(hq) and not any(hq))
-        chunks = self._padded_chunks(lst, batch) if not mixed else []
+        chunks = self._padded_chunks(lst, batch, fill=True) if not mixed else []
         n_steps = len(chunks)
         if self.world > 1:
             # ranks hold different shards: every rank must join the same number of all-reduces
@@ -811,9 +827,9 @@ class GanTrainer:
         has_qua = int(self.D_Qua is not None and bool(with_q))
         for k in range(n_steps):
             if k < len(chunks):
-                din, tgt, tq, frames = chunks[k]
-                self.d_step(din, tgt, tq if has_qua else None, weight=din.shape[0] if self.world > 1 else None, frames=frames,
-                            has_qua=bool(has_qua))
+                din, tgt, tq, frames, items = chunks[k]
+                self.d_step(din, tgt, tq if has_qua else None, weight=items if self.world > 1 else None, frames=frames,
+                            has_qua=bool(has_qua), items=items)
             else:
                 self.d_step(None, None, None, weight=0, has_qua=bool(has_qua))
         return n_steps

@@ -112,11 +112,18 @@ def test_padded_chunks_keep_list_order_and_carry_frame_counts():
     items = [(torch.full((64, T, 4), float(i)), torch.tensor([float(i)])) for i, T in enumerate([30, 40, 30, 30, 41, 50, 30])]
     chunks = GanTrainer._padded_chunks(items, 2)
     assert [[int(v) for v in ch[1][:, 0]] for ch in chunks] == [[0, 1], [2, 3], [4, 5], [6]]
-    din, tgt, tq, frames = chunks[0]
+    din, tgt, tq, frames, nreal = chunks[0]
+    assert nreal == 2 and chunks[3][4] == 1
     assert din.shape == (2, 64, 48, 4) and frames.tolist() == [30, 40] and tq is None
     assert float(din[0, :, 30:].abs().sum()) == 0.0 and float(din[0, :, :30].min()) == 0.0 and float(din[1, :, :40].min()) == 1.0 and not din[1, :, 40:].any()
     assert chunks[1][3] is None and chunks[1][0].shape == (2, 64, 30, 4)          # equal lengths: plain stack, no frame counts
     assert chunks[2][0].shape == (2, 64, 64, 4) and chunks[2][3].tolist() == [41, 50]   # padded to a multiple of 16 (few distinct buffer shapes)
+    # fill: the short last batch of a pass is filled up with all-zero items outside the loss (a batch size that has not occurred before costs buffers)
+    filled = GanTrainer._padded_chunks(items, 2, fill=True)
+    assert [c[0].shape[0] for c in filled] == [2, 2, 2, 2] and [c[4] for c in filled] == [2, 2, 2, 1]
+    assert not filled[3][0][1].any() and filled[3][1].shape == (2, 1) and float(filled[3][1][1, 0]) == 0.0 and filled[3][3] is None
+    short = GanTrainer._padded_chunks(items[:1], 2, fill=True)                     # a pass without a full batch keeps its size
+    assert short[0][0].shape[0] == 1 and short[0][4] == 1
 
 
 # ------------------------------------------------------------------------------------------ data-parallel D epoch on ragged shards

@@ -89,13 +89,15 @@ def test_d_epoch_three_passes_and_history_replay():
     item = lambda i: (din[i % 2].clone(), torch.tensor([0.25 + 0.01 * i], device='cuda'))
     seen = []
     orig = tr.d_step
-    tr.d_step = lambda d, t, *a, **k: (seen.append(d.shape[0]), orig(d, t, *a, **k))[1]   # equal lengths here: plain batches
+    rows = []
+    tr.d_step = lambda d, t, *a, **k: (seen.append(k.get('items', d.shape[0])), rows.append(d.shape[0]), orig(d, t, *a, **k))[2]
     tr.history = [item(i) for i in range(60)]                       # 60 // 30 = 2 replayed items
     cur = [item(100 + i) for i in range(5)]
     w0 = tr.D.layers[4].weight_orig.detach().clone()
     tr.d_epoch(cur, batch=4)
     assert sum(seen) == 5 + (2 + 5) + 5                             # items seen by D in passes A, B, C
-    assert seen == [4, 1, 4, 3, 4, 1]                               # batches of at most 4
+    assert seen == [4, 1, 4, 3, 4, 1]                               # batches of at most 4 items ...
+    assert rows == [4, 4, 4, 4, 4, 4]                               # ... the short ones filled up with all-zero rows outside the loss (one buffer shape)
     assert len(tr.history) == 65
     assert not torch.equal(w0, tr.D.layers[4].weight_orig.detach())
 
@@ -252,3 +254,26 @@ def test_adam_after_a_masked_step_matches_torch_adam_that_never_saw_it():
     assert opt.skipped_steps() == 2 and opt.step_count == 5
     torch.testing.assert_close(fp.flat, ref_p.detach(), rtol=2e-6, atol=1e-9)
     torch.testing.assert_close(opt.m, ref.state[ref_p]['exp_avg'], rtol=1e-5, atol=1e-7)        # (fused multiply-adds against torch's separate ops)
+
+
+def test_fill_rows_of_a_padded_d_batch_do_not_touch_the_update():
+    """d_step(items=n): rows behind the first n are fill rows (all-zero items) - the loss, hence every gradient, is that of the n items:
+    the same D update (to summation order) as the step on the n items alone."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(3, 16000, start=21)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    res = []
+    for fill in (0, 5):
+        tr = GanTrainer('estoi', seed=11)
+        f = tr.features(cw, nw)
+        din = tr.d_inputs(cw, f['noise_band'], f['clean_band'])
+        tgt = torch.tensor([[0.2], [0.5], [0.7]], device='cuda')
+        if fill:
+            din = torch.cat([din, din.new_zeros((fill,) + tuple(din.shape[1:]))])
+            tgt = torch.cat([tgt, tgt.new_zeros((fill, 1))])
+        loss = tr.d_step(din, tgt, items=3)
+        res.append((float(loss), tr.D.flat_parameters().flat.clone()))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
+    d = (res[0][1] - res[1][1]).abs()
+    assert float(d.max()) <= 2.5e-4 * 1.01 and float(d.mean()) < 1e-6      # Adam's first step moves every weight by lr: equal up to gradient-sign noise at zero
