@@ -53,8 +53,10 @@ class _MetricFork:
 
     def __init__(self, tr, inputs):
         self.tr, self.inputs, self.outs, self.used = tr, [t for t in inputs if t is not None], [], []
+        self.marks = None
         self.multi = (tr.device.type == 'cuda' and len(tr.metrics) > 1 and tr.metric_streams and not torch.cuda.is_current_stream_capturing())
         if self.multi:
+            tr._check_queues()
             self.main = torch.cuda.current_stream()
             self.ev0 = torch.cuda.Event()
             self.ev0.record(self.main)
@@ -66,17 +68,49 @@ class _MetricFork:
         self.outs.append(t)
         return t
 
-    def join(self):
+    def mark(self):
+        """Record the end of this batch's metric work on its streams (the events join() / wait() makes the consumer wait for)."""
+        if self.multi and self.marks is None:
+            self.marks = []
+            for st in self.used:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.marks.append((st, ev))
+
+    def wait(self):
+        """The CURRENT stream waits for the marked metric work (the deferred half of join(): run_epoch lets the metrics of a batch run
+        under the next batch's generator and resolves all targets at the end of the pass)."""
         if not self.multi:
             return
-        for st in self.used:
-            ev = torch.cuda.Event()
-            ev.record(st)
-            self.main.wait_event(ev)
+        self.mark()
+        cur = torch.cuda.current_stream()
+        for st, ev in self.marks:
+            cur.wait_event(ev)
             for t in self.inputs:
                 t.record_stream(st)
         for t in self.outs:
-            t.record_stream(self.main)
+            t.record_stream(cur)
+
+    def join(self):
+        self.mark()
+        self.wait()
+
+
+class _PendingTargets:
+    """Targets whose metric kernels are enqueued on the metric streams; result() makes the current stream wait for them and assembles
+    the [B, n_metrics] tensor(s).  (true_metrics(..., defer=True))"""
+
+    def __init__(self, forks, build):
+        self.forks, self.build, self.value = forks, build, None
+        for f in forks:
+            f.mark()
+
+    def result(self):
+        if self.build is not None:
+            for f in self.forks:
+                f.wait()
+            self.value, self.build = self.build(), None
+        return self.value
 
 
 class _MetricForkCtx:
@@ -346,11 +380,13 @@ class GanTrainer:
         return _MetricFork(self, inputs)
 
     @torch.no_grad()
-    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None):
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None, defer=False):
         """[B, n_metrics] targets of (clean, enhanced + noise) (audio_util.py:120-203).  lengths [B]: samples of each utterance inside the
         padded batch; resynth=True: ``enh_wav`` came out of ``generate`` (each row holds 256 * (L // 256) samples); False: ``lengths``
         already are min(clean, enhanced) per utterance (the pre-enhanced 'DRC' examples, audio_util.py:267-321).
-        utt_ids [B] int64: utterance ids for the per-utterance HASPI dither (haspi_dither='utterance')."""
+        utt_ids [B] int64: utterance ids for the per-utterance HASPI dither (haspi_dither='utterance').
+        defer: return a _PendingTargets instead - the kernels are enqueued on the metric streams, the caller's stream is not made to
+        wait for them until .result() (run_epoch: a batch's metrics run under the next batch's generator)."""
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
         x = clean_wav[:, :L].contiguous()
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
@@ -360,16 +396,19 @@ class GanTrainer:
         elif lengths is not None:
             lengths = torch.clamp(lengths, max=L)
         cols = []
-        fork = self._metric_fork((x, y))
+        fork = self._metric_fork((x, y, lengths))             # (everything allocated on THIS stream that the metric streams read: kept alive and
+                                                               #  marked as used there until the targets are waited for)
         for m in self.metrics:
             with fork.on(m) as which:
                 raw, mapped = self._metric(m, x, y, which, lengths, utt_ids)
                 cols.append(fork.out(mapped if norm else raw))
+        if defer:
+            return _PendingTargets([fork], lambda: torch.stack(cols, dim=1))
         fork.join()
         return torch.stack(cols, dim=1)
 
     @torch.no_grad()
-    def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None):
+    def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None, defer=False):
         """Targets of TWO degraded versions of one clean batch - the generated example and the pre-enhanced ('DRC') one, which the loop
         scores back to back (train_nele.py:318-340) - with the clean-signal work done once: SIIB's VAD / clean spectra / covariance /
         eigen-decomposition (its KLT basis) and HASPI's whole reference-signal chain depend on the clean signal only
@@ -386,13 +425,17 @@ class GanTrainer:
             ml_d = torch.clamp(torch.minimum(full(drc_lengths, drc_wav), full(lengths, clean_wav)), max=Ld)
         same = (L == Ld) and ((ml_e is None and ml_d is None) or (ml_e is not None and ml_d is not None and bool(torch.equal(ml_e, ml_d))))
         if not same:
+            if defer:
+                pa = self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids, defer=True)
+                pb = self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids, defer=True)
+                return _PendingTargets([], lambda: (pa.result(), pb.result()))
             return (self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids),
                     self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids))
         x = clean_wav[:, :L].contiguous()
         ys = [(enh_wav[:, :L] + noise_wav[:, :L]).contiguous(), (drc_wav[:, :L] + noise_wav[:, :L]).contiguous()]
         pick = (lambda r, m_: m_) if norm else (lambda r, m_: r)
         cols = [{}, {}]
-        fork = self._metric_fork([x] + ys)
+        fork = self._metric_fork([x] + ys + [ml_e, ml_d])
         for m in self.metrics:
             with fork.on(m) as which:
                 if m == 'siib':
@@ -414,6 +457,8 @@ class GanTrainer:
                     for k, y in enumerate(ys):
                         raw, mapped = mt.batch_estoi(x, y, lengths=ml_e)
                         cols[k][m] = fork.out(pick(raw, mapped))
+        if defer:
+            return _PendingTargets([fork], lambda: tuple(torch.stack([c[m] for m in self.metrics], dim=1) for c in cols))
         fork.join()
         return tuple(torch.stack([c[m] for m in self.metrics], dim=1) for c in cols)
 
@@ -509,21 +554,49 @@ class GanTrainer:
 
     def _shares_queue(self, a, b, spin_us=300.0):
         """Does a kernel on stream ``b`` wait behind a kernel running on stream ``a`` (same hardware queue)?  Parks one idle wave on ``a`` for
-        ``spin_us`` and times a trivial kernel on ``b``: on another queue it finishes long before the spin does.  Synchronises (called
-        a handful of times, once per trainer)."""
-        from ._lib import call
+        ``spin_us`` and times a trivial kernel on ``b``: on another queue it finishes long before the spin does.  Probed in BOTH directions
+        (a first probe of a process misreads one direction: the kernels' first launches; two streams that do share a queue wait for each
+        other either way).  Synchronises (called a handful of times, once per trainer)."""
+        from ._lib import lib
         dev = self.device
-        torch.cuda.synchronize(dev)
         t = torch.zeros(64, device=dev)
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(a):
-            call('nele_stream_spin', float(spin_us), ctypes.c_void_p(a.cuda_stream))
-            ea.record(a)
-        with torch.cuda.stream(b):
-            t.add_(1.0)
-            eb.record(b)
-        torch.cuda.synchronize(dev)
-        return eb.elapsed_time(ea) < 0.5 * spin_us * 1e-3       # b's kernel ended less than half a spin before the spin did (or after it)
+
+        def probe(p, q):
+            torch.cuda.synchronize(dev)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(p):
+                lib.nele_stream_spin(float(spin_us), ctypes.c_void_p(p.cuda_stream))
+                ea.record(p)
+            with torch.cuda.stream(q):
+                t.add_(1.0)
+                eb.record(q)
+            torch.cuda.synchronize(dev)
+            return eb.elapsed_time(ea) < 0.5 * spin_us * 1e-3   # q's kernel ended less than half a spin before the spin did (or after it)
+        if not getattr(self, '_probe_warm', False):
+            self._probe_warm = True
+            probe(a, b)                                         # first launches of both kernels: result discarded
+        return probe(a, b) and probe(b, a)
+
+    def _check_queues(self):
+        """Once per trainer: the second metric stream and the feature stream must not share the METRIC stream's hardware queue (SIIB's
+        latency chain through the eigensolver lives there: whatever else is multiplexed onto that queue runs in submission order with
+        it, and the chain waits behind every kernel in between - measured on true_metrics at B = 64: SIIB + HASPI 7.4 ms, + ESTOI on a
+        third stream that happened to share the queue 10.6 ms).  A stream that does is replaced by a fresh one that does not."""
+        dev = self.device
+        if self._queues_checked or dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+            return
+        for name in ('_side', '_side2', '_fside'):
+            if getattr(self, name) is None:
+                setattr(self, name, ops.side_stream(dev))
+        if self._side == torch.cuda.current_stream(dev):
+            return
+        self._queues_checked = True
+        for name in ('_side2', '_fside'):
+            tries = 0
+            while tries < 8 and (self._shares_queue(self._side, getattr(self, name)) or
+                                 (name == '_fside' and self._shares_queue(self._side2, self._fside))):
+                setattr(self, name, torch.cuda.Stream(device=dev))      # (three hardware queues serve the side streams: one each)
+                tries += 1
 
     def _pipeline_queues(self, on):
         """The HIP runtime multiplexes all streams onto four hardware queues: the default stream has its own; side streams get
@@ -542,13 +615,7 @@ class GanTrainer:
             self._side2 = ops.side_stream(dev)
         if self._fside is None:
             self._fside = ops.side_stream(dev)
-        if on and not self._queues_checked and dev.type == 'cuda' and self._side != torch.cuda.current_stream(dev):
-            self._queues_checked = True
-            for name in ('_side2', '_fside'):
-                tries = 0
-                while self._shares_queue(self._side, getattr(self, name)) and tries < 8:
-                    setattr(self, name, torch.cuda.Stream(device=dev))
-                    tries += 1
+        self._check_queues()                            # (plain steps too: SIIB's and HASPI's streams on one queue run one after the other)
         if on and self._wstreams_plain is None:
             self._wstreams_plain = (self.D._wstream, self.G._wstream)
             self.D._wstream = (self._fside, self._side2)
@@ -902,7 +969,8 @@ class GanTrainer:
             if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
                 self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch,
                                    lengths=b.get('lengths_host', b.get('lengths')), wait=False)
-            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids')))
+            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids'), defer=True))
+        raw = [p.result() for p in raw]                                 # (a batch's metrics ran under the next batch's generator)
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
             acc = torch.zeros(n_m + 1, dtype=torch.float64, device=self.device)
@@ -923,7 +991,7 @@ class GanTrainer:
                         fh.write(line)
         if chkpt_path is not None and ndist.rank() == 0:
             self.save_checkpoint(chkpt_path)                            # :272-277
-        samples = []
+        samples, pending = [], []
         out['sample_files'] = []
         for i, b in enumerate(train_batches):                           # :279-340
             f = feats[i] if feats[i] is not None else fts(b)
@@ -936,15 +1004,23 @@ class GanTrainer:
             if b.get('drc') is not None:
                 # generated + pre-enhanced ('DRC') example of the same utterances (:318-340; audio_util.py:267-321; the DRC file keeps its
                 # own length): one pass over the clean signal for both when they are compared over the same samples (audio_util.py:134-137)
-                tgt, tgt_d = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'))
+                pend = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'), defer=True)
             else:
-                tgt = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'))
+                pend = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'), defer=True)
+            # the targets are not waited for here: this batch's metric kernels (three streams, SIIB's a latency chain through the
+            # eigensolver) run under the next batch's generator and feature kernels; everything is resolved behind the loop
             din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
-            qua = b.get('qua')
-            samples += self._items(din, tgt, qua, frames)
+            din_d = None
             if b.get('drc') is not None:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
-                samples += self._items(din_d, tgt_d, b.get('drc_qua'), frames)
+            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua')))
+        for pend, din, qua, frames, din_d, drc_qua in pending:
+            tgt = pend.result()
+            if din_d is not None:
+                tgt, tgt_d = tgt
+            samples += self._items(din, tgt, qua, frames)
+            if din_d is not None:
+                samples += self._items(din_d, tgt_d, drc_qua, frames)
         out['samples'] = len(samples)
         d0 = self.step_d
         self.d_epoch(samples, batch=d_batch)                            # :342-426
