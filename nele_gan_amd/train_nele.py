@@ -843,13 +843,15 @@ class GanTrainer:
         (rounded up to a multiple of ``round_to`` so that few distinct buffer shapes occur) and carry their own frame counts, which
         D's pooling honours (nele_gap_mlp_fwd_var).  -> list of (din [b,64,T,4], target [b,n], target_qua [b,2] | None, frames [b],
         items): the loss runs over the first ``items`` rows.  ``fill``: the short last batch of a pass that has full ones is filled up to
-        ``batch`` rows with all-zero items (outside the loss: zero gradient rows) - the replay list grows every epoch, and a batch size
-        that has not occurred before costs a set of activation buffers and recorded passes (tens of milliseconds) for one step."""
+        the next multiple of an eighth of ``batch`` (at least 8) rows with all-zero items (outside the loss: zero gradient rows) - the
+        replay list grows every epoch, and a batch size that has not occurred before costs a set of activation buffers and recorded
+        passes (tens of milliseconds) for one step."""
         out = []
         for k in range(0, len(lst), batch):
             ch = lst[k:k + batch]
             n = len(ch)
-            rows = batch if (fill and n < batch and len(lst) > batch) else n
+            q = max(8, batch // 8)                                       # (row buckets: an eighth of a batch - a handful of shapes, little fill)
+            rows = min(batch, (n + q - 1) // q * q) if (fill and n < batch and len(lst) > batch) else n
             Ts = [int(c[0].shape[1]) for c in ch]
             Tm = (max(Ts) + round_to - 1) // round_to * round_to
             if all(t == Ts[0] for t in Ts):

@@ -130,6 +130,8 @@ def test_padded_chunks_keep_list_order_and_carry_frame_counts():
     # fill: the short last batch of a pass is filled up with all-zero items outside the loss (a batch size that has not occurred before costs buffers)
     filled = GanTrainer._padded_chunks(items, 2, fill=True)
     assert [c[0].shape[0] for c in filled] == [2, 2, 2, 2] and [c[4] for c in filled] == [2, 2, 2, 1]
+    big = GanTrainer._padded_chunks(items * 5, 32, fill=True)                      # 35 items in batches of 32: the last one (3 items) takes 8 rows, not 32
+    assert [c[0].shape[0] for c in big] == [32, 8] and big[1][4] == 3
     assert not filled[3][0][1].any() and filled[3][1].shape == (2, 1) and float(filled[3][1][1, 0]) == 0.0 and filled[3][3] is None
     short = GanTrainer._padded_chunks(items[:1], 2, fill=True)                     # a pass without a full batch keeps its size
     assert short[0][0].shape[0] == 1 and short[0][4] == 1
