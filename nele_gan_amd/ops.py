@@ -116,6 +116,49 @@ def side_stream(device):
     return torch.cuda.Stream(device=device)
 
 
+_probe_warm = False
+
+
+def shares_queue(a, b, device, spin_us=300.0):
+    """Does a kernel on stream ``b`` wait behind a kernel running on stream ``a`` - do the two sit on the same hardware queue?  (The HIP
+    runtime multiplexes all streams onto four hardware queues - the default stream's and three for the side streams, assigned at
+    creation; streams on one queue run in submission order, whatever their events say.)  Parks one idle wave on ``a`` for ``spin_us`` and
+    times a trivial kernel on ``b``: on another queue it finishes long before the spin does.  Asked in BOTH directions (the first probe
+    of a process misreads one of them - first kernel launches - and streams that do share a queue wait for each other either way).
+    Synchronises the device a few times: for set-up code, once per object."""
+    global _probe_warm
+    t = torch.zeros(64, device=device)
+
+    def probe(p, q):
+        torch.cuda.synchronize(device)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(p):
+            _lib.lib.nele_stream_spin(float(spin_us), c_void_p(p.cuda_stream))
+            ea.record(p)
+        with torch.cuda.stream(q):
+            t.add_(1.0)
+            eb.record(q)
+        torch.cuda.synchronize(device)
+        return eb.elapsed_time(ea) < 0.5 * spin_us * 1e-3       # q's kernel ended less than half a spin before the spin did (or after it)
+    if not _probe_warm:
+        _probe_warm = True
+        probe(a, b)                                             # first launches of both kernels: result discarded
+    return probe(a, b) and probe(b, a)
+
+
+def streams_on_distinct_queues(device, n, have=()):
+    """``n`` (at most three) side streams on pairwise different hardware queues, none of them the queue of a stream in ``have``."""
+    if os.environ.get('NELE_SERIAL', '0') == '1' or torch.cuda.is_current_stream_capturing():
+        return [side_stream(device) for _ in range(n)]
+    out = []
+    for _ in range(n):
+        st, tries = torch.cuda.Stream(device=device), 0
+        while tries < 8 and any(shares_queue(o, st, device) for o in list(have) + out):
+            st, tries = torch.cuda.Stream(device=device), tries + 1
+        out.append(st)
+    return out
+
+
 class Events:
     """Hand-over events between the streams of one pass, created once per buffer set and addressed by position: a recorded plan
     (_lib.PlanRecorder) holds their handles, so the n-th fork of a pass must always use the n-th event."""

@@ -553,29 +553,8 @@ class GanTrainer:
         return [st_ for st_ in (self._side, self._side2, self._fside) if st_ is not None]
 
     def _shares_queue(self, a, b, spin_us=300.0):
-        """Does a kernel on stream ``b`` wait behind a kernel running on stream ``a`` (same hardware queue)?  Parks one idle wave on ``a`` for
-        ``spin_us`` and times a trivial kernel on ``b``: on another queue it finishes long before the spin does.  Probed in BOTH directions
-        (a first probe of a process misreads one direction: the kernels' first launches; two streams that do share a queue wait for each
-        other either way).  Synchronises (called a handful of times, once per trainer)."""
-        from ._lib import lib
-        dev = self.device
-        t = torch.zeros(64, device=dev)
-
-        def probe(p, q):
-            torch.cuda.synchronize(dev)
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(p):
-                lib.nele_stream_spin(float(spin_us), ctypes.c_void_p(p.cuda_stream))
-                ea.record(p)
-            with torch.cuda.stream(q):
-                t.add_(1.0)
-                eb.record(q)
-            torch.cuda.synchronize(dev)
-            return eb.elapsed_time(ea) < 0.5 * spin_us * 1e-3   # q's kernel ended less than half a spin before the spin did (or after it)
-        if not getattr(self, '_probe_warm', False):
-            self._probe_warm = True
-            probe(a, b)                                         # first launches of both kernels: result discarded
-        return probe(a, b) and probe(b, a)
+        """ops.shares_queue on this trainer's device."""
+        return ops.shares_queue(a, b, self.device, spin_us)
 
     def _check_queues(self):
         """Once per trainer: the second metric stream and the feature stream must not share the METRIC stream's hardware queue (SIIB's
