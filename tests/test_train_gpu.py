@@ -277,3 +277,21 @@ def test_fill_rows_of_a_padded_d_batch_do_not_touch_the_update():
     assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
     d = (res[0][1] - res[1][1]).abs()
     assert float(d.max()) <= 2.5e-4 * 1.01 and float(d.mean()) < 1e-6      # Adam's first step moves every weight by lr: equal up to gradient-sign noise at zero
+
+
+def test_hardware_queue_probe_and_streams_on_distinct_queues():
+    """ops.shares_queue: a stream shares a queue with itself, three probed streams do not share one pairwise, and among seven unprobed
+    side streams (three hardware queues serve them) some pair does - which the probe reports the same way in both argument orders."""
+    from nele_gan_amd import ops
+    dev = torch.device('cuda:0')
+    s = torch.cuda.Stream(device=dev)
+    assert ops.shares_queue(s, s, dev)
+    three = ops.streams_on_distinct_queues(dev, 3)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert not ops.shares_queue(three[i], three[j], dev)
+    many = [torch.cuda.Stream(device=dev) for _ in range(7)]
+    pairs = [(i, j) for i in range(7) for j in range(i + 1, 7) if ops.shares_queue(many[i], many[j], dev)]
+    assert pairs, "seven side streams on distinct hardware queues?"
+    i, j = pairs[0]
+    assert ops.shares_queue(many[j], many[i], dev)
