@@ -168,6 +168,7 @@ class GanTrainer:
         self.step_g = 0
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
+        self.history_hbm_bytes = 64 << 30            # D inputs of past epochs kept in HBM for the replay; beyond it items move to host memory (_history_trim)
         self._side = None
         self._side2 = None
         self._fside = None
@@ -897,9 +898,28 @@ class GanTrainer:
         else:
             random.shuffle(self.history)                                # :373-376
             replay = self.history[0:n_hist // 30]
+        replay = [self._on_device(it) for it in replay]                 # (items of old epochs may live in host memory: _history_trim)
         self._d_pass(replay + cur, batch)                               # pass B: 1/30 of the history + current (:380-398)
         self.history = self.history + cur                               # :403
+        self._history_trim()
         self._d_pass(cur, batch)                                        # pass C (:406-424)
+
+    def _on_device(self, item):
+        return item if item[0].device == self.device else tuple(None if t is None else t.to(self.device, non_blocking=True) for t in item)
+
+    def _history_trim(self):
+        """The reference's replay list holds FILE NAMES and re-reads them (train_nele.py:373-403); here it holds the D inputs themselves
+        ([64, T, 4] float32, ~0.2 MB per item), which grows by an epoch's worth of samples per epoch.  Beyond ``history_hbm_bytes`` of
+        device memory, items (whichever come first in the shuffled list) are moved to host memory; a replayed one is uploaded again."""
+        if self.device.type != 'cuda':
+            return
+        used = 0
+        for k, it in enumerate(self.history):
+            if it[0].device.type != 'cuda':
+                continue
+            used += it[0].numel() * it[0].element_size()
+            if used > self.history_hbm_bytes:
+                self.history[k] = tuple(None if t is None else t.to('cpu') for t in it)
 
     # ---------------------------------------------------------------- one GAN epoch (train_nele.py:110-429)
     def run_epoch(self, gan_epoch, train_batches, valid_batches=(), chkpt_path=None, sample_dir=None, log_path=None, d_batch=32,

@@ -295,3 +295,28 @@ def test_hardware_queue_probe_and_streams_on_distinct_queues():
     assert pairs, "seven side streams on distinct hardware queues?"
     i, j = pairs[0]
     assert ops.shares_queue(many[j], many[i], dev)
+
+
+def test_replay_history_beyond_its_device_budget_moves_to_host_memory_and_is_still_replayed():
+    """GanTrainer.history_hbm_bytes: the D inputs of past epochs beyond the budget live in host memory; pass B uploads the replayed ones."""
+    from nele_gan_amd import synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(2, 16000, start=9)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    tr = GanTrainer('estoi')
+    f = tr.features(cw, nw)
+    din = tr.d_inputs(cw, f['noise_band'], f['clean_band'])
+    item = lambda i: (din[i % 2].clone(), torch.tensor([0.25 + 0.01 * i], device='cuda'))
+    per_item = din[0].numel() * 4
+    tr.history_hbm_bytes = 10 * per_item                          # room for ten items
+    tr.history = [item(i) for i in range(60)]
+    seen = []
+    orig = tr.d_step
+    tr.d_step = lambda d, t, *a, **k: (seen.append(k.get('items', d.shape[0])), orig(d, t, *a, **k))[1]
+    tr.d_epoch([item(100 + i) for i in range(5)], batch=4)
+    on_dev = sum(1 for it in tr.history if it[0].is_cuda)
+    assert len(tr.history) == 65 and on_dev == 10 and all(it[1].device == it[0].device for it in tr.history)
+    seen.clear()
+    tr.d_epoch([item(200 + i) for i in range(5)], batch=4)        # 65 // 30 = 2 replayed items, most likely from host memory
+    assert sum(seen) == 5 + (2 + 5) + 5 and len(tr.history) == 70
+    assert tr.check_status()['skipped_d_steps'] == 0
