@@ -48,6 +48,10 @@ def parse_metrics(target_metric):
     return names
 
 
+# raw score -> target in (0, 1): 1 / (1 + exp(-k (x - x0))) (intel.py mapping_*_harvard)
+_MAPS = {'siib': (0.06, 32.0), 'haspi': (0.95, 2.8), 'estoi': (8.0, 0.25)}
+
+
 class _MetricFork:
     """See GanTrainer._metric_fork."""
 
@@ -922,8 +926,30 @@ class GanTrainer:
                 self.history[k] = tuple(None if t is None else t.to('cpu') for t in it)
 
     # ---------------------------------------------------------------- one GAN epoch (train_nele.py:110-429)
+    def d_mse(self, samples, batch=32):
+        """Mean squared error of D's predictions over a list of D training items (din, target[, target_qua]) - evaluation mode, no
+        gradient, no optimiser step, the spectral-norm iteration does not advance.  The health signal of the D half of the loop
+        (train_nele.py:356-367 prints its loss every 1000 steps): before ``d_epoch`` it says how well D predicts the true metric
+        scores of samples it has not seen, afterwards how well it fits them.  This rank's items only."""
+        if not samples:
+            return None
+        self._flush_d()
+        was = self.D.training
+        self.D.eval()
+        tot = torch.zeros((), dtype=torch.float64, device=self.device)
+        cnt = 0
+        try:
+            with torch.no_grad():
+                for din, tgt, _tq, frames, items in self._padded_chunks(list(samples), batch):
+                    score = self.D.forward_packed(din, frames)[:items]
+                    tot = tot + ((score.double() - tgt[:items].double()) ** 2).sum()
+                    cnt += items * score.shape[1]
+        finally:
+            self.D.train(was)
+        return float(tot) / max(1, cnt)
+
     def run_epoch(self, gan_epoch, train_batches, valid_batches=(), chkpt_path=None, sample_dir=None, log_path=None, d_batch=32,
-                  check=True):
+                  check=True, d_eval=False):
         """One iteration of ``for gan_epoch in np.arange(1, GAN_epoch+1)`` (train_nele.py:110) in the reference's order.
 
         train_batches / valid_batches: sequences of dicts {'clean': wav [B,L], 'noise': wav [B,L], optional 'names': [B] wave names,
@@ -940,6 +966,8 @@ class GanTrainer:
           4. generate the D training samples of the same training utterances (:279-316)
           5. true metric targets of the generated and of the pre-enhanced examples (:318-340)
           6. D (and D_Qua) training: three passes with 1/30 history replay (:342-426)
+        ``d_eval``: also report D's mean squared error on the epoch's new samples before (``d_mse_fresh``) and after (``d_mse_fit``)
+        its three training passes and the mean true targets of those samples (``target_mean``) - see tools/learn_curve.py.
         Returns a dict of what happened (losses, validation means, counts)."""
         out = {'gan_epoch': int(gan_epoch), 'g_steps': 0, 'g_loss': None, 'valid': None, 'samples': 0}
         feats = [None] * len(train_batches)
@@ -974,11 +1002,16 @@ class GanTrainer:
         raw = [p.result() for p in raw]                                 # (a batch's metrics ran under the next batch's generator)
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
-            acc = torch.zeros(n_m + 1, dtype=torch.float64, device=self.device)
+            acc = torch.zeros(2 * n_m + 1, dtype=torch.float64, device=self.device)
             if raw:
                 r = torch.cat(raw, dim=0).double()
                 acc[:n_m] = r.sum(dim=0)
                 acc[n_m] = r.shape[0]
+                # the same scores through the reference's logistic maps (intel.py:52-55,102-106,116-118): what D is trained to predict
+                # and G is trained to push to 1 - not part of the reference's log line, reported beside it (out['valid_mapped'])
+                for i, m in enumerate(self.metrics):
+                    k_, x0_ = _MAPS[m]
+                    acc[n_m + 1 + i] = (1.0 / (1.0 + torch.exp(-k_ * (r[:, i] - x0_)))).sum()
             if dp:                                                      # the learning curve is the mean over ALL validation utterances
                 import torch.distributed as tdist
                 tdist.all_reduce(acc)
@@ -986,6 +1019,8 @@ class GanTrainer:
                 r = (acc[:n_m] / acc[n_m]).cpu().numpy()
                 col = {m: float(r[i]) for i, m in enumerate(self.metrics)}
                 out['valid'] = col
+                rm = (acc[n_m + 1:] / acc[n_m]).cpu().numpy()
+                out['valid_mapped'] = {m: float(rm[i]) for i, m in enumerate(self.metrics)}
                 line = self.validation_log_line(col.get('siib', 0.0), col.get('haspi', 0.0), col.get('estoi', 0.0), gan_epoch)
                 if log_path is not None and ndist.rank() == 0:
                     with open(log_path, 'a') as fh:                     # :224-225
@@ -1024,8 +1059,13 @@ class GanTrainer:
                 samples += self._items(din_d, tgt_d, drc_qua, frames)
         out['samples'] = len(samples)
         d0 = self.step_d
+        if d_eval:                                                      # D's error on this epoch's samples before it has trained on them
+            out['d_mse_fresh'] = self.d_mse(samples, d_batch)
+            out['target_mean'] = torch.stack([s_[1] for s_ in samples]).double().mean(dim=0).tolist() if samples else None
         self.d_epoch(samples, batch=d_batch)                            # :342-426
         out['d_steps'] = self.step_d - d0
+        if d_eval:
+            out['d_mse_fit'] = self.d_mse(samples, d_batch)
         self.flush_writes()                                             # the epoch's sample files are on disk when it returns
         if check:
             out['status'] = self.check_status()
@@ -1117,7 +1157,13 @@ class GanTrainer:
             sd['quality-model'] = self.D_Qua.state_dict()
         torch.save(sd, path)
 
+    def flush(self):
+        """Complete a deferred D update (overlap_allreduce: canonical_step leaves D's gradient all-reduce and Adam-D step pending until
+        something touches D).  Call before reading ``self.D``'s weights or ``step_d`` directly after canonical_step."""
+        self._flush_d()
+
     def load_checkpoint(self, path):
+        self._flush_d()                 # a pending pre-load gradient must not be applied to the loaded weights
         ck = torch.load(path, map_location=self.device)
         self.G.load_state_dict(ck['enhance-model'])
         if 'intel-model' in ck:
