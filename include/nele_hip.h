@@ -68,6 +68,13 @@ int nele_plan_op_id(const char* name);    /* -1: not an operation */
 int nele_plan_op_nargs(int op);
 int nele_plan_create(const nele_plan_job* jobs, int njobs, int nslots, int nstreams, void** plan_out);
 int nele_plan_run(void* plan, void* const* streams_host, int nstreams, const long long* slots_host, int nslots);
+/* Slot declarations: what a call must provide behind slot k (bytes of device memory; 0 = a scalar slot; nullable != 0: the pointer may be
+ * NULL).  nele_plan_run refuses a NULL in a declared non-optional slot; nele_plan_run_sized also takes the sizes of the caller's buffers
+ * (sizes_host[k] bytes behind slots_host[k]) and refuses one that is shorter than what the plan touches.  Plans built by
+ * nele_gen_plan_build / nele_disc_plan_build come fully declared; a recorded plan is declared by its recorder. */
+int nele_plan_declare_slot(void* plan, int slot, long long bytes, int nullable);
+long long nele_plan_slot_bytes(void* plan, int slot);
+int nele_plan_run_sized(void* plan, void* const* streams_host, int nstreams, const long long* slots_host, const long long* sizes_host, int nslots);
 int nele_plan_destroy(void* plan);
 /* model.py:83-98.  Slots 0 .. 3 of the plan = x [B][T][64], y [B][T][64], mask [B][T][64] (out), token (nele_glayer16_fwd's counter: the
  * plan uses token, token + 1, ..). */
@@ -79,6 +86,36 @@ int nele_disc_fwd(void* plan, const float* din, const int* wvalid, float* score,
 /* autograd of the above: slots 0 .. 3 = dscore, score, wvalid, din (the forward pass's input: the first layer's weight gradient reads it);
  * the input gradient lands in the buffer the plan was recorded with */
 int nele_disc_bwd(void* plan, const float* dscore, const float* score, const int* wvalid, const float* din, void* const* streams_host, int nstreams);
+/* ---- plans built inside the library (csrc/netplan.hip, round 6): the composite entry points above need no host-language recorder --------
+ * model.py:43-98 (Generator_Conv1D_cLN), :101-166 (Discriminator / Discriminator_Quality) and their autograd as job tables over this
+ * header's per-layer entry points: which kernels, layouts, workspaces and stream hand-overs make up a pass is stated by the library.
+ * The caller owns (a) the model's parameters and gradients as two flat float32 buffers in nn.Module.parameters() order of the reference
+ * modules - nele_{gen,disc}_param_layout give the offsets (G: 6 x {conv.weight, conv.bias, cLN.gain0, cLN.bias0}, fc1.weight, fc1.bias,
+ * fc2.weight, fc2.bias; D: 8 x {bias, weight_orig} for conv1..5, fc1..3) - (b) for a discriminator the spectral-norm vectors, sn_uv_host
+ * [16] = HOST array of device pointers {weight_u, weight_v} per layer in that order, and (c) ONE workspace of nele_*_workspace_bytes per
+ * (B, T, precision) which holds every activation, weight layout and temporary of both passes: the backward plan reads what the forward
+ * plan left there.  *_plan_build zero-fills the workspace on `stream` (padding rows, zero borders, carry slots) and returns the plans;
+ * run them with nele_gen_fwd / nele_gen_bwd / nele_disc_fwd / nele_disc_bwd (or nele_plan_run[_sized]) and release them with
+ * nele_plan_destroy.  bf16 != 0: bf16 MFMA operands / float32 accumulate (BASELINE configs[1]); 0: float32 operands.
+ * need_bwd: the forward plan keeps what a backward pass needs (and bwd_out is built).  overlap_wgrad != 0: weight gradients run on
+ * side streams beside the data-gradient chain - streams_host then needs 2 (G) / 3 (D) streams - else everything on streams_host[0].
+ * Gradients ACCUMULATE into grads_flat (zero it per optimiser step, as optimizer.zero_grad()). */
+long long nele_gen_param_count(void);
+int nele_gen_param_layout(long long* offsets_host, int n /* >= 28 */);
+long long nele_gen_workspace_bytes(int B, int T, int bf16, int need_bwd);
+int nele_gen_plan_build(int B, int T, int bf16, int need_bwd, int overlap_wgrad, const float* params_flat, float* grads_flat, void* workspace,
+                        long long workspace_bytes, void* stream, void** fwd_out, void** bwd_out);
+/* cin = 3 (Discriminator: enhanced, noise, clean) or 2 (Discriminator_Quality); nout = number of scores (<= 4).  train != 0: the forward
+ * plan runs one spectral-norm power iteration first (model.py:105-116 in training mode), 0: sigma from the stored u, v.  need_din: the
+ * backward plan also produces the input gradient (the G-step), at nele_disc_workspace_ddin(...) [B][64][T][4].  weight_grads == 0: data
+ * gradients only.  bwd_out may be NULL (forward only). */
+long long nele_disc_param_count(int cin, int nout);
+int nele_disc_param_layout(int cin, int nout, long long* offsets_host, int n /* >= 16 */);
+long long nele_disc_workspace_bytes(int B, int T, int cin, int bf16);
+float* nele_disc_workspace_ddin(void* workspace, int B, int T, int cin, int bf16);
+int nele_disc_plan_build(int B, int T, int cin, int nout, int bf16, int train, int need_din, int weight_grads, int overlap_wgrad,
+                         const float* params_flat, float* grads_flat, const void* const* sn_uv_host, void* workspace, long long workspace_bytes,
+                         void* stream, void** fwd_out, void** bwd_out);
 /* Hand-over events between the streams of a pass (hipEvent, timing disabled), recordable as plan operations */
 int nele_event_create(void** event_out);
 int nele_event_destroy(void* event);
@@ -389,6 +426,14 @@ int nele_metric_siib(const float* x, const float* y, int B, int L, void* workspa
  * phase 4 = the rest (y spectra / masking / stacking, projections, score).  Phase 3 can run before y exists. */
 int nele_metric_siib_phase(const float* x, const float* y, int B, int L, void* workspace, long long workspace_bytes, float* raw,
                            float* mapped, int* info, int phase, void* stream);
+/* Clean-signal state across calls.  The reference scores the SAME clean training files in every GAN epoch (train_nele.py:35-38,119,
+ * 318-340 -> audio_util.py:120-203 -> intel.py:57-100) and recomputes their half of SIIB - VAD, clean spectra, covariance, the KLT
+ * eigen-decomposition (np.linalg.eigh in pysiib) - every time.  This describes what phase 3 leaves in a workspace for phase 4 as byte
+ * ranges of the workspace, out[3k..3k+2] = {offset, stride, bytes}: stride > 0 = per-utterance section (utterance b's part = the first
+ * `bytes` bytes at offset + b * stride), stride 0 = a table all utterances share.  A caller may copy the ranges out after phase 3 and, in
+ * a later call with the same L, copy them in (any row order, any B) INSTEAD of running phase 3: phase 4 then gives bit-identical scores.
+ * Returns the number of sections (max_sections >= 13) or a negative status.  Host-only: no device work. */
+int nele_metric_siib_clean_sections(int B, int L, long long* out, int max_sections);
 /* Same with per-utterance lengths (the frame-periodic shortcut for L % 200 == 0 is not taken then; results are identical). */
 int nele_metric_siib_var(const float* x, const float* y, const int* lengths, int B, int L, void* workspace, long long workspace_bytes,
                          float* raw, float* mapped, int* info, int phase, void* stream);
@@ -423,6 +468,10 @@ int nele_metric_haspi(const float* x, const float* y, int B, int L, int fs_in, c
  * (x may be NULL).  Phase 0 runs 3 then 4, so the split is bit-identical to the one-shot call. */
 int nele_metric_haspi_var(const float* x, const float* y, const int* lengths, int B, int L, int fs_in, const double* dither,
                           void* workspace, long long workspace_bytes, float* raw, float* mapped, int* info, int phase, void* stream);
+/* The same for HASPI's reference-signal half (pyhaspi2.py:76-107: eb_EarModel / eb_EnvFilt / eb_melcor9's reference side of the clean
+ * file, recomputed by the reference every epoch): byte ranges {offset, stride, bytes} of what phase 3 leaves for phase 4.  Valid for the
+ * same L, fs_in, audiogram and dither rows.  max_sections >= 16. */
+int nele_metric_haspi_clean_sections(int B, int L, int fs_in, long long* out, int max_sections);
 /* pyhaspi2.py:362-365: the reference dithers the envelopes in EVERY haspi_v2 call with np.random.randn(n_active, 32) rows (x, then y)
  * from numpy's global generator.  This fills the `dither` argument of nele_metric_haspi* with rows that are a pure function of
  * (seed, utt_ids[b], signal, active-frame index, channel): the same on whichever rank / in whichever batch the utterance is scored

@@ -83,6 +83,19 @@ _SIGS.update({
     'nele_plan_create': [ctypes.c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
     'nele_plan_run': [c_void_p, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_longlong), c_int],
     'nele_plan_destroy': [c_void_p],
+    'nele_plan_declare_slot': [c_void_p, c_int, c_longlong, c_int],
+    'nele_plan_slot_bytes': [c_void_p, c_int],
+    'nele_plan_run_sized': [c_void_p, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_longlong), ctypes.POINTER(c_longlong), c_int],
+    'nele_gen_param_count': [],
+    'nele_gen_param_layout': [ctypes.POINTER(c_longlong), c_int],
+    'nele_gen_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'nele_gen_plan_build': [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)],
+    'nele_disc_param_count': [c_int, c_int],
+    'nele_disc_param_layout': [c_int, c_int, ctypes.POINTER(c_longlong), c_int],
+    'nele_disc_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'nele_disc_workspace_ddin': [c_void_p, c_int, c_int, c_int, c_int],
+    'nele_disc_plan_build': [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_longlong, c_void_p,
+                             ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)],
     'nele_gen_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, ctypes.POINTER(c_void_p), c_int],
     'nele_gen_bwd': [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
     'nele_disc_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
@@ -91,6 +104,13 @@ _SIGS.update({
 for _n in ('nele_wav_decode_pcm16', 'nele_wav_write_pcm16', 'nele_wav_read_pcm16_batch', 'nele_wav_write_pcm16_batch', 'nele_pcm16_to_float', 'nele_float_to_pcm16', 'nele_event_record', 'nele_stream_wait_event', 'nele_vec_add', 'nele_event_create', 'nele_event_destroy', 'nele_plan_op_id', 'nele_plan_op_nargs',
            'nele_plan_create', 'nele_plan_run', 'nele_plan_destroy', 'nele_gen_fwd', 'nele_gen_bwd', 'nele_disc_fwd', 'nele_disc_bwd'):
     declare(_n, _SIGS[_n])
+for _n in ('nele_plan_declare_slot', 'nele_plan_run_sized', 'nele_gen_param_layout', 'nele_gen_plan_build', 'nele_disc_param_layout', 'nele_disc_plan_build'):
+    declare(_n, _SIGS[_n])
+for _n in ('nele_plan_slot_bytes', 'nele_gen_param_count', 'nele_gen_workspace_bytes', 'nele_disc_param_count', 'nele_disc_workspace_bytes'):
+    getattr(lib, _n).argtypes = _SIGS[_n]
+    getattr(lib, _n).restype = c_longlong
+lib.nele_disc_workspace_ddin.argtypes = _SIGS['nele_disc_workspace_ddin']
+lib.nele_disc_workspace_ddin.restype = c_void_p
 lib.nele_wav_post_workspace_doubles.argtypes = [c_int, c_int]
 lib.nele_wav_post_workspace_doubles.restype = c_longlong
 _SIGS['nele_wav_post_workspace_doubles'] = lib.nele_wav_post_workspace_doubles.argtypes
@@ -195,6 +215,9 @@ class Plan:
         h = c_void_p()
         check(lib.nele_plan_create(self._jobs, self.n, self.nslots, len(rec.streams), ctypes.byref(h)), 'nele_plan_create')
         self.handle = h
+        for k, rng in enumerate(rec.dyn):                  # what a call must provide behind each pointer slot (nele_plan_run refuses a NULL there)
+            if rng is not None and rng[1] > 0:
+                check(lib.nele_plan_declare_slot(h, k, int(rng[1]), 0), 'nele_plan_declare_slot')
 
     def run(self, *slots):
         """Enqueue the recorded pass: streams[0] = the current stream, the side streams as recorded."""

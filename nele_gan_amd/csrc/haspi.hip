@@ -2101,6 +2101,42 @@ static size_t haspi_layout(int B, int L, int fs_in, HaspiWs* w, char* base) {
 
 extern "C" long long nele_metric_haspi_workspace_bytes(int B, int L, int fs_in) { return (long long)haspi_layout(B, L, fs_in, nullptr, nullptr); }
 
+// What phase 3 (the reference-signal half: ear model, envelope filter, silence gate, group-delay shifts, cepstra, modulation filters of
+// the CLEAN signal) leaves in a workspace for phase 4, as byte ranges {offset, stride, bytes} exactly like
+// nele_metric_siib_clean_sections (stride 0 = a table shared by all utterances: resampler window, control-bank transition matrices, IHC
+// transition, envelope and modulation-filter taps).  A pure function of the clean waveform, the padded length L, fs_in, the audiogram and
+// the reference's dither rows: a loop that scores the same clean files every epoch may keep it and skip phase 3 (same L, fs_in, HL,
+// dither; any row order, any B).  Returns the number of sections (<= max_sections) or a negative status.
+extern "C" int nele_metric_haspi_clean_sections(int B, int L, int fs_in, long long* out, int max_sections) {
+    NELE_CHECK_ARG(B > 0 && out && max_sections >= 16, "nele_metric_haspi_clean_sections: bad arguments (16 sections)");
+    NELE_CHECK_ARG(fs_in >= 1000 && fs_in <= 24000 && L >= 2400, "nele_metric_haspi_clean_sections: bad signal geometry");
+    HaspiWs w;
+    char* base = reinterpret_cast<char*>((uintptr_t)1 << 20);
+    haspi_layout(B, L, fs_in, &w, base);
+    int k = 0;
+    auto put = [&](const void* p, long long stride, long long bytes) {
+        out[3 * k] = (long long)(reinterpret_cast<const char*>(p) - base); out[3 * k + 1] = stride; out[3 * k + 2] = bytes; ++k;
+    };
+    const size_t ns = (size_t)w.nsub;
+    put(w.win, 0, sizeof(double) * (HP_NWIN_AL + RS3_TAB));
+    put(w.pmat, 0, sizeof(double) * HP_NCH * 16);                                   // entry 0: the control bank (per channel only)
+    put(w.pihc, 0, sizeof(double) * 4);
+    put(w.benv, 0, sizeof(double) * 64);
+    put(w.bkt, 0, sizeof(double) * 10 * 616);
+    put(w.bw, sizeof(double) * 2 * HP_NCH, sizeof(double) * 2 * HP_NCH);
+    put(w.rinfo, sizeof(float) * 2 * 4, sizeof(float) * 2 * 4);
+    put(w.shift, sizeof(int) * HP_NCH, sizeof(int) * HP_NCH);
+    put(w.act, sizeof(int) * ns, sizeof(int) * ns);
+    put(w.grank, sizeof(int) * ns, sizeof(int) * ns);
+    put(w.gcnt, sizeof(int) * (size_t)w.ngb, sizeof(int) * (size_t)w.ngb);
+    put(w.cpsum, sizeof(double) * 2 * (size_t)w.ngb * HP_NBASIS, sizeof(double) * (size_t)w.ngb * HP_NBASIS);   // clean half
+    put(w.cmean, sizeof(double) * 2 * HP_NBASIS, sizeof(double) * 2 * HP_NBASIS);
+    put(w.info, sizeof(int) * 2, sizeof(int) * 2);
+    put(w.cep, sizeof(double) * 2 * HP_NBASIS * ns, sizeof(double) * HP_NBASIS * ns);                             // clean half
+    put(w.xf, sizeof(double) * 64 * ns, sizeof(double) * 64 * ns);
+    return k;
+}
+
 extern "C" int nele_metric_haspi_nsub(int L, int fs_in) {
     const int n24 = hp_n24_of(L, fs_in);
     return (n24 + HP_SPACE - 1) / HP_SPACE;

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "../../include/nele_hip.h"
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -25,6 +26,11 @@ struct NelePlan {
     unsigned magic;
     int nslots, nstreams;
     std::vector<PlanJobI> jobs;
+    long long slot_bytes[64];                       // bytes a call must provide behind slot k (0: a scalar slot / not declared)
+    unsigned char slot_nullable[64];                // the slot may be NULL (an optional argument such as wvalid)
+    std::vector<std::unique_ptr<char[]>> blobs;     // host arrays the jobs point to (plans built inside the library, netplan.hip)
+    std::vector<hipEvent_t> events;                 // hand-over events owned by the plan
+    ~NelePlan() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 #define PLAN_MAGIC 0x4e504c4eu
 
@@ -74,6 +80,7 @@ extern "C" int nele_plan_create(const nele_plan_job* jobs, int njobs, int nslots
     NelePlan* p = new (std::nothrow) NelePlan;
     if (!p) return nele_set_error(NELE_ERR_HIP, "nele_plan_create: out of host memory");
     p->magic = PLAN_MAGIC; p->nslots = nslots; p->nstreams = nstreams;
+    memset(p->slot_bytes, 0, sizeof(p->slot_bytes)); memset(p->slot_nullable, 0, sizeof(p->slot_nullable));
     p->jobs.resize(njobs);
     for (int j = 0; j < njobs; ++j) {
         PlanJobI& o = p->jobs[j];
@@ -81,6 +88,29 @@ extern "C" int nele_plan_create(const nele_plan_job* jobs, int njobs, int nslots
         memcpy(o.slot, jobs[j].slot, sizeof(o.slot)); memcpy(o.ival, jobs[j].ival, sizeof(o.ival)); memcpy(o.fval, jobs[j].fval, sizeof(o.fval));
     }
     *plan_out = p;
+    return NELE_OK;
+}
+
+// Declares what a call must provide behind slot k: `bytes` of device memory (0 = a scalar slot), `nullable` != 0: the pointer may be NULL.
+// nele_plan_run_sized and the composite entry points check their arguments against it: a recorded job table holds raw offsets, and a
+// short or missing buffer would otherwise be a wild device access.
+extern "C" int nele_plan_declare_slot(void* plan, int slot, long long bytes, int nullable) {
+    NelePlan* p = reinterpret_cast<NelePlan*>(plan);
+    NELE_CHECK_ARG(p && p->magic == PLAN_MAGIC && slot >= 0 && slot < p->nslots && bytes >= 0, "nele_plan_declare_slot: bad arguments");
+    p->slot_bytes[slot] = bytes; p->slot_nullable[slot] = nullable ? 1 : 0;
+    return NELE_OK;
+}
+extern "C" long long nele_plan_slot_bytes(void* plan, int slot) {
+    NelePlan* p = reinterpret_cast<NelePlan*>(plan);
+    if (!p || p->magic != PLAN_MAGIC || slot < 0 || slot >= p->nslots) return -1;
+    return p->slot_bytes[slot];
+}
+
+// netplan.hip: the library's own plan builders hand over the host arrays and events their jobs refer to
+int nele_plan_adopt(void* plan, std::vector<std::unique_ptr<char[]>>&& blobs, std::vector<hipEvent_t>&& events) {
+    NelePlan* p = reinterpret_cast<NelePlan*>(plan);
+    if (!p || p->magic != PLAN_MAGIC) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_plan_adopt: not a plan");
+    p->blobs = std::move(blobs); p->events = std::move(events);
     return NELE_OK;
 }
 
@@ -97,6 +127,9 @@ extern "C" int nele_plan_run(void* plan, void* const* streams_host, int nstreams
     NELE_CHECK_ARG(p && p->magic == PLAN_MAGIC, "nele_plan_run: not a plan");
     NELE_CHECK_ARG(streams_host && nstreams >= p->nstreams && nslots >= p->nslots && (slots_host || p->nslots == 0), "nele_plan_run: %d streams / %d slots given, the plan needs %d / %d",
                    nstreams, nslots, p->nstreams, p->nslots);
+    for (int k = 0; k < p->nslots; ++k)              // a declared pointer slot must not be NULL unless it was declared optional
+        if (p->slot_bytes[k] > 0 && !p->slot_nullable[k] && slots_host[k] == 0)
+            return nele_set_error(NELE_ERR_INVALID_ARG, "nele_plan_run: slot %d is NULL (the plan reads / writes %lld bytes there)", k, p->slot_bytes[k]);
     long long v[NELE_PLAN_MAXARGS];
     for (const PlanJobI& q : p->jobs) {
         const int na = q.nargs - 1;                        // the last argument is the stream
@@ -105,6 +138,16 @@ extern "C" int nele_plan_run(void* plan, void* const* streams_host, int nstreams
         if (st != NELE_OK) return st;                      // (the entry point has set the error string)
     }
     return NELE_OK;
+}
+
+// The same with the sizes of the caller's buffers: sizes_host[k] = bytes behind slots_host[k] (ignored for scalar slots).
+extern "C" int nele_plan_run_sized(void* plan, void* const* streams_host, int nstreams, const long long* slots_host, const long long* sizes_host, int nslots) {
+    NelePlan* p = reinterpret_cast<NelePlan*>(plan);
+    NELE_CHECK_ARG(p && p->magic == PLAN_MAGIC && sizes_host && slots_host && nslots >= p->nslots, "nele_plan_run_sized: bad arguments");
+    for (int k = 0; k < p->nslots; ++k)
+        if (p->slot_bytes[k] > 0 && slots_host[k] != 0 && sizes_host[k] < p->slot_bytes[k])
+            return nele_set_error(NELE_ERR_INVALID_ARG, "nele_plan_run_sized: slot %d holds %lld bytes, the plan touches %lld", k, sizes_host[k], p->slot_bytes[k]);
+    return nele_plan_run(plan, streams_host, nstreams, slots_host, nslots);
 }
 
 // ---- the composite entry points: a plan + the per-call pointers in its first slots

@@ -1337,6 +1337,41 @@ static size_t siib_layout(int B, int L, SiibWs* w, char* base) {
 
 extern "C" long long nele_metric_siib_workspace_bytes(int B, int L) { return (long long)siib_layout(B, L, nullptr, nullptr); }
 
+// What phase 3 (the clean-signal half) leaves in a workspace for phase 4, as byte ranges of the workspace: out[3 k .. 3 k + 2] =
+// {offset, stride, bytes}.  stride > 0: a per-utterance section - utterance b's state is the first `bytes` bytes at offset + b * stride;
+// stride == 0: a table every utterance shares (gammatone responses, DFT / window tables).  The clean-signal state of an utterance - the
+// active-frame list, the clean log spectra and row statistics, the window means, the KLT eigenvalues and eigenvectors, the eigensolver's
+// repair flag - is a pure function of the clean waveform (and of the padded length L, which fixes the strides): a training loop that
+// scores the same clean files every epoch (train_nele.py:35-38,119,318-340) may copy these ranges out after phase 3 and, in a later call
+// with the same L, copy them into the workspace INSTEAD of running phase 3 (utterances may sit at other rows b, B may differ).
+// Returns the number of sections (<= max_sections), or a negative status.
+extern "C" int nele_metric_siib_clean_sections(int B, int L, long long* out, int max_sections) {
+    NELE_CHECK_ARG(B > 0 && out && max_sections >= 13, "nele_metric_siib_clean_sections: bad arguments (13 sections)");
+    if (!siib_lag_path()) return nele_set_error(NELE_ERR_UNSUPPORTED, "nele_metric_siib_clean_sections: lag-product path only");
+    SiibWs w;
+    char* base = reinterpret_cast<char*>((uintptr_t)1 << 20);
+    siib_layout(B, L, &w, base);
+    const int* fl = nele_eigh_flags(w.eigws, B, SB_D);
+    int k = 0;
+    auto put = [&](const void* p, long long stride, long long bytes) {
+        out[3 * k] = (long long)(reinterpret_cast<const char*>(p) - base); out[3 * k + 1] = stride; out[3 * k + 2] = bytes; ++k;
+    };
+    put(w.g2, 0, sizeof(double) * SB_J * SB_NBIN);
+    put(w.tab, 0, sizeof(double) * 3 * SB_WLEN);
+    put(w.g2t, 0, sizeof(double) * SB_NBIN * SB_J);
+    put(w.rowstat, sizeof(double) * 2 * SB_J * 2, sizeof(double) * 2 * SB_J * 2);
+    put(w.xdb, sizeof(double) * (size_t)w.NT, sizeof(double) * (size_t)w.NT);
+    put(w.list, sizeof(int) * (size_t)w.NA, sizeof(int) * (size_t)w.NA);
+    put(w.info, sizeof(int) * 4, sizeof(int) * 4);
+    put(w.nprim, sizeof(int), sizeof(int));
+    put(w.XL, sizeof(double) * 2 * SB_J * (size_t)w.NA, sizeof(double) * SB_J * (size_t)w.NA);        // the clean half of [2][28][NA]
+    put(w.lam, sizeof(double) * SB_D, sizeof(double) * SB_D);
+    put(w.U, sizeof(double) * SB_D * SB_D, sizeof(double) * SB_D * SB_D);
+    put(w.mu, sizeof(double) * 2 * SB_D, sizeof(double) * SB_D);                                       // the clean half of [2][420]
+    put(fl, sizeof(int), sizeof(int));
+    return k;
+}
+
 // phase: 0 = everything, 1 = front only (VAD .. covariance), 2 = back only (eigenvectors .. score): the split lets the caller put
 // independent work between the wide front kernels and the latency-bound eigen-decomposition.
 // 3 = everything that depends on the CLEAN signal only (VAD, active-frame list, x spectra / masking / stacking, covariance,

@@ -57,6 +57,11 @@ _lib.lib.nele_metric_haspi_nsub.argtypes = [c_int, c_int]
 _lib.lib.nele_metric_haspi_nsub.restype = c_int
 _lib._SIGS['nele_metric_haspi_nsub'] = _lib.lib.nele_metric_haspi_nsub.argtypes
 
+declare('nele_metric_siib_clean_sections', [c_int, c_int, ctypes.POINTER(c_longlong), c_int])
+_lib._SIGS['nele_metric_siib_clean_sections'] = _lib.lib.nele_metric_siib_clean_sections.argtypes
+declare('nele_metric_haspi_clean_sections', [c_int, c_int, c_int, ctypes.POINTER(c_longlong), c_int])
+_lib._SIGS['nele_metric_haspi_clean_sections'] = _lib.lib.nele_metric_haspi_clean_sections.argtypes
+
 declare('nele_haspi_dither_rows', [_P, ctypes.c_ulonglong, c_int, c_int, _P, _P])
 _lib._SIGS['nele_haspi_dither_rows'] = _lib.lib.nele_haspi_dither_rows.argtypes
 
@@ -88,6 +93,153 @@ def _workspace(kind, nbytes, dev, cache=None):
 def release_workspaces():
     """Drop the module-global scratch buffers (they are re-created on demand)."""
     _ws_cache.clear()
+
+
+class CleanStateCache:
+    """Per-utterance clean-signal state of the split metrics, kept across calls (GanTrainer.enable_clean_cache).
+
+    The reference scores the same <= 720 clean training files in every one of its 500 GAN epochs (train_nele.py:35-38,119,318-340) and
+    recomputes the clean file's half of every metric each time.  That half is a pure function of the clean waveform: SIIB's VAD,
+    clean spectra, covariance and KLT eigen-decomposition (phase 3 of nele_metric_siib_var: the step's single most expensive
+    kernel chain), HASPI's whole reference-signal chain (phase 3 of nele_metric_haspi_var).  The library says which byte ranges of a
+    workspace make up that state (nele_metric_{siib,haspi}_clean_sections); this class copies them out after phase 3 - one row per
+    utterance and section in pooled device buffers - and copies them back in place of phase 3 when the same utterances come by again,
+    at whatever rows of whatever batch.  Copies only: the scores are bit-identical to recomputation (tests/test_clean_cache_gpu.py).
+    Keys: (kind, geometry = padded length L (+ fs, dither mode for HASPI), utterance key); the utterance key (file name, corpus id)
+    stands for the clean waveform including its own length.  Never invalidated (clean files are immutable); once ``budget_bytes`` of device memory are in use, new utterances are simply not stored (they are recomputed)."""
+
+    BLOCK_ROWS = 64
+
+    def __init__(self, budget_bytes):
+        self.budget = int(budget_bytes)
+        self.used = 0
+        self.pools = {}             # (kind, geometry) -> pool dict
+        self.hits = self.misses = self.stored = self.declined = 0
+        self.poison = False         # tests: fill the workspace with 0xFF bytes before a restore (a forgotten section cannot go unnoticed)
+
+    @staticmethod
+    def _sections(kind, B, L, fs):
+        buf = (c_longlong * (3 * 24))()
+        if kind == 'siib':
+            n = _lib.lib.nele_metric_siib_clean_sections(int(B), int(L), buf, 24)
+        else:
+            n = _lib.lib.nele_metric_haspi_clean_sections(int(B), int(L), int(fs), buf, 24)
+        if n < 0:
+            return None
+        return [(int(buf[3 * k]), int(buf[3 * k + 1]), int(buf[3 * k + 2])) for k in range(n)]
+
+    def _pool(self, kind, geom, L, fs):
+        key = (kind, geom)
+        p = self.pools.get(key)
+        if p is None:
+            sec = self._sections(kind, 1, L, fs)
+            if sec is None:
+                return None
+            p = self.pools[key] = {'row_bytes': [b for (_o, st, b) in sec if st > 0], 'shared': None, 'blocks': [], 'index': {}, 'free': 0,
+                                   'event': None, 'per_utt': sum(b for (_o, st, b) in sec if st > 0)}
+        return p
+
+    def lookup(self, kind, geom, keys):
+        """-> list of (block, row) slots when EVERY utterance of the batch is cached, else None."""
+        p = self.pools.get((kind, geom))
+        if p is None or p['shared'] is None:
+            self.misses += 1
+            return None
+        idx = p['index']
+        slots = [idx.get(k) for k in keys]
+        if any(s is None for s in slots):
+            self.misses += 1
+            return None
+        self.hits += 1
+        return slots
+
+    @staticmethod
+    def _runs(slots):
+        """[(block, row)] in batch order -> runs (first batch row, block, first block row, count) of consecutive rows"""
+        runs, k = [], 0
+        while k < len(slots):
+            b, r = slots[k]
+            n = 1
+            while k + n < len(slots) and slots[k + n] == (b, r + n):
+                n += 1
+            runs.append((k, b, r, n))
+            k += n
+        return runs
+
+    def restore(self, kind, geom, ws, B, L, fs, slots):
+        """Copy the cached state of the batch's utterances into workspace ``ws`` (uint8 tensor) on the current stream."""
+        p = self.pools[(kind, geom)]
+        sec = self._sections(kind, B, L, fs)
+        cur = torch.cuda.current_stream(ws.device)
+        if p['event'] is not None:
+            cur.wait_event(p['event'])           # the stores may have run on another stream
+        if self.poison:
+            ws.fill_(255)
+        runs = self._runs(slots)
+        j = sh = 0
+        for (off, st, nb) in sec:
+            if st == 0:
+                ws[off:off + nb].copy_(p['shared'][sh])
+                sh += 1
+                continue
+            view = ws[off:off + B * st].view(B, st)[:, :nb]
+            for (k0, blk, r0, n) in runs:
+                view[k0:k0 + n].copy_(p['blocks'][blk][j][r0:r0 + n])
+            j += 1
+
+    def store(self, kind, geom, ws, B, L, fs, keys):
+        """Copy the state phase 3 just left in ``ws`` into the pool for the utterances not cached yet (current stream)."""
+        p = self._pool(kind, geom, L, fs)
+        if p is None:
+            return
+        sec = self._sections(kind, B, L, fs)
+        if p['shared'] is None:
+            p['shared'] = [ws[off:off + nb].clone() for (off, st, nb) in sec if st == 0]
+            self.used += sum(t.numel() for t in p['shared'])
+        new = [(k, key) for k, key in enumerate(keys) if key not in p['index']]
+        if not new:
+            return
+        slots = []
+        for _k, _key in new:
+            if p['free'] == 0:
+                need = self.BLOCK_ROWS * p['per_utt']
+                if self.used + need > self.budget:
+                    self.declined += len(new) - len(slots)
+                    break
+                p['blocks'].append([torch.empty((self.BLOCK_ROWS, nb), dtype=torch.uint8, device=ws.device) for nb in p['row_bytes']])
+                p['free'] = self.BLOCK_ROWS
+                self.used += need
+            slots.append((len(p['blocks']) - 1, self.BLOCK_ROWS - p['free']))
+            p['free'] -= 1
+        new = new[:len(slots)]
+        if not new:
+            return
+        # runs of consecutive batch rows that landed in consecutive pool rows
+        runs, k = [], 0
+        while k < len(new):
+            n = 1
+            while (k + n < len(new) and new[k + n][0] == new[k][0] + n and slots[k + n] == (slots[k][0], slots[k][1] + n)):
+                n += 1
+            runs.append((new[k][0], slots[k][0], slots[k][1], n))
+            k += n
+        j = 0
+        for (off, st, nb) in sec:
+            if st == 0:
+                continue
+            view = ws[off:off + B * st].view(B, st)[:, :nb]
+            for (k0, blk, r0, n) in runs:
+                p['blocks'][blk][j][r0:r0 + n].copy_(view[k0:k0 + n])
+            j += 1
+        for (_k, key), slot in zip(new, slots):
+            p['index'][key] = slot
+        self.stored += len(new)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ws.device))
+        p['event'] = ev
+
+    def stats(self):
+        return {'hits': self.hits, 'misses': self.misses, 'stored': self.stored, 'declined': self.declined, 'bytes': self.used,
+                'utterances': {'%s@%s' % k: len(p['index']) for k, p in self.pools.items()}}
 
 
 def eigh_batched(A, return_repaired=False):
@@ -170,8 +322,22 @@ class SiibSplit:
         self._call(2)
         return self.raw, self.mapped
 
-    def clean_part(self):
+    def clean_part(self, cache=None, keys=None):
+        """cache (CleanStateCache) + keys (one hashable per utterance, e.g. the file name): when every utterance's clean-signal state is
+        cached it is copied into the workspace instead of being recomputed; otherwise phase 3 runs and the new utterances are stored."""
+        if cache is None or keys is None:
+            self._call(3)
+            return False
+        B, L = self.x.shape
+        geom = ('L', L)
+        full = list(keys)                       # a key stands for the clean waveform, its own length included
+        slots = cache.lookup('siib', geom, full)
+        if slots is not None:
+            cache.restore('siib', geom, self.ws, B, L, 0, slots)
+            return True
         self._call(3)
+        cache.store('siib', geom, self.ws, B, L, 0, full)
+        return False
 
     def degraded_part(self, y):
         assert y.shape == self.x.shape
@@ -301,8 +467,23 @@ class HaspiSplit:
         call('nele_metric_haspi_var', ptr(self.x), ptr(y), ptr(self.lengths), B, L, self.fs, ptr(dither), ptr(self.ws), self.ws.numel(),
              ptr(self.raw), ptr(self.mapped), ptr(self.info), phase, stream())
 
-    def clean_part(self, dither=None):
+    def clean_part(self, dither=None, cache=None, keys=None, dither_tag=None):
+        """cache / keys: as SiibSplit.clean_part.  ``dither_tag``: hashable that identifies the reference's dither rows (None = no dither;
+        e.g. ('utterance', seed) for rows drawn per utterance id) - a cached state is only valid for the dither it was computed with;
+        a dither with no tag is never cached."""
+        if cache is None or keys is None or (dither is not None and dither_tag is None):
+            self._call(None, dither, 3)
+            return False
+        B, L = self.x.shape
+        geom = ('L', L, 'fs', self.fs, 'dither', dither_tag)
+        full = list(keys)
+        slots = cache.lookup('haspi', geom, full)
+        if slots is not None:
+            cache.restore('haspi', geom, self.ws, B, L, self.fs, slots)
+            return True
         self._call(None, dither, 3)
+        cache.store('haspi', geom, self.ws, B, L, self.fs, full)
+        return False
 
     def degraded_part(self, y, dither=None):
         assert y.shape == self.x.shape

@@ -206,6 +206,7 @@ class GanTrainer:
         # hides under them.  One rank: no collective, nothing is deferred.
         self.overlap_allreduce = True
         self._pending_d = None
+        self.clean_cache = None                      # metrics.CleanStateCache (enable_clean_cache): clean-signal halves of SIIB / HASPI kept across epochs
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
                 ndist.broadcast_module_(m, 0)
@@ -361,7 +362,38 @@ class GanTrainer:
         return st
 
     # ---------------------------------------------------------------- true metric targets (train_nele.py:318-340)
-    def _metric(self, m, x, y, which, lengths=None, utt_ids=None):
+    def enable_clean_cache(self, budget_bytes=None):
+        """Keep the clean-signal halves of SIIB (VAD .. KLT eigen-decomposition) and HASPI (the reference-signal chain) of every scored
+        utterance in device memory and reuse them whenever the utterance is scored again: the reference draws the same <= 720 training
+        files for 500 epochs (train_nele.py:35-38,119,318-340) and recomputes them each time.  Batches must carry ``keys`` (or ``names``):
+        one hashable per utterance that stands for its clean waveform (with haspi_dither='utterance': also for its utterance id).
+        ~2.1 MB (SIIB) + ~6.5 MB (HASPI) per 4 s utterance.  budget_bytes: device-memory cap (default: a quarter of what is free now);
+        beyond it new utterances are recomputed every time.  Scores are bit-identical to recomputation (copies only)."""
+        if budget_bytes is None:
+            budget_bytes = torch.cuda.mem_get_info(self.device)[0] // 4
+        self.clean_cache = mt.CleanStateCache(budget_bytes)
+        self._feat_cache = {}                        # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys
+        return self.clean_cache
+
+    def _dither_tag(self):
+        return None if self.haspi_dither is None else (self.haspi_dither, self.dither_seed)
+
+    def _metric(self, m, x, y, which, lengths=None, utt_ids=None, keys=None):
+        if self.clean_cache is not None and keys is not None and m in ('siib', 'haspi'):
+            # split form: the clean-signal half comes from the cache when every utterance of the batch is in it (bit-identical to the
+            # one-call form: phase 0 runs exactly phases 3 and 4 back to back)
+            if m == 'siib':
+                sp = mt.SiibSplit(x, lengths=lengths, owner=self._ws)
+                sp.clean_part(cache=self.clean_cache, keys=keys)
+                raw, mapped = sp.degraded_part(y)
+                self._note_status(which, siib_info=sp.info)
+            else:
+                hp = mt.HaspiSplit(x, lengths=lengths, owner=self._ws)
+                dz = self._dither(x, utt_ids)
+                hp.clean_part(dither=dz, cache=self.clean_cache, keys=keys, dither_tag=self._dither_tag())
+                raw, mapped = hp.degraded_part(y, dither=dz)
+                self._note_status(which, haspi_info=hp.info)
+            return raw, mapped
         if m == 'siib':
             raw, mapped, info = mt.batch_siib(x, y, return_info=True, lengths=lengths)
             self._note_status(which, siib_info=info)
@@ -385,13 +417,14 @@ class GanTrainer:
         return _MetricFork(self, inputs)
 
     @torch.no_grad()
-    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None, defer=False):
+    def true_metrics(self, clean_wav, enh_wav, noise_wav, norm=True, lengths=None, resynth=True, utt_ids=None, defer=False, keys=None):
         """[B, n_metrics] targets of (clean, enhanced + noise) (audio_util.py:120-203).  lengths [B]: samples of each utterance inside the
         padded batch; resynth=True: ``enh_wav`` came out of ``generate`` (each row holds 256 * (L // 256) samples); False: ``lengths``
         already are min(clean, enhanced) per utterance (the pre-enhanced 'DRC' examples, audio_util.py:267-321).
         utt_ids [B] int64: utterance ids for the per-utterance HASPI dither (haspi_dither='utterance').
         defer: return a _PendingTargets instead - the kernels are enqueued on the metric streams, the caller's stream is not made to
-        wait for them until .result() (run_epoch: a batch's metrics run under the next batch's generator)."""
+        wait for them until .result() (run_epoch: a batch's metrics run under the next batch's generator).
+        keys [B] (host list of hashables, one per utterance): with enable_clean_cache() the clean-signal halves are reused across calls."""
         L = min(clean_wav.shape[1], enh_wav.shape[1])          # audio_util.py:134-141
         x = clean_wav[:, :L].contiguous()
         y = (enh_wav[:, :L] + noise_wav[:, :L]).contiguous()
@@ -405,7 +438,7 @@ class GanTrainer:
                                                                #  marked as used there until the targets are waited for)
         for m in self.metrics:
             with fork.on(m) as which:
-                raw, mapped = self._metric(m, x, y, which, lengths, utt_ids)
+                raw, mapped = self._metric(m, x, y, which, lengths, utt_ids, keys)
                 cols.append(fork.out(mapped if norm else raw))
         if defer:
             return _PendingTargets([fork], lambda: torch.stack(cols, dim=1))
@@ -413,7 +446,8 @@ class GanTrainer:
         return torch.stack(cols, dim=1)
 
     @torch.no_grad()
-    def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None, defer=False):
+    def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None, defer=False,
+                          keys=None):
         """Targets of TWO degraded versions of one clean batch - the generated example and the pre-enhanced ('DRC') one, which the loop
         scores back to back (train_nele.py:318-340) - with the clean-signal work done once: SIIB's VAD / clean spectra / covariance /
         eigen-decomposition (its KLT basis) and HASPI's whole reference-signal chain depend on the clean signal only
@@ -430,12 +464,14 @@ class GanTrainer:
             ml_d = torch.clamp(torch.minimum(full(drc_lengths, drc_wav), full(lengths, clean_wav)), max=Ld)
         same = (L == Ld) and ((ml_e is None and ml_d is None) or (ml_e is not None and ml_d is not None and bool(torch.equal(ml_e, ml_d))))
         if not same:
+            # (the pre-enhanced comparison sees the clean file cut to another length: its clean-signal state is cached under its own key)
+            kd = None if keys is None else [('drc', k_) for k_ in keys]
             if defer:
-                pa = self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids, defer=True)
-                pb = self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids, defer=True)
+                pa = self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids, defer=True, keys=keys)
+                pb = self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids, defer=True, keys=kd)
                 return _PendingTargets([], lambda: (pa.result(), pb.result()))
-            return (self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids),
-                    self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids))
+            return (self.true_metrics(clean_wav, enh_wav, noise_wav, norm=norm, lengths=lengths, utt_ids=utt_ids, keys=keys),
+                    self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids, keys=kd))
         x = clean_wav[:, :L].contiguous()
         ys = [(enh_wav[:, :L] + noise_wav[:, :L]).contiguous(), (drc_wav[:, :L] + noise_wav[:, :L]).contiguous()]
         pick = (lambda r, m_: m_) if norm else (lambda r, m_: r)
@@ -445,7 +481,7 @@ class GanTrainer:
             with fork.on(m) as which:
                 if m == 'siib':
                     sp = mt.SiibSplit(x, lengths=ml_e, owner=self._ws)
-                    sp.clean_part()
+                    sp.clean_part(cache=self.clean_cache, keys=keys)
                     for k, y in enumerate(ys):
                         raw, mapped = sp.degraded_part(y)
                         cols[k][m] = fork.out(pick(raw, mapped).clone())
@@ -453,7 +489,7 @@ class GanTrainer:
                 elif m == 'haspi':
                     hp = mt.HaspiSplit(x, lengths=ml_e, owner=self._ws)
                     dz = self._dither(x, utt_ids)
-                    hp.clean_part(dither=dz)
+                    hp.clean_part(dither=dz, cache=self.clean_cache, keys=keys, dither_tag=self._dither_tag())
                     for k, y in enumerate(ys):
                         raw, mapped = hp.degraded_part(y, dither=dz)
                         cols[k][m] = fork.out(pick(raw, mapped).clone())
@@ -957,7 +993,9 @@ class GanTrainer:
         'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua),
         optional 'lengths': [B] samples of each utterance inside the zero-padded batch (files of different lengths side by side, as
         the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths'),
-        optional 'ids': [B] int64 utterance ids (haspi_dither='utterance': the dither rows follow the utterance, not the rank)}.
+        optional 'ids': [B] int64 utterance ids (haspi_dither='utterance': the dither rows follow the utterance, not the rank),
+        optional 'keys' (default: 'names'): one hashable per utterance - with enable_clean_cache() the clean-signal halves of SIIB / HASPI
+        of an utterance are computed the first time it is scored and reused in every later epoch}.
         Under data parallelism every rank passes its own shard of batches; ranks may hold different batch counts and sizes (empty
         G-steps / D-steps join the collectives, gradients are item-weighted means, the validation means run over all ranks).
           1. G-steps over the training batches - from epoch 2 on (:122-156; epoch 1 fits D to the untrained generator first)
@@ -974,7 +1012,26 @@ class GanTrainer:
         dp = self.world > 1
 
         def fts(b):
-            return self.features(b['clean'], b['noise'], b.get('lengths'))
+            # with the clean-signal cache on, a batch's features (STFT / band energies of the clean file, IMCRA noise track of its noise
+            # file: both files are fixed per utterance, train_nele.py:119, dataloader.py:30-42) are kept too, keyed by the batch's keys
+            kw_ = ckw(b)
+            fc = getattr(self, '_feat_cache', None)
+            k_ = None
+            if kw_ and kw_['keys'] is not None and fc is not None:
+                k_ = (tuple(kw_['keys']), tuple(b['clean'].shape))
+                hit = fc.get(k_)
+                if hit is not None:
+                    return hit
+            f_ = self.features(b['clean'], b['noise'], b.get('lengths'))
+            if k_ is not None:
+                nb_ = sum(t.numel() * t.element_size() for t in f_.values() if torch.is_tensor(t))
+                if self.clean_cache.used + nb_ <= self.clean_cache.budget:
+                    self.clean_cache.used += nb_
+                    fc[k_] = f_
+            return f_
+
+        def ckw(b):                                                     # utterance keys travel only when the clean-signal cache is on
+            return {'keys': b.get('keys', b.get('names'))} if getattr(self, 'clean_cache', None) is not None else {}
 
         if gan_epoch >= 2:                                              # :122
             tot = None
@@ -998,7 +1055,7 @@ class GanTrainer:
             if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
                 self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch,
                                    lengths=b.get('lengths_host', b.get('lengths')), wait=False)
-            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids'), defer=True))
+            raw.append(self.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b.get('lengths'), utt_ids=b.get('ids'), defer=True, **ckw(b)))
         raw = [p.result() for p in raw]                                 # (a batch's metrics ran under the next batch's generator)
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
@@ -1040,9 +1097,9 @@ class GanTrainer:
             if b.get('drc') is not None:
                 # generated + pre-enhanced ('DRC') example of the same utterances (:318-340; audio_util.py:267-321; the DRC file keeps its
                 # own length): one pass over the clean signal for both when they are compared over the same samples (audio_util.py:134-137)
-                pend = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'), defer=True)
+                pend = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'), defer=True, **ckw(b))
             else:
-                pend = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'), defer=True)
+                pend = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'), defer=True, **ckw(b))
             # the targets are not waited for here: this batch's metric kernels (three streams, SIIB's a latency chain through the
             # eigensolver) run under the next batch's generator and feature kernels; everything is resolved behind the loop
             din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
