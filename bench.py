@@ -630,10 +630,19 @@ def main():
         assert bool(torch.isfinite(lg_)) and bool(torch.isfinite(ld_)) and bool(torch.isfinite(tgt_).all()), "non-finite loss / targets in the timed region"
         assert bool(torch.isfinite(tr.G.flat_parameters().flat).all()) and bool(torch.isfinite(tr.D.flat_parameters().flat).all()), "non-finite weights"
         status = tr.check_status(raise_on_error=True)
+    rank_ms = None
     if world > 1:
+        # per-rank clocks of the same timed region (the line's ms_per_step is their maximum): a slow rank, a rank that waited in the
+        # collectives and the eigensolver's repair count of every rank are visible in the first real multi-GPU line
+        mine = dt / a.steps * 1e3
+        lo_ = torch.tensor([mine], device='cuda', dtype=torch.float64)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        rep_ = torch.tensor([float(status.get('eigh_repaired', 0)) if not a.breakdown else 0.0], device='cuda', dtype=torch.float64)
+        dist.all_reduce(rep_, op=dist.ReduceOp.MAX)
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        rank_ms = {'min': float(lo_.item()), 'max': dt / a.steps * 1e3, 'rank0': mine, 'eigh_repaired_max_over_ranks': int(rep_.item())}
     hbm_ms = _lib.profile_collect_tag(htag) if 'haspi' in metrics else []
     eig_ms = _lib.profile_collect_tag(etag) if 'siib' in metrics else []
 
@@ -737,6 +746,7 @@ def main():
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops,
                          'pmc_source': pmc_note},
             'ranks_seen': ranks_seen,
+            **({'per_rank_ms_per_step': rank_ms} if rank_ms is not None else {}),
             **({'one_device_test': True} if one_device else {}),
             'step_status': status if not a.breakdown else None,      # device-side counters of the timed region + warm-up (GanTrainer.check_status): eigh_repaired must be 0
         }

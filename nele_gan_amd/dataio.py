@@ -13,6 +13,7 @@ PCM_16 semantics follow libsndfile: write ``rint(x * 0x7FFF)`` (round half to ev
 (PARITY UNPINNED: libsndfile itself is absent; same rule as ``nele_wav_post`` on the device).
 """
 import os
+import threading
 import struct
 
 import numpy as np
@@ -340,23 +341,54 @@ def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
 # Page-locked host buffers cost milliseconds to allocate (tens for a 64 MB batch): they are pooled per shape for the life of the process and
 # shared by every loader / writer (FileBatches, inference.enhance_files).
 _PINNED = {}
+_PINNED_LOCK = threading.Lock()
+_PINNED_BYTES = 0
+PINNED_POOL_MAX_BYTES = 2 << 30      # page-locked host memory kept for reuse; buffers returned beyond it are freed (variable-length batches)
 
 
 def pinned_get(shape, dtype=None):
+    """A page-locked host buffer of this shape from the pool (hipHostMalloc per batch costs milliseconds), or a new one.  The pool is shared
+    by the loader threads, the background writer thread and the main thread: one lock around the check-and-pop."""
+    global _PINNED_BYTES
     import torch
     dtype = torch.float32 if dtype is None else dtype
-    lst = _PINNED.get((tuple(shape), dtype))
-    return lst.pop() if lst else torch.empty(tuple(shape), dtype=dtype).pin_memory()
+    with _PINNED_LOCK:
+        lst = _PINNED.get((tuple(shape), dtype))
+        if lst:
+            t = lst.pop()
+            _PINNED_BYTES -= t.numel() * t.element_size()
+            return t
+    return torch.empty(tuple(shape), dtype=dtype).pin_memory()
 
 
 def pinned_put(t):
-    if t is not None:
+    """Return a buffer to the pool; beyond PINNED_POOL_MAX_BYTES the oldest pooled buffers are dropped first (shapes that no longer occur -
+    padded lengths vary from batch to batch - must not pin host memory for good)."""
+    global _PINNED_BYTES
+    if t is None:
+        return
+    nb = t.numel() * t.element_size()
+    with _PINNED_LOCK:
         _PINNED.setdefault((tuple(t.shape), t.dtype), []).append(t)
+        _PINNED_BYTES += nb
+        if _PINNED_BYTES > PINNED_POOL_MAX_BYTES:
+            for key in list(_PINNED.keys()):                # insertion order: the shapes seen first
+                lst = _PINNED[key]
+                while lst and _PINNED_BYTES > PINNED_POOL_MAX_BYTES and not (key == (tuple(t.shape), t.dtype) and len(lst) == 1):
+                    d = lst.pop(0)
+                    _PINNED_BYTES -= d.numel() * d.element_size()
+                if not lst:
+                    del _PINNED[key]
+                if _PINNED_BYTES <= PINNED_POOL_MAX_BYTES:
+                    break
 
 
 def pinned_release():
     """Drop the pooled buffers (they are re-created on demand)."""
-    _PINNED.clear()
+    global _PINNED_BYTES
+    with _PINNED_LOCK:
+        _PINNED.clear()
+        _PINNED_BYTES = 0
 
 
 # ------------------------------------------------------------------------------------------------ batches from files, prefetched

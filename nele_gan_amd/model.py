@@ -353,6 +353,7 @@ class Generator_Conv1D_cLN(nn.Module):
     def _weights(self, dev):
         dev = _norm_dev(dev)
         if self._wf is None or self._wf[0][0].device != dev:
+            self._wgen = getattr(self, '_wgen', 0) + 1       # generation of the weight-layout tensors: part of every recorded plan's key
             wf, wb = [], []
             for (cin, cout, k) in _G_LAYERS:
                 wf.append(_zeros((cout, k * cin), dev))
@@ -474,7 +475,7 @@ class Generator_Conv1D_cLN(nn.Module):
         mask = _empty((B, T, 64), dev)
         tok0 = bf.reserve_tokens(len(_G_LAYERS))
         # the pass as ONE call (nele_gen_fwd on the job table recorded the first time this shape / mode came by), or call by call
-        pkey = ('fwd', bool(need_bwd), self.precision, fused, self._weights_frozen, self._flat.flat.data_ptr(), self._wf[0][0].data_ptr())
+        pkey = ('fwd', bool(need_bwd), self.precision, fused, self._weights_frozen, self._flat.flat.data_ptr(), self._wf[0][0].data_ptr(), self._wgen)
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
             plan.streams[0] = stream()
@@ -543,7 +544,8 @@ class Generator_Conv1D_cLN(nn.Module):
             if self._wstream is None:
                 self._wstream = ops.side_stream(dmask.device)
             wst = self._wstream
-        pkey = ('bwd', self.precision, fused, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr())
+        pkey = ('bwd', self.precision, fused, None if wst is None else wst.cuda_stream, self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), self._wf[0][0].data_ptr(),
+                self._wgen)
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
             plan.streams[0] = stream()
@@ -760,6 +762,7 @@ class _DiscriminatorBase(nn.Module):
     def _weights(self, dev):
         dev = _norm_dev(dev)
         if self._w is None or self._w['sigma'].device != dev:
+            self._wgen = getattr(self, '_wgen', 0) + 1       # generation of the weight-layout tensors: part of every recorded plan's key
             w = {'sigma': _zeros((8,), dev), 'wf': [], 'wb': [], 'wff': [], 'wbf': [], 'wff16': [], 'wbf16': [], 'wf16c': [], 'wb16c': []}
             cin = 4
             for (cout, k) in _D_CONVS:
@@ -911,7 +914,7 @@ class _DiscriminatorBase(nn.Module):
         # padded batch of utterances of different lengths: the pooling runs over each utterance's own valid output columns (frames - 20)
         bf.wvalid = None if frames is None else (frames.to(device=dev, dtype=torch.int32) - 20).contiguous()
         # the conv stack + head as ONE call (nele_disc_fwd on the job table recorded the first time this shape / mode came by), or call by call
-        pkey = ('fwd', self.precision, self.profile_prefix, bf.wvalid is None, self._flat.flat.data_ptr(), w['sigma'].data_ptr())
+        pkey = ('fwd', self.precision, self.profile_prefix, bf.wvalid is None, self._flat.flat.data_ptr(), w['sigma'].data_ptr(), self._wgen)
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
             plan.streams[0] = stream()
@@ -980,7 +983,7 @@ class _DiscriminatorBase(nn.Module):
         if g16 and not bf.c16 and bf.gbuf16 is None:
             bf.gbuf16 = torch.zeros(bf.gbuf[-1].shape, dtype=torch.bfloat16, device=bf.gbuf[-1].device)
         pkey = ('bwd', self.precision, bool(need_din), bool(wgrad), None if wsts is None else tuple(q.cuda_stream for q in wsts), wvalid is None,
-                self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), w['sigma'].data_ptr())
+                self._flat.flat.data_ptr(), self._flat.grad.data_ptr(), w['sigma'].data_ptr(), self._wgen)
         plan = bf.plans.get(pkey) if ops.plans_enabled() else None
         if plan is not None:
             plan.streams[0] = stream()

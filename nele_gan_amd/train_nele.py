@@ -172,7 +172,9 @@ class GanTrainer:
         self.step_g = 0
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
-        self.history_hbm_bytes = 64 << 30            # D inputs of past epochs kept in HBM for the replay; beyond it items move to host memory (_history_trim)
+        # D inputs of past epochs kept in HBM for the replay; beyond it items move to host memory (_history_trim).  A quarter of the device's
+        # memory (72 GB of an MI355X's 288), not a constant: a smaller GPU must spill before it runs out
+        self.history_hbm_bytes = (torch.cuda.get_device_properties(self.device).total_memory // 4) if self.device.type == 'cuda' else (64 << 30)
         self._side = None
         self._side2 = None
         self._fside = None
@@ -206,6 +208,7 @@ class GanTrainer:
         # hides under them.  One rank: no collective, nothing is deferred.
         self.overlap_allreduce = True
         self._pending_d = None
+        self.target_lag = 3                          # run_epoch: batches whose metric targets may be in flight behind the sample-generation loop
         self.clean_cache = None                      # metrics.CleanStateCache (enable_clean_cache): clean-signal halves of SIIB / HASPI kept across epochs
         for m in (self.G, self.D, self.D_Qua):
             if m is not None:
@@ -947,10 +950,17 @@ class GanTrainer:
     def _on_device(self, item):
         return item if item[0].device == self.device else tuple(None if t is None else t.to(self.device, non_blocking=True) for t in item)
 
+    @staticmethod
+    def _to_pinned(t):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)                 # ordered on the current stream; read again only through _on_device (same stream)
+        return h
+
     def _history_trim(self):
         """The reference's replay list holds FILE NAMES and re-reads them (train_nele.py:373-403); here it holds the D inputs themselves
         ([64, T, 4] float32, ~0.2 MB per item), which grows by an epoch's worth of samples per epoch.  Beyond ``history_hbm_bytes`` of
-        device memory, items (whichever come first in the shuffled list) are moved to host memory; a replayed one is uploaded again."""
+        device memory the items that follow in list order - the list is shuffled before every replay draw (d_epoch), so these are a random
+        subset, the newest epoch's items among them - move to page-locked host memory (asynchronous copies); a replayed one is uploaded again."""
         if self.device.type != 'cuda':
             return
         used = 0
@@ -959,7 +969,7 @@ class GanTrainer:
                 continue
             used += it[0].numel() * it[0].element_size()
             if used > self.history_hbm_bytes:
-                self.history[k] = tuple(None if t is None else t.to('cpu') for t in it)
+                self.history[k] = tuple(None if t is None else self._to_pinned(t) for t in it)
 
     # ---------------------------------------------------------------- one GAN epoch (train_nele.py:110-429)
     def d_mse(self, samples, batch=32):
@@ -1084,8 +1094,17 @@ class GanTrainer:
                         fh.write(line)
         if chkpt_path is not None and ndist.rank() == 0:
             self.save_checkpoint(chkpt_path)                            # :272-277
-        samples, pending = [], []
+        samples, pending, resolved = [], [], 0
         out['sample_files'] = []
+
+        def resolve(item):
+            pend, din, qua, frames, din_d, drc_qua = item
+            tgt = pend.result()
+            if din_d is not None:
+                tgt, tgt_d = tgt
+            samples.extend(self._items(din, tgt, qua, frames))
+            if din_d is not None:
+                samples.extend(self._items(din_d, tgt_d, drc_qua, frames))
         for i, b in enumerate(train_batches):                           # :279-340
             f = feats[i] if feats[i] is not None else fts(b)
             lens, frames = b.get('lengths'), f.get('frames')
@@ -1107,13 +1126,14 @@ class GanTrainer:
             if b.get('drc') is not None:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
             pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua')))
-        for pend, din, qua, frames, din_d, drc_qua in pending:
-            tgt = pend.result()
-            if din_d is not None:
-                tgt, tgt_d = tgt
-            samples += self._items(din, tgt, qua, frames)
-            if din_d is not None:
-                samples += self._items(din_d, tgt_d, drc_qua, frames)
+            # bounded lag: the targets of batch i - target_lag are resolved now, so that at most target_lag batches keep their metric inputs
+            # (x, y, lengths: 2 - 3 x B x L x 4 bytes each) alive and the main stream cannot run arbitrarily far ahead of the metric streams
+            while len(pending) - resolved > getattr(self, 'target_lag', 3):
+                resolve(pending[resolved])
+                resolved += 1
+        while resolved < len(pending):
+            resolve(pending[resolved])
+            resolved += 1
         out['samples'] = len(samples)
         d0 = self.step_d
         if d_eval:                                                      # D's error on this epoch's samples before it has trained on them
