@@ -38,18 +38,20 @@ def clean_utterance(i, length):
     return x.astype(np.float32)
 
 
-def noise_utterance(i, length, clean=None):
+def noise_utterance(i, length, clean=None, tilt=0.5):
+    """tilt: spectral slope of the noise, 1/f^tilt in amplitude (0.5 = the bench recipe: the same long-term spectrum as the clean signal;
+    larger = low-pass noise such as car or babble noise, where moving speech energy to higher bands pays - tools/learn_curve.py)"""
     rng = np.random.default_rng(987654 + i)
     w = rng.standard_normal(length)
-    v = _shape_1_over_f(w, 0.5)
+    v = _shape_1_over_f(w, tilt)
     snr = SNRS_DB[int(rng.integers(0, len(SNRS_DB)))]
     ref_rms = 0.03 if clean is None else float(np.sqrt(np.mean(clean.astype(np.float64) ** 2)))
     v = v / np.sqrt(np.mean(v ** 2)) * ref_rms * 10 ** (-snr / 20.0)
     return v.astype(np.float32)
 
 
-def batch(n, length, start=0):
+def batch(n, length, start=0, noise_tilt=0.5):
     """-> (clean [n, length] float32, noise [n, length] float32)."""
     c = np.stack([clean_utterance(start + k, length) for k in range(n)])
-    v = np.stack([noise_utterance(start + k, length, c[k]) for k in range(n)])
+    v = np.stack([noise_utterance(start + k, length, c[k], tilt=noise_tilt) for k in range(n)])
     return c, v

@@ -113,10 +113,11 @@ def main():
     ap.add_argument('--metrics', default='siib&haspi&estoi')
     ap.add_argument('--seed', type=int, default=666)
     ap.add_argument('--f32-second-seed', type=int, default=None, help='also run f32 with this seed: the seed-to-seed band the bf16 curve is compared with')
+    ap.add_argument('--noise-tilt', type=float, default=0.5, help='noise spectrum 1/f^tilt (0.5 = the bench recipe, same long-term spectrum as the speech; 1.5 = low-pass noise)')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
-    c, v = synth.batch(args.utts, args.length, start=0)
-    cv, vv = synth.batch(args.valid, args.length, start=100000)
+    c, v = synth.batch(args.utts, args.length, start=0, noise_tilt=args.noise_tilt)
+    cv, vv = synth.batch(args.valid, args.length, start=100000, noise_tilt=args.noise_tilt)
     dev = 'cuda'
     train = batches_of(torch.from_numpy(c).to(dev), torch.from_numpy(v).to(dev), args.batch, 0)
     valid = batches_of(torch.from_numpy(cv).to(dev), torch.from_numpy(vv).to(dev), max(args.batch, 64), 100000)
