@@ -403,8 +403,9 @@ def epoch_from_files(a, n_utt=256, batch=64):
         torch.cuda.synchronize()
         dt_mem = (time.perf_counter() - t0) / 2
         fb2 = dataio.FileBatches(files, root + '/Noise/', batch=batch, workers=nthreads, ahead=2, keep=1)
-        for b in fb2:                                                       # first pass: the pinned staging buffers are allocated (milliseconds each)
-            pass
+        for _ in range(2):                                                  # two passes: the pinned staging buffers are allocated (tens of milliseconds
+            for b in fb2:                                                   # each; the wrap-around from the last batch to the first needs one set more)
+                pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in fb2:                                                       # steady state: every file decoded again (keep = 1), buffers from the pool
@@ -467,15 +468,19 @@ def inference_from_files(tr, n_utt=4096, batch=128):
         nthreads = min(8, os.cpu_count() or 8)        # library threads per batch call (measured: 8 - 16 flat, 32 slower: the calls only move bytes)
         enhance_files(enh, files, root + '/Noise/', root + '/Warm', batch=batch, workers=nthreads)    # first pass: buffer sets, plans, pinned staging buffers
         shutil.rmtree(root + '/Warm', ignore_errors=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = enhance_files(enh, files, root + '/Noise/', root + '/Enh', batch=batch, workers=nthreads)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        passes = []
+        for k in range(2):                                                  # two timed passes, the better one is reported (a pass is ~0.1 s: one page-locked allocation shows)
+            shutil.rmtree(root + '/Enh', ignore_errors=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = enhance_files(enh, files, root + '/Noise/', root + '/Enh', batch=batch, workers=nthreads)
+            torch.cuda.synchronize()
+            passes.append(time.perf_counter() - t0)
+        dt = min(passes)
         tr.G.train()
         nbytes = sum(os.path.getsize(f) for f in files) * 2 + sum(os.path.getsize(f) for f in out)
         return {'value': n_utt / dt, 'unit': 'utterances/s', 'files': n_utt, 'utterance_seconds': '7 .. 8', 'batch': batch, 'host_threads': nthreads,
-                'wav_MB_per_s': nbytes / dt / 1e6, 'seconds': dt,
+                'wav_MB_per_s': nbytes / dt / 1e6, 'seconds': dt, 'passes_seconds': passes,
                 'path': 'wav files on tmpfs -> int16 rows of a pinned buffer (one library call per batch) -> HBM -> float32 on the device -> 3 batches in flight -> int16 on the device -> pinned -> PCM_16 files (one library call per batch)'}
     except Exception as e:
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
@@ -543,6 +548,11 @@ def main():
     if one_device:
         local = 0
     torch.cuda.set_device(local)
+    # one process per GPU, bound to the CPUs of that GPU's NUMA node before anything is allocated (pinned staging buffers, loader threads):
+    # the file-fed companions are host-bound, and an unbound process on a two-socket box copies across the socket link
+    cpus_before = os.sched_getaffinity(0)
+    from nele_gan_amd import dist as _nd
+    numa_cpus = _nd.bind_to_gpu_numa_node(local)
     if world > 1:
         import torch.distributed as dist
         if one_device:
@@ -746,6 +756,7 @@ def main():
                          'frac_isolated': (flops / (iso_ms * 1e-3) / 1e12 / peak if iso_ms > 0 else 0.0), 'launches_timed': len(prof), 'flops_per_launch': flops,
                          'pmc_source': pmc_note},
             'ranks_seen': ranks_seen,
+            'host_cpus_bound': (len(numa_cpus) if numa_cpus else None),     # CPUs of the GPU's NUMA node this process was restricted to (None: unbound)
             **({'per_rank_ms_per_step': rank_ms} if rank_ms is not None else {}),
             **({'one_device_test': True} if one_device else {}),
             'step_status': status if not a.breakdown else None,      # device-side counters of the timed region + warm-up (GanTrainer.check_status): eigh_repaired must be 0
@@ -853,6 +864,7 @@ def main():
                 if 'cached' in out['epoch_from_files']:
                     out['epoch_from_files_cached'] = out['epoch_from_files'].pop('cached')   # a companion of its own: never the headline `value`
         if world == 1 and a.cpu_utts > 0:
+            os.sched_setaffinity(0, cpus_before)         # the CPU leg parallelises like the reference over ALL host cores
             out['cpu_baseline'] = cpu_baseline(metrics, a.length, a.cpu_utts)
         print(json.dumps(out))
     if world > 1:

@@ -138,6 +138,9 @@ int nele_wav_write_pcm16(const char* path, const float* wav_host, long long n, i
  * -2 = cannot open; sample_rate_out[n] may be NULL.  `threads` (1 .. 256) library threads share the files; no GPU work. */
 int nele_wav_read_pcm16_batch(const char* const* paths, int n, short* out_host, long long row_stride, long long cap, int* n_out,
                               int* sample_rate_out, int threads);
+/* Sample counts of n wav files from their RIFF headers in one call (what os.path.getsize / sf.info per file would tell the loader, dataloader.py:34):
+ * n_out[i] = samples of a mono PCM_16 file, -1 = another flavour, -2 = cannot open.  No GPU work. */
+int nele_wav_probe_pcm16_batch(const char* const* paths, int n, int* n_out, int threads);
 /* ... rows of in_host [n][row_stride] int16 HOST memory -> n mono PCM_16 RIFF files of n_samples[i] samples (sf.write(path, wav, 16000, 'PCM_16')) */
 int nele_wav_write_pcm16_batch(const char* const* paths, int n, const short* in_host, long long row_stride, const int* n_samples, int sample_rate,
                                int threads);

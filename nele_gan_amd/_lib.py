@@ -71,6 +71,7 @@ _SIGS.update({
     'nele_wav_write_pcm16': [ctypes.c_char_p, c_void_p, c_longlong, c_int, c_int],
     'nele_wav_read_pcm16_batch': [c_void_p, c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int],
     'nele_wav_write_pcm16_batch': [c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_int, c_int],
+    'nele_wav_probe_pcm16_batch': [c_void_p, c_int, c_void_p, c_int],
     'nele_pcm16_to_float': [c_void_p, c_longlong, c_void_p, c_int, c_longlong, c_void_p, c_longlong, c_void_p],
     'nele_float_to_pcm16': [c_void_p, c_longlong, c_int, c_longlong, c_void_p, c_longlong, c_int, c_void_p],
     'nele_event_record': [c_void_p, c_void_p],
@@ -101,7 +102,7 @@ _SIGS.update({
     'nele_disc_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
     'nele_disc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int],
 })
-for _n in ('nele_wav_decode_pcm16', 'nele_wav_write_pcm16', 'nele_wav_read_pcm16_batch', 'nele_wav_write_pcm16_batch', 'nele_pcm16_to_float', 'nele_float_to_pcm16', 'nele_event_record', 'nele_stream_wait_event', 'nele_vec_add', 'nele_event_create', 'nele_event_destroy', 'nele_plan_op_id', 'nele_plan_op_nargs',
+for _n in ('nele_wav_decode_pcm16', 'nele_wav_write_pcm16', 'nele_wav_read_pcm16_batch', 'nele_wav_write_pcm16_batch', 'nele_wav_probe_pcm16_batch', 'nele_pcm16_to_float', 'nele_float_to_pcm16', 'nele_event_record', 'nele_stream_wait_event', 'nele_vec_add', 'nele_event_create', 'nele_event_destroy', 'nele_plan_op_id', 'nele_plan_op_nargs',
            'nele_plan_create', 'nele_plan_run', 'nele_plan_destroy', 'nele_gen_fwd', 'nele_gen_bwd', 'nele_disc_fwd', 'nele_disc_bwd'):
     declare(_n, _SIGS[_n])
 for _n in ('nele_plan_declare_slot', 'nele_plan_run_sized', 'nele_gen_param_layout', 'nele_gen_plan_build', 'nele_disc_param_layout', 'nele_disc_plan_build'):

@@ -89,6 +89,24 @@ extern "C" int nele_wav_read_pcm16_batch(const char* const* paths, int n, short*
     return NELE_OK;
 }
 
+// Sample counts of a batch of wav files from their headers (one foreign call instead of n stat() calls in the host language: the padded
+// length of a batch must be known before its staging rows are taken).  n_out[i] = samples of a mono PCM_16 file, -1 = another wav flavour
+// (the caller's general reader takes that file), -2 = cannot open.  No GPU work.
+extern "C" int nele_wav_probe_pcm16_batch(const char* const* paths, int n, int* n_out, int threads) {
+    if (!paths || n < 0 || (n > 0 && !n_out) || threads < 1 || threads > 256) return nele_set_error(NELE_ERR_INVALID_ARG, "nele_wav_probe_pcm16_batch: bad arguments");
+    for_each_file(n, threads, [&](int i) {
+        long long got = -2;
+        FILE* f = paths[i] ? fopen(paths[i], "rb") : nullptr;
+        if (f) {
+            WavHead h{0, 0};
+            got = wav_seek_data(f, &h) ? h.samples : -1;
+            fclose(f);
+        }
+        n_out[i] = got > 0x7fffffffLL ? 0x7fffffff : (int)got;
+    });
+    return NELE_OK;
+}
+
 extern "C" int nele_wav_write_pcm16_batch(const char* const* paths, int n, const short* in_host, long long row_stride, const int* n_samples,
                                           int sample_rate, int threads) {
     if (!paths || n < 0 || (n > 0 && (!in_host || !n_samples)) || row_stride < 0 || sample_rate <= 0 || threads < 1 || threads > 256)

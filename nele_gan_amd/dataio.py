@@ -144,6 +144,18 @@ def read_wav_batch_pcm16(paths, out_rows, threads=8):
     return got, sr
 
 
+def probe_wav_batch_pcm16(paths, threads=8):
+    """Sample counts of a batch of wav files from their RIFF headers in ONE foreign call (-1: not mono PCM_16, -2: unreadable) - what a
+    loop over os.path.getsize tells a loader, without 2 x B stat() calls per batch in the interpreter."""
+    import ctypes
+    n = len(paths)
+    got = np.zeros(n, dtype=np.int32)
+    st = _nele_lib.nele_wav_probe_pcm16_batch(ctypes.cast(_c_paths(paths), ctypes.c_void_p), n, ctypes.c_void_p(got.ctypes.data), max(1, min(256, int(threads))))
+    if st != 0:
+        raise IOError(_nele_lib.nele_last_error_string().decode('utf-8', 'replace'))
+    return got
+
+
 def write_wav_batch_pcm16(paths, rows, n_samples, sr=fs, threads=8):
     """Rows of ``rows`` ([n][>= max n_samples] int16: the sample values themselves) -> n mono PCM_16 files, written by the library's own
     threads in one foreign call."""
@@ -409,6 +421,7 @@ class FileBatches:
         import concurrent.futures as cf
         self.int16 = bool(int16)
         self.files, self.noise_path, self.drc_path = list(file_list), noise_path, drc_path
+        self.names = [f.split('/')[-1] for f in self.files]
         self.groups = [list(range(k, min(k + batch, len(self.files)))) for k in range(0, len(self.files), batch)]
         self.workers = max(1, int(workers))
         self.pool = cf.ThreadPoolExecutor(max_workers=self.workers)
@@ -457,7 +470,17 @@ class FileBatches:
         if not (0 <= g < len(self.groups)) or g in self._pending or g in self._ready:
             return
         idxs = self.groups[g]
-        names = [self.files[i].split('/')[-1] for i in idxs]
+        names = [self.names[i] for i in idxs]
+        if self.int16 and not force_f32:
+            # the files' sample counts in one library call (round 6: 2 x B stat() calls per batch were 0.8 of the ~3.1 ms of interpreter time
+            # that bound the streamed file path - tools/files_sweep.py: the same 41 k utterances/s with 4, 8 or 16 reader threads, with or
+            # without writing)
+            need = [p_ for p_ in [self.files[i] for i in idxs] + [self.noise_path + nm for nm in names] +
+                    ([self.drc_path + nm for nm in names] if self.drc_path is not None else []) if p_ not in self._bounds]
+            if need:
+                for p_, n_ in zip(need, probe_wav_batch_pcm16(need, self.workers)):
+                    if n_ > 0:
+                        self._bounds[p_] = int(n_)
         Lmax = max(max(self._bound(self.files[i]), self._bound(self.noise_path + nm)) for i, nm in zip(idxs, names))
         if self.pad_to:
             Lmax = (Lmax + self.pad_to - 1) // self.pad_to * self.pad_to
@@ -513,9 +536,16 @@ class FileBatches:
         with torch.cuda.stream(self._copy):
             sh = self._copy.cuda_stream
 
+            dls, small = {}, []
+
             def up(h, ln):
                 raw = h.to(self.device, non_blocking=True)
-                dl = torch.from_numpy(ln).pin_memory().to(self.device, non_blocking=True)
+                dl = dls.get(id(ln))
+                if dl is None:                                             # (clean and noise rows share their lengths: one upload, through a POOLED
+                    hl = pinned_get((len(ln),), torch.int32)               #  page-locked buffer: .pin_memory() allocated one per call, and a copy from
+                    hl.numpy()[:] = ln                                     #  pageable memory would make this thread wait for the stream's 65 MB uploads)
+                    small.append(hl)
+                    dl = dls[id(ln)] = hl.to(self.device, non_blocking=True)
                 out = torch.empty(tuple(h.shape), dtype=torch.float32, device=self.device)
                 _lib.check(_lib.lib.nele_pcm16_to_float(raw.data_ptr(), h.shape[1], dl.data_ptr(), h.shape[0], h.shape[1], out.data_ptr(), h.shape[1], sh),
                            'nele_pcm16_to_float')       # (not _lib.call: never part of a recorded pass)
@@ -528,7 +558,7 @@ class FileBatches:
                 b['drc'], b['drc_lengths'] = up(hd, dlens)
             ev = torch.cuda.Event()
             ev.record(self._copy)
-        self._ready[g] = (b, ev, (hc, hn, hd))
+        self._ready[g] = (b, ev, (hc, hn, hd) + tuple(small))
 
     def _stage(self, g):
         import torch

@@ -119,7 +119,7 @@ class Enhancer:
 
 
 def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=8,
-                  pad_to=4096):
+                  pad_to=4096, ahead=2, write=True):
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
     Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.
 
@@ -142,9 +142,13 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
         sizes = {i: os.path.getsize(file_list[i]) for i in mine}
         order = sorted(mine, key=lambda i: sizes[i])
     dev = enhancer.device
-    fb = dataio.FileBatches([file_list[i] for i in order], noise_path, batch=batch, workers=workers, ahead=2, device=dev, pad_to=pad_to,
-                            keep=inflight + 2)
+    fb = dataio.FileBatches([file_list[i] for i in order], noise_path, batch=batch, workers=workers, ahead=ahead, device=dev, pad_to=pad_to,
+                            keep=inflight + ahead)
+    if sort_by_length:
+        for i in mine:                                                   # the sizes are known already: no second stat() per clean file
+            fb._bounds[file_list[i]] = max(1, (sizes[i] - 44 + 1) // 2)
     written = {}
+    names = {i: file_list[i].split('/')[-1] for i in mine}
     copy_out = torch.cuda.Stream(device=dev)
     pool = cf.ThreadPoolExecutor(max_workers=inflight + 2)           # a task = one batch's write call
     meta, outq, writes = [], collections.deque(), []
@@ -161,12 +165,15 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
             ev.synchronize()
             paths = []
             for i in sel:
-                path = dataio.enhanced_name(output_path, file_list[i].split('/')[-1], epoch_tag)
+                path = dataio.enhanced_name(output_path, names[i], epoch_tag)
                 paths.append(path)
                 written[i] = path
             ns = [256 * (int(n) // 256) for n in lens]
             # one task per batch: the library's own threads write the files (nele_wav_write_pcm16_batch), no per-file work in the interpreter
-            writes.append((pool.submit(dataio.write_wav_batch_pcm16, paths, host.numpy(), ns, fs, workers), host))
+            if write:
+                writes.append((pool.submit(dataio.write_wav_batch_pcm16, paths, host.numpy(), ns, fs, workers), host))
+            else:                                                        # (diagnostic: everything but the file writes)
+                dataio.pinned_put(host)
         while writes and (block_all or writes[0][0].done()):
             fut, host = writes.pop(0)
             fut.result()                                                 # re-raises a writer's error
