@@ -36,7 +36,7 @@ F64_PEAK_TFLOPS = 78.6            # MI355X_MICROARCH.md: float64, vector FMA and
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, about 8 TB/s
-PROFILE_ROUND = 'r05'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
+PROFILE_ROUND = 'r06'            # profiles/<round>/traffic.json: PMC passes of this command (tools/prof_round.sh + tools/make_traffic_json.py)
 
 
 def csrc_sha():
