@@ -375,7 +375,9 @@ class GanTrainer:
         if budget_bytes is None:
             budget_bytes = torch.cuda.mem_get_info(self.device)[0] // 4
         self.clean_cache = mt.CleanStateCache(budget_bytes)
-        self._feat_cache = {}                        # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys
+        import collections
+        self._feat_cache = collections.OrderedDict() # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys (LRU)
+        self._feat_bytes = 0
         return self.clean_cache
 
     def _dither_tag(self):
@@ -1031,13 +1033,20 @@ class GanTrainer:
                 k_ = (tuple(kw_['keys']), tuple(b['clean'].shape))
                 hit = fc.get(k_)
                 if hit is not None:
-                    return hit
+                    fc.move_to_end(k_)
+                    return hit[0]
             f_ = self.features(b['clean'], b['noise'], b.get('lengths'))
             if k_ is not None:
+                # least-recently-used, at most an eighth of the cache's budget: a loop that re-draws its batches every epoch (fit: the
+                # reference shuffles its file list, train_nele.py:118) never sees a batch twice and must not crowd the per-utterance states out
                 nb_ = sum(t.numel() * t.element_size() for t in f_.values() if torch.is_tensor(t))
-                if self.clean_cache.used + nb_ <= self.clean_cache.budget:
-                    self.clean_cache.used += nb_
-                    fc[k_] = f_
+                cap_ = self.clean_cache.budget // 8
+                if nb_ <= cap_:
+                    while fc and self._feat_bytes + nb_ > cap_:
+                        _, old_ = fc.popitem(last=False)
+                        self._feat_bytes -= old_[1]
+                    fc[k_] = (f_, nb_)
+                    self._feat_bytes += nb_
             return f_
 
         def ckw(b):                                                     # utterance keys travel only when the clean-signal cache is on
@@ -1147,6 +1156,51 @@ class GanTrainer:
         if check:
             out['status'] = self.check_status()
         return out
+
+    # ---------------------------------------------------------------- the script's outer loop (train_nele.py:28-120, 272-277, 426-428)
+    def fit(self, train_clean_files, train_noise_path, valid_clean_files=(), valid_noise_path=None, train_enh_path=None, epochs=GAN_epoch,
+            sampling=num_of_sampling, valid_samples=num_of_valid_sample, batch=32, output_path='./output', pt_dir='./chkpt', log_path='./log.txt',
+            workers=8, first_epoch=1, clean_cache=False, on_epoch=None):
+        """``for gan_epoch in np.arange(1, GAN_epoch+1)`` of the reference script over folders of wav files, in its order:
+        every epoch the training list is shuffled and its first ``sampling`` files are drawn (train_nele.py:118-119), `run_epoch` runs on them
+        (G-steps from epoch 2, validation on the first ``valid_samples`` validation files with the learning-curve line appended to
+        ``log_path``, checkpoint ``pt_dir/chkpt_<epoch>.pt``, generated samples as ``<output_path>/For_discriminator_training/<name>@<epoch>.wav``,
+        true targets of the generated and - ``train_enh_path``: the folder of pre-enhanced 'MultiEnh' examples, train_nele.py:52 - the
+        pre-enhanced examples, three D passes with 1/30 replay).  Files are read in batches of ``batch`` through dataio.FileBatches (the
+        reference: batch 1); ``clean_cache``: keep the clean-signal halves of the metrics across epochs (enable_clean_cache).
+        ``on_epoch(result_dict)``: called after every epoch (return True to stop).  -> list of the epochs' result dicts.
+        The shuffles use Python's global generator, seeded by the constructor like train_nele.py:28."""
+        from . import dataio
+        dataio.creatdir(pt_dir)                                         # :45-46
+        dataio.creatdir(output_path)
+        if clean_cache and self.clean_cache is None:
+            self.enable_clean_cache()
+        train_files = list(train_clean_files)
+        random.shuffle(train_files)                                     # :57
+        valid_files = list(valid_clean_files)
+        random.shuffle(valid_files)                                     # :68
+        valid_files = valid_files[:int(valid_samples)]
+        vb = None
+        if valid_files:
+            vb = dataio.FileBatches(valid_files, valid_noise_path, batch=batch, workers=workers, ahead=2, keep=2, device=self.device)
+        results = []
+        try:
+            for gan_epoch in range(int(first_epoch), int(epochs) + 1):
+                random.shuffle(train_files)                             # :118
+                sel = train_files[0:int(round(sampling))]
+                fb = dataio.FileBatches(sel, train_noise_path, batch=batch, drc_path=train_enh_path, workers=workers, ahead=2, keep=2, device=self.device)
+                try:
+                    res = self.run_epoch(gan_epoch, fb, vb if vb is not None else (), chkpt_path=os.path.join(pt_dir, 'chkpt_%d.pt' % gan_epoch),
+                                         sample_dir=output_path, log_path=log_path, d_batch=batch)
+                finally:
+                    fb.close()
+                results.append(res)
+                if on_epoch is not None and on_epoch(res):
+                    break
+        finally:
+            if vb is not None:
+                vb.close()
+        return results
 
     @staticmethod
     def _items(din, tgt, qua, frames):

@@ -272,3 +272,47 @@ def test_enhance_stream_survives_a_consumer_that_stops_early():
     gen.close()                                                          # GeneratorExit inside the loop: pending batches are waited for, G unfrozen
     assert torch.equal(first, ref) and not e.G._weights_frozen and e.G.buffer_slot == 0
     assert torch.equal(e.enhance(cw, nw), ref)
+
+
+def test_fit_runs_the_scripts_outer_loop_over_folders(tmp_path):
+    """GanTrainer.fit = `for gan_epoch in np.arange(1, GAN_epoch+1)` of train_nele.py:110-428 over folders of wav files: per epoch a shuffled
+    draw of the training list, validation with the learning-curve line, chkpt_<epoch>.pt, name@epoch.wav samples, targets of the generated and
+    the pre-enhanced examples, three D passes - here with the clean-signal cache on, against a second trainer that recomputes everything."""
+    from nele_gan_amd import dataio, synth
+    from nele_gan_amd.train_nele import GanTrainer
+    root = str(tmp_path)
+    rs = np.random.RandomState(3)
+    c, v = synth.batch(10, 40000, start=300)
+    for sub in ('Train/Clean', 'Train/Noise', 'Train/MultiEnh', 'Test/Clean', 'Test/Noise'):
+        os.makedirs(os.path.join(root, sub))
+    for i in range(10):
+        L = int(rs.randint(30000, 40001))
+        part = 'Train' if i < 7 else 'Test'
+        dataio.write_wav_pcm16('%s/%s/Clean/u%02d.wav' % (root, part, i), c[i, :L])
+        dataio.write_wav_pcm16('%s/%s/Noise/u%02d.wav' % (root, part, i), v[i, :L])
+        if i < 7:
+            dataio.write_wav_pcm16('%s/Train/MultiEnh/u%02d.wav' % (root, i), (1.4 * c[i, :L]).astype(np.float32))
+    train = sorted(dataio.get_filepaths(root + '/Train/Clean/'))
+    test = sorted(dataio.get_filepaths(root + '/Test/Clean/'))
+
+    def run(cache, tag):
+        tr = GanTrainer('siib&haspi&estoi', seed=666)
+        res = tr.fit(train, root + '/Train/Noise/', test, root + '/Test/Noise/', train_enh_path=root + '/Train/MultiEnh/', epochs=3, sampling=5, valid_samples=2, batch=4,
+                     output_path=root + '/out_' + tag, pt_dir=root + '/chkpt_' + tag, log_path=root + '/log_%s.txt' % tag, clean_cache=cache)
+        return tr, res
+    a, ra = run(True, 'a')
+    b, rb = run(False, 'b')
+    assert [r['g_steps'] for r in ra] == [0, 2, 2] and all(r['samples'] == 10 for r in ra)          # 5 drawn files: generated + pre-enhanced
+    assert a.clean_cache.hits > 0
+    for (k, ta), (_, tb) in zip(a.G.state_dict().items(), b.G.state_dict().items()):                 # the cache changes nothing
+        assert torch.equal(ta, tb), k
+    for (k, ta), (_, tb) in zip(a.D.state_dict().items(), b.D.state_dict().items()):
+        assert torch.equal(ta, tb), k
+    assert [r['valid'] for r in ra] == [r['valid'] for r in rb]
+    lines = open(root + '/log_a.txt').read().splitlines()
+    assert len(lines) == 3 and lines[2].startswith('SIIB is ') and lines[2].rstrip().endswith('EPOCH:3')
+    for ep in (1, 2, 3):
+        assert set(torch.load(root + '/chkpt_a/chkpt_%d.pt' % ep, map_location='cpu').keys()) == {'enhance-model', 'intel-model'}
+        assert len(os.listdir(root + '/out_a/Test_epoch%d' % ep)) == 2
+    files = os.listdir(root + '/out_a/For_discriminator_training')
+    assert len(files) == 15 and all('@' in f for f in files)
