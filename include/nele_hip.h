@@ -345,6 +345,12 @@ int nele_energy_norm_bwd(const float* clean, const float* mask, const float* bet
 /* dataloader.py:76-84: band features (enhanced, noise, clean) [B][T][64] -> D input [B][64][T][4]
  * (c2 NULL for Discriminator_Quality's (enhanced, clean)). */
 int nele_d_pack(const float* c0, const float* c1, const float* c2, float* din, int B, int T, void* stream);
+/* dataloader.py:54-84 + train_nele.py:349-367, batched: a shuffled list of per-utterance D items -> one padded batch.  items_host [n]: HOST
+ * array of device pointers to channels-last items [64][T_k][4] float32 whose band rows lie strides_host[i] floats apart (NULL: 4 T_k, a
+ * contiguous item; a row of a larger padded batch is a valid item), frames_host [n] = T_k <= Tm.  din_out [rows][64][Tm][4]: item r in row r,
+ * columns >= T_k and rows >= n zero; frames_out [rows] (device, may be NULL) = T_k, Tm for the fill rows.  One launch per 64 items. */
+int nele_d_gather_items(const void* const* items_host, const int* frames_host, const long long* strides_host, int n, int rows, int Tm,
+                        float* din_out, int* frames_out, void* stream);
 /* Reference tensor layout [B][Cin][64][T] (model.py:118) <-> channels-last [B][64][T][4]. */
 int nele_d_layout(const float* src, float* dst, int B, int Cin, int T, int to_nhwc, void* stream);
 

@@ -52,6 +52,7 @@ _SIGS = {
     'nele_energy_norm_bwd': [_P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int, c_int, _P],
     'nele_d_pack': [_P, _P, _P, _P, c_int, c_int, _P],
     'nele_d_layout': [_P, _P, c_int, c_int, c_int, c_int, _P],
+    'nele_d_gather_items': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_longlong), c_int, c_int, c_int, _P, _P, _P],
     'nele_spectral_norm': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, _P, c_int, _P],
     'nele_sn_grad': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     'nele_sn_grad_scratch_doubles': [c_int],
@@ -416,6 +417,25 @@ def d_pack(c0, c1, c2=None):
     call('nele_d_pack', ptr(c0.contiguous()), ptr(c1.contiguous()), ptr(c2.contiguous() if c2 is not None else None), ptr(din), B, T,
          stream())
     return din
+
+
+def d_gather(items, rows, Tm, want_frames=True):
+    """A list of per-utterance D items [64, T_k, 4] (float32, device; contiguous or rows of a larger padded batch: band rows
+    item.stride(0) floats apart) -> (din [rows, 64, Tm, 4] zero-padded, frames [rows] int32 or None): one launch per 64 items
+    (nele_d_gather_items) instead of one copy per item."""
+    n = len(items)
+    dev = items[0].device
+    Ts = [int(t.shape[1]) for t in items]
+    for t in items:
+        if t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != 64 or t.shape[2] != 4 or t.stride(2) != 1 or t.stride(1) != 4:
+            raise ValueError('d_gather: items must be float32 [64, T, 4] with contiguous (T, 4) rows')
+    din = torch.empty((rows, 64, Tm, 4), device=dev)
+    frames = torch.empty((rows,), dtype=torch.int32, device=dev) if want_frames else None
+    pa = (c_void_p * n)(*[t.data_ptr() for t in items])
+    fa = (c_int * n)(*Ts)
+    sa = (c_longlong * n)(*[int(t.stride(0)) for t in items])
+    call('nele_d_gather_items', pa, fa, sa, n, rows, Tm, ptr(din), ptr(frames), stream())
+    return din, frames
 
 
 def nchw_to_nhwc4(x):

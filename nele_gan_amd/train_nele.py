@@ -883,6 +883,10 @@ class GanTrainer:
                 Tm = Ts[0]
             if rows == n and Tm == Ts[0] and all(t == Ts[0] for t in Ts):
                 din, frames = torch.stack([c[0] for c in ch]), None
+            elif ch[0][0].is_cuda:
+                # one gather launch per 64 items (zero padding and the device-side frame counts included) instead of a copy per item and a
+                # host -> device copy of the frame list per batch
+                din, frames = ops.d_gather([c[0] for c in ch], rows, Tm, want_frames=not all(t == Tm for t in Ts))
             else:
                 din = ch[0][0].new_zeros((rows, 64, Tm, 4))
                 for r, c in enumerate(ch):
@@ -1107,13 +1111,13 @@ class GanTrainer:
         out['sample_files'] = []
 
         def resolve(item):
-            pend, din, qua, frames, din_d, drc_qua = item
+            pend, din, qua, frames, din_d, drc_qua, fh = item
             tgt = pend.result()
             if din_d is not None:
                 tgt, tgt_d = tgt
-            samples.extend(self._items(din, tgt, qua, frames))
+            samples.extend(self._items(din, tgt, qua, frames, fh))
             if din_d is not None:
-                samples.extend(self._items(din_d, tgt_d, drc_qua, frames))
+                samples.extend(self._items(din_d, tgt_d, drc_qua, frames, fh))
         for i, b in enumerate(train_batches):                           # :279-340
             f = feats[i] if feats[i] is not None else fts(b)
             lens, frames = b.get('lengths'), f.get('frames')
@@ -1134,7 +1138,8 @@ class GanTrainer:
             din_d = None
             if b.get('drc') is not None:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
-            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua')))
+            lh = b.get('lengths_host')
+            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), None if lh is None else [1 + int(v) // 256 for v in lh]))
             # bounded lag: the targets of batch i - target_lag are resolved now, so that at most target_lag batches keep their metric inputs
             # (x, y, lengths: 2 - 3 x B x L x 4 bytes each) alive and the main stream cannot run arbitrarily far ahead of the metric streams
             while len(pending) - resolved > getattr(self, 'target_lag', 3):
@@ -1203,10 +1208,19 @@ class GanTrainer:
         return results
 
     @staticmethod
-    def _items(din, tgt, qua, frames):
-        """A batch's D training items: (din [64, T_k, 4] cut to the utterance's own frames, target [n], quality target [2] | None)."""
-        fr = None if frames is None else [int(v) for v in frames.tolist()]
-        return [(din[k] if fr is None else din[k, :, :fr[k]].contiguous(), tgt[k], qua[k] if qua is not None else None)
+    def _items(din, tgt, qua, frames, frames_host=None):
+        """A batch's D training items: (din [64, T_k, 4] cut to the utterance's own frames, target [n], quality target [2] | None).
+        The items are VIEWS of the batch's rows (the gather kernel of _padded_chunks takes band rows of any stride); ``frames_host``:
+        the frame counts on the host when the loader knows them (dataio.FileBatches: 'lengths_host') - reading them back from the device
+        stalls the thread that enqueues the GPU work until everything before it has run."""
+        if frames is None:
+            fr = None
+        elif frames_host is not None:
+            fr = [int(v) for v in frames_host]
+        else:
+            fr = [int(v) for v in frames.tolist()]
+        T = din.shape[2]
+        return [(din[k] if (fr is None or fr[k] == T) else din[k, :, :fr[k]], tgt[k], qua[k] if qua is not None else None)
                 for k in range(din.shape[0])]
 
     # ---------------------------------------------------------------- file hand-off (train_nele.py:303-340, 224-225)

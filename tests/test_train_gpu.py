@@ -320,3 +320,27 @@ def test_replay_history_beyond_its_device_budget_moves_to_host_memory_and_is_sti
     tr.d_epoch([item(200 + i) for i in range(5)], batch=4)        # 65 // 30 = 2 replayed items, most likely from host memory
     assert sum(seen) == 5 + (2 + 5) + 5 and len(tr.history) == 70
     assert tr.check_status()['skipped_d_steps'] == 0
+
+
+def test_gathered_d_batches_equal_the_per_item_copies():
+    """ops.d_gather (nele_d_gather_items): a shuffled list of per-utterance D items - rows of larger padded batches, cut to their own frame
+    counts - as one zero-padded batch with device-side frame counts, against the per-item copies it replaces (dataloader.py:54-84)."""
+    import torch
+    from nele_gan_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    src = [torch.rand((7, 64, T, 4), device='cuda', generator=g) for T in (40, 97, 251)]
+    items = []
+    for k in range(150):                                       # more than two launches' worth, views with three different row strides
+        b = src[k % 3]
+        T = b.shape[2]
+        fr = T if k % 5 == 0 else 21 + (k * 7) % (T - 20)
+        items.append(b[k % 7] if fr == T else b[k % 7, :, :fr])
+    rows, Tm = 160, 256
+    din, frames = ops.d_gather(items, rows, Tm)
+    ref = torch.zeros((rows, 64, Tm, 4), device='cuda')
+    for r, it in enumerate(items):
+        ref[r, :, :it.shape[1]] = it
+    assert torch.equal(din, ref)
+    assert frames.tolist() == [it.shape[1] for it in items] + [Tm] * (rows - len(items))
+    with pytest.raises(Exception):
+        ops.d_gather([src[2][0]], 1, 100)                     # an item longer than the batch
