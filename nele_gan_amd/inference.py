@@ -55,29 +55,35 @@ class Enhancer:
         return self._enhance_impl(clean_wav, noise_wav, pcm16, lengths)
 
     @torch.no_grad()
-    def enhance_stream(self, batches, inflight=3, pcm16=True):
+    def enhance_stream(self, batches, inflight=4, pcm16=True):
         """batches: iterable of (clean_wav [B,L], noise_wav [B,L]) or (clean_wav, noise_wav, lengths) device tensors (shapes may differ
         from batch to batch).  Generator of the enhanced batches, in order; each equals ``enhance`` of the same batch bit for bit.
 
         Up to ``inflight`` batches are enqueued before the oldest result is handed out, each on a stream of its own with its own set
         of generator activation buffers (``Generator_Conv1D_cLN.buffer_slot``); the generator's weight layouts are written once
         (``freeze_weights``) and only read afterwards.  One batch by itself is a chain of kernels of which the IMCRA scan (serial over
-        the frames, 1 / 8 .. 1 / 4 of the chip) and the per-utterance tails leave most of the GPU idle: with three batches in flight those
-        phases run under another batch's generator (inference.py:79-117 is a loop over independent files).
+        the frames, 1 / 8 .. 1 / 4 of the chip) and the per-utterance tails leave most of the GPU idle: with several batches in flight those
+        phases run under another batch's generator (inference.py:79-117 is a loop over independent files).  Throughput = batches in
+        flight / a batch's latency as long as every batch sits on a hardware queue of its own; the runtime has four, so the default is
+        four batches - three side streams and the caller's own stream (round 6: 102 k -> 111 k utterances/s at 128 x 8 s; a fifth: 97 k).
         The consumer's current stream waits for a result before it is yielded; the result stays valid until the consumer drops it."""
         if self.device.type != 'cuda':
             raise RuntimeError("nele_gan_amd: the enhancement path runs on the GPU only (no CPU fallback)")
         inflight = max(1, int(inflight))
-        if len(self._slots) < inflight:
+        caller = torch.cuda.current_stream(self.device)
+        n_side = inflight if inflight <= 3 else inflight - 1
+        if len(self._slots) < n_side:
             # a hardware queue each for the first three (which of a process's streams share one is decided at their creation: two slots
             # on one queue run their batches one after the other - 65 k instead of 100 k utterances/s)
-            if min(inflight, 3) > len(self._slots):
-                self._slots += ops.streams_on_distinct_queues(self.device, min(inflight, 3) - len(self._slots), have=self._slots)
-            while len(self._slots) < inflight:
+            if min(n_side, 3) > len(self._slots):
+                self._slots += ops.streams_on_distinct_queues(self.device, min(n_side, 3) - len(self._slots), have=self._slots)
+            while len(self._slots) < n_side:
                 self._slots.append(ops.side_stream(self.device))
+        # the runtime has four hardware queues: the three side streams above + the one of the caller's own stream.  A FOURTH batch in
+        # flight therefore runs on the caller's stream (a fourth side stream would share a queue with one of the three: 66 k utterances/s)
+        slots = list(self._slots[:min(n_side, 3)]) + ([caller] if inflight >= 4 else []) + list(self._slots[3:n_side])
         G = self.G
         slot0 = G.buffer_slot
-        caller = torch.cuda.current_stream(self.device)
         frozen = G.freeze_weights(self.device)
         pending = collections.deque()
 
@@ -94,7 +100,7 @@ class Enhancer:
                     yield hand_out()
                 clean_wav, noise_wav = batch[0], batch[1]
                 lengths = batch[2] if len(batch) > 2 else None
-                st = self._slots[k % inflight]
+                st = slots[k % inflight]
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(self.device))       # the inputs (and, first round, the frozen layouts) exist
                 G.buffer_slot = ('stream', k % inflight)
@@ -118,7 +124,7 @@ class Enhancer:
                 done.synchronize()
 
 
-def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=8,
+def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=4, workers=8,
                   pad_to=4096, ahead=2, write=True):
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
     Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.
