@@ -76,7 +76,9 @@ class Enhancer:
             # a hardware queue each for the first three (which of a process's streams share one is decided at their creation: two slots
             # on one queue run their batches one after the other - 65 k instead of 100 k utterances/s)
             if min(n_side, 3) > len(self._slots):
-                self._slots += ops.streams_on_distinct_queues(self.device, min(n_side, 3) - len(self._slots), have=self._slots)
+                # (round 6: and none of them on the CALLER's queue - "the default stream has a queue of its own" only holds in a fresh
+                #  process; after a trainer has created its side streams a new stream may land on it: 93 k instead of 112 k with four in flight)
+                self._slots += ops.streams_on_distinct_queues(self.device, min(n_side, 3) - len(self._slots), have=[caller] + self._slots)
             while len(self._slots) < n_side:
                 self._slots.append(ops.side_stream(self.device))
         # the runtime has four hardware queues: the three side streams above + the one of the caller's own stream.  A FOURTH batch in
