@@ -126,7 +126,7 @@ class Enhancer:
                 done.synchronize()
 
 
-def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=4, workers=8,
+def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_tag=1, sort_by_length=True, inflight=3, workers=8,
                   pad_to=4096, ahead=2, write=True):
     """inference.py:79-117 over ``file_list`` (clean wav paths; the noise file of each has the same name under ``noise_path``).
     Returns the list of written files ('<output_path>/<stem>@<epoch_tag>.wav'), in list order, for this rank's shard.

@@ -34,7 +34,7 @@ try:
     enh = Enhancer(G=tr.G); enh.G.precision = 'bf16'
     enhance_files(enh, files, root + '/Noise/', root + '/Warm', batch=batch, workers=8)
     shutil.rmtree(root + '/Warm', ignore_errors=True)
-    for workers, ahead, inflight, write in ((8, 2, 3, True), (8, 2, 3, False), (16, 2, 3, True), (8, 2, 3, True), (8, 2, 3, False), (16, 2, 3, True)):
+    for workers, ahead, inflight, write in ((8, 2, 3, True), (8, 2, 4, True), (8, 2, 2, True), (8, 2, 3, True), (8, 2, 4, True), (8, 2, 4, False)):
         best = 0.0
         for rep in range(3):
             shutil.rmtree(root + '/Enh', ignore_errors=True)
