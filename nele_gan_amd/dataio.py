@@ -556,6 +556,7 @@ class FileBatches:
             if hd is not None:
                 dlens = got[2].astype(np.int32)
                 b['drc'], b['drc_lengths'] = up(hd, dlens)
+                b['drc_lengths_host'] = dlens
             ev = torch.cuda.Event()
             ev.record(self._copy)
         self._ready[g] = (b, ev, (hc, hn, hd) + tuple(small))

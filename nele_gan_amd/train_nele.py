@@ -378,6 +378,7 @@ class GanTrainer:
         import collections
         self._feat_cache = collections.OrderedDict() # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys (LRU)
         self._feat_bytes = 0
+        self._drc_cache = {}                         # run_epoch: D item (input, targets[, quality targets]) of an utterance's pre-enhanced example
         return self.clean_cache
 
     def _dither_tag(self):
@@ -452,7 +453,7 @@ class GanTrainer:
 
     @torch.no_grad()
     def true_metrics_pair(self, clean_wav, enh_wav, drc_wav, noise_wav, norm=True, lengths=None, drc_lengths=None, utt_ids=None, defer=False,
-                          keys=None):
+                          keys=None, lengths_host=None, drc_lengths_host=None):
         """Targets of TWO degraded versions of one clean batch - the generated example and the pre-enhanced ('DRC') one, which the loop
         scores back to back (train_nele.py:318-340) - with the clean-signal work done once: SIIB's VAD / clean spectra / covariance /
         eigen-decomposition (its KLT basis) and HASPI's whole reference-signal chain depend on the clean signal only
@@ -467,7 +468,15 @@ class GanTrainer:
         if drc_lengths is not None or lengths is not None:
             full = lambda t, w: torch.full((w.shape[0],), w.shape[1], dtype=torch.int32, device=self.device) if t is None else au._i32(t, self.device)
             ml_d = torch.clamp(torch.minimum(full(drc_lengths, drc_wav), full(lengths, clean_wav)), max=Ld)
-        same = (L == Ld) and ((ml_e is None and ml_d is None) or (ml_e is not None and ml_d is not None and bool(torch.equal(ml_e, ml_d))))
+        if ml_e is not None and ml_d is not None and lengths_host is not None and (drc_lengths_host is not None or drc_lengths is None):
+            # the same comparison on the host copies of the lengths a loader hands over (dataio.FileBatches): no device read-back, which
+            # would stall the thread that enqueues the GPU work once per batch
+            lh = np.asarray(lengths_host, dtype=np.int64)
+            dh = np.full_like(lh, drc_wav.shape[1]) if drc_lengths_host is None else np.asarray(drc_lengths_host, dtype=np.int64)
+            eq = bool(np.array_equal(256 * (lh // 256), np.minimum(np.minimum(dh, lh), Ld)))
+        else:
+            eq = (ml_e is None and ml_d is None) or (ml_e is not None and ml_d is not None and bool(torch.equal(ml_e, ml_d)))
+        same = (L == Ld) and eq
         if not same:
             # (the pre-enhanced comparison sees the clean file cut to another length: its clean-signal state is cached under its own key)
             kd = None if keys is None else [('drc', k_) for k_ in keys]
@@ -1053,6 +1062,10 @@ class GanTrainer:
                     self._feat_bytes += nb_
             return f_
 
+        def hkw(b):                                                     # host copies of the lengths, when the loader has them (test doubles take none)
+            return ({'lengths_host': b['lengths_host'], 'drc_lengths_host': b.get('drc_lengths_host')}
+                    if (b.get('lengths_host') is not None and (b.get('drc_lengths_host') is not None or b.get('drc_lengths') is None)) else {})
+
         def ckw(b):                                                     # utterance keys travel only when the clean-signal cache is on
             return {'keys': b.get('keys', b.get('names'))} if getattr(self, 'clean_cache', None) is not None else {}
 
@@ -1111,13 +1124,22 @@ class GanTrainer:
         out['sample_files'] = []
 
         def resolve(item):
-            pend, din, qua, frames, din_d, drc_qua, fh = item
+            pend, din, qua, frames, din_d, drc_qua, fh, drc_items, store_keys = item
             tgt = pend.result()
             if din_d is not None:
                 tgt, tgt_d = tgt
             samples.extend(self._items(din, tgt, qua, frames, fh))
             if din_d is not None:
-                samples.extend(self._items(din_d, tgt_d, drc_qua, frames, fh))
+                items_d = self._items(din_d, tgt_d, drc_qua, frames, fh)
+                samples.extend(items_d)
+                if store_keys is not None:                              # first time these utterances' pre-enhanced examples are scored: keep them
+                    for k_, it in zip(store_keys, items_d):
+                        nb_ = it[0].numel() * 4 + 64
+                        if k_ not in self._drc_cache and self.clean_cache.used + nb_ <= self.clean_cache.budget:
+                            self._drc_cache[k_] = tuple(None if t is None else t.clone() for t in it)   # (own storage: not a view of the batch)
+                            self.clean_cache.used += nb_
+            elif drc_items is not None:
+                samples.extend(drc_items)
         for i, b in enumerate(train_batches):                           # :279-340
             f = feats[i] if feats[i] is not None else fts(b)
             lens, frames = b.get('lengths'), f.get('frames')
@@ -1126,20 +1148,33 @@ class GanTrainer:
                 out['sample_files'] += self.write_samples(enh, b['names'], sample_dir + '/For_discriminator_training', gan_epoch,
                                                           lengths=b.get('lengths_host', lens), wait=False)
             dl = b.get('drc_lengths', lens)
-            if b.get('drc') is not None:
-                # generated + pre-enhanced ('DRC') example of the same utterances (:318-340; audio_util.py:267-321; the DRC file keeps its
-                # own length): one pass over the clean signal for both when they are compared over the same samples (audio_util.py:134-137)
-                pend = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'), defer=True, **ckw(b))
+            # The pre-enhanced ('DRC') example of an utterance (:318-340; audio_util.py:267-321) never changes: its files are fixed, so its D
+            # input and its true targets are the same in every epoch the utterance is drawn.  With the clean-signal cache on they are kept
+            # per utterance key after the first time (the reference recomputes read_batch_*_DRC every epoch); a batch whose utterances are
+            # all known skips the DRC file's STFT and its three metric calls altogether.
+            dkeys = ckw(b).get('keys') if b.get('drc') is not None else None
+            dcache = getattr(self, '_drc_cache', None)
+            drc_items = None
+            if dkeys is not None and dcache is not None:
+                drc_items = [dcache.get(k_) for k_ in dkeys]
+                if any(it is None for it in drc_items):
+                    drc_items = None
+            if b.get('drc') is not None and drc_items is None:
+                # generated + pre-enhanced example of the same utterances: one pass over the clean signal for both when they are compared over
+                # the same samples (audio_util.py:134-137)
+                pend = self.true_metrics_pair(b['clean'], enh, b['drc'], b['noise'], lengths=lens, drc_lengths=dl, utt_ids=b.get('ids'), defer=True,
+                                              **ckw(b), **hkw(b))
             else:
                 pend = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'), defer=True, **ckw(b))
             # the targets are not waited for here: this batch's metric kernels (three streams, SIIB's a latency chain through the
             # eigensolver) run under the next batch's generator and feature kernels; everything is resolved behind the loop
             din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
             din_d = None
-            if b.get('drc') is not None:
+            if b.get('drc') is not None and drc_items is None:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
             lh = b.get('lengths_host')
-            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), None if lh is None else [1 + int(v) // 256 for v in lh]))
+            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), None if lh is None else [1 + int(v) // 256 for v in lh],
+                            drc_items, dkeys if (dcache is not None and drc_items is None) else None))
             # bounded lag: the targets of batch i - target_lag are resolved now, so that at most target_lag batches keep their metric inputs
             # (x, y, lengths: 2 - 3 x B x L x 4 bytes each) alive and the main stream cannot run arbitrarily far ahead of the metric streams
             while len(pending) - resolved > getattr(self, 'target_lag', 3):
