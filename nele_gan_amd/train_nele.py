@@ -375,6 +375,7 @@ class GanTrainer:
         if budget_bytes is None:
             budget_bytes = torch.cuda.mem_get_info(self.device)[0] // 4
         self.clean_cache = mt.CleanStateCache(budget_bytes)
+        self.cache_len_quantum = 16384               # metric inputs are padded to multiples of this many samples while the cache is on (_canon)
         import collections
         self._feat_cache = collections.OrderedDict() # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys (LRU)
         self._feat_bytes = 0
@@ -383,6 +384,24 @@ class GanTrainer:
 
     def _dither_tag(self):
         return None if self.haspi_dither is None else (self.haspi_dither, self.dither_seed)
+
+    def _canon(self, x, ys, lengths):
+        """Metric inputs of a batch in the cache's canonical geometry: rows zero-padded to the next multiple of ``cache_len_quantum`` samples
+        and explicit per-row lengths.  A cached clean-signal state is laid out for one padded length; a loop that re-draws its batches every
+        epoch (fit) pads every batch to its own longest file, so the same utterance would otherwise be looked up under ever new lengths.  The
+        scores do not depend on the padding (everything behind a row's own end is zeros and never read; tests/test_varlen_gpu.py)."""
+        q = int(getattr(self, 'cache_len_quantum', 16384))
+        B, L = x.shape
+        Lc = (L + q - 1) // q * q
+        if lengths is None:
+            lengths = torch.full((B,), L, dtype=torch.int32, device=x.device)
+        if Lc == L:
+            return x, ys, lengths
+        def pad(t):
+            o = t.new_zeros((B, Lc))
+            o[:, :L] = t
+            return o
+        return pad(x), [pad(y_) for y_ in ys], lengths
 
     def _metric(self, m, x, y, which, lengths=None, utt_ids=None, keys=None):
         if self.clean_cache is not None and keys is not None and m in ('siib', 'haspi'):
@@ -439,6 +458,8 @@ class GanTrainer:
             lengths = self.enhanced_lengths(lengths)
         elif lengths is not None:
             lengths = torch.clamp(lengths, max=L)
+        if self.clean_cache is not None and keys is not None:
+            x, (y,), lengths = self._canon(x, [y], lengths)
         cols = []
         fork = self._metric_fork((x, y, lengths))             # (everything allocated on THIS stream that the metric streams read: kept alive and
                                                                #  marked as used there until the targets are waited for)
@@ -488,6 +509,9 @@ class GanTrainer:
                     self.true_metrics(clean_wav, drc_wav, noise_wav, norm=norm, lengths=ml_d, resynth=False, utt_ids=utt_ids, keys=kd))
         x = clean_wav[:, :L].contiguous()
         ys = [(enh_wav[:, :L] + noise_wav[:, :L]).contiguous(), (drc_wav[:, :L] + noise_wav[:, :L]).contiguous()]
+        if self.clean_cache is not None and keys is not None:
+            x, ys, ml_e = self._canon(x, ys, ml_e)
+            ml_d = ml_e
         pick = (lambda r, m_: m_) if norm else (lambda r, m_: r)
         cols = [{}, {}]
         fork = self._metric_fork([x] + ys + [ml_e, ml_d])
