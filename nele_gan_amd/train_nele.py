@@ -1244,6 +1244,9 @@ class GanTrainer:
         valid_files = list(valid_clean_files)
         random.shuffle(valid_files)                                     # :68
         valid_files = valid_files[:int(valid_samples)]
+        if self.world > 1:                                              # data parallelism: every rank scores its contiguous shard of the validation
+            lo_, hi_ = ndist.shard_range(len(valid_files))              # list (run_epoch all-reduces the means) ...
+            valid_files = valid_files[lo_:hi_]
         vb = None
         if valid_files:
             vb = dataio.FileBatches(valid_files, valid_noise_path, batch=batch, workers=workers, ahead=2, keep=2, device=self.device)
@@ -1252,6 +1255,9 @@ class GanTrainer:
             for gan_epoch in range(int(first_epoch), int(epochs) + 1):
                 random.shuffle(train_files)                             # :118
                 sel = train_files[0:int(round(sampling))]
+                if self.world > 1:                                      # ... and trains on its shard of the epoch's draw (the same shuffle on every
+                    lo_, hi_ = ndist.shard_range(len(sel))              # rank: the constructor seeds the generator; gradients are item-weighted means)
+                    sel = sel[lo_:hi_]
                 fb = dataio.FileBatches(sel, train_noise_path, batch=batch, drc_path=train_enh_path, workers=workers, ahead=2, keep=2, device=self.device)
                 try:
                     res = self.run_epoch(gan_epoch, fb, vb if vb is not None else (), chkpt_path=os.path.join(pt_dir, 'chkpt_%d.pt' % gan_epoch),
