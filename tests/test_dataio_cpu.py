@@ -127,3 +127,22 @@ def test_batch_reader_and_writer_move_the_same_samples_as_the_per_file_functions
         assert open(p, 'rb').read() == open(one, 'rb').read()
     with pytest.raises(IOError):
         dataio.write_wav_batch_pcm16([str(tmp_path / 'no_such_dir' / 'a.wav')], q, [10])
+
+
+def test_wav_headers_probed_in_one_library_call(tmp_path):
+    """nele_wav_probe_pcm16_batch (dataio.probe_wav_batch_pcm16): the sample counts a loader needs for its padded batch shapes, from the RIFF
+    headers of a whole batch in one foreign call (no GPU): -1 = another wav flavour, -2 = unreadable."""
+    import numpy as np
+    from nele_gan_amd import dataio
+    rs = np.random.RandomState(0)
+    paths, want = [], []
+    for k, n in enumerate((1, 255, 16000, 40001)):
+        p = str(tmp_path / ('a%d.wav' % k))
+        dataio.write_wav_pcm16(p, (0.1 * rs.randn(n)).astype(np.float32))
+        paths.append(p)
+        want.append(n)
+    junk = str(tmp_path / 'junk.wav')
+    open(junk, 'wb').write(b'RIFF' + b'\\0' * 60)
+    got = dataio.probe_wav_batch_pcm16(paths + [junk, str(tmp_path / 'missing.wav')], threads=3)
+    assert got.tolist() == want + [-1, -2]
+    assert dataio.probe_wav_batch_pcm16([], threads=1).tolist() == []

@@ -119,3 +119,16 @@ def test_two_ranks_on_one_device_with_64_compute_units_held_for_the_whole_step()
     assert all(torch.equal(a, b) for a, b in zip(b0, b1))
     assert s0['eigh_repaired'] == 0 and s1['eigh_repaired'] == 0, (s0, s1)
     assert all(x == 0 for x in s0.values()) and all(x == 0 for x in s1.values())
+
+
+def test_process_can_be_bound_to_the_gpus_numa_node():
+    """dist.bind_to_gpu_numa_node: the CPUs of the NUMA node the GPU hangs on (never more than the launcher allowed), or None where the
+    topology cannot be read; the file-fed paths are host-bound and an unbound process copies across the socket link (tools/files_sweep.py)."""
+    from nele_gan_amd import dist as nd
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = nd.bind_to_gpu_numa_node(0)
+        if cpus is not None:
+            assert cpus and cpus <= before and os.sched_getaffinity(0) == cpus
+    finally:
+        os.sched_setaffinity(0, before)
