@@ -114,7 +114,7 @@ class CleanStateCache:
         self.budget = int(budget_bytes)
         self.used = 0
         self.pools = {}             # (kind, geometry) -> pool dict
-        self.hits = self.misses = self.stored = self.declined = 0
+        self.hits = self.misses = self.stored = self.declined = self.partial = 0
         self.poison = False         # tests: fill the workspace with 0xFF bytes before a restore (a forgotten section cannot go unnoticed)
 
     @staticmethod
@@ -139,19 +139,28 @@ class CleanStateCache:
                                    'event': None, 'per_utt': sum(b for (_o, st, b) in sec if st > 0)}
         return p
 
-    def lookup(self, kind, geom, keys):
+    def lookup(self, kind, geom, keys, count=True):
         """-> list of (block, row) slots when EVERY utterance of the batch is cached, else None."""
         p = self.pools.get((kind, geom))
         if p is None or p['shared'] is None:
-            self.misses += 1
+            self.misses += int(count)
             return None
         idx = p['index']
         slots = [idx.get(k) for k in keys]
         if any(s is None for s in slots):
-            self.misses += 1
+            self.misses += int(count)
             return None
-        self.hits += 1
+        self.hits += int(count)
         return slots
+
+    def missing(self, kind, geom, keys):
+        """Rows of the batch whose utterances are not cached yet, or None when the batch is better computed as a whole (nothing of it is
+        cached, or the pool of this geometry does not exist yet)."""
+        p = self.pools.get((kind, geom))
+        if p is None or p['shared'] is None:
+            return None
+        rows = [i for i, k in enumerate(keys) if k not in p['index']]
+        return rows if 0 < len(rows) < len(keys) else None
 
     @staticmethod
     def _runs(slots):
@@ -191,14 +200,15 @@ class CleanStateCache:
         """Copy the state phase 3 just left in ``ws`` into the pool for the utterances not cached yet (current stream)."""
         p = self._pool(kind, geom, L, fs)
         if p is None:
-            return
+            return False
         sec = self._sections(kind, B, L, fs)
         if p['shared'] is None:
             p['shared'] = [ws[off:off + nb].clone() for (off, st, nb) in sec if st == 0]
             self.used += sum(t.numel() for t in p['shared'])
         new = [(k, key) for k, key in enumerate(keys) if key not in p['index']]
         if not new:
-            return
+            return True
+        n_new = len(new)
         slots = []
         for _k, _key in new:
             if p['free'] == 0:
@@ -213,7 +223,7 @@ class CleanStateCache:
             p['free'] -= 1
         new = new[:len(slots)]
         if not new:
-            return
+            return False
         # runs of consecutive batch rows that landed in consecutive pool rows
         runs, k = [], 0
         while k < len(new):
@@ -236,9 +246,10 @@ class CleanStateCache:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ws.device))
         p['event'] = ev
+        return len(new) == n_new
 
     def stats(self):
-        return {'hits': self.hits, 'misses': self.misses, 'stored': self.stored, 'declined': self.declined, 'bytes': self.used,
+        return {'hits': self.hits, 'misses': self.misses, 'partial': self.partial, 'stored': self.stored, 'declined': self.declined, 'bytes': self.used,
                 'utterances': {'%s@%s' % k: len(p['index']) for k, p in self.pools.items()}}
 
 
@@ -294,8 +305,9 @@ class SiibSplit:
     dependence - SIIB's Karhunen-Loeve basis comes from the clean signal alone, so VAD, the clean spectra, the covariance and its
     eigen-decomposition can run before the degraded signal exists."""
 
-    def __init__(self, x, y=None, lengths=None, owner=None):
+    def __init__(self, x, y=None, lengths=None, owner=None, ws_kind='siib_split'):
         self.lengths = None
+        self.owner = owner
         if y is None:
             self.x = x.contiguous().float()
             self.y = None
@@ -304,7 +316,7 @@ class SiibSplit:
         B, L = self.x.shape
         # own workspace: the clean-signal state must survive until degraded_part(), whatever else calls batch_siib() meanwhile
         # (``owner``: a dict held by the caller, e.g. one per trainer, that owns the workspace - released with the trainer)
-        self.ws = _workspace('siib_split', _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device, cache=owner)
+        self.ws = _workspace(ws_kind, _lib.lib.nele_metric_siib_workspace_bytes(B, L), self.x.device, cache=owner)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 4), dtype=torch.int32, device=self.x.device)
@@ -335,6 +347,19 @@ class SiibSplit:
         if slots is not None:
             cache.restore('siib', geom, self.ws, B, L, 0, slots)
             return True
+        rows = cache.missing('siib', geom, full)
+        if rows is not None:
+            # some utterances of the batch are known (a loop that re-draws its batches every epoch): phase 3 for the others only, as a batch
+            # of their own on a second workspace, then everything comes from the cache (the kernels are batch-invariant: an utterance's state
+            # does not depend on its row or on its batch-mates)
+            sub = SiibSplit(self.x[rows], lengths=None if self.lengths is None else self.lengths[rows], owner=self.owner, ws_kind='siib_split_sub')
+            sub._call(3)
+            if cache.store('siib', geom, sub.ws, len(rows), L, 0, [full[i] for i in rows]):
+                slots = cache.lookup('siib', geom, full, count=False)
+                if slots is not None:
+                    cache.partial += 1
+                    cache.restore('siib', geom, self.ws, B, L, 0, slots)
+                    return True
         self._call(3)
         cache.store('siib', geom, self.ws, B, L, 0, full)
         return False
@@ -452,12 +477,13 @@ class HaspiSplit:
     silence gate, group-delay shifts, cepstra, modulation filters) before the degraded signal exists; degraded_part(y) does the same
     for y and correlates.  Own workspace: the clean-signal state must survive until degraded_part()."""
 
-    def __init__(self, x, fs=16000, lengths=None, owner=None):
+    def __init__(self, x, fs=16000, lengths=None, owner=None, ws_kind='haspi_split'):
         self.x = x.contiguous().float()
         self.fs = int(fs)
+        self.owner = owner
         B, L = self.x.shape
         self.lengths = None if lengths is None else lengths.to(device=self.x.device, dtype=torch.int32).contiguous()
-        self.ws = _workspace('haspi_split', _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs), self.x.device, cache=owner)
+        self.ws = _workspace(ws_kind, _lib.lib.nele_metric_haspi_workspace_bytes(B, L, self.fs), self.x.device, cache=owner)
         self.raw = torch.empty(B, device=self.x.device)
         self.mapped = torch.empty(B, device=self.x.device)
         self.info = torch.zeros((B, 2), dtype=torch.int32, device=self.x.device)
@@ -481,6 +507,16 @@ class HaspiSplit:
         if slots is not None:
             cache.restore('haspi', geom, self.ws, B, L, self.fs, slots)
             return True
+        rows = cache.missing('haspi', geom, full)
+        if rows is not None:                                      # (see SiibSplit.clean_part: the unknown utterances as a batch of their own)
+            sub = HaspiSplit(self.x[rows], fs=self.fs, lengths=None if self.lengths is None else self.lengths[rows], owner=self.owner, ws_kind='haspi_split_sub')
+            sub._call(None, None if dither is None else dither[rows].contiguous(), 3)
+            if cache.store('haspi', geom, sub.ws, len(rows), L, self.fs, [full[i] for i in rows]):
+                slots = cache.lookup('haspi', geom, full, count=False)
+                if slots is not None:
+                    cache.partial += 1
+                    cache.restore('haspi', geom, self.ws, B, L, self.fs, slots)
+                    return True
         self._call(None, dither, 3)
         cache.store('haspi', geom, self.ws, B, L, self.fs, full)
         return False

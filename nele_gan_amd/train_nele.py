@@ -1148,7 +1148,7 @@ class GanTrainer:
         out['sample_files'] = []
 
         def resolve(item):
-            pend, din, qua, frames, din_d, drc_qua, fh, drc_items, store_keys = item
+            pend, din, qua, frames, din_d, drc_qua, fh, drc_items, store_keys, part = item
             tgt = pend.result()
             if din_d is not None:
                 tgt, tgt_d = tgt
@@ -1163,6 +1163,18 @@ class GanTrainer:
                             self._drc_cache[k_] = tuple(None if t is None else t.clone() for t in it)   # (own storage: not a view of the batch)
                             self.clean_cache.used += nb_
             elif drc_items is not None:
+                if part is not None:                                    # the batch's new pre-enhanced examples, computed as a batch of their own
+                    pend_sub, din_sub, miss, dkeys, frames_b, fh_b, qua_b = part
+                    tgt_sub = pend_sub.result()
+                    fr_sub = None if frames_b is None else ([fh_b[r_] for r_ in miss] if fh_b is not None else [int(v) for v in frames_b[miss].tolist()])
+                    new_items = self._items(din_sub, tgt_sub, None if qua_b is None else qua_b[miss], None if fr_sub is None else frames_b, fr_sub)
+                    for r_, it in zip(miss, new_items):
+                        it = tuple(None if t is None else t.clone() for t in it)
+                        drc_items[r_] = it
+                        nb_ = it[0].numel() * 4 + 64
+                        if self.clean_cache.used + nb_ <= self.clean_cache.budget:
+                            self._drc_cache[dkeys[r_]] = it
+                            self.clean_cache.used += nb_
                 samples.extend(drc_items)
         for i, b in enumerate(train_batches):                           # :279-340
             f = feats[i] if feats[i] is not None else fts(b)
@@ -1178,11 +1190,13 @@ class GanTrainer:
             # all known skips the DRC file's STFT and its three metric calls altogether.
             dkeys = ckw(b).get('keys') if b.get('drc') is not None else None
             dcache = getattr(self, '_drc_cache', None)
-            drc_items = None
+            drc_items, miss = None, None
             if dkeys is not None and dcache is not None:
                 drc_items = [dcache.get(k_) for k_ in dkeys]
-                if any(it is None for it in drc_items):
-                    drc_items = None
+                miss = [r_ for r_, it in enumerate(drc_items) if it is None]
+                if len(miss) == len(dkeys):
+                    drc_items, miss = None, None                         # nothing known: the ordinary path for the whole batch
+            pend_sub = din_sub = None
             if b.get('drc') is not None and drc_items is None:
                 # generated + pre-enhanced example of the same utterances: one pass over the clean signal for both when they are compared over
                 # the same samples (audio_util.py:134-137)
@@ -1190,6 +1204,21 @@ class GanTrainer:
                                               **ckw(b), **hkw(b))
             else:
                 pend = self.true_metrics(b['clean'], enh, b['noise'], lengths=lens, utt_ids=b.get('ids'), defer=True, **ckw(b))
+                if miss:
+                    # some pre-enhanced examples of this batch are new (a loop that re-draws its batches every epoch): their targets and D
+                    # inputs as a batch of their own - true_metrics on (clean, pre-enhanced + noise) over min(clean, pre-enhanced) samples is
+                    # what true_metrics_pair computes for them (audio_util.py:267-321), and every kernel is batch-invariant
+                    idx = torch.tensor(miss, dtype=torch.long).to(self.device, non_blocking=True)
+                    sub = lambda t: None if t is None else t.index_select(0, idx)
+                    Ld_ = min(b['clean'].shape[1], b['drc'].shape[1])
+                    ml_d = None
+                    if dl is not None or lens is not None:
+                        full_ = lambda t, w: torch.full((w.shape[0],), w.shape[1], dtype=torch.int32, device=self.device) if t is None else au._i32(t, self.device)
+                        ml_d = torch.clamp(torch.minimum(full_(dl, b['drc']), full_(lens, b['clean'])), max=Ld_)
+                    pend_sub = self.true_metrics(sub(b['clean']), sub(b['drc']), sub(b['noise']), lengths=sub(ml_d), resynth=False,
+                                                 utt_ids=sub(b.get('ids')), defer=True, keys=[('drc', dkeys[r_]) for r_ in miss])
+                    din_sub = self.d_inputs(sub(b['drc']), sub(f['noise_band']), sub(f['clean_band']),
+                                            sub(au._i32(dl, self.device)) if dl is not None else None, resynth=False)
             # the targets are not waited for here: this batch's metric kernels (three streams, SIIB's a latency chain through the
             # eigensolver) run under the next batch's generator and feature kernels; everything is resolved behind the loop
             din = self.d_inputs(enh, f['noise_band'], f['clean_band'], lens)
@@ -1197,8 +1226,10 @@ class GanTrainer:
             if b.get('drc') is not None and drc_items is None:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
             lh = b.get('lengths_host')
-            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), None if lh is None else [1 + int(v) // 256 for v in lh],
-                            drc_items, dkeys if (dcache is not None and drc_items is None) else None))
+            fh_ = None if lh is None else [1 + int(v) // 256 for v in lh]
+            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), fh_,
+                            drc_items, dkeys if (dcache is not None and drc_items is None) else None,
+                            None if not miss else (pend_sub, din_sub, miss, dkeys, frames, fh_, b.get('drc_qua'))))
             # bounded lag: the targets of batch i - target_lag are resolved now, so that at most target_lag batches keep their metric inputs
             # (x, y, lengths: 2 - 3 x B x L x 4 bytes each) alive and the main stream cannot run arbitrarily far ahead of the metric streams
             while len(pending) - resolved > getattr(self, 'target_lag', 3):

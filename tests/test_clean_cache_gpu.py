@@ -59,13 +59,16 @@ def test_cached_rows_in_another_order_and_batch_size(setup):
     got = tr.true_metrics(c[rows].contiguous(), enh[rows].contiguous(), v[rows].contiguous(), norm=False, keys=[keys[r] for r in rows])
     assert cache.hits == 2
     assert torch.equal(got, ref[rows])
-    # a batch with one unknown utterance: recomputed as a whole, the new one stored, the result unchanged
+    # a batch with one unknown utterance: phase 3 runs for that utterance alone (a batch of one on a second workspace), its state is stored
+    # and the whole batch comes from the cache - the known rows unchanged, the new row equal to a fresh computation
     c7, v7 = _batch(1, c.shape[1], 950)
     cc, vv = torch.cat([c[:2], c7]), torch.cat([v[:2], v7])
     ee = torch.cat([enh[:2], c7[:, :enh.shape[1]]])
     mixed = tr.true_metrics(cc, ee, vv, norm=False, keys=['u0', 'u1', 'new'])
     assert torch.equal(mixed[:2], ref[:2])
-    assert cache.stats()['stored'] == 14
+    assert cache.stats()['stored'] == 14 and cache.partial == 2
+    fresh = GanTrainer('siib&haspi&estoi').true_metrics(cc, ee, vv, norm=False)
+    assert torch.equal(mixed, fresh)
 
 
 def test_pair_targets_with_cache_equal_those_without(setup):

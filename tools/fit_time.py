@@ -41,6 +41,6 @@ try:
         per = np.diff([t0] + ts) * 1e3
         print('clean cache %-5s: ms per epoch %s; last %d epochs %.0f ms = %.0f drawn utterances/s (+ %d validation utterances scored per epoch)%s' % (
             cache, ' '.join('%.0f' % p for p in per), len(per) // 2, per[len(per) // 2:].mean(), S / per[len(per) // 2:].mean() * 1e3, V,
-            '' if not cache else '; cache %s' % {k_: v_ for k_, v_ in tr.clean_cache.stats().items() if k_ in ('hits', 'misses', 'stored', 'bytes')}))
+            '' if not cache else '; cache %s' % {k_: v_ for k_, v_ in tr.clean_cache.stats().items() if k_ in ('hits', 'misses', 'partial', 'stored', 'bytes')}))
 finally:
     shutil.rmtree(root, ignore_errors=True)
