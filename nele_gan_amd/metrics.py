@@ -336,7 +336,8 @@ class SiibSplit:
 
     def clean_part(self, cache=None, keys=None):
         """cache (CleanStateCache) + keys (one hashable per utterance, e.g. the file name): when every utterance's clean-signal state is
-        cached it is copied into the workspace instead of being recomputed; otherwise phase 3 runs and the new utterances are stored."""
+        cached it is copied into the workspace instead of being recomputed; when some are, phase 3 runs for the others only (a batch of
+        their own on a second workspace) and everything is copied in; otherwise phase 3 runs for the batch and its utterances are stored."""
         if cache is None or keys is None:
             self._call(3)
             return False
