@@ -989,26 +989,39 @@ class GanTrainer:
     def _on_device(self, item):
         return item if item[0].device == self.device else tuple(None if t is None else t.to(self.device, non_blocking=True) for t in item)
 
-    @staticmethod
-    def _to_pinned(t):
-        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        h.copy_(t, non_blocking=True)                 # ordered on the current stream; read again only through _on_device (same stream)
-        return h
-
     def _history_trim(self):
         """The reference's replay list holds FILE NAMES and re-reads them (train_nele.py:373-403); here it holds the D inputs themselves
         ([64, T, 4] float32, ~0.2 MB per item), which grows by an epoch's worth of samples per epoch.  Beyond ``history_hbm_bytes`` of
         device memory the items that follow in list order - the list is shuffled before every replay draw (d_epoch), so these are a random
-        subset, the newest epoch's items among them - move to page-locked host memory (asynchronous copies); a replayed one is uploaded again."""
+        subset, the newest epoch's items among them - move to page-locked host memory: ONE slab per call (a page-locked allocation per item
+        would cost more than the epoch), asynchronous copies on the current stream; a replayed item is uploaded again."""
         if self.device.type != 'cuda':
             return
-        used = 0
+        used, spill = 0, []
         for k, it in enumerate(self.history):
             if it[0].device.type != 'cuda':
                 continue
             used += it[0].numel() * it[0].element_size()
             if used > self.history_hbm_bytes:
-                self.history[k] = tuple(None if t is None else self._to_pinned(t) for t in it)
+                spill.append(k)
+        if not spill:
+            return
+        al = lambda n: (n + 15) // 16 * 16
+        total = sum(al(t.numel() * t.element_size()) for k in spill for t in self.history[k] if t is not None)
+        slab = torch.empty(max(16, total), dtype=torch.uint8, pin_memory=True)
+        off = 0
+        for k in spill:
+            out = []
+            for t in self.history[k]:
+                if t is None:
+                    out.append(None)
+                    continue
+                nb = t.numel() * t.element_size()
+                h = slab[off:off + nb].view(t.dtype).view(t.shape)     # (views keep the slab alive)
+                h.copy_(t, non_blocking=True)                           # ordered on the current stream; read again only through _on_device (same stream)
+                out.append(h)
+                off += al(nb)
+            self.history[k] = tuple(out)
 
     # ---------------------------------------------------------------- one GAN epoch (train_nele.py:110-429)
     def d_mse(self, samples, batch=32):
