@@ -379,6 +379,7 @@ class GanTrainer:
         import collections
         self._feat_cache = collections.OrderedDict() # run_epoch: features of a batch of (clean, noise) files, keyed by the batch's keys (LRU)
         self._feat_bytes = 0
+        self._feat_seen = collections.OrderedDict()  # batch keys seen once (no tensors): a batch's features are kept from its second sighting on
         self._drc_cache = {}                         # run_epoch: D item (input, targets[, quality targets]) of an utterance's pre-enhanced example
         return self.clean_cache
 
@@ -1091,7 +1092,13 @@ class GanTrainer:
                 # reference shuffles its file list, train_nele.py:118) never sees a batch twice and must not crowd the per-utterance states out
                 nb_ = sum(t.numel() * t.element_size() for t in f_.values() if torch.is_tensor(t))
                 cap_ = self.clean_cache.budget // 8
-                if nb_ <= cap_:
+                seen_ = self._feat_seen
+                first_ = k_ not in seen_                                # admitted on its SECOND sighting: a composition that never comes back
+                seen_[k_] = True                                        # (re-drawn batches) is not kept at all
+                seen_.move_to_end(k_)
+                while len(seen_) > 4096:
+                    seen_.popitem(last=False)
+                if nb_ <= cap_ and not first_:
                     while fc and self._feat_bytes + nb_ > cap_:
                         _, old_ = fc.popitem(last=False)
                         self._feat_bytes -= old_[1]
