@@ -79,6 +79,9 @@ def test_generator_beats_unprocessed_speech_in_low_pass_noise(curves_lowpass, pr
     assert s['valid_last']['siib'] > 1.15 * s['unprocessed']['siib'], s
     assert s['valid_last']['haspi'] > 1.08 * s['unprocessed']['haspi'], s
     assert s['objective_tail_mean'] < s['unprocessed_objective'] < s['objective_first'], s
+    # every validation metric rises in trend over the epochs (Spearman rank correlation with the epoch number: 0.92 / 0.90 / 0.44 with
+    # float32 operands, 0.95 / 0.84 / 0.58 with bf16 in the committed curves)
+    assert s['spearman']['siib'] > 0.7 and s['spearman']['haspi'] > 0.7 and s['spearman']['estoi'] > 0.2, s['spearman']
     assert c[-1]['d_mse_fresh'] < 0.01 * c[0]['d_mse_fresh']
     assert not any(r['status'] for r in c)
 
