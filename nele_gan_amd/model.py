@@ -337,6 +337,8 @@ class Generator_Conv1D_cLN(nn.Module):
         self._weights_frozen = False
         self.fused = True                 # bf16 mode: one fused launch per layer (conv + bias + cLN + LeakyReLU, csrc/glayer.hip) where the shapes allow
         self.fused_ok = False
+        # new weights invalidate frozen layouts (inference.Enhancer keeps the layouts of a generator it owns across calls)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.unfreeze_weights())
 
     # ---- plumbing
     def train(self, mode=True):
@@ -467,8 +469,9 @@ class Generator_Conv1D_cLN(nn.Module):
         B, T, _ = x.shape
         key, bf = self._get_bufs(B, T, dev)
         bf.gen += 1
-        if self._weights_frozen and torch.is_grad_enabled() and self.training:
-            raise RuntimeError("Generator_Conv1D_cLN: freeze_weights() is for evaluation loops; call unfreeze_weights() before training")
+        if self._weights_frozen and need_bwd:
+            self.unfreeze_weights()           # a pass that will be differentiated: the layouts follow the weights again (an evaluation loop
+                                              # freezes them anew)
         self._weights(dev)
         fused = self._fused_for(T, need_bwd)
         xs, ys = x.contiguous().float(), y.contiguous().float()

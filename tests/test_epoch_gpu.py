@@ -251,12 +251,17 @@ def test_enhance_stream_is_bit_identical_to_enhance(inflight):
     assert len(outs) == len(ref)
     for o, r in zip(outs, ref):
         assert o.shape == r.shape and torch.equal(o, r)
-    assert e.G.buffer_slot == 0 and not e.G._weights_frozen
-    # the generator trains again afterwards (weight layouts are rewritten per forward pass once unfrozen)
+    assert e.G.buffer_slot == 0 and e.G._weights_frozen         # an Enhancer that owns its generator keeps the layouts it wrote
+    # the generator trains again afterwards: a training pass unfreezes (weight layouts are rewritten per forward pass), the next enhance()
+    # freezes the new weights
     e.G.train()
     m = e.G(torch.rand(1, 30, 64, device='cuda'), torch.rand(1, 30, 64, device='cuda'))
+    assert not e.G._weights_frozen
     m.sum().backward()
     e.G.eval()
+    b = batches[0]
+    again = e.enhance(b[0], b[1])
+    assert e.G._weights_frozen and torch.equal(again, ref[0])   # (no optimiser step happened: same weights, same result)
 
 
 def test_enhance_stream_survives_a_consumer_that_stops_early():
@@ -269,9 +274,16 @@ def test_enhance_stream_survives_a_consumer_that_stops_early():
     ref = e.enhance(cw, nw)
     gen = e.enhance_stream([(cw, nw)] * 6, inflight=3)
     first = next(gen)
-    gen.close()                                                          # GeneratorExit inside the loop: pending batches are waited for, G unfrozen
-    assert torch.equal(first, ref) and not e.G._weights_frozen and e.G.buffer_slot == 0
+    gen.close()                                                          # GeneratorExit inside the loop: pending batches are waited for
+    assert torch.equal(first, ref) and e.G._weights_frozen and e.G.buffer_slot == 0      # (its own generator: the layouts stay)
     assert torch.equal(e.enhance(cw, nw), ref)
+    # a generator handed in (a trainer's) is given back unfrozen - it is the trainer's to change
+    e2 = Enhancer(G=e.G)
+    e.G.unfreeze_weights()
+    gen = e2.enhance_stream([(cw, nw)] * 6, inflight=3)
+    first = next(gen)
+    gen.close()
+    assert torch.equal(first, ref) and not e.G._weights_frozen and e.G.buffer_slot == 0
 
 
 def test_fit_runs_the_scripts_outer_loop_over_folders(tmp_path):
@@ -316,3 +328,36 @@ def test_fit_runs_the_scripts_outer_loop_over_folders(tmp_path):
         assert len(os.listdir(root + '/out_a/Test_epoch%d' % ep)) == 2
     files = os.listdir(root + '/out_a/For_discriminator_training')
     assert len(files) == 15 and all('@' in f for f in files)
+
+
+def test_an_enhancer_that_owns_its_generator_keeps_the_weight_layouts_and_notices_new_weights(tmp_path):
+    """inference.py:71-72: the generator is loaded from a checkpoint once; plain enhance() then writes the weight layouts once instead of per
+    batch - and a later load_state_dict() must not be served from stale layouts."""
+    from nele_gan_amd import model, synth
+    from nele_gan_amd.inference import Enhancer
+    c, v = synth.batch(3, 40000, start=4000)
+    cw, nw = torch.from_numpy(c).cuda(), torch.from_numpy(v).cuda()
+    torch.manual_seed(1)
+    Ga = model.Generator_Conv1D_cLN()
+    torch.manual_seed(2)
+    Gb = model.Generator_Conv1D_cLN()
+    pa, pb = str(tmp_path / 'a.pt'), str(tmp_path / 'b.pt')
+    torch.save({'enhance-model': Ga.state_dict()}, pa)
+    torch.save({'enhance-model': Gb.state_dict()}, pb)
+    for prec in ('f32', 'bf16'):
+        own = Enhancer(pa)
+        own.G.precision = prec
+        shared = Enhancer(G=Ga.cuda())
+        shared.G.precision = prec
+        a1 = own.enhance(cw, nw)
+        assert own.G._weights_frozen
+        a2 = own.enhance(cw, nw)                                  # second call: no weight-layout launches, same result
+        assert torch.equal(a1, a2) and torch.equal(a1, shared.enhance(cw, nw))
+        assert not shared.G._weights_frozen                       # a generator handed in may be trained between calls
+        own.G.load_state_dict(torch.load(pb, map_location='cpu')['enhance-model'])
+        assert not own.G._weights_frozen
+        want = Enhancer(pb)
+        want.G.precision = prec
+        assert torch.equal(own.enhance(cw, nw), want.enhance(cw, nw))
+        outs = list(own.enhance_stream([(cw, nw)] * 3, inflight=2))
+        assert all(torch.equal(o, outs[0]) for o in outs) and torch.equal(outs[0], want.enhance(cw, nw)) and own.G._weights_frozen
