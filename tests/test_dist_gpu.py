@@ -69,6 +69,21 @@ def test_two_replicas_stay_bit_identical_over_three_steps():
     assert all(x == 0 for x in s0.values()) and all(x == 0 for x in s1.values())
 
 
+def test_a_world_of_one_over_rccl_is_the_single_process_step():
+    """The RCCL code path on a 1-GPU box: init_process_group('nccl', device_id=...), the bucketed all-reduce of the flat gradient buffers on
+    the collective stream beside the metric streams, the rank-0 broadcast - with one rank the collectives are identities, so three steps must
+    leave exactly the weights of a process that never initialised torch.distributed."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    g0, d0, b0, s0 = out[0]
+    mp.spawn(_run_whole, args=(out,), nprocs=1, join=True)
+    gw, dw = out['whole']
+    assert torch.equal(g0, gw) and torch.equal(d0, dw)
+    assert all(x == 0 for x in s0.values())
+
+
 def _whole_batch(out):
     from nele_gan_amd import synth
     from nele_gan_amd.train_nele import GanTrainer
