@@ -349,6 +349,11 @@ def read_batch_HASPI_DRC(clean_root, noise_root, enhanced_list):
     return _read_batch('haspi', clean_root, noise_root, enhanced_list, True, drc=True)
 
 
+# PESQ / ViSQOL fan-out (audio_util.py:205-265, 323-364): external programs, see quality.py
+from .quality import (read_PESQ, read_batch_PESQ, read_batch_VISQOL, read_PESQ_DRC, read_batch_PESQ_DRC,   # noqa: E402,F401
+                      read_batch_VISQOL_DRC)
+
+
 # ------------------------------------------------------------------------------------------------ pinned staging buffers
 # Page-locked host buffers cost milliseconds to allocate (tens for a 64 MB batch): they are pooled per shape for the life of the process and
 # shared by every loader / writer (FileBatches, inference.enhance_files).

@@ -144,8 +144,11 @@ class _MetricForkCtx:
 
 class GanTrainer:
     def __init__(self, target_metric=TargetMetric, device='cuda', lr_g=5e-4, lr_d=2.5e-4, use_quality=False, pcm16=True, seed=666,
-                 haspi_dither=None, dither_seed=0):
-        """haspi_dither: None = HASPI targets without the IHC firing jitter (deterministic); 'utterance' = the reference's semantics
+                 haspi_dither=None, dither_seed=0, quality_scorer=None):
+        """quality_scorer: a ``quality.Scorer`` (PESQ / ViSQOL are external host programs, registered with quality.set_backends): with
+        ``use_quality`` run_epoch then scores the generated and the pre-enhanced examples for D_Qua's targets where the batches bring none
+        ('qua' / 'drc_qua'), and the validation utterances for the learning curve (train_nele.py:216-222, 323-324, 336-337).
+        haspi_dither: None = HASPI targets without the IHC firing jitter (deterministic); 'utterance' = the reference's semantics
         (pyhaspi2.py:362-365 dithers every call): standard-normal rows drawn per UTTERANCE ID from a counter-based generator
         (``dither_seed``, utterance id) - not per rank or per batch position, so a sharded run scores an utterance exactly
         as a single-GPU run does.  The ids come with the batch (``utt_ids``; default: position in the batch)."""
@@ -169,6 +172,8 @@ class GanTrainer:
                 m.flat_parameters(self.device)
         self.MSELoss = nn.MSELoss()
         self.pcm16 = pcm16
+        self.quality_scorer = quality_scorer
+        self._quality_pool = None
         self.step_g = 0
         self.step_d = 0
         self.history = []                            # Previous_Discriminator_training_list (train_nele.py:373-403)
@@ -1047,13 +1052,48 @@ class GanTrainer:
             self.D.train(was)
         return float(tot) / max(1, cnt)
 
+    def _quality_async(self, clean, deg, n_samples, rows=None, mapped=True):
+        """PESQ / ViSQOL of the rows of a batch on a background thread (both are host programs: quality.Scorer): the two batches leave
+        through pinned buffers behind everything enqueued so far, the caller's stream is not waited for.  ``n_samples`` [B] (host): the
+        samples of row k the reference compares (the enhanced FILE's length - 256 * (L // 256) for a generated example, audio_util.py:216-218).
+        ``rows``: score only these (the others stay 0).  -> Future of float32 [B, 2]: D_Qua's targets (``mapped``) or the raw scores."""
+        import concurrent.futures as cf
+        from . import dataio
+        B = clean.shape[0]
+        sel = list(range(B)) if rows is None else [int(r) for r in rows]
+        ns = [int(min(int(n_samples[k]), clean.shape[1], deg.shape[1])) for k in range(B)]
+        hc = dataio.pinned_get(tuple(clean.shape), torch.float32)
+        hd = dataio.pinned_get(tuple(deg.shape), torch.float32)
+        hc.copy_(clean.detach(), non_blocking=True)
+        hd.copy_(deg.detach(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        scorer = self.quality_scorer
+
+        def job():
+            ev.synchronize()
+            try:
+                refs = [hc[k, :ns[k]].numpy().copy() for k in sel]
+                degs = [hd[k, :ns[k]].numpy().copy() for k in sel]
+            finally:
+                dataio.pinned_put(hc)
+                dataio.pinned_put(hd)
+            raw = scorer.raw(refs, degs, fs)
+            out = np.zeros((B, 2), dtype=np.float32)
+            out[sel] = scorer.map(raw) if mapped else raw
+            return out
+        if self._quality_pool is None:
+            self._quality_pool = cf.ThreadPoolExecutor(max_workers=2)
+        return self._quality_pool.submit(job)
+
     def run_epoch(self, gan_epoch, train_batches, valid_batches=(), chkpt_path=None, sample_dir=None, log_path=None, d_batch=32,
                   check=True, d_eval=False):
         """One iteration of ``for gan_epoch in np.arange(1, GAN_epoch+1)`` (train_nele.py:110) in the reference's order.
 
         train_batches / valid_batches: sequences of dicts {'clean': wav [B,L], 'noise': wav [B,L], optional 'names': [B] wave names,
         optional 'drc': pre-enhanced wav [B,L] (the MultiEnh example of the same utterance, train_nele.py:333-340), optional
-        'qua': quality targets [B,2] / 'drc_qua' (PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua),
+        'qua': quality targets [B,2] / 'drc_qua' (mapped PESQ / ViSQOL of the generated / pre-enhanced example; only used with D_Qua -
+        without them a trainer that has a ``quality_scorer`` scores the examples itself, as train_nele.py:323-324, 336-337 do),
         optional 'lengths': [B] samples of each utterance inside the zero-padded batch (files of different lengths side by side, as
         the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths'),
         optional 'ids': [B] int64 utterance ids (haspi_dither='utterance': the dither rows follow the utterance, not the rank),
@@ -1128,10 +1168,27 @@ class GanTrainer:
                     self.g_step(None, None, weight=0)
                 out['g_steps'] += 1
             out['g_loss'] = tot / max(1, len(train_batches)) if tot is not None else None
-        raw = []
+        raw, vq = [], []
+        scorer = getattr(self, 'quality_scorer', None)
+
+        def nsamp(b, wav, resynth=True, other=None):
+            # samples of every row the quality programs compare: the file the reference would have written (256 * (L // 256) samples of a
+            # generated example), or min(clean, pre-enhanced) for a pre-enhanced one
+            lh = b.get('lengths_host')
+            if lh is None:
+                lh = b['lengths'].tolist() if b.get('lengths') is not None else [b['clean'].shape[1]] * b['clean'].shape[0]
+            ns_ = [int(v) for v in lh]
+            if other is not None:
+                ns_ = [min(a_, int(o_)) for a_, o_ in zip(ns_, other)]
+            if resynth:
+                ns_ = [256 * (v // 256) for v in ns_]
+            return [min(v, wav.shape[1]) for v in ns_]
+
         for b in valid_batches:                                         # :159-222
             f = fts(b)
             enh = self.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f.get('frames'))
+            if scorer is not None:                                      # :216-222 (norm=False: the raw scores of the learning curve)
+                vq.append(self._quality_async(b['clean'], enh, nsamp(b, enh), mapped=False))
             if sample_dir is not None and 'names' in b:                 # :190-198 (the reference keeps the first 20 for listening)
                 self.write_samples(enh, b['names'], sample_dir + '/Test_epoch' + str(gan_epoch), gan_epoch,
                                    lengths=b.get('lengths_host', b.get('lengths')), wait=False)
@@ -1139,7 +1196,10 @@ class GanTrainer:
         raw = [p.result() for p in raw]                                 # (a batch's metrics ran under the next batch's generator)
         if raw or (dp and valid_batches is not None):
             n_m = len(self.metrics)
-            acc = torch.zeros(2 * n_m + 1, dtype=torch.float64, device=self.device)
+            acc = torch.zeros(2 * n_m + 1 + 3, dtype=torch.float64, device=self.device)
+            if vq:                                                      # [.., sum PESQ, sum ViSQOL, utterances scored]
+                q_ = np.concatenate([p.result() for p in vq], axis=0).astype(np.float64)
+                acc[2 * n_m + 1:] = torch.tensor([q_[:, 0].sum(), q_[:, 1].sum(), float(q_.shape[0])], dtype=torch.float64)
             if raw:
                 r = torch.cat(raw, dim=0).double()
                 acc[:n_m] = r.sum(dim=0)
@@ -1156,8 +1216,11 @@ class GanTrainer:
                 r = (acc[:n_m] / acc[n_m]).cpu().numpy()
                 col = {m: float(r[i]) for i, m in enumerate(self.metrics)}
                 out['valid'] = col
-                rm = (acc[n_m + 1:] / acc[n_m]).cpu().numpy()
+                rm = (acc[n_m + 1:2 * n_m + 1] / acc[n_m]).cpu().numpy()
                 out['valid_mapped'] = {m: float(rm[i]) for i, m in enumerate(self.metrics)}
+                if float(acc[2 * n_m + 3]) > 0:                         # Test_PESQ / Test_VISQOL (:217-222)
+                    col['pesq'] = float(acc[2 * n_m + 1] / acc[2 * n_m + 3])
+                    col['visqol'] = float(acc[2 * n_m + 2] / acc[2 * n_m + 3])
                 line = self.validation_log_line(col.get('siib', 0.0), col.get('haspi', 0.0), col.get('estoi', 0.0), gan_epoch)
                 if log_path is not None and ndist.rank() == 0:
                     with open(log_path, 'a') as fh:                     # :224-225
@@ -1167,8 +1230,12 @@ class GanTrainer:
         samples, pending, resolved = [], [], 0
         out['sample_files'] = []
 
+        def rq(q):                                                      # quality targets scored on the host meanwhile (_quality_async)
+            return torch.from_numpy(q.result()).to(self.device) if hasattr(q, 'result') else q
+
         def resolve(item):
             pend, din, qua, frames, din_d, drc_qua, fh, drc_items, store_keys, part = item
+            qua, drc_qua = rq(qua), rq(drc_qua)
             tgt = pend.result()
             if din_d is not None:
                 tgt, tgt_d = tgt
@@ -1185,6 +1252,7 @@ class GanTrainer:
             elif drc_items is not None:
                 if part is not None:                                    # the batch's new pre-enhanced examples, computed as a batch of their own
                     pend_sub, din_sub, miss, dkeys, frames_b, fh_b, qua_b = part
+                    qua_b = drc_qua                                     # (resolved above when it was a future)
                     tgt_sub = pend_sub.result()
                     fr_sub = None if frames_b is None else ([fh_b[r_] for r_ in miss] if fh_b is not None else [int(v) for v in frames_b[miss].tolist()])
                     new_items = self._items(din_sub, tgt_sub, None if qua_b is None else qua_b[miss], None if fr_sub is None else frames_b, fr_sub)
@@ -1247,9 +1315,19 @@ class GanTrainer:
                 din_d = self.d_inputs(b['drc'], f['noise_band'], f['clean_band'], au._i32(dl, self.device) if dl is not None else None, resynth=False)
             lh = b.get('lengths_host')
             fh_ = None if lh is None else [1 + int(v) // 256 for v in lh]
-            pending.append((pend, din, b.get('qua'), frames, din_d, b.get('drc_qua'), fh_,
+            qua, drc_qua = b.get('qua'), b.get('drc_qua')
+            if scorer is not None and self.D_Qua is not None:          # :323-324, 336-337: PESQ / ViSQOL of the examples D_Qua is trained on
+                if qua is None:
+                    qua = self._quality_async(b['clean'], enh, nsamp(b, enh))
+                if drc_qua is None and b.get('drc') is not None and (drc_items is None or miss):
+                    dlh = b.get('drc_lengths_host')
+                    if dlh is None:
+                        dlh = dl.tolist() if torch.is_tensor(dl) else (dl if dl is not None else [b['drc'].shape[1]] * b['drc'].shape[0])
+                    drc_qua = self._quality_async(b['clean'], b['drc'], nsamp(b, b['drc'], resynth=False, other=dlh),
+                                                  rows=None if drc_items is None else miss)
+            pending.append((pend, din, qua, frames, din_d, drc_qua, fh_,
                             drc_items, dkeys if (dcache is not None and drc_items is None) else None,
-                            None if not miss else (pend_sub, din_sub, miss, dkeys, frames, fh_, b.get('drc_qua'))))
+                            None if not miss else (pend_sub, din_sub, miss, dkeys, frames, fh_, drc_qua)))
             # bounded lag: the targets of batch i - target_lag are resolved now, so that at most target_lag batches keep their metric inputs
             # (x, y, lengths: 2 - 3 x B x L x 4 bytes each) alive and the main stream cannot run arbitrarily far ahead of the metric streams
             while len(pending) - resolved > getattr(self, 'target_lag', 3):

@@ -206,6 +206,77 @@ def test_run_epoch_with_the_quality_discriminator(tmp_path):
         tr.run_epoch(3, train, ())
 
 
+def test_run_epoch_scores_the_quality_targets_with_the_registered_programs(tmp_path):
+    """train_nele.py:216-222, 323-324, 336-337: with a quality.Scorer the epoch driver itself obtains D_Qua's targets - PESQ / ViSQOL of the
+    GENERATED file's samples (PCM_16, 256 * (L // 256)) against the clean file cut to them, of the pre-enhanced example over
+    min(clean, pre-enhanced), mapped - and the raw validation means.  PESQ and ViSQOL are external programs that are not in the image:
+    STAND-INS are registered here (functions of both signals), which shows the plumbing, not a score."""
+    from nele_gan_amd import quality
+    from nele_gan_amd.train_nele import GanTrainer
+    seen = []
+
+    def pesq(ref, deg, fs):
+        assert fs == 16000 and len(ref) == len(deg) and ref.dtype == np.float32
+        seen.append((ref.copy(), deg.copy()))
+        r, d = ref.astype(np.float64), deg.astype(np.float64)
+        return 1.0 + 3.5 * abs(float(r @ d)) / (np.sqrt(float(r @ r) * float(d @ d)) + 1e-30)
+
+    def visqol(pairs):
+        from nele_gan_amd import dataio
+        out = []
+        for rp, dp in pairs:
+            x, y = dataio.load(rp)[0].astype(np.float64), dataio.load(dp)[0].astype(np.float64)
+            n = min(len(x), len(y))
+            out.append(1.0 + 4.0 / (1.0 + 50.0 * float(np.abs(x[:n] - y[:n]).mean())))
+        return out
+    quality.clear_backends()
+    quality.set_backends(pesq=pesq, visqol=visqol)
+    try:
+        train, valid = _corpus()
+        tr = GanTrainer('estoi', use_quality=True, quality_scorer=quality.Scorer(tmp_root=str(tmp_path)))
+        # epoch 1 has no G-step: the generated examples are those of the untrained generator, computable beforehand
+        want = []
+        for b in train:
+            f = tr.features(b['clean'], b['noise'], b['lengths'])
+            enh = tr.generate(f['clean_band'], f['noise_band'], f['clean_spec'], frames=f['frames']).cpu().numpy()
+            cl, dr = b['clean'].cpu().numpy(), b['drc'].cpu().numpy()
+            for k, (L, Ld) in enumerate(zip(b['lengths'].tolist(), b['drc_lengths'].tolist())):
+                n = 256 * (L // 256)
+                want.append(('gen', cl[k, :n], enh[k, :n]))
+                m = min(L, Ld)
+                want.append(('drc', cl[k, :m], dr[k, :m]))
+        out = tr.run_epoch(1, train, valid, d_batch=4)
+        assert out['samples'] == 8 and out['d_steps'] == 6 and tr.optimizer_dqua.step_count == 6
+        assert np.isfinite(float(tr.last_loss_qua))
+        # 2 validation + 4 generated + 4 pre-enhanced utterances went to the programs, with exactly the samples the reference compares
+        assert len(seen) == 10
+        for kind, ref, deg in want:
+            assert any(len(r) == len(ref) and np.array_equal(r, ref) and np.array_equal(d, deg) for r, d in seen), kind
+        # the D_Qua items carry the mapped scores
+        items = {}
+        for it in tr.history:
+            items[tuple(np.round(it[2].cpu().numpy().astype(np.float64), 6))] = True
+        for kind, ref, deg in want:
+            p = pesq(ref, deg, 16000)
+            v = 1.0 + 4.0 / (1.0 + 50.0 * float(np.abs(ref.astype(np.float64) - deg.astype(np.float64)).mean()))
+            key = (round(float(quality.mapping_PESQ_harvard(p)), 6), round(float(quality.mapping_VISQOL(v)), 6))
+            assert any(abs(a - key[0]) < 2e-6 and abs(b_ - key[1]) < 2e-6 for a, b_ in items), (kind, key)
+        # raw validation means for the learning curve (Test_PESQ / Test_VISQOL)
+        assert 1.0 <= out['valid']['pesq'] <= 4.5 and 1.0 <= out['valid']['visqol'] <= 5.0
+        # targets that come with the batch win: nothing is scored for that batch's generated examples
+        n0 = len(seen)
+        train[0]['qua'] = torch.tensor([[0.4, 0.5], [0.6, 0.3]], device='cuda')
+        train[0]['drc_qua'] = torch.tensor([[0.7, 0.8], [0.2, 0.9]], device='cuda')
+        tr.run_epoch(2, train, (), d_batch=4)
+        assert len(seen) - n0 == 4
+        # and without the programs the call fails loudly instead of training D_Qua on nothing
+        quality.clear_backends()
+        with pytest.raises(quality.QualityBackendMissing):
+            tr.run_epoch(3, train, (), d_batch=4)
+    finally:
+        quality.clear_backends()
+
+
 def test_inference_on_eight_second_utterances_matches_the_oracle():
     """BASELINE configs[4]: 8 s utterances (L = 128 000, T = 501: the IMCRA scan over 501 frames, G, iSTFT, RMS 0.03, PCM_16)."""
     from nele_gan_amd import synth
