@@ -222,3 +222,36 @@ def enhance_files(enhancer, file_list, noise_path, output_path, batch=32, epoch_
         pool.shutdown(wait=True)
         fb.close()
     return [written[i] for i in mine]
+
+
+def score_enhanced(clean_path, noise_path, enhanced_names, groups=('Cafeteria', 'AirportAnnouncement'), quality=None, out=None):
+    """inference.py:119-146: the true (unmapped) scores of the enhanced test files, per noise type - ``groups``: substrings of the file
+    names (the reference's test set carries the noise type in the name); ``None`` / an empty tuple scores the whole list as one group ''.
+    SIIB, HASPI and ESTOI through dataio.read_batch_* (one launch per metric and 256 files); PESQ and ViSQOL - external host programs,
+    quality.py - when ``quality`` is true (None: when both programs are registered), else reported as nan.
+    -> {group: {'siib', 'haspi', 'estoi', 'pesq', 'visqol': mean, 'files': n}}; the reference's report lines are printed to ``out``
+    (a file object; default sys.stdout)."""
+    import sys
+    import numpy as np
+    from . import dataio
+    from . import quality as q
+    if quality is None:
+        quality = q._BACKENDS['visqol'] is not None and (q._BACKENDS['pesq'] is not None or q._BACKENDS['pesq_batch'] is not None)
+    out = sys.stdout if out is None else out
+    res = {}
+    for g in (tuple(groups) if groups else ('',)):
+        names = [x for x in enhanced_names if g in x]                               # :120
+        if not names:
+            continue
+        r = {'haspi': float(np.mean(dataio.read_batch_HASPI(clean_path, noise_path, names, norm=False))),      # :122-131
+             'estoi': float(np.mean(dataio.read_batch_STOI(clean_path, noise_path, names, norm=False))),
+             'siib': float(np.mean(dataio.read_batch_SIIB(clean_path, noise_path, names, norm=False))),
+             'pesq': float('nan'), 'visqol': float('nan'), 'files': len(names)}
+        if quality:                                                                  # :134-141
+            r['pesq'] = float(np.mean(q.read_batch_PESQ(clean_path, names, norm=False)))
+            r['visqol'] = float(np.mean(q.read_batch_VISQOL(clean_path, names, norm=False)))
+        res[g] = r
+        out.write(g + ':\n')                                                         # :142-145
+        out.write('SIIB is %.3f, HASPI is %.3f, ESTOI is %.3f, PESQ is %.3f, VISQOL is %.3f\n\n' % (r['siib'], r['haspi'], r['estoi'], r['pesq'], r['visqol']))
+        out.write('======\n')
+    return res

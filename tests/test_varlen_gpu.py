@@ -164,6 +164,25 @@ def test_enhance_files_writes_the_reference_layout(tmp_path):
         ref = e.enhance(torch.from_numpy(c[:m]).cuda().unsqueeze(0), torch.from_numpy(n[:m]).cuda().unsqueeze(0))[0].cpu().numpy()
         np.testing.assert_array_equal(got, ref)                           # PCM_16 grid on both sides: exact
         assert np.sqrt(np.mean(got.astype(np.float64) ** 2)) == pytest.approx(0.03, rel=2e-3)
+    # the script's report behind the loop (inference.py:119-146): unmapped means per noise type (a substring of the file name)
+    import io
+    from nele_gan_amd.inference import score_enhanced
+    from nele_gan_amd import quality
+    quality.clear_backends()
+    buf = io.StringIO()
+    rep = score_enhanced(str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/', out, groups=('Train', 'Test', 'Cafeteria'), out=buf)
+    assert set(rep) == {'Train', 'Test'} and rep['Train']['files'] == 1
+    for g, path in (('Train', out[0]), ('Test', out[1])):
+        one = [path]
+        assert rep[g]['siib'] == pytest.approx(dataio.read_batch_SIIB(str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/', one, norm=False)[0], rel=1e-12)
+        assert rep[g]['estoi'] == pytest.approx(dataio.read_batch_STOI(str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/', one, norm=False)[0], rel=1e-12)
+        assert rep[g]['haspi'] == pytest.approx(dataio.read_batch_HASPI(str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/', one, norm=False)[0], rel=1e-12)
+        assert np.isnan(rep[g]['pesq']) and np.isnan(rep[g]['visqol'])           # the external programs are not registered: not scored, not invented
+    lines = buf.getvalue().splitlines()
+    assert lines[0] == 'Train:' and lines[1] == ('SIIB is %.3f, HASPI is %.3f, ESTOI is %.3f, PESQ is nan, VISQOL is nan'
+                                                 % (rep['Train']['siib'], rep['Train']['haspi'], rep['Train']['estoi']))
+    with pytest.raises(quality.QualityBackendMissing):
+        score_enhanced(str(tmp_path / 'Clean') + '/', str(tmp_path / 'Noise') + '/', out, groups=None, quality=True, out=buf)
     # one file per batch, three batches in flight, no length bucketing, in list order: the same files byte for byte
     out1 = enhance_files(e, files + files[:1], str(tmp_path / 'Noise') + '/', str(tmp_path / 'Enh1'), batch=1, sort_by_length=False, pad_to=0)
     assert [os.path.basename(p) for p in out1] == ['Train@1.wav', 'Test@1.wav', 'Train@1.wav']
