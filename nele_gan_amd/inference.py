@@ -255,3 +255,35 @@ def score_enhanced(clean_path, noise_path, enhanced_names, groups=('Cafeteria', 
         out.write('SIIB is %.3f, HASPI is %.3f, ESTOI is %.3f, PESQ is %.3f, VISQOL is %.3f\n\n' % (r['siib'], r['haspi'], r['estoi'], r['pesq'], r['visqol']))
         out.write('======\n')
     return res
+
+
+def main(argv=None):
+    """``python -m nele_gan_amd.inference --chkpt ./trained_model/chkpt_GD.pt --clean <dir> --noise <dir> --output <dir>`` = the
+    reference's usage step 4 (`python inference.py`, README; inference.py:28-146): every wav under --clean is enhanced against the noise file
+    of the same name, written as '<output>/<name>@1.wav' (PCM_16), and - ``--score`` - the per-noise report of :119-146 is printed."""
+    import argparse
+    from . import dataio
+    ap = argparse.ArgumentParser(prog='python -m nele_gan_amd.inference', description=main.__doc__)
+    ap.add_argument('--chkpt', default=None, help="checkpoint with an 'enhance-model' entry (reference checkpoints load unchanged); default: random weights")
+    ap.add_argument('--clean', required=True)
+    ap.add_argument('--noise', required=True)
+    ap.add_argument('--output', default='./output_inference')
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16')
+    ap.add_argument('--score', action='store_true', help='SIIB / HASPI / ESTOI (PESQ / ViSQOL when registered) of the written files')
+    ap.add_argument('--groups', default='Cafeteria,AirportAnnouncement', help='noise types (substrings of the file names) reported separately; empty = all files together')
+    a = ap.parse_args(argv)
+    e = Enhancer(a.chkpt)
+    e.G.precision = a.precision
+    files = sorted(dataio.get_filepaths(a.clean))
+    noise = a.noise.rstrip('/') + '/'
+    out = enhance_files(e, files, noise, a.output, batch=a.batch)
+    print('%d files -> %s' % (len(out), a.output))
+    if a.score:
+        score_enhanced(a.clean.rstrip('/') + '/', noise, out, groups=tuple(g for g in a.groups.split(',') if g))
+    return 0
+
+
+if __name__ == '__main__':
+    import sys
+    sys.exit(main())

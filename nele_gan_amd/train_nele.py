@@ -1509,3 +1509,73 @@ class GanTrainer:
             self.D.load_state_dict(ck['intel-model'])
         if self.D_Qua is not None and 'quality-model' in ck:
             self.D_Qua.load_state_dict(ck['quality-model'])
+
+
+def main(argv=None):
+    """``python -m nele_gan_amd.train_nele --data ./toy_dataset`` = the reference's usage step 3 (`python train_nele.py`, README) with the
+    script's constants (train_nele.py:28-43, 49-70) as options instead of edits: <data>/Train/{Clean,Noise,MultiEnh}, <data>/Test/{Clean,Noise}
+    as in ./toy_dataset; checkpoints in --chkpt, samples and the learning-curve log under --output.  Under torchrun every rank takes its
+    shard of the epoch's draw (one process per GPU, RCCL)."""
+    import argparse
+    from . import dataio
+    ap = argparse.ArgumentParser(prog='python -m nele_gan_amd.train_nele', description=main.__doc__)
+    ap.add_argument('--data', required=True, help='corpus root with Train/Clean, Train/Noise, Train/MultiEnh (optional), Test/Clean, Test/Noise')
+    ap.add_argument('--metrics', default=TargetMetric)
+    ap.add_argument('--epochs', type=int, default=GAN_epoch)
+    ap.add_argument('--sampling', type=int, default=num_of_sampling)
+    ap.add_argument('--valid-samples', type=int, default=num_of_valid_sample)
+    ap.add_argument('--batch', type=int, default=32, help='utterances per batch (the reference: 1)')
+    ap.add_argument('--output', default='./output')
+    ap.add_argument('--chkpt', default='./chkpt')
+    ap.add_argument('--log', default='./log.txt')
+    ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16', help='MFMA operand precision of G and D (f32 = the reference\'s arithmetic)')
+    ap.add_argument('--valid-filter', default=None, help='keep validation files whose name contains this (train_nele.py:65: \'AIR_stairway\')')
+    ap.add_argument('--resume', default=None, help='checkpoint to start from (train_nele.py:82-84)')
+    ap.add_argument('--first-epoch', type=int, default=1)
+    ap.add_argument('--no-cache', action='store_true', help='recompute the clean-signal halves of the metrics every epoch')
+    ap.add_argument('--quality', action='store_true', help='train Discriminator_Quality too: needs quality.set_backends(...) - PESQ / ViSQOL are external programs')
+    a = ap.parse_args(argv)
+    root = a.data.rstrip('/')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as tdist
+        torch.cuda.set_device(local)
+        tdist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    scorer = None
+    if a.quality:
+        from . import quality
+        scorer = quality.Scorer()
+    tr = GanTrainer(a.metrics, device='cuda:%d' % local, use_quality=a.quality, quality_scorer=scorer)
+    for m_ in (tr.G, tr.D, tr.D_Qua):
+        if m_ is not None:
+            m_.precision = a.precision
+    if a.resume:
+        tr.load_checkpoint(a.resume)
+    train = sorted(dataio.get_filepaths(root + '/Train/Clean/'))
+    valid = sorted(dataio.get_filepaths(root + '/Test/Clean/'))
+    if a.valid_filter:
+        valid = [x for x in valid if a.valid_filter in x]
+    enh = root + '/Train/MultiEnh/'
+    if ndist.rank() == 0:
+        print('%d training files, %d validation files, %s' % (len(train), len(valid), 'pre-enhanced examples: ' + enh if os.path.isdir(enh) else 'no pre-enhanced examples'))
+
+    def report(res):
+        if ndist.rank() == 0:
+            v = res.get('valid') or {}
+            print('epoch %d: g_loss %s, %d samples, %d D steps, valid %s' % (res['gan_epoch'], res['g_loss'] if res['g_loss'] is None else '%.4f' % float(res['g_loss']),
+                                                                             res['samples'], res['d_steps'], ', '.join('%s %.3f' % kv for kv in v.items())), flush=True)
+    try:
+        tr.fit(train, root + '/Train/Noise/', valid, root + '/Test/Noise/', train_enh_path=enh if os.path.isdir(enh) else None, epochs=a.epochs,
+               sampling=a.sampling, valid_samples=a.valid_samples, batch=a.batch, output_path=a.output, pt_dir=a.chkpt, log_path=a.log,
+               first_epoch=a.first_epoch, clean_cache=not a.no_cache, on_epoch=report)
+    finally:
+        if world > 1:
+            import torch.distributed as tdist
+            tdist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    import sys
+    sys.exit(main())

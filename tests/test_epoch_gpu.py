@@ -401,6 +401,52 @@ def test_fit_runs_the_scripts_outer_loop_over_folders(tmp_path):
     assert len(files) == 15 and all('@' in f for f in files)
 
 
+def test_the_two_scripts_run_as_modules_on_a_toy_corpus(tmp_path):
+    """The reference's usage steps 3 and 4 (README: `python train_nele.py`, `python inference.py`) as `python -m nele_gan_amd.train_nele`
+    and `python -m nele_gan_amd.inference` over a corpus laid out like ./toy_dataset - the toy files themselves plus synthetic utterances."""
+    import shutil
+    import subprocess
+    import sys
+    from nele_gan_amd import dataio, synth
+    root = str(tmp_path / 'toy')
+    for sub in ('Train/Clean', 'Train/Noise', 'Train/MultiEnh', 'Test/Clean', 'Test/Noise'):
+        os.makedirs(os.path.join(root, sub))
+    name = 'f_hvd_100#Babble#-11.wav'
+    shutil.copy(os.path.join(TOY, 'Train_Clean.wav'), root + '/Train/Clean/' + name)
+    shutil.copy(os.path.join(TOY, 'Train_Noise.wav'), root + '/Train/Noise/' + name)
+    shutil.copy(os.path.join(TOY, 'Train_MultiEnh.wav'), root + '/Train/MultiEnh/' + name)
+    shutil.copy(os.path.join(TOY, 'Test_Clean.wav'), root + '/Test/Clean/f_hvd_669#AirportAnnouncement#-9.wav')
+    shutil.copy(os.path.join(TOY, 'Test_Noise.wav'), root + '/Test/Noise/f_hvd_669#AirportAnnouncement#-9.wav')
+    c, v = synth.batch(4, 36000, start=40)
+    for i in range(3):
+        nm = 'syn_%d#Cafeteria#-5.wav' % i
+        dataio.write_wav_pcm16(root + '/Train/Clean/' + nm, c[i])
+        dataio.write_wav_pcm16(root + '/Train/Noise/' + nm, v[i])
+        dataio.write_wav_pcm16(root + '/Train/MultiEnh/' + nm, (1.3 * c[i]).astype(np.float32))
+    dataio.write_wav_pcm16(root + '/Test/Clean/syn_3#Cafeteria#-5.wav', c[3])
+    dataio.write_wav_pcm16(root + '/Test/Noise/syn_3#Cafeteria#-5.wav', v[3])
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    out, ck, log = str(tmp_path / 'output'), str(tmp_path / 'chkpt'), str(tmp_path / 'log.txt')
+    r = subprocess.run([sys.executable, '-m', 'nele_gan_amd.train_nele', '--data', root, '--epochs', '2', '--sampling', '3', '--valid-samples', '2',
+                        '--batch', '2', '--output', out, '--chkpt', ck, '--log', log], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '4 training files, 2 validation files' in r.stdout and 'epoch 2:' in r.stdout
+    assert len(open(log).read().splitlines()) == 2
+    sd = torch.load(ck + '/chkpt_2.pt', map_location='cpu')
+    assert set(sd.keys()) == {'enhance-model', 'intel-model'}
+    assert len(os.listdir(out + '/For_discriminator_training')) == 6                                # 3 drawn files x 2 epochs: name@epoch.wav
+    enh = str(tmp_path / 'enh')
+    r = subprocess.run([sys.executable, '-m', 'nele_gan_amd.inference', '--chkpt', ck + '/chkpt_2.pt', '--clean', root + '/Test/Clean', '--noise', root + '/Test/Noise',
+                        '--output', enh, '--score'], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(enh)) == ['f_hvd_669#AirportAnnouncement#-9@1.wav', 'syn_3#Cafeteria#-5@1.wav']
+    lines = r.stdout.splitlines()
+    assert 'Cafeteria:' in lines and 'AirportAnnouncement:' in lines and sum(l.startswith('SIIB is ') for l in lines) == 2
+    w, sr = dataio.load(enh + '/syn_3#Cafeteria#-5@1.wav')
+    assert sr == 16000 and len(w) == 256 * (36000 // 256) and np.sqrt(np.mean(w.astype(np.float64) ** 2)) == pytest.approx(0.03, rel=2e-3)
+
+
 def test_an_enhancer_that_owns_its_generator_keeps_the_weight_layouts_and_notices_new_weights(tmp_path):
     """inference.py:71-72: the generator is loaded from a checkpoint once; plain enhance() then writes the weight layouts once instead of per
     batch - and a later load_state_dict() must not be served from stale layouts."""
