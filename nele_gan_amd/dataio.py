@@ -439,6 +439,12 @@ class FileBatches:
     def __len__(self):
         return len(self.groups)
 
+    def _keys(self, g):
+        """One hashable per utterance of group g for the trainer's caches (GanTrainer.enable_clean_cache): the clean FILE (not its base name:
+        Train/Clean/x.wav and Test/Clean/x.wav are different utterances) with the noise and pre-enhanced folders it is paired with - the
+        cached features and D items of an utterance depend on those files too."""
+        return [(self.files[i], self.noise_path, self.drc_path) for i in self.groups[g]]
+
     def _bound(self, path):
         """upper bound of a file's samples from its size (exact for the 44-byte-header PCM_16 files the reference writes)"""
         b = self._bounds.get(path)
@@ -557,7 +563,7 @@ class FileBatches:
                 return out, dl
             clean, dl = up(hc, lens)
             noise, _ = up(hn, lens)
-            b = {'clean': clean, 'noise': noise, 'lengths': dl, 'names': list(names), 'lengths_host': lens}
+            b = {'clean': clean, 'noise': noise, 'lengths': dl, 'names': list(names), 'lengths_host': lens, 'keys': self._keys(g)}
             if hd is not None:
                 dlens = got[2].astype(np.int32)
                 b['drc'], b['drc_lengths'] = up(hd, dlens)
@@ -587,7 +593,7 @@ class FileBatches:
         with torch.cuda.stream(self._copy):
             b = {'clean': hc.to(self.device, non_blocking=True), 'noise': hn.to(self.device, non_blocking=True),
                  'lengths': torch.from_numpy(lens).pin_memory().to(self.device, non_blocking=True), 'names': [r[2] for r in res],
-                 'lengths_host': lens}
+                 'lengths_host': lens, 'keys': self._keys(g)}
             if hd is not None:
                 dlens = np.asarray([r[1] for r in res], dtype=np.int32)
                 b['drc'] = hd.to(self.device, non_blocking=True)

@@ -1097,7 +1097,8 @@ class GanTrainer:
         optional 'lengths': [B] samples of each utterance inside the zero-padded batch (files of different lengths side by side, as
         the reference's batch-1 loop handles them one at a time) and 'drc_lengths' (of the pre-enhanced files; default 'lengths'),
         optional 'ids': [B] int64 utterance ids (haspi_dither='utterance': the dither rows follow the utterance, not the rank),
-        optional 'keys' (default: 'names'): one hashable per utterance - with enable_clean_cache() the clean-signal halves of SIIB / HASPI
+        optional 'keys' (dataio.FileBatches: the clean file's path + the folders it is paired with; default: 'names' - base names, which
+        must then be unique over everything this trainer ever scores): one hashable per utterance - with enable_clean_cache() the clean-signal halves of SIIB / HASPI
         of an utterance are computed the first time it is scored and reused in every later epoch}.
         Under data parallelism every rank passes its own shard of batches; ranks may hold different batch counts and sizes (empty
         G-steps / D-steps join the collectives, gradients are item-weighted means, the validation means run over all ranks).

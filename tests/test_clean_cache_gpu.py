@@ -113,3 +113,36 @@ def test_utterance_dither_is_part_of_the_haspi_key(setup):
     tr.dither_seed = 6                                                        # another dither: another key, no stale hit
     tr.true_metrics(c, enh, v, norm=False, utt_ids=ids, keys=keys)
     assert cache.hits == 1
+
+
+def test_file_batches_key_utterances_by_path_not_by_base_name(tmp_path):
+    """Train/Clean/x.wav and Test/Clean/x.wav are different utterances: dataio.FileBatches hands the trainer's caches the clean file's PATH
+    (with the noise / pre-enhanced folders it is paired with), so an epoch over one folder never finds the other folder's clean-signal state."""
+    import os
+    from nele_gan_amd import dataio, synth
+    from nele_gan_amd.train_nele import GanTrainer
+    c, v = synth.batch(4, 36000, start=500)
+    for part, rows in (('A', (0, 1)), ('B', (2, 3))):
+        for sub in ('Clean', 'Noise'):
+            os.makedirs(str(tmp_path / part / sub))
+        for j, r in enumerate(rows):                                          # the SAME two base names in both folders, different signals
+            dataio.write_wav_pcm16(str(tmp_path / part / 'Clean' / ('u%d.wav' % j)), c[r])
+            dataio.write_wav_pcm16(str(tmp_path / part / 'Noise' / ('u%d.wav' % j)), v[r])
+    fa = dataio.FileBatches(sorted(dataio.get_filepaths(str(tmp_path / 'A' / 'Clean'))), str(tmp_path / 'A' / 'Noise') + '/', batch=2)
+    fb = dataio.FileBatches(sorted(dataio.get_filepaths(str(tmp_path / 'B' / 'Clean'))), str(tmp_path / 'B' / 'Noise') + '/', batch=2)
+    try:
+        ba, bb = fa[0], fb[0]
+        assert ba['names'] == bb['names'] and ba['keys'] != bb['keys'] and len(set(ba['keys'] + bb['keys'])) == 4
+        plain = GanTrainer('siib&haspi&estoi')
+        tr = GanTrainer('siib&haspi&estoi')
+        tr.enable_clean_cache(2 << 30)
+        for b in (ba, bb, ba, bb):
+            Lr = 256 * (b['clean'].shape[1] // 256)
+            enh = (1.2 * b['clean'][:, :Lr]).contiguous()
+            want = plain.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b['lengths'])
+            got = tr.true_metrics(b['clean'], enh, b['noise'], norm=False, lengths=b['lengths'], keys=b['keys'])
+            assert torch.equal(got, want)
+        assert tr.clean_cache.hits > 0
+    finally:
+        fa.close()
+        fb.close()
