@@ -167,3 +167,40 @@ __device__ __forceinline__ double block_max(double v, double* scratch) {
     for (int i = 1; i < nw; ++i) t = fmax(t, scratch[i]);
     return t;
 }
+
+// x ** p of the band features (audio_util.py:434, 451: `compute_band_E(...) ** p_power`, a float32 array to a Python float: numpy's float32
+// loop, i.e. powf(x, float32(p)) - itself only accurate to an ulp).  This build returns the float32 NEAREST to x ^ float32(p).
+// General p: the float64 pow (267 instructions - a quarter of the STFT kernel's issue slots at two calls per frame pair).  p = float32(1/6),
+// what every caller passes (train_nele.py:39 p_power): x = m6 2^(6q), m6 in [0.5, 32); m6^(1/6) from the float32 hardware log2 / exp2
+// (relative error ~2e-7) and ONE Newton step on y^6 = m6 in float64 (error 2.5 e^2 = 1e-13; the quotient by a float32 reciprocal: the
+// correction term is itself 1e-6); times x^(float32(1/6) - 1/6) = 1 + ln(x) 4.97e-9.  3e-14 relative before the rounding to float32: the
+// result differs from the float64 pow's in 6 of 10^7 values (a tie broken the other way, 1 ulp) - the reference's own powf differs from
+// both in every fifth.  ~35 instructions.  Also the G-step glue's mask ** p (train_nele.py:137, gen.hip).
+__device__ __forceinline__ float nele_pow_f32(float x, float p) {
+    if (p != (float)(1.0 / 6.0)) return (float)pow((double)x, (double)p);          // (uniform: p is a kernel argument)
+    const bool ok = x > 0.f && x < __builtin_inff();
+    const double d = ok ? (double)x : 1.0;                                           // float32 subnormals are normal doubles
+    const int e = __builtin_amdgcn_frexp_exp(d);                                     // d = m 2^e, m in [0.5, 1)
+    const double m = __builtin_amdgcn_frexp_mant(d);
+    const int q = (int)(((unsigned)(e + 1536) * 43691u) >> 18) - 256;               // floor(e / 6) for |e| <= 1100
+    const int r = e - 6 * q;                                                         // 0 .. 5
+    const double m6 = ldexp(m, r);                                                   // [0.5, 32): 24 significant bits, exact as a float
+    const float l2 = __builtin_amdgcn_logf((float)m6);                               // v_log_f32
+    const double y0 = (double)__builtin_amdgcn_exp2f(l2 * (float)(1.0 / 6.0));       // v_exp_f32
+    const double y2 = y0 * y0, z = y2 * y2 * y2;
+    const double rc = (double)__builtin_amdgcn_rcpf((float)(6.0 * z));
+    double y1 = fma(-y0, (z - m6) * rc, y0);                                         // Newton: y - (y^6 - m6) / (6 y^5)
+    const double eps_ln2 = ((double)(float)(1.0 / 6.0) - 1.0 / 6.0) * 0.6931471805599453;
+    y1 = fma(y1, ((double)(6 * q) + (double)l2) * eps_ln2, y1);                      // x ^ (float32(1/6) - 1/6)
+    const float v = (float)ldexp(y1, q);
+    return ok ? v : (x == 0.f ? 0.f : (x > 0.f ? x : __builtin_nanf("")));           // 0 -> 0, inf -> inf, negative / NaN -> NaN
+}
+
+// x ** inv_p of the G-step glue (train_nele.py:133 / inference.py:100 `torch.pow(clean_in, inv_p)`, inv_p = 6): for the integer 6 three
+// float64 products, rounded once - the float32 nearest to x^6 (torch's powf is within an ulp of it); energy_norm_fwd_kernel spent three
+// quarters of its time in powf(x, 6.0f).  Any other exponent: powf.
+__device__ __forceinline__ float nele_powi_f32(float x, float inv_p) {
+    if (inv_p != 6.0f) return powf(x, inv_p);                                        // (uniform: a kernel argument)
+    const double d = (double)x, d2 = d * d;
+    return (float)(d2 * d2 * d2);
+}

@@ -77,7 +77,8 @@ __device__ __forceinline__ float np_cabsf(float re, float im) {
     return sqrtf(__builtin_fmaf(ratio, ratio, 1.0f)) * larger;
 }
 
-__device__ __forceinline__ float pow_f32(float x, float p) { return (float)pow((double)x, (double)p); }
+// the power law of the band features: nele_pow_f32 (common.h)
+__device__ __forceinline__ float pow_f32(float x, float p) { return nele_pow_f32(x, p); }
 
 __device__ __forceinline__ double hann512(int n) { return 0.5 - 0.5 * cospi((double)n / 256.0); }
 

@@ -226,3 +226,38 @@ def test_wave_per_transform_stft_istft_are_bit_identical_to_the_workgroup_kernel
         res.append(np.load(out))
     assert res[0].shape == res[1].shape and np.all(np.isfinite(res[0]))
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+
+
+def test_band_power_law_is_the_nearest_float32_to_the_float64_power():
+    """`compute_band_E(...) ** p_power` (audio_util.py:434, 451): the kernels' x ** float32(1/6) fast path (float32 hardware log2 / exp2 +
+    one float64 Newton step, features.hip pow_f32) against numpy's float64 power of the SAME band energies (power = 1 returns them raw),
+    rounded to float32: equal except where a tie falls the other way (1 ulp, a few in 10^7); general exponents take the float64 pow."""
+    from nele_gan_amd import audio_util as au
+    from nele_gan_amd import synth
+    c, v = synth.batch(16, 64000, start=40)
+    x = torch.from_numpy(np.concatenate([c, v * 30.0, c * 1e-4])).cuda()                   # band energies over ~14 decades
+    lens = torch.full((x.shape[0],), 64000, dtype=torch.int32)
+    lens[3] = 40000                                                                          # zero frames behind a short row: 0 ** p = 0
+    _, raw = au.stft_band(x, power=1.0, want_spec=False, lengths=lens)
+    _, got = au.stft_band(x, power=1.0 / 6, want_spec=False, lengths=lens)
+    e = raw.cpu().numpy()
+    p32 = np.float32(1.0 / 6)
+    want = np.power(e.astype(np.float64), np.float64(p32)).astype(np.float32)
+    g = got.cpu().numpy()
+    assert (e == 0).any() and (e > 0).sum() > 700000 and e[e > 0].max() / e[e > 0].min() > 1e12
+    diff = g != want
+    assert diff.mean() < 5e-6
+    if diff.any():
+        assert np.max(np.abs(g[diff].astype(np.float64) - want[diff]) / np.spacing(want[diff])) <= 1.0
+    assert np.all(g[e == 0] == 0)
+    # a general exponent: the float64 pow
+    _, g3 = au.stft_band(x[:4], power=0.3, want_spec=False)
+    _, r3 = au.stft_band(x[:4], power=1.0, want_spec=False)
+    w3 = np.power(r3.cpu().numpy().astype(np.float64), np.float64(np.float32(0.3))).astype(np.float32)
+    assert np.mean(g3.cpu().numpy() != w3) < 1e-4
+    # the noise path's band feature goes through the same function (band_from_psd_kernel)
+    spec, _ = au.stft_band(x[:8], want_band=False)
+    psd, nb = au.imcra_band(spec, want_psd=True)
+    _, nb1 = au.imcra_band(spec, power=1.0, want_psd=True)
+    w = np.power(nb1.cpu().numpy().astype(np.float64), np.float64(p32)).astype(np.float32)
+    assert np.mean(nb.cpu().numpy() != w) < 5e-6
