@@ -272,7 +272,10 @@ def main(argv=None):
     ap.add_argument('--precision', choices=('bf16', 'f32'), default='bf16')
     ap.add_argument('--score', action='store_true', help='SIIB / HASPI / ESTOI (PESQ / ViSQOL when registered) of the written files')
     ap.add_argument('--groups', default='Cafeteria,AirportAnnouncement', help='noise types (substrings of the file names) reported separately; empty = all files together')
+    from . import quality as _q
+    _q.add_cli_arguments(ap)
     a = ap.parse_args(argv)
+    _q.backends_from_cli(a)
     e = Enhancer(a.chkpt)
     e.G.precision = a.precision
     files = sorted(dataio.get_filepaths(a.clean))

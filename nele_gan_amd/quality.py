@@ -53,6 +53,26 @@ def set_backends(pesq=None, visqol=None, pesq_batch=None):
         _BACKENDS['visqol'] = visqol
 
 
+def add_cli_arguments(ap):
+    """--pesq / --visqol / --visqol-model for the two module entry points (train_nele, inference)."""
+    ap.add_argument('--pesq', default=None, metavar='MODULE:FUNCTION', help='pesq(ref, deg, fs) of an installed PESQ package, e.g. pypesq:pesq (intel.py:14)')
+    ap.add_argument('--visqol', default=None, metavar='PROGRAM', help='the ViSQOL binary (audio_util.py:230)')
+    ap.add_argument('--visqol-model', default=None, metavar='FILE', help='its --similarity_to_quality_model file (audio_util.py:231)')
+
+
+def backends_from_cli(a):
+    """Register what --pesq / --visqol name; -> True when both programs are there afterwards."""
+    if getattr(a, 'pesq', None):
+        import importlib
+        mod, _, fn = a.pesq.partition(':')
+        set_backends(pesq=getattr(importlib.import_module(mod), fn or 'pesq'))
+    if getattr(a, 'visqol', None):
+        if not getattr(a, 'visqol_model', None):
+            raise SystemExit('--visqol needs --visqol-model')
+        set_backends(visqol=visqol_program(a.visqol, a.visqol_model))
+    return _BACKENDS['visqol'] is not None and (_BACKENDS['pesq'] is not None or _BACKENDS['pesq_batch'] is not None)
+
+
 def clear_backends():
     for k in _BACKENDS:
         _BACKENDS[k] = None

@@ -1534,8 +1534,12 @@ def main(argv=None):
     ap.add_argument('--resume', default=None, help='checkpoint to start from (train_nele.py:82-84)')
     ap.add_argument('--first-epoch', type=int, default=1)
     ap.add_argument('--no-cache', action='store_true', help='recompute the clean-signal halves of the metrics every epoch')
-    ap.add_argument('--quality', action='store_true', help='train Discriminator_Quality too: needs quality.set_backends(...) - PESQ / ViSQOL are external programs')
+    ap.add_argument('--quality', action='store_true', help='train Discriminator_Quality too (train_nele.py:150-152, 362-365): needs --pesq and --visqol - external programs')
+    from . import quality as _q
+    _q.add_cli_arguments(ap)
     a = ap.parse_args(argv)
+    if a.quality and not _q.backends_from_cli(a):
+        ap.error('--quality needs both programs: --pesq MODULE:FUNCTION and --visqol PROGRAM --visqol-model FILE (neither is part of this build)')
     root = a.data.rstrip('/')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

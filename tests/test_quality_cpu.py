@@ -184,3 +184,18 @@ def test_scorer_scores_a_batch_in_memory_like_the_files_would_be(tmp_path):
     np.testing.assert_allclose(raw2, raw, rtol=0, atol=1e-9)
     assert quality.Scorer(use=('pesq',)).raw(refs, degs)[:, 1].tolist() == [0.0, 0.0, 0.0]
     assert sc.raw([], []).shape == (0, 2)
+
+
+def test_the_module_entry_points_take_the_programs_from_the_command_line(tmp_path):
+    import argparse
+    _program(tmp_path)
+    ap = argparse.ArgumentParser()
+    quality.add_cli_arguments(ap)
+    a = ap.parse_args(['--pesq', 'math:hypot', '--visqol', str(tmp_path / 'visqol'), '--visqol-model', str(tmp_path / 'model.txt')])
+    assert quality.backends_from_cli(a)
+    import math
+    assert quality._BACKENDS['pesq'] is math.hypot and callable(quality._BACKENDS['visqol'])
+    quality.clear_backends()
+    assert not quality.backends_from_cli(ap.parse_args([]))
+    with pytest.raises(SystemExit):
+        quality.backends_from_cli(ap.parse_args(['--visqol', 'x']))
