@@ -168,6 +168,20 @@ int nele_stft_band_var(const float* wav, const int* lengths, int B, int L, float
  * band [B][T][64] f32 = compute_band_E(sqrt(psd))**power (may be NULL). */
 int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream);
 int nele_imcra_band_var(const void* spec, const int* frames, int B, int T, float power, float* psd, float* band, void* stream);
+/* The same recursion without a workgroup-wide serial loop (round 6): the frequency smoothing is the only thing that couples bins, and
+ * what it smooths exists ahead of the recursion that consumes it - |Y|^2 for all frames at once, then one THREAD per utterance and bin for
+ * S / S_min / the speech indicator (imcra.py:363-412), then one thread per utterance and bin for S~ / S~_min / the speech-absence prior q and
+ * the tracker (Gamma, xi, G, p, lambda_D: imcra.py:413-484, 543-557, 22-36).  psd (required) and band are BIT-identical to
+ * nele_imcra_band_var's.  workspace: device scratch of nele_imcra_workspace_bytes(B, T) (5 bytes per frame and bin), 16-byte aligned. */
+long long nele_imcra_workspace_bytes(int B, int T);
+/* The noise file's features without its spectrum in memory: nele_stft_pow_var = nele_stft_band_var + pw [B][T][257] float32 =
+ * np.abs(STFT) ** 2 (float32, as audio_util.py:113-117 / imcra.py:523-527 see it; frames behind a short row's end are not written);
+ * nele_imcra_band_pw = nele_imcra_band_ws starting from pw.  Bit-identical psd / band. */
+int nele_stft_pow_var(const float* wav, const int* lengths, int B, int L, float power, void* spec, float* band, float* pw, void* stream);
+int nele_imcra_band_pw(const float* pw, const int* frames, int B, int T, float power, float* psd, float* band, void* workspace,
+                       long long workspace_bytes, void* stream);
+int nele_imcra_band_ws(const void* spec, const int* frames, int B, int T, float power, float* psd, float* band, void* workspace,
+                       long long workspace_bytes, void* stream);
 
 /* audio_util.py:30-50 compute_band_E by itself: magnitude spectrogram mag [N][257] f32 -> band [N][64] f32 (no power law). */
 int nele_compute_band_E(const float* mag, int N, float* band, void* stream);

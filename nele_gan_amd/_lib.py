@@ -50,6 +50,10 @@ _SIGS = {
     'nele_profile_collect_tag': [ctypes.c_char_p, c_void_p, c_int],
     'nele_stft_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     'nele_imcra_band_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'nele_imcra_band_ws': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
+    'nele_imcra_workspace_bytes': [c_int, c_int],
+    'nele_stft_pow_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nele_imcra_band_pw': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
     'nele_gain_istft_var': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     'nele_wav_post_var': [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     'nele_compute_band_E': [c_void_p, c_int, c_void_p, c_void_p],
@@ -112,6 +116,7 @@ for _n in ('nele_plan_slot_bytes', 'nele_gen_param_count', 'nele_gen_workspace_b
     getattr(lib, _n).restype = c_longlong
 lib.nele_disc_workspace_ddin.argtypes = _SIGS['nele_disc_workspace_ddin']
 lib.nele_disc_workspace_ddin.restype = c_void_p
+lib.nele_imcra_workspace_bytes.restype = c_longlong
 lib.nele_wav_post_workspace_doubles.argtypes = [c_int, c_int]
 lib.nele_wav_post_workspace_doubles.restype = c_longlong
 _SIGS['nele_wav_post_workspace_doubles'] = lib.nele_wav_post_workspace_doubles.argtypes

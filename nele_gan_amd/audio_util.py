@@ -8,6 +8,8 @@ arithmetic happens in libnele_hip.so (csrc/features.hip); torch only owns the me
 Device layouts (frame-major): spec [B,T,257] complex64, band [B,T,64] f32,
 psd [B,T,257] f32.  The single-utterance reference-shaped wrappers return mag/phase as [257,T].
 """
+import os
+
 import numpy as np
 import torch
 
@@ -19,6 +21,7 @@ N_FFT = 512
 HOP = 256
 N_BINS = 257
 fs = 16000
+TWO_KERNEL_IMCRA = os.environ.get('NELE_IMCRA_SPLIT', '1') != '0'      # imcra_band through nele_imcra_band_ws (0: the one-kernel form, A/B)
 # audio_util.py:23
 gmtband = [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 28, 30, 32, 34,
            36, 38, 41, 43, 46, 49, 52, 55, 58, 62, 66, 70, 74, 79, 83, 88, 93, 99, 105, 111, 117, 124, 131, 139, 147,
@@ -76,8 +79,42 @@ def imcra_band(spec, power=1.0 / 6, want_psd=False, frames=None):
     # the PSD buffer is always handed over: with it the kernel computes the band feature from the PSD after the serial scan instead of inside it
     psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=spec.device)
     band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=spec.device)
-    call('nele_imcra_band_var', ptr(spec), ptr(_i32(frames, spec.device)), B, T, float(power), ptr(psd), ptr(band), stream())
+    if TWO_KERNEL_IMCRA:
+        # the prior q (per utterance, bins through LDS) and the tracker (per utterance and bin) as two kernels: bit-identical, shorter
+        # (nele_imcra_band_ws); the prior's q / (1 - q) travels through a scratch buffer of the caching allocator
+        nb = int(_lib.lib.nele_imcra_workspace_bytes(B, T))
+        ws = torch.empty((nb,), dtype=torch.uint8, device=spec.device)
+        call('nele_imcra_band_ws', ptr(spec), ptr(_i32(frames, spec.device)), B, T, float(power), ptr(psd), ptr(band), ptr(ws), nb, stream())
+    else:
+        call('nele_imcra_band_var', ptr(spec), ptr(_i32(frames, spec.device)), B, T, float(power), ptr(psd), ptr(band), stream())
     return psd, band
+
+
+def noise_band(wav, power=1.0 / 6, lengths=None, frames=None, want_psd=False):
+    """Sp_and_phase_Noise's band feature (audio_util.py:439-451: compute_band_E(sqrt(NoisePSD(STFT(noise)))) ** power) of a batch of noise
+    signals, wav [B,L] -> band [B,T,64] (and the PSD [B,T,257] with ``want_psd``): IMCRA needs |STFT|^2 only, so the STFT kernel writes
+    that (float32, as numpy squares np.abs) and the spectrum never exists in memory (nele_stft_pow_var + nele_imcra_band_pw).  The same
+    numbers, bit for bit, as imcra_band(stft_band(wav)) - which stays for callers that want the spectrum."""
+    if not TWO_KERNEL_IMCRA:
+        spec, _ = stft_band(wav, power, want_band=False, lengths=lengths)
+        psd, band = imcra_band(spec, power, want_psd=True, frames=frames if frames is not None else frames_of(_i32(lengths, spec.device)))
+        return (psd, band) if want_psd else band
+    wav = _dev(wav).float()
+    if wav.dim() != 2:
+        raise ValueError("noise_band: wav must be [B, L]")
+    B, L = wav.shape
+    T = n_frames(L)
+    lengths = _i32(lengths, wav.device)
+    if frames is None:
+        frames = frames_of(lengths)
+    nb = int(_lib.lib.nele_imcra_workspace_bytes(B, T))
+    pw = torch.empty((B, T, N_BINS), dtype=torch.float32, device=wav.device)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=wav.device)
+    psd = torch.empty((B, T, N_BINS), dtype=torch.float32, device=wav.device)
+    band = torch.empty((B, T, NB_BANDS), dtype=torch.float32, device=wav.device)
+    call('nele_stft_pow_var', ptr(wav), ptr(lengths), B, L, float(power), None, None, ptr(pw), stream())
+    call('nele_imcra_band_pw', ptr(pw), ptr(_i32(frames, wav.device)), B, T, float(power), ptr(psd), ptr(band), ptr(ws), nb, stream())
+    return (psd, band) if want_psd else band
 
 
 def gain_istft(alpha2, spec, rms_target=0.0, pcm16=False, frames=None):

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void stft_band_kernel(const float* __restrict_
 // grid (ceil(ceil(T / 2) / (4 STW_NP)), B), block 256.
 #define STW_NP 2
 __global__ __launch_bounds__(256) void stft_band_wave_kernel(const float* __restrict__ wav, int L, int T, float power,
-                                                             float2* __restrict__ spec, float* __restrict__ band, const int* __restrict__ lens) {
+                                                             float2* __restrict__ spec, float* __restrict__ band, const int* __restrict__ lens, float* __restrict__ pw) {
     __shared__ double2 tw[256];
     __shared__ double hw[NELE_NFFT];
     __shared__ __attribute__((aligned(16))) double2 xs[4][FFTW_SLOTS];
@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256) void stft_band_wave_kernel(const float* __rest
                 const float m1 = np_cabsf(Bv.x, Bv.y);
                 p0[q] = m0 * m0;
                 p1[q] = m1 * m1;
+                if (pw) {                                   // |X|^2 as numpy squares np.abs(complex64): what IMCRA starts from (nele_imcra_band_pw)
+                    pw[((size_t)b * T + t0) * NELE_NBINS + k] = p0[q];
+                    if (has1) pw[((size_t)b * T + t1) * NELE_NBINS + k] = p1[q];
+                }
             }
         }
         if (band) {
@@ -390,6 +394,223 @@ __global__ __launch_bounds__(IMCRA_THREADS) void imcra_band_kernel(const float2*
         }
         // LDS hazards without those barriers: |Y|^2 is double-buffered by frame parity; s.a / s.b of frame l are read after frame l's
         // second barrier and rewritten after frame l+1's first one, which every reader has to reach first
+    }
+}
+
+// ---- IMCRA without a workgroup-wide recursion (round 6).  The one-kernel form above paces every frame through two barriers and four
+// dependent levels of float64 divisions (3 000 of its 3 800 cycles per frame - measured by splitting it: docs/REJECTED.md), because the
+// neighbour exchange of the frequency smoothing sits inside the serial loop.  But the smoothing is the ONLY thing that couples bins, and
+// what it smooths is available ahead of the recursion that consumes it:
+//   imcra_pow_kernel    |Y|^2 (float32, as numpy computes it) for every frame and bin at once;
+//   imcra_ind_kernel    one THREAD per utterance and bin, serial over frames, no LDS: S_f = smooth(|Y|^2) from the three neighbouring
+//                       values, S, S_min and its minima store, the speech indicator I (imcra.py:363-412) -> one byte per frame and bin;
+//   imcra_track_kernel  one thread per utterance and bin: S again (one multiply-add: cheaper than storing it), S~_f = smooth(I |Y|^2) /
+//                       smooth(I) from the neighbours' indicators, S~, S~_min + store, the speech-absence prior q (:413-429, 452-484) and the
+//                       tracker proper (Gamma, xi, G, p, lambda_D: :543-557, 22-36, 430-450) -> PSD.
+// The loop-carried chains left are S (a multiply-add), the minima, and the tracker's lambda_D -> Gamma -> nu -> exp -> p -> lambda_D; every
+// other division hangs off them and pipelines across the eight frames a thread keeps in flight.  257 bins pack into waves across
+// utterances (the one-kernel form spends a fifth of its issue slots on a wave with one live lane).  Same operations on the same operands
+// in the same order: bit-identical PSDs (tests/test_features_gpu.py).
+__global__ __launch_bounds__(256) void imcra_pow_kernel(const float2* __restrict__ spec, size_t n, float* __restrict__ y2f) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float2 y = spec[i];
+        const float h = np_cabsf(y.x, y.y);                                   // np.abs(complex64)
+        y2f[i] = h * h;                                                       // **2 on a float32 array
+    }
+}
+
+#define IMT_PF 8
+struct ImcraBin {                                   // what a thread of the two serial kernels knows about its bin
+    const float* y2;                                // |Y|^2 row pointer of (utterance, bin)
+    int dl, dr;                                     // offsets of the left / right neighbour (0 at the edges: the edge bins stand in for themselves)
+    double w0, w1, w2;                              // imcra.py:270-280 (sym_hanning(3), row-normalised)
+};
+__device__ __forceinline__ ImcraBin imcra_bin(const float* y2f, int b, int k, int T) {
+    ImcraBin q;
+    q.y2 = y2f + (size_t)b * T * NELE_NBINS + k;
+    q.dl = (k == 0) ? 0 : -1;
+    q.dr = (k == NELE_NBINS - 1) ? 0 : 1;
+    q.w0 = 0.25; q.w1 = 0.5; q.w2 = 0.25;
+    if (k == 0) { q.w0 = 0.0; q.w1 = 1.0 / 1.5; q.w2 = 0.5 / 1.5; }
+    if (k == NELE_NBINS - 1) { q.w0 = 0.5 / 1.5; q.w1 = 1.0 / 1.5; q.w2 = 0.0; }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void imcra_ind_kernel(const float* __restrict__ y2f, int B, int T, unsigned char* __restrict__ ind,
+                                                        const int* __restrict__ tlens) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= B * NELE_NBINS) return;
+    const int b = gid / NELE_NBINS, k = gid - b * NELE_NBINS;
+    const ImcraBin bn = imcra_bin(y2f, b, k, T);
+    unsigned char* Iout = ind + (size_t)b * T * NELE_NBINS + k;
+    const double alpha_s = 0.9, Bmin = 3.2, Gamma0 = 4.6, zeta0 = 1.67;
+    const double one_m_as = 1.0 - alpha_s;
+    const int Tb = tlens ? min(tlens[b], T) : T;
+    double S = 0, Smin = 0, Smin_sw = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = 0, u = 0;
+    float fa[IMT_PF][3], fb[IMT_PF][3];
+    auto fetch = [&](int l0, float (&f)[IMT_PF][3]) {
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d) {
+            const int l = l0 + d;
+            const float* r = bn.y2 + (size_t)l * NELE_NBINS;
+            f[d][0] = (l < Tb) ? r[bn.dl] : 0.f;
+            f[d][1] = (l < Tb) ? r[0] : 0.f;
+            f[d][2] = (l < Tb) ? r[bn.dr] : 0.f;
+        }
+    };
+    auto step = [&](int l, const float (&f)[3]) {
+        const double Y2 = (double)f[1];
+        const double Sf = (bn.w0 * (double)f[0] + bn.w1 * (double)f[1]) + bn.w2 * (double)f[2];
+        if (l == 0) { S = Sf; Smin = Sf; Smin_sw = Sf; }
+        S = alpha_s * S + one_m_as * Sf;
+        Smin = fmin(Smin, S);
+        Smin_sw = fmin(Smin_sw, S);
+        if (l >= 15) {
+            const double Gamma_min = Y2 / (Bmin * Smin);
+            const double zeta = S / (Bmin * Smin);
+            Iout[(size_t)l * NELE_NBINS] = (Gamma_min < Gamma0 && zeta < zeta0) ? 1 : 0;
+            if (j + 1 == 15) {                                   // minimum tracking (imcra.py:452-481); np.roll of the U = 8 store == ring buffer
+                const int slot = u & 7;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[i] = (i == slot) ? Smin_sw : st[i];
+                const int n = (u < 8) ? (u + 1) : 8;
+                double m = st[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) m = (i < n) ? fmin(m, st[i]) : m;
+                Smin = m;
+                Smin_sw = S;
+            }
+            if (++j == 15) { j = 0; ++u; }
+        }
+    };
+    fetch(0, fa);
+    for (int l0 = 0; l0 < Tb; l0 += 2 * IMT_PF) {
+        fetch(l0 + IMT_PF, fb);
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d)
+            if (l0 + d < Tb) step(l0 + d, fa[d]);
+        fetch(l0 + 2 * IMT_PF, fa);
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d)
+            if (l0 + IMT_PF + d < Tb) step(l0 + IMT_PF + d, fb[d]);
+    }
+}
+
+__global__ __launch_bounds__(256) void imcra_track_kernel(const float* __restrict__ y2f, const unsigned char* __restrict__ ind, int B, int T,
+                                                          float* __restrict__ psd, const int* __restrict__ tlens) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= B * NELE_NBINS) return;
+    const int b = gid / NELE_NBINS, k = gid - b * NELE_NBINS;
+    const ImcraBin bn = imcra_bin(y2f, b, k, T);
+    const unsigned char* Iin = ind + (size_t)b * T * NELE_NBINS + k;
+    float* P = psd + (size_t)b * T * NELE_NBINS + k;
+    const double alpha_s = 0.9, alpha_d = 0.85, Bmin = 3.2, Gamma1 = 3.0, zeta0 = 1.67, beta = 1.47;
+    const double alpha_dd = 0.92, xi_min = pow(10.0, -25.0 / 20.0), p_up = 0.9;
+    const double one_m_as = 1.0 - alpha_s, one_m_ad = 1.0 - alpha_d, one_m_add = 1.0 - alpha_dd;
+    double S = 0, tS = 0, tSmin = 0, tSmin_sw = 0, tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double ovL = 0, Lam64 = 1e-6, G = 1.0, Gamma = 1.0;
+    float Lam32 = 0.f;
+    int j = 0, u = 0;
+    const int Tb = tlens ? min(tlens[b], T) : T;
+    for (int l = Tb; l < T; ++l) P[(size_t)l * NELE_NBINS] = 0.f;        // behind the end of a short row: zeros
+    float fa[IMT_PF][3], fb[IMT_PF][3];
+    unsigned char ia[IMT_PF][3], ib[IMT_PF][3];
+    auto fetch = [&](int l0, float (&f)[IMT_PF][3], unsigned char (&ii)[IMT_PF][3]) {
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d) {
+            const int l = l0 + d;
+            const float* r = bn.y2 + (size_t)l * NELE_NBINS;
+            const unsigned char* q = Iin + (size_t)l * NELE_NBINS;
+            const bool in = l < Tb, in15 = in && l >= 15;
+            f[d][0] = in ? r[bn.dl] : 0.f;
+            f[d][1] = in ? r[0] : 0.f;
+            f[d][2] = in ? r[bn.dr] : 0.f;
+            ii[d][0] = in15 ? q[bn.dl] : (unsigned char)0;
+            ii[d][1] = in15 ? q[0] : (unsigned char)0;
+            ii[d][2] = in15 ? q[bn.dr] : (unsigned char)0;
+        }
+    };
+    auto step = [&](int l, const float (&f)[3], const unsigned char (&ii)[3]) {
+        const float Y2f = f[1];
+        const double Y2 = (double)Y2f;
+        float outv = 0.f;
+        const double Sf = (bn.w0 * (double)f[0] + bn.w1 * (double)f[1]) + bn.w2 * (double)f[2];
+        // ---- decision-directed a-priori SNR (imcra.py:543-557)
+        const double xi_G = (l == 0) ? 1.0 : (G * G) * Gamma;
+        double term;
+        if (l == 0 || l >= 16) {
+            Gamma = Y2 / Lam64;
+            double xi_ML = Gamma - 1.0;
+            if (xi_ML < 1e-6) xi_ML = 1e-6;
+            term = one_m_add * xi_ML;
+        } else {  // Lambda_D (hence Gamma, xi_ML) is a float32 array for frames 1..15
+            const float Gf = Y2f / Lam32;
+            float xf = Gf - 1.0f;
+            if (xf < (float)1e-6) xf = (float)1e-6;
+            term = (double)((float)one_m_add * xf);
+            Gamma = (double)Gf;
+        }
+        double xi = alpha_dd * xi_G + term;
+        if (xi < xi_min) xi = xi_min;
+        G = xi / (1.0 + xi);
+        if (l == 0) {  // init_params (imcra.py:338-361)
+            S = Sf; tS = Sf; tSmin = Sf; tSmin_sw = Sf;
+            ovL = Y2;
+            Lam32 = Y2f;
+        }
+        S = alpha_s * S + one_m_as * Sf;
+        if (l < 15) {
+            Lam32 = (float)alpha_d * Lam32 + (float)one_m_ad * Y2f;
+            outv = Lam32;
+        } else {
+            const double I0 = (double)ii[0], I1 = (double)ii[1], I2 = (double)ii[2];
+            const double a0 = I0 * (double)f[0], a1 = I1 * (double)f[1], a2 = I2 * (double)f[2];
+            const double norm = (bn.w0 * I0 + bn.w1 * I1) + bn.w2 * I2;
+            double tSf = (bn.w0 * a0 + bn.w1 * a1) + bn.w2 * a2;
+            if (norm > 0.0) tSf = tSf / norm;
+            tS = alpha_s * tS + one_m_as * tSf;
+            tSmin = fmin(tSmin, tS);
+            tSmin_sw = fmin(tSmin_sw, tS);
+            const double tG = Y2 / (Bmin * tSmin);
+            const double tz = S / (Bmin * tSmin);
+            double q = 0.0;
+            if (tG <= 1.0 && tz < zeta0) q = 1.0;
+            else if (1.0 < tG && tG < Gamma1 && tz < zeta0) q = (Gamma1 - tG) / (Gamma1 - 1.0);
+            // post_speech_prob (imcra.py:22-36)
+            const double nu = Gamma * xi / (1.0 + xi);
+            double p = 0.0;
+            if (q < 1.0) p = 1.0 / (1.0 + (q / (1.0 - q)) * (1.0 + xi) * exp(-nu));
+            if (p > p_up) p = p_up;
+            const double tad = alpha_d + one_m_ad * p;
+            ovL = tad * ovL + (1.0 - tad) * Y2;
+            Lam64 = beta * ovL;
+            outv = (float)Lam64;
+            if (j + 1 == 15) {                                   // minimum tracking (imcra.py:452-481)
+                const int slot = u & 7;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tst[i] = (i == slot) ? tSmin_sw : tst[i];
+                const int n = (u < 8) ? (u + 1) : 8;
+                double tm = tst[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) tm = (i < n) ? fmin(tm, tst[i]) : tm;
+                tSmin = tm;
+                tSmin_sw = tS;
+            }
+            if (++j == 15) { j = 0; ++u; }
+        }
+        P[(size_t)l * NELE_NBINS] = outv;
+    };
+    fetch(0, fa, ia);
+    for (int l0 = 0; l0 < Tb; l0 += 2 * IMT_PF) {
+        fetch(l0 + IMT_PF, fb, ib);
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d)
+            if (l0 + d < Tb) step(l0 + d, fa[d], ia[d]);
+        fetch(l0 + 2 * IMT_PF, fa, ia);
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d)
+            if (l0 + IMT_PF + d < Tb) step(l0 + IMT_PF + d, fb[d], ib[d]);
     }
 }
 
@@ -626,12 +847,24 @@ extern "C" int nele_stft_band_var(const float* wav, const int* lengths, int B, i
     const int wave_on = NELE_SWITCH_INT("NELE_STFT_WAVE", 1);                                // NELE_STFT_WAVE=0: the workgroup-per-frame-pair kernels (A/B diagnostic)
     if (wave_on) {
         dim3 grid(((T + 1) / 2 + 4 * STW_NP - 1) / (4 * STW_NP), B);
-        hipLaunchKernelGGL(stft_band_wave_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);
+        hipLaunchKernelGGL(stft_band_wave_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths, (float*)nullptr);
     } else {
         NELE_AB_ONLY(dim3 grid((T + 1) / 2, B);
                      hipLaunchKernelGGL(stft_band_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths);)
     }
     NELE_CHECK_LAUNCH("nele_stft_band");
+    return NELE_OK;
+}
+// The noise file's side of the features (audio_util.py:439-456): IMCRA consumes |STFT|^2 only, so the spectrum need not exist in memory -
+// pw [B][T][257] float32 = np.abs(STFT) ** 2 as numpy computes it in float32 (frames behind a short row's end are NOT written; nothing
+// reads them), the input of nele_imcra_band_pw.  spec / band as in nele_stft_band_var (either may be NULL).
+extern "C" int nele_stft_pow_var(const float* wav, const int* lengths, int B, int L, float power, void* spec, float* band, float* pw, void* stream) {
+    NELE_CHECK_ARG(wav && B > 0 && pw, "nele_stft_pow: null wav / pw or B <= 0");
+    NELE_CHECK_ARG(L > NELE_HOP, "nele_stft_pow: L=%d must exceed 256 (reflect padding)", L);
+    const int T = 1 + L / NELE_HOP;
+    dim3 grid(((T + 1) / 2 + 4 * STW_NP - 1) / (4 * STW_NP), B);
+    hipLaunchKernelGGL(stft_band_wave_kernel, grid, dim3(256), 0, as_stream(stream), wav, L, T, power, (float2*)spec, band, lengths, pw);
+    NELE_CHECK_LAUNCH("nele_stft_pow");
     return NELE_OK;
 }
 extern "C" int nele_stft_band(const float* wav, int B, int L, float power, void* spec, float* band, void* stream) {
@@ -654,6 +887,43 @@ extern "C" int nele_imcra_band_var(const void* spec, const int* frames, int B, i
         hipLaunchKernelGGL(band_pow_kernel, dim3((unsigned)((nb + 255) / 256 < 2048 ? (nb + 255) / 256 : 2048)), dim3(256), 0, as_stream(stream), band, nb, power);
     }
     NELE_CHECK_LAUNCH("nele_imcra_band");
+    return NELE_OK;
+}
+extern "C" long long nele_imcra_workspace_bytes(int B, int T) {
+    if (B <= 0 || T <= 0) return -1;
+    return ((long long)B * T * NELE_NBINS * 5 + 255) / 256 * 256;             // |Y|^2 (float32) + the speech indicator (one byte)
+}
+// The same result as nele_imcra_band_var(spec, frames, .., psd, band) - bit for bit - without a workgroup-wide recursion: imcra_pow_kernel,
+// imcra_ind_kernel, imcra_track_kernel (see there), |Y|^2 and the indicator in a caller-provided workspace of nele_imcra_workspace_bytes(B, T).
+extern "C" int nele_imcra_band_ws(const void* spec, const int* frames, int B, int T, float power, float* psd, float* band, void* ws,
+                                  long long ws_bytes, void* stream) {
+    NELE_CHECK_ARG(spec && psd && B > 0 && T > 0, "nele_imcra_band_ws: bad arguments (the PSD buffer is required)");
+    NELE_CHECK_ARG(ws && ws_bytes >= nele_imcra_workspace_bytes(B, T) && ((size_t)ws % 16) == 0, "nele_imcra_band_ws: workspace of %lld bytes needed",
+                   nele_imcra_workspace_bytes(B, T));
+    const size_t n = (size_t)B * T * NELE_NBINS;
+    float* y2f = (float*)ws;
+    unsigned char* ind = (unsigned char*)ws + 4 * n;
+    const unsigned nb = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(imcra_pow_kernel, dim3(nb), dim3(256), 0, as_stream(stream), (const float2*)spec, n, y2f);
+    const dim3 grid((B * NELE_NBINS + 255) / 256);
+    hipLaunchKernelGGL(imcra_ind_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)y2f, B, T, ind, frames);
+    hipLaunchKernelGGL(imcra_track_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)y2f, (const unsigned char*)ind, B, T, psd, frames);
+    if (band) hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
+    NELE_CHECK_LAUNCH("nele_imcra_band_ws");
+    return NELE_OK;
+}
+// ... and from |Y|^2 itself (nele_stft_pow_var's pw): the first kernel and the spectrum's round trip through memory drop out.
+// workspace: nele_imcra_workspace_bytes(B, T) as above (only its indicator part is used).
+extern "C" int nele_imcra_band_pw(const float* pw, const int* frames, int B, int T, float power, float* psd, float* band, void* ws,
+                                  long long ws_bytes, void* stream) {
+    NELE_CHECK_ARG(pw && psd && B > 0 && T > 0, "nele_imcra_band_pw: bad arguments (the PSD buffer is required)");
+    NELE_CHECK_ARG(ws && ws_bytes >= nele_imcra_workspace_bytes(B, T), "nele_imcra_band_pw: workspace of %lld bytes needed", nele_imcra_workspace_bytes(B, T));
+    unsigned char* ind = (unsigned char*)ws;
+    const dim3 grid((B * NELE_NBINS + 255) / 256);
+    hipLaunchKernelGGL(imcra_ind_kernel, grid, dim3(256), 0, as_stream(stream), pw, B, T, ind, frames);
+    hipLaunchKernelGGL(imcra_track_kernel, grid, dim3(256), 0, as_stream(stream), pw, (const unsigned char*)ind, B, T, psd, frames);
+    if (band) hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
+    NELE_CHECK_LAUNCH("nele_imcra_band_pw");
     return NELE_OK;
 }
 extern "C" int nele_imcra_band(const void* spec, int B, int T, float power, float* psd, float* band, void* stream) {

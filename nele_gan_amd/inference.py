@@ -49,8 +49,7 @@ class Enhancer:
         lengths = au._i32(lengths, self.device)
         frames = au.frames_of(lengths)
         clean_spec, clean_band = au.stft_band(clean_wav, p_power, lengths=lengths)
-        noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False, lengths=lengths)
-        _, noise_band = au.imcra_band(noise_spec, p_power, frames=frames)
+        noise_band = au.noise_band(noise_wav, p_power, lengths=lengths, frames=frames)
         mask = self.G(clean_band, noise_band)
         alpha2 = M.normed_alpha2(mask, clean_band, inv_p, frames=frames)
         return au.gain_istft(alpha2, clean_spec, rms_target=0.030, pcm16=pcm16, frames=frames)

@@ -273,8 +273,7 @@ class GanTrainer:
             clean_spec, clean_band = au.stft_band(clean_wav, p_power, lengths=lengths)
             evc = torch.cuda.Event()
             evc.record(fs_)
-        noise_spec, _ = au.stft_band(noise_wav, p_power, want_band=False, lengths=lengths)
-        _, noise_band = au.imcra_band(noise_spec, p_power, frames=frames)
+        noise_band = au.noise_band(noise_wav, p_power, lengths=lengths, frames=frames)
         main.wait_event(evc)
         clean_spec.record_stream(main)
         clean_band.record_stream(main)

@@ -261,3 +261,62 @@ def test_band_power_law_is_the_nearest_float32_to_the_float64_power():
     _, nb1 = au.imcra_band(spec, power=1.0, want_psd=True)
     w = np.power(nb1.cpu().numpy().astype(np.float64), np.float64(p32)).astype(np.float32)
     assert np.mean(nb.cpu().numpy() != w) < 5e-6
+
+
+@pytest.mark.parametrize('B,L,ragged', [(3, 40000, False), (5, 64000, True), (2, 128000, True), (1, 5000, False), (4, 3800, True)])
+def test_two_kernel_imcra_is_bit_identical_to_the_one_kernel_form(B, L, ragged):
+    """nele_imcra_band_ws (|Y|^2 at once, then the indicator and the prior + tracker as one thread per utterance and bin)
+    against nele_imcra_band_var (everything in one serial kernel): the same PSD and band feature, bit for bit - frames 0..14 (float32
+    lambda_D), the hand-over at frames 15 / 16, minima-store rotations, short rows of a padded batch."""
+    import ctypes
+    from nele_gan_amd import _lib
+    from nele_gan_amd import audio_util as au
+    from nele_gan_amd import synth
+    c, v = synth.batch(B, L, start=70)
+    x = torch.from_numpy(v + 0.3 * c).cuda()
+    T = 1 + L // 256
+    lens = None
+    if ragged:
+        lens = torch.tensor([L - 777 * k for k in range(B)], dtype=torch.int32)
+    spec, _ = au.stft_band(x, want_band=False, lengths=lens)
+    frames = None if lens is None else (1 + lens // 256).to(torch.int32).cuda()
+    out = []
+    for two in (False, True):
+        psd = torch.full((B, T, 257), -1.0, dtype=torch.float32, device='cuda')
+        band = torch.full((B, T, 64), -1.0, dtype=torch.float32, device='cuda')
+        if two:
+            nb = int(_lib.lib.nele_imcra_workspace_bytes(B, T))
+            assert nb >= B * T * 257 * 5
+            ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device='cuda')
+            _lib.call('nele_imcra_band_ws', _lib.ptr(spec), _lib.ptr(frames), B, T, 1.0 / 6, _lib.ptr(psd), _lib.ptr(band), _lib.ptr(ws), nb, _lib.stream())
+            with pytest.raises(Exception):
+                _lib.call('nele_imcra_band_ws', _lib.ptr(spec), _lib.ptr(frames), B, T, 1.0 / 6, _lib.ptr(psd), _lib.ptr(band), _lib.ptr(ws), nb - 256, _lib.stream())
+        else:
+            _lib.call('nele_imcra_band_var', _lib.ptr(spec), _lib.ptr(frames), B, T, 1.0 / 6, _lib.ptr(psd), _lib.ptr(band), _lib.stream())
+        torch.cuda.synchronize()
+        out.append((psd.cpu().numpy(), band.cpu().numpy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.isfinite(out[1][0]).all() and (out[1][0] >= 0).all()
+    if T > 40:
+        assert (out[1][0][0, 20:40] > 0).all()
+
+
+def test_noise_band_from_the_power_spectrum_equals_the_route_through_the_spectrum():
+    """audio_util.noise_band (nele_stft_pow_var: the STFT kernel writes |Y|^2 itself; nele_imcra_band_pw: IMCRA from it) against
+    imcra_band(stft_band(noise)) through the ONE-kernel recursion: PSD and band feature bit for bit, short rows of a padded batch included."""
+    from nele_gan_amd import _lib
+    from nele_gan_amd import audio_util as au
+    from nele_gan_amd import synth
+    B, L = 6, 50000
+    c, v = synth.batch(B, L, start=90)
+    x = torch.from_numpy(v).cuda()
+    for lens in (None, torch.tensor([50000, 49000, 31000, 50000, 4100, 26000], dtype=torch.int32)):
+        T = 1 + L // 256
+        spec, _ = au.stft_band(x, want_band=False, lengths=lens)
+        frames = au.frames_of(au._i32(lens, x.device))
+        psd0 = torch.empty((B, T, 257), dtype=torch.float32, device='cuda')
+        band0 = torch.empty((B, T, 64), dtype=torch.float32, device='cuda')
+        _lib.call('nele_imcra_band_var', _lib.ptr(spec), _lib.ptr(frames), B, T, 1.0 / 6, _lib.ptr(psd0), _lib.ptr(band0), _lib.stream())
+        psd1, band1 = au.noise_band(x, lengths=lens, want_psd=True)
+        assert torch.equal(psd0, psd1) and torch.equal(band0, band1)
+        assert torch.equal(au.noise_band(x, lengths=lens), band0)
