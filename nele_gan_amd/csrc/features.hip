@@ -497,45 +497,98 @@ __global__ __launch_bounds__(256) void imcra_ind_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void imcra_track_kernel(const float* __restrict__ y2f, const unsigned char* __restrict__ ind, int B, int T,
+// Two waves per 64 bins: wave 0 runs the speech-absence prior (S, S~ from the neighbours' indicators, S~_min + store, q -> r = q / (1 - q):
+// five divisions that hang off short recurrences - issue-bound), wave 1 the tracker (lambda_D -> Gamma -> nu -> exp -> p -> lambda_D: three
+// dependent divisions and an exponential per frame - latency-bound), one batch of IMT_PF frames behind, r through LDS.  In one instruction
+// stream the compiler does not interleave the two across frames: a wave that did both took their SUM, 2 500 cycles per frame (0.52 ms at
+// T = 501); side by side they take the longer one.
+__global__ __launch_bounds__(128) void imcra_track_kernel(const float* __restrict__ y2f, const unsigned char* __restrict__ ind, int B, int T,
                                                           float* __restrict__ psd, const int* __restrict__ tlens) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= B * NELE_NBINS) return;
-    const int b = gid / NELE_NBINS, k = gid - b * NELE_NBINS;
+    __shared__ double rq[2][IMT_PF][64];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;              // 0: prior, 1: tracker (wave-uniform)
+    const int gid = blockIdx.x * 64 + lane;
+    const bool live = gid < B * NELE_NBINS;
+    const int b = live ? gid / NELE_NBINS : 0, k = live ? gid - b * NELE_NBINS : 0;
     const ImcraBin bn = imcra_bin(y2f, b, k, T);
     const unsigned char* Iin = ind + (size_t)b * T * NELE_NBINS + k;
     float* P = psd + (size_t)b * T * NELE_NBINS + k;
     const double alpha_s = 0.9, alpha_d = 0.85, Bmin = 3.2, Gamma1 = 3.0, zeta0 = 1.67, beta = 1.47;
     const double alpha_dd = 0.92, xi_min = pow(10.0, -25.0 / 20.0), p_up = 0.9;
     const double one_m_as = 1.0 - alpha_s, one_m_ad = 1.0 - alpha_d, one_m_add = 1.0 - alpha_dd;
+    const int Tb = live ? (tlens ? min(tlens[b], T) : T) : 0;
+    int Tmax = Tb;                                                            // the lanes of a wave may belong to two utterances
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+    const int nbatch = (Tmax + IMT_PF - 1) / IMT_PF;
+    if (role == 1 && live)
+        for (int l = Tb; l < T; ++l) P[(size_t)l * NELE_NBINS] = 0.f;        // behind the end of a short row: zeros
+    // ---- prior state (wave 0)
     double S = 0, tS = 0, tSmin = 0, tSmin_sw = 0, tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = 0, u = 0;
+    float fa[IMT_PF][3];
+    unsigned char ia[IMT_PF][3];
+    // ---- tracker state (wave 1)
     double ovL = 0, Lam64 = 1e-6, G = 1.0, Gamma = 1.0;
     float Lam32 = 0.f;
-    int j = 0, u = 0;
-    const int Tb = tlens ? min(tlens[b], T) : T;
-    for (int l = Tb; l < T; ++l) P[(size_t)l * NELE_NBINS] = 0.f;        // behind the end of a short row: zeros
-    float fa[IMT_PF][3], fb[IMT_PF][3];
-    unsigned char ia[IMT_PF][3], ib[IMT_PF][3];
-    auto fetch = [&](int l0, float (&f)[IMT_PF][3], unsigned char (&ii)[IMT_PF][3]) {
+    float ya[IMT_PF];
+    auto fetch_prior = [&](int l0) {
 #pragma unroll
         for (int d = 0; d < IMT_PF; ++d) {
             const int l = l0 + d;
             const float* r = bn.y2 + (size_t)l * NELE_NBINS;
             const unsigned char* q = Iin + (size_t)l * NELE_NBINS;
             const bool in = l < Tb, in15 = in && l >= 15;
-            f[d][0] = in ? r[bn.dl] : 0.f;
-            f[d][1] = in ? r[0] : 0.f;
-            f[d][2] = in ? r[bn.dr] : 0.f;
-            ii[d][0] = in15 ? q[bn.dl] : (unsigned char)0;
-            ii[d][1] = in15 ? q[0] : (unsigned char)0;
-            ii[d][2] = in15 ? q[bn.dr] : (unsigned char)0;
+            fa[d][0] = in ? r[bn.dl] : 0.f;
+            fa[d][1] = in ? r[0] : 0.f;
+            fa[d][2] = in ? r[bn.dr] : 0.f;
+            ia[d][0] = in15 ? q[bn.dl] : (unsigned char)0;
+            ia[d][1] = in15 ? q[0] : (unsigned char)0;
+            ia[d][2] = in15 ? q[bn.dr] : (unsigned char)0;
         }
     };
-    auto step = [&](int l, const float (&f)[3], const unsigned char (&ii)[3]) {
-        const float Y2f = f[1];
+    auto fetch_track = [&](int l0) {
+#pragma unroll
+        for (int d = 0; d < IMT_PF; ++d) ya[d] = (l0 + d < Tb) ? bn.y2[(size_t)(l0 + d) * NELE_NBINS] : 0.f;
+    };
+    auto prior = [&](int l, const float (&f)[3], const unsigned char (&ii)[3]) -> double {
+        const double Y2 = (double)f[1];
+        const double Sf = (bn.w0 * (double)f[0] + bn.w1 * (double)f[1]) + bn.w2 * (double)f[2];
+        if (l == 0) { S = Sf; tS = Sf; tSmin = Sf; tSmin_sw = Sf; }          // init_params (imcra.py:338-361)
+        S = alpha_s * S + one_m_as * Sf;
+        double r = -1.0;
+        if (l >= 15) {
+            const double I0 = (double)ii[0], I1 = (double)ii[1], I2 = (double)ii[2];
+            const double a0 = I0 * (double)f[0], a1 = I1 * (double)f[1], a2 = I2 * (double)f[2];
+            const double norm = (bn.w0 * I0 + bn.w1 * I1) + bn.w2 * I2;
+            double tSf = (bn.w0 * a0 + bn.w1 * a1) + bn.w2 * a2;
+            if (norm > 0.0) tSf = tSf / norm;
+            tS = alpha_s * tS + one_m_as * tSf;
+            tSmin = fmin(tSmin, tS);
+            tSmin_sw = fmin(tSmin_sw, tS);
+            const double tG = Y2 / (Bmin * tSmin);
+            const double tz = S / (Bmin * tSmin);
+            double q = 0.0;
+            if (tG <= 1.0 && tz < zeta0) q = 1.0;
+            else if (1.0 < tG && tG < Gamma1 && tz < zeta0) q = (Gamma1 - tG) / (Gamma1 - 1.0);
+            if (q < 1.0) r = q / (1.0 - q);                                  // post_speech_prob's q / (1 - q) (imcra.py:22-36); -1: p = 0
+            if (j + 1 == 15) {                                               // minimum tracking (imcra.py:452-481)
+                const int slot = u & 7;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tst[i] = (i == slot) ? tSmin_sw : tst[i];
+                const int n = (u < 8) ? (u + 1) : 8;
+                double tm = tst[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) tm = (i < n) ? fmin(tm, tst[i]) : tm;
+                tSmin = tm;
+                tSmin_sw = tS;
+            }
+            if (++j == 15) { j = 0; ++u; }
+        }
+        return r;
+    };
+    auto track = [&](int l, const float Y2f, const double r) {
         const double Y2 = (double)Y2f;
         float outv = 0.f;
-        const double Sf = (bn.w0 * (double)f[0] + bn.w1 * (double)f[1]) + bn.w2 * (double)f[2];
         // ---- decision-directed a-priori SNR (imcra.py:543-557)
         const double xi_G = (l == 0) ? 1.0 : (G * G) * Gamma;
         double term;
@@ -554,63 +607,52 @@ __global__ __launch_bounds__(256) void imcra_track_kernel(const float* __restric
         double xi = alpha_dd * xi_G + term;
         if (xi < xi_min) xi = xi_min;
         G = xi / (1.0 + xi);
-        if (l == 0) {  // init_params (imcra.py:338-361)
-            S = Sf; tS = Sf; tSmin = Sf; tSmin_sw = Sf;
-            ovL = Y2;
-            Lam32 = Y2f;
-        }
-        S = alpha_s * S + one_m_as * Sf;
+        if (l == 0) { ovL = Y2; Lam32 = Y2f; }
         if (l < 15) {
             Lam32 = (float)alpha_d * Lam32 + (float)one_m_ad * Y2f;
             outv = Lam32;
         } else {
-            const double I0 = (double)ii[0], I1 = (double)ii[1], I2 = (double)ii[2];
-            const double a0 = I0 * (double)f[0], a1 = I1 * (double)f[1], a2 = I2 * (double)f[2];
-            const double norm = (bn.w0 * I0 + bn.w1 * I1) + bn.w2 * I2;
-            double tSf = (bn.w0 * a0 + bn.w1 * a1) + bn.w2 * a2;
-            if (norm > 0.0) tSf = tSf / norm;
-            tS = alpha_s * tS + one_m_as * tSf;
-            tSmin = fmin(tSmin, tS);
-            tSmin_sw = fmin(tSmin_sw, tS);
-            const double tG = Y2 / (Bmin * tSmin);
-            const double tz = S / (Bmin * tSmin);
-            double q = 0.0;
-            if (tG <= 1.0 && tz < zeta0) q = 1.0;
-            else if (1.0 < tG && tG < Gamma1 && tz < zeta0) q = (Gamma1 - tG) / (Gamma1 - 1.0);
-            // post_speech_prob (imcra.py:22-36)
             const double nu = Gamma * xi / (1.0 + xi);
             double p = 0.0;
-            if (q < 1.0) p = 1.0 / (1.0 + (q / (1.0 - q)) * (1.0 + xi) * exp(-nu));
+            if (r >= 0.0) p = 1.0 / (1.0 + r * (1.0 + xi) * exp(-nu));
             if (p > p_up) p = p_up;
             const double tad = alpha_d + one_m_ad * p;
             ovL = tad * ovL + (1.0 - tad) * Y2;
             Lam64 = beta * ovL;
             outv = (float)Lam64;
-            if (j + 1 == 15) {                                   // minimum tracking (imcra.py:452-481)
-                const int slot = u & 7;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) tst[i] = (i == slot) ? tSmin_sw : tst[i];
-                const int n = (u < 8) ? (u + 1) : 8;
-                double tm = tst[0];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) tm = (i < n) ? fmin(tm, tst[i]) : tm;
-                tSmin = tm;
-                tSmin_sw = tS;
-            }
-            if (++j == 15) { j = 0; ++u; }
         }
         P[(size_t)l * NELE_NBINS] = outv;
     };
-    fetch(0, fa, ia);
-    for (int l0 = 0; l0 < Tb; l0 += 2 * IMT_PF) {
-        fetch(l0 + IMT_PF, fb, ib);
+    if (role == 0) fetch_prior(0); else fetch_track(0);
+    for (int i = 0; i <= nbatch; ++i) {
+        if (role == 0) {
+            if (i < nbatch) {
+                float f[IMT_PF][3];
+                unsigned char ii[IMT_PF][3];
 #pragma unroll
-        for (int d = 0; d < IMT_PF; ++d)
-            if (l0 + d < Tb) step(l0 + d, fa[d], ia[d]);
-        fetch(l0 + 2 * IMT_PF, fa, ia);
+                for (int d = 0; d < IMT_PF; ++d)
 #pragma unroll
-        for (int d = 0; d < IMT_PF; ++d)
-            if (l0 + IMT_PF + d < Tb) step(l0 + IMT_PF + d, fb[d], ib[d]);
+                    for (int c = 0; c < 3; ++c) { f[d][c] = fa[d][c]; ii[d][c] = ia[d][c]; }
+                fetch_prior((i + 1) * IMT_PF);                               // the next batch's loads fly under this batch's arithmetic
+#pragma unroll
+                for (int d = 0; d < IMT_PF; ++d) {
+                    const int l = i * IMT_PF + d;
+                    rq[i & 1][d][lane] = (l < Tb) ? prior(l, f[d], ii[d]) : -1.0;
+                }
+            }
+        } else if (i >= 1) {
+            float y[IMT_PF];
+#pragma unroll
+            for (int d = 0; d < IMT_PF; ++d) y[d] = ya[d];
+            fetch_track(i * IMT_PF);
+#pragma unroll
+            for (int d = 0; d < IMT_PF; ++d) {
+                const int l = (i - 1) * IMT_PF + d;
+                const double r = rq[(i - 1) & 1][d][lane];
+                if (l < Tb) track(l, y[d], r);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -907,7 +949,7 @@ extern "C" int nele_imcra_band_ws(const void* spec, const int* frames, int B, in
     hipLaunchKernelGGL(imcra_pow_kernel, dim3(nb), dim3(256), 0, as_stream(stream), (const float2*)spec, n, y2f);
     const dim3 grid((B * NELE_NBINS + 255) / 256);
     hipLaunchKernelGGL(imcra_ind_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)y2f, B, T, ind, frames);
-    hipLaunchKernelGGL(imcra_track_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)y2f, (const unsigned char*)ind, B, T, psd, frames);
+    hipLaunchKernelGGL(imcra_track_kernel, dim3((B * NELE_NBINS + 63) / 64), dim3(128), 0, as_stream(stream), (const float*)y2f, (const unsigned char*)ind, B, T, psd, frames);
     if (band) hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
     NELE_CHECK_LAUNCH("nele_imcra_band_ws");
     return NELE_OK;
@@ -921,7 +963,7 @@ extern "C" int nele_imcra_band_pw(const float* pw, const int* frames, int B, int
     unsigned char* ind = (unsigned char*)ws;
     const dim3 grid((B * NELE_NBINS + 255) / 256);
     hipLaunchKernelGGL(imcra_ind_kernel, grid, dim3(256), 0, as_stream(stream), pw, B, T, ind, frames);
-    hipLaunchKernelGGL(imcra_track_kernel, grid, dim3(256), 0, as_stream(stream), pw, (const unsigned char*)ind, B, T, psd, frames);
+    hipLaunchKernelGGL(imcra_track_kernel, dim3((B * NELE_NBINS + 63) / 64), dim3(128), 0, as_stream(stream), pw, (const unsigned char*)ind, B, T, psd, frames);
     if (band) hipLaunchKernelGGL(band_from_psd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, as_stream(stream), psd, T, power, band);
     NELE_CHECK_LAUNCH("nele_imcra_band_pw");
     return NELE_OK;
