@@ -258,8 +258,9 @@ class GanTrainer:
         """wav [B,L] x2 -> dict(clean_band, noise_band [B,T,64], clean_spec [B,T,257] complex64, frames).
         lengths [B] (optional): samples of each utterance inside the padded batch - the reference handles one file of any length at a
         time (dataloader.py:30-42); 'frames' = 1 + lengths // 256 travels with the features to the stages that need it.
-        The noise branch (STFT -> IMCRA, a 1.1 ms scan that is serial over frames and fills 1/8 of the GPU) heads the step's critical
-        path, so it is issued first; the clean STFT + band energies run beside it on their own stream."""
+        The noise branch (STFT -> IMCRA: recursions that are serial over frames - 0.5 ms at B = 256, T = 251 as one thread per utterance
+        and bin, audio_util.noise_band) heads the step's critical path, so it is issued first; the clean STFT + band energies run beside
+        it on their own stream."""
         main = torch.cuda.current_stream()
         if self._fside is None:
             self._fside = ops.side_stream(self.device)
