@@ -20,6 +20,18 @@ __device__ __forceinline__ void fft512_init_twiddles(Fft512Lds& s) {
     }
 }
 
+// One radix-2 butterfly, a' = a + w b, b' = a - w b, as eight fused multiply-adds (round 6; ten separate multiplies / adds before - this
+// header is compiled without FMA contraction in features.hip): a'.x = fma(-w.y, b.y, fma(w.x, b.x, a.x)) and so on.  With a trivial twiddle
+// (1 or -+i, which the table holds exactly) the fused form IS the plain sum / difference, so code that skips those multiplications
+// (fftw_triple0) gives the same bits.
+template <bool INVERSE>
+__device__ __forceinline__ void fft512_bfly(double2& a, double2& b, const double2 w) {
+    const double wy = INVERSE ? -w.y : w.y;
+    const double2 a0 = a, b0 = b;
+    a = make_double2(fma(-wy, b0.y, fma(w.x, b0.x, a0.x)), fma(wy, b0.x, fma(w.x, b0.y, a0.y)));
+    b = make_double2(fma(wy, b0.y, fma(-w.x, b0.x, a0.x)), fma(-wy, b0.x, fma(-w.x, b0.y, a0.y)));
+}
+
 // Forward (INVERSE=false): X[k] = sum x[n] exp(-2 pi i k n / 512).
 // Inverse (INVERSE=true): unnormalised, x[n] = sum X[k] exp(+2 pi i k n / 512).
 // Caller stores input element n at s.x[fft512_brev(n)], then __syncthreads(); output is in
@@ -34,13 +46,10 @@ __device__ __forceinline__ void fft512_run(Fft512Lds& s) {
             const int pos = j & (half - 1);
             const int i0 = ((j >> st) << (st + 1)) + pos;
             const int i1 = i0 + half;
-            double2 w = s.tw[pos << (8 - st)];
-            if (INVERSE) w.y = -w.y;
-            const double2 a = s.x[i0], b = s.x[i1];
-            const double tr = w.x * b.x - w.y * b.y;
-            const double ti = w.x * b.y + w.y * b.x;
-            s.x[i0] = make_double2(a.x + tr, a.y + ti);
-            s.x[i1] = make_double2(a.x - tr, a.y - ti);
+            double2 a = s.x[i0], b = s.x[i1];
+            fft512_bfly<INVERSE>(a, b, s.tw[pos << (8 - st)]);
+            s.x[i0] = a;
+            s.x[i1] = b;
         }
         __syncthreads();
     }
@@ -50,8 +59,8 @@ __device__ __forceinline__ void fft512_run(Fft512Lds& s) {
 // The same transform, ONE WAVE per 512-point FFT with the data in registers (round 3, third session).  fft512_run() pays a workgroup
 // barrier and five LDS accesses per butterfly stage; here a lane holds 8 complex values and runs three stages at a time in registers,
 // so nine stages cost two LDS exchanges and no workgroup barrier (the wave's LDS accesses execute in order).  Every butterfly is the
-// SAME operation on the SAME operands with the SAME twiddle (tw[pos << (8 - st)]) as in fft512_run(): results are bit-identical in a
-// translation unit compiled without FMA contraction (features.hip).
+// SAME operation on the SAME operands with the SAME twiddle (tw[pos << (8 - st)]) as in fft512_run() (fft512_bfly; trivial twiddles skipped,
+// which changes no bit): results are bit-identical in a translation unit compiled without FMA contraction (features.hip).
 //   in : v[r] = element (8 * lane + r) of the bit-reversed-order array, i.e. input sample  n = fftw_n(lane, r)
 //   out: v[m] = X[64 * m + lane]
 // xw: the wave's exchange buffer (FFTW_SLOTS double2; position i lives in slot i + (i >> 3): conflict-free 16-byte accesses in all
@@ -69,13 +78,40 @@ __device__ __forceinline__ void fftw_wave_sync() {
 }
 
 template <bool INVERSE>
-__device__ __forceinline__ void fftw_bfly(double2& a, double2& b, double2 w) {
-    if (INVERSE) w.y = -w.y;
-    const double tr = w.x * b.x - w.y * b.y;
-    const double ti = w.x * b.y + w.y * b.x;
-    const double2 a0 = a;
-    a = make_double2(a0.x + tr, a0.y + ti);
-    b = make_double2(a0.x - tr, a0.y - ti);
+__device__ __forceinline__ void fftw_bfly(double2& a, double2& b, double2 w) { fft512_bfly<INVERSE>(a, b, w); }
+// w = 1
+__device__ __forceinline__ void fftw_bfly1(double2& a, double2& b) {
+    const double2 a0 = a, b0 = b;
+    a = make_double2(a0.x + b0.x, a0.y + b0.y);
+    b = make_double2(a0.x - b0.x, a0.y - b0.y);
+}
+// w = -i (forward) / +i (inverse): w b = (b.y, -b.x) / (-b.y, b.x)
+template <bool INVERSE>
+__device__ __forceinline__ void fftw_bflyI(double2& a, double2& b) {
+    const double2 a0 = a, b0 = b;
+    if (INVERSE) {
+        a = make_double2(a0.x - b0.y, a0.y + b0.x);
+        b = make_double2(a0.x + b0.y, a0.y - b0.x);
+    } else {
+        a = make_double2(a0.x + b0.y, a0.y - b0.x);
+        b = make_double2(a0.x - b0.y, a0.y + b0.x);
+    }
+}
+// stages 0-2 of the transform (twiddle position 0): the twiddles are 1, -+i and exp(-+i pi / 4), exp(-+3 i pi / 4) - 10 of the 12
+// butterflies multiply by 1 or -+i
+template <bool INVERSE>
+__device__ __forceinline__ void fftw_triple0(double2 (&v)[8], const double2* __restrict__ tw) {
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) fftw_bfly1(v[m], v[m + 1]);
+#pragma unroll
+    for (int m = 0; m < 8; m += 4) {
+        fftw_bfly1(v[m], v[m + 2]);
+        fftw_bflyI<INVERSE>(v[m + 1], v[m + 3]);
+    }
+    fftw_bfly1(v[0], v[4]);
+    fftw_bfly<INVERSE>(v[1], v[5], tw[64]);
+    fftw_bflyI<INVERSE>(v[2], v[6]);
+    fftw_bfly<INVERSE>(v[3], v[7], tw[192]);
 }
 
 // three consecutive stages on the 8 register values; stage s of the triple pairs (m, m + 2^s); pos0/1/2 = twiddle position of element 0
@@ -103,7 +139,7 @@ __device__ __forceinline__ void fftw_triple(double2 (&v)[8], const double2* __re
 
 template <bool INVERSE>
 __device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* __restrict__ xw, const double2* __restrict__ tw, int lane) {
-    fftw_triple<INVERSE, 0>(v, tw, 0);                       // stages 0-2 inside blocks of 8 positions
+    fftw_triple0<INVERSE>(v, tw);                            // stages 0-2 inside blocks of 8 positions
 #pragma unroll
     for (int r = 0; r < 8; ++r) xw[9 * lane + r] = v[r];     // slot(8 lane + r)
     fftw_wave_sync();
